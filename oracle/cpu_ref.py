@@ -1,0 +1,568 @@
+"""CPU oracle: a plain-PyTorch (fp32, CPU) restatement of the reference's pair-training hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this module; the product path (semantic-superpoint_amd/) never does and fails
+loudly when its HIP library is missing.
+
+Parity pin: every function below is checked against the REAL reference (imported in the build
+container through oracle/ref_harness.py) by oracle/make_goldens.py, which also writes the
+fixtures in tests/golden/ that tests/test_oracle_golden.py re-checks on every run (the reference
+itself ships no tests or golden vectors for this path: SURVEY.md section 4).
+Third-party arithmetic (torch ops) is torch 2.10 semantics; cv2.erode / cv2.getPerspectiveTransform
+are absent from the image, so `erode_ellipse` and `sample_homography` are "parity unpinned"
+ and masks / homographies are *inputs* in every parity test.
+
+All file:line citations are relative to the reference repository root.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# Architecture tables (models/SuperPointNet_gauss2.py:15-40, models/SuperPointNet_gauss2_ssmall.py:17-49,
+# models/unet_parts.py:10-48).  Each entry: (conv key, bn key | None, cin, cout, ksize)
+# --------------------------------------------------------------------------------------
+_ENC = [
+    ("inc.conv.conv.0", "inc.conv.conv.1", 1, 64, 3),
+    ("inc.conv.conv.3", "inc.conv.conv.4", 64, 64, 3),
+    ("down1.mpconv.1.conv.0", "down1.mpconv.1.conv.1", 64, 64, 3),
+    ("down1.mpconv.1.conv.3", "down1.mpconv.1.conv.4", 64, 64, 3),
+    ("down2.mpconv.1.conv.0", "down2.mpconv.1.conv.1", 64, 128, 3),
+    ("down2.mpconv.1.conv.3", "down2.mpconv.1.conv.4", 128, 128, 3),
+    ("down3.mpconv.1.conv.0", "down3.mpconv.1.conv.1", 128, 128, 3),
+    ("down3.mpconv.1.conv.3", "down3.mpconv.1.conv.4", 128, 128, 3),
+]
+_HEADS_SP = [
+    ("convPa", "bnPa", 128, 256, 3),
+    ("convPb", "bnPb", 256, 65, 1),
+    ("convDa", "bnDa", 128, 256, 3),
+    ("convDb", "bnDb", 256, 256, 1),
+]
+
+
+def layer_table(arch, n_classes=133):
+    if arch == "SuperPointNet_gauss2":
+        return _ENC + _HEADS_SP
+    if arch == "SuperPointNet_gauss2_ssmall":
+        return _ENC + _HEADS_SP + [("convDS", "bnS1", 128, 256, 3), ("convSout", None, 256, n_classes, 1)]
+    raise KeyError(arch)
+
+
+def state_spec(arch, n_classes=133):
+    """(key, shape, dtype) in torch state_dict order."""
+    spec = []
+    for conv, bn, cin, cout, k in layer_table(arch, n_classes):
+        spec.append((conv + ".weight", (cout, cin, k, k), np.float32))
+        spec.append((conv + ".bias", (cout,), np.float32))
+        if bn is not None:
+            spec.append((bn + ".weight", (cout,), np.float32))
+            spec.append((bn + ".bias", (cout,), np.float32))
+            spec.append((bn + ".running_mean", (cout,), np.float32))
+            spec.append((bn + ".running_var", (cout,), np.float32))
+            spec.append((bn + ".num_batches_tracked", (), np.int64))
+    return spec
+
+
+def init_state_dict(arch, seed=0, n_classes=133):
+    """Deterministic test weights (NOT the reference's default init): conv ~ U(+-sqrt(3/fan_in)),
+    conv bias ~ U(+-0.1), BN gamma ~ U(0.5,1.5), beta ~ U(-0.3,0.3) so that parity tests exercise
+    the affine terms.  Draw order == state_dict order."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for conv, bn, cin, cout, k in layer_table(arch, n_classes):
+        b = math.sqrt(3.0 / (cin * k * k))
+        sd[conv + ".weight"] = rs.uniform(-b, b, size=(cout, cin, k, k)).astype(np.float32)
+        sd[conv + ".bias"] = rs.uniform(-0.1, 0.1, size=(cout,)).astype(np.float32)
+        if bn is not None:
+            sd[bn + ".weight"] = rs.uniform(0.5, 1.5, size=(cout,)).astype(np.float32)
+            sd[bn + ".bias"] = rs.uniform(-0.3, 0.3, size=(cout,)).astype(np.float32)
+            sd[bn + ".running_mean"] = np.zeros((cout,), np.float32)
+            sd[bn + ".running_var"] = np.ones((cout,), np.float32)
+            sd[bn + ".num_batches_tracked"] = np.zeros((), np.int64)
+    return sd
+
+
+def to_torch(sd, requires_grad=False):
+    out = OrderedDict()
+    for k, v in sd.items():
+        t = torch.as_tensor(np.array(v)).clone()
+        if requires_grad and t.dtype == torch.float32 and not (k.endswith("running_mean") or k.endswith("running_var")):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def param_keys(arch, n_classes=133):
+    """Keys of trainable tensors in net.parameters() order (== state_dict order minus buffers)."""
+    return [k for k, _, _ in state_spec(arch, n_classes)
+            if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
+
+
+# --------------------------------------------------------------------------------------
+# Model forward  (models/unet_parts.py:10-48; SuperPointNet_gauss2.py:42-69; _ssmall.py:58-99)
+# --------------------------------------------------------------------------------------
+def _conv_bn(x, sd, conv, bn, k, train, relu):
+    y = F.conv2d(x, sd[conv + ".weight"], sd[conv + ".bias"], padding=k // 2)
+    if bn is not None:
+        # nn.BatchNorm2d defaults: eps 1e-5, momentum 0.1
+        y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"],
+                         sd[bn + ".bias"], training=train, momentum=0.1, eps=1e-5)
+        if train:
+            sd[bn + ".num_batches_tracked"] += 1
+    return F.relu(y) if relu else y
+
+
+def forward(sd, x, arch="SuperPointNet_gauss2", train=True, n_classes=133, return_x4=False):
+    """x [N,1,H,W] -> {"semi","desc"[,"sem"]}.  `sd` is a dict of torch tensors; BN running
+    statistics are updated in place when train=True (module default; the reference never calls
+    .eval() while training: SURVEY.md section 7 'Hard parts')."""
+    t = layer_table(arch, n_classes)
+    h = x
+    for i, (conv, bn, cin, cout, k) in enumerate(t[:8]):
+        if i in (2, 4, 6):  # down = MaxPool2d(2) -> double_conv   (unet_parts.py:41-44)
+            h = F.max_pool2d(h, 2)
+        h = _conv_bn(h, sd, conv, bn, k, train, relu=True)
+    x4 = h
+    cPa = _conv_bn(x4, sd, "convPa", "bnPa", 3, train, relu=True)
+    semi = _conv_bn(cPa, sd, "convPb", "bnPb", 1, train, relu=False)
+    cDa = _conv_bn(x4, sd, "convDa", "bnDa", 3, train, relu=True)
+    desc = _conv_bn(cDa, sd, "convDb", "bnDb", 1, train, relu=False)
+    out = {}
+    if arch.endswith("ssmall"):
+        s = _conv_bn(x4, sd, "convDS", "bnS1", 3, train, relu=True)
+        s = _conv_bn(s, sd, "convSout", None, 1, train, relu=False)
+        out["sem"] = F.interpolate(s, x.shape[2:], mode="bilinear", align_corners=False)
+    dn = torch.norm(desc, p=2, dim=1)  # SuperPointNet_gauss2.py:64-65 (no epsilon)
+    desc = desc.div(dn.unsqueeze(1))
+    out["semi"] = semi
+    out["desc"] = desc
+    if return_x4:
+        out["x4"] = x4
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Label / mask ops
+# --------------------------------------------------------------------------------------
+def space_to_depth(x, bs=8):
+    """utils/d2s.py:27-44: [B,C,H,W] -> [B,C*bs*bs,H/bs,W/bs], channel = dy*bs+dx for C=1."""
+    B, C, H, W = x.shape
+    x = x.view(B, C, H // bs, bs, W // bs, bs)
+    # reference builds depth index (dy, dx, c): for C == 1 that is dy*bs+dx
+    return x.permute(0, 3, 5, 1, 2, 4).reshape(B, bs * bs * C, H // bs, W // bs)
+
+
+def labels2Dto3D(labels, cell_size=8, add_dustbin=True):
+    """utils/utils.py:408-440."""
+    B, C, H, W = labels.shape
+    Hc, Wc = H // cell_size, W // cell_size
+    lab = space_to_depth(labels, cell_size)
+    if add_dustbin:
+        dustbin = 1 - lab.sum(dim=1)
+        dustbin = torch.where(dustbin < 1.0, torch.zeros_like(dustbin), dustbin)  # :431
+        lab = torch.cat((lab, dustbin.view(B, 1, Hc, Wc)), dim=1)
+        lab = lab / lab.sum(dim=1, keepdim=True)  # :438-439
+    return lab
+
+
+def get_masks(mask_2D, cell_size=8):
+    """Train_model_frontend_all.py:373-386: cell valid iff all 64 pixels valid."""
+    return torch.prod(labels2Dto3D(mask_2D, cell_size, add_dustbin=False).float(), 1)
+
+
+def detector_loss(semi, target, mask):
+    """Train_model_heatmap_all.py:173-178 (softmax branch): BCELoss(softmax) summed over 65
+    channels, masked, / (mask.sum()+1e-5).  BCELoss clamps each log at -100."""
+    p = F.softmax(semi, dim=1)
+    loss = F.binary_cross_entropy(p, target, reduction="none")
+    loss = (loss.sum(dim=1) * mask).sum()
+    return loss / (mask.sum() + 1e-5)
+
+
+def sem_loss(pred, label):
+    """Train_model_heatmap_all.py:181-193: CrossEntropyLoss(ignore_index=133), mean over valid."""
+    return F.cross_entropy(pred, label, ignore_index=133)
+
+
+# --------------------------------------------------------------------------------------
+# Geometry helpers
+# --------------------------------------------------------------------------------------
+def scale_homography(Hm, shape, shift=(-1.0, -1.0)):
+    """utils/homographies.py:270-276 and utils/utils.py:297-300 (same formula; note 2/W not 2/(W-1))."""
+    height, width = shape
+    trans = torch.tensor([[2.0 / width, 0.0, shift[0]], [0.0, 2.0 / height, shift[1]], [0.0, 0.0, 1.0]],
+                         dtype=torch.float32)
+    return torch.inverse(trans) @ Hm @ trans
+
+
+def warp_points(points, Hm):
+    """utils/utils.py:315-343 for one 3x3 homography: points [N,2](x,y) -> [N,2]."""
+    pts = torch.cat((points.float(), torch.ones((points.shape[0], 1))), dim=1)
+    w = Hm.view(3, 3) @ pts.transpose(0, 1)
+    w = w.transpose(0, 1)
+    return w[:, :2] / w[:, 2:]
+
+
+def filter_points(points, shape_wh):
+    """utils/utils.py:303-311: keep 0 <= x <= W-1, 0 <= y <= H-1.  Returns (points, mask)."""
+    shape = torch.as_tensor(shape_wh).float()
+    m = (points >= 0) & (points <= shape - 1)
+    m = m[:, 0] & m[:, 1]
+    return points[m], m
+
+
+def cell_matches(Hm, Hc, Wc):
+    """sparse_loss.py:184-207: integer cell correspondences under the normalised homography Hm.
+    Returns uv_a [n,2], uv_b [n,2] (float tensors holding integers), row-major with v outer."""
+    vs, us = torch.meshgrid(torch.arange(Hc), torch.arange(Wc), indexing="ij")
+    uv_a = torch.stack((us.reshape(-1), vs.reshape(-1)), dim=1).float()
+    H_cell = scale_homography(Hm.float(), (Hc, Wc))
+    uv_b = warp_points(uv_a, H_cell)
+    uv_b = uv_b.round()  # half-to-even (:197)
+    uv_b, m = filter_points(uv_b, (Wc, Hc))
+    return uv_a[m], uv_b
+
+
+def crop_or_pad_choice(n_in, n_out, np_rng):
+    """utils/utils.py:964-986 with shuffle=True; `np_rng` exposes permutation/choice
+    (np.random module or a RandomState)."""
+    choice = np_rng.permutation(n_in)
+    if n_in >= n_out:
+        return choice[:n_out]
+    pad = np_rng.choice(choice, n_out - n_in, replace=True)
+    return np.concatenate([choice, pad])
+
+
+def sample_sparse_indices(Hm, Hc, Wc, n_match=1000, n_non=100, np_rng=np.random, torch_gen=None):
+    """The stochastic half of descriptor_loss_sparse (sparse_loss.py:184-246) for one image.
+    RNG draw order reproduces the reference: numpy permutation(+choice), torch.rand(2,K),
+    torch.rand(K), torch.randn(K)  (correspondence_finder.py:30,278,280).
+    Returns dict: uv_a, uv_b [n_match,2] float (integer-valued cells), nm_b [n_match*n_non] int64
+    flat cell index (u + v*Wc) in image b.  The a-side of non-match k*n_non+j is match k."""
+    uv_a, uv_b = cell_matches(Hm, Hc, Wc)
+    choice = torch.as_tensor(crop_or_pad_choice(uv_b.shape[0], n_match, np_rng)).long()
+    uv_a, uv_b = uv_a[choice], uv_b[choice]
+    K = n_match * n_non
+    two = torch.rand(2, K, generator=torch_gen)          # correspondence_finder.py:29-34
+    nu = torch.floor(two[0] * Wc).long()
+    nv = torch.floor(two[1] * Hc).long()
+    # the "perturb near matches" stage is a no-op (`ones = zeros_like`, :269) but burns two draws
+    torch.rand(K, generator=torch_gen)
+    torch.randn(K, generator=torch_gen)
+    return {"uv_a": uv_a, "uv_b": uv_b, "nm_b": nu + nv * Wc}
+
+
+def norm_pts(pts, shape_wh):
+    """utils/utils.py:745-755."""
+    return pts / torch.as_tensor(shape_wh).float() * 2 - 1
+
+
+def descriptor_loss_sparse_given(desc_a, desc_b, idx, lamda_d=1.0, n_non=100):
+    """Deterministic half of descriptor_loss_sparse (sparse_loss.py:219-254) for one image given
+    the sampled indices.  desc_* [D,Hc,Wc].  Returns (loss, pos, neg)."""
+    D, Hc, Wc = desc_a.shape
+    wh = (Wc, Hc)
+    ga = norm_pts(idx["uv_a"], wh).view(1, -1, 1, 2)
+    gb = norm_pts(idx["uv_b"], wh).view(1, -1, 1, 2)
+    # match_loss(method="2d"): pixelwise_contrastive_loss.py:160-206
+    da = F.grid_sample(desc_a.unsqueeze(0), ga, mode="bilinear", align_corners=True).squeeze(0).squeeze(-1).t()
+    db = F.grid_sample(desc_b.unsqueeze(0), gb, mode="bilinear", align_corners=True).squeeze(0).squeeze(-1).t()
+    pos = torch.clamp(1.0 - (da * db).sum(-1), min=0).sum() / da.shape[0]
+    # non matches: sparse_loss.py:96-100,245-246 ; pixelwise_contrastive_loss.py:238-263
+    flat_a = desc_a.reshape(D, Hc * Wc).t()
+    flat_b = desc_b.reshape(D, Hc * Wc).t()
+    ia = (idx["uv_a"][:, 0] + idx["uv_a"][:, 1] * Wc).long().repeat_interleave(n_non)
+    ib = idx["nm_b"].long()
+    nm = torch.clamp((flat_a[ia] * flat_b[ib]).sum(-1) - 0.2, min=0)
+    nnz = int((nm != 0).sum())
+    neg = nm.sum() / (nnz + 1)  # sparse_loss.py:154
+    return lamda_d * pos + neg, pos, neg
+
+
+def batch_descriptor_loss_sparse(desc, desc_w, homographies, indices=None, lamda_d=1.0, n_match=1000,
+                                 n_non=100, np_rng=np.random, torch_gen=None):
+    """sparse_loss.py:267-284.  `indices` (list per image) overrides sampling."""
+    ls, ps, ns, used = [], [], [], []
+    for i in range(desc.shape[0]):
+        idx = indices[i] if indices is not None else sample_sparse_indices(
+            homographies[i].float(), desc.shape[2], desc.shape[3], n_match, n_non, np_rng, torch_gen)
+        l, p, n = descriptor_loss_sparse_given(desc[i], desc_w[i], idx, lamda_d, n_non)
+        ls.append(l), ps.append(p), ns.append(n), used.append(idx)
+    return torch.stack(ls).mean(), torch.stack(ps).mean(), torch.stack(ns).mean(), used
+
+
+def multi_task_loss(eta, det, pos, neg, sem=None):
+    """Train_model_heatmap_all.py:62-77 (Kendall uncertainty weighting, 'v2_normal')."""
+    loss = det * torch.exp(-eta[0]) + eta[0] + 0.5 * (pos + neg) * torch.exp(-eta[1]) + 0.5 * eta[1]
+    if sem is not None:
+        loss = loss + sem * torch.exp(-eta[2]) + eta[2]
+    return loss
+
+
+# --------------------------------------------------------------------------------------
+# The pair step  (Train_model_heatmap_all.py:195-443)
+# --------------------------------------------------------------------------------------
+def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lambda_loss=1.0, lamda_d=1.0,
+                multi_task=True, gaussian=True, n_match=1000, n_non=100, np_rng=np.random, torch_gen=None,
+                train=True):
+    """Forward of both views + all losses.  Returns (loss, scalars dict, aux dict)."""
+    semantic = arch.endswith("ssmall")
+    out = forward(sd, sample["image"], arch, train=train)
+    out_w = forward(sd, sample["warped_img"], arch, train=train)  # separate BN statistics (:258,262)
+    lab = sample["labels_2D_gaussian"] if gaussian else sample["labels_2D"]
+    lab_w = sample["warped_labels_gaussian"] if gaussian else sample["warped_labels"]
+    l3 = labels2Dto3D(lab).float()
+    m3 = get_masks(sample["valid_mask"])
+    loss_det = detector_loss(out["semi"], l3, m3)
+    l3w = labels2Dto3D(lab_w).float()
+    m3w = get_masks(sample["warped_valid_mask"])
+    loss_det_w = detector_loss(out_w["semi"], l3w, m3w)
+    zero = torch.zeros(())
+    loss_sem = sem_loss(out["sem"], sample["semantic"]) if semantic else zero
+    loss_sem_w = sem_loss(out_w["sem"], sample["warped_sem"]) if semantic else zero
+    if lambda_loss > 0:
+        loss_desc, pos, neg, used = batch_descriptor_loss_sparse(
+            out["desc"], out_w["desc"], sample["homographies"], indices, lamda_d, n_match, n_non, np_rng, torch_gen)
+    else:
+        loss_desc, pos, neg, used = zero, zero, zero, None
+    if multi_task:
+        loss = multi_task_loss(eta, loss_det + loss_det_w, pos, neg, (loss_sem + loss_sem_w) if semantic else None)
+    else:  # uniform sum (:363-365)
+        loss = loss_det + loss_det_w + loss_sem + loss_sem_w
+        if lambda_loss > 0:
+            loss = loss + lambda_loss * loss_desc
+    scal = {"loss": loss, "loss_det": loss_det, "loss_det_warp": loss_det_w, "loss_desc": loss_desc,
+            "loss_sem": loss_sem, "loss_sem_warp": loss_sem_w, "eta_det": eta[0], "eta_desc": eta[1],
+            "positive_dist": pos, "negative_dist": neg}
+    if semantic:
+        scal["eta_sem"] = eta[2]
+    return loss, scal, {"out": out, "out_warp": out_w, "indices": used}
+
+
+class AdamState:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) restated
+    (Train_model_frontend_all.py:183-198).  LR is constant: the scheduler drives an orphaned
+    optimizer."""
+
+    def __init__(self, params, lr):
+        self.params = params
+        self.lr = lr
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+
+    def step(self):
+        self.t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        bc1 = 1 - b1 ** self.t
+        bc2 = 1 - b2 ** self.t
+        with torch.no_grad():
+            for p, m, v in zip(self.params, self.m, self.v):
+                if p.grad is None:
+                    continue
+                g = p.grad
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+                p.addcdiv_(m, denom, value=-self.lr / bc1)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+class Trainer:
+    """Minimal restatement of the Train_model_heatmap_all step state (net params, eta, Adam)."""
+
+    def __init__(self, arch="SuperPointNet_gauss2", sd_np=None, lr=0.001, seed=0, **loss_kw):
+        self.arch = arch
+        self.sd = to_torch(sd_np if sd_np is not None else init_state_dict(arch, seed), requires_grad=True)
+        self.eta = torch.tensor([1.0, 2.0, 1.0], requires_grad=True)  # Train_model_heatmap_all.py:58
+        self.pkeys = param_keys(arch)
+        self.opt = AdamState([self.sd[k] for k in self.pkeys] + [self.eta], lr)
+        self.loss_kw = loss_kw
+        self.batch_size = None
+        self.real_batch_size = None
+
+    def train_val_sample(self, sample, n_iter=0, train=True, indices=None, **kw):
+        args = dict(self.loss_kw)
+        args.update(kw)
+        B = sample["image"].shape[0]
+        real = self.real_batch_size or B
+        if train:
+            loss, scal, aux = pair_losses(self.sd, self.eta, sample, self.arch, indices, **args)
+            loss.backward()
+            self.last_grads = OrderedDict(
+                (k, None if self.sd[k].grad is None else self.sd[k].grad.clone()) for k in self.pkeys)
+            self.last_grads["eta"] = self.eta.grad.clone()
+            if ((n_iter + 1) * B) % real == 0:  # :410-413
+                self.opt.step()
+                self.opt.zero_grad()
+        else:
+            with torch.no_grad():
+                loss, scal, aux = pair_losses(self.sd, self.eta, sample, self.arch, indices, **args)
+        self.scalar_dict = {k: float(v) for k, v in scal.items()}
+        self.aux = aux
+        return float(loss)
+
+
+# --------------------------------------------------------------------------------------
+# Pair construction (dataset side)
+# --------------------------------------------------------------------------------------
+def inv_warp_image_batch(img, mat_homo_inv, mode="bilinear"):
+    """utils/utils.py:347-385: sample img at H^-1 * (linspace(-1,1) grid), zeros padding,
+    align_corners=True."""
+    if img.dim() in (2, 3):
+        img = img.view(1, 1, img.shape[-2], img.shape[-1])
+    if mat_homo_inv.dim() == 2:
+        mat_homo_inv = mat_homo_inv.view(1, 3, 3)
+    B, C, H, W = img.shape
+    gx, gy = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(-1, 1, H), indexing="ij")
+    coor = torch.stack((gx, gy), dim=2).transpose(0, 1).contiguous().view(-1, 2)  # [H*W,2] (x,y), row-major
+    pts = torch.cat((coor, torch.ones(coor.shape[0], 1)), dim=1)
+    w = (mat_homo_inv.float().reshape(B * 3, 3) @ pts.t()).view(B, 3, -1).transpose(2, 1)
+    src = (w[:, :, :2] / w[:, :, 2:]).view(B, H, W, 2).float()
+    return F.grid_sample(img, src, mode=mode, align_corners=True)
+
+
+def ellipse_kernel(r):
+    """cv2.getStructuringElement(MORPH_ELLIPSE,(2r,2r)) as documented by OpenCV (parity unpinned:
+    cv2 is not in the image).  Returns a (2r x 2r) uint8 array, anchor at (r, r)."""
+    n = 2 * r
+    k = np.zeros((n, n), np.uint8)
+    c = n // 2
+    rr = n // 2
+    inv_r2 = 1.0 / (rr * rr) if rr else 0.0
+    for i in range(n):
+        dy = i - c
+        if abs(dy) <= rr:
+            dx = int(round(rr * math.sqrt(max((rr * rr - dy * dy) * inv_r2, 0.0))))
+            j1, j2 = max(c - dx, 0), min(c + dx + 1, n)
+            k[i, j1:j2] = 1
+    return k
+
+
+def erode_ellipse(mask, r):
+    """cv2.erode(mask, ellipse(2r), iterations=1) with the default (constant +inf) border:
+    out[y,x] = min over kernel support of mask[y+i-r, x+j-r], out-of-image pixels ignored."""
+    if r <= 0:
+        return mask
+    k = ellipse_kernel(r)
+    H, W = mask.shape
+    out = mask.clone()
+    for i in range(k.shape[0]):
+        for j in range(k.shape[1]):
+            if not k[i, j]:
+                continue
+            dy, dx = i - r, j - r
+            ys0, ys1 = max(0, -dy), min(H, H - dy)
+            xs0, xs1 = max(0, -dx), min(W, W - dx)
+            out[ys0:ys1, xs0:xs1] = torch.minimum(out[ys0:ys1, xs0:xs1], mask[ys0 + dy:ys1 + dy, xs0 + dx:xs1 + dx])
+    return out
+
+
+def compute_valid_mask(image_shape, inv_homography, erosion_radius=0):
+    """utils/utils.py:715-742: nearest warp of ones, then elliptical erosion."""
+    if inv_homography.dim() == 2:
+        inv_homography = inv_homography.view(-1, 3, 3)
+    B = inv_homography.shape[0]
+    mask = inv_warp_image_batch(torch.ones(B, 1, image_shape[0], image_shape[1]), inv_homography, mode="nearest")
+    mask = mask.view(B, image_shape[0], image_shape[1])
+    if erosion_radius > 0:
+        mask = torch.stack([erode_ellipse(mask[i], erosion_radius) for i in range(B)])
+    return mask
+
+
+def warp_labels(pnts_xy, H, W, homography):
+    """datasets/data_tools.py:37-63 (labels only): warp integer keypoints (x,y) with the
+    normalised homography, keep in-range, round half-to-even, scatter 1."""
+    Hpix = scale_homography(homography.float(), (H, W))  # utils/utils.py:297-300
+    wp = warp_points(pnts_xy.long().float(), Hpix)
+    wp, _ = filter_points(wp, (W, H))
+    lab = torch.zeros(H, W)
+    q = wp.round().long()
+    lab[q[:, 1], q[:, 0]] = 1
+    return lab.view(1, H, W)
+
+
+def sample_homography(rs, shape=(2, 2), shift=-1, perspective=True, scaling=True, rotation=True, translation=True,
+                      n_scales=5, n_angles=25, scaling_amplitude=0.2, perspective_amplitude_x=0.2,
+                      perspective_amplitude_y=0.2, patch_ratio=0.85, max_angle=1.57, allow_artifacts=True,
+                      translation_overflow=0.0):
+    """utils/homographies.py:12-141 restated with numpy only (truncnorm via rejection, the 4-point
+    solve via an 8x8 linear system instead of cv2.getPerspectiveTransform) -- distribution-level
+    restatement, parity unpinned (scipy RNG stream / cv2 not reproduced).  Returns 3x3 float32,
+    the matrix the reference returns (pts1*shape+shift -> pts2*shape+shift ... solved as in :135-141)."""
+    def tn(std):  # truncnorm(-2,2, scale=std)
+        while True:
+            v = rs.randn()
+            if abs(v) <= 2:
+                return v * std
+    pts1 = np.array([[0., 0.], [0., 1.], [1., 1.], [1., 0.]])
+    margin = (1 - patch_ratio) / 2
+    pts2 = margin + np.array([[0, 0], [0, patch_ratio], [patch_ratio, patch_ratio], [patch_ratio, 0]])
+    if perspective:
+        if not allow_artifacts:
+            perspective_amplitude_x = min(perspective_amplitude_x, margin)
+            perspective_amplitude_y = min(perspective_amplitude_y, margin)
+        pd = tn(perspective_amplitude_y / 2)
+        hl = tn(perspective_amplitude_x / 2)
+        hr = tn(perspective_amplitude_x / 2)
+        pts2 += np.array([[hl, pd], [hl, -pd], [hr, pd], [hr, -pd]])
+    if scaling:
+        scales = np.array([1 + tn(scaling_amplitude / 2) for _ in range(n_scales)] + [1.0])
+        center = pts2.mean(axis=0, keepdims=True)
+        scaled = (pts2 - center)[None] * scales[:, None, None] + center
+        valid = np.arange(n_scales + 1) if allow_artifacts else \
+            np.where(((scaled >= 0) & (scaled < 1)).all(axis=(1, 2)))[0]
+        pts2 = scaled[valid[rs.randint(valid.shape[0])]]
+    if translation:
+        t_min, t_max = pts2.min(axis=0), (1 - pts2).min(axis=0)
+        if allow_artifacts:
+            t_min += translation_overflow
+            t_max += translation_overflow
+        pts2 += np.array([rs.uniform(-t_min[0], t_max[0]), rs.uniform(-t_min[1], t_max[1])])[None]
+    if rotation:
+        angles = np.concatenate((np.linspace(-max_angle, max_angle, n_angles), [0.0]))
+        center = pts2.mean(axis=0, keepdims=True)
+        rot = np.stack([np.cos(angles), -np.sin(angles), np.sin(angles), np.cos(angles)], axis=1).reshape(-1, 2, 2)
+        rotated = np.matmul((pts2 - center)[None], rot) + center
+        valid = np.arange(n_angles + 1) if allow_artifacts else \
+            np.where(((rotated >= 0) & (rotated < 1)).all(axis=(1, 2)))[0]
+        pts2 = rotated[valid[rs.randint(valid.shape[0])]]
+    sh = np.array(shape[::-1], dtype=np.float64)
+    p1 = pts1 * sh[None] + shift
+    p2 = pts2 * sh[None] + shift
+    A, b = [], []
+    for (x, y), (u, v) in zip(p1, p2):  # maps p1 -> p2
+        A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)
+        A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
+    h = np.linalg.solve(np.array(A), np.array(b))
+    return np.append(h, 1.0).reshape(3, 3).astype(np.float32)
+
+
+def make_synthetic_pair(B, H, W, seed=0, semantic=False, kp_prob=0.003, erosion=3, n_classes=133):
+    """Seeded synthetic `sample` dict with the shapes/dtypes of SURVEY.md section 8a row a4 and the
+    recipe of section 8d (uniform images, Bernoulli keypoints, homographies as in datasets/Coco.py:341-392)."""
+    rs = np.random.RandomState(seed)
+    img = torch.from_numpy(rs.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    lab = torch.from_numpy((rs.uniform(size=(B, 1, H, W)) < kp_prob).astype(np.float32))
+    Hs = np.stack([np.linalg.inv(sample_homography(rs)) for _ in range(B)]).astype(np.float32)  # Coco.py:342-350
+    Hs_t = torch.from_numpy(Hs)
+    inv_t = torch.inverse(Hs_t).contiguous()
+    warped = inv_warp_image_batch(img, inv_t)
+    wl = torch.stack([warp_labels(torch.nonzero(lab[i, 0]).flip(1), H, W, Hs_t[i]) for i in range(B)])
+    vm = compute_valid_mask((H, W), inv_t, erosion_radius=erosion).view(B, 1, H, W)
+    s = {"image": img, "warped_img": warped, "labels_2D": lab, "warped_labels": wl,
+         "labels_2D_gaussian": lab.clone(), "warped_labels_gaussian": wl.clone(),
+         "valid_mask": torch.ones(B, 1, H, W), "warped_valid_mask": vm,
+         "homographies": Hs_t, "inv_homographies": inv_t}
+    if semantic:
+        sem = torch.from_numpy(rs.randint(0, n_classes + 1, size=(B, H, W)).astype(np.int64))
+        ws = inv_warp_image_batch(sem.float().unsqueeze(1), inv_t, mode="bilinear").squeeze(1).long()
+        ws[vm.view(B, H, W) == 0] = n_classes
+        s["semantic"], s["warped_sem"] = sem, ws
+    return s

@@ -1,0 +1,357 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference through
+oracle/ref_harness.py) on seeded inputs, asserting on the way that oracle/cpu_ref.py reproduces it.
+
+Run in the build container only:  python oracle/make_goldens.py
+Fixtures are DATA (inputs + the reference's outputs); no reference source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import cpu_ref as C  # noqa: E402
+from oracle import ref_harness as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+ARCHS = ("SuperPointNet_gauss2", "SuperPointNet_gauss2_ssmall")
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, tol, what):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= tol, "%s: oracle differs from reference by %g (tol %g)" % (what, err, tol)
+    return err
+
+
+def close_adam(a, b, lr, what):
+    """Post-Adam parameters: the first steps move every element by ~lr*sign(g), so elements whose
+    true gradient is ~0 (dead ReLU taps) are rounding-noise driven on BOTH sides.  Require: max
+    difference <= 2.2*lr and fewer than 5 % of elements off by more than 5 % of lr."""
+    d = (torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs()
+    frac = float((d > 0.05 * lr).double().mean())
+    assert float(d.max()) <= 2.2 * lr and frac < 5e-2, "%s: max %g frac %g" % (what, float(d.max()), frac)
+
+
+def ref_net(arch, sd):
+    import importlib
+    R.install()
+    mod = importlib.import_module("models." + arch)
+    net = getattr(mod, arch)()
+    net.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in sd.items()})
+    return net
+
+
+def g1_forward():
+    """G1: model forward (train mode, two consecutive forwards -> running stats)."""
+    for arch in ARCHS:
+        sd = C.init_state_dict(arch, seed=11)
+        net = ref_net(arch, sd)
+        rs = np.random.RandomState(5)
+        x1 = torch.from_numpy(rs.uniform(0, 1, (2, 1, 32, 48)).astype(np.float32))
+        x2 = torch.from_numpy(rs.uniform(0, 1, (2, 1, 32, 48)).astype(np.float32))
+        o1 = net(x1)
+        o2 = net(x2)
+        tsd = C.to_torch(sd)
+        p1 = C.forward(tsd, x1, arch)
+        p2 = C.forward(tsd, x2, arch)
+        for k in o1:
+            close(o1[k], p1[k], 1e-6, "G1 %s %s" % (arch, k))
+            close(o2[k], p2[k], 1e-6, "G1 %s %s (2nd)" % (arch, k))
+        rsd = net.state_dict()
+        for k in rsd:
+            close(rsd[k], tsd[k], 1e-6, "G1 state " + k)
+        save = {"x1": npy(x1), "x2": npy(x2), "semi1": npy(o1["semi"]), "desc1": npy(o1["desc"]),
+                "semi2": npy(o2["semi"]), "desc2": npy(o2["desc"])}
+        if "sem" in o1:
+            save["sem1_s"] = npy(o1["sem"][:, ::7, ::3, ::5])  # strided slice keeps the file small
+            save["sem2_s"] = npy(o2["sem"][:, ::7, ::3, ::5])
+        for k in rsd:
+            if "running" in k or "num_batches" in k:
+                save["state/" + k] = npy(rsd[k])
+        np.savez_compressed(os.path.join(OUT, "g1_forward_%s.npz" % arch), **save)
+        # eval-mode forward (Val_model_heatmap.py:68 calls .eval())
+        net.eval()
+        oe = net(x1)
+        pe = C.forward(tsd, x1, arch, train=False)
+        for k in oe:
+            close(oe[k], pe[k], 1e-6, "G1 eval %s" % k)
+        np.savez_compressed(os.path.join(OUT, "g1_eval_%s.npz" % arch), semi=npy(oe["semi"]), desc=npy(oe["desc"]))
+
+
+def g2_labels():
+    """G2: labels2Dto3D / getMasks - exact arrays."""
+    R.install()
+    from utils.utils import labels2Dto3D
+    import Train_model_frontend_all as TF
+    rs = np.random.RandomState(7)
+    lab = (rs.uniform(size=(2, 1, 32, 48)) < 0.02).astype(np.float32)
+    lab[0, 0, 0:8, 0:8] = 0  # an empty cell -> dustbin 1
+    lab[1, 0, 8, 8] = 1; lab[1, 0, 9, 9] = 1  # two points in one cell -> renormalised to 0.5
+    gau = lab * rs.uniform(0.2, 1.0, size=lab.shape).astype(np.float32)  # "gaussian" labels in [0,1]
+    mask = (rs.uniform(size=(2, 1, 32, 48)) < 0.995).astype(np.float32)
+    out = {}
+    for name, arr in (("bin", lab), ("gauss", gau)):
+        r = labels2Dto3D(torch.from_numpy(arr), 8, add_dustbin=True).float()
+        o = C.labels2Dto3D(torch.from_numpy(arr), 8, True).float()
+        assert torch.equal(torch.nan_to_num(r), torch.nan_to_num(o)), "G2 labels " + name
+        out["labels_" + name] = arr
+        out["labels3D_" + name] = npy(r)
+    rm = TF.Train_model_frontend_all.getMasks(None, torch.from_numpy(mask), 8)
+    om = C.get_masks(torch.from_numpy(mask), 8)
+    assert torch.equal(rm, om), "G2 masks"
+    out["mask"] = mask
+    out["mask3D"] = npy(rm)
+    np.savez_compressed(os.path.join(OUT, "g2_labels.npz"), **out)
+
+
+def g3_detector_loss():
+    R.install()
+    import Train_model_heatmap_all as T
+    rs = np.random.RandomState(9)
+    semi = torch.from_numpy((rs.randn(2, 65, 4, 6) * 3).astype(np.float32)).requires_grad_(True)
+    semi.data[0, :, 0, 0] = torch.tensor([200.0] + [0.0] * 64)  # saturates: exercises the -100 log clamp
+    lab = (rs.uniform(size=(2, 1, 32, 48)) < 0.03).astype(np.float32)
+    t = C.labels2Dto3D(torch.from_numpy(lab)).float()
+    mask = torch.from_numpy((rs.uniform(size=(2, 4, 6)) < 0.8).astype(np.float32))
+    lr = T.Train_model_heatmap_all.detector_loss(None, semi, t, mask, "softmax")
+    gr, = torch.autograd.grad(lr, semi)
+    s2 = semi.detach().clone().requires_grad_(True)
+    lo = C.detector_loss(s2, t, mask)
+    go, = torch.autograd.grad(lo, s2)
+    close(lr, lo, 1e-6, "G3 loss")
+    close(gr, go, 1e-7, "G3 grad")
+    np.savez_compressed(os.path.join(OUT, "g3_detector_loss.npz"), semi=npy(semi), target=npy(t), mask=npy(mask),
+                        loss=npy(lr), dsemi=npy(gr))
+
+
+def g5_sem_loss():
+    R.install()
+    import Train_model_heatmap_all as T
+    rs = np.random.RandomState(13)
+    pred = torch.from_numpy(rs.randn(2, 133, 16, 24).astype(np.float32)).requires_grad_(True)
+    lab = torch.from_numpy(rs.randint(0, 134, size=(2, 16, 24)).astype(np.int64))
+    lr = T.Train_model_heatmap_all.sem_loss(None, pred, lab, "cpu")
+    gr, = torch.autograd.grad(lr, pred)
+    p2 = pred.detach().clone().requires_grad_(True)
+    lo = C.sem_loss(p2, lab)
+    go, = torch.autograd.grad(lo, p2)
+    close(lr, lo, 0, "G5 loss")
+    close(gr, go, 0, "G5 grad")
+    np.savez_compressed(os.path.join(OUT, "g5_sem_loss.npz"), pred_s=npy(pred[:, ::9]), label=npy(lab), loss=npy(lr),
+                        dpred_s=npy(gr[:, ::9]), seed=13)
+
+
+def _capture_sparse(desc, desc_w, Hs, **params):
+    """Run the reference's batch_descriptor_loss_sparse with the two hinge terms monkey-patched to
+    record the sampled coordinates / indices."""
+    R.install()
+    import utils.loss_functions.sparse_loss as SL
+    from utils.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss as P
+    rec = []
+    om, on = P.match_loss, P.non_match_descriptor_loss
+
+    def ml(a, b, ma, mb, **kw):
+        rec.append({"ma": ma.detach().clone().view(-1, 2), "mb": mb.detach().clone().view(-1, 2)})
+        return om(a, b, ma, mb, **kw)
+
+    def nl(a, b, na, nb, **kw):
+        rec[-1]["na"] = na.detach().clone()
+        rec[-1]["nb"] = nb.detach().clone()
+        return on(a, b, na, nb, **kw)
+
+    P.match_loss, P.non_match_descriptor_loss = staticmethod(ml), staticmethod(nl)
+    try:
+        out = SL.batch_descriptor_loss_sparse(desc, desc_w, Hs, device="cpu", **params)
+    finally:
+        P.match_loss, P.non_match_descriptor_loss = staticmethod(om), staticmethod(on)
+    return out, rec
+
+
+def g4_sparse_loss():
+    params = {"num_matching_attempts": 1000, "num_masked_non_matches_per_match": 100, "lamda_d": 1, "dist": "cos",
+              "method": "2d"}
+    for tag, (Hc, Wc) in (("small", (4, 6)), ("full", (30, 40))):
+        rs = np.random.RandomState(17)
+        B = 2
+        d = rs.randn(B, 256, Hc, Wc).astype(np.float32)
+        dw = (0.6 * d + 0.8 * rs.randn(B, 256, Hc, Wc)).astype(np.float32)  # correlated: many hard negatives
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        dw /= np.linalg.norm(dw, axis=1, keepdims=True)
+        Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(B)]).astype(np.float32))
+        desc = torch.from_numpy(d).requires_grad_(True)
+        desc_w = torch.from_numpy(dw).requires_grad_(True)
+        np.random.seed(123); torch.manual_seed(321)
+        (loss, _, pos, neg), rec = _capture_sparse(desc, desc_w, Hs, **params)
+        g_d, g_dw = torch.autograd.grad(loss + 0.5 * pos + 0.25 * neg, (desc, desc_w))
+        # oracle with the SAME rng streams must reproduce the sampled indices bit-exactly
+        np.random.seed(123); torch.manual_seed(321)
+        d2 = desc.detach().clone().requires_grad_(True)
+        dw2 = desc_w.detach().clone().requires_grad_(True)
+        lo, po, no, used = C.batch_descriptor_loss_sparse(d2, dw2, Hs, None, 1.0, 1000, 100, np.random, None)
+        for i in range(B):
+            wh = torch.tensor([Wc, Hc]).float()
+            assert torch.equal(C.norm_pts(used[i]["uv_a"], wh), rec[i]["ma"]), "G4 uv_a"
+            assert torch.equal(C.norm_pts(used[i]["uv_b"], wh), rec[i]["mb"]), "G4 uv_b"
+            ia = (used[i]["uv_a"][:, 0] + used[i]["uv_a"][:, 1] * Wc).long().repeat_interleave(100)
+            assert torch.equal(ia, rec[i]["na"]) and torch.equal(used[i]["nm_b"], rec[i]["nb"]), "G4 non-match idx"
+        close(loss, lo, 1e-6, "G4 loss"); close(pos, po, 1e-6, "G4 pos"); close(neg, no, 1e-6, "G4 neg")
+        go_d, go_dw = torch.autograd.grad(lo + 0.5 * po + 0.25 * no, (d2, dw2))
+        close(g_d, go_d, 1e-7, "G4 d desc"); close(g_dw, go_dw, 1e-7, "G4 d desc_w")
+        save = {"H": npy(Hs), "loss": npy(loss), "pos": npy(pos), "neg": npy(neg), "seed": 17,
+                "grad_weights": np.array([1.0, 0.5, 0.25], np.float32)}
+        if tag == "small":
+            save.update({"desc": d, "desc_w": dw, "ddesc": npy(g_d), "ddesc_w": npy(g_dw)})
+        else:  # inputs are regenerated from the seed by the test (see tests/golden_util.py)
+            save.update({"ddesc_s": npy(g_d[:, ::16]), "ddesc_w_s": npy(g_dw[:, ::16]),
+                         "ddesc_norm": np.float32(g_d.norm()), "ddesc_w_norm": np.float32(g_dw.norm()),
+                         "desc_sum": np.float64(d.astype(np.float64).sum()),
+                         "desc_w_sum": np.float64(dw.astype(np.float64).sum())})
+        for i in range(B):
+            save["uv_a%d" % i] = npy(used[i]["uv_a"]).astype(np.int16)
+            save["uv_b%d" % i] = npy(used[i]["uv_b"]).astype(np.int16)
+            save["nm_b%d" % i] = npy(used[i]["nm_b"]).astype(np.int16)
+        np.savez_compressed(os.path.join(OUT, "g4_sparse_loss_%s.npz" % tag), **save)
+    # by-eye KAT of the reference (sparse_loss.py:335-345): identical descriptors + identity H => pos == 0.
+    # It holds for method="1d" (index_select); with the configs' method="2d" the bilinear sample at
+    # u*(Wc-1)/Wc blends neighbours, so pos = mean(1-|blend|^2) > 0 - both facts are asserted here.
+    dd = torch.from_numpy(d)
+    np.random.seed(1); torch.manual_seed(1)
+    (l, _, p, n), _ = _capture_sparse(dd, dd, torch.eye(3).repeat(B, 1, 1), **dict(params, method="1d"))
+    assert abs(float(p)) < 1e-6, float(p)
+    np.random.seed(1); torch.manual_seed(1)
+    (l, _, p2, n), _ = _capture_sparse(dd, dd, torch.eye(3).repeat(B, 1, 1), **params)
+    np.random.seed(1); torch.manual_seed(1)
+    _, po, _, _ = C.batch_descriptor_loss_sparse(dd, dd, torch.eye(3).repeat(B, 1, 1))
+    assert float(p2) > 0.01 and abs(float(p2) - float(po)) < 1e-6
+
+
+def _sample_to_npz(s):
+    return {("in/" + k): npy(v) for k, v in s.items()}
+
+
+def g6_train_step():
+    """G6: full train_val_sample (2 forwards + losses + backward + Adam) on the reference vs oracle."""
+    cases = [("sp_64x96", "SuperPointNet_gauss2", 64, 96, dict()),
+             ("ssp_64x96", "SuperPointNet_gauss2_ssmall", 64, 96, dict()),
+             ("magicpoint_32x48", "SuperPointNet_gauss2", 32, 48, dict(lambda_loss=0, warp_only_det=True))]
+    for tag, arch, H, W, opt in cases:
+        semantic = arch.endswith("ssmall")
+        lam = opt.get("lambda_loss", 1)
+        cfg = R.base_config(semantic=semantic, H=H, W=W, batch=2, lr=0.001, lambda_loss=lam)
+        sd = C.init_state_dict(arch, seed=23)
+        agent = R.make_trainer(cfg, sd)
+        sample = C.make_synthetic_pair(2, H, W, seed=31, semantic=semantic, kp_prob=0.01)
+        tr = C.Trainer(arch, sd, lr=0.001, lambda_loss=float(lam))
+        steps = {}
+        noisy = {conv + ".bias" for conv, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+        for it in range(2):
+            np.random.seed(100 + it); torch.manual_seed(200 + it)
+            # n_iter=1,2: skips the tensorboard branch (uses removed np.int) - SURVEY.md 8c
+            agent.optimizer.zero_grad() if False else None
+            grads_before = None
+            l_ref = agent.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=it + 1, train=True)
+            sc_ref = {k: float(v) for k, v in agent.scalar_dict.items()}
+            np.random.seed(100 + it); torch.manual_seed(200 + it)
+            l_or = tr.train_val_sample(sample, n_iter=it + 1, train=True)
+            for k in sc_ref:
+                close(sc_ref[k], tr.scalar_dict[k], 2e-5 * max(1.0, abs(sc_ref[k])), "G6 %s scalar %s it%d" % (tag, k, it))
+            steps[it] = sc_ref
+            # post-step parameters (weights / BN affine / eta; NOT the conv biases feeding a BN:
+            # their true gradient is 0 and Adam amplifies rounding noise - SURVEY.md section 7)
+            for k, p in agent.net.named_parameters():
+                if k in noisy:
+                    continue
+                close_adam(p, tr.sd[k], 0.001, "G6 %s post-step %s it%d" % (tag, k, it))
+            close(agent.multi_task_loss.eta, tr.eta, 1e-5, "G6 eta")
+        # gradients of a fresh step without optimizer step: recompute on a new agent for storage
+        agent2 = R.make_trainer(cfg, sd)
+        np.random.seed(100); torch.manual_seed(200)
+        agent2.real_batch_size = 10 ** 9  # never step: leaves .grad in place
+        agent2.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=1, train=True)
+        tr2 = C.Trainer(arch, sd, lr=0.001, lambda_loss=float(lam))
+        tr2.real_batch_size = 10 ** 9
+        np.random.seed(100); torch.manual_seed(200)
+        tr2.train_val_sample(sample, n_iter=1, train=True)
+        save = _sample_to_npz(sample)
+        for k, p in agent2.net.named_parameters():
+            g = p.grad
+            go = tr2.last_grads[k]
+            if g is None:  # lambda_loss == 0: the descriptor head is not in the graph
+                assert go is None, k
+                continue
+            scale = max(1e-6, float(g.abs().max()))
+            if k in noisy:  # true gradient is 0: both sides hold rounding noise only
+                assert float(g.abs().max()) < 1e-3 and float(go.abs().max()) < 1e-3, k
+            else:
+                close(g, go, 2e-4 * scale + 1e-6, "G6 %s grad %s" % (tag, k))
+            save["grad_norm/" + k] = np.float32(g.norm().item())
+            save["grad_slice/" + k] = npy(g.reshape(-1)[:64])
+        save["grad/eta"] = npy(agent2.multi_task_loss.eta.grad)
+        close(agent2.multi_task_loss.eta.grad, tr2.last_grads["eta"], 1e-5, "G6 eta grad")
+        for i, idx in enumerate(tr2.aux["indices"] or []):
+            save["idx/uv_a%d" % i] = npy(idx["uv_a"]).astype(np.int16)
+            save["idx/uv_b%d" % i] = npy(idx["uv_b"]).astype(np.int16)
+            save["idx/nm_b%d" % i] = npy(idx["nm_b"]).astype(np.int16)
+        for it in steps:
+            for k, v in steps[it].items():
+                save["step%d/%s" % (it, k)] = np.float32(v)
+        save["post/eta"] = npy(agent.multi_task_loss.eta)
+        for k in ("inc.conv.conv.3.weight", "down3.mpconv.1.conv.4.weight", "convPb.weight", "bnDb.bias"):
+            save["post_slice/" + k] = npy(dict(agent.net.named_parameters())[k].reshape(-1)[:64])
+        rsd = agent.net.state_dict()
+        for k in rsd:
+            if "running_var" in k:
+                save["post_state/" + k] = npy(rsd[k])
+        np.savez_compressed(os.path.join(OUT, "g6_step_%s.npz" % tag), **save)
+        print("G6", tag, "ok; loss", steps[0]["loss"], "->", steps[1]["loss"])
+
+
+def g7_warps():
+    R.install()
+    from utils.utils import inv_warp_image_batch, compute_valid_mask
+    from utils.homographies import scale_homography_torch
+    from datasets.data_tools import warpLabels
+    rs = np.random.RandomState(41)
+    H, W = 40, 56
+    Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(4)]).astype(np.float32))
+    inv = torch.inverse(Hs).contiguous()
+    img = torch.from_numpy(rs.uniform(0, 1, (4, 1, H, W)).astype(np.float32))
+    wr = inv_warp_image_batch(img, inv, mode="bilinear")
+    wo = C.inv_warp_image_batch(img, inv, mode="bilinear")
+    close(wr, wo, 1e-6, "G7 warp")
+    mr = compute_valid_mask(torch.tensor([H, W]), inv, erosion_radius=0)
+    mo = C.compute_valid_mask((H, W), inv, 0)
+    assert torch.equal(mr, mo), "G7 mask"
+    save = {"H": npy(Hs), "img": npy(img), "warped": npy(wr), "mask": npy(mr)}
+    for i in range(4):
+        pts = torch.nonzero(torch.from_numpy((rs.uniform(size=(H, W)) < 0.02))).flip(1)
+        lr = warpLabels(pts, H, W, Hs[i])["labels"]
+        lo = C.warp_labels(pts, H, W, Hs[i])
+        assert torch.equal(lr, lo), "G7 warpLabels"
+        close(scale_homography_torch(Hs[i], (30, 40)), C.scale_homography(Hs[i], (30, 40)), 0, "G7 scaleH")
+        save["pts%d" % i] = npy(pts).astype(np.int16)
+        save["wlabels%d" % i] = npy(lr)
+        save["Hcell%d" % i] = npy(scale_homography_torch(Hs[i], (30, 40)))
+    np.savez_compressed(os.path.join(OUT, "g7_warps.npz"), **save)
+
+
+def main():
+    assert R.available(), "reference not mounted"
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step):
+        fn()
+        print(fn.__name__, "done")
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()
