@@ -1,0 +1,148 @@
+/*
+ * ssp_hip.h - C ABI of the MI355X-native Semantic-SuperPoint pair-training path.
+ *
+ * Every pointer named *_dev is a DEVICE pointer owned by the caller (PyTorch tensors in the
+ * Python shims); the library never frees caller memory and keeps no host threads.  All entry
+ * points return 0 on success or a negative code; ssp_last_error() gives the message.  `stream`
+ * is a hipStream_t passed as void* (0 = default stream).  One handle per GPU / stream.
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   ssp_forward      <- models/SuperPointNet_gauss2.py:42-69, models/SuperPointNet_gauss2_ssmall.py:58-99
+ *                       (+ models/unet_parts.py:10-48)
+ *   ssp_backward     <- autograd of the above (loss.backward(), Train_model_heatmap_all.py:407)
+ *   ssp_pair_step    <- Train_model_heatmap_all.py:195-413 (train_val_sample: 2 forwards, labels2Dto3D
+ *                       utils/utils.py:408-440, getMasks Train_model_frontend_all.py:373-386,
+ *                       detector_loss :155-179, sem_loss :181-193, batch_descriptor_loss_sparse
+ *                       utils/loss_functions/sparse_loss.py:267-284, MultiTaskLoss :46-77, backward)
+ *   ssp_adam_step    <- optimizer.step() of Train_model_frontend_all.py:183-198 (Adam, constant LR)
+ *   ssp_sample_indices <- the stochastic half of descriptor_loss_sparse (sparse_loss.py:184-246,
+ *                       correspondence_finder.py:191-320), device RNG
+ */
+#ifndef SSP_HIP_H
+#define SSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssp_handle ssp_handle;
+
+enum { SSP_ARCH_GAUSS2 = 0, SSP_ARCH_GAUSS2_SSMALL = 1 };
+
+typedef struct {
+  int arch;      /* SSP_ARCH_* */
+  int n_classes; /* 133 for the ssmall seg head; ignored for gauss2 */
+  int max_batch; /* largest N of any forward */
+  int height;    /* H, multiple of 8 */
+  int width;     /* W, multiple of 8 */
+  int n_match;   /* num_matching_attempts (1000) */
+  int n_non;     /* num_masked_non_matches_per_match (100) */
+} ssp_config;
+
+/* Device buffers bound once after create (all float32 unless noted).
+ * params/grads/adam_m/adam_v: [n_params + 3]  (net.parameters() order = state_dict order without
+ * buffers, OIHW conv weights; the 3 trailing floats are MultiTaskLoss.eta).
+ * bn_running: [2 * n_bn_channels] = all running_mean (layer order) then all running_var.
+ * num_batches_tracked: int64 [n_bn_layers]. */
+typedef struct {
+  float* params_dev;
+  float* grads_dev;
+  float* adam_m_dev;
+  float* adam_v_dev;
+  float* bn_running_dev;
+  int64_t* num_batches_tracked_dev;
+  void* workspace_dev;
+  size_t workspace_bytes;
+} ssp_buffers;
+
+/* One micro-batch of pairs (Train_model_heatmap_all.py:212-251 `sample`). NCHW with C==1. */
+typedef struct {
+  int batch;
+  const float* image_dev;             /* [B,1,H,W] */
+  const float* warped_image_dev;      /* [B,1,H,W] */
+  const float* labels_dev;            /* [B,1,H,W] labels_2D(_gaussian) */
+  const float* warped_labels_dev;     /* [B,1,H,W] */
+  const float* valid_mask_dev;        /* [B,1,H,W] */
+  const float* warped_valid_mask_dev; /* [B,1,H,W] */
+  const float* homographies_dev;      /* [B,3,3] normalised coords, image -> warped */
+  const int64_t* semantic_dev;        /* [B,H,W] or NULL */
+  const int64_t* warped_semantic_dev; /* [B,H,W] or NULL */
+  /* sparse-loss indices, either given (parity mode) or sampled on device when match_a_dev==NULL */
+  const int32_t* match_a_dev;    /* [B,n_match] cell index u+v*Wc in image a */
+  const int32_t* match_b_dev;    /* [B,n_match] cell index in image b */
+  const int32_t* nonmatch_b_dev; /* [B,n_match*n_non] cell index in image b */
+  uint64_t seed;                 /* device sampler seed (used when match_a_dev == NULL) */
+  float lambda_loss;             /* model.lambda_loss; 0 disables the descriptor loss */
+  float lamda_d;                 /* sparse_loss.params.lamda_d */
+  int multi_task;                /* model.multi_task_loss */
+  int train;                     /* 1: accumulate gradients; 0: forward + losses only */
+} ssp_pair_inputs;
+
+/* indices into the float scalars[SSP_N_SCALARS] array filled by ssp_pair_step (the reference's
+ * scalar_dict, Train_model_heatmap_all.py:415-441) */
+enum {
+  SSP_S_LOSS = 0, SSP_S_LOSS_DET, SSP_S_LOSS_DET_WARP, SSP_S_LOSS_DESC, SSP_S_LOSS_SEM, SSP_S_LOSS_SEM_WARP,
+  SSP_S_POSITIVE_DIST, SSP_S_NEGATIVE_DIST, SSP_S_ETA_DET, SSP_S_ETA_DESC, SSP_S_ETA_SEM,
+  SSP_N_SCALARS = 16
+};
+
+const char* ssp_last_error(void);
+int ssp_create(const ssp_config* cfg, ssp_handle** out);
+void ssp_destroy(ssp_handle* h);
+size_t ssp_param_count(const ssp_handle* h);       /* net parameters (without eta) */
+size_t ssp_bn_channel_count(const ssp_handle* h);  /* sum of C over BatchNorm layers */
+int ssp_bn_layer_count(const ssp_handle* h);
+size_t ssp_workspace_bytes(const ssp_handle* h);
+int ssp_bind(ssp_handle* h, const ssp_buffers* b, void* stream);
+
+/* forward of one batch into activation slot 0/1; outputs (may be NULL) are NCHW like the reference:
+ * semi [N,65,H/8,W/8], desc [N,256,H/8,W/8], sem [N,n_classes,H,W]. train: 1 = batch statistics +
+ * running-stat update (module default), 0 = eval() (running statistics). */
+int ssp_forward(ssp_handle* h, int slot, const float* x_dev, int n, int height, int width, int train,
+                float* semi_dev, float* desc_dev, float* sem_dev, void* stream);
+/* backward of slot given dL/d(outputs) in NCHW (NULL = zero); ACCUMULATES into grads_dev. */
+int ssp_backward(ssp_handle* h, int slot, const float* dsemi_dev, const float* ddesc_dev, const float* dsem_dev,
+                 void* stream);
+int ssp_zero_grad(ssp_handle* h, void* stream);
+int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, void* stream);
+int ssp_adam_step(ssp_handle* h, float lr, int step, void* stream);
+int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
+                       int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream);
+
+/* timing hook for bench.py: when enabled, every launch of the tagged kernel family is bracketed by
+ * hipEvents on `stream`; ssp_profile_read returns accumulated milliseconds, launches and FLOPs. */
+enum { SSP_PROF_NONE = 0, SSP_PROF_CONV3X3_FWD = 1, SSP_PROF_CONV3X3_DGRAD = 2, SSP_PROF_CONV3X3_WGRAD = 3,
+       SSP_PROF_CONV_BIG_FWD = 4 };
+int ssp_profile_enable(ssp_handle* h, int family);
+int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- operator-level entry points (used by the unit parity tests; same kernels as above) ---- */
+/* 3x3 / 1x1 convolution, NHWC fp32, stride 1, "same" padding, weights OIHW (reference layout).
+ * in_mode: 0 raw input, 1 input = relu(in*scale+shift), 2 = maxpool2(relu(in*scale+shift)) where `in`
+ * is [N,2H,2W,Cin]. stats_dev (double [2*Cout]: sum, sumsq) may be NULL. */
+int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_dev, float* out_dev, int n, int h,
+                int w, int cin, int cout, int ksize, int in_mode, const float* in_scale_dev,
+                const float* in_shift_dev, double* stats_dev, int transpose_flip, void* workspace_dev,
+                size_t workspace_bytes, void* stream);
+int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw_dev, int n, int h, int w, int cin,
+                      int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* labels2Dto3D (utils/utils.py:408-440, add_dustbin=True) -> target [B,65,H/8,W/8] NCHW and getMasks
+ * (Train_model_frontend_all.py:373-386) -> cellmask [B,H/8,W/8]; either pair of pointers may be NULL. */
+int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* target_dev, float* cellmask_dev, int b,
+                  int h, int w, void* stream);
+
+/* forward of batch_descriptor_loss_sparse (utils/loss_functions/sparse_loss.py:267-284) on NHWC descriptor
+ * maps [B][hc*wc][256] with explicit indices; out2_dev = {mean positive_dist, mean negative_dist}. */
+int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,
+                       const int32_t* match_b_dev, const int32_t* nonmatch_b_dev, int b, int hc, int wc, int n_match,
+                       int n_non, float* out2_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSP_HIP_H */

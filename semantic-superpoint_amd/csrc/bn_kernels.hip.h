@@ -1,0 +1,432 @@
+// HBM-bound kernels around the convolutions: first-layer direct conv (1->64), BatchNorm statistics
+// finalisation, BatchNorm(+ReLU(+max-pool)) backward, head epilogues.  NHWC fp32, float4 per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sspk {
+
+// ---- block reduction helper: per-thread `NV` floats, threads with the same (tid % nq) are summed ----
+// smem must hold blockDim.x * NV floats.  Result valid for tid < nq (returned in v[]).
+template <int NV>
+__device__ __forceinline__ void reduce_by_column(float (&v)[NV], float* smem, int nq) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) smem[tid * NV + i] = v[i];
+  __syncthreads();
+  if (tid < nq) {
+    const int rows = blockDim.x / nq;
+    for (int r = 1; r < rows; ++r)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] += smem[(r * nq + tid) * NV + i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First layer: Conv2d(1, 64, 3, padding=1) on the grayscale image (models/unet_parts.py:14, in_ch = 1).
+// K = 9: HBM-bound (writes 256 B per pixel).  16 lanes per pixel, float4 of channels per lane.
+// Also accumulates the BatchNorm sums.  grid: ceil(npix / (16 * PIX_ITERS)), block 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int C0_ITERS = 64;
+__global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           double* __restrict__ stats, int N, int H, int W) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int q = tid & 15;      // channel quad
+  const int pl = tid >> 4;     // pixel lane 0..15
+  float wr[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[c][t] = w[(q * 4 + c) * 9 + t];
+  const float4 bv = *reinterpret_cast<const float4*>(bias + q * 4);
+  const long npix = (long)N * H * W;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long base = (long)blockIdx.x * 16 * C0_ITERS;
+  for (int it = 0; it < C0_ITERS; ++it) {
+    const long p = base + it * 16 + pl;
+    if (p >= npix) break;
+    const int xx = (int)(p % W);
+    const int yy = (int)((p / W) % H);
+    const float* xi = x + p;
+    float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int gy = yy + dy - 1, gx = xx + dx - 1;
+        v[dy * 3 + dx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? xi[(dy - 1) * W + (dx - 1)] : 0.f;
+      }
+    float o[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) o[c] = fmaf(v[t], wr[c][t], o[c]);
+    *reinterpret_cast<float4*>(out + p * 64 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] += o[c];
+      acc[4 + c] += o[c] * o[c];
+    }
+  }
+  if (stats != nullptr) {
+    reduce_by_column<8>(acc, red, 16);
+    if (tid < 16) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsafeAtomicAdd(stats + tid * 4 + c, (double)acc[c]);
+        unsafeAtomicAdd(stats + 64 + tid * 4 + c, (double)acc[4 + c]);
+      }
+    }
+  }
+}
+
+// dW[64][1][3][3] and db for the first layer: reduction over all pixels of dY[p][co] * x[p+tap].
+// One block handles a strip of pixels for all 64 channels; partial sums -> atomics (576+64 values).
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dw, int N, int H, int W) {
+  __shared__ float red[256 * 9];
+  const int tid = threadIdx.x;
+  const int q = tid & 15, pl = tid >> 4;
+  const long npix = (long)N * H * W;
+  const long base = (long)blockIdx.x * 16 * C0_ITERS;
+  float acc[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  for (int it = 0; it < C0_ITERS; ++it) {
+    const long p = base + it * 16 + pl;
+    if (p >= npix) break;
+    const int xx = (int)(p % W);
+    const int yy = (int)((p / W) % H);
+    const float4 g = *reinterpret_cast<const float4*>(dy + p * 64 + q * 4);
+    const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int dyy = 0; dyy < 3; ++dyy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int gy = yy + dyy - 1, gx = xx + dx - 1;
+        const float v = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? x[p + (dyy - 1) * W + (dx - 1)] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c][dyy * 3 + dx] = fmaf(gv[c], v, acc[c][dyy * 3 + dx]);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = acc[c][t];
+    __syncthreads();
+    reduce_by_column<9>(v, red, 16);
+    if (tid < 16) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(dw + (tid * 4 + c) * 9 + t, v[t]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics -> per-channel affine (nn.BatchNorm2d defaults eps 1e-5, momentum 0.1).
+// train: batch statistics from the fp64 sums + running-stat update; eval: running statistics.
+// ------------------------------------------------------------------------------------------------
+struct BnLayer {
+  const double* stats;  // [2C] sum, sumsq
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* scale;   // gamma * invstd
+  float* shift;   // beta - mean * scale
+  float* mean;
+  float* invstd;
+  int C;
+  double count;
+};
+
+__global__ void bn_finalize_kernel(const BnLayer L, int train, int64_t* nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= L.C) return;
+  double mean, var;
+  if (train) {
+    mean = L.stats[c] / L.count;
+    var = L.stats[L.C + c] / L.count - mean * mean;
+    if (var < 0) var = 0;
+    const double unbiased = L.count > 1 ? var * L.count / (L.count - 1) : var;
+    L.running_mean[c] = (float)(0.9 * (double)L.running_mean[c] + 0.1 * mean);
+    L.running_var[c] = (float)(0.9 * (double)L.running_var[c] + 0.1 * unbiased);
+    if (c == 0 && nbt != nullptr) *nbt += 1;
+  } else {
+    mean = L.running_mean[c];
+    var = L.running_var[c];
+  }
+  const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+  const float sc = L.gamma[c] * invstd;
+  L.mean[c] = (float)mean;
+  L.invstd[c] = invstd;
+  L.scale[c] = sc;
+  L.shift[c] = L.beta[c] - (float)mean * sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm (+ReLU (+2x2 max-pool)) backward, two passes over (dOut, Y):
+//   pass 1 (reduce): S1 = sum dZ, S2 = sum dZ * xhat            (fp64 atomics, [2C])
+//   pass 2 (apply) : dY = gamma*invstd * (dZ - S1/n - xhat*S2/n)    and   db_conv += sum dY (~0)
+// where z = y*scale+shift, dZ = dA * [z > 0] (RELU) and dA is dOut routed to the first arg-max of each
+// 2x2 window (POOL; torch max_pool2d backward semantics).  dgamma = S2, dbeta = S1.
+// Layout: Y [N,H,W,cs] (H,W = full resolution of this layer), dOut [N,H/2,W/2,dcs] when POOL.
+// ------------------------------------------------------------------------------------------------
+struct BnBwdArgs {
+  const float* y;
+  const float* dout;
+  float* dy;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  double* sums;      // [2C]
+  float* dbias;      // conv bias gradient (accumulated) or nullptr
+  int N, H, W, C;
+  int y_cs, y_co, d_cs, d_co, dy_cs, dy_co;
+  double count;
+};
+
+template <bool RELU, bool POOL, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int nq = (a.C + 3) / 4;                 // channel quads
+  const int rows = 256 / nq;                    // pixel lanes per block
+  const int q = tid % nq, pl = tid / nq;
+  const bool active = pl < rows;
+  const int c0 = q * 4;
+  const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;  // resolution of dOut
+  const long npix = (long)a.N * Ho * Wo;
+  float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, is = sc, k1 = sc, k2 = sc, gs = sc;
+  bool cv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cv[i] = (c0 + i) < a.C;
+  auto ld4 = [&](const float* p) {
+    float4 v = make_float4(0, 0, 0, 0);
+    if (cv[0]) v.x = p[c0];
+    if (cv[1]) v.y = p[c0 + 1];
+    if (cv[2]) v.z = p[c0 + 2];
+    if (cv[3]) v.w = p[c0 + 3];
+    return v;
+  };
+  if (active) {
+    sc = ld4(a.scale);
+    sh = ld4(a.shift);
+    mu = ld4(a.mean);
+    is = ld4(a.invstd);
+    if (APPLY) {
+      const float4 g = ld4(a.gamma);
+      const float inv_n = (float)(1.0 / a.count);
+      float s1[4], s2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s1[i] = cv[i] ? (float)a.sums[c0 + i] * inv_n : 0.f;
+        s2[i] = cv[i] ? (float)a.sums[a.C + c0 + i] * inv_n : 0.f;
+      }
+      k1 = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      k2 = make_float4(s2[0], s2[1], s2[2], s2[3]);
+      gs = make_float4(g.x * is.x, g.y * is.y, g.z * is.z, g.w * is.w);
+    }
+  }
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+  const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+  const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
+  const float gsv[4] = {gs.x, gs.y, gs.z, gs.w};
+  if (active) {
+    for (long p = (long)blockIdx.x * rows + pl; p < npix; p += (long)gridDim.x * rows) {
+      const int ox = (int)(p % Wo);
+      const int oy = (int)((p / Wo) % Ho);
+      const int n = (int)(p / ((long)Wo * Ho));
+      const float4 d4 = *reinterpret_cast<const float4*>(a.dout + (size_t)p * a.d_cs + a.d_co + c0);
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+      if (!POOL) {
+        const size_t yo = (size_t)p * a.y_cs + a.y_co + c0;
+        const float4 y4 = *reinterpret_cast<const float4*>(a.y + yo);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float z = fmaf(yv[i], scv[i], shv[i]);
+          const float dz = (!RELU || z > 0.f) ? dv[i] : 0.f;
+          const float xh = (yv[i] - muv[i]) * isv[i];
+          if (!APPLY) {
+            acc[i] += dz;
+            acc[4 + i] += dz * xh;
+          } else {
+            o[i] = gsv[i] * (dz - k1v[i] - xh * k2v[i]);
+            acc[i] += o[i];
+          }
+        }
+        if (APPLY)
+          *reinterpret_cast<float4*>(a.dy + (size_t)p * a.dy_cs + a.dy_co + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        float yv[4][4], o[4][4];
+        size_t yo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+          yo[k] = ((size_t)(n * a.H + yy) * a.W + xx);
+          const float4 y4 = *reinterpret_cast<const float4*>(a.y + yo[k] * a.y_cs + a.y_co + c0);
+          yv[k][0] = y4.x; yv[k][1] = y4.y; yv[k][2] = y4.z; yv[k][3] = y4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // first maximum of relu(z) in window scan order (torch: strictly greater replaces)
+          float best = -1.f;
+          int bk = 0;
+          float zk[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            zk[k] = fmaf(yv[k][i], scv[i], shv[i]);
+            const float av = fmaxf(zk[k], 0.f);
+            if (av > best) {
+              best = av;
+              bk = k;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float dz = (k == bk && zk[k] > 0.f) ? dv[i] : 0.f;
+            const float xh = (yv[k][i] - muv[i]) * isv[i];
+            if (!APPLY) {
+              acc[i] += dz;
+              acc[4 + i] += dz * xh;
+            } else {
+              o[k][i] = gsv[i] * (dz - k1v[i] - xh * k2v[i]);
+              acc[i] += o[k][i];
+            }
+          }
+        }
+        if (APPLY) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<float4*>(a.dy + yo[k] * a.dy_cs + a.dy_co + c0) =
+                make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+        }
+      }
+    }
+  }
+  if (!active) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  }
+  // reduce over the block's pixel lanes
+  {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[tid * 8 + i] = acc[i];
+    __syncthreads();
+    if (tid < nq) {
+      for (int r = 1; r < rows; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += red[(r * nq + tid) * 8 + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!cv[i]) continue;
+        if (!APPLY) {
+          unsafeAtomicAdd(a.sums + c0 + i, (double)acc[i]);
+          unsafeAtomicAdd(a.sums + a.C + c0 + i, (double)acc[4 + i]);
+        } else if (a.dbias != nullptr) {
+          atomicAdd(a.dbias + c0 + i, acc[i]);
+        }
+      }
+    }
+  }
+}
+
+// dgamma += S2, dbeta += S1 (fp64 sums of bn_bwd pass 1)
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] += (float)sums[c];
+  dgamma[c] += (float)sums[C + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head epilogues.
+// semi = bnPb(convPb(.)) : NHWC raw [cells][cs] -> NCHW [N,65,Hc,Wc] (API output only).
+// desc = bnDb(convDb(.)) / ||.||_2 : one wave per cell (256 channels = 4 per lane).
+// ------------------------------------------------------------------------------------------------
+__global__ void nhwc_affine_to_nchw_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, float* __restrict__ out, int N, int HW,
+                                           int C, int cs, int co) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*C*HW, HW fastest
+  if (idx >= (long)N * C * HW) return;
+  const int p = (int)(idx % HW);
+  const int c = (int)((idx / HW) % C);
+  const int n = (int)(idx / ((long)HW * C));
+  float v = y[((size_t)n * HW + p) * cs + co + c];
+  if (scale != nullptr) v = fmaf(v, scale[c], shift[c]);
+  out[idx] = v;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int HW, int C, int cs,
+                                    int co) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*HW*C, C fastest
+  if (idx >= (long)N * C * HW) return;
+  const int c = (int)(idx % C);
+  const int p = (int)((idx / C) % HW);
+  const int n = (int)(idx / ((long)HW * C));
+  out[((size_t)n * HW + p) * cs + co + c] = in[((size_t)n * C + c) * HW + p];
+}
+
+// desc: raw YDb [cells][cs] -> normalised desc [cells][256] and 1/norm [cells]
+// (models/SuperPointNet_gauss2.py:64-65, no epsilon).
+__global__ __launch_bounds__(256) void desc_normalize_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ desc,
+                                                             float* __restrict__ inv_norm, int ncells, int cs, int co) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= ncells) return;
+  const float4 v = *reinterpret_cast<const float4*>(y + (size_t)wave * cs + co + lane * 4);
+  const float4 sc = *reinterpret_cast<const float4*>(scale + lane * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + lane * 4);
+  float4 r = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  float s = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.f / sqrtf(s);
+  *reinterpret_cast<float4*>(desc + (size_t)wave * 256 + lane * 4) = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+  if (lane == 0) inv_norm[wave] = inv;
+}
+
+// backward of the L2 normalisation: d_raw = (d - desc * <desc, d>) * inv_norm   (in place on d)
+__global__ __launch_bounds__(256) void desc_normalize_bwd_kernel(const float* __restrict__ desc,
+                                                                 const float* __restrict__ inv_norm,
+                                                                 float* __restrict__ d, int ncells) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= ncells) return;
+  const float4 n = *reinterpret_cast<const float4*>(desc + (size_t)wave * 256 + lane * 4);
+  float4 g = *reinterpret_cast<const float4*>(d + (size_t)wave * 256 + lane * 4);
+  float s = n.x * g.x + n.y * g.y + n.z * g.z + n.w * g.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = inv_norm[wave];
+  g = make_float4((g.x - n.x * s) * inv, (g.y - n.y * s) * inv, (g.z - n.z * s) * inv, (g.w - n.w * s) * inv);
+  *reinterpret_cast<float4*>(d + (size_t)wave * 256 + lane * 4) = g;
+}
+
+// Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float bc1, float bc2_sqrt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = 0.9f * m[i] + 0.1f * gi;
+  const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace sspk

@@ -1,0 +1,418 @@
+// Implicit-GEMM convolution kernels for gfx950 (CDNA4), fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, 157 TF peak).  NHWC activations, stride 1, "same" padding.
+//
+//   conv_mfma_kernel   forward conv and data-gradient conv (dgrad = conv with flipped/transposed weights)
+//   wgrad_mfma_kernel  weight-gradient: dW[tap][ci][co] = sum_pixels X[pixel+tap][ci] * dY[pixel][co]
+//
+// The BatchNorm+ReLU(+2x2 max-pool) of the PRODUCING layer is applied while the input tile is staged
+// into LDS ("normalise on load"), so activations make one HBM round trip per layer
+// (reference: models/unet_parts.py:10-48 runs conv, BN, ReLU, pool as four separate passes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace sspk {
+
+constexpr int CK = 16;       // input channels staged per K-chunk
+constexpr int CS = CK + 4;   // LDS pixel stride in floats (pad 4 -> conflict-free ds_read_b128)
+constexpr int NB = 64;       // output channels per block
+
+struct ConvArgs {
+  const float* in;        // NHWC [N, H*(pool?2:1), W*(pool?2:1), in_cs]
+  const float* wpk;       // packed weights [cob][chunk][tap][g][h][64][4]
+  const float* bias;      // [Cout] or nullptr
+  float* out;             // NHWC [N,H,W,out_cs]
+  const float* in_scale;  // [Cin] (IN_MODE != 0)
+  const float* in_shift;
+  double* stats;          // [2*Cout] sum, sumsq of the (biased) conv output, or nullptr
+  int N, H, W;
+  int Cin, in_cs, in_co;
+  int Cout, out_cs, out_co;
+  int tiles_x, tiles_y;
+  int nchunks, ncob;
+  int accumulate;         // out += result
+};
+
+// lane/row index m (0..31) of an MFMA M-tile -> pixel (r,c) inside the SH x SW sub-rectangle.
+// SW==32: one image row.  SW==8: 4x8 patch; the Thue-Morse column swizzle makes the four 16-lane
+// groups of ds_read_b128 hit 16 distinct bank quads with an LDS row pitch of 12 pixels.
+template <int SW>
+__device__ __forceinline__ void mpix(int m, int& r, int& c) {
+  if (SW == 32) {
+    r = 0;
+    c = m;
+  } else {
+    const int b = m >> 2;
+    r = b >> 1;
+    c = (m & 3) + 4 * (__popc(b) & 1);
+  }
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int IN_MODE>
+__device__ __forceinline__ float4 xform(float4 v, float4 sc, float4 sh) {
+  if (IN_MODE == 0) return v;
+  float4 o;
+  o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+  o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+  o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+  o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+  return o;
+}
+
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+// Loads the (transformed) 4-channel value of conv-input pixel (n,gy,gx); zero outside the image.
+template <int IN_MODE>
+__device__ __forceinline__ float4 load_in(const float* __restrict__ in, int n, int gy, int gx, int H, int W, int cs,
+                                          int coff, bool cvalid, float4 sc, float4 sh) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cvalid && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+    if (IN_MODE != 2) {
+      const size_t off = ((size_t)(n * H + gy) * W + gx) * cs + coff;
+      v = xform<IN_MODE>(*reinterpret_cast<const float4*>(in + off), sc, sh);
+    } else {
+      const int W2 = 2 * W;
+      const size_t off = ((size_t)(n * 2 * H + 2 * gy) * W2 + 2 * gx) * cs + coff;
+      const float4 a = xform<1>(*reinterpret_cast<const float4*>(in + off), sc, sh);
+      const float4 b = xform<1>(*reinterpret_cast<const float4*>(in + off + cs), sc, sh);
+      const float4 c = xform<1>(*reinterpret_cast<const float4*>(in + off + (size_t)W2 * cs), sc, sh);
+      const float4 d = xform<1>(*reinterpret_cast<const float4*>(in + off + (size_t)W2 * cs + cs), sc, sh);
+      v = max4(max4(a, b), max4(c, d));
+    }
+  }
+  return v;
+}
+
+template <int KS, int SH, int SW>
+struct ConvGeom {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int PAD = KS / 2;
+  static constexpr int TH = 8 * SH;
+  static constexpr int TW = SW;
+  static constexpr int HT = TH + 2 * PAD;
+  static constexpr int WT = TW + 2 * PAD;
+  static constexpr int RP = (SW == 32) ? WT : 12;  // LDS row pitch in pixels
+  static constexpr int A_FLOATS = HT * RP * CS;
+  static constexpr int B_FLOATS = TAPS * CK * NB;
+  static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
+};
+
+// Block: 256 threads (4 waves).  Output tile: (8*SH) x SW pixels x 64 output channels; wave w owns M-tiles
+// 2w, 2w+1 (32 pixels each) x both 32-channel N-tiles -> 4 accumulators of 32x32.
+template <int KS, int IN_MODE, int SH, int SW>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+  using G = ConvGeom<KS, SH, SW>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;
+  float* sB = smem + G::A_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int cob = id % a.ncob;
+  int tile = id / a.ncob;
+  const int tx = tile % a.tiles_x;
+  tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y;
+  const int n = tile / a.tiles_y;
+  const int ty0 = ty * G::TH, tx0 = tx * G::TW;
+
+  int pr, pc;
+  mpix<SW>(li, pr, pc);
+  int aoff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) aoff[mt] = (((wave * 2 + mt) * SH + pr) * G::RP + pc) * CS + lh * 4;
+  const int boff = (lh * NB + li) * 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int q4 = tid & 3;
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    __syncthreads();
+    // ---- stage input halo tile (with BN/ReLU/pool of the producer applied) ----
+    {
+      const int c0 = chunk * CK + q4 * 4;
+      const bool cvalid = c0 < a.Cin;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (IN_MODE != 0 && cvalid) {
+        sc = *reinterpret_cast<const float4*>(a.in_scale + c0);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + c0);
+      }
+      const int coff = a.in_co + c0;
+#pragma unroll 2
+      for (int pp = tid >> 2; pp < G::HT * G::WT; pp += 64) {
+        const int r = pp / G::WT, c = pp - r * G::WT;
+        const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs, coff,
+                                          cvalid, sc, sh);
+        *reinterpret_cast<float4*>(sA + (r * G::RP + c) * CS + q4 * 4) = v;
+      }
+    }
+    // ---- stage weight chunk (straight copy of the pre-packed image) ----
+    {
+      const float4* src =
+          reinterpret_cast<const float4*>(a.wpk + (size_t)(cob * a.nchunks + chunk) * G::B_FLOATS);
+      float4* dst = reinterpret_cast<float4*>(sB);
+#pragma unroll
+      for (int i = tid; i < G::B_FLOATS / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    // ---- MFMA ----
+#pragma unroll
+    for (int tap = 0; tap < G::TAPS; ++tap) {
+      const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+      for (int g = 0; g < CK / 8; ++g) {
+        const float4 a0 = *reinterpret_cast<const float4*>(sA + aoff[0] + (dy * G::RP + dx) * CS + g * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(sA + aoff[1] + (dy * G::RP + dx) * CS + g * 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(sB + boff + (tap * (CK / 8) + g) * 2 * NB * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(sB + boff + (tap * (CK / 8) + g) * 2 * NB * 4 + 32 * 4);
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, store, per-channel sum / sum of squares for the BatchNorm statistics ----
+  float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int co = cob * NB + nt * 32 + li;
+    const bool covalid = co < a.Cout;
+    const float bv = (a.bias != nullptr && covalid) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        int rr, cc;
+        mpix<SW>(m, rr, cc);
+        const int oy = ty0 + (wave * 2 + mt) * SH + rr, ox = tx0 + cc;
+        if (covalid && oy < a.H && ox < a.W) {
+          float v = acc[mt][nt][r] + bv;
+          float* p = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co;
+          if (a.accumulate) v += *p;
+          *p = v;
+          ssum[nt] += v;
+          ssq[nt] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    __syncthreads();
+    float* red = smem;  // [4 waves][2 nt][32][2]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float s = ssum[nt] + __shfl_xor(ssum[nt], 32);
+      float q = ssq[nt] + __shfl_xor(ssq[nt], 32);
+      if (lh == 0) {
+        red[((wave * 2 + nt) * 32 + li) * 2 + 0] = s;
+        red[((wave * 2 + nt) * 32 + li) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid >> 1, which = tid & 1;  // ch in 0..63 -> nt = ch>>5, li = ch&31
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[((w * 2 + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
+      const int co = cob * NB + ch;
+      if (co < a.Cout) unsafeAtomicAdd(a.stats + which * a.Cout + co, (double)t);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient.  Block = 4 waves; block owns a 64(ci) x 64(co) x TAPS slab and loops over spatial tiles
+// of 128 pixels, keeping the slab in accumulators (9 x 32x32 per wave: wave = (ci half, co half)).
+// Partial slabs of the `nsplit` blocks are written to scratch and summed by wgrad_reduce_kernel.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* in;        // conv input (pre-transform), NHWC
+  const float* dout;      // dY NHWC [N,H,W,dout_cs]
+  float* partial;         // [ncib*ncob*nsplit][TAPS][64][64]
+  const float* in_scale;
+  const float* in_shift;
+  int N, H, W;
+  int Cin, in_cs, in_co;
+  int Cout, dout_cs, dout_co;
+  int tiles_x, tiles_y, ntiles;  // per-image tiles and total tiles
+  int ncib, ncob, nsplit;
+};
+
+template <int KS, int SH, int SW>
+struct WgradGeom {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int PAD = KS / 2;
+  static constexpr int TH = 4 * SH;
+  static constexpr int TW = SW;
+  static constexpr int HT = TH + 2 * PAD;
+  static constexpr int WT = TW + 2 * PAD;
+  static constexpr int P = TH * TW;  // 128
+  static constexpr int X_FLOATS = HT * WT * 64;
+  static constexpr int D_FLOATS = P * 64;
+  static constexpr int LDS_BYTES = (X_FLOATS + D_FLOATS) * 4;
+};
+
+template <int KS, int IN_MODE, int SH, int SW>
+__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
+  using G = WgradGeom<KS, SH, SW>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem;
+  float* sD = smem + G::X_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cih = wave >> 1, coh = wave & 1;
+
+  int bid = blockIdx.x;
+  const int split = bid % a.nsplit;
+  bid /= a.nsplit;
+  const int cob = bid % a.ncob;
+  const int cib = bid / a.ncob;
+
+  f32x16 acc[G::TAPS];
+#pragma unroll
+  for (int t = 0; t < G::TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int q16 = tid & 15;  // channel quad 0..15 of the 64-channel slab
+  const int ci0 = cib * 64 + q16 * 4;
+  const bool civalid = ci0 < a.Cin;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (IN_MODE != 0 && civalid) {
+    sc = *reinterpret_cast<const float4*>(a.in_scale + ci0);
+    sh = *reinterpret_cast<const float4*>(a.in_shift + ci0);
+  }
+  const int co0 = cob * 64 + q16 * 4;
+  const bool covalid = co0 < a.Cout;
+
+  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int ty0 = ty * G::TH, tx0 = tx * G::TW;
+    __syncthreads();
+    for (int pp = tid >> 4; pp < G::HT * G::WT; pp += 16) {
+      const int r = pp / G::WT, c = pp - r * G::WT;
+      const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs, a.in_co + ci0,
+                                        civalid, sc, sh);
+      *reinterpret_cast<float4*>(sX + pp * 64 + q16 * 4) = v;
+    }
+    for (int pp = tid >> 4; pp < G::P; pp += 16) {
+      const int r = pp / G::TW, c = pp - r * G::TW;
+      const int gy = ty0 + r, gx = tx0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (covalid && gy < a.H && gx < a.W)
+        v = *reinterpret_cast<const float4*>(a.dout + ((size_t)(n * a.H + gy) * a.W + gx) * a.dout_cs + a.dout_co + co0);
+      *reinterpret_cast<float4*>(sD + pp * 64 + q16 * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < G::P / 2; ++s) {
+      const int p = 2 * s + lh;
+      const int r = p / G::TW, c = p - r * G::TW;
+      const float b = sD[p * 64 + coh * 32 + li];
+      const float* xb = sX + (r * G::WT + c) * 64 + cih * 32 + li;
+#pragma unroll
+      for (int tap = 0; tap < G::TAPS; ++tap) {
+        const int dy = tap / KS, dx = tap % KS;
+        const float av = xb[(dy * G::WT + dx) * 64];
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+  // partial slab: [blk][tap][ci 64][co 64]
+  float* dst = a.partial + (size_t)blockIdx.x * G::TAPS * 4096;
+#pragma unroll
+  for (int tap = 0; tap < G::TAPS; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;  // ci within the 32-half
+      dst[tap * 4096 + (cih * 32 + m) * 64 + coh * 32 + li] = acc[tap][r];
+    }
+}
+
+// Sums the partial slabs over splits and ACCUMULATES into the OIHW gradient tensor.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cin, int Cout,
+                                    int KS, int ncob, int nsplit) {
+  const int taps = KS * KS;
+  const int total = Cout * Cin * taps;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  // idx enumerates (tap, ci, co) with co fastest so that reads of `partial` coalesce
+  const int co = idx % Cout;
+  const int ci = (idx / Cout) % Cin;
+  const int tap = idx / (Cout * Cin);
+  const int cob = co >> 6, cib = ci >> 6;
+  const float* src = partial + ((size_t)((cib * ncob + cob) * nsplit) * taps + tap) * 4096 + (ci & 63) * 64 + (co & 63);
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += src[(size_t)k * taps * 4096];
+  dw[((size_t)co * Cin + ci) * taps + tap] += s;
+}
+
+// Packs OIHW weights into the LDS image of conv_mfma_kernel: [cob][chunk][tap][g][h][64][4].
+// transpose_flip: build the data-gradient convolution (input channels = Cout_w, output = Cin_w, taps mirrored).
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout_w, int Cin_w, int KS,
+                                    int transpose_flip, int nchunks_total, int chunk_off, int cob_off, int ncob,
+                                    int nchunks) {
+  const int taps = KS * KS;
+  const int per_chunk = taps * CK * NB;
+  const int total = ncob * nchunks * per_chunk;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int t = idx;
+  const int e = t & 3;
+  t >>= 2;
+  const int nn = t & 63;
+  t >>= 6;
+  const int h = t & 1;
+  t >>= 1;
+  const int g = t % (CK / 8);
+  t /= (CK / 8);
+  const int tap = t % taps;
+  t /= taps;
+  const int chunk = t % nchunks;
+  const int cob = t / nchunks;
+  const int co = cob * NB + nn;                 // conv output channel
+  const int ci = chunk * CK + g * 8 + h * 4 + e;  // conv input channel
+  const int ky = tap / KS, kx = tap % KS;
+  float v = 0.f;
+  if (!transpose_flip) {
+    if (co < Cout_w && ci < Cin_w) v = w[(((size_t)co * Cin_w + ci) * KS + ky) * KS + kx];
+  } else {
+    if (co < Cin_w && ci < Cout_w) v = w[(((size_t)ci * Cin_w + co) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)];
+  }
+  dst[((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * per_chunk +
+      (((tap * (CK / 8) + g) * 2 + h) * NB + nn) * 4 + e] = v;
+}
+
+}  // namespace sspk

@@ -1,0 +1,348 @@
+// Wavefront-level loss kernels of the pair step (one wave64 per cell / per match).
+//   detector : labels2Dto3D (utils/utils.py:408-440) + getMasks (Train_model_frontend_all.py:373-386)
+//              + BCE(softmax) (Train_model_heatmap_all.py:173-178), forward and d/d semi in one pass
+//   sparse descriptor loss: match term (pixelwise_contrastive_loss.py:160-206, bilinear grid_sample with
+//              align_corners=True at normPts coordinates) and non-match term (:238-263, sparse_loss.py:154)
+//   MultiTaskLoss (Train_model_heatmap_all.py:62-77)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sspk {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_prod(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v *= __shfl_xor(v, o);
+  return v;
+}
+
+// Device-side accumulators / coefficients of one pair step (doubles for order-insensitive sums).
+struct StepAccum {
+  double det_sum[2];    // sum over cells of mask * sum_c BCE, per view
+  double mask_cnt[2];   // mask.sum() per view
+  double sem_sum[2];    // sum of NLL over non-ignored pixels
+  double sem_cnt[2];    // number of non-ignored pixels
+  double pos_sum[64];   // per image: sum_k max(0, 1 - <a,b>)
+  double neg_sum[64];   // per image: sum max(0, <a,b> - 0.2)
+  unsigned int nnz[64]; // per image: number of non-zero non-match hinges
+  float coef_det, coef_pos, coef_neg, coef_sem;  // d total / d (loss_det sum), d/d pos mean, d/d neg mean, d/d sem sum
+};
+
+// ---- cell masks: one wave per cell; lane = dy*8+dx --------------------------------------------
+__global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict__ mask2d, float* __restrict__ cellmask,
+                                                        double* __restrict__ mask_cnt, int B, int H, int W) {
+  const int Hc = H / 8, Wc = W / 8;
+  const int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (cell >= B * Hc * Wc) return;
+  const int cx = cell % Wc, cy = (cell / Wc) % Hc, n = cell / (Wc * Hc);
+  const float m = mask2d[((size_t)n * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
+  const float p = wave_prod(m);
+  if (lane == 0) {
+    cellmask[cell] = p;
+    unsafeAtomicAdd(mask_cnt, (double)p);
+  }
+}
+
+// ---- labels2Dto3D as an operator (parity tests): target [B,65,Hc,Wc] NCHW, same arithmetic as the
+// fused detector kernel below ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void labels2dto3d_kernel(const float* __restrict__ labels2d, float* __restrict__ target,
+                                                           int B, int H, int W) {
+  const int Hc = H / 8, Wc = W / 8;
+  const int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (cell >= B * Hc * Wc) return;
+  const int cx = cell % Wc, cy = (cell / Wc) % Hc, n = cell / (Wc * Hc);
+  const float lab = labels2d[((size_t)n * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
+  const float lsum = wave_sum(lab);
+  float dust = 1.f - lsum;
+  if (dust < 1.f) dust = 0.f;
+  const float dn = lsum + dust;
+  target[(((size_t)n * 65 + lane) * Hc + cy) * Wc + cx] = lab / dn;
+  if (lane == 0) target[(((size_t)n * 65 + 64) * Hc + cy) * Wc + cx] = dust / dn;
+}
+
+// ---- detector loss fwd+bwd: one wave per cell --------------------------------------------------
+// ypb: raw convPb output NHWC [cells][cs] (65 channels), BN affine applied here.
+// dsemi (may be nullptr): d total / d semi, NHWC [cells][cs] (pads written 0).
+__global__ __launch_bounds__(256) void detector_loss_kernel(const float* __restrict__ ypb, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ labels2d,
+                                                            const float* __restrict__ cellmask, float* __restrict__ dsemi,
+                                                            StepAccum* __restrict__ acc, int view, int B, int H, int W,
+                                                            int cs) {
+  const int Hc = H / 8, Wc = W / 8;
+  const int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (cell >= B * Hc * Wc) return;
+  const int cx = cell % Wc, cy = (cell / Wc) % Hc, n = cell / (Wc * Hc);
+  // labels2Dto3D: channel = dy*8+dx ; dustbin = 1 - sum, zeroed when < 1 ; renormalise
+  const float lab = labels2d[((size_t)n * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
+  const float lsum = wave_sum(lab);
+  float dust = 1.f - lsum;
+  if (dust < 1.f) dust = 0.f;
+  const float dn = lsum + dust;
+  const float t = lab / dn, td = dust / dn;
+  // logits
+  const float* yp = ypb + (size_t)cell * cs;
+  const float s = fmaf(yp[lane], scale[lane], shift[lane]);
+  const float sd = fmaf(yp[64], scale[64], shift[64]);
+  const float mx = fmaxf(wave_max(s), sd);
+  const float e = expf(s - mx), ed = expf(sd - mx);
+  const float inv = 1.f / (wave_sum(e) + ed);
+  const float p = e * inv, pd = ed * inv;
+  // BCELoss: -(t*max(log p,-100) + (1-t)*max(log(1-p),-100))
+  const float l = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1pf(-p), -100.f));
+  const float ld = -(td * fmaxf(logf(pd), -100.f) + (1.f - td) * fmaxf(log1pf(-pd), -100.f));
+  const float m = cellmask[cell];
+  const float tot = wave_sum(l) + ld;
+  if (lane == 0) unsafeAtomicAdd(&acc->det_sum[view], (double)(tot * m));
+  if (dsemi != nullptr) {
+    const float coef = acc->coef_det * m / ((float)acc->mask_cnt[view] + 1e-5f);
+    // BCE backward: (p - t) / max(p*(1-p), 1e-12) ; softmax backward: p_j * (g_j - sum_c g_c p_c)
+    const float g = (p - t) / fmaxf(p * (1.f - p), 1e-12f);
+    const float gd = (pd - td) / fmaxf(pd * (1.f - pd), 1e-12f);
+    const float dot = wave_sum(g * p) + gd * pd;
+    float* dp = dsemi + (size_t)cell * cs;
+    dp[lane] = coef * p * (g - dot);
+    if (lane == 0) dp[64] = coef * pd * (gd - dot);
+    if (lane >= 1 && lane < cs - 64) dp[64 + lane] = 0.f;
+  }
+}
+
+// ---- sparse descriptor loss --------------------------------------------------------------------
+// desc_a/desc_b: normalised descriptors NHWC [B][Hc*Wc][256].
+// match term: one wave per match. Coordinates follow the reference bit-for-bit:
+//   g = u / Wc * 2 - 1 (normPts, utils/utils.py:745-755); ix = ((g + 1) / 2) * (Wc - 1) (grid_sample,
+//   align_corners=True) -> bilinear blend of 4 cells.
+struct Bilin {
+  int i00, i01, i10, i11;
+  float w00, w01, w10, w11;
+};
+__device__ __forceinline__ Bilin bilin_setup(int cell, int Hc, int Wc) {
+  const float u = (float)(cell % Wc), v = (float)(cell / Wc);
+  const float gx = u / (float)Wc * 2.f - 1.f, gy = v / (float)Hc * 2.f - 1.f;
+  const float ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1), iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  const float ax = ix - fx, ay = iy - fy;
+  Bilin b;
+  // zeros padding: out-of-range corners contribute nothing (weight 0, index clamped)
+  const bool vx0 = x0 >= 0 && x0 < Wc, vx1 = x1 >= 0 && x1 < Wc, vy0 = y0 >= 0 && y0 < Hc, vy1 = y1 >= 0 && y1 < Hc;
+  const int cx0 = min(max(x0, 0), Wc - 1), cx1 = min(max(x1, 0), Wc - 1);
+  const int cy0 = min(max(y0, 0), Hc - 1), cy1 = min(max(y1, 0), Hc - 1);
+  b.i00 = cy0 * Wc + cx0; b.i01 = cy0 * Wc + cx1; b.i10 = cy1 * Wc + cx0; b.i11 = cy1 * Wc + cx1;
+  b.w00 = (vx0 && vy0) ? (1.f - ax) * (1.f - ay) : 0.f;
+  b.w01 = (vx1 && vy0) ? ax * (1.f - ay) : 0.f;
+  b.w10 = (vx0 && vy1) ? (1.f - ax) * ay : 0.f;
+  b.w11 = (vx1 && vy1) ? ax * ay : 0.f;
+  return b;
+}
+__device__ __forceinline__ float4 f4_fma(float w, float4 a, float4 acc) {
+  return make_float4(fmaf(w, a.x, acc.x), fmaf(w, a.y, acc.y), fmaf(w, a.z, acc.z), fmaf(w, a.w, acc.w));
+}
+__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
+  atomicAdd(p, v.x);
+  atomicAdd(p + 1, v.y);
+  atomicAdd(p + 2, v.z);
+  atomicAdd(p + 3, v.w);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict__ desc_a, const float* __restrict__ desc_b,
+                                                         const int32_t* __restrict__ match_a,
+                                                         const int32_t* __restrict__ match_b, float* __restrict__ dd_a,
+                                                         float* __restrict__ dd_b, StepAccum* __restrict__ acc, int B,
+                                                         int Hc, int Wc, int n_match) {
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= B * n_match) return;
+  const int img = w / n_match;
+  const size_t base = (size_t)img * Hc * Wc * 256 + lane * 4;
+  const Bilin ba = bilin_setup(match_a[w], Hc, Wc), bb = bilin_setup(match_b[w], Hc, Wc);
+  auto ld = [&](const float* d, int i) { return *reinterpret_cast<const float4*>(d + base + (size_t)i * 256); };
+  float4 va = make_float4(0, 0, 0, 0), vb = va;
+  // torch accumulates nw, ne, sw, se in this order
+  va = f4_fma(ba.w00, ld(desc_a, ba.i00), va); va = f4_fma(ba.w01, ld(desc_a, ba.i01), va);
+  va = f4_fma(ba.w10, ld(desc_a, ba.i10), va); va = f4_fma(ba.w11, ld(desc_a, ba.i11), va);
+  vb = f4_fma(bb.w00, ld(desc_b, bb.i00), vb); vb = f4_fma(bb.w01, ld(desc_b, bb.i01), vb);
+  vb = f4_fma(bb.w10, ld(desc_b, bb.i10), vb); vb = f4_fma(bb.w11, ld(desc_b, bb.i11), vb);
+  const float dot = wave_sum(va.x * vb.x + va.y * vb.y + va.z * vb.z + va.w * vb.w);
+  const float hinge = fmaxf(1.f - dot, 0.f);
+  if (!BWD) {
+    if (lane == 0) unsafeAtomicAdd(&acc->pos_sum[img], (double)hinge);
+  } else if (hinge > 0.f) {
+    const float c = -acc->coef_pos / ((float)n_match * (float)B);  // d total / d dot
+    const float4 ga = make_float4(c * vb.x, c * vb.y, c * vb.z, c * vb.w);
+    const float4 gb = make_float4(c * va.x, c * va.y, c * va.z, c * va.w);
+    auto sc = [&](float* d, int i, float wgt, float4 g) {
+      if (wgt != 0.f) atomic_add4(d + base + (size_t)i * 256, make_float4(wgt * g.x, wgt * g.y, wgt * g.z, wgt * g.w));
+    };
+    sc(dd_a, ba.i00, ba.w00, ga); sc(dd_a, ba.i01, ba.w01, ga); sc(dd_a, ba.i10, ba.w10, ga); sc(dd_a, ba.i11, ba.w11, ga);
+    sc(dd_b, bb.i00, bb.w00, gb); sc(dd_b, bb.i01, bb.w01, gb); sc(dd_b, bb.i10, bb.w10, gb); sc(dd_b, bb.i11, bb.w11, gb);
+  }
+}
+
+// non-match term: one wave per match k; 4 non-matches per iteration (16 lanes each, 16 channels per lane).
+// a-side = integer-cell gather of image a at match_a[k] (sparse_loss.py:55-58,245), b-side = nonmatch_b.
+template <bool BWD>
+__global__ __launch_bounds__(256) void desc_nonmatch_kernel(const float* __restrict__ desc_a,
+                                                            const float* __restrict__ desc_b,
+                                                            const int32_t* __restrict__ match_a,
+                                                            const int32_t* __restrict__ nonmatch_b,
+                                                            float* __restrict__ dd_a, float* __restrict__ dd_b,
+                                                            StepAccum* __restrict__ acc, int B, int Hc, int Wc,
+                                                            int n_match, int n_non) {
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= B * n_match) return;
+  const int img = w / n_match;
+  const int grp = lane >> 4, l16 = lane & 15;
+  const size_t ibase = (size_t)img * Hc * Wc * 256;
+  const float* ap = desc_a + ibase + (size_t)match_a[w] * 256 + l16 * 4;
+  float4 a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(ap + i * 64);
+  float4 ga[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ga[i] = make_float4(0, 0, 0, 0);
+  float wgt = 0.f;
+  if (BWD) wgt = acc->coef_neg / (((float)acc->nnz[img] + 1.f) * (float)B);
+  float hsum = 0.f;
+  unsigned cnt = 0;
+  const int32_t* nm = nonmatch_b + (size_t)w * n_non;
+  for (int j0 = 0; j0 < n_non; j0 += 4) {
+    const int j = j0 + grp;
+    const bool valid = j < n_non;
+    const int bi = valid ? nm[j] : 0;
+    const float* bp = desc_b + ibase + (size_t)bi * 256 + l16 * 4;
+    float4 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const float4*>(bp + i * 64);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d += a[i].x * b[i].x + a[i].y * b[i].y + a[i].z * b[i].z + a[i].w * b[i].w;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    const float h = valid ? fmaxf(d - 0.2f, 0.f) : 0.f;
+    if (!BWD) {
+      if (l16 == 0) {
+        hsum += h;
+        cnt += (h != 0.f) ? 1u : 0u;
+      }
+    } else if (h > 0.f) {
+      float* gp = dd_b + ibase + (size_t)bi * 256 + l16 * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ga[i] = f4_fma(wgt, b[i], ga[i]);
+        atomic_add4(gp + i * 64, make_float4(wgt * a[i].x, wgt * a[i].y, wgt * a[i].z, wgt * a[i].w));
+      }
+    }
+  }
+  if (!BWD) {
+    hsum = wave_sum(hsum);
+    float c = wave_sum((float)cnt);
+    if (lane == 0) {
+      unsafeAtomicAdd(&acc->neg_sum[img], (double)hsum);
+      atomicAdd(&acc->nnz[img], (unsigned)(c + 0.5f));
+    }
+  } else {
+    // sum the 4 lane groups' contributions to d a_k, then one atomic per channel
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 g = ga[i];
+      g.x += __shfl_xor(g.x, 16); g.y += __shfl_xor(g.y, 16); g.z += __shfl_xor(g.z, 16); g.w += __shfl_xor(g.w, 16);
+      g.x += __shfl_xor(g.x, 32); g.y += __shfl_xor(g.y, 32); g.z += __shfl_xor(g.z, 32); g.w += __shfl_xor(g.w, 32);
+      if (grp == 0 && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
+        atomic_add4(dd_a + ibase + (size_t)match_a[w] * 256 + l16 * 4 + i * 64, g);
+    }
+  }
+}
+
+// ---- MultiTaskLoss coefficients (before the loss kernels) and scalars / eta gradient (after) ----
+__global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta, int multi_task, float lambda_loss,
+                                  float lamda_d, int semantic) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 2; ++i) acc->det_sum[i] = acc->mask_cnt[i] = acc->sem_sum[i] = acc->sem_cnt[i] = 0.0;
+  for (int i = 0; i < 64; ++i) {
+    acc->pos_sum[i] = acc->neg_sum[i] = 0.0;
+    acc->nnz[i] = 0u;
+  }
+  if (multi_task) {
+    acc->coef_det = expf(-eta[0]);
+    acc->coef_pos = 0.5f * expf(-eta[1]);
+    acc->coef_neg = 0.5f * expf(-eta[1]);
+    acc->coef_sem = expf(-eta[2]);
+  } else {  // uniform sum (Train_model_heatmap_all.py:363-365)
+    acc->coef_det = 1.f;
+    acc->coef_pos = lambda_loss * lamda_d;
+    acc->coef_neg = lambda_loss;
+    acc->coef_sem = 1.f;
+  }
+}
+
+__global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ eta, float* __restrict__ deta,
+                                float* __restrict__ scal, int B, int n_match, int multi_task, float lambda_loss,
+                                float lamda_d, int semantic, int train) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float det0 = (float)acc->det_sum[0] / ((float)acc->mask_cnt[0] + 1e-5f);
+  const float det1 = (float)acc->det_sum[1] / ((float)acc->mask_cnt[1] + 1e-5f);
+  float pos = 0.f, neg = 0.f, ldesc = 0.f;
+  if (lambda_loss > 0.f) {
+    for (int i = 0; i < B; ++i) {
+      const float p = (float)acc->pos_sum[i] / (float)n_match;
+      const float q = (float)acc->neg_sum[i] / ((float)acc->nnz[i] + 1.f);
+      pos += p;
+      neg += q;
+      ldesc += lamda_d * p + q;
+    }
+    pos /= (float)B;
+    neg /= (float)B;
+    ldesc /= (float)B;
+  }
+  float sem0 = 0.f, sem1 = 0.f;
+  if (semantic) {
+    sem0 = (float)(acc->sem_sum[0] / acc->sem_cnt[0]);
+    sem1 = (float)(acc->sem_sum[1] / acc->sem_cnt[1]);
+  }
+  float loss;
+  if (multi_task) {
+    const float e0 = expf(-eta[0]), e1 = expf(-eta[1]), e2 = expf(-eta[2]);
+    loss = (det0 + det1) * e0 + eta[0] + 0.5f * (pos + neg) * e1 + 0.5f * eta[1];
+    if (semantic) loss += (sem0 + sem1) * e2 + eta[2];
+    if (train) {
+      deta[0] += 1.f - (det0 + det1) * e0;
+      deta[1] += 0.5f - 0.5f * (pos + neg) * e1;
+      if (semantic) deta[2] += 1.f - (sem0 + sem1) * e2;
+    }
+  } else {
+    loss = det0 + det1 + sem0 + sem1;
+    if (lambda_loss > 0.f) loss += lambda_loss * ldesc;
+  }
+  scal[0] = loss; scal[1] = det0; scal[2] = det1; scal[3] = ldesc; scal[4] = sem0; scal[5] = sem1;
+  scal[6] = pos; scal[7] = neg; scal[8] = eta[0]; scal[9] = eta[1]; scal[10] = eta[2];
+}
+
+// operator-level helper: mean positive / negative distances of batch_descriptor_loss_sparse
+__global__ void sparse_loss_means_kernel(const StepAccum* acc, float* out, int B, int n_match) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float pos = 0.f, neg = 0.f;
+  for (int i = 0; i < B; ++i) {
+    pos += (float)acc->pos_sum[i] / (float)n_match;
+    neg += (float)acc->neg_sum[i] / ((float)acc->nnz[i] + 1.f);
+  }
+  out[0] = pos / (float)B;
+  out[1] = neg / (float)B;
+}
+
+}  // namespace sspk

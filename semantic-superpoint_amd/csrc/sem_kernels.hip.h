@@ -1,0 +1,246 @@
+// Segmentation head loss (fused bilinear upsample + log-softmax + NLL, never materialising the
+// [B,133,H,W] logits) and the device-side sparse-loss index sampler.
+//   reference: models/SuperPointNet_gauss2_ssmall.py:87-91 (F.interpolate bilinear, align_corners=False),
+//              Train_model_heatmap_all.py:181-193 (CrossEntropyLoss(ignore_index=133)),
+//              utils/loss_functions/sparse_loss.py:184-246, correspondence_finder.py:29-34 (sampling).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "loss_kernels.hip.h"
+
+namespace sspk {
+
+// PyTorch area_pixel_compute_source_index (align_corners=False, non-cubic): clamp below at 0.
+__device__ __forceinline__ void up_src(int dst, int in_size, int out_size, int& i0, int& i1, float& l1) {
+  const float scale = (float)in_size / (float)out_size;
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+// One wave per 8x8 pixel tile shifted by (4,4): all 64 pixels share the same 4 source cells.
+// sout: convSout output NHWC [B][Hc*Wc][cs]; labels int64 [B,H,W]; dsout (BWD) accumulated with atomics.
+template <bool BWD>
+__global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ sout, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ dsout, StepAccum* __restrict__ acc, int view,
+                                                     int B, int Hc, int Wc, int H, int W, int C, int cs) {
+  __shared__ float corner[4][4][160];  // [wave][corner][class]
+  const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long tile = (long)blockIdx.x * 4 + wave_in_blk;
+  const int TX = Wc + 1, TY = Hc + 1;
+  const bool tile_ok = tile < (long)B * TX * TY;
+  int n = 0, ty = 0, tx = 0;
+  if (tile_ok) {
+    tx = (int)(tile % TX) - 1;
+    ty = (int)((tile / TX) % TY) - 1;
+    n = (int)(tile / ((long)TX * TY));
+  }
+  const int cy0 = max(ty, 0), cy1 = min(ty + 1, Hc - 1), cx0 = max(tx, 0), cx1 = min(tx + 1, Wc - 1);
+  const int cidx[4] = {cy0 * Wc + cx0, cy0 * Wc + cx1, cy1 * Wc + cx0, cy1 * Wc + cx1};
+  float(*cw)[160] = corner[wave_in_blk];
+  if (tile_ok) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int c = lane; c < C; c += 64) cw[k][c] = sout[((size_t)n * Hc * Wc + cidx[k]) * cs + c];
+  }
+  __syncthreads();
+  if (!tile_ok) return;
+  const int y = 8 * ty + 4 + (lane >> 3), x = 8 * tx + 4 + (lane & 7);
+  const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+  int label = C;  // ignore
+  float wy1 = 0.f, wx1 = 0.f;
+  if (inside) {
+    int a0, a1;
+    up_src(y, Hc, H, a0, a1, wy1);
+    up_src(x, Wc, W, a0, a1, wx1);
+    label = (int)labels[((size_t)n * H + y) * W + x];
+  }
+  const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+  const bool counted = inside && label != C;  // ignore_index == n_classes (133)
+  // log-sum-exp over classes (two passes; logits are 4 FMAs to recompute)
+  auto logit = [&](int c) { return wy0 * (wx0 * cw[0][c] + wx1 * cw[1][c]) + wy1 * (wx0 * cw[2][c] + wx1 * cw[3][c]); };
+  float m = -INFINITY;
+  for (int c = 0; c < C; ++c) m = fmaxf(m, logit(c));
+  float se = 0.f;
+  for (int c = 0; c < C; ++c) se += expf(logit(c) - m);
+  if (!BWD) {
+    float nll = 0.f;
+    if (counted) nll = (m + logf(se)) - logit(label);
+    const float tot = wave_sum(nll), cnt = wave_sum(counted ? 1.f : 0.f);
+    if (lane == 0) {
+      unsafeAtomicAdd(&acc->sem_sum[view], (double)tot);
+      unsafeAtomicAdd(&acc->sem_cnt[view], (double)cnt);
+    }
+  } else {
+    const float g = counted ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
+    const float inv = 1.f / se;
+    const float w4[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+    for (int c = 0; c < C; ++c) {
+      const float d = g * (expf(logit(c) - m) * inv - ((c == label) ? 1.f : 0.f));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float s = wave_sum(w4[k] * d);
+        if (lane == 0 && s != 0.f) atomicAdd(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + c, s);
+      }
+    }
+  }
+}
+
+// API output only: materialise sem [N,C,H,W] = bilinear upsample of the NHWC convSout map.
+__global__ void sem_upsample_nchw_kernel(const float* __restrict__ sout, float* __restrict__ out, int N, int Hc, int Wc,
+                                         int H, int W, int C, int cs) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * C * H * W) return;
+  const int x = (int)(idx % W), y = (int)((idx / W) % H), c = (int)((idx / ((long)W * H)) % C);
+  const int n = (int)(idx / ((long)W * H * C));
+  int y0, y1, x0, x1;
+  float ly, lx;
+  up_src(y, Hc, H, y0, y1, ly);
+  up_src(x, Wc, W, x0, x1, lx);
+  const float* b = sout + (size_t)n * Hc * Wc * cs + c;
+  const float p00 = b[(size_t)(y0 * Wc + x0) * cs], p01 = b[(size_t)(y0 * Wc + x1) * cs];
+  const float p10 = b[(size_t)(y1 * Wc + x0) * cs], p11 = b[(size_t)(y1 * Wc + x1) * cs];
+  out[idx] = (1.f - ly) * ((1.f - lx) * p00 + lx * p01) + ly * ((1.f - lx) * p10 + lx * p11);
+}
+
+// autograd-compat path only: dsem [N,C,H,W] -> dsout NHWC (gather form, no atomics; dsout += ...)
+__global__ void sem_upsample_bwd_nchw_kernel(const float* __restrict__ dsem, float* __restrict__ dsout, int N, int Hc,
+                                             int Wc, int H, int W, int C, int cs) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total_cells = (long)N * C * Hc * Wc;
+  // the launch is sized for N*C*H*W threads (same as the forward); only the first N*C*Hc*Wc do work
+  if (idx >= total_cells) return;
+  const int cx = (int)(idx % Wc), cy = (int)((idx / Wc) % Hc), c = (int)((idx / ((long)Wc * Hc)) % C);
+  const int n = (int)(idx / ((long)Wc * Hc * C));
+  const int sy = H / Hc, sx = W / Wc;
+  float s = 0.f;
+  for (int y = max(cy * sy - sy, 0); y < min(cy * sy + 2 * sy, H); ++y) {
+    int y0, y1;
+    float ly;
+    up_src(y, Hc, H, y0, y1, ly);
+    const float wy = (y0 == cy ? 1.f - ly : 0.f) + (y1 == cy ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int x = max(cx * sx - sx, 0); x < min(cx * sx + 2 * sx, W); ++x) {
+      int x0, x1;
+      float lx;
+      up_src(x, Wc, W, x0, x1, lx);
+      const float wx = (x0 == cx ? 1.f - lx : 0.f) + (x1 == cx ? lx : 0.f);
+      if (wx != 0.f) s += wy * wx * dsem[(((size_t)n * C + c) * H + y) * W + x];
+    }
+  }
+  dsout[((size_t)n * Hc * Wc + cy * Wc + cx) * cs + c] += s;
+}
+
+// column sums of an NHWC matrix [rows][cs] -> out[C] (accumulated): convSout bias gradient
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m, float* __restrict__ out, int rows, int C,
+                                                     int cs) {
+  // block handles 64 rows; thread t handles columns t, t+256, ...
+  const int r0 = blockIdx.x * 64;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int r = r0; r < min(r0 + 64, rows); ++r) s += m[(size_t)r * cs + c];
+    atomicAdd(out + c, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device sampler for the sparse descriptor loss (distribution-level equivalent of the reference's
+// numpy/torch CPU sampling; parity tests pass the reference's own indices instead).
+// ------------------------------------------------------------------------------------------------
+constexpr int SAMPLER_MAX_CELLS = 2048;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// One block of 1024 threads per image.  match_a/match_b: [B][n_match] cell indices (u + v*Wc).
+__global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __restrict__ Hn, uint64_t seed,
+                                                              int32_t* __restrict__ match_a, int32_t* __restrict__ match_b,
+                                                              int Hc, int Wc, int n_match) {
+  __shared__ uint64_t key[SAMPLER_MAX_CELLS];  // (random key << 32) | (cell_a << 16 ... ) packed below
+  __shared__ int32_t cellb[SAMPLER_MAX_CELLS];
+  __shared__ float Hs[9];
+  __shared__ int nvalid;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int ncell = Hc * Wc;
+  if (tid == 0) {
+    // H_cell = inv(T) @ H @ T, T = [[2/Wc,0,-1],[0,2/Hc,-1],[0,0,1]]  (utils/homographies.py:270-276)
+    const float* h = Hn + img * 9;
+    const float a = 2.f / Wc, b = 2.f / Hc;
+    float M[9];  // H @ T
+    for (int r = 0; r < 3; ++r) {
+      M[r * 3 + 0] = h[r * 3 + 0] * a;
+      M[r * 3 + 1] = h[r * 3 + 1] * b;
+      M[r * 3 + 2] = -h[r * 3 + 0] - h[r * 3 + 1] + h[r * 3 + 2];
+    }
+    // inv(T) = [[1/a,0,1/a],[0,1/b,1/b],[0,0,1]]
+    for (int c = 0; c < 3; ++c) {
+      Hs[0 * 3 + c] = (M[0 * 3 + c] + M[2 * 3 + c]) / a;
+      Hs[1 * 3 + c] = (M[1 * 3 + c] + M[2 * 3 + c]) / b;
+      Hs[2 * 3 + c] = M[2 * 3 + c];
+    }
+    nvalid = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < SAMPLER_MAX_CELLS; i += 1024) {
+    uint64_t k = ~0ull;
+    int32_t cb = 0;
+    if (i < ncell) {
+      const float u = (float)(i % Wc), v = (float)(i / Wc);
+      const float X = Hs[0] * u + Hs[1] * v + Hs[2], Y = Hs[3] * u + Hs[4] * v + Hs[5], Z = Hs[6] * u + Hs[7] * v + Hs[8];
+      const float ub = rintf(X / Z), vb = rintf(Y / Z);  // torch.round: half to even
+      if (ub >= 0.f && ub <= (float)(Wc - 1) && vb >= 0.f && vb <= (float)(Hc - 1)) {
+        const uint32_t r = (uint32_t)(splitmix64(seed ^ ((uint64_t)img << 40) ^ (uint64_t)i) >> 33);  // 31 bits
+        k = ((uint64_t)r << 32) | (uint32_t)i;
+        cb = (int)ub + (int)vb * Wc;
+        atomicAdd(&nvalid, 1);
+      }
+    }
+    key[i] = k;
+    cellb[i] = cb;
+  }
+  __syncthreads();
+  // bitonic sort of the keys (ascending): valid cells come first in random order
+  for (int k2 = 2; k2 <= SAMPLER_MAX_CELLS; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < SAMPLER_MAX_CELLS; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const bool up = (i & k2) == 0;
+          const uint64_t a = key[i], b = key[ixj];
+          if ((a > b) == up) {
+            key[i] = b;
+            key[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int nv = nvalid;
+  for (int j = tid; j < n_match; j += 1024) {
+    int src = j;
+    if (j >= nv) src = nv > 0 ? (int)(splitmix64(seed ^ 0xA5A5A5A5ull ^ ((uint64_t)img << 40) ^ (uint64_t)j) % (uint64_t)nv) : 0;
+    const int ca = nv > 0 ? (int)(uint32_t)(key[src] & 0xFFFFFFFFull) : 0;
+    match_a[(size_t)img * n_match + j] = ca;
+    match_b[(size_t)img * n_match + j] = nv > 0 ? cellb[ca] : 0;
+  }
+}
+
+__global__ void sample_nonmatches_kernel(uint64_t seed, int32_t* __restrict__ nm, long total, int Hc, int Wc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint64_t r = splitmix64(seed ^ 0x5EED5EEDull ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
+  const float u1 = (float)(uint32_t)(r >> 40) * (1.f / 16777216.f);          // 24 bits -> [0,1)
+  const float u2 = (float)(uint32_t)((r >> 16) & 0xFFFFFF) * (1.f / 16777216.f);
+  const int u = min((int)floorf(u1 * Wc), Wc - 1), v = min((int)floorf(u2 * Hc), Hc - 1);
+  nm[i] = u + v * Wc;
+}
+
+}  // namespace sspk

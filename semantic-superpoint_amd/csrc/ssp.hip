@@ -1,0 +1,914 @@
+// C-ABI library of the MI355X-native Semantic-SuperPoint pair-training path (see include/ssp_hip.h).
+// Host orchestration only: every arithmetic step is a HIP kernel from the three headers below.
+#include "../../include/ssp_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bn_kernels.hip.h"
+#include "conv_mfma.hip.h"
+#include "loss_kernels.hip.h"
+#include "sem_kernels.hip.h"
+
+using namespace sspk;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(x)             \
+  do {                     \
+    int r_ = (x);          \
+    if (r_ != 0) return r_; \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+struct LayerDesc {
+  int cin, cout, ks;
+  bool bn;
+  size_t w_off, b_off, g_off, be_off;  // offsets into the flat parameter vector
+  int bn_index;                        // index among BN layers, -1 if none
+  size_t bn_ch_off;                    // channel offset into bn_running
+  // packed weights (floats offset into wpk_fwd / wpk_bwd)
+  size_t pk_fwd, pk_bwd;
+  int nchunks_fwd, ncob_fwd, nchunks_bwd, ncob_bwd;
+};
+
+struct BnBufs {
+  double* stats;   // [2C]
+  double* bsums;   // [2C] backward sums
+  float *scale, *shift, *mean, *invstd;
+};
+
+struct Slot {
+  float* Y[16];     // raw conv outputs (heads share Yheads via offsets)
+  int y_cs[16], y_co[16];
+  BnBufs bn[16];
+  float* desc;      // [B*cells*256] normalised descriptors
+  float* inv_norm;  // [B*cells]
+  float* cellmask;  // [B*cells]
+  float* dsemi;     // [B*cells*80]
+  float* ddesc;     // [B*cells*256]
+  float* dsout;     // [B*cells*SOUT_CS] gradient wrt convSout output (ssmall)
+  const float* x;   // input image of the last forward (caller-owned)
+  void* stats_region;
+  size_t stats_bytes;
+  int N, H, W;
+};
+
+struct ssp_handle {
+  ssp_config cfg;
+  int nlayers, nheads;
+  LayerDesc L[16];
+  size_t n_params, n_bn_ch;
+  int n_bn;
+  ssp_buffers buf;
+  bool bound;
+  size_t ws_bytes;
+  Slot slot[2];
+  float *wpk_fwd, *wpk_bwd;
+  float *gP, *gQ;    // backward ping-pong buffers
+  float* partial;    // wgrad partial slabs
+  size_t partial_floats;
+  StepAccum* accum;
+  int sout_cs;
+  // profiling
+  int prof_family;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used;
+  double prof_flops, prof_bytes;
+  int64_t prof_launches;
+  int n_cu;
+};
+
+enum { L_PA = 8, L_PB = 9, L_DA = 10, L_DB = 11, L_DS = 12, L_SOUT = 13 };
+static const int kEnc[8][2] = {{1, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 128}, {128, 128}};
+
+static void build_layers(ssp_handle* h) {
+  int n = 0;
+  auto add = [&](int cin, int cout, int ks, bool bn) {
+    LayerDesc& d = h->L[n++];
+    d.cin = cin; d.cout = cout; d.ks = ks; d.bn = bn;
+  };
+  for (int i = 0; i < 8; ++i) add(kEnc[i][0], kEnc[i][1], 3, true);
+  add(128, 256, 3, true);   // convPa/bnPa
+  add(256, 65, 1, true);    // convPb/bnPb
+  add(128, 256, 3, true);   // convDa/bnDa
+  add(256, 256, 1, true);   // convDb/bnDb
+  h->nheads = 2;
+  if (h->cfg.arch == SSP_ARCH_GAUSS2_SSMALL) {
+    add(128, 256, 3, true);                  // convDS/bnS1
+    add(256, h->cfg.n_classes, 1, false);    // convSout
+    h->nheads = 3;
+  }
+  h->nlayers = n;
+  size_t off = 0, bnch = 0, pf = 0, pb = 0;
+  int nbn = 0;
+  for (int i = 0; i < n; ++i) {
+    LayerDesc& d = h->L[i];
+    d.w_off = off; off += (size_t)d.cout * d.cin * d.ks * d.ks;
+    d.b_off = off; off += d.cout;
+    if (d.bn) {
+      d.g_off = off; off += d.cout;
+      d.be_off = off; off += d.cout;
+      d.bn_index = nbn++;
+      d.bn_ch_off = bnch; bnch += d.cout;
+    } else {
+      d.g_off = d.be_off = 0; d.bn_index = -1; d.bn_ch_off = 0;
+    }
+    const int taps = d.ks * d.ks;
+    d.nchunks_fwd = cdiv(d.cin, CK); d.ncob_fwd = cdiv(d.cout, NB);
+    d.nchunks_bwd = cdiv(d.cout, CK); d.ncob_bwd = cdiv(d.cin, NB);
+    d.pk_fwd = pf; pf += (size_t)d.ncob_fwd * d.nchunks_fwd * taps * CK * NB;
+    d.pk_bwd = pb; pb += (size_t)d.ncob_bwd * d.nchunks_bwd * taps * CK * NB;
+  }
+  h->n_params = off; h->n_bn_ch = bnch; h->n_bn = nbn;
+}
+
+// resolution (H, W) of layer l's output for an input of H0 x W0
+static void layer_res(int l, int H0, int W0, int& H, int& W) {
+  int s = 0;
+  if (l >= 2) s = 1;
+  if (l >= 4) s = 2;
+  if (l >= 6) s = 3;
+  H = H0 >> s; W = W0 >> s;
+}
+static int layer_in_mode(int l) { return (l == 2 || l == 4 || l == 6) ? 2 : 1; }
+
+struct Carver {
+  char* base; size_t off;
+  template <typename T> T* take(size_t n) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+static size_t carve(ssp_handle* h, void* base) {
+  Carver c{reinterpret_cast<char*>(base), 0};
+  const int B = h->cfg.max_batch, H = h->cfg.height, W = h->cfg.width;
+  const size_t cells = (size_t)B * (H / 8) * (W / 8);
+  h->sout_cs = (int)align_up(h->cfg.n_classes, 4);
+  size_t pf = 0, pb = 0;
+  for (int i = 0; i < h->nlayers; ++i) {
+    const LayerDesc& d = h->L[i];
+    pf = d.pk_fwd + (size_t)d.ncob_fwd * d.nchunks_fwd * d.ks * d.ks * CK * NB;
+    pb = d.pk_bwd + (size_t)d.ncob_bwd * d.nchunks_bwd * d.ks * d.ks * CK * NB;
+  }
+  h->wpk_fwd = c.take<float>(pf);
+  h->wpk_bwd = c.take<float>(pb);
+  for (int s = 0; s < 2; ++s) {
+    Slot& S = h->slot[s];
+    for (int l = 0; l < 8; ++l) {
+      int lh, lw; layer_res(l, H, W, lh, lw);
+      S.Y[l] = c.take<float>((size_t)B * lh * lw * h->L[l].cout);
+      S.y_cs[l] = h->L[l].cout; S.y_co[l] = 0;
+    }
+    const int hcs = 256 * h->nheads;
+    float* yheads = c.take<float>(cells * hcs);
+    S.Y[L_PA] = yheads; S.y_cs[L_PA] = hcs; S.y_co[L_PA] = 0;
+    S.Y[L_DA] = yheads; S.y_cs[L_DA] = hcs; S.y_co[L_DA] = 256;
+    S.Y[L_PB] = c.take<float>(cells * 80); S.y_cs[L_PB] = 80; S.y_co[L_PB] = 0;
+    S.Y[L_DB] = c.take<float>(cells * 256); S.y_cs[L_DB] = 256; S.y_co[L_DB] = 0;
+    if (h->nheads == 3) {
+      S.Y[L_DS] = yheads; S.y_cs[L_DS] = hcs; S.y_co[L_DS] = 512;
+      S.Y[L_SOUT] = c.take<float>(cells * h->sout_cs); S.y_cs[L_SOUT] = h->sout_cs; S.y_co[L_SOUT] = 0;
+      S.dsout = c.take<float>(cells * h->sout_cs);
+    } else {
+      S.dsout = nullptr;
+    }
+    S.desc = c.take<float>(cells * 256);
+    S.inv_norm = c.take<float>(cells);
+    S.cellmask = c.take<float>(cells);
+    S.dsemi = c.take<float>(cells * 80);
+    S.ddesc = c.take<float>(cells * 256);
+    // BN buffers; the fp64 sums of all layers are contiguous so that one memset clears them
+    size_t nst = 0;
+    for (int l = 0; l < h->nlayers; ++l) nst += 4 * (size_t)h->L[l].cout;
+    double* st = c.take<double>(nst);
+    S.stats_region = st; S.stats_bytes = nst * sizeof(double);
+    for (int l = 0; l < h->nlayers; ++l) {
+      const int C = h->L[l].cout;
+      S.bn[l].stats = st; st += 2 * C;
+      S.bn[l].bsums = st; st += 2 * C;
+      S.bn[l].scale = c.take<float>(C); S.bn[l].shift = c.take<float>(C);
+      S.bn[l].mean = c.take<float>(C); S.bn[l].invstd = c.take<float>(C);
+    }
+  }
+  const size_t big = (size_t)B * H * W * 64;
+  h->gP = c.take<float>(big);
+  h->gQ = c.take<float>(big);
+  h->partial_floats = (size_t)1024 * 9 * 4096;
+  h->partial = c.take<float>(h->partial_floats);
+  h->accum = c.take<StepAccum>(1);
+  return align_up(c.off, 256);
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling (bench.py roofline leg): hipEvents around the tagged kernel family
+// ------------------------------------------------------------------------------------------------
+struct ProfScope {
+  ssp_handle* h; hipStream_t st; bool on;
+  ProfScope(ssp_handle* h_, int family, hipStream_t s, double flops, double bytes) : h(h_), st(s), on(false) {
+    if (h && h->prof_family == family && h->ev_used + 2 <= h->ev_pool.size()) {
+      on = true;
+      (void)hipEventRecord(h->ev_pool[h->ev_used], st);
+      h->prof_flops += flops; h->prof_bytes += bytes; h->prof_launches += 1;
+    }
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(h->ev_pool[h->ev_used + 1], st); h->ev_used += 2; }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+template <int KS, int IN_MODE, int SH, int SW>
+static int launch_conv_t(const ConvArgs& a, int nblocks, hipStream_t st) {
+  using G = ConvGeom<KS, SH, SW>;
+  static bool attr_set = false;
+  auto kern = conv_mfma_kernel<KS, IN_MODE, SH, SW>;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+struct ConvCall {
+  const float* in; int in_cs, in_co, cin;
+  const float* wpk; const float* bias;
+  float* out; int out_cs, out_co, cout;
+  const float* in_scale; const float* in_shift; double* stats;
+  int N, H, W, ks, in_mode, nchunks, ncob, accumulate;
+};
+
+static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int prof_family = 0) {
+  ConvArgs a;
+  a.in = c.in; a.wpk = c.wpk; a.bias = c.bias; a.out = c.out; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
+  a.stats = c.stats; a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
+  a.Cout = c.cout; a.out_cs = c.out_cs; a.out_co = c.out_co; a.nchunks = c.nchunks; a.ncob = c.ncob;
+  a.accumulate = c.accumulate;
+  const bool wide = (c.W % 32) == 0;
+  const int TH = wide ? 8 : 32, TW = wide ? 32 : 8;
+  a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
+  const int nblocks = c.N * a.tiles_x * a.tiles_y * c.ncob;
+  const double flops = 2.0 * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
+  const double bytes = 4.0 * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
+  int fam = prof_family;
+  if (prof_family == SSP_PROF_CONV3X3_FWD && h && h->prof_family == SSP_PROF_CONV_BIG_FWD && c.H * c.W >= 240 * 320 &&
+      c.cin == 64)
+    fam = SSP_PROF_CONV_BIG_FWD;
+  ProfScope ps(h, fam, st, flops, bytes);
+#define CONV_CASE(KS_, M_)                                                          \
+  if (c.ks == KS_ && c.in_mode == M_) {                                             \
+    return wide ? launch_conv_t<KS_, M_, 1, 32>(a, nblocks, st) : launch_conv_t<KS_, M_, 4, 8>(a, nblocks, st); \
+  }
+  CONV_CASE(3, 0) CONV_CASE(3, 1) CONV_CASE(3, 2) CONV_CASE(1, 0) CONV_CASE(1, 1)
+#undef CONV_CASE
+  return fail(-3, "unsupported conv variant ks=%d in_mode=%d", c.ks, c.in_mode);
+}
+
+template <int KS, int IN_MODE, int SH, int SW>
+static int launch_wgrad_t(const WgradArgs& a, int nblocks, hipStream_t st) {
+  using G = WgradGeom<KS, SH, SW>;
+  static bool attr_set = false;
+  auto kern = wgrad_mfma_kernel<KS, IN_MODE, SH, SW>;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+struct WgradCall {
+  const float* in; int in_cs, in_co, cin;
+  const float* dout; int dout_cs, dout_co, cout;
+  const float* in_scale; const float* in_shift;
+  float* dw;  // OIHW gradient, accumulated
+  int N, H, W, ks, in_mode;
+};
+
+static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_t partial_floats, int n_cu,
+                        hipStream_t st) {
+  WgradArgs a;
+  a.in = c.in; a.dout = c.dout; a.partial = partial; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
+  a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
+  a.Cout = c.cout; a.dout_cs = c.dout_cs; a.dout_co = c.dout_co;
+  const bool wide = (c.W % 32) == 0;
+  const int TH = wide ? 4 : 16, TW = wide ? 32 : 8;
+  a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
+  a.ntiles = c.N * a.tiles_x * a.tiles_y;
+  a.ncib = cdiv(c.cin, 64); a.ncob = cdiv(c.cout, 64);
+  const int pairs = a.ncib * a.ncob;
+  const int taps = c.ks * c.ks;
+  int nsplit = (2 * n_cu) / pairs;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  while ((size_t)pairs * nsplit * taps * 4096 > partial_floats && nsplit > 1) --nsplit;
+  if ((size_t)pairs * nsplit * taps * 4096 > partial_floats) return fail(-4, "wgrad scratch too small");
+  a.nsplit = nsplit;
+  const int nblocks = pairs * nsplit;
+  {
+    const double flops = 2.0 * c.N * c.H * c.W * (double)c.cin * c.cout * taps;
+    const double bytes = 4.0 * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
+    ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes);
+#define WG_CASE(KS_, M_)                                                              \
+  if (c.ks == KS_ && c.in_mode == M_) {                                               \
+    CHK((wide ? launch_wgrad_t<KS_, M_, 1, 32>(a, nblocks, st) : launch_wgrad_t<KS_, M_, 4, 8>(a, nblocks, st))); \
+  } else
+    WG_CASE(3, 0) WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(1, 0) WG_CASE(1, 1)
+    return fail(-3, "unsupported wgrad variant ks=%d in_mode=%d", c.ks, c.in_mode);
+#undef WG_CASE
+  }
+  const int total = c.cout * c.cin * taps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, partial, c.dw, c.cin, c.cout, c.ks,
+                     a.ncob, nsplit);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, hipStream_t st) {
+  const int taps = ks * ks;
+  const int conv_cin = tf ? cout_w : cin_w, conv_cout = tf ? cin_w : cout_w;
+  const int nchunks = cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
+  const int total = ncob * nchunks * taps * CK * NB;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, ks, tf,
+                     nchunks, 0, 0, ncob, nchunks);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <bool RELU, bool POOL>
+static int launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
+  const int nq = (a.C + 3) / 4, rows = 256 / nq;
+  const long npix = (long)a.N * (POOL ? a.H / 2 : a.H) * (POOL ? a.W / 2 : a.W);
+  int nb = cdiv(npix, rows);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb), dim3(256), 0, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* ssp_last_error(void) { return g_err.c_str(); }
+
+int ssp_create(const ssp_config* cfg, ssp_handle** out) {
+  if (!cfg || !out) return fail(-1, "null argument");
+  if (cfg->arch != SSP_ARCH_GAUSS2 && cfg->arch != SSP_ARCH_GAUSS2_SSMALL) return fail(-1, "unknown arch %d", cfg->arch);
+  if (cfg->height % 8 || cfg->width % 8 || cfg->height <= 0 || cfg->width <= 0)
+    return fail(-1, "height/width must be positive multiples of 8 (got %dx%d)", cfg->height, cfg->width);
+  if (cfg->max_batch < 1 || cfg->max_batch > 64) return fail(-1, "max_batch must be in 1..64");
+  if (cfg->arch == SSP_ARCH_GAUSS2_SSMALL && cfg->n_classes > 160) return fail(-1, "n_classes must be <= 160");
+  ssp_handle* h = new ssp_handle();
+  h->cfg = *cfg;
+  if (h->cfg.n_classes <= 0) h->cfg.n_classes = 133;
+  if (h->cfg.n_match <= 0) h->cfg.n_match = 1000;
+  if (h->cfg.n_non <= 0) h->cfg.n_non = 100;
+  build_layers(h);
+  h->bound = false;
+  h->ws_bytes = carve(h, nullptr);
+  h->prof_family = 0; h->ev_used = 0; h->prof_flops = h->prof_bytes = 0; h->prof_launches = 0;
+  h->n_cu = 256;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    h->n_cu = prop.multiProcessorCount;
+  *out = h;
+  return 0;
+}
+
+void ssp_destroy(ssp_handle* h) {
+  if (!h) return;
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  delete h;
+}
+
+size_t ssp_param_count(const ssp_handle* h) { return h ? h->n_params : 0; }
+size_t ssp_bn_channel_count(const ssp_handle* h) { return h ? h->n_bn_ch : 0; }
+int ssp_bn_layer_count(const ssp_handle* h) { return h ? h->n_bn : 0; }
+size_t ssp_workspace_bytes(const ssp_handle* h) { return h ? h->ws_bytes : 0; }
+
+int ssp_bind(ssp_handle* h, const ssp_buffers* b, void* stream) {
+  if (!h || !b) return fail(-1, "null argument");
+  if (!b->params_dev || !b->bn_running_dev || !b->workspace_dev) return fail(-1, "params, bn_running and workspace are required");
+  if (b->workspace_bytes < h->ws_bytes) return fail(-1, "workspace too small: %zu < %zu", b->workspace_bytes, h->ws_bytes);
+  h->buf = *b;
+  carve(h, b->workspace_dev);
+  // padding channels (65->80, n_classes->sout_cs) must read as zero forever: clear everything once
+  HIPCHK(hipMemsetAsync(b->workspace_dev, 0, h->ws_bytes, (hipStream_t)stream));
+  h->bound = true;
+  return 0;
+}
+
+int ssp_zero_grad(ssp_handle* h, void* stream) {
+  if (!h || !h->bound || !h->buf.grads_dev) return fail(-1, "handle not bound with a gradient buffer");
+  HIPCHK(hipMemsetAsync(h->buf.grads_dev, 0, (h->n_params + 3) * sizeof(float), (hipStream_t)stream));
+  return 0;
+}
+
+int ssp_profile_enable(ssp_handle* h, int family) {
+  if (!h) return fail(-1, "null handle");
+  h->prof_family = family; h->ev_used = 0; h->prof_flops = h->prof_bytes = 0; h->prof_launches = 0;
+  if (family != 0 && h->ev_pool.empty()) {
+    h->ev_pool.resize(8192);
+    for (auto& e : h->ev_pool) HIPCHK(hipEventCreate(&e));
+  }
+  return 0;
+}
+
+int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops, double* bytes) {
+  if (!h) return fail(-1, "null handle");
+  double tot = 0;
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float t = 0;
+    HIPCHK(hipEventSynchronize(h->ev_pool[i + 1]));
+    HIPCHK(hipEventElapsedTime(&t, h->ev_pool[i], h->ev_pool[i + 1]));
+    tot += t;
+  }
+  if (ms) *ms = tot;
+  if (launches) *launches = h->prof_launches;
+  if (flops) *flops = h->prof_flops;
+  if (bytes) *bytes = h->prof_bytes;
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// forward / backward of one activation slot
+// ------------------------------------------------------------------------------------------------
+static const float* P(const ssp_handle* h, size_t off) { return h->buf.params_dev + off; }
+static float* Gd(const ssp_handle* h, size_t off) { return h->buf.grads_dev + off; }
+
+static int bn_finalize(ssp_handle* h, Slot& S, int l, double count, int train, hipStream_t st) {
+  const LayerDesc& d = h->L[l];
+  BnLayer b;
+  b.stats = S.bn[l].stats; b.gamma = P(h, d.g_off); b.beta = P(h, d.be_off);
+  b.running_mean = h->buf.bn_running_dev + d.bn_ch_off;
+  b.running_var = h->buf.bn_running_dev + h->n_bn_ch + d.bn_ch_off;
+  b.scale = S.bn[l].scale; b.shift = S.bn[l].shift; b.mean = S.bn[l].mean; b.invstd = S.bn[l].invstd;
+  b.C = d.cout; b.count = count;
+  int64_t* nbt = h->buf.num_batches_tracked_dev ? h->buf.num_batches_tracked_dev + d.bn_index : nullptr;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, b, train, nbt);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
+  for (int l = 1; l < h->nlayers; ++l) {
+    const LayerDesc& d = h->L[l];
+    CHK(launch_pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, st));
+    if (with_bwd) CHK(launch_pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, st));
+  }
+  return 0;
+}
+
+static int conv_layer_fwd(ssp_handle* h, Slot& S, int l, int src, int N, int H, int W, int in_mode, int train,
+                          hipStream_t st) {
+  const LayerDesc& d = h->L[l];
+  ConvCall c;
+  c.in = S.Y[src]; c.in_cs = S.y_cs[src]; c.in_co = S.y_co[src]; c.cin = d.cin;
+  c.wpk = h->wpk_fwd + d.pk_fwd; c.bias = P(h, d.b_off);
+  c.out = S.Y[l]; c.out_cs = S.y_cs[l]; c.out_co = S.y_co[l]; c.cout = d.cout;
+  c.in_scale = S.bn[src].scale; c.in_shift = S.bn[src].shift;
+  c.stats = (d.bn && train) ? S.bn[l].stats : nullptr;
+  c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = in_mode; c.nchunks = d.nchunks_fwd; c.ncob = d.ncob_fwd;
+  c.accumulate = 0;
+  CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
+  if (d.bn) CHK(bn_finalize(h, S, l, (double)N * H * W, train, st));
+  return 0;
+}
+
+static int run_forward(ssp_handle* h, int slot, const float* x, int N, int H, int W, int train, bool for_backward,
+                       hipStream_t st) {
+  Slot& S = h->slot[slot];
+  S.N = N; S.H = H; S.W = W; S.x = x;
+  HIPCHK(hipMemsetAsync(S.stats_region, 0, S.stats_bytes, st));
+  CHK(pack_all(h, for_backward, st));
+  // layer 0: direct 1->64 conv
+  {
+    const LayerDesc& d = h->L[0];
+    const long npix = (long)N * H * W;
+    hipLaunchKernelGGL(conv0_direct_kernel, dim3(cdiv(npix, 16 * C0_ITERS)), dim3(256), 0, st, x, P(h, d.w_off),
+                       P(h, d.b_off), S.Y[0], train ? S.bn[0].stats : nullptr, N, H, W);
+    HIPCHK(hipGetLastError());
+    CHK(bn_finalize(h, S, 0, (double)npix, train, st));
+  }
+  for (int l = 1; l < 8; ++l) {
+    int lh, lw; layer_res(l, H, W, lh, lw);
+    CHK(conv_layer_fwd(h, S, l, l - 1, N, lh, lw, layer_in_mode(l), train, st));
+  }
+  const int Hc = H / 8, Wc = W / 8;
+  CHK(conv_layer_fwd(h, S, L_PA, 7, N, Hc, Wc, 1, train, st));
+  CHK(conv_layer_fwd(h, S, L_DA, 7, N, Hc, Wc, 1, train, st));
+  CHK(conv_layer_fwd(h, S, L_PB, L_PA, N, Hc, Wc, 1, train, st));
+  CHK(conv_layer_fwd(h, S, L_DB, L_DA, N, Hc, Wc, 1, train, st));
+  if (h->nheads == 3) {
+    CHK(conv_layer_fwd(h, S, L_DS, 7, N, Hc, Wc, 1, train, st));
+    CHK(conv_layer_fwd(h, S, L_SOUT, L_DS, N, Hc, Wc, 1, train, st));
+  }
+  const int ncells = N * Hc * Wc;
+  hipLaunchKernelGGL(desc_normalize_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_DB], S.bn[L_DB].scale,
+                     S.bn[L_DB].shift, S.desc, S.inv_norm, ncells, S.y_cs[L_DB], S.y_co[L_DB]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// backward of a conv+BN(+ReLU) layer: dOut (grad wrt the activated [pooled] output, in `dout`) ->
+// parameter gradients and, unless l == 0, the gradient wrt the layer's (activated) input in `din`.
+static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* dout, int d_cs, int d_co, bool relu,
+                          bool pool_after, float* dy, int dy_cs, int dy_co, float* din, int din_cs, int din_co,
+                          int din_accumulate, int N, int H, int W, int in_mode, hipStream_t st) {
+  const LayerDesc& d = h->L[l];
+  if (d.bn) {
+    BnBwdArgs a;
+    a.y = S.Y[l]; a.dout = dout; a.dy = dy; a.scale = S.bn[l].scale; a.shift = S.bn[l].shift; a.mean = S.bn[l].mean;
+    a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums; a.dbias = Gd(h, d.b_off);
+    a.N = N; a.H = H; a.W = W; a.C = d.cout; a.y_cs = S.y_cs[l]; a.y_co = S.y_co[l]; a.d_cs = d_cs; a.d_co = d_co;
+    a.dy_cs = dy_cs; a.dy_co = dy_co; a.count = (double)N * H * W;
+    if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, st)));
+    else if (relu) CHK((launch_bn_bwd<true, false>(a, st)));
+    else CHK((launch_bn_bwd<false, false>(a, st)));
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, S.bn[l].bsums, Gd(h, d.g_off),
+                       Gd(h, d.be_off), d.cout);
+    HIPCHK(hipGetLastError());
+  }
+  if (l == 0) {
+    const long npix = (long)N * H * W;
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(cdiv(npix, 16 * C0_ITERS)), dim3(256), 0, st, S.x, dy, Gd(h, d.w_off), N,
+                       H, W);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  WgradCall w;
+  w.in = S.Y[src]; w.in_cs = S.y_cs[src]; w.in_co = S.y_co[src]; w.cin = d.cin;
+  w.dout = dy; w.dout_cs = dy_cs; w.dout_co = dy_co; w.cout = d.cout;
+  w.in_scale = S.bn[src].scale; w.in_shift = S.bn[src].shift; w.dw = Gd(h, d.w_off);
+  w.N = N; w.H = H; w.W = W; w.ks = d.ks; w.in_mode = in_mode;
+  CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
+  ConvCall c;
+  c.in = dy; c.in_cs = dy_cs; c.in_co = dy_co; c.cin = (int)align_up(d.cout, 4);
+  c.wpk = h->wpk_bwd + d.pk_bwd; c.bias = nullptr;
+  c.out = din; c.out_cs = din_cs; c.out_co = din_co; c.cout = d.cin;
+  c.in_scale = nullptr; c.in_shift = nullptr; c.stats = nullptr;
+  c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 0; c.nchunks = d.nchunks_bwd; c.ncob = d.ncob_bwd;
+  c.accumulate = din_accumulate;
+  CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_DGRAD : 0));
+  return 0;
+}
+
+// dsemi: [cells][80] grad wrt semi (post bnPb); draw_desc: [cells][256] grad wrt bnDb output (pre-normalisation);
+// dsout: [cells][sout_cs] grad wrt convSout output (ssmall) or nullptr.
+static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float* draw_desc, const float* dsout,
+                        hipStream_t st) {
+  Slot& S = h->slot[slot];
+  const int N = S.N, H = S.H, W = S.W, Hc = H / 8, Wc = W / 8;
+  const int hcs = 256 * h->nheads;
+  // zero the backward fp64 sums (interleaved with the forward stats: clear only the bsums halves)
+  for (int l = 0; l < h->nlayers; ++l) HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * h->L[l].cout * sizeof(double), st));
+  float* dHeadsAct = h->gP;  // grad wrt relu(bn(conv{Pa,Da,DS})) [cells][hcs]
+  float* dYtmp = h->gQ;
+  const bool has_semi = dsemi != nullptr, has_desc = draw_desc != nullptr, has_sem = dsout != nullptr && h->nheads == 3;
+  if (!has_semi || !has_desc || (h->nheads == 3 && !has_sem))
+    HIPCHK(hipMemsetAsync(dHeadsAct, 0, (size_t)N * Hc * Wc * hcs * sizeof(float), st));
+  // 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only)
+  if (has_semi)
+    CHK(layer_backward(h, S, L_PB, L_PA, dsemi, 80, 0, false, false, dYtmp, 80, 0, dHeadsAct, hcs, 0, 0, N, Hc, Wc, 1, st));
+  if (has_desc)
+    CHK(layer_backward(h, S, L_DB, L_DA, draw_desc, 256, 0, false, false, dYtmp, 256, 0, dHeadsAct, hcs, 256, 0, N, Hc, Wc, 1, st));
+  if (has_sem) {
+    const LayerDesc& d = h->L[L_SOUT];
+    const int ncells = N * Hc * Wc;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, 64)), dim3(256), 0, st, dsout, Gd(h, d.b_off), ncells, d.cout,
+                       h->sout_cs);
+    HIPCHK(hipGetLastError());
+    CHK(layer_backward(h, S, L_SOUT, L_DS, nullptr, 0, 0, false, false, const_cast<float*>(dsout), h->sout_cs, 0,
+                       dHeadsAct, hcs, 512, 0, N, Hc, Wc, 1, st));
+  }
+  // 3x3 heads: BN+ReLU backward into dYtmp [cells][hcs], then wgrad + dgrad (accumulated into dOut7)
+  float* dOut = h->gP;
+  {
+    const int heads[3] = {L_PA, L_DA, L_DS};
+    for (int k = 0; k < h->nheads; ++k) {
+      const int l = heads[k];
+      const LayerDesc& d = h->L[l];
+      BnBwdArgs a;
+      a.y = S.Y[l]; a.dout = dHeadsAct; a.dy = dYtmp; a.scale = S.bn[l].scale; a.shift = S.bn[l].shift;
+      a.mean = S.bn[l].mean; a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums;
+      a.dbias = Gd(h, d.b_off); a.N = N; a.H = Hc; a.W = Wc; a.C = 256; a.y_cs = hcs; a.y_co = 256 * k; a.d_cs = hcs;
+      a.d_co = 256 * k; a.dy_cs = hcs; a.dy_co = 256 * k; a.count = (double)N * Hc * Wc;
+      CHK((launch_bn_bwd<true, false>(a, st)));
+      hipLaunchKernelGGL(bn_param_grad_kernel, dim3(4), dim3(64), 0, st, S.bn[l].bsums, Gd(h, d.g_off), Gd(h, d.be_off), 256);
+      HIPCHK(hipGetLastError());
+    }
+    for (int k = 0; k < h->nheads; ++k) {
+      const int l = heads[k];
+      const LayerDesc& d = h->L[l];
+      WgradCall w;
+      w.in = S.Y[7]; w.in_cs = 128; w.in_co = 0; w.cin = 128; w.dout = dYtmp; w.dout_cs = hcs; w.dout_co = 256 * k;
+      w.cout = 256; w.in_scale = S.bn[7].scale; w.in_shift = S.bn[7].shift; w.dw = Gd(h, d.w_off);
+      w.N = N; w.H = Hc; w.W = Wc; w.ks = 3; w.in_mode = 1;
+      CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
+      ConvCall c;
+      c.in = dYtmp; c.in_cs = hcs; c.in_co = 256 * k; c.cin = 256; c.wpk = h->wpk_bwd + d.pk_bwd; c.bias = nullptr;
+      c.out = dOut; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
+      c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = d.nchunks_bwd;
+      c.ncob = d.ncob_bwd; c.accumulate = (k > 0);
+      CHK(launch_conv(h, c, st, SSP_PROF_CONV3X3_DGRAD));
+    }
+  }
+  // encoder
+  for (int l = 7; l >= 0; --l) {
+    int lh, lw; layer_res(l, H, W, lh, lw);
+    const bool pool_after = (l == 1 || l == 3 || l == 5);
+    const int C = h->L[l].cout;
+    const int cin = h->L[l].cin;
+    CHK(layer_backward(h, S, l, l - 1, dOut, C, 0, true, pool_after, dYtmp, C, 0, dOut, cin, 0, 0, N, lh, lw,
+                       l > 0 ? layer_in_mode(l) : 0, st));
+  }
+  return 0;
+}
+
+extern "C" {
+
+int ssp_forward(ssp_handle* h, int slot, const float* x_dev, int n, int height, int width, int train, float* semi_dev,
+                float* desc_dev, float* sem_dev, void* stream) {
+  if (!h || !h->bound) return fail(-1, "handle not bound");
+  if (slot < 0 || slot > 1) return fail(-1, "slot must be 0 or 1");
+  if (n < 1 || n > h->cfg.max_batch || height > h->cfg.height || width > h->cfg.width || height % 8 || width % 8)
+    return fail(-1, "forward shape [%d,1,%d,%d] exceeds the configured maximum or is not a multiple of 8", n, height, width);
+  if ((size_t)height * width != (size_t)h->cfg.height * h->cfg.width && (size_t)n * height * width > (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width)
+    return fail(-1, "forward shape too large");
+  hipStream_t st = (hipStream_t)stream;
+  CHK(run_forward(h, slot, x_dev, n, height, width, train, h->buf.grads_dev != nullptr, st));
+  Slot& S = h->slot[slot];
+  const int HW = (height / 8) * (width / 8);
+  if (semi_dev) {
+    const long tot = (long)n * 65 * HW;
+    hipLaunchKernelGGL(nhwc_affine_to_nchw_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
+                       S.bn[L_PB].shift, semi_dev, n, HW, 65, 80, 0);
+  }
+  if (desc_dev) {
+    const long tot = (long)n * 256 * HW;
+    hipLaunchKernelGGL(nhwc_affine_to_nchw_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, S.desc, (const float*)nullptr,
+                       (const float*)nullptr, desc_dev, n, HW, 256, 256, 0);
+  }
+  if (sem_dev) {
+    if (h->nheads != 3) return fail(-1, "sem output requested from a model without a segmentation head");
+    const long tot = (long)n * h->cfg.n_classes * height * width;
+    hipLaunchKernelGGL(sem_upsample_nchw_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, S.Y[L_SOUT], sem_dev, n,
+                       height / 8, width / 8, height, width, h->cfg.n_classes, h->sout_cs);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_backward(ssp_handle* h, int slot, const float* dsemi_dev, const float* ddesc_dev, const float* dsem_dev,
+                 void* stream) {
+  if (!h || !h->bound || !h->buf.grads_dev) return fail(-1, "handle not bound with a gradient buffer");
+  if (slot < 0 || slot > 1) return fail(-1, "slot must be 0 or 1");
+  hipStream_t st = (hipStream_t)stream;
+  Slot& S = h->slot[slot];
+  const int N = S.N, Hc = S.H / 8, Wc = S.W / 8, HW = Hc * Wc, ncells = N * HW;
+  const float *ds = nullptr, *dd = nullptr, *dso = nullptr;
+  if (dsemi_dev) {
+    const long tot = (long)N * 65 * HW;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, dsemi_dev, S.dsemi, N, HW, 65, 80, 0);
+    ds = S.dsemi;
+  }
+  if (ddesc_dev) {
+    const long tot = (long)N * 256 * HW;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, ddesc_dev, S.ddesc, N, HW, 256, 256, 0);
+    hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.desc, S.inv_norm, S.ddesc, ncells);
+    dd = S.ddesc;
+  }
+  if (dsem_dev) {
+    if (h->nheads != 3) return fail(-1, "dsem given for a model without a segmentation head");
+    HIPCHK(hipMemsetAsync(S.dsout, 0, (size_t)ncells * h->sout_cs * sizeof(float), st));
+    const long tot = (long)N * h->cfg.n_classes * Hc * Wc;
+    hipLaunchKernelGGL(sem_upsample_bwd_nchw_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, dsem_dev, S.dsout, N, Hc, Wc,
+                       S.H, S.W, h->cfg.n_classes, h->sout_cs);
+    dso = S.dsout;
+  }
+  HIPCHK(hipGetLastError());
+  return run_backward(h, slot, ds, dd, dso, st);
+}
+
+int ssp_adam_step(ssp_handle* h, float lr, int step, void* stream) {
+  if (!h || !h->bound || !h->buf.grads_dev || !h->buf.adam_m_dev || !h->buf.adam_v_dev)
+    return fail(-1, "handle not bound with gradient and Adam state buffers");
+  if (step < 1) return fail(-1, "Adam step index starts at 1");
+  const long n = (long)h->n_params + 3;
+  const float bc1 = 1.f - powf(0.9f, (float)step);
+  const float bc2 = 1.f - powf(0.999f, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, h->buf.params_dev,
+                     h->buf.grads_dev, h->buf.adam_m_dev, h->buf.adam_v_dev, n, lr, bc1, sqrtf(bc2));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, void* stream) {
+  if (!h || !h->bound) return fail(-1, "handle not bound");
+  if (!in || !scalars_dev) return fail(-1, "null argument");
+  if (in->train && !h->buf.grads_dev) return fail(-1, "train step needs a gradient buffer");
+  const int B = in->batch, H = h->cfg.height, W = h->cfg.width, Hc = H / 8, Wc = W / 8;
+  if (B < 1 || B > h->cfg.max_batch) return fail(-1, "batch %d out of range", B);
+  const bool semantic = h->nheads == 3;
+  if (semantic && (!in->semantic_dev || !in->warped_semantic_dev)) return fail(-1, "semantic labels required for the ssmall model");
+  const bool use_desc = in->lambda_loss > 0.f;
+  if (use_desc && (!in->match_a_dev || !in->match_b_dev || !in->nonmatch_b_dev))
+    return fail(-1, "sparse-loss indices required (call ssp_sample_indices or pass the reference's indices)");
+  hipStream_t st = (hipStream_t)stream;
+  const float* eta = h->buf.params_dev + h->n_params;
+  const int ncells = B * Hc * Wc;
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
+                     in->lamda_d, (int)semantic);
+  CHK(run_forward(h, 0, in->image_dev, B, H, W, 1, in->train != 0, st));
+  CHK(run_forward(h, 1, in->warped_image_dev, B, H, W, 1, in->train != 0, st));
+  const float* masks[2] = {in->valid_mask_dev, in->warped_valid_mask_dev};
+  const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
+  const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
+  for (int v = 0; v < 2; ++v) {
+    Slot& S = h->slot[v];
+    hipLaunchKernelGGL(cell_mask_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, masks[v], S.cellmask,
+                       &h->accum->mask_cnt[v], B, H, W);
+  }
+  for (int v = 0; v < 2; ++v) {
+    Slot& S = h->slot[v];
+    hipLaunchKernelGGL(detector_loss_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
+                       S.bn[L_PB].shift, labels[v], S.cellmask, in->train ? S.dsemi : nullptr, h->accum, v, B, H, W, 80);
+  }
+  HIPCHK(hipGetLastError());
+  if (semantic) {
+    for (int v = 0; v < 2; ++v) {
+      Slot& S = h->slot[v];
+      const long npx = (long)B * H * W;
+      hipLaunchKernelGGL((sem_ce_kernel<false>), dim3(cdiv(npx, 4)), dim3(256), 0, st, S.Y[L_SOUT], sems[v], (float*)nullptr,
+                         h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
+    }
+    if (in->train) {
+      for (int v = 0; v < 2; ++v) {
+        Slot& S = h->slot[v];
+        const long npx = (long)B * H * W;
+        HIPCHK(hipMemsetAsync(S.dsout, 0, (size_t)ncells * h->sout_cs * sizeof(float), st));
+        hipLaunchKernelGGL((sem_ce_kernel<true>), dim3(cdiv(npx, 4)), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
+                           h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
+      }
+    }
+    HIPCHK(hipGetLastError());
+  }
+  if (use_desc) {
+    const int nw = B * h->cfg.n_match;
+    Slot &A = h->slot[0], &Bs = h->slot[1];
+    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+                       in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
+    hipLaunchKernelGGL((desc_nonmatch_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc,
+                       in->match_a_dev, in->nonmatch_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc,
+                       h->cfg.n_match, h->cfg.n_non);
+    if (in->train) {
+      HIPCHK(hipMemsetAsync(A.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(Bs.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
+      hipLaunchKernelGGL((desc_match_kernel<true>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+                         in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
+      hipLaunchKernelGGL((desc_nonmatch_kernel<true>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc,
+                         in->match_a_dev, in->nonmatch_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
+                         h->cfg.n_non);
+      for (int v = 0; v < 2; ++v) {
+        Slot& S = h->slot[v];
+        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.desc, S.inv_norm, S.ddesc, ncells);
+      }
+    }
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, st, h->accum, eta,
+                     in->train ? h->buf.grads_dev + h->n_params : (float*)nullptr, scalars_dev, B, h->cfg.n_match,
+                     in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train);
+  HIPCHK(hipGetLastError());
+  if (in->train) {
+    for (int v = 0; v < 2; ++v) {
+      Slot& S = h->slot[v];
+      CHK(run_backward(h, v, S.dsemi, use_desc ? S.ddesc : nullptr, semantic ? S.dsout : nullptr, st));
+    }
+  }
+  return 0;
+}
+
+int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
+                       int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream) {
+  if (!h) return fail(-1, "null handle");
+  if (batch < 1 || batch > 64) return fail(-1, "batch out of range");
+  const int Hc = h->cfg.height / 8, Wc = h->cfg.width / 8;
+  if (Hc * Wc > SAMPLER_MAX_CELLS) return fail(-1, "sampler supports at most %d cells", SAMPLER_MAX_CELLS);
+  if (h->cfg.n_match > SAMPLER_MAX_CELLS) return fail(-1, "n_match too large for the device sampler");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sample_matches_kernel, dim3(batch), dim3(1024), 0, st, homographies_dev, seed, match_a_dev,
+                     match_b_dev, Hc, Wc, h->cfg.n_match);
+  const long tot = (long)batch * h->cfg.n_match * h->cfg.n_non;
+  hipLaunchKernelGGL(sample_nonmatches_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, seed, nonmatch_b_dev, tot, Hc, Wc);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- operator-level entry points ------------------------------------------------------------------
+int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_dev, float* out_dev, int n, int hh, int w,
+                int cin, int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
+                double* stats_dev, int transpose_flip, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  // with transpose_flip the weight tensor is [cin_conv... see header]: w is OIHW with O = (tf ? cin : cout)
+  const int taps = ksize * ksize;
+  const int nchunks = cdiv(cin, CK), ncob = cdiv(cout, NB);
+  const size_t need = (size_t)ncob * nchunks * taps * CK * NB * sizeof(float);
+  if (workspace_bytes < need) return fail(-4, "ssp_op_conv workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  float* wpk = reinterpret_cast<float*>(workspace_dev);
+  if (!transpose_flip) CHK(launch_pack(w_oihw_dev, wpk, cout, cin, ksize, 0, st));
+  else CHK(launch_pack(w_oihw_dev, wpk, cin, cout, ksize, 1, st));
+  ConvCall c;
+  c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.wpk = wpk; c.bias = bias_dev; c.out = out_dev; c.out_cs = cout;
+  c.out_co = 0; c.cout = cout; c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.stats = stats_dev; c.N = n;
+  c.H = hh; c.W = w; c.ks = ksize; c.in_mode = in_mode; c.nchunks = nchunks; c.ncob = ncob; c.accumulate = 0;
+  return launch_conv(nullptr, c, st, 0);
+}
+
+int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw_dev, int n, int hh, int w, int cin,
+                      int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* stream) {
+  WgradCall c;
+  c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.dout = dout_dev; c.dout_cs = cout; c.dout_co = 0; c.cout = cout;
+  c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.dw = dw_oihw_dev; c.N = n; c.H = hh; c.W = w; c.ks = ksize;
+  c.in_mode = in_mode;
+  int n_cu = 256;
+  return launch_wgrad(nullptr, c, reinterpret_cast<float*>(workspace_dev), workspace_bytes / sizeof(float), n_cu,
+                      (hipStream_t)stream);
+}
+
+
+int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,
+                       const int32_t* match_b_dev, const int32_t* nonmatch_b_dev, int b, int hc, int wc, int n_match,
+                       int n_non, float* out2_dev, void* stream) {
+  if (b < 1 || b > 64) return fail(-1, "batch out of range");
+  hipStream_t st = (hipStream_t)stream;
+  StepAccum* acc = nullptr;
+  HIPCHK(hipMallocAsync((void**)&acc, sizeof(StepAccum), st));
+  HIPCHK(hipMemsetAsync(acc, 0, sizeof(StepAccum), st));
+  const int nw = b * n_match;
+  hipLaunchKernelGGL((desc_match_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
+                     match_a_dev, match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match);
+  hipLaunchKernelGGL((desc_nonmatch_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, desc_a_nhwc_dev,
+                     desc_b_nhwc_dev, match_a_dev, nonmatch_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc,
+                     n_match, n_non);
+  hipLaunchKernelGGL(sparse_loss_means_kernel, dim3(1), dim3(1), 0, st, acc, out2_dev, b, n_match);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipFreeAsync(acc, st));
+  return 0;
+}
+
+int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* target_dev, float* cellmask_dev, int b,
+                  int hh, int w, void* stream) {
+  if (hh % 8 || w % 8) return fail(-1, "H and W must be multiples of 8");
+  hipStream_t st = (hipStream_t)stream;
+  const int ncells = b * (hh / 8) * (w / 8);
+  if (labels2d_dev && target_dev)
+    hipLaunchKernelGGL(labels2dto3d_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, labels2d_dev, target_dev, b, hh, w);
+  if (mask2d_dev && cellmask_dev) {
+    double* cnt = nullptr;
+    HIPCHK(hipMallocAsync((void**)&cnt, sizeof(double), st));
+    hipLaunchKernelGGL(cell_mask_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, mask2d_dev, cellmask_dev, cnt, b, hh, w);
+    HIPCHK(hipFreeAsync(cnt, st));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

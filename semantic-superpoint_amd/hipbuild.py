@@ -1,0 +1,42 @@
+"""Builds the HIP library in-tree (semantic-superpoint_amd/csrc/libssp_hip.so) for gfx950.
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libssp_hip.so")
+SOURCES = ["ssp.hip", "conv_mfma.hip.h", "bn_kernels.hip.h", "loss_kernels.hip.h", "sem_kernels.hip.h",
+           os.path.join("..", "..", "include", "ssp_hip.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+
+
+def hipcc_path():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.isabs(p) and os.path.exists(p) or not os.path.isabs(p)):
+            return p
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ssp.hip -> csrc/libssp_hip.so (gfx950). Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+           "ssp.hip", "-o", "libssp_hip.so"]
+    r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 or verbose:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed (%d): %s" % (r.returncode, " ".join(cmd)))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

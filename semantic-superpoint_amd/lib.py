@@ -1,0 +1,387 @@
+"""ctypes binding of include/ssp_hip.h plus `Engine`, the owner of the torch-allocated device buffers.
+
+PyTorch is plumbing here: it allocates HBM, provides the stream and (in the trainer) RCCL; every
+arithmetic step runs in csrc/libssp_hip.so.  There is NO CPU / eager fallback: if the library cannot be
+loaded or the tensors are not on a HIP device, calls raise.
+"""
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import hipbuild as _build
+
+ARCHS = {"SuperPointNet_gauss2": 0, "SuperPointNet_gauss2_ssmall": 1}
+SCALAR_NAMES = ["loss", "loss_det", "loss_det_warp", "loss_desc", "loss_sem", "loss_sem_warp", "positive_dist",
+                "negative_dist", "eta_det", "eta_desc", "eta_sem"]
+N_SCALARS = 16
+PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4}
+
+
+class SspConfig(C.Structure):
+    _fields_ = [("arch", C.c_int), ("n_classes", C.c_int), ("max_batch", C.c_int), ("height", C.c_int),
+                ("width", C.c_int), ("n_match", C.c_int), ("n_non", C.c_int)]
+
+
+class SspBuffers(C.Structure):
+    _fields_ = [("params_dev", C.c_void_p), ("grads_dev", C.c_void_p), ("adam_m_dev", C.c_void_p),
+                ("adam_v_dev", C.c_void_p), ("bn_running_dev", C.c_void_p), ("num_batches_tracked_dev", C.c_void_p),
+                ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class SspPairInputs(C.Structure):
+    _fields_ = [("batch", C.c_int), ("image_dev", C.c_void_p), ("warped_image_dev", C.c_void_p),
+                ("labels_dev", C.c_void_p), ("warped_labels_dev", C.c_void_p), ("valid_mask_dev", C.c_void_p),
+                ("warped_valid_mask_dev", C.c_void_p), ("homographies_dev", C.c_void_p), ("semantic_dev", C.c_void_p),
+                ("warped_semantic_dev", C.c_void_p), ("match_a_dev", C.c_void_p), ("match_b_dev", C.c_void_p),
+                ("nonmatch_b_dev", C.c_void_p), ("seed", C.c_uint64), ("lambda_loss", C.c_float),
+                ("lamda_d", C.c_float), ("multi_task", C.c_int), ("train", C.c_int)]
+
+
+_lib = None
+
+EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ssp_bn_channel_count",
+           "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
+           "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
+           "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss"]
+
+
+def load_library(path=None):
+    """dlopen csrc/libssp_hip.so (building it first when stale). Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.LIB
+    if not os.path.exists(path):
+        path = _build.build()
+    lib = C.CDLL(path)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    lib.ssp_last_error.restype = C.c_char_p
+    lib.ssp_create.argtypes = [C.POINTER(SspConfig), C.POINTER(vp)]
+    lib.ssp_destroy.argtypes = [vp]
+    lib.ssp_destroy.restype = None
+    for n in ("ssp_param_count", "ssp_bn_channel_count", "ssp_workspace_bytes"):
+        getattr(lib, n).argtypes = [vp]
+        getattr(lib, n).restype = C.c_size_t
+    lib.ssp_bn_layer_count.argtypes = [vp]
+    lib.ssp_bind.argtypes = [vp, C.POINTER(SspBuffers), vp]
+    lib.ssp_forward.argtypes = [vp, i, vp, i, i, i, i, vp, vp, vp, vp]
+    lib.ssp_backward.argtypes = [vp, i, vp, vp, vp, vp]
+    lib.ssp_zero_grad.argtypes = [vp, vp]
+    lib.ssp_pair_step.argtypes = [vp, C.POINTER(SspPairInputs), vp, vp]
+    lib.ssp_adam_step.argtypes = [vp, f, i, vp]
+    lib.ssp_sample_indices.argtypes = [vp, vp, i, C.c_uint64, vp, vp, vp, vp]
+    lib.ssp_profile_enable.argtypes = [vp, i]
+    lib.ssp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]
+    lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
+    lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
+    lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("libssp_hip: %s (code %d)" % (load_library().ssp_last_error().decode(), rc))
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a HIP device: the MI355X path has no CPU fallback" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter layout == reference state_dict layout
+# ------------------------------------------------------------------------------------------------
+_ENC = [("inc.conv.conv.0", "inc.conv.conv.1", 1, 64, 3), ("inc.conv.conv.3", "inc.conv.conv.4", 64, 64, 3),
+        ("down1.mpconv.1.conv.0", "down1.mpconv.1.conv.1", 64, 64, 3),
+        ("down1.mpconv.1.conv.3", "down1.mpconv.1.conv.4", 64, 64, 3),
+        ("down2.mpconv.1.conv.0", "down2.mpconv.1.conv.1", 64, 128, 3),
+        ("down2.mpconv.1.conv.3", "down2.mpconv.1.conv.4", 128, 128, 3),
+        ("down3.mpconv.1.conv.0", "down3.mpconv.1.conv.1", 128, 128, 3),
+        ("down3.mpconv.1.conv.3", "down3.mpconv.1.conv.4", 128, 128, 3)]
+_HEADS = [("convPa", "bnPa", 128, 256, 3), ("convPb", "bnPb", 256, 65, 1), ("convDa", "bnDa", 128, 256, 3),
+          ("convDb", "bnDb", 256, 256, 1)]
+
+
+def layer_table(arch, n_classes=133):
+    t = _ENC + _HEADS
+    if arch == "SuperPointNet_gauss2_ssmall":
+        t = t + [("convDS", "bnS1", 128, 256, 3), ("convSout", None, 256, n_classes, 1)]
+    elif arch != "SuperPointNet_gauss2":
+        raise KeyError(arch)
+    return t
+
+
+def param_layout(arch, n_classes=133):
+    """[(state_dict key, shape, offset)] of the flat parameter vector, net.parameters() order."""
+    out, off = [], 0
+    for conv, bn, cin, cout, k in layer_table(arch, n_classes):
+        for key, shape in ((conv + ".weight", (cout, cin, k, k)), (conv + ".bias", (cout,))):
+            out.append((key, shape, off))
+            off += int(np.prod(shape))
+        if bn is not None:
+            for key in (bn + ".weight", bn + ".bias"):
+                out.append((key, (cout,), off))
+                off += cout
+    return out, off
+
+
+def bn_layout(arch, n_classes=133):
+    """[(bn key prefix, C, channel offset)] in layer order."""
+    out, off = [], 0
+    for conv, bn, cin, cout, k in layer_table(arch, n_classes):
+        if bn is not None:
+            out.append((bn, cout, off))
+            off += cout
+    return out, off
+
+
+class Engine:
+    """One libssp handle plus its torch-owned device buffers (one per GPU / stream)."""
+
+    def __init__(self, arch, max_batch, height, width, device, n_classes=133, n_match=1000, n_non=100,
+                 with_grad=True):
+        self.lib = load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Engine needs a HIP device (got %s): no CPU fallback exists" % self.device)
+        self.arch, self.n_classes = arch, n_classes
+        self.max_batch, self.height, self.width = max_batch, height, width
+        self.n_match, self.n_non = n_match, n_non
+        cfg = SspConfig(ARCHS[arch], n_classes, max_batch, height, width, n_match, n_non)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.layout, self.n_params = param_layout(arch, n_classes)
+        self.bns, self.n_bn_ch = bn_layout(arch, n_classes)
+        assert self.n_params == self.lib.ssp_param_count(h), "parameter layout mismatch with the library"
+        assert self.n_bn_ch == self.lib.ssp_bn_channel_count(h)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.n_params + 3, **f32)
+        self.params[self.n_params:] = torch.tensor([1.0, 2.0, 1.0])  # MultiTaskLoss.eta init
+        self.grads = torch.zeros(self.n_params + 3, **f32) if with_grad else None
+        self.adam_m = torch.zeros(self.n_params + 3, **f32) if with_grad else None
+        self.adam_v = torch.zeros(self.n_params + 3, **f32) if with_grad else None
+        self.bn_running = torch.cat([torch.zeros(self.n_bn_ch, **f32), torch.ones(self.n_bn_ch, **f32)])
+        self.nbt = torch.zeros(len(self.bns), dtype=torch.int64, device=self.device)
+        self.ws_bytes = self.lib.ssp_workspace_bytes(h)
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        self.scalars = torch.zeros(N_SCALARS, **f32)
+        self.adam_t = 0
+        self.bind()
+
+    def bind(self):
+        b = SspBuffers(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                       _ptr(self.bn_running), _ptr(self.nbt), _ptr(self.workspace), self.ws_bytes)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_bind(self.h, C.byref(b), _stream()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ssp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- state ----
+    def load_state_dict(self, sd):
+        for key, shape, off in self.layout:
+            v = torch.as_tensor(np.asarray(sd[key]) if not torch.is_tensor(sd[key]) else sd[key])
+            self.params[off:off + v.numel()] = v.reshape(-1).to(self.device, torch.float32)
+        for i, (bn, c, off) in enumerate(self.bns):
+            for j, name in enumerate(("running_mean", "running_var")):
+                k = bn + "." + name
+                if k in sd:
+                    v = torch.as_tensor(np.asarray(sd[k]) if not torch.is_tensor(sd[k]) else sd[k])
+                    self.bn_running[j * self.n_bn_ch + off:j * self.n_bn_ch + off + c] = v.to(self.device, torch.float32)
+            k = bn + ".num_batches_tracked"
+            if k in sd:
+                self.nbt[i] = int(sd[k])
+
+    def state_dict(self):
+        out = OrderedDict()
+        bn_iter = {bn: (i, c, off) for i, (bn, c, off) in enumerate(self.bns)}
+        for key, shape, off in self.layout:
+            n = int(np.prod(shape))
+            out[key] = self.params[off:off + n].view(shape).clone()
+            prefix = key.rsplit(".", 1)[0]
+            if key.endswith(".bias") and prefix in bn_iter:
+                i, c, boff = bn_iter[prefix]
+                out[prefix + ".running_mean"] = self.bn_running[boff:boff + c].clone()
+                out[prefix + ".running_var"] = self.bn_running[self.n_bn_ch + boff:self.n_bn_ch + boff + c].clone()
+                out[prefix + ".num_batches_tracked"] = self.nbt[i].clone()
+        return out
+
+    def grad_dict(self):
+        out = OrderedDict()
+        for key, shape, off in self.layout:
+            out[key] = self.grads[off:off + int(np.prod(shape))].view(shape)
+        out["eta"] = self.grads[self.n_params:]
+        return out
+
+    @property
+    def eta(self):
+        return self.params[self.n_params:]
+
+    # ---- compute ----
+    def forward(self, x, slot=0, train=True, want=("semi", "desc")):
+        _need_gpu(x, "x")
+        n, c, hh, ww = x.shape
+        assert c == 1 and x.dtype == torch.float32
+        f32 = dict(dtype=torch.float32, device=self.device)
+        out = {}
+        semi = torch.empty(n, 65, hh // 8, ww // 8, **f32) if "semi" in want else None
+        desc = torch.empty(n, 256, hh // 8, ww // 8, **f32) if "desc" in want else None
+        sem = torch.empty(n, self.n_classes, hh, ww, **f32) if "sem" in want else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_forward(self.h, slot, _ptr(x), n, hh, ww, int(bool(train)), _ptr(semi), _ptr(desc),
+                                        _ptr(sem), _stream()))
+        if semi is not None:
+            out["semi"] = semi
+        if desc is not None:
+            out["desc"] = desc
+        if sem is not None:
+            out["sem"] = sem
+        return out
+
+    def backward(self, slot, dsemi=None, ddesc=None, dsem=None):
+        for t, nm in ((dsemi, "dsemi"), (ddesc, "ddesc"), (dsem, "dsem")):
+            if t is not None:
+                _need_gpu(t, nm)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_backward(self.h, slot, _ptr(dsemi), _ptr(ddesc), _ptr(dsem), _stream()))
+
+    def zero_grad(self):
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_zero_grad(self.h, _stream()))
+
+    def adam_step(self, lr):
+        self.adam_t += 1
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_adam_step(self.h, float(lr), self.adam_t, _stream()))
+
+    def sample_indices(self, homographies, seed):
+        _need_gpu(homographies, "homographies")
+        B = homographies.shape[0]
+        i32 = dict(dtype=torch.int32, device=self.device)
+        ma = torch.empty(B, self.n_match, **i32)
+        mb = torch.empty(B, self.n_match, **i32)
+        nm = torch.empty(B, self.n_match * self.n_non, **i32)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_sample_indices(self.h, _ptr(homographies), B, int(seed), _ptr(ma), _ptr(mb), _ptr(nm),
+                                               _stream()))
+        return ma, mb, nm
+
+    def pair_step(self, sample, indices=None, seed=0, train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True,
+                  gaussian=True):
+        """`sample`: dict of device tensors with the reference's keys (Train_model_heatmap_all.py:212-251).
+        indices: (match_a, match_b, nonmatch_b) int32 device tensors or None (device sampler with `seed`).
+        Returns the device tensor of SSP_N_SCALARS floats (no host sync)."""
+        img = sample["image"]
+        B = img.shape[0]
+        lab = sample["labels_2D_gaussian"] if gaussian else sample["labels_2D"]
+        labw = sample["warped_labels_gaussian"] if gaussian else sample["warped_labels"]
+        req = [img, sample["warped_img"], lab, labw, sample["valid_mask"], sample["warped_valid_mask"]]
+        for t in req:
+            _need_gpu(t, "sample tensor")
+        Hm = sample["homographies"].to(torch.float32)
+        if not Hm.is_contiguous():
+            Hm = Hm.contiguous()
+        _need_gpu(Hm, "homographies")
+        if lambda_loss > 0 and indices is None:
+            indices = self.sample_indices(Hm, seed)
+        ma, mb, nm = indices if indices is not None else (None, None, None)
+        sem = sample.get("semantic") if self.arch.endswith("ssmall") else None
+        semw = sample.get("warped_sem") if self.arch.endswith("ssmall") else None
+        inp = SspPairInputs(B, _ptr(img), _ptr(sample["warped_img"]), _ptr(lab), _ptr(labw), _ptr(sample["valid_mask"]),
+                            _ptr(sample["warped_valid_mask"]), _ptr(Hm), _ptr(sem), _ptr(semw), _ptr(ma), _ptr(mb),
+                            _ptr(nm), int(seed), float(lambda_loss), float(lamda_d), int(bool(multi_task)),
+                            int(bool(train)))
+        self._keep = (req, Hm, indices, sem, semw)  # keep alive until the stream has consumed them
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_pair_step(self.h, C.byref(inp), _ptr(self.scalars), _stream()))
+        return self.scalars
+
+    def profile_enable(self, family):
+        _check(self.lib.ssp_profile_enable(self.h, PROF[family] if isinstance(family, str) else int(family)))
+
+    def profile_read(self):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _check(self.lib.ssp_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+
+# ---- operator-level wrappers (tests) ----
+def op_conv(x_nhwc, w_oihw, bias, ksize, in_mode=0, in_scale=None, in_shift=None, stats=None, transpose_flip=False,
+            out_hw=None):
+    lib = load_library()
+    _need_gpu(x_nhwc, "x")
+    N, Hin, Win, cin = x_nhwc.shape
+    H, W = (Hin // 2, Win // 2) if in_mode == 2 else (Hin, Win)
+    cout = w_oihw.shape[1] if transpose_flip else w_oihw.shape[0]
+    out = torch.empty(N, H, W, cout, dtype=torch.float32, device=x_nhwc.device)
+    ws = torch.empty(((cin + 15) // 16) * ((cout + 63) // 64) * ksize * ksize * 16 * 64 * 4 + 1024, dtype=torch.uint8,
+                     device=x_nhwc.device)
+    with torch.cuda.device(x_nhwc.device):
+        _check(lib.ssp_op_conv(_ptr(x_nhwc), _ptr(w_oihw), _ptr(bias), _ptr(out), N, H, W, cin, cout, ksize, in_mode,
+                               _ptr(in_scale), _ptr(in_shift), _ptr(stats), int(transpose_flip), _ptr(ws), ws.numel(),
+                               _stream()))
+    return out
+
+
+def op_conv_wgrad(x_nhwc, dout_nhwc, ksize, in_mode=0, in_scale=None, in_shift=None):
+    lib = load_library()
+    N, Hin, Win, cin = x_nhwc.shape
+    _, H, W, cout = dout_nhwc.shape
+    dw = torch.zeros(cout, cin, ksize, ksize, dtype=torch.float32, device=x_nhwc.device)
+    ws = torch.empty(512 * ksize * ksize * 4096 * 4, dtype=torch.uint8, device=x_nhwc.device)
+    with torch.cuda.device(x_nhwc.device):
+        _check(lib.ssp_op_conv_wgrad(_ptr(x_nhwc), _ptr(dout_nhwc), _ptr(dw), N, H, W, cin, cout, ksize, in_mode,
+                                     _ptr(in_scale), _ptr(in_shift), _ptr(ws), ws.numel(), _stream()))
+    return dw
+
+
+def op_labels(labels2d=None, mask2d=None):
+    """labels2Dto3D(add_dustbin=True) and getMasks on the device; returns (target [B,65,Hc,Wc], cellmask [B,Hc,Wc])."""
+    lib = load_library()
+    ref = labels2d if labels2d is not None else mask2d
+    _need_gpu(ref, "labels/mask")
+    B, _, H, W = ref.shape
+    f32 = dict(dtype=torch.float32, device=ref.device)
+    tgt = torch.empty(B, 65, H // 8, W // 8, **f32) if labels2d is not None else None
+    cm = torch.empty(B, H // 8, W // 8, **f32) if mask2d is not None else None
+    with torch.cuda.device(ref.device):
+        _check(lib.ssp_op_labels(_ptr(labels2d), _ptr(mask2d), _ptr(tgt), _ptr(cm), B, H, W, _stream()))
+    return tgt, cm
+
+
+def op_sparse_loss(desc_a_nchw, desc_b_nchw, match_a, match_b, nonmatch_b):
+    """(positive_dist, negative_dist) of the sparse descriptor loss for NCHW descriptor maps and explicit indices."""
+    lib = load_library()
+    _need_gpu(desc_a_nchw, "desc")
+    B, D, Hc, Wc = desc_a_nchw.shape
+    a = desc_a_nchw.permute(0, 2, 3, 1).contiguous()
+    b = desc_b_nchw.permute(0, 2, 3, 1).contiguous()
+    out = torch.zeros(2, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _check(lib.ssp_op_sparse_loss(_ptr(a), _ptr(b), _ptr(match_a), _ptr(match_b), _ptr(nonmatch_b), B, Hc, Wc,
+                                      match_a.shape[1], nonmatch_b.shape[1] // match_a.shape[1], _ptr(out), _stream()))
+    torch.cuda.synchronize()
+    return float(out[0]), float(out[1])

@@ -1,0 +1,225 @@
+"""GPU: the HIP path (through the C ABI / Engine) against the CPU oracle on the same seeded inputs and
+against the committed golden fixtures generated from the real reference.
+Tolerances (north star): detector logits / descriptors within 1e-3 (fp32); label indexing bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as C
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+ARCHS = ("SuperPointNet_gauss2", "SuperPointNet_gauss2_ssmall")
+TOL = 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (run through gpurun)"
+    return torch.device("cuda:0")
+
+
+def _engine(arch, B, H, W, sd, **kw):
+    from semantic_superpoint_amd.lib import Engine
+    e = Engine(arch, B, H, W, _dev(), **kw)
+    e.load_state_dict(sd)
+    return e
+
+
+@pytest.mark.parametrize("arch", ARCHS)
+def test_forward_golden(arch):
+    """G1: two consecutive train-mode forwards + running statistics + eval forward, vs the reference."""
+    g = G.load("g1_forward_%s.npz" % arch)
+    sd = C.init_state_dict(arch, seed=11)
+    e = _engine(arch, 2, 32, 48, sd)
+    want = ("semi", "desc", "sem") if arch.endswith("ssmall") else ("semi", "desc")
+    dev = _dev()
+    o1 = e.forward(torch.from_numpy(g["x1"]).to(dev), slot=0, train=True, want=want)
+    o2 = e.forward(torch.from_numpy(g["x2"]).to(dev), slot=1, train=True, want=want)
+    torch.cuda.synchronize()
+    assert (o1["semi"].cpu() - torch.from_numpy(g["semi1"])).abs().max() < TOL
+    assert (o1["desc"].cpu() - torch.from_numpy(g["desc1"])).abs().max() < TOL
+    assert (o2["semi"].cpu() - torch.from_numpy(g["semi2"])).abs().max() < TOL
+    assert (o2["desc"].cpu() - torch.from_numpy(g["desc2"])).abs().max() < TOL
+    if "sem" in o1:
+        assert (o1["sem"].cpu()[:, ::7, ::3, ::5] - torch.from_numpy(g["sem1_s"])).abs().max() < TOL
+        assert (o2["sem"].cpu()[:, ::7, ::3, ::5] - torch.from_numpy(g["sem2_s"])).abs().max() < TOL
+    st = e.state_dict()
+    for k, v in g.items():
+        if k.startswith("state/"):
+            assert (st[k[6:]].cpu().double() - torch.from_numpy(np.asarray(v)).double()).abs().max() < TOL, k
+    ge = G.load("g1_eval_%s.npz" % arch)
+    oe = e.forward(torch.from_numpy(g["x1"]).to(dev), slot=0, train=False)
+    assert (oe["semi"].cpu() - torch.from_numpy(ge["semi"])).abs().max() < TOL
+    assert (oe["desc"].cpu() - torch.from_numpy(ge["desc"])).abs().max() < TOL
+
+
+@pytest.mark.parametrize("arch,H,W,B", [(ARCHS[0], 64, 96, 2), (ARCHS[1], 64, 96, 2), (ARCHS[0], 120, 160, 2),
+                                         (ARCHS[0], 240, 320, 2)])
+def test_forward_vs_oracle(arch, H, W, B):
+    """Covers both tile geometries (W % 32 == 0 layers and the 8-wide ones) and BASELINE's 240x320."""
+    sd = C.init_state_dict(arch, seed=3)
+    rs = np.random.RandomState(H + W)
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32))
+    ref = C.forward(C.to_torch(sd), x, arch)
+    e = _engine(arch, B, H, W, sd, with_grad=False)
+    want = ("semi", "desc", "sem") if arch.endswith("ssmall") else ("semi", "desc")
+    out = e.forward(x.to(_dev()), slot=0, train=True, want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        err = (out[k].cpu() - ref[k]).abs().max()
+        assert err < TOL, (k, float(err))
+
+
+@pytest.mark.parametrize("arch", ARCHS)
+def test_backward_vs_oracle(arch):
+    """ssp_backward (autograd-compat entry): gradients of a random linear functional of the outputs."""
+    B, H, W = 2, 64, 96
+    sd = C.init_state_dict(arch, seed=5)
+    rs = np.random.RandomState(77)
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32))
+    tsd = C.to_torch(sd, requires_grad=True)
+    ref = C.forward(tsd, x, arch)
+    gs = {k: torch.from_numpy(rs.randn(*ref[k].shape).astype(np.float32)) for k in ref}
+    if "sem" in gs:
+        gs["sem"] *= 0.05
+    loss = sum((ref[k] * gs[k]).sum() for k in ref)
+    loss.backward()
+    e = _engine(arch, B, H, W, sd)
+    dev = _dev()
+    e.forward(x.to(dev), slot=0, train=True, want=())
+    e.zero_grad()
+    e.backward(0, gs["semi"].to(dev), gs["desc"].to(dev), gs["sem"].to(dev) if "sem" in gs else None)
+    torch.cuda.synchronize()
+    gd = e.grad_dict()
+    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+    for k in C.param_keys(arch):
+        r = tsd[k].grad
+        mine = gd[k].cpu()
+        scale = float(r.abs().max())
+        if k in noisy:  # exact gradient is 0; both sides hold rounding noise of the size of the dY sums
+            assert float(mine.abs().max()) < 1e-3 * max(1.0, scale) + 1e-2, k
+            continue
+        err = float((mine - r).abs().max())
+        assert err < 2e-3 * scale + 1e-6, (k, err, scale)
+
+
+def _to_dev(sample):
+    return {k: v.to(_dev()).contiguous() for k, v in sample.items()}
+
+
+def _idx_to_dev(idx, Wc):
+    ma = torch.stack([(i["uv_a"][:, 0] + i["uv_a"][:, 1] * Wc) for i in idx]).to(torch.int32)
+    mb = torch.stack([(i["uv_b"][:, 0] + i["uv_b"][:, 1] * Wc) for i in idx]).to(torch.int32)
+    nm = torch.stack([i["nm_b"] for i in idx]).to(torch.int32)
+    return ma.to(_dev()).contiguous(), mb.to(_dev()).contiguous(), nm.to(_dev()).contiguous()
+
+
+@pytest.mark.parametrize("tag,arch,lam", [("sp_64x96", ARCHS[0], 1.0), ("ssp_64x96", ARCHS[1], 1.0),
+                                          ("magicpoint_32x48", ARCHS[0], 0.0)])
+def test_pair_step_golden(tag, arch, lam):
+    """G6: the full step (2 forwards + losses + backward + Adam) against the reference's scalars,
+    gradients and post-step eta, with the reference's own sampled indices."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    g = G.load("g6_step_%s.npz" % tag)
+    sample = G.sample_from(g)
+    B, _, H, W = sample["image"].shape
+    sd = C.init_state_dict(arch, seed=23)
+    e = _engine(arch, B, H, W, sd)
+    idx = _idx_to_dev(G.indices_from(g, "idx/", B), W // 8) if lam > 0 else None
+    e.zero_grad()
+    sc = e.pair_step(_to_dev(sample), indices=idx, train=True, lambda_loss=lam, lamda_d=1.0, multi_task=True)
+    torch.cuda.synchronize()
+    sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+    for name in ("loss", "loss_det", "loss_det_warp", "loss_desc", "loss_sem", "loss_sem_warp", "positive_dist",
+                 "negative_dist"):
+        ref = float(g["step0/" + name])
+        assert abs(sc[name] - ref) < TOL * max(1.0, abs(ref)), (name, sc[name], ref)
+    gd = e.grad_dict()
+    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+    for k in C.param_keys(arch):
+        if k in noisy or ("grad_norm/" + k) not in g:
+            continue
+        n_ref = float(g["grad_norm/" + k])
+        mine = gd[k].cpu().reshape(-1)
+        assert abs(float(mine.norm()) - n_ref) < 5e-3 * n_ref + 1e-6, (k, float(mine.norm()), n_ref)
+        sl = torch.from_numpy(g["grad_slice/" + k])
+        assert (mine[:64] - sl).abs().max() < 5e-3 * float(mine.abs().max()) + 1e-6, k
+    assert (gd["eta"].cpu() - torch.from_numpy(g["grad/eta"])).abs().max() < 1e-3
+    e.adam_step(0.001)
+    torch.cuda.synchronize()
+    # the reference logs the LIVE eta parameter, i.e. post-step values (oracle/cpu_ref.py Trainer)
+    eta = e.eta.cpu()
+    assert abs(float(eta[0]) - float(g["step0/eta_det"])) < 1e-5 and abs(float(eta[1]) - float(g["step0/eta_desc"])) < 1e-5
+    if "step0/eta_sem" in g:
+        assert abs(float(eta[2]) - float(g["step0/eta_sem"])) < 1e-5
+
+
+@pytest.mark.parametrize("arch", ARCHS)
+def test_pair_step_vs_oracle_two_steps(arch):
+    """Two optimizer steps on fresh seeded data (120x160, B=2) vs the oracle; also the no-grad (val) path."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    B, H, W = 2, 120, 160
+    semantic = arch.endswith("ssmall")
+    sd = C.init_state_dict(arch, seed=9)
+    sample = C.make_synthetic_pair(B, H, W, seed=4, semantic=semantic, kp_prob=0.005)
+    tr = C.Trainer(arch, sd, lr=0.001)
+    e = _engine(arch, B, H, W, sd)
+    ds = _to_dev(sample)
+    for it in range(2):
+        np.random.seed(50 + it)
+        torch.manual_seed(60 + it)
+        tr.train_val_sample(sample, n_iter=it, train=True)
+        idx = _idx_to_dev(tr.aux["indices"], W // 8)
+        e.zero_grad()
+        sc = e.pair_step(ds, indices=idx, train=True)
+        e.adam_step(0.001)
+        torch.cuda.synchronize()
+        sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+        for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
+            ref = tr.scalar_dict[name]
+            assert abs(sc[name] - ref) < 2e-3 * max(1.0, abs(ref)), (it, name, sc[name], ref)
+    assert (e.eta.cpu() - tr.eta.detach()).abs().max() < 1e-4
+    rv = e.state_dict()
+    for k in ("inc.conv.conv.1.running_var", "bnPb.running_mean", "down3.mpconv.1.conv.4.running_var"):
+        assert (rv[k].cpu() - tr.sd[k]).abs().max() < 1e-3 * max(1.0, float(tr.sd[k].abs().max())), k
+    # validation path: train=False leaves the gradient buffer untouched
+    before = e.grads.clone()
+    e.pair_step(ds, indices=idx, train=False)
+    torch.cuda.synchronize()
+    assert torch.equal(before, e.grads)
+
+
+def test_sparse_loss_golden_full():
+    """G4 at the real 30x40 cell grid: loss values with the reference's indices (descriptor maps are inputs)."""
+    from semantic_superpoint_amd import lib as L
+    g = G.load("g4_sparse_loss_full.npz")
+    d, dw = G.g4_full_inputs()
+    B = d.shape[0]
+    idx = G.indices_from(g, "", B)
+    pos, neg = L.op_sparse_loss(torch.from_numpy(d).to(_dev()), torch.from_numpy(dw).to(_dev()), *_idx_to_dev(idx, 40))
+    assert abs(pos - float(g["pos"])) < 1e-4 and abs(neg - float(g["neg"])) < 1e-4
+
+
+def test_device_sampler_distribution():
+    """ssp_sample_indices: every sampled match is a valid correspondence of the oracle, matches are distinct
+    when >= n_match candidates exist, non-matches are uniform over the grid."""
+    from semantic_superpoint_amd.lib import Engine
+    B, H, W = 4, 240, 320
+    e = Engine("SuperPointNet_gauss2", B, H, W, _dev(), with_grad=False)
+    rs = np.random.RandomState(2)
+    Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(B)]).astype(np.float32))
+    ma, mb, nm = e.sample_indices(Hs.to(_dev()), seed=1234)
+    torch.cuda.synchronize()
+    ma, mb, nm = ma.cpu(), mb.cpu(), nm.cpu()
+    for i in range(B):
+        uv_a, uv_b = C.cell_matches(Hs[i], 30, 40)
+        valid = {int(a[0] + a[1] * 40): int(b[0] + b[1] * 40) for a, b in zip(uv_a, uv_b)}
+        bad = sum(1 for a, b in zip(ma[i].tolist(), mb[i].tolist()) if valid.get(a, -1) != b)
+        assert bad <= 2, bad  # rounding ties at .5 may differ (H_cell computed analytically on device)
+        if len(valid) >= 1000:
+            assert len(set(ma[i].tolist())) == 1000
+    assert nm.min() >= 0 and nm.max() < 1200
+    hist = torch.bincount(nm.reshape(-1).long(), minlength=1200).float()
+    assert hist.min() > 0.8 * hist.mean() and hist.max() < 1.2 * hist.mean()
+    ma2, _, nm2 = e.sample_indices(Hs.to(_dev()), seed=1234)
+    assert torch.equal(ma2.cpu(), ma) and torch.equal(nm2.cpu(), nm)  # deterministic in the seed

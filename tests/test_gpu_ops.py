@@ -1,0 +1,119 @@
+"""GPU: operator-level parity of the HIP kernels (called through the C ABI) against plain PyTorch fp32
+references computed on the CPU.  Tolerances: 2e-4 relative to the output scale (fp32, different
+summation order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (run through gpurun)"
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _ref_input(x_nhwc, in_mode, sc, sh):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if in_mode >= 1:
+        x = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if in_mode == 2:
+        x = F.max_pool2d(x, 2)
+    return x
+
+
+CONV_CASES = [
+    # N, H, W, cin, cout, ks, in_mode   (H,W = conv resolution; the input is 2H x 2W for in_mode 2)
+    (2, 16, 64, 64, 64, 3, 1),    # wide tiles (8x32), full tiles
+    (1, 12, 32, 64, 128, 3, 0),   # wide, partial tile rows, 2 cout blocks
+    (2, 8, 32, 64, 64, 3, 2),     # wide + pooled input
+    (2, 30, 40, 128, 128, 3, 1),  # narrow tiles (32x8): the 30x40 layers
+    (1, 8, 24, 64, 128, 3, 2),    # narrow + pooled input
+    (2, 6, 8, 128, 256, 3, 1),    # heads on a tiny map
+    (2, 30, 40, 256, 65, 1, 1),   # convPb: 1x1, cout tail
+    (1, 4, 6, 256, 256, 1, 1),    # convDb
+    (1, 16, 32, 256, 133, 1, 0),  # 1x1 raw input, wide
+]
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,ks,mode", CONV_CASES)
+def test_conv_forward(N, H, W, cin, cout, ks, mode):
+    from semantic_superpoint_amd import lib as L
+    dev = _dev()
+    rs = np.random.RandomState(N * 1000 + H * 10 + cout + ks + mode)
+    mul = 2 if mode == 2 else 1
+    x = torch.from_numpy(rs.randn(N, H * mul, W * mul, cin).astype(np.float32))
+    w = torch.from_numpy((rs.randn(cout, cin, ks, ks) / np.sqrt(cin * ks * ks)).astype(np.float32))
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32) * 0.1)
+    sc = torch.from_numpy(rs.uniform(-1.5, 1.5, cin).astype(np.float32))  # negative scales too
+    sh = torch.from_numpy(rs.uniform(-0.5, 0.5, cin).astype(np.float32))
+    ref = F.conv2d(_ref_input(x, mode, sc, sh), w, b, padding=ks // 2).permute(0, 2, 3, 1).contiguous()
+    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    out = L.op_conv(x.to(dev), w.to(dev), b.to(dev), ks, mode, sc.to(dev), sh.to(dev), stats)
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref) < 2e-4
+    s_ref = ref.double().sum(dim=(0, 1, 2))
+    q_ref = (ref.double() ** 2).sum(dim=(0, 1, 2))
+    assert (stats[:cout].cpu() - s_ref).abs().max() < 1e-3 * (s_ref.abs().max() + 1)
+    assert (stats[cout:].cpu() - q_ref).abs().max() < 1e-4 * q_ref.abs().max()
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,ks", [(2, 16, 32, 64, 64, 3), (1, 30, 40, 128, 256, 3), (2, 6, 8, 256, 65, 1),
+                                                 (1, 8, 32, 64, 128, 3)])
+def test_conv_dgrad(N, H, W, cin, cout, ks):
+    """data gradient = conv with transposed/flipped weights; `cin/cout` are those of the FORWARD conv."""
+    from semantic_superpoint_amd import lib as L
+    dev = _dev()
+    rs = np.random.RandomState(7 + cin + cout)
+    cpad = (cout + 3) // 4 * 4
+    dy = torch.zeros(N, H, W, cpad)
+    dy[..., :cout] = torch.from_numpy(rs.randn(N, H, W, cout).astype(np.float32))
+    w = torch.from_numpy((rs.randn(cout, cin, ks, ks) / np.sqrt(cout * ks * ks)).astype(np.float32))
+    ref = torch.nn.grad.conv2d_input((N, cin, H, W), w, dy[..., :cout].permute(0, 3, 1, 2).contiguous(), padding=ks // 2)
+    ref = ref.permute(0, 2, 3, 1).contiguous()
+    if cpad != cout:  # channel-padded dY as used for convPb (65 -> 68 readable channels)
+        pytest.skip("padded-stride dgrad is covered by the model-level backward test")
+    out = L.op_conv(dy.to(dev), w.to(dev), None, ks, 0, None, None, None, transpose_flip=True)
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref) < 2e-4
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,ks,mode", [(2, 16, 64, 64, 64, 3, 1), (2, 30, 40, 128, 128, 3, 1),
+                                                      (2, 8, 32, 64, 128, 3, 2), (1, 12, 24, 128, 256, 3, 0),
+                                                      (2, 30, 40, 256, 64, 1, 1), (3, 5, 8, 256, 256, 1, 0)])
+def test_conv_wgrad(N, H, W, cin, cout, ks, mode):
+    from semantic_superpoint_amd import lib as L
+    dev = _dev()
+    rs = np.random.RandomState(11 + cin + cout + mode)
+    mul = 2 if mode == 2 else 1
+    x = torch.from_numpy(rs.randn(N, H * mul, W * mul, cin).astype(np.float32))
+    dy = torch.from_numpy(rs.randn(N, H, W, cout).astype(np.float32))
+    sc = torch.from_numpy(rs.uniform(-1.5, 1.5, cin).astype(np.float32))
+    sh = torch.from_numpy(rs.uniform(-0.5, 0.5, cin).astype(np.float32))
+    xin = _ref_input(x, mode, sc, sh)
+    ref = torch.nn.grad.conv2d_weight(xin, (cout, cin, ks, ks), dy.permute(0, 3, 1, 2).contiguous(), padding=ks // 2)
+    out = L.op_conv_wgrad(x.to(dev), dy.to(dev), ks, mode, sc.to(dev), sh.to(dev))
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref) < 2e-4
+
+
+def test_labels_bit_exact(golden_dir):
+    """labels2Dto3D / getMasks: bit-exact against the reference's arrays (G2) for binary labels,
+    1e-7 for gaussian-valued labels (64-term fp32 sum in a different order)."""
+    from semantic_superpoint_amd import lib as L
+    from tests import golden_util as G
+    dev = _dev()
+    g = G.load("g2_labels.npz")
+    tgt, cm = L.op_labels(torch.from_numpy(g["labels_bin"]).to(dev), torch.from_numpy(g["mask"]).to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(tgt.cpu(), torch.from_numpy(g["labels3D_bin"]))
+    assert torch.equal(cm.cpu(), torch.from_numpy(g["mask3D"]))
+    tgt, _ = L.op_labels(torch.from_numpy(g["labels_gauss"]).to(dev), None)
+    ref = torch.from_numpy(g["labels3D_gauss"])
+    assert (tgt.cpu() - ref).abs().max() < 2e-7
+    assert torch.equal(tgt.cpu() == 0, ref == 0)  # indexing: identical support
