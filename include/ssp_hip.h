@@ -136,6 +136,15 @@ int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw
 int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* target_dev, float* cellmask_dev, int b,
                   int h, int w, void* stream);
 
+/* BatchNorm2d(train) (+ReLU (+MaxPool2d(2))) backward. y: raw conv output NHWC; dout: gradient wrt the activated
+ * (and pooled) output; stats4 = scale|shift|mean|invstd ([4*C]); dgamma/dbeta/dbias are accumulated. */
+int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_dev, const float* stats4_dev,
+                  float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int h,
+                  int w, int c, int relu, int pool, void* stream);
+
+/* test hook: device pointer of an internal buffer ("gP","gQ","dsemi","ddesc","desc","dsout","Y<l>","scale<l>","shift<l>") */
+int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, size_t* nfloats);
+
 /* forward of batch_descriptor_loss_sparse (utils/loss_functions/sparse_loss.py:267-284) on NHWC descriptor
  * maps [B][hc*wc][256] with explicit indices; out2_dev = {mean positive_dist, mean negative_dist}. */
 int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -873,6 +874,50 @@ int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw
                       (hipStream_t)stream);
 }
 
+
+// BatchNorm(+ReLU(+2x2 max-pool)) backward as an operator: y [N,H,W,C] raw conv output, dout = gradient wrt the
+// activated (pooled when pool=1: [N,H/2,W/2,C]) output; stats4 = {scale, shift, mean, invstd} each [C].
+// Outputs: dy [N,H,W,C], dgamma/dbeta/dbias [C] (accumulated), sums_dev: double[2C] scratch.
+int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_dev, const float* stats4_dev,
+                  float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int hh,
+                  int w, int c, int relu, int pool, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(sums_dev, 0, 2 * c * sizeof(double), st));
+  BnBwdArgs a;
+  a.y = y_dev; a.dout = dout_dev; a.dy = dy_dev; a.scale = stats4_dev; a.shift = stats4_dev + c; a.mean = stats4_dev + 2 * c;
+  a.invstd = stats4_dev + 3 * c; a.gamma = gamma_dev; a.sums = sums_dev; a.dbias = dbias_dev; a.N = n; a.H = hh; a.W = w;
+  a.C = c; a.y_cs = c; a.y_co = 0; a.d_cs = c; a.d_co = 0; a.dy_cs = c; a.dy_co = 0; a.count = (double)n * hh * w;
+  if (relu && pool) CHK((launch_bn_bwd<true, true>(a, st)));
+  else if (relu) CHK((launch_bn_bwd<true, false>(a, st)));
+  else CHK((launch_bn_bwd<false, false>(a, st)));
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, sums_dev, dgamma_dev, dbeta_dev, c);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// debug/test hook: device pointers of internal buffers (never used by the product path)
+int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, size_t* nfloats) {
+  if (!h || !h->bound || !name || !ptr) return fail(-1, "bad argument");
+  Slot& S = h->slot[slot & 1];
+  const size_t cells = (size_t)h->cfg.max_batch * (h->cfg.height / 8) * (h->cfg.width / 8);
+  std::string n(name);
+  float* p = nullptr; size_t cnt = 0;
+  if (n == "gP") { p = h->gP; cnt = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * 64; }
+  else if (n == "gQ") { p = h->gQ; cnt = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * 64; }
+  else if (n == "dsemi") { p = S.dsemi; cnt = cells * 80; }
+  else if (n == "ddesc") { p = S.ddesc; cnt = cells * 256; }
+  else if (n == "desc") { p = S.desc; cnt = cells * 256; }
+  else if (n == "dsout") { p = S.dsout; cnt = cells * h->sout_cs; }
+  else if (n[0] == 'Y') { int l = atoi(name + 1); if (l < 0 || l >= h->nlayers) return fail(-1, "bad layer"); p = S.Y[l]; cnt = 0; }
+  else if (n.rfind("scale", 0) == 0) { int l = atoi(name + 5); p = S.bn[l].scale; cnt = h->L[l].cout; }
+  else if (n.rfind("shift", 0) == 0) { int l = atoi(name + 5); p = S.bn[l].shift; cnt = h->L[l].cout; }
+  else if (n.rfind("mean", 0) == 0) { int l = atoi(name + 4); p = S.bn[l].mean; cnt = h->L[l].cout; }
+  else if (n.rfind("invstd", 0) == 0) { int l = atoi(name + 6); p = S.bn[l].invstd; cnt = h->L[l].cout; }
+  else return fail(-1, "unknown buffer %s", name);
+  *ptr = p;
+  if (nfloats) *nfloats = cnt;
+  return 0;
+}
 
 int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,
                        const int32_t* match_b_dev, const int32_t* nonmatch_b_dev, int b, int hc, int wc, int n_match,

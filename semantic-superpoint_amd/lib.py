@@ -45,7 +45,8 @@ _lib = None
 EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ssp_bn_channel_count",
            "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
            "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
-           "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss"]
+           "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
+           "ssp_debug_buffer"]
 
 
 def load_library(path=None):
@@ -78,6 +79,8 @@ def load_library(path=None):
                                      C.POINTER(C.c_double)]
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
+    lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.ssp_op_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
     lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
     _lib = lib
@@ -250,6 +253,9 @@ class Engine:
         semi = torch.empty(n, 65, hh // 8, ww // 8, **f32) if "semi" in want else None
         desc = torch.empty(n, 256, hh // 8, ww // 8, **f32) if "desc" in want else None
         sem = torch.empty(n, self.n_classes, hh, ww, **f32) if "sem" in want else None
+        if not hasattr(self, "_x"):
+            self._x = [None, None]
+        self._x[slot] = x  # the first-layer weight gradient re-reads the image in backward: keep it alive
         with torch.cuda.device(self.device):
             _check(self.lib.ssp_forward(self.h, slot, _ptr(x), n, hh, ww, int(bool(train)), _ptr(semi), _ptr(desc),
                                         _ptr(sem), _stream()))
@@ -319,6 +325,16 @@ class Engine:
             _check(self.lib.ssp_pair_step(self.h, C.byref(inp), _ptr(self.scalars), _stream()))
         return self.scalars
 
+    def debug_buffer(self, slot, name, shape):
+        """Test hook: copy of an internal NHWC buffer as a torch tensor of `shape`."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib.ssp_debug_buffer(self.h, slot, name.encode(), C.byref(p), C.byref(n)))
+        numel = int(np.prod(shape))
+        base = self.workspace.data_ptr()
+        off = p.value - base
+        assert 0 <= off and off + numel * 4 <= self.ws_bytes
+        return self.workspace[off:off + numel * 4].view(torch.float32).view(*shape).clone()
+
     def profile_enable(self, family):
         _check(self.lib.ssp_profile_enable(self.h, PROF[family] if isinstance(family, str) else int(family)))
 
@@ -385,3 +401,19 @@ def op_sparse_loss(desc_a_nchw, desc_b_nchw, match_a, match_b, nonmatch_b):
                                       match_a.shape[1], nonmatch_b.shape[1] // match_a.shape[1], _ptr(out), _stream()))
     torch.cuda.synchronize()
     return float(out[0]), float(out[1])
+
+
+def op_bn_bwd(y_nhwc, dout_nhwc, gamma, scale, shift, mean, invstd, relu=True, pool=False):
+    """Backward of BatchNorm2d(train)+ReLU(+MaxPool2d(2)); returns (dy, dgamma, dbeta, dbias)."""
+    lib = load_library()
+    _need_gpu(y_nhwc, "y")
+    N, H, W, Cc = y_nhwc.shape
+    dev = y_nhwc.device
+    stats4 = torch.cat([scale, shift, mean, invstd]).contiguous()
+    dy = torch.empty_like(y_nhwc)
+    dg, db, dbias = (torch.zeros(Cc, dtype=torch.float32, device=dev) for _ in range(3))
+    sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.ssp_op_bn_bwd(_ptr(y_nhwc), _ptr(dout_nhwc), _ptr(gamma), _ptr(stats4), _ptr(dy), _ptr(dg), _ptr(db),
+                                 _ptr(dbias), _ptr(sums), N, H, W, Cc, int(relu), int(pool), _stream()))
+    return dy, dg, db, dbias

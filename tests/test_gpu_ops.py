@@ -76,8 +76,8 @@ def test_conv_dgrad(N, H, W, cin, cout, ks):
     w = torch.from_numpy((rs.randn(cout, cin, ks, ks) / np.sqrt(cout * ks * ks)).astype(np.float32))
     ref = torch.nn.grad.conv2d_input((N, cin, H, W), w, dy[..., :cout].permute(0, 3, 1, 2).contiguous(), padding=ks // 2)
     ref = ref.permute(0, 2, 3, 1).contiguous()
-    if cpad != cout:  # channel-padded dY as used for convPb (65 -> 68 readable channels)
-        pytest.skip("padded-stride dgrad is covered by the model-level backward test")
+    if cpad != cout:  # channel-padded dY as used for convPb (65 -> 68 readable channels, zero pads)
+        w = torch.cat([w, torch.zeros(cpad - cout, cin, ks, ks)], 0).contiguous()
     out = L.op_conv(dy.to(dev), w.to(dev), None, ks, 0, None, None, None, transpose_flip=True)
     torch.cuda.synchronize()
     assert _rel(out.cpu(), ref) < 2e-4
@@ -117,3 +117,41 @@ def test_labels_bit_exact(golden_dir):
     ref = torch.from_numpy(g["labels3D_gauss"])
     assert (tgt.cpu() - ref).abs().max() < 2e-7
     assert torch.equal(tgt.cpu() == 0, ref == 0)  # indexing: identical support
+
+
+@pytest.mark.parametrize("N,H,W,C,relu,pool", [(2, 8, 12, 256, True, False), (2, 16, 24, 64, True, True),
+                                               (2, 8, 12, 65, False, False), (1, 30, 40, 128, True, False),
+                                               (2, 12, 16, 128, True, True)])
+def test_bn_relu_pool_backward(N, H, W, C, relu, pool):
+    """BatchNorm2d(train)+ReLU(+MaxPool2d) backward vs torch autograd (CPU fp32)."""
+    from semantic_superpoint_amd import lib as L
+    dev = _dev()
+    rs = np.random.RandomState(C + H)
+    y = torch.from_numpy(rs.randn(N, C, H, W).astype(np.float32) * 1.7 + 0.3).requires_grad_(True)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy(rs.uniform(-0.3, 0.3, C).astype(np.float32)).requires_grad_(True)
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    a = F.relu(z) if relu else z
+    if pool:
+        a = F.max_pool2d(a, 2)
+    g = torch.from_numpy(rs.randn(*a.shape).astype(np.float32))
+    (a * g).sum().backward()
+    with torch.no_grad():
+        mean = y.mean(dim=(0, 2, 3))
+        var = y.var(dim=(0, 2, 3), unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        scale = gamma * invstd
+        shift = beta - mean * scale
+    Cp = (C + 3) // 4 * 4
+    def nhwc(t, c_pad=Cp):
+        o = torch.zeros(t.shape[0], t.shape[2], t.shape[3], c_pad)
+        o[..., :t.shape[1]] = t.detach().permute(0, 2, 3, 1)
+        return o.contiguous().to(dev)
+    if Cp != C:
+        pytest.skip("padded-stride BN backward is covered by the model-level test")
+    dy, dg, db, dbias = L.op_bn_bwd(nhwc(y), nhwc(g), gamma.detach().to(dev), scale.to(dev), shift.to(dev), mean.to(dev),
+                                    invstd.to(dev), relu, pool)
+    torch.cuda.synchronize()
+    ref = y.grad.permute(0, 2, 3, 1)
+    assert _rel(dy.cpu(), ref) < 1e-4
+    assert _rel(dg.cpu(), gamma.grad) < 1e-4 and _rel(db.cpu(), beta.grad) < 1e-4
