@@ -115,7 +115,7 @@ int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, 
 /* timing hook for bench.py: when enabled, every launch of the tagged kernel family is bracketed by
  * hipEvents on `stream`; ssp_profile_read returns accumulated milliseconds, launches and FLOPs. */
 enum { SSP_PROF_NONE = 0, SSP_PROF_CONV3X3_FWD = 1, SSP_PROF_CONV3X3_DGRAD = 2, SSP_PROF_CONV3X3_WGRAD = 3,
-       SSP_PROF_CONV_BIG_FWD = 4 };
+       SSP_PROF_CONV_BIG_FWD = 4, SSP_PROF_CONV3X3_ALL = 5 /* fwd + dgrad launches of conv_mfma_kernel */ };
 int ssp_profile_enable(ssp_handle* h, int family);
 int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops, double* bytes);
 

@@ -232,7 +232,9 @@ static size_t carve(ssp_handle* h, void* base) {
 struct ProfScope {
   ssp_handle* h; hipStream_t st; bool on;
   ProfScope(ssp_handle* h_, int family, hipStream_t s, double flops, double bytes) : h(h_), st(s), on(false) {
-    if (h && h->prof_family == family && h->ev_used + 2 <= h->ev_pool.size()) {
+    const bool match = h && family > 0 && (h->prof_family == family ||
+        (h->prof_family == SSP_PROF_CONV3X3_ALL && (family == SSP_PROF_CONV3X3_FWD || family == SSP_PROF_CONV3X3_DGRAD)));
+    if (match && h->ev_used + 2 <= h->ev_pool.size()) {
       on = true;
       (void)hipEventRecord(h->ev_pool[h->ev_used], st);
       h->prof_flops += flops; h->prof_bytes += bytes; h->prof_launches += 1;

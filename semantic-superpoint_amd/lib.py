@@ -17,7 +17,7 @@ ARCHS = {"SuperPointNet_gauss2": 0, "SuperPointNet_gauss2_ssmall": 1}
 SCALAR_NAMES = ["loss", "loss_det", "loss_det_warp", "loss_desc", "loss_sem", "loss_sem_warp", "positive_dist",
                 "negative_dist", "eta_det", "eta_desc", "eta_sem"]
 N_SCALARS = 16
-PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4}
+PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4, "conv3x3_all": 5}
 
 
 class SspConfig(C.Structure):
