@@ -31,6 +31,7 @@ extern "C" {
 typedef struct ssp_handle ssp_handle;
 
 enum { SSP_ARCH_GAUSS2 = 0, SSP_ARCH_GAUSS2_SSMALL = 1 };
+enum { SSP_NREP = 32 }; /* replicas of each fp64 statistics accumulator (spreads same-address atomics) */
 
 typedef struct {
   int arch;      /* SSP_ARCH_* */
@@ -122,7 +123,8 @@ int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops
 /* ---- operator-level entry points (used by the unit parity tests; same kernels as above) ---- */
 /* 3x3 / 1x1 convolution, NHWC fp32, stride 1, "same" padding, weights OIHW (reference layout).
  * in_mode: 0 raw input, 1 input = relu(in*scale+shift), 2 = maxpool2(relu(in*scale+shift)) where `in`
- * is [N,2H,2W,Cin]. stats_dev (double [2*Cout]: sum, sumsq) may be NULL. */
+ * is [N,2H,2W,Cin]. stats_dev (double [SSP_NREP][2*Cout]: partial sum, sumsq replicas; zeroed by the caller)
+ * may be NULL. */
 int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_dev, float* out_dev, int n, int h,
                 int w, int cin, int cout, int ksize, int in_mode, const float* in_scale_dev,
                 const float* in_shift_dev, double* stats_dev, int transpose_flip, void* workspace_dev,
@@ -137,7 +139,8 @@ int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* tar
                   int h, int w, void* stream);
 
 /* BatchNorm2d(train) (+ReLU (+MaxPool2d(2))) backward. y: raw conv output NHWC; dout: gradient wrt the activated
- * (and pooled) output; stats4 = scale|shift|mean|invstd ([4*C]); dgamma/dbeta/dbias are accumulated. */
+ * (and pooled) output; stats4 = scale|shift|mean|invstd ([4*C]); dgamma/dbeta/dbias are accumulated;
+ * sums_dev: double [SSP_NREP][2*C] scratch. */
 int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_dev, const float* stats4_dev,
                   float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int h,
                   int w, int c, int relu, int pool, void* stream);

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "conv_mfma.hip.h"
+
 namespace sspk {
 
 // ---- block reduction helper: per-thread `NV` floats, threads with the same (tid % nq) are summed ----
@@ -28,6 +30,7 @@ __device__ __forceinline__ void reduce_by_column(float (&v)[NV], float* smem, in
 // Also accumulates the BatchNorm sums.  grid: ceil(npix / (16 * PIX_ITERS)), block 256.
 // ------------------------------------------------------------------------------------------------
 constexpr int C0_ITERS = 64;
+constexpr int C0W_ITERS = 256;  // conv0_wgrad: fewer, fatter blocks (576 float atomics per block)
 __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            double* __restrict__ stats, int N, int H, int W) {
@@ -75,8 +78,9 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
     if (tid < 16) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        unsafeAtomicAdd(stats + tid * 4 + c, (double)acc[c]);
-        unsafeAtomicAdd(stats + 64 + tid * 4 + c, (double)acc[4 + c]);
+        double* st = stats + (size_t)(blockIdx.x % NREP) * 128;
+        unsafeAtomicAdd(st + tid * 4 + c, (double)acc[c]);
+        unsafeAtomicAdd(st + 64 + tid * 4 + c, (double)acc[4 + c]);
       }
     }
   }
@@ -90,13 +94,14 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   const int tid = threadIdx.x;
   const int q = tid & 15, pl = tid >> 4;
   const long npix = (long)N * H * W;
-  const long base = (long)blockIdx.x * 16 * C0_ITERS;
+  const long base = (long)blockIdx.x * 16 * C0W_ITERS;
   float acc[4][9];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
-  for (int it = 0; it < C0_ITERS; ++it) {
+#pragma unroll 4
+  for (int it = 0; it < C0W_ITERS; ++it) {
     const long p = base + it * 16 + pl;
     if (p >= npix) break;
     const int xx = (int)(p % W);
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 // train: batch statistics from the fp64 sums + running-stat update; eval: running statistics.
 // ------------------------------------------------------------------------------------------------
 struct BnLayer {
-  const double* stats;  // [2C] sum, sumsq
+  const double* stats;  // [NREP][2C] sum, sumsq
   const float* gamma;
   const float* beta;
   float* running_mean;
@@ -150,8 +155,13 @@ __global__ void bn_finalize_kernel(const BnLayer L, int train, int64_t* nbt) {
   if (c >= L.C) return;
   double mean, var;
   if (train) {
-    mean = L.stats[c] / L.count;
-    var = L.stats[L.C + c] / L.count - mean * mean;
+    double s1 = 0, s2 = 0;
+    for (int r = 0; r < NREP; ++r) {
+      s1 += L.stats[(size_t)r * 2 * L.C + c];
+      s2 += L.stats[(size_t)r * 2 * L.C + L.C + c];
+    }
+    mean = s1 / L.count;
+    var = s2 / L.count - mean * mean;
     if (var < 0) var = 0;
     const double unbiased = L.count > 1 ? var * L.count / (L.count - 1) : var;
     L.running_mean[c] = (float)(0.9 * (double)L.running_mean[c] + 0.1 * mean);
@@ -186,7 +196,7 @@ struct BnBwdArgs {
   const float* mean;
   const float* invstd;
   const float* gamma;
-  double* sums;      // [2C]
+  double* sums;      // [NREP][2C]
   float* dbias;      // conv bias gradient (accumulated) or nullptr
   int N, H, W, C;
   int y_cs, y_co, d_cs, d_co, dy_cs, dy_co;
@@ -223,12 +233,18 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
     is = ld4(a.invstd);
     if (APPLY) {
       const float4 g = ld4(a.gamma);
-      const float inv_n = (float)(1.0 / a.count);
       float s1[4], s2[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        s1[i] = cv[i] ? (float)a.sums[c0 + i] * inv_n : 0.f;
-        s2[i] = cv[i] ? (float)a.sums[a.C + c0 + i] * inv_n : 0.f;
+        double t1 = 0, t2 = 0;
+        if (cv[i]) {
+          for (int r = 0; r < NREP; ++r) {
+            t1 += a.sums[(size_t)r * 2 * a.C + c0 + i];
+            t2 += a.sums[(size_t)r * 2 * a.C + a.C + c0 + i];
+          }
+        }
+        s1[i] = (float)(t1 / a.count);
+        s2[i] = (float)(t2 / a.count);
       }
       k1 = make_float4(s1[0], s1[1], s1[2], s1[3]);
       k2 = make_float4(s2[0], s2[1], s2[2], s2[3]);
@@ -331,8 +347,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
       for (int i = 0; i < 4; ++i) {
         if (!cv[i]) continue;
         if (!APPLY) {
-          unsafeAtomicAdd(a.sums + c0 + i, (double)acc[i]);
-          unsafeAtomicAdd(a.sums + a.C + c0 + i, (double)acc[4 + i]);
+          double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 2 * a.C;
+          unsafeAtomicAdd(sm + c0 + i, (double)acc[i]);
+          unsafeAtomicAdd(sm + a.C + c0 + i, (double)acc[4 + i]);
         } else if (a.dbias != nullptr) {
           atomicAdd(a.dbias + c0 + i, acc[i]);
         }
@@ -346,8 +363,13 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __r
                                      float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  dbeta[c] += (float)sums[c];
-  dgamma[c] += (float)sums[C + c];
+  double s1 = 0, s2 = 0;
+  for (int r = 0; r < NREP; ++r) {
+    s1 += sums[(size_t)r * 2 * C + c];
+    s2 += sums[(size_t)r * 2 * C + C + c];
+  }
+  dbeta[c] += (float)s1;
+  dgamma[c] += (float)s2;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ namespace sspk {
 constexpr int CK = 16;       // input channels staged per K-chunk
 constexpr int CS = CK + 4;   // LDS pixel stride in floats (pad 4 -> conflict-free ds_read_b128)
 constexpr int NB = 64;       // output channels per block
+constexpr int NREP = 32;     // replicas of every fp64 statistics accumulator (spreads same-address atomics)
 
 struct ConvArgs {
   const float* in;        // NHWC [N, H*(pool?2:1), W*(pool?2:1), in_cs]
@@ -26,7 +27,7 @@ struct ConvArgs {
   float* out;             // NHWC [N,H,W,out_cs]
   const float* in_scale;  // [Cin] (IN_MODE != 0)
   const float* in_shift;
-  double* stats;          // [2*Cout] sum, sumsq of the (biased) conv output, or nullptr
+  double* stats;          // [NREP][2*Cout] sum, sumsq of the (biased) conv output, or nullptr
   int N, H, W;
   int Cin, in_cs, in_co;
   int Cout, out_cs, out_co;
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) t += red[((w * 2 + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
       const int co = cob * NB + ch;
-      if (co < a.Cout) unsafeAtomicAdd(a.stats + which * a.Cout + co, (double)t);
+      if (co < a.Cout)
+        unsafeAtomicAdd(a.stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
     }
   }
 }
@@ -362,21 +364,29 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
 }
 
 // Sums the partial slabs over splits and ACCUMULATES into the OIHW gradient tensor.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cin, int Cout,
-                                    int KS, int ncob, int nsplit) {
+// block = 256 threads = 64 outputs x 4 split groups
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int Cin, int Cout, int KS, int ncob, int nsplit) {
+  __shared__ float red[256];
   const int taps = KS * KS;
   const int total = Cout * Cin * taps;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  // idx enumerates (tap, ci, co) with co fastest so that reads of `partial` coalesce
-  const int co = idx % Cout;
-  const int ci = (idx / Cout) % Cin;
-  const int tap = idx / (Cout * Cin);
-  const int cob = co >> 6, cib = ci >> 6;
-  const float* src = partial + ((size_t)((cib * ncob + cob) * nsplit) * taps + tap) * 4096 + (ci & 63) * 64 + (co & 63);
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += src[(size_t)k * taps * 4096];
-  dw[((size_t)co * Cin + ci) * taps + tap] += s;
+  int co = 0, ci = 0, tap = 0;
+  if (idx < total) {
+    // idx enumerates (tap, ci, co) with co fastest so that reads of `partial` coalesce
+    co = idx % Cout;
+    ci = (idx / Cout) % Cin;
+    tap = idx / (Cout * Cin);
+    const int cob = co >> 6, cib = ci >> 6;
+    const float* src = partial + ((size_t)((cib * ncob + cob) * nsplit) * taps + tap) * 4096 + (ci & 63) * 64 + (co & 63);
+    for (int k = grp; k < nsplit; k += 4) s += src[(size_t)k * taps * 4096];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (grp == 0 && idx < total)
+    dw[((size_t)co * Cin + ci) * taps + tap] += red[o] + red[64 + o] + red[128 + o] + red[192 + o];
 }
 
 // Packs OIHW weights into the LDS image of conv_mfma_kernel: [cob][chunk][tap][g][h][64][4].

@@ -26,6 +26,15 @@ __device__ __forceinline__ float wave_prod(float v) {
   return v;
 }
 
+// block (4 waves) sum of a per-wave value held by lane 0 of each wave; result valid in thread 0
+__device__ __forceinline__ float block_sum_of_waves(float v, float* smem4) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) smem4[wave] = v;
+  __syncthreads();
+  return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
 // Device-side accumulators / coefficients of one pair step (doubles for order-insensitive sums).
 struct StepAccum {
   double det_sum[2];    // sum over cells of mask * sum_c BCE, per view
@@ -41,17 +50,20 @@ struct StepAccum {
 // ---- cell masks: one wave per cell; lane = dy*8+dx --------------------------------------------
 __global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict__ mask2d, float* __restrict__ cellmask,
                                                         double* __restrict__ mask_cnt, int B, int H, int W) {
+  __shared__ float red[4];
   const int Hc = H / 8, Wc = W / 8;
-  const int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (cell >= B * Hc * Wc) return;
-  const int cx = cell % Wc, cy = (cell / Wc) % Hc, n = cell / (Wc * Hc);
-  const float m = mask2d[((size_t)n * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
-  const float p = wave_prod(m);
-  if (lane == 0) {
-    cellmask[cell] = p;
-    unsafeAtomicAdd(mask_cnt, (double)p);
+  const int ncell = B * Hc * Wc;
+  float cnt = 0.f;
+  for (int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; cell < ncell; cell += (gridDim.x * blockDim.x) >> 6) {
+    const int cx = cell % Wc, cy = (cell / Wc) % Hc, n = cell / (Wc * Hc);
+    const float m = mask2d[((size_t)n * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
+    const float p = wave_prod(m);
+    if (lane == 0) cellmask[cell] = p;
+    cnt += p;
   }
+  const float tot = block_sum_of_waves(cnt, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(mask_cnt, (double)tot);
 }
 
 // ---- labels2Dto3D as an operator (parity tests): target [B,65,Hc,Wc] NCHW, same arithmetic as the
@@ -81,43 +93,49 @@ __global__ __launch_bounds__(256) void detector_loss_kernel(const float* __restr
                                                             const float* __restrict__ cellmask, float* __restrict__ dsemi,
                                                             StepAccum* __restrict__ acc, int view, int B, int H, int W,
                                                             int cs) {
+  __shared__ float red[4];
   const int Hc = H / 8, Wc = W / 8;
-  const int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (cell >= B * Hc * Wc) return;
-  const int cx = cell % Wc, cy = (cell / Wc) % Hc, n = cell / (Wc * Hc);
-  // labels2Dto3D: channel = dy*8+dx ; dustbin = 1 - sum, zeroed when < 1 ; renormalise
-  const float lab = labels2d[((size_t)n * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
-  const float lsum = wave_sum(lab);
-  float dust = 1.f - lsum;
-  if (dust < 1.f) dust = 0.f;
-  const float dn = lsum + dust;
-  const float t = lab / dn, td = dust / dn;
-  // logits
-  const float* yp = ypb + (size_t)cell * cs;
-  const float s = fmaf(yp[lane], scale[lane], shift[lane]);
-  const float sd = fmaf(yp[64], scale[64], shift[64]);
-  const float mx = fmaxf(wave_max(s), sd);
-  const float e = expf(s - mx), ed = expf(sd - mx);
-  const float inv = 1.f / (wave_sum(e) + ed);
-  const float p = e * inv, pd = ed * inv;
-  // BCELoss: -(t*max(log p,-100) + (1-t)*max(log(1-p),-100))
-  const float l = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1pf(-p), -100.f));
-  const float ld = -(td * fmaxf(logf(pd), -100.f) + (1.f - td) * fmaxf(log1pf(-pd), -100.f));
-  const float m = cellmask[cell];
-  const float tot = wave_sum(l) + ld;
-  if (lane == 0) unsafeAtomicAdd(&acc->det_sum[view], (double)(tot * m));
-  if (dsemi != nullptr) {
-    const float coef = acc->coef_det * m / ((float)acc->mask_cnt[view] + 1e-5f);
-    // BCE backward: (p - t) / max(p*(1-p), 1e-12) ; softmax backward: p_j * (g_j - sum_c g_c p_c)
-    const float g = (p - t) / fmaxf(p * (1.f - p), 1e-12f);
-    const float gd = (pd - td) / fmaxf(pd * (1.f - pd), 1e-12f);
-    const float dot = wave_sum(g * p) + gd * pd;
-    float* dp = dsemi + (size_t)cell * cs;
-    dp[lane] = coef * p * (g - dot);
-    if (lane == 0) dp[64] = coef * pd * (gd - dot);
-    if (lane >= 1 && lane < cs - 64) dp[64 + lane] = 0.f;
+  const int ncell = B * Hc * Wc;
+  const float sc_l = scale[lane], sh_l = shift[lane], sc_d = scale[64], sh_d = shift[64];
+  const float coef0 = (dsemi != nullptr) ? acc->coef_det / ((float)acc->mask_cnt[view] + 1e-5f) : 0.f;
+  float lsum_acc = 0.f;
+  for (int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; cell < ncell; cell += (gridDim.x * blockDim.x) >> 6) {
+    const int cx = cell % Wc, cy = (cell / Wc) % Hc, n = cell / (Wc * Hc);
+    // labels2Dto3D: channel = dy*8+dx ; dustbin = 1 - sum, zeroed when < 1 ; renormalise
+    const float lab = labels2d[((size_t)n * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
+    const float lsum = wave_sum(lab);
+    float dust = 1.f - lsum;
+    if (dust < 1.f) dust = 0.f;
+    const float dn = lsum + dust;
+    const float t = lab / dn, td = dust / dn;
+    // logits
+    const float* yp = ypb + (size_t)cell * cs;
+    const float s = fmaf(yp[lane], sc_l, sh_l);
+    const float sd = fmaf(yp[64], sc_d, sh_d);
+    const float mx = fmaxf(wave_max(s), sd);
+    const float e = expf(s - mx), ed = expf(sd - mx);
+    const float inv = 1.f / (wave_sum(e) + ed);
+    const float p = e * inv, pd = ed * inv;
+    // BCELoss: -(t*max(log p,-100) + (1-t)*max(log(1-p),-100))
+    const float l = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1pf(-p), -100.f));
+    const float ld = -(td * fmaxf(logf(pd), -100.f) + (1.f - td) * fmaxf(log1pf(-pd), -100.f));
+    const float m = cellmask[cell];
+    lsum_acc += (wave_sum(l) + ld) * m;
+    if (dsemi != nullptr) {
+      const float coef = coef0 * m;
+      // BCE backward: (p - t) / max(p*(1-p), 1e-12) ; softmax backward: p_j * (g_j - sum_c g_c p_c)
+      const float g = (p - t) / fmaxf(p * (1.f - p), 1e-12f);
+      const float gd = (pd - td) / fmaxf(pd * (1.f - pd), 1e-12f);
+      const float dot = wave_sum(g * p) + gd * pd;
+      float* dp = dsemi + (size_t)cell * cs;
+      dp[lane] = coef * p * (g - dot);
+      if (lane == 0) dp[64] = coef * pd * (gd - dot);
+      if (lane >= 1 && lane < cs - 64) dp[64 + lane] = 0.f;
+    }
   }
+  const float tot = block_sum_of_waves(lsum_acc, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&acc->det_sum[view], (double)tot);
 }
 
 // ---- sparse descriptor loss --------------------------------------------------------------------
@@ -180,6 +198,7 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
   const float dot = wave_sum(va.x * vb.x + va.y * vb.y + va.z * vb.z + va.w * vb.w);
   const float hinge = fmaxf(1.f - dot, 0.f);
   if (!BWD) {
+    // n_match is a multiple of 4 in every config: the 4 waves of a block belong to one image
     if (lane == 0) unsafeAtomicAdd(&acc->pos_sum[img], (double)hinge);
   } else if (hinge > 0.f) {
     const float c = -acc->coef_pos / ((float)n_match * (float)B);  // d total / d dot

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -206,13 +207,13 @@ static size_t carve(ssp_handle* h, void* base) {
     S.ddesc = c.take<float>(cells * 256);
     // BN buffers; the fp64 sums of all layers are contiguous so that one memset clears them
     size_t nst = 0;
-    for (int l = 0; l < h->nlayers; ++l) nst += 4 * (size_t)h->L[l].cout;
+    for (int l = 0; l < h->nlayers; ++l) nst += 4 * (size_t)h->L[l].cout * NREP;
     double* st = c.take<double>(nst);
     S.stats_region = st; S.stats_bytes = nst * sizeof(double);
     for (int l = 0; l < h->nlayers; ++l) {
       const int C = h->L[l].cout;
-      S.bn[l].stats = st; st += 2 * C;
-      S.bn[l].bsums = st; st += 2 * C;
+      S.bn[l].stats = st; st += 2 * C * NREP;
+      S.bn[l].bsums = st; st += 2 * C * NREP;
       S.bn[l].scale = c.take<float>(C); S.bn[l].shift = c.take<float>(C);
       S.bn[l].mean = c.take<float>(C); S.bn[l].invstd = c.take<float>(C);
     }
@@ -351,7 +352,7 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
 #undef WG_CASE
   }
   const int total = c.cout * c.cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, partial, c.dw, c.cin, c.cout, c.ks,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, c.dw, c.cin, c.cout, c.ks,
                      a.ncob, nsplit);
   HIPCHK(hipGetLastError());
   return 0;
@@ -373,7 +374,7 @@ static int launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
   const int nq = (a.C + 3) / 4, rows = 256 / nq;
   const long npix = (long)a.N * (POOL ? a.H / 2 : a.H) * (POOL ? a.W / 2 : a.W);
   int nb = cdiv(npix, rows);
-  if (nb > 4096) nb = 4096;
+  if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb), dim3(256), 0, st, a);
   hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
@@ -570,7 +571,7 @@ static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* d
   }
   if (l == 0) {
     const long npix = (long)N * H * W;
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(cdiv(npix, 16 * C0_ITERS)), dim3(256), 0, st, S.x, dy, Gd(h, d.w_off), N,
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(cdiv(npix, 16 * C0W_ITERS)), dim3(256), 0, st, S.x, dy, Gd(h, d.w_off), N,
                        H, W);
     HIPCHK(hipGetLastError());
     return 0;
@@ -600,7 +601,8 @@ static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float
   const int N = S.N, H = S.H, W = S.W, Hc = H / 8, Wc = W / 8;
   const int hcs = 256 * h->nheads;
   // zero the backward fp64 sums (interleaved with the forward stats: clear only the bsums halves)
-  for (int l = 0; l < h->nlayers; ++l) HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * h->L[l].cout * sizeof(double), st));
+  for (int l = 0; l < h->nlayers; ++l)
+    HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * (size_t)h->L[l].cout * NREP * sizeof(double), st));
   float* dHeadsAct = h->gP;  // grad wrt relu(bn(conv{Pa,Da,DS})) [cells][hcs]
   float* dYtmp = h->gQ;
   const bool has_semi = dsemi != nullptr, has_desc = draw_desc != nullptr, has_sem = dsout != nullptr && h->nheads == 3;
@@ -765,12 +767,12 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
   for (int v = 0; v < 2; ++v) {
     Slot& S = h->slot[v];
-    hipLaunchKernelGGL(cell_mask_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, masks[v], S.cellmask,
+    hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, st, masks[v], S.cellmask,
                        &h->accum->mask_cnt[v], B, H, W);
   }
   for (int v = 0; v < 2; ++v) {
     Slot& S = h->slot[v];
-    hipLaunchKernelGGL(detector_loss_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
+    hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
                        S.bn[L_PB].shift, labels[v], S.cellmask, in->train ? S.dsemi : nullptr, h->accum, v, B, H, W, 80);
   }
   HIPCHK(hipGetLastError());
@@ -884,7 +886,7 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
                   float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int hh,
                   int w, int c, int relu, int pool, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(hipMemsetAsync(sums_dev, 0, 2 * c * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(sums_dev, 0, 2 * (size_t)c * NREP * sizeof(double), st));
   BnBwdArgs a;
   a.y = y_dev; a.dout = dout_dev; a.dy = dy_dev; a.scale = stats4_dev; a.shift = stats4_dev + c; a.mean = stats4_dev + 2 * c;
   a.invstd = stats4_dev + 3 * c; a.gamma = gamma_dev; a.sums = sums_dev; a.dbias = dbias_dev; a.N = n; a.H = hh; a.W = w;
@@ -951,7 +953,8 @@ int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* tar
   if (mask2d_dev && cellmask_dev) {
     double* cnt = nullptr;
     HIPCHK(hipMallocAsync((void**)&cnt, sizeof(double), st));
-    hipLaunchKernelGGL(cell_mask_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, mask2d_dev, cellmask_dev, cnt, b, hh, w);
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(double), st));
+    hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, st, mask2d_dev, cellmask_dev, cnt, b, hh, w);
     HIPCHK(hipFreeAsync(cnt, st));
   }
   HIPCHK(hipGetLastError());

@@ -17,6 +17,7 @@ ARCHS = {"SuperPointNet_gauss2": 0, "SuperPointNet_gauss2_ssmall": 1}
 SCALAR_NAMES = ["loss", "loss_det", "loss_det_warp", "loss_desc", "loss_sem", "loss_sem_warp", "positive_dist",
                 "negative_dist", "eta_det", "eta_desc", "eta_sem"]
 N_SCALARS = 16
+NREP = 32  # SSP_NREP
 PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4, "conv3x3_all": 5}
 
 
@@ -412,7 +413,7 @@ def op_bn_bwd(y_nhwc, dout_nhwc, gamma, scale, shift, mean, invstd, relu=True, p
     stats4 = torch.cat([scale, shift, mean, invstd]).contiguous()
     dy = torch.empty_like(y_nhwc)
     dg, db, dbias = (torch.zeros(Cc, dtype=torch.float32, device=dev) for _ in range(3))
-    sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+    sums = torch.zeros(NREP * 2 * Cc, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         _check(lib.ssp_op_bn_bwd(_ptr(y_nhwc), _ptr(dout_nhwc), _ptr(gamma), _ptr(stats4), _ptr(dy), _ptr(dg), _ptr(db),
                                  _ptr(dbias), _ptr(sums), N, H, W, Cc, int(relu), int(pool), _stream()))

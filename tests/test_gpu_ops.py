@@ -53,9 +53,10 @@ def test_conv_forward(N, H, W, cin, cout, ks, mode):
     sc = torch.from_numpy(rs.uniform(-1.5, 1.5, cin).astype(np.float32))  # negative scales too
     sh = torch.from_numpy(rs.uniform(-0.5, 0.5, cin).astype(np.float32))
     ref = F.conv2d(_ref_input(x, mode, sc, sh), w, b, padding=ks // 2).permute(0, 2, 3, 1).contiguous()
-    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    stats = torch.zeros(L.NREP, 2 * cout, dtype=torch.float64, device=dev)
     out = L.op_conv(x.to(dev), w.to(dev), b.to(dev), ks, mode, sc.to(dev), sh.to(dev), stats)
     torch.cuda.synchronize()
+    stats = stats.sum(0)
     assert _rel(out.cpu(), ref) < 2e-4
     s_ref = ref.double().sum(dim=(0, 1, 2))
     q_ref = (ref.double() ** 2).sum(dim=(0, 1, 2))
