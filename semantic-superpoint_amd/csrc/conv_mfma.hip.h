@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace sspk {
 
@@ -34,6 +35,7 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int nchunks, ncob;
   int accumulate;         // out += result
+  int ablate;             // perf-debug only (tools/ablate_conv.py): 1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA
 };
 
 // lane/row index m (0..31) of an MFMA M-tile -> pixel (r,c) inside the SH x SW sub-rectangle.
@@ -109,6 +111,13 @@ struct ConvGeom {
 
 // Block: 256 threads (4 waves).  Output tile: (8*SH) x SW pixels x 64 output channels; wave w owns M-tiles
 // 2w, 2w+1 (32 pixels each) x both 32-channel N-tiles -> 4 accumulators of 32x32.
+//
+// PERSISTENT: the grid is 2 blocks per CU (a multiple of 8).  Block b runs on XCD b%8 (observed placement; only
+// speed depends on it), owns ONE 64-channel output block `cob` and walks the tiles of its XCD's contiguous tile
+// range, so neighbouring tiles (shared halos) and the cob's packed weights stay in that XCD's L2.  The loads of
+// the next (tile, chunk) step are issued before the MFMAs of the current step, the output stores of a tile are
+// fire-and-forget and drain under the next tile's MFMAs, and the BatchNorm sums are kept in registers until the
+// block ends (one atomic flush per block instead of one per tile).
 template <int KS, int IN_MODE, int SH, int SW>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   using G = ConvGeom<KS, SH, SW>;
@@ -120,14 +129,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int cob = id % a.ncob;
-  int tile = id / a.ncob;
-  const int tx = tile % a.tiles_x;
-  tile /= a.tiles_x;
-  const int ty = tile % a.tiles_y;
-  const int n = tile / a.tiles_y;
-  const int ty0 = ty * G::TH, tx0 = tx * G::TW;
+  // ---- work assignment ----
+  const int nslot = gridDim.x >> 3;             // blocks per XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_cob = nslot / a.ncob;           // blocks per (XCD, cob)
+  const int cob = slot % a.ncob, jj = slot / a.ncob;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const int per_t = (ntiles + 7) >> 3;
+  const int t_end = min(ntiles, (xcd + 1) * per_t);
+  int tile = xcd * per_t + jj;
+  if (jj >= per_cob || tile >= t_end) return;   // whole block exits before any barrier
 
   int pr, pc;
   mpix<SW>(li, pr, pc);
@@ -136,93 +147,180 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   for (int mt = 0; mt < 2; ++mt) aoff[mt] = (((wave * 2 + mt) * SH + pr) * G::RP + pc) * CS + lh * 4;
   const int boff = (lh * NB + li) * 4;
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int q4 = tid & 3;
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    __syncthreads();
-    // ---- stage input halo tile (with BN/ReLU/pool of the producer applied) ----
-    {
-      const int c0 = chunk * CK + q4 * 4;
-      const bool cvalid = c0 < a.Cin;
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (IN_MODE != 0 && cvalid) {
-        sc = *reinterpret_cast<const float4*>(a.in_scale + c0);
-        sh = *reinterpret_cast<const float4*>(a.in_shift + c0);
-      }
-      const int coff = a.in_co + c0;
-#pragma unroll 2
-      for (int pp = tid >> 2; pp < G::HT * G::WT; pp += 64) {
-        const int r = pp / G::WT, c = pp - r * G::WT;
-        const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs, coff,
-                                          cvalid, sc, sh);
-        *reinterpret_cast<float4*>(sA + (r * G::RP + c) * CS + q4 * 4) = v;
-      }
-    }
-    // ---- stage weight chunk (straight copy of the pre-packed image) ----
-    {
-      const float4* src =
-          reinterpret_cast<const float4*>(a.wpk + (size_t)(cob * a.nchunks + chunk) * G::B_FLOATS);
-      float4* dst = reinterpret_cast<float4*>(sB);
+  constexpr int NH = (G::HT * G::WT + 63) / 64;
+  constexpr int NW = G::B_FLOATS / 4 / 256;
+  f32x4 hreg[NH], wreg[NW];
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  int hoff[NH];     // element offset (pixel index) of halo slot i for the tile being LOADED, -1 = outside
+  int lds_off[NH];  // float offset in sA (tile independent), -1 = unused slot
 #pragma unroll
-      for (int i = tid; i < G::B_FLOATS / 4; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
-    // ---- MFMA ----
-#pragma unroll
-    for (int tap = 0; tap < G::TAPS; ++tap) {
-      const int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-      for (int g = 0; g < CK / 8; ++g) {
-        const float4 a0 = *reinterpret_cast<const float4*>(sA + aoff[0] + (dy * G::RP + dx) * CS + g * 8);
-        const float4 a1 = *reinterpret_cast<const float4*>(sA + aoff[1] + (dy * G::RP + dx) * CS + g * 8);
-        const float4 b0 = *reinterpret_cast<const float4*>(sB + boff + (tap * (CK / 8) + g) * 2 * NB * 4);
-        const float4 b1 = *reinterpret_cast<const float4*>(sB + boff + (tap * (CK / 8) + g) * 2 * NB * 4 + 32 * 4);
-        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
-        }
-      }
-    }
+  for (int i = 0; i < NH; ++i) {
+    const int pp = (tid >> 2) + 64 * i;
+    const int r = pp / G::WT, c = pp - r * G::WT;
+    lds_off[i] = (pp < G::HT * G::WT) ? (r * G::RP + c) * CS + q4 * 4 : -1;
+  }
+  // tile decode + halo slot offsets of the tile whose loads are issued next
+  int ld_n, ld_ty0, ld_tx0;
+#define SSP_DECODE_TILE(T)                                                                               \
+  {                                                                                                      \
+    const int tx_ = (T) % a.tiles_x, t2_ = (T) / a.tiles_x;                                              \
+    ld_tx0 = tx_ * G::TW;                                                                                \
+    ld_ty0 = (t2_ % a.tiles_y) * G::TH;                                                                  \
+    ld_n = t2_ / a.tiles_y;                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                                     \
+      const int pp = (tid >> 2) + 64 * i;                                                                \
+      const int r = pp / G::WT, c = pp - r * G::WT;                                                      \
+      const int gy = ld_ty0 + r - G::PAD, gx = ld_tx0 + c - G::PAD;                                      \
+      const bool ok = pp < G::HT * G::WT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
+      hoff[i] = ok ? ((ld_n * a.H + gy) * a.W + gx) : -1;                                                \
+    }                                                                                                    \
+  }
+#define SSP_ISSUE_LOADS(CHUNK)                                                                          \
+  if (!(a.ablate & 1)) {                                                                                \
+    const int c0_ = (CHUNK) * CK + q4 * 4;                                                              \
+    const bool cvalid_ = c0_ < a.Cin;                                                                   \
+    if (IN_MODE != 0) {                                                                                 \
+      const int cc_ = cvalid_ ? c0_ : 0;                                                                \
+      psc = *reinterpret_cast<const f32x4*>(a.in_scale + cc_);                                          \
+      psh = *reinterpret_cast<const f32x4*>(a.in_shift + cc_);                                          \
+    }                                                                                                   \
+    if (IN_MODE != 2) {                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                                  \
+        const size_t off_ = (hoff[i] >= 0 && cvalid_) ? (size_t)hoff[i] * a.in_cs + a.in_co + c0_ : (size_t)0; \
+        hreg[i] = *reinterpret_cast<const f32x4*>(a.in + off_);                                         \
+      }                                                                                                 \
+    }                                                                                                   \
+    const f32x4* src_ = reinterpret_cast<const f32x4*>(a.wpk + (size_t)(cob * a.nchunks + (CHUNK)) * G::B_FLOATS); \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) wreg[j] = src_[tid + 256 * j];                       \
   }
 
-  // ---- epilogue: bias, store, per-channel sum / sum of squares for the BatchNorm statistics ----
+  SSP_DECODE_TILE(tile)
+  SSP_ISSUE_LOADS(0)
+
   float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+  float bias_v[2];
+  bool covalid[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int co = cob * NB + nt * 32 + li;
-    const bool covalid = co < a.Cout;
-    const float bv = (a.bias != nullptr && covalid) ? a.bias[co] : 0.f;
+    covalid[nt] = co < a.Cout;
+    bias_v[nt] = (a.bias != nullptr && covalid[nt]) ? a.bias[co] : 0.f;
+  }
+
+  for (;;) {  // ---- one output tile per iteration ----
+    const int n = ld_n, ty0 = ld_ty0, tx0 = ld_tx0;  // the tile being computed (= the one just prefetched)
+    unsigned hmask = 0;                               // validity of its halo slots
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int i = 0; i < NH; ++i) hmask |= (hoff[i] >= 0 ? 1u : 0u) << i;
+    const int next_tile = tile + per_cob;
+    const bool has_next = next_tile < t_end;
+
+    f32x16 acc[2][2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        int rr, cc;
-        mpix<SW>(m, rr, cc);
-        const int oy = ty0 + (wave * 2 + mt) * SH + rr, ox = tx0 + cc;
-        if (covalid && oy < a.H && ox < a.W) {
-          float v = acc[mt][nt][r] + bv;
-          float* p = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co;
-          if (a.accumulate) v += *p;
-          *p = v;
-          ssum[nt] += v;
-          ssq[nt] += v * v;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+      __syncthreads();  // every wave has finished reading the LDS image of the previous step
+      if (!(a.ablate & 2)) {
+        const int c0 = chunk * CK + q4 * 4;
+        const bool cvalid = c0 < a.Cin;
+        if (IN_MODE != 2) {
+#pragma unroll
+          for (int i = 0; i < NH; ++i) {
+            if (lds_off[i] >= 0) {
+              f32x4 v = {0.f, 0.f, 0.f, 0.f};
+              if (cvalid && ((hmask >> i) & 1u)) {
+                v = hreg[i];
+                if (IN_MODE != 0) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], psc[e], psh[e]), 0.f);
+                }
+              }
+              *reinterpret_cast<f32x4*>(sA + lds_off[i]) = v;
+            }
+          }
+        } else {
+          const int coff = a.in_co + c0;
+          const float4 sc4 = make_float4(psc[0], psc[1], psc[2], psc[3]), sh4 = make_float4(psh[0], psh[1], psh[2], psh[3]);
+#pragma unroll 2
+          for (int pp = tid >> 2; pp < G::HT * G::WT; pp += 64) {
+            const int r = pp / G::WT, c = pp - r * G::WT;
+            const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs, coff,
+                                              cvalid, sc4, sh4);
+            *reinterpret_cast<float4*>(sA + (r * G::RP + c) * CS + q4 * 4) = v;
+          }
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(sB);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) dst[tid + 256 * j] = wreg[j];
+      }
+      __syncthreads();
+      // Unconditional prefetch of the next step: next chunk of this tile, or chunk 0 of the block's next tile
+      // (of this tile again when it was the last: redundant but free of control flow, so the loads stay in
+      // flight during the MFMAs below).
+      {
+        const bool last = chunk + 1 == a.nchunks;
+        if (last && has_next) SSP_DECODE_TILE(next_tile)
+        const int nxt = last ? 0 : chunk + 1;
+        SSP_ISSUE_LOADS(nxt)
+        __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the loads below the MFMAs (checked in the ISA)
+      }
+      // ---- MFMA ----
+      if (!(a.ablate & 8))
+#pragma unroll
+      for (int tap = 0; tap < G::TAPS; ++tap) {
+        const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+        for (int g = 0; g < CK / 8; ++g) {
+          const float4 a0 = *reinterpret_cast<const float4*>(sA + aoff[0] + (dy * G::RP + dx) * CS + g * 8);
+          const float4 a1 = *reinterpret_cast<const float4*>(sA + aoff[1] + (dy * G::RP + dx) * CS + g * 8);
+          const float4 b0 = *reinterpret_cast<const float4*>(sB + boff + (tap * (CK / 8) + g) * 2 * NB * 4);
+          const float4 b1 = *reinterpret_cast<const float4*>(sB + boff + (tap * (CK / 8) + g) * 2 * NB * 4 + 32 * 4);
+          const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+          const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
+          }
         }
       }
     }
+
+    // ---- tile epilogue: bias, store (fire and forget), BatchNorm partial sums in registers ----
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int co = cob * NB + nt * 32 + li;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int rr, cc;
+          mpix<SW>(m, rr, cc);
+          const int oy = ty0 + (wave * 2 + mt) * SH + rr, ox = tx0 + cc;
+          if (covalid[nt] && oy < a.H && ox < a.W && !(a.ablate & 4)) {
+            float v = acc[mt][nt][r] + bias_v[nt];
+            float* p = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co;
+            if (a.accumulate) v += *p;
+            *p = v;
+            ssum[nt] += v;
+            ssq[nt] += v * v;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    tile = next_tile;
   }
+
   if (a.stats != nullptr) {
     __syncthreads();
     float* red = smem;  // [4 waves][2 nt][32][2]
@@ -247,6 +345,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 }
+
+#undef SSP_DECODE_TILE
+#undef SSP_ISSUE_LOADS
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient.  Block = 4 waves; block owns a 64(ci) x 64(co) x TAPS slab and loops over spatial tiles

@@ -277,10 +277,15 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   a.stats = c.stats; a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
   a.Cout = c.cout; a.out_cs = c.out_cs; a.out_co = c.out_co; a.nchunks = c.nchunks; a.ncob = c.ncob;
   a.accumulate = c.accumulate;
+  a.ablate = getenv("SSP_ABLATE_CONV") ? atoi(getenv("SSP_ABLATE_CONV")) : 0;
   const bool wide = (c.W % 32) == 0;
   const int TH = wide ? 8 : 32, TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
-  const int nblocks = c.N * a.tiles_x * a.tiles_y * c.ncob;
+  // persistent grid: 2 blocks per CU (LDS-limited residency), a multiple of 8 (one slot set per XCD)
+  const int n_cu = h ? h->n_cu : 256;
+  int nblocks = std::max(8, (2 * n_cu) / 8 * 8);
+  if (getenv("SSP_CONV_GRID")) nblocks = atoi(getenv("SSP_CONV_GRID"));  // perf-debug only
+  if ((nblocks / 8) < c.ncob) return fail(-3, "too many output-channel blocks (%d) for the persistent grid", c.ncob);
   const double flops = 2.0 * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
   const double bytes = 4.0 * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
   int fam = prof_family;
