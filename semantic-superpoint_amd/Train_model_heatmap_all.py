@@ -1,0 +1,240 @@
+"""Drop-in for the reference's trainer plugin `Train_model_heatmap_all` (Train_model_heatmap_all.py:80-572 on top
+of Train_model_frontend_all.py:100-439): same constructor, same `loadModel / dataParallel / train /
+train_val_sample / saveModel`, same `scalar_dict` and writer calls - but the whole pair step (2 forwards, label
+ops, losses, backward) is ONE call into libssp_hip.so (`ssp_pair_step`) followed by the fused Adam kernel.
+
+Deliberate behaviours kept from the reference:
+  * the live optimizer's learning rate is CONSTANT (the scheduler built in loadModel drives an orphaned Adam);
+  * gradients accumulate un-scaled over micro-batches until ((n_iter+1)*batch) % real_batch_size == 0;
+  * scalar_dict["eta_*"] are read AFTER the optimizer step (the reference logs the live parameter);
+  * validation (train=False) runs BatchNorm in train mode under no_grad, i.e. it updates running statistics.
+Not reproduced (out of the accelerated path): the tensorboard image / precision-recall branch every
+`tensorboard_interval` steps (Train_model_heatmap_all.py:447-568) - scalars are still logged.
+"""
+import copy
+import logging
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import parallel
+from .models import SuperPointNet_gauss2, SuperPointNet_gauss2_ssmall
+
+_MODELS = {"SuperPointNet_gauss2": SuperPointNet_gauss2, "SuperPointNet_gauss2_ssmall": SuperPointNet_gauss2_ssmall}
+
+
+def dict_update(d, u):
+    """Nested dict merge (utils/tools.py:7-23 semantics)."""
+    for k, v in u.items():
+        if isinstance(v, dict):
+            d[k] = dict_update(d.get(k, {}) or {}, v)
+        else:
+            d[k] = v
+    return d
+
+
+def sample_sparse_indices_host(homographies, Hc, Wc, n_match, n_non):
+    """Reference-faithful HOST sampling of the sparse-loss indices (sparse_loss.py:184-246,
+    correspondence_finder.py:29-34,278-280): consumes numpy's and torch's global CPU RNG streams in the
+    reference's order, so a run seeded like the reference draws the same indices.  Returns int32 tensors."""
+    ma, mb, nm = [], [], []
+    for Hn in homographies.detach().cpu().float():
+        vs, us = torch.meshgrid(torch.arange(Hc), torch.arange(Wc), indexing="ij")
+        uv_a = torch.stack((us.reshape(-1), vs.reshape(-1)), dim=1).float()
+        T = torch.tensor([[2.0 / Wc, 0.0, -1.0], [0.0, 2.0 / Hc, -1.0], [0.0, 0.0, 1.0]])
+        Hcell = torch.inverse(T) @ Hn @ T
+        w = (Hcell @ torch.cat((uv_a, torch.ones(uv_a.shape[0], 1)), dim=1).t()).t()
+        uv_b = (w[:, :2] / w[:, 2:]).round()
+        keep = (uv_b[:, 0] >= 0) & (uv_b[:, 0] <= Wc - 1) & (uv_b[:, 1] >= 0) & (uv_b[:, 1] <= Hc - 1)
+        uv_a, uv_b = uv_a[keep], uv_b[keep]
+        n = uv_b.shape[0]
+        choice = np.random.permutation(n)
+        if n >= n_match:
+            choice = choice[:n_match]
+        else:
+            choice = np.concatenate([choice, np.random.choice(choice, n_match - n, replace=True)])
+        choice = torch.as_tensor(choice).long()
+        uv_a, uv_b = uv_a[choice], uv_b[choice]
+        K = n_match * n_non
+        two = torch.rand(2, K)
+        nu, nv = torch.floor(two[0] * Wc).long(), torch.floor(two[1] * Hc).long()
+        torch.rand(K)   # the no-op "perturbation" of the reference still burns these two draws
+        torch.randn(K)
+        ma.append((uv_a[:, 0] + uv_a[:, 1] * Wc).int())
+        mb.append((uv_b[:, 0] + uv_b[:, 1] * Wc).int())
+        nm.append((nu + nv * Wc).int())
+    return torch.stack(ma), torch.stack(mb), torch.stack(nm)
+
+
+class Train_model_heatmap_all(object):
+    default_config = {
+        "train_iter": 170000, "save_interval": 2000, "tensorboard_interval": 200,
+        "model": {"subpixel": {"enable": False}}, "data": {"gaussian_label": {"enable": False}},
+    }
+
+    def __init__(self, config, save_path=Path("."), device="cpu", verbose=False):
+        self.config = dict_update(copy.deepcopy(self.default_config), copy.deepcopy(config))
+        m = self.config["model"]
+        self.r = m["real_batch_size"] // m["batch_size"]
+        for k in ("train_iter", "validation_interval", "tensorboard_interval", "save_interval"):
+            self.config[k] *= self.r
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Train_model_heatmap_all (MI355X build) needs a HIP device, got %s" % device)
+        self.save_path = Path(save_path)
+        self._train, self._eval = True, True
+        self.cell_size = 8
+        self.real_batch_size = m["real_batch_size"]
+        self.max_iter = self.config["train_iter"]
+        self.gaussian = bool(self.config["data"]["gaussian_label"]["enable"])
+        if m.get("dense_loss", {}).get("enable", False):
+            raise NotImplementedError("dense descriptor loss (utils/utils.py:779-893) is outside the accelerated path")
+        if not m.get("sparse_loss", {}).get("enable", False):
+            raise KeyError("model.sparse_loss.enable must be true")
+        self.desc_params = m["sparse_loss"]["params"]
+        if self.desc_params.get("method", "2d") != "2d" or self.desc_params.get("dist", "cos") != "cos":
+            raise NotImplementedError("only sparse_loss method='2d', dist='cos' (all shipped configs) is accelerated")
+        self.desc_loss_type = "sparse"
+        self.sampler = self.config.get("ssp_sampler", "device")  # "device" | "reference" (host RNG streams)
+        self.n_iter = 0
+        self.net = None
+        self._writer = None
+        self.scalar_dict, self.images_dict, self.hist_dict = {}, {}, {}
+
+    # ---- properties of the reference base class ----
+    @property
+    def writer(self):
+        return self._writer
+
+    @writer.setter
+    def writer(self, writer):
+        self._writer = writer
+
+    @property
+    def train_loader(self):
+        return self._train_loader
+
+    @train_loader.setter
+    def train_loader(self, loader):
+        self._train_loader = loader
+
+    @property
+    def val_loader(self):
+        return self._val_loader
+
+    @val_loader.setter
+    def val_loader(self, loader):
+        self._val_loader = loader
+
+    # ---- model / optimizer ----
+    def loadModel(self):
+        name = self.config["model"]["name"]
+        params = self.config["model"].get("params") or {}
+        if name not in _MODELS:
+            raise KeyError("model %r is not on the accelerated path" % name)
+        self.net = _MODELS[name](**params).to(self.device)
+        n_iter = 0
+        if not self.config.get("retrain", True) and self.config.get("pretrained"):
+            path = self.config["pretrained"]
+            ckpt = torch.load(path, map_location="cpu")
+            if path[-4:] == ".pth":
+                self.net.load_state_dict(ckpt)
+            else:
+                self.net.load_state_dict(ckpt["model_state_dict"])
+                n_iter = ckpt.get("n_iter", 0)
+        self.n_iter = 0 if self.config.get("reset_iter", True) else n_iter
+        self.learning_rate = self.config["model"]["learning_rate"]
+        return self.net
+
+    def dataParallel(self):
+        """Reference: re-creates Adam and zeroes the gradients (Train_model_frontend_all.py:171-181).  Here: the
+        fused Adam state lives in the engine; replicas (if torch.distributed is initialised) are made identical."""
+        self._adam_reset = True
+
+    def _engine_for(self, B, H, W):
+        e = self.net.engine(B, H, W, self.device)
+        if getattr(self, "_adam_reset", True):
+            e.adam_m.zero_(); e.adam_v.zero_(); e.adam_t = 0
+            e.zero_grad()
+            parallel.broadcast_(e.params)
+            parallel.broadcast_(e.bn_running)
+            self._adam_reset = False
+        return e
+
+    # ---- the step ----
+    def train_val_sample(self, sample, n_iter=0, train=False):
+        task = "train" if train else "val"
+        cfg, m = self.config, self.config["model"]
+        if not cfg["data"]["warped_pair"]["enable"]:
+            raise NotImplementedError("the accelerated step is the PAIR step (data.warped_pair.enable: true)")
+        img = sample["image"]
+        B, _, H, W = img.shape
+        self.batch_size = B
+        eng = self._engine_for(B, H, W)
+        dev = {k: (v.to(self.device, non_blocking=True).contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
+        for k in ("image", "warped_img", "labels_2D", "warped_labels", "valid_mask", "warped_valid_mask",
+                  "labels_2D_gaussian", "warped_labels_gaussian"):
+            if k in dev:
+                dev[k] = dev[k].float()
+        lam = float(m["lambda_loss"])
+        idx = None
+        if lam > 0 and self.sampler == "reference":
+            idx = tuple(t.to(self.device) for t in sample_sparse_indices_host(
+                sample["homographies"], H // 8, W // 8, eng.n_match, eng.n_non))
+        sc = eng.pair_step(dev, indices=idx, seed=int(cfg.get("ssp_seed", 0)) * 1000003 + n_iter, train=train,
+                           lambda_loss=lam, lamda_d=float(self.desc_params.get("lamda_d", 1)),
+                           multi_task=bool(m["multi_task_loss"]), gaussian=self.gaussian)
+        if train and ((n_iter + 1) * B) % self.real_batch_size == 0:
+            parallel.allreduce_mean_(eng.grads)
+            eng.adam_step(self.learning_rate)
+            eng.zero_grad()
+        vals = sc.cpu().tolist()  # the single host sync of the step (the reference syncs on every .item())
+        s = dict(zip(L.SCALAR_NAMES, vals))
+        eta = eng.eta.cpu().tolist()
+        self.loss = s["loss"]
+        self.scalar_dict = {"loss": s["loss"], "loss_det": s["loss_det"], "loss_det_warp": s["loss_det_warp"],
+                            "loss_desc": s["loss_desc"], "loss_sem": s["loss_sem"], "loss_sem_warp": s["loss_sem_warp"],
+                            "eta_det": eta[0], "eta_desc": eta[1], "positive_dist": s["positive_dist"],
+                            "negative_dist": s["negative_dist"]}
+        if cfg["data"].get("semantic", False):
+            self.scalar_dict["eta_sem"] = eta[2]
+        self.tb_scalar_dict(self.scalar_dict, task)
+        return float(s["loss"])
+
+    def tb_scalar_dict(self, losses, task="training"):
+        if self._writer is None:
+            return
+        for element in list(losses):
+            self._writer.add_scalar(task + "-" + element, losses[element], self.n_iter // self.r)
+
+    # ---- outer loop / checkpoints (Train_model_frontend_all.py:315-359, 422-439) ----
+    def train(self, **options):
+        logging.info("n_iter: %d  max_iter: %d", self.n_iter, self.max_iter)
+        while self.n_iter < self.max_iter:
+            for sample_train in self.train_loader:
+                self.train_val_sample(sample_train, self.n_iter, True)
+                self.n_iter += 1
+                if self._eval and self.n_iter % self.config["validation_interval"] == 0:
+                    for j, sample_val in enumerate(self.val_loader):
+                        self.train_val_sample(sample_val, self.n_iter + j, False)
+                        if j > self.config.get("validation_size", 3):
+                            break
+                if self.n_iter % self.config["save_interval"] == 0:
+                    self.saveModel()
+                if self.n_iter > self.max_iter:
+                    break
+
+    def saveModel(self):
+        """Checkpoint in the reference's wire format {n_iter, model_state_dict, optimizer_state_dict, loss}
+        -> <save_path>/superPointNet_<n_iter>_checkpoint.pth.tar (utils/utils.py:134-140)."""
+        eng = self.net.engine()
+        os.makedirs(self.save_path, exist_ok=True)
+        state = {"n_iter": self.n_iter + 1, "model_state_dict": {k: v.detach().cpu() for k, v in self.net.state_dict().items()},
+                 "optimizer_state_dict": {"adam_m": eng.adam_m.cpu(), "adam_v": eng.adam_v.cpu(), "step": eng.adam_t},
+                 "loss": getattr(self, "loss", None), "eta": eng.eta.cpu()}
+        path = Path(self.save_path) / ("superPointNet_%d_checkpoint.pth.tar" % (self.n_iter + 1))
+        torch.save(state, path)
+        return path

@@ -1,0 +1,128 @@
+"""CPU: the drop-in boundary without a GPU - the C-ABI library loads and exports every symbol declared in
+include/ssp_hip.h, the Python shims expose the reference's state_dict layout, refuse to run on the CPU, and the
+host-side logic (reference-faithful index sampler, data-parallel helpers over gloo) is correct."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cpu_ref as C
+from tests import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import semantic_superpoint_amd as ssp
+    hdr = open(os.path.join(ROOT, "include", "ssp_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(ssp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = ssp.load_library()
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(ssp.lib.EXPORTS) == declared
+
+
+def test_create_without_gpu_reports_layout():
+    """ssp_create / counts need no device memory: parameter and BN layout match the oracle's spec."""
+    import ctypes as Ct
+    import semantic_superpoint_amd as ssp
+    lib = ssp.load_library()
+    for arch, aid in (("SuperPointNet_gauss2", 0), ("SuperPointNet_gauss2_ssmall", 1)):
+        cfg = ssp.lib.SspConfig(aid, 133, 2, 64, 96, 1000, 100)
+        h = Ct.c_void_p()
+        assert lib.ssp_create(Ct.byref(cfg), Ct.byref(h)) == 0, lib.ssp_last_error()
+        n = sum(int(np.prod(s)) for k, s, _ in C.state_spec(arch) if k in C.param_keys(arch))
+        assert lib.ssp_param_count(h) == n
+        assert lib.ssp_bn_layer_count(h) == sum(1 for _, bn, _, _, _ in C.layer_table(arch) if bn)
+        assert lib.ssp_workspace_bytes(h) > 0
+        lib.ssp_destroy(h)
+    bad = ssp.lib.SspConfig(0, 133, 2, 60, 96, 1000, 100)  # H not a multiple of 8
+    assert lib.ssp_create(Ct.byref(bad), Ct.byref(h)) != 0 and b"multiples of 8" in lib.ssp_last_error()
+
+
+@pytest.mark.parametrize("arch", ["SuperPointNet_gauss2", "SuperPointNet_gauss2_ssmall"])
+def test_module_state_dict_is_the_reference_wire_format(arch):
+    from semantic_superpoint_amd import models
+    net = getattr(models, arch)()
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(s)) for k, s, _ in C.state_spec(arch)]
+    assert [k for k, _ in net.named_parameters()] == C.param_keys(arch)
+    sd = C.init_state_dict(arch, seed=1)
+    net.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in sd.items()})  # golden weights load unchanged
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 1, 8, 8))
+
+
+def test_trainer_refuses_cpu_and_unsupported_configs():
+    from semantic_superpoint_amd.Train_model_heatmap_all import Train_model_heatmap_all as T
+    cfg = {"data": {"semantic": False, "gaussian_label": {"enable": True}, "warped_pair": {"enable": True}},
+           "model": {"name": "SuperPointNet_gauss2", "params": {}, "batch_size": 2, "real_batch_size": 2,
+                     "learning_rate": 1e-3, "lambda_loss": 1, "multi_task_loss": True,
+                     "dense_loss": {"enable": False}, "sparse_loss": {"enable": True, "params": {"method": "2d", "dist": "cos"}}},
+           "validation_interval": 10}
+    with pytest.raises(RuntimeError, match="HIP device"):
+        T(cfg, device="cpu")
+
+
+def test_host_sampler_reproduces_reference_indices():
+    """`ssp_sampler: reference` consumes numpy/torch RNG like the reference: same seeds => G4's indices."""
+    from semantic_superpoint_amd.Train_model_heatmap_all import sample_sparse_indices_host
+    g = G.load("g4_sparse_loss_small.npz")
+    np.random.seed(123)
+    torch.manual_seed(321)
+    ma, mb, nm = sample_sparse_indices_host(torch.from_numpy(g["H"]), 4, 6, 1000, 100)
+    for i in range(ma.shape[0]):
+        assert np.array_equal(ma[i].numpy(), (g["uv_a%d" % i][:, 0] + g["uv_a%d" % i][:, 1] * 6).astype(np.int32))
+        assert np.array_equal(mb[i].numpy(), (g["uv_b%d" % i][:, 0] + g["uv_b%d" % i][:, 1] * 6).astype(np.int32))
+        assert np.array_equal(nm[i].numpy(), g["nm_b%d" % i].astype(np.int32))
+
+
+def test_synthetic_pair_generator_matches_oracle_warps():
+    """semantic-superpoint_amd/synth.py (product side) against the oracle's restatement of the dataset warps."""
+    from semantic_superpoint_amd import synth
+    s = synth.make_pair(2, 40, 56, "cpu", seed=3, semantic=True)
+    inv = s["inv_homographies"]
+    w = C.inv_warp_image_batch(s["image"], inv)
+    assert (w - s["warped_img"]).abs().max() < 1e-5
+    vm = C.compute_valid_mask((40, 56), inv, erosion_radius=3).view(2, 1, 40, 56)
+    assert float((vm != s["warped_valid_mask"]).float().mean()) < 2e-3
+    for i in range(2):
+        pts = torch.nonzero(s["labels_2D"][i, 0]).flip(1)
+        assert torch.equal(C.warp_labels(pts, 40, 56, s["homographies"][i]), s["warped_labels"][i])
+    assert s["semantic"].dtype == torch.int64 and int(s["warped_sem"].max()) <= 133
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from semantic_superpoint_amd import parallel
+    r, w = parallel.init_from_env(backend="gloo")
+    g = torch.full((1000,), float(rank + 1))
+    parallel.allreduce_mean_(g)
+    p = torch.full((10,), float(rank))
+    parallel.broadcast_(p, src=0)
+    q.put((rank, float(g[0]), float(p[0]), parallel.shard_batch(7)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_helpers_gloo_world2():
+    """N > 1 path on CPU: gradient bucket mean, replica broadcast and unit sharding with 2 gloo processes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 1.5          # mean of (1, 2)
+    assert res[0][2] == res[1][2] == 0.0          # broadcast from rank 0
+    assert res[0][3] == (0, 4) and res[1][3] == (4, 7)
