@@ -34,7 +34,7 @@ struct ConvArgs {
   int Cout, out_cs, out_co;
   int tiles_x, tiles_y;
   int nchunks, ncob;
-  int accumulate;         // out += result
+  unsigned in_bytes, out_bytes, wpk_bytes;  // sizes for the buffer resource descriptors (clamped to 2^32-1)
   int ablate;             // perf-debug only (tools/ablate_conv.py): 1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA
 };
 
@@ -106,7 +106,8 @@ struct ConvGeom {
   static constexpr int RP = (SW == 32) ? WT : 12;  // LDS row pitch in pixels
   static constexpr int A_FLOATS = HT * RP * CS;
   static constexpr int B_FLOATS = TAPS * CK * NB;
-  static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
+  static constexpr int O_FLOATS = TH * TW * NB;  // output tile staged for the transposed store
+  static constexpr int LDS_BYTES = ((A_FLOATS + B_FLOATS) > O_FLOATS ? (A_FLOATS + B_FLOATS) : O_FLOATS) * 4;
 };
 
 // Block: 256 threads (4 waves).  Output tile: (8*SH) x SW pixels x 64 output channels; wave w owns M-tiles
@@ -152,7 +153,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NW = G::B_FLOATS / 4 / 256;
   f32x4 hreg[NH], wreg[NW];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-  int hoff[NH];     // element offset (pixel index) of halo slot i for the tile being LOADED, -1 = outside
+  // byte offset (without channel chunk) of halo slot i for the tile being LOADED; OOB marker = outside the image:
+  // a raw buffer load beyond num_records returns 0 without touching memory.
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned hoff[NH];
   int lds_off[NH];  // float offset in sA (tile independent), -1 = unused slot
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       const int r = pp / G::WT, c = pp - r * G::WT;                                                      \
       const int gy = ld_ty0 + r - G::PAD, gx = ld_tx0 + c - G::PAD;                                      \
       const bool ok = pp < G::HT * G::WT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
-      hoff[i] = ok ? ((ld_n * a.H + gy) * a.W + gx) : -1;                                                \
+      hoff[i] = ok ? (unsigned)(((ld_n * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + q4 * 4) * 4u : OOB;  \
     }                                                                                                    \
   }
 #define SSP_ISSUE_LOADS(CHUNK)                                                                          \
@@ -186,14 +190,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       psh = *reinterpret_cast<const f32x4*>(a.in_shift + cc_);                                          \
     }                                                                                                   \
     if (IN_MODE != 2) {                                                                                 \
+      const int soff_ = (CHUNK) * CK * 4;                                                               \
       _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                                  \
-        const size_t off_ = (hoff[i] >= 0 && cvalid_) ? (size_t)hoff[i] * a.in_cs + a.in_co + c0_ : (size_t)0; \
-        hreg[i] = *reinterpret_cast<const f32x4*>(a.in + off_);                                         \
+        const unsigned vo_ = partial_k ? (cvalid_ ? hoff[i] : OOB) : hoff[i];                           \
+        hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo_, soff_, 0)); \
       }                                                                                                 \
     }                                                                                                   \
-    const f32x4* src_ = reinterpret_cast<const f32x4*>(a.wpk + (size_t)(cob * a.nchunks + (CHUNK)) * G::B_FLOATS); \
-    _Pragma("unroll") for (int j = 0; j < NW; ++j) wreg[j] = src_[tid + 256 * j];                       \
+    const int wbase_ = (cob * a.nchunks + (CHUNK)) * G::B_FLOATS * 4;                                   \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j)                                                      \
+      wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 4096, 0)); \
   }
+
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
+  const bool partial_k = (a.Cin % CK) != 0;  // last K-chunk has channel quads beyond Cin (65/133-channel dY)
 
   SSP_DECODE_TILE(tile)
   SSP_ISSUE_LOADS(0)
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int n = ld_n, ty0 = ld_ty0, tx0 = ld_tx0;  // the tile being computed (= the one just prefetched)
     unsigned hmask = 0;                               // validity of its halo slots
 #pragma unroll
-    for (int i = 0; i < NH; ++i) hmask |= (hoff[i] >= 0 ? 1u : 0u) << i;
+    for (int i = 0; i < NH; ++i) hmask |= (hoff[i] != OOB ? 1u : 0u) << i;
     const int next_tile = tile + per_cob;
     const bool has_next = next_tile < t_end;
 
@@ -294,25 +304,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       }
     }
 
-    // ---- tile epilogue: bias, store (fire and forget), BatchNorm partial sums in registers ----
+    // ---- tile epilogue ----
+    // Global stores are issue-bound (one dword store per accumulator register cost ~12 % of the kernel), so the
+    // tile is transposed through LDS: 64 ds_write_b32 per lane into a [pixel][64 co] image, then 16 x
+    // (ds_read_b128 + global_store_dwordx4) per lane, a wave writing 4 pixels x 256 contiguous bytes.
+    // Bias is added and the BatchNorm partial sums are taken from the registers on the way.
+    if (!(a.ablate & 4)) {
+      const bool full = (ty0 + G::TH <= a.H) && (tx0 + G::TW <= a.W);
+      __syncthreads();  // all waves have finished their MFMA reads of sA/sB: the LDS image can be reused
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int co = cob * NB + nt * 32 + li;
+      for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          int rr, cc;
-          mpix<SW>(m, rr, cc);
-          const int oy = ty0 + (wave * 2 + mt) * SH + rr, ox = tx0 + cc;
-          if (covalid[nt] && oy < a.H && ox < a.W && !(a.ablate & 4)) {
-            float v = acc[mt][nt][r] + bias_v[nt];
-            float* p = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co;
-            if (a.accumulate) v += *p;
-            *p = v;
-            ssum[nt] += v;
-            ssq[nt] += v * v;
+          for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int rr, cc;
+            mpix<SW>(m, rr, cc);
+            const int orow = (wave * 2 + mt) * SH + rr;
+            const float v = acc[mt][nt][r] + bias_v[nt];
+            smem[(orow * G::TW + cc) * NB + nt * 32 + li] = v;
+            if (a.stats != nullptr && covalid[nt] && (full || (ty0 + orow < a.H && tx0 + cc < a.W))) {
+              ssum[nt] += v;
+              ssq[nt] += v * v;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int q16 = tid & 15;               // channel quad of the 64-channel block
+      const int co4 = cob * NB + q16 * 4;
+      const int nvalid = min(4, a.Cout - co4);  // channels of this quad that exist (<= 0: none)
+#pragma unroll 4
+      for (int k = 0; k < (G::TH * G::TW) / 16; ++k) {
+        const int lp = (tid >> 4) + 16 * k;
+        const int orow = lp / G::TW, ocol = lp - orow * G::TW;
+        const int oy = ty0 + orow, ox = tx0 + ocol;
+        if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(smem + lp * NB + q16 * 4);
+          float* p = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
+          if (nvalid == 4) {
+            *reinterpret_cast<f32x4*>(p) = v;
+          } else {
+            p[0] = v[0];
+            if (nvalid > 1) p[1] = v[1];
+            if (nvalid > 2) p[2] = v[2];
           }
         }
       }
@@ -371,18 +407,22 @@ template <int KS, int SH, int SW>
 struct WgradGeom {
   static constexpr int TAPS = KS * KS;
   static constexpr int PAD = KS / 2;
-  static constexpr int TH = 4 * SH;
+  static constexpr int TH = 2 * SH;   // 64-pixel tiles: 2x32 (wide maps) or 8x8
   static constexpr int TW = SW;
   static constexpr int HT = TH + 2 * PAD;
   static constexpr int WT = TW + 2 * PAD;
-  static constexpr int P = TH * TW;  // 128
+  static constexpr int P = TH * TW;  // 64
   static constexpr int X_FLOATS = HT * WT * 64;
   static constexpr int D_FLOATS = P * 64;
-  static constexpr int LDS_BYTES = (X_FLOATS + D_FLOATS) * 4;
+  static constexpr int LDS_BYTES = (X_FLOATS + D_FLOATS + 128) * 4;  // + scale/shift of the 64 input channels
 };
 
+// Block = 4 waves = (ci half, co half); 2 blocks per CU (51 KB LDS, <= 256 registers incl. 144 accumulators).
+// Each block walks a CONTIGUOUS range of 64-pixel tiles; the global loads of tile t+1 (X halo rows + dY tile,
+// 13 float4 per lane) are issued before the 288 MFMAs of tile t and written to LDS (with the producer's
+// BN/ReLU applied) afterwards.  IN_MODE 2 (pooled input, 4 loads per pixel) stages its X tile synchronously.
 template <int KS, int IN_MODE, int SH, int SW>
-__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
   using G = WgradGeom<KS, SH, SW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem;
@@ -398,6 +438,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   bid /= a.nsplit;
   const int cob = bid % a.ncob;
   const int cib = bid / a.ncob;
+  const int per = (a.ntiles + a.nsplit - 1) / a.nsplit;
+  const int t_begin = split * per, t_end = min(a.ntiles, t_begin + per);
 
   f32x16 acc[G::TAPS];
 #pragma unroll
@@ -408,37 +450,104 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   const int q16 = tid & 15;  // channel quad 0..15 of the 64-channel slab
   const int ci0 = cib * 64 + q16 * 4;
   const bool civalid = ci0 < a.Cin;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (IN_MODE != 0 && civalid) {
-    sc = *reinterpret_cast<const float4*>(a.in_scale + ci0);
-    sh = *reinterpret_cast<const float4*>(a.in_shift + ci0);
+  // BN scale/shift of this block's 64 input channels live in LDS (frees 8 VGPRs of a 256-register kernel)
+  float* sS = smem + G::X_FLOATS + G::D_FLOATS;
+  if (IN_MODE != 0 && tid < 16) {
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
+    if (civalid) {
+      sc0 = *reinterpret_cast<const f32x4*>(a.in_scale + ci0);
+      sh0 = *reinterpret_cast<const f32x4*>(a.in_shift + ci0);
+    }
+    *reinterpret_cast<f32x4*>(sS + q16 * 4) = sc0;
+    *reinterpret_cast<f32x4*>(sS + 64 + q16 * 4) = sh0;
   }
   const int co0 = cob * 64 + q16 * 4;
   const bool covalid = co0 < a.Cout;
 
-  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
-    int t = tile;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int n = t / a.tiles_y;
-    const int ty0 = ty * G::TH, tx0 = tx * G::TW;
-    __syncthreads();
-    for (int pp = tid >> 4; pp < G::HT * G::WT; pp += 16) {
-      const int r = pp / G::WT, c = pp - r * G::WT;
-      const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs, a.in_co + ci0,
-                                        civalid, sc, sh);
-      *reinterpret_cast<float4*>(sX + pp * 64 + q16 * 4) = v;
+  constexpr int NX = (G::HT * G::WT + 15) / 16;  // halo pixels per thread (pp = (tid>>4) + 16*i)
+  constexpr int ND = G::P / 16;                  // dY pixels per thread
+  f32x4 xreg[NX], dreg[ND];
+  unsigned xmask = 0, dmask = 0;  // validity of the slots of the tile whose loads are in flight
+
+#define SSP_WG_ISSUE(TILE)                                                                                    \
+  {                                                                                                           \
+    const int tx_ = (TILE) % a.tiles_x, t2_ = (TILE) / a.tiles_x;                                             \
+    const int ty0_ = (t2_ % a.tiles_y) * G::TH, tx0_ = tx_ * G::TW, n_ = t2_ / a.tiles_y;                     \
+    xmask = 0; dmask = 0;                                                                                     \
+    if (IN_MODE != 2) {                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                        \
+        const int pp = (tid >> 4) + 16 * i;                                                                   \
+        const int r = pp / G::WT, c = pp - r * G::WT;                                                         \
+        const int gy = ty0_ + r - G::PAD, gx = tx0_ + c - G::PAD;                                             \
+        const bool ok = pp < G::HT * G::WT && civalid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
+        const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + ci0 : (size_t)0;   \
+        xreg[i] = *reinterpret_cast<const f32x4*>(a.in + off);                                                \
+        xmask |= (ok ? 1u : 0u) << i;                                                                         \
+      }                                                                                                       \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                          \
+      const int pp = (tid >> 4) + 16 * i;                                                                     \
+      const int r = pp / G::TW, c = pp - r * G::TW;                                                           \
+      const int gy = ty0_ + r, gx = tx0_ + c;                                                                 \
+      const bool ok = covalid && gy < a.H && gx < a.W;                                                        \
+      const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.dout_cs + a.dout_co + co0 : (size_t)0; \
+      dreg[i] = *reinterpret_cast<const f32x4*>(a.dout + off);                                                \
+      dmask |= (ok ? 1u : 0u) << i;                                                                           \
+    }                                                                                                         \
+  }
+
+  if (t_begin < t_end) SSP_WG_ISSUE(t_begin)
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();  // all waves finished reading the previous tile's LDS image
+    {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (IN_MODE != 0) {  // written before the first barrier above by threads 0..15
+        sc = *reinterpret_cast<const f32x4*>(sS + q16 * 4);
+        sh = *reinterpret_cast<const f32x4*>(sS + 64 + q16 * 4);
+      }
+      if (IN_MODE != 2) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const int pp = (tid >> 4) + 16 * i;
+          if (pp < G::HT * G::WT) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((xmask >> i) & 1u) {
+              v = xreg[i];
+              if (IN_MODE != 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+              }
+            }
+            *reinterpret_cast<f32x4*>(sX + pp * 64 + q16 * 4) = v;
+          }
+        }
+      } else {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty0 = (t % a.tiles_y) * G::TH, tx0 = tx * G::TW, n = t / a.tiles_y;
+        const float4 sc4 = make_float4(sc[0], sc[1], sc[2], sc[3]), sh4 = make_float4(sh[0], sh[1], sh[2], sh[3]);
+        for (int pp = tid >> 4; pp < G::HT * G::WT; pp += 16) {
+          const int r = pp / G::WT, c = pp - r * G::WT;
+          const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs,
+                                            a.in_co + ci0, civalid, sc4, sh4);
+          *reinterpret_cast<float4*>(sX + pp * 64 + q16 * 4) = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int pp = (tid >> 4) + 16 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((dmask >> i) & 1u) v = dreg[i];
+        *reinterpret_cast<f32x4*>(sD + pp * 64 + q16 * 4) = v;
+      }
     }
-    for (int pp = tid >> 4; pp < G::P; pp += 16) {
-      const int r = pp / G::TW, c = pp - r * G::TW;
-      const int gy = ty0 + r, gx = tx0 + c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (covalid && gy < a.H && gx < a.W)
-        v = *reinterpret_cast<const float4*>(a.dout + ((size_t)(n * a.H + gy) * a.W + gx) * a.dout_cs + a.dout_co + co0);
-      *reinterpret_cast<float4*>(sD + pp * 64 + q16 * 4) = v;
-    }
     __syncthreads();
+    {
+      const int nxt = min(tile + 1, t_end - 1);  // unconditional prefetch (redundant on the last tile)
+      SSP_WG_ISSUE(nxt)
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll 4
     for (int s = 0; s < G::P / 2; ++s) {
       const int p = 2 * s + lh;
@@ -453,6 +562,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
       }
     }
   }
+#undef SSP_WG_ISSUE
   // partial slab: [blk][tap][ci 64][co 64]
   float* dst = a.partial + (size_t)blockIdx.x * G::TAPS * 4096;
 #pragma unroll

@@ -88,7 +88,7 @@ struct ssp_handle {
   bool bound;
   size_t ws_bytes;
   Slot slot[2];
-  float *wpk_fwd, *wpk_bwd;
+  float *wpk_fwd, *wpk_bwd, *wpk_heads_bwd;
   float *gP, *gQ;    // backward ping-pong buffers
   float* partial;    // wgrad partial slabs
   size_t partial_floats;
@@ -180,6 +180,7 @@ static size_t carve(ssp_handle* h, void* base) {
   }
   h->wpk_fwd = c.take<float>(pf);
   h->wpk_bwd = c.take<float>(pb);
+  h->wpk_heads_bwd = c.take<float>((size_t)2 * 16 * h->nheads * 9 * CK * NB);
   for (int s = 0; s < 2; ++s) {
     Slot& S = h->slot[s];
     for (int l = 0; l < 8; ++l) {
@@ -268,7 +269,7 @@ struct ConvCall {
   const float* wpk; const float* bias;
   float* out; int out_cs, out_co, cout;
   const float* in_scale; const float* in_shift; double* stats;
-  int N, H, W, ks, in_mode, nchunks, ncob, accumulate;
+  int N, H, W, ks, in_mode, nchunks, ncob;
 };
 
 static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int prof_family = 0) {
@@ -276,7 +277,13 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   a.in = c.in; a.wpk = c.wpk; a.bias = c.bias; a.out = c.out; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.stats = c.stats; a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
   a.Cout = c.cout; a.out_cs = c.out_cs; a.out_co = c.out_co; a.nchunks = c.nchunks; a.ncob = c.ncob;
-  a.accumulate = c.accumulate;
+  {
+    auto clampu = [](double v) { return v > 4294967295.0 ? 4294967295u : (unsigned)v; };
+    const double in_px = (double)c.N * c.H * c.W * (c.in_mode == 2 ? 4 : 1);
+    a.in_bytes = clampu(in_px * c.in_cs * 4.0);
+    a.out_bytes = clampu((double)c.N * c.H * c.W * c.out_cs * 4.0);
+    a.wpk_bytes = clampu((double)c.ncob * c.nchunks * c.ks * c.ks * CK * NB * 4.0);
+  }
   a.ablate = getenv("SSP_ABLATE_CONV") ? atoi(getenv("SSP_ABLATE_CONV")) : 0;
   const bool wide = (c.W % 32) == 0;
   const int TH = wide ? 8 : 32, TW = wide ? 32 : 8;
@@ -331,13 +338,13 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
   a.Cout = c.cout; a.dout_cs = c.dout_cs; a.dout_co = c.dout_co;
   const bool wide = (c.W % 32) == 0;
-  const int TH = wide ? 4 : 16, TW = wide ? 32 : 8;
+  const int TH = wide ? 2 : 8, TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
   a.ntiles = c.N * a.tiles_x * a.tiles_y;
   a.ncib = cdiv(c.cin, 64); a.ncob = cdiv(c.cout, 64);
   const int pairs = a.ncib * a.ncob;
   const int taps = c.ks * c.ks;
-  int nsplit = (2 * n_cu) / pairs;
+  int nsplit = (2 * n_cu) / pairs / 8 * 8;  // 2 blocks per CU; multiple of 8: blocks sharing tiles share an XCD
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   while ((size_t)pairs * nsplit * taps * 4096 > partial_floats && nsplit > 1) --nsplit;
@@ -501,6 +508,15 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
     CHK(launch_pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, st));
     if (with_bwd) CHK(launch_pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, st));
   }
+  if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
+    const int heads[3] = {L_PA, L_DA, L_DS};
+    const int total = 2 * 16 * 9 * CK * NB;
+    for (int k = 0; k < h->nheads; ++k) {
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, P(h, h->L[heads[k]].w_off),
+                         h->wpk_heads_bwd, 256, 128, 3, 1, 16 * h->nheads, 16 * k, 0, 2, 16);
+    }
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -514,7 +530,6 @@ static int conv_layer_fwd(ssp_handle* h, Slot& S, int l, int src, int N, int H, 
   c.in_scale = S.bn[src].scale; c.in_shift = S.bn[src].shift;
   c.stats = (d.bn && train) ? S.bn[l].stats : nullptr;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = in_mode; c.nchunks = d.nchunks_fwd; c.ncob = d.ncob_fwd;
-  c.accumulate = 0;
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
   if (d.bn) CHK(bn_finalize(h, S, l, (double)N * H * W, train, st));
   return 0;
@@ -558,8 +573,7 @@ static int run_forward(ssp_handle* h, int slot, const float* x, int N, int H, in
 // backward of a conv+BN(+ReLU) layer: dOut (grad wrt the activated [pooled] output, in `dout`) ->
 // parameter gradients and, unless l == 0, the gradient wrt the layer's (activated) input in `din`.
 static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* dout, int d_cs, int d_co, bool relu,
-                          bool pool_after, float* dy, int dy_cs, int dy_co, float* din, int din_cs, int din_co,
-                          int din_accumulate, int N, int H, int W, int in_mode, hipStream_t st) {
+                          bool pool_after, float* dy, int dy_cs, int dy_co, float* din, int din_cs, int din_co, int N, int H, int W, int in_mode, hipStream_t st) {
   const LayerDesc& d = h->L[l];
   if (d.bn) {
     BnBwdArgs a;
@@ -593,7 +607,6 @@ static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* d
   c.out = din; c.out_cs = din_cs; c.out_co = din_co; c.cout = d.cin;
   c.in_scale = nullptr; c.in_shift = nullptr; c.stats = nullptr;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 0; c.nchunks = d.nchunks_bwd; c.ncob = d.ncob_bwd;
-  c.accumulate = din_accumulate;
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_DGRAD : 0));
   return 0;
 }
@@ -615,9 +628,9 @@ static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float
     HIPCHK(hipMemsetAsync(dHeadsAct, 0, (size_t)N * Hc * Wc * hcs * sizeof(float), st));
   // 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only)
   if (has_semi)
-    CHK(layer_backward(h, S, L_PB, L_PA, dsemi, 80, 0, false, false, dYtmp, 80, 0, dHeadsAct, hcs, 0, 0, N, Hc, Wc, 1, st));
+    CHK(layer_backward(h, S, L_PB, L_PA, dsemi, 80, 0, false, false, dYtmp, 80, 0, dHeadsAct, hcs, 0, N, Hc, Wc, 1, st));
   if (has_desc)
-    CHK(layer_backward(h, S, L_DB, L_DA, draw_desc, 256, 0, false, false, dYtmp, 256, 0, dHeadsAct, hcs, 256, 0, N, Hc, Wc, 1, st));
+    CHK(layer_backward(h, S, L_DB, L_DA, draw_desc, 256, 0, false, false, dYtmp, 256, 0, dHeadsAct, hcs, 256, N, Hc, Wc, 1, st));
   if (has_sem) {
     const LayerDesc& d = h->L[L_SOUT];
     const int ncells = N * Hc * Wc;
@@ -625,7 +638,7 @@ static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float
                        h->sout_cs);
     HIPCHK(hipGetLastError());
     CHK(layer_backward(h, S, L_SOUT, L_DS, nullptr, 0, 0, false, false, const_cast<float*>(dsout), h->sout_cs, 0,
-                       dHeadsAct, hcs, 512, 0, N, Hc, Wc, 1, st));
+                       dHeadsAct, hcs, 512, N, Hc, Wc, 1, st));
   }
   // 3x3 heads: BN+ReLU backward into dYtmp [cells][hcs], then wgrad + dgrad (accumulated into dOut7)
   float* dOut = h->gP;
@@ -651,11 +664,13 @@ static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float
       w.cout = 256; w.in_scale = S.bn[7].scale; w.in_shift = S.bn[7].shift; w.dw = Gd(h, d.w_off);
       w.N = N; w.H = Hc; w.W = Wc; w.ks = 3; w.in_mode = 1;
       CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
+    }
+    {  // data gradient of the 3x3 heads: ONE conv over the concatenated dY channels (sums the heads' contributions)
       ConvCall c;
-      c.in = dYtmp; c.in_cs = hcs; c.in_co = 256 * k; c.cin = 256; c.wpk = h->wpk_bwd + d.pk_bwd; c.bias = nullptr;
+      c.in = dYtmp; c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = h->wpk_heads_bwd; c.bias = nullptr;
       c.out = dOut; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
-      c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = d.nchunks_bwd;
-      c.ncob = d.ncob_bwd; c.accumulate = (k > 0);
+      c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = 16 * h->nheads;
+      c.ncob = 2;
       CHK(launch_conv(h, c, st, SSP_PROF_CONV3X3_DGRAD));
     }
   }
@@ -665,7 +680,7 @@ static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float
     const bool pool_after = (l == 1 || l == 3 || l == 5);
     const int C = h->L[l].cout;
     const int cin = h->L[l].cin;
-    CHK(layer_backward(h, S, l, l - 1, dOut, C, 0, true, pool_after, dYtmp, C, 0, dOut, cin, 0, 0, N, lh, lw,
+    CHK(layer_backward(h, S, l, l - 1, dOut, C, 0, true, pool_after, dYtmp, C, 0, dOut, cin, 0, N, lh, lw,
                        l > 0 ? layer_in_mode(l) : 0, st));
   }
   return 0;
@@ -867,7 +882,7 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
   ConvCall c;
   c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.wpk = wpk; c.bias = bias_dev; c.out = out_dev; c.out_cs = cout;
   c.out_co = 0; c.cout = cout; c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.stats = stats_dev; c.N = n;
-  c.H = hh; c.W = w; c.ks = ksize; c.in_mode = in_mode; c.nchunks = nchunks; c.ncob = ncob; c.accumulate = 0;
+  c.H = hh; c.W = w; c.ks = ksize; c.in_mode = in_mode; c.nchunks = nchunks; c.ncob = ncob;
   return launch_conv(nullptr, c, st, 0);
 }
 
