@@ -30,7 +30,6 @@ __device__ __forceinline__ void reduce_by_column(float (&v)[NV], float* smem, in
 // Also accumulates the BatchNorm sums.  grid: ceil(npix / (16 * PIX_ITERS)), block 256.
 // ------------------------------------------------------------------------------------------------
 constexpr int C0_ITERS = 64;
-constexpr int C0W_ITERS = 256;  // conv0_wgrad: fewer, fatter blocks (576 float atomics per block)
 __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            double* __restrict__ stats, int N, int H, int W) {
@@ -86,48 +85,42 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
   }
 }
 
-// dW[64][1][3][3] and db for the first layer: reduction over all pixels of dY[p][co] * x[p+tap].
-// One block handles a strip of pixels for all 64 channels; partial sums -> atomics (576+64 values).
+// dW[64][1][3][3] of the first layer = dY^T [64 x pixels] * patches [pixels x 9]: a GEMM with K = N*H*W.
+// On the matrix cores (32x32x2: M = 32 output channels, N = taps (9 of 32 columns used), K = 2 pixels) the
+// kernel is bound by streaming dY0 (256 B / pixel) instead of by 36 FMAs + 9 loads per lane and pixel.
+// One wave = one image row x one channel half; A = dY[pixel][co] straight from HBM (128 B per half-wave),
+// B = x[pixel + tap] (L2-resident image).  Partial 32x9 blocks are added with atomics.
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dw, int N, int H, int W) {
-  __shared__ float red[256 * 9];
-  const int tid = threadIdx.x;
-  const int q = tid & 15, pl = tid >> 4;
-  const long npix = (long)N * H * W;
-  const long base = (long)blockIdx.x * 16 * C0W_ITERS;
-  float acc[4][9];
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // global wave id
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  const int coh = gw & 1;                                       // channel half of this wave (fixed: one flush)
+  const int nrow = N * H;
+  const int tdy = li / 3 - 1, tdx = li % 3 - 1;                 // tap of this B column (li < 9)
+  f32x16 acc;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int row = gw >> 1; row < nrow; row += nw >> 1) {
+    const int yy = row % H;
+    const float* dyr = dy + (size_t)row * W * 64 + coh * 32 + li;
+    const int sy = yy + tdy;
+    const bool rowok = li < 9 && (unsigned)sy < (unsigned)H;
+    const float* xr = x + ((long)row + tdy) * W + tdx;         // x[(n*H + yy + tdy) * W + (xx + tdx)]
 #pragma unroll 4
-  for (int it = 0; it < C0W_ITERS; ++it) {
-    const long p = base + it * 16 + pl;
-    if (p >= npix) break;
-    const int xx = (int)(p % W);
-    const int yy = (int)((p / W) % H);
-    const float4 g = *reinterpret_cast<const float4*>(dy + p * 64 + q * 4);
-    const float gv[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-    for (int dyy = 0; dyy < 3; ++dyy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int gy = yy + dyy - 1, gx = xx + dx - 1;
-        const float v = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? x[p + (dyy - 1) * W + (dx - 1)] : 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c][dyy * 3 + dx] = fmaf(gv[c], v, acc[c][dyy * 3 + dx]);
-      }
+    for (int xx = 0; xx < W; xx += 2) {
+      const int px = xx + lh;
+      const float a = dyr[(size_t)px * 64];
+      const int sx = px + tdx;
+      const float b = (rowok && (unsigned)sx < (unsigned)W) ? xr[px] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
   }
+  if (li < 9) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    float v[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = acc[c][t];
-    __syncthreads();
-    reduce_by_column<9>(v, red, 16);
-    if (tid < 16) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(dw + (tid * 4 + c) * 9 + t, v[t]);
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      atomicAdd(dw + (coh * 32 + m) * 9 + li, acc[r]);
     }
   }
 }

@@ -21,71 +21,114 @@ __device__ __forceinline__ void up_src(int dst, int in_size, int out_size, int& 
   l1 = s - (float)i0;
 }
 
-// One wave per 8x8 pixel tile shifted by (4,4): all 64 pixels share the same 4 source cells.
-// sout: convSout output NHWC [B][Hc*Wc][cs]; labels int64 [B,H,W]; dsout (BWD) accumulated with atomics.
+// Number of non-ignored labels (CrossEntropyLoss(ignore_index=C) averages over them): sem_cnt[view] += count.
+__global__ __launch_bounds__(256) void sem_count_kernel(const int64_t* __restrict__ labels, long n, int C,
+                                                        StepAccum* __restrict__ acc, int view) {
+  __shared__ float red[4];
+  float cnt = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    cnt += (labels[i] != (int64_t)C) ? 1.f : 0.f;
+  cnt = wave_sum(cnt);
+  const float tot = block_sum_of_waves(cnt, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&acc->sem_cnt[view], (double)tot);
+}
+
+// Fused bilinear upsample (align_corners=False) + log-softmax + NLL (+ gradient), one wave per 8x8 pixel tile
+// shifted by (4,4): all 64 pixels of such a tile interpolate between the same 4 source cells.
+// Lanes hold CLASSES (c = lane + 64*j, j < 3): the 4 corner logit vectors live in 12 registers per lane, the
+// wave walks the 64 pixels (bilinear weights / label broadcast from the lane that owns the pixel), softmax is
+// two wave reductions per pixel, and d(convSout) of the 4 corners accumulates in 12 registers per lane that are
+// flushed with 12 atomics per lane and tile.  sem_cnt[view] must be final before a BWD launch.
 template <bool BWD>
 __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ sout, const int64_t* __restrict__ labels,
                                                      float* __restrict__ dsout, StepAccum* __restrict__ acc, int view,
                                                      int B, int Hc, int Wc, int H, int W, int C, int cs) {
-  __shared__ float corner[4][4][160];  // [wave][corner][class]
+  __shared__ float red[4];
   const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long tile = (long)blockIdx.x * 4 + wave_in_blk;
   const int TX = Wc + 1, TY = Hc + 1;
-  const bool tile_ok = tile < (long)B * TX * TY;
-  int n = 0, ty = 0, tx = 0;
-  if (tile_ok) {
-    tx = (int)(tile % TX) - 1;
-    ty = (int)((tile / TX) % TY) - 1;
-    n = (int)(tile / ((long)TX * TY));
-  }
-  const int cy0 = max(ty, 0), cy1 = min(ty + 1, Hc - 1), cx0 = max(tx, 0), cx1 = min(tx + 1, Wc - 1);
-  const int cidx[4] = {cy0 * Wc + cx0, cy0 * Wc + cx1, cy1 * Wc + cx0, cy1 * Wc + cx1};
-  float(*cw)[160] = corner[wave_in_blk];
-  if (tile_ok) {
+  const long ntile = (long)B * TX * TY;
+  float nll_acc = 0.f;
+  const float g = BWD ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
+  for (long tile = (long)blockIdx.x * 4 + wave_in_blk; tile < ntile; tile += (long)gridDim.x * 4) {
+    const int tx = (int)(tile % TX) - 1, ty = (int)((tile / TX) % TY) - 1, n = (int)(tile / ((long)TX * TY));
+    const int cy0 = max(ty, 0), cy1 = min(ty + 1, Hc - 1), cx0 = max(tx, 0), cx1 = min(tx + 1, Wc - 1);
+    const int cidx[4] = {cy0 * Wc + cx0, cy0 * Wc + cx1, cy1 * Wc + cx0, cy1 * Wc + cx1};
+    // corner logits of this lane's classes
+    float cv[4][3];
+    bool cok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = lane + 64 * j;
+      cok[j] = c < C;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cv[k][j] = cok[j] ? sout[((size_t)n * Hc * Wc + cidx[k]) * cs + c] : 0.f;
+    }
+    // this lane's pixel: weights and label
+    const int y = 8 * ty + 4 + (lane >> 3), x = 8 * tx + 4 + (lane & 7);
+    const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+    int label_l = C;
+    float wy1_l = 0.f, wx1_l = 0.f;
+    if (inside) {
+      int a0, a1;
+      up_src(y, Hc, H, a0, a1, wy1_l);
+      up_src(x, Wc, W, a0, a1, wx1_l);
+      label_l = (int)labels[((size_t)n * H + y) * W + x];
+    }
+    const unsigned long long counted_mask = __ballot(inside && label_l != C);
+    float dacc[4][3];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      for (int c = lane; c < C; c += 64) cw[k][c] = sout[((size_t)n * Hc * Wc + cidx[k]) * cs + c];
-  }
-  __syncthreads();
-  if (!tile_ok) return;
-  const int y = 8 * ty + 4 + (lane >> 3), x = 8 * tx + 4 + (lane & 7);
-  const bool inside = y >= 0 && y < H && x >= 0 && x < W;
-  int label = C;  // ignore
-  float wy1 = 0.f, wx1 = 0.f;
-  if (inside) {
-    int a0, a1;
-    up_src(y, Hc, H, a0, a1, wy1);
-    up_src(x, Wc, W, a0, a1, wx1);
-    label = (int)labels[((size_t)n * H + y) * W + x];
-  }
-  const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-  const bool counted = inside && label != C;  // ignore_index == n_classes (133)
-  // log-sum-exp over classes (two passes; logits are 4 FMAs to recompute)
-  auto logit = [&](int c) { return wy0 * (wx0 * cw[0][c] + wx1 * cw[1][c]) + wy1 * (wx0 * cw[2][c] + wx1 * cw[3][c]); };
-  float m = -INFINITY;
-  for (int c = 0; c < C; ++c) m = fmaxf(m, logit(c));
-  float se = 0.f;
-  for (int c = 0; c < C; ++c) se += expf(logit(c) - m);
-  if (!BWD) {
-    float nll = 0.f;
-    if (counted) nll = (m + logf(se)) - logit(label);
-    const float tot = wave_sum(nll), cnt = wave_sum(counted ? 1.f : 0.f);
-    if (lane == 0) {
-      unsafeAtomicAdd(&acc->sem_sum[view], (double)tot);
-      unsafeAtomicAdd(&acc->sem_cnt[view], (double)cnt);
-    }
-  } else {
-    const float g = counted ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
-    const float inv = 1.f / se;
-    const float w4[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
-    for (int c = 0; c < C; ++c) {
-      const float d = g * (expf(logit(c) - m) * inv - ((c == label) ? 1.f : 0.f));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float s = wave_sum(w4[k] * d);
-        if (lane == 0 && s != 0.f) atomicAdd(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + c, s);
+      for (int j = 0; j < 3; ++j) dacc[k][j] = 0.f;
+    for (int p = 0; p < 64; ++p) {
+      if (!((counted_mask >> p) & 1ull)) continue;  // wave-uniform: ignored / outside pixels contribute nothing
+      const float wy1 = __shfl(wy1_l, p), wx1 = __shfl(wx1_l, p);
+      const int label = __shfl(label_l, p);
+      const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+      float l[3];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        l[j] = wy0 * (wx0 * cv[0][j] + wx1 * cv[1][j]) + wy1 * (wx0 * cv[2][j] + wx1 * cv[3][j]);
+        if (cok[j]) mx = fmaxf(mx, l[j]);
+      }
+      mx = wave_max(mx);
+      float e[3], se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        e[j] = cok[j] ? expf(l[j] - mx) : 0.f;
+        se += e[j];
+      }
+      se = wave_sum(se);
+      if (!BWD) {
+        const int lj = label >> 6;  // wave-uniform
+        const float lsel = lj == 0 ? l[0] : (lj == 1 ? l[1] : l[2]);
+        const float ll = __shfl(lsel, label & 63);
+        nll_acc += (mx + logf(se)) - ll;  // identical in every lane; lane 0's copy is used
+      } else {
+        const float inv = 1.f / se;
+        const float w4[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float d = g * (e[j] * inv - ((lane + 64 * j == label) ? 1.f : 0.f));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dacc[k][j] = fmaf(w4[k], d, dacc[k][j]);
+        }
       }
     }
+    if (BWD && counted_mask != 0ull) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (cok[j]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (dacc[k][j] != 0.f) atomicAdd(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + lane + 64 * j, dacc[k][j]);
+        }
+    }
+  }
+  if (!BWD) {
+    const float tot = block_sum_of_waves(nll_acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&acc->sem_sum[view], (double)tot);
   }
 }
 

@@ -76,6 +76,7 @@ struct Slot {
   void* stats_region;
   size_t stats_bytes;
   int N, H, W;
+  bool bsums_dirty;
 };
 
 struct ssp_handle {
@@ -406,7 +407,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   if (cfg->height % 8 || cfg->width % 8 || cfg->height <= 0 || cfg->width <= 0)
     return fail(-1, "height/width must be positive multiples of 8 (got %dx%d)", cfg->height, cfg->width);
   if (cfg->max_batch < 1 || cfg->max_batch > 64) return fail(-1, "max_batch must be in 1..64");
-  if (cfg->arch == SSP_ARCH_GAUSS2_SSMALL && cfg->n_classes > 160) return fail(-1, "n_classes must be <= 160");
+  if (cfg->arch == SSP_ARCH_GAUSS2_SSMALL && cfg->n_classes > 192) return fail(-1, "n_classes must be <= 192");
   ssp_handle* h = new ssp_handle();
   h->cfg = *cfg;
   if (h->cfg.n_classes <= 0) h->cfg.n_classes = 133;
@@ -536,11 +537,12 @@ static int conv_layer_fwd(ssp_handle* h, Slot& S, int l, int src, int N, int H, 
 }
 
 static int run_forward(ssp_handle* h, int slot, const float* x, int N, int H, int W, int train, bool for_backward,
-                       hipStream_t st) {
+                       hipStream_t st, bool repack = true) {
   Slot& S = h->slot[slot];
   S.N = N; S.H = H; S.W = W; S.x = x;
   HIPCHK(hipMemsetAsync(S.stats_region, 0, S.stats_bytes, st));
-  CHK(pack_all(h, for_backward, st));
+  S.bsums_dirty = false;
+  if (repack) CHK(pack_all(h, for_backward, st));
   // layer 0: direct 1->64 conv
   {
     const LayerDesc& d = h->L[0];
@@ -590,7 +592,7 @@ static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* d
   }
   if (l == 0) {
     const long npix = (long)N * H * W;
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(cdiv(npix, 16 * C0W_ITERS)), dim3(256), 0, st, S.x, dy, Gd(h, d.w_off), N,
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(std::min(cdiv((long)N * H * 2, 4 * 4), 512)), dim3(256), 0, st, S.x, dy, Gd(h, d.w_off), N,
                        H, W);
     HIPCHK(hipGetLastError());
     return 0;
@@ -619,8 +621,13 @@ static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float
   const int N = S.N, H = S.H, W = S.W, Hc = H / 8, Wc = W / 8;
   const int hcs = 256 * h->nheads;
   // zero the backward fp64 sums (interleaved with the forward stats: clear only the bsums halves)
-  for (int l = 0; l < h->nlayers; ++l)
-    HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * (size_t)h->L[l].cout * NREP * sizeof(double), st));
+  // the forward's single memset of the statistics region also cleared the backward sums; clear them again only
+  // when this slot is back-propagated a second time (autograd retain_graph)
+  if (S.bsums_dirty) {
+    for (int l = 0; l < h->nlayers; ++l)
+      HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * (size_t)h->L[l].cout * NREP * sizeof(double), st));
+  }
+  S.bsums_dirty = true;
   float* dHeadsAct = h->gP;  // grad wrt relu(bn(conv{Pa,Da,DS})) [cells][hcs]
   float* dYtmp = h->gQ;
   const bool has_semi = dsemi != nullptr, has_desc = draw_desc != nullptr, has_sem = dsout != nullptr && h->nheads == 3;
@@ -781,7 +788,7 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
                      in->lamda_d, (int)semantic);
   CHK(run_forward(h, 0, in->image_dev, B, H, W, 1, in->train != 0, st));
-  CHK(run_forward(h, 1, in->warped_image_dev, B, H, W, 1, in->train != 0, st));
+  CHK(run_forward(h, 1, in->warped_image_dev, B, H, W, 1, in->train != 0, st, /*repack=*/false));  // same parameters
   const float* masks[2] = {in->valid_mask_dev, in->warped_valid_mask_dev};
   const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
   const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
@@ -797,18 +804,18 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   }
   HIPCHK(hipGetLastError());
   if (semantic) {
+    const long npx = (long)B * H * W;
+    const long ntile = (long)B * (Hc + 1) * (Wc + 1);
+    const int grid = (int)std::min<long>((ntile + 3) / 4, 4096);
+    for (int v = 0; v < 2; ++v)
+      hipLaunchKernelGGL(sem_count_kernel, dim3(1024), dim3(256), 0, st, sems[v], npx, h->cfg.n_classes, h->accum, v);
     for (int v = 0; v < 2; ++v) {
       Slot& S = h->slot[v];
-      const long npx = (long)B * H * W;
-      hipLaunchKernelGGL((sem_ce_kernel<false>), dim3(cdiv(npx, 4)), dim3(256), 0, st, S.Y[L_SOUT], sems[v], (float*)nullptr,
+      hipLaunchKernelGGL((sem_ce_kernel<false>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], (float*)nullptr,
                          h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
-    }
-    if (in->train) {
-      for (int v = 0; v < 2; ++v) {
-        Slot& S = h->slot[v];
-        const long npx = (long)B * H * W;
+      if (in->train) {
         HIPCHK(hipMemsetAsync(S.dsout, 0, (size_t)ncells * h->sout_cs * sizeof(float), st));
-        hipLaunchKernelGGL((sem_ce_kernel<true>), dim3(cdiv(npx, 4)), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
+        hipLaunchKernelGGL((sem_ce_kernel<true>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
                            h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
       }
     }
