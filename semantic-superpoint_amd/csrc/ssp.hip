@@ -583,20 +583,20 @@ static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* d
     a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums; a.dbias = Gd(h, d.b_off);
     a.N = N; a.H = H; a.W = W; a.C = d.cout; a.y_cs = S.y_cs[l]; a.y_co = S.y_co[l]; a.d_cs = d_cs; a.d_co = d_co;
     a.dy_cs = dy_cs; a.dy_co = dy_co; a.count = (double)N * H * W;
-    if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, st)));
+    if (l == 0) {
+      // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised)
+      const long npix = (long)N * H * W;
+      const int nb = std::min(cdiv(npix, 16), 1024);
+      hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, Gd(h, d.w_off));
+    } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, st)));
     else if (relu) CHK((launch_bn_bwd<true, false>(a, st)));
     else CHK((launch_bn_bwd<false, false>(a, st)));
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, S.bn[l].bsums, Gd(h, d.g_off),
                        Gd(h, d.be_off), d.cout);
     HIPCHK(hipGetLastError());
   }
-  if (l == 0) {
-    const long npix = (long)N * H * W;
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(std::min(cdiv((long)N * H * 2, 4 * 4), 512)), dim3(256), 0, st, S.x, dy, Gd(h, d.w_off), N,
-                       H, W);
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
+  if (l == 0) return 0;
   WgradCall w;
   w.in = S.Y[src]; w.in_cs = S.y_cs[src]; w.in_co = S.y_co[src]; w.cin = d.cin;
   w.dout = dy; w.dout_cs = dy_cs; w.dout_co = dy_co; w.cout = d.cout;
