@@ -131,9 +131,14 @@ def main():
             pr = eng.profile_read()
             if pr["launches"] > 0 and pr["ms"] > 0:
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
+                traffic = None  # HBM bytes / launch from the committed rocprofv3 PMC passes (cannot be read live)
+                tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+                if args.arch == "sp" and (B, H, W) == (32, 240, 320) and os.path.exists(tpath):
+                    traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
                 out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (3x3 forward + data-gradient)",
                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                                   "frac": round(ach / PEAK_FP32_MFMA_TF, 4), "traffic": None,
+                                   "frac": round(ach / PEAK_FP32_MFMA_TF, 4), "traffic": traffic,
+                                   "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                    "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4),
                                    "flops_per_launch_avg": round(pr["flops"] / pr["launches"] / 1e9, 3)}
             eng.profile_enable("none")
