@@ -138,6 +138,17 @@ int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw
 int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* target_dev, float* cellmask_dev, int b,
                   int h, int w, void* stream);
 
+/* ---- pair construction on the device (dataset side of the reference, datasets/Coco.py:341-392) ----
+ * ssp_op_warp_image : inv_warp_image_batch (utils/utils.py:347-385): out[p] = sample(img, inv_h * p), p on the
+ *                     linspace(-1,1) grid, zeros padding, align_corners=True; nearest != 0 selects mode="nearest".
+ * ssp_op_erode      : the erosion of compute_valid_mask (utils/utils.py:737-740): MORPH_ELLIPSE(2r,2r), anchor (r,r).
+ * ssp_op_warp_labels: warpLabels (datasets/data_tools.py:37-63) on a keypoint MAP: every non-zero pixel (x,y) is warped
+ *                     with T^-1 h T (utils/utils.py:297-300), kept if inside, rounded half-to-even, scattered as 1. */
+int ssp_op_warp_image(const float* img_dev, const float* inv_h_dev, float* out_dev, int b, int h, int w, int nearest,
+                      void* stream);
+int ssp_op_erode(const float* mask_dev, float* out_dev, int b, int h, int w, int radius, void* stream);
+int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_dev, int b, int h, int w, void* stream);
+
 /* BatchNorm2d(train) (+ReLU (+MaxPool2d(2))) backward. y: raw conv output NHWC; dout: gradient wrt the activated
  * (and pooled) output; stats4 = scale|shift|mean|invstd ([4*C]); dgamma/dbeta/dbias are accumulated;
  * sums_dev: double [SSP_NREP][2*C] scratch. */

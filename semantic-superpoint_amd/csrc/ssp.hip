@@ -16,6 +16,7 @@
 #include "bn_kernels.hip.h"
 #include "conv_mfma.hip.h"
 #include "loss_kernels.hip.h"
+#include "pair_kernels.hip.h"
 #include "sem_kernels.hip.h"
 
 using namespace sspk;
@@ -905,6 +906,34 @@ int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw
                       (hipStream_t)stream);
 }
 
+
+// ---- pair construction (row a15) ----
+int ssp_op_warp_image(const float* img_dev, const float* inv_h_dev, float* out_dev, int b, int hh, int w, int nearest,
+                      void* stream) {
+  const long n = (long)b * hh * w;
+  hipLaunchKernelGGL(warp_image_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img_dev, inv_h_dev,
+                     out_dev, b, hh, w, nearest ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_erode(const float* mask_dev, float* out_dev, int b, int hh, int w, int radius, void* stream) {
+  if (radius < 0 || radius > 32) return fail(-1, "erosion radius out of range");
+  const long n = (long)b * hh * w;
+  hipLaunchKernelGGL(erode_ellipse_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, mask_dev, out_dev, b,
+                     hh, w, radius);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_dev, int b, int hh, int w, void* stream) {
+  const long n = (long)b * hh * w;
+  HIPCHK(hipMemsetAsync(out_dev, 0, n * sizeof(float), (hipStream_t)stream));
+  hipLaunchKernelGGL(warp_labels_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, labels_dev, h_dev, out_dev,
+                     b, hh, w);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 
 // BatchNorm(+ReLU(+2x2 max-pool)) backward as an operator: y [N,H,W,C] raw conv output, dout = gradient wrt the
 // activated (pooled when pool=1: [N,H/2,W/2,C]) output; stats4 = {scale, shift, mean, invstd} each [C].

@@ -47,7 +47,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
            "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
-           "ssp_debug_buffer"]
+           "ssp_debug_buffer", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels"]
 
 
 def load_library(path=None):
@@ -81,6 +81,9 @@ def load_library(path=None):
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.ssp_op_warp_image.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    lib.ssp_op_erode.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.ssp_op_warp_labels.argtypes = [vp, vp, vp, i, i, i, vp]
     lib.ssp_op_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
     lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
@@ -418,3 +421,36 @@ def op_bn_bwd(y_nhwc, dout_nhwc, gamma, scale, shift, mean, invstd, relu=True, p
         _check(lib.ssp_op_bn_bwd(_ptr(y_nhwc), _ptr(dout_nhwc), _ptr(gamma), _ptr(stats4), _ptr(dy), _ptr(dg), _ptr(db),
                                  _ptr(dbias), _ptr(sums), N, H, W, Cc, int(relu), int(pool), _stream()))
     return dy, dg, db, dbias
+
+
+def op_warp_image(img, inv_h, nearest=False):
+    """inv_warp_image_batch on the device: img [B,1,H,W], inv_h [B,3,3] -> warped [B,1,H,W]."""
+    lib = load_library()
+    _need_gpu(img, "img")
+    inv_h = inv_h.to(img.device, torch.float32).contiguous()
+    B, _, H, W = img.shape
+    out = torch.empty_like(img)
+    with torch.cuda.device(img.device):
+        _check(lib.ssp_op_warp_image(_ptr(img), _ptr(inv_h), _ptr(out), B, H, W, int(bool(nearest)), _stream()))
+    return out
+
+
+def op_erode(mask, radius):
+    lib = load_library()
+    _need_gpu(mask, "mask")
+    B, _, H, W = mask.shape
+    out = torch.empty_like(mask)
+    with torch.cuda.device(mask.device):
+        _check(lib.ssp_op_erode(_ptr(mask), _ptr(out), B, H, W, int(radius), _stream()))
+    return out
+
+
+def op_warp_labels(labels, hn):
+    lib = load_library()
+    _need_gpu(labels, "labels")
+    hn = hn.to(labels.device, torch.float32).contiguous()
+    B, _, H, W = labels.shape
+    out = torch.empty_like(labels)
+    with torch.cuda.device(labels.device):
+        _check(lib.ssp_op_warp_labels(_ptr(labels), _ptr(hn), _ptr(out), B, H, W, _stream()))
+    return out

@@ -126,7 +126,18 @@ def warp_labels(labels, Hm):
     return out
 
 
+def _warps(device):
+    """(warp_image, erode, warp_labels): the HIP kernels on a GPU; the torch restatements above only serve the
+    host-side CPU tests of this generator (they are not a fallback of the training path)."""
+    if torch.device(device).type == "cuda":
+        from . import lib as L
+        return (lambda img, inv, mode="bilinear": L.op_warp_image(img.contiguous(), inv, nearest=(mode == "nearest")),
+                lambda m, r: L.op_erode(m.contiguous(), r), lambda lab, Hm: L.op_warp_labels(lab.contiguous(), Hm))
+    return warp_image, erode, warp_labels
+
+
 def make_pair(B, H, W, device, seed=0, semantic=False, kp_prob=0.003, erosion=3, n_classes=133):
+    warp_image, erode, warp_labels = _warps(device)
     rs = np.random.RandomState(seed)
     g = torch.Generator(device="cpu").manual_seed(seed)
     img = torch.rand(B, 1, H, W, generator=g).to(device)

@@ -156,3 +156,33 @@ def test_bn_relu_pool_backward(N, H, W, C, relu, pool):
     ref = y.grad.permute(0, 2, 3, 1)
     assert _rel(dy.cpu(), ref) < 1e-4
     assert _rel(dg.cpu(), gamma.grad) < 1e-4 and _rel(db.cpu(), beta.grad) < 1e-4
+
+
+def test_pair_construction_kernels_golden(golden_dir):
+    """Row a15: device warps vs the reference's arrays (G7: inv_warp_image_batch, compute_valid_mask with erosion 0,
+    warpLabels) and vs the oracle's erosion."""
+    from semantic_superpoint_amd import lib as L
+    from oracle import cpu_ref as C
+    from tests import golden_util as G
+    dev = _dev()
+    g = G.load("g7_warps.npz")
+    Hs = torch.from_numpy(g["H"])
+    inv = torch.inverse(Hs).contiguous()
+    img = torch.from_numpy(g["img"]).to(dev)
+    w = L.op_warp_image(img, inv)
+    assert (w.cpu() - torch.from_numpy(g["warped"])).abs().max() < 1e-5
+    ones = torch.ones_like(img)
+    m = L.op_warp_image(ones, inv, nearest=True)
+    ref_m = torch.from_numpy(g["mask"]).view_as(m.cpu())
+    assert float((m.cpu() != ref_m).float().mean()) < 1e-3  # nearest ties at .5 may flip
+    er = L.op_erode(m, 3).cpu()
+    er_ref = torch.stack([C.erode_ellipse(m.cpu()[i, 0], 3) for i in range(4)]).unsqueeze(1)
+    assert torch.equal(er, er_ref)
+    Hh, Ww = img.shape[2:]
+    for i in range(4):
+        lab = torch.zeros(1, 1, Hh, Ww)
+        pts = torch.from_numpy(g["pts%d" % i].astype(np.int64))
+        lab[0, 0, pts[:, 1], pts[:, 0]] = 1
+        out = L.op_warp_labels(lab.to(dev), Hs[i:i + 1]).cpu()
+        ref = torch.from_numpy(g["wlabels%d" % i]).view(1, 1, Hh, Ww)
+        assert float((out != ref).float().sum()) <= 2, i  # rounding ties of the analytic T^-1 H T
