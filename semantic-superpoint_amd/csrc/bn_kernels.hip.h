@@ -149,7 +149,8 @@ struct BnBwdArgs {
   const float* mean;
   const float* invstd;
   const float* gamma;
-  double* sums;      // [NREP][2C]
+  double* sums;      // [NREP][2C] pass-1 accumulators
+  const float* k12;  // [2C] S1/n, S2/n reduced over the replicas by bn_bwd_sums_kernel (pass 2 input)
   float* dbias;      // conv bias gradient (accumulated) or nullptr
   int N, H, W, C;
   int y_cs, y_co, d_cs, d_co, dy_cs, dy_co;
@@ -189,15 +190,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
       float s1[4], s2[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        double t1 = 0, t2 = 0;
-        if (cv[i]) {
-          for (int r = 0; r < NREP; ++r) {
-            t1 += a.sums[(size_t)r * 2 * a.C + c0 + i];
-            t2 += a.sums[(size_t)r * 2 * a.C + a.C + c0 + i];
-          }
-        }
-        s1[i] = (float)(t1 / a.count);
-        s2[i] = (float)(t2 / a.count);
+        s1[i] = cv[i] ? a.k12[c0 + i] : 0.f;
+        s2[i] = cv[i] ? a.k12[a.C + c0 + i] : 0.f;
       }
       k1 = make_float4(s1[0], s1[1], s1[2], s1[3]);
       k2 = make_float4(s2[0], s2[1], s2[2], s2[3]);
@@ -303,8 +297,6 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
           double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 2 * a.C;
           unsafeAtomicAdd(sm + c0 + i, (double)acc[i]);
           unsafeAtomicAdd(sm + a.C + c0 + i, (double)acc[4 + i]);
-        } else if (a.dbias != nullptr) {
-          atomicAdd(a.dbias + c0 + i, acc[i]);
         }
       }
     }
@@ -326,13 +318,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     scv[i] = a.scale[c0 + i]; shv[i] = a.shift[c0 + i]; muv[i] = a.mean[c0 + i]; isv[i] = a.invstd[c0 + i];
-    double t1 = 0, t2 = 0;
-    for (int r = 0; r < NREP; ++r) {
-      t1 += a.sums[(size_t)r * 128 + c0 + i];
-      t2 += a.sums[(size_t)r * 128 + 64 + c0 + i];
-    }
-    k1v[i] = (float)(t1 / a.count);
-    k2v[i] = (float)(t2 / a.count);
+    k1v[i] = a.k12[c0 + i];
+    k2v[i] = a.k12[64 + c0 + i];
     gsv[i] = a.gamma[c0 + i] * isv[i];
   }
   float wacc[4][9], bacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -379,14 +366,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a,
       for (int r = 0; r < 16; ++r) sum += red[(r * 16 + qq) * 10 + t];
       const int co = qq * 4 + i;
       if (t < 9) atomicAdd(dw + co * 9 + t, sum);
-      else if (a.dbias != nullptr) atomicAdd(a.dbias + co, sum);
     }
   }
 }
 
-// dgamma += S2, dbeta += S1 (fp64 sums of bn_bwd pass 1)
-__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int C) {
+// Between the two passes: reduce the NREP replicas of the fp64 sums ONCE (one thread per channel) into
+// k12 = {S1/n, S2/n} for pass 2, and accumulate dgamma += S2, dbeta += S1.  (Letting every pass-2 thread sum the
+// 32 replicas itself cost a fixed ~110 us per launch: 2.6 ms per step in the first profiles.)
+__global__ void bn_bwd_sums_kernel(const double* __restrict__ sums, float* __restrict__ k12, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta, float* __restrict__ dbias, const float* __restrict__ gamma,
+                                   const float* __restrict__ invstd, int C, double count) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0, s2 = 0;
@@ -394,8 +383,16 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __r
     s1 += sums[(size_t)r * 2 * C + c];
     s2 += sums[(size_t)r * 2 * C + C + c];
   }
-  dbeta[c] += (float)s1;
-  dgamma[c] += (float)s2;
+  const float k1 = (float)(s1 / count), k2 = (float)(s2 / count);
+  k12[c] = k1;
+  k12[C + c] = k2;
+  if (dbeta != nullptr) dbeta[c] += (float)s1;
+  if (dgamma != nullptr) dgamma[c] += (float)s2;
+  // Gradient of the conv bias that feeds this BatchNorm: sum_p dY = gamma*invstd*(S1 - n*k1 - k2*sum xhat) == 0 in
+  // exact arithmetic (the reference's autograd produces rounding noise here).  It is
+  // evaluated from the sums (what is left is the fp32 rounding of k1) instead of by one float atomic per channel
+  // and block in pass 2, which cost ~110 us per launch through same-address contention.
+  if (dbias != nullptr) dbias[c] += gamma[c] * invstd[c] * (float)(s1 - count * (double)k1);
 }
 
 // ------------------------------------------------------------------------------------------------

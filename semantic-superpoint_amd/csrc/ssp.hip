@@ -61,6 +61,7 @@ struct BnBufs {
   double* stats;   // [2C]
   double* bsums;   // [2C] backward sums
   float *scale, *shift, *mean, *invstd;
+  float* k12;      // [2C] reduced backward sums / n
 };
 
 struct Slot {
@@ -219,6 +220,7 @@ static size_t carve(ssp_handle* h, void* base) {
       S.bn[l].bsums = st; st += 2 * C * NREP;
       S.bn[l].scale = c.take<float>(C); S.bn[l].shift = c.take<float>(C);
       S.bn[l].mean = c.take<float>(C); S.bn[l].invstd = c.take<float>(C);
+      S.bn[l].k12 = c.take<float>(2 * C);
     }
   }
   const size_t big = (size_t)B * H * W * 64;
@@ -383,13 +385,17 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   return 0;
 }
 
+// pass 1 (sums) -> replica reduction + dgamma/dbeta -> pass 2 (apply)
 template <bool RELU, bool POOL>
-static int launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
+static int launch_bn_bwd(const BnBwdArgs& a, float* k12, float* dgamma, float* dbeta, hipStream_t st) {
+  // a.dbias (conv bias gradient, may be null) is produced by bn_bwd_sums_kernel
   const int nq = (a.C + 3) / 4, rows = 256 / nq;
   const long npix = (long)a.N * (POOL ? a.H / 2 : a.H) * (POOL ? a.W / 2 : a.W);
   int nb = cdiv(npix, rows);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a.C, 64)), dim3(64), 0, st, a.sums, k12, dgamma, dbeta, a.dbias, a.gamma,
+                     a.invstd, a.C, a.count);
   hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -584,17 +590,19 @@ static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* d
     a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums; a.dbias = Gd(h, d.b_off);
     a.N = N; a.H = H; a.W = W; a.C = d.cout; a.y_cs = S.y_cs[l]; a.y_co = S.y_co[l]; a.d_cs = d_cs; a.d_co = d_co;
     a.dy_cs = dy_cs; a.dy_co = dy_co; a.count = (double)N * H * W;
+    a.k12 = S.bn[l].k12;
+    float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
     if (l == 0) {
       // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised)
       const long npix = (long)N * H * W;
       const int nb = std::min(cdiv(npix, 16), 1024);
       hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(64), 0, st, a.sums, S.bn[l].k12, dg, db, a.dbias, a.gamma, a.invstd,
+                         64, a.count);
       hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, Gd(h, d.w_off));
-    } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, st)));
-    else if (relu) CHK((launch_bn_bwd<true, false>(a, st)));
-    else CHK((launch_bn_bwd<false, false>(a, st)));
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, S.bn[l].bsums, Gd(h, d.g_off),
-                       Gd(h, d.be_off), d.cout);
+    } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, S.bn[l].k12, dg, db, st)));
+    else if (relu) CHK((launch_bn_bwd<true, false>(a, S.bn[l].k12, dg, db, st)));
+    else CHK((launch_bn_bwd<false, false>(a, S.bn[l].k12, dg, db, st)));
     HIPCHK(hipGetLastError());
   }
   if (l == 0) return 0;
@@ -660,9 +668,8 @@ static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float
       a.mean = S.bn[l].mean; a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums;
       a.dbias = Gd(h, d.b_off); a.N = N; a.H = Hc; a.W = Wc; a.C = 256; a.y_cs = hcs; a.y_co = 256 * k; a.d_cs = hcs;
       a.d_co = 256 * k; a.dy_cs = hcs; a.dy_co = 256 * k; a.count = (double)N * Hc * Wc;
-      CHK((launch_bn_bwd<true, false>(a, st)));
-      hipLaunchKernelGGL(bn_param_grad_kernel, dim3(4), dim3(64), 0, st, S.bn[l].bsums, Gd(h, d.g_off), Gd(h, d.be_off), 256);
-      HIPCHK(hipGetLastError());
+      a.k12 = S.bn[l].k12;
+      CHK((launch_bn_bwd<true, false>(a, S.bn[l].k12, Gd(h, d.g_off), Gd(h, d.be_off), st)));
     }
     for (int k = 0; k < h->nheads; ++k) {
       const int l = heads[k];
@@ -947,11 +954,13 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
   a.y = y_dev; a.dout = dout_dev; a.dy = dy_dev; a.scale = stats4_dev; a.shift = stats4_dev + c; a.mean = stats4_dev + 2 * c;
   a.invstd = stats4_dev + 3 * c; a.gamma = gamma_dev; a.sums = sums_dev; a.dbias = dbias_dev; a.N = n; a.H = hh; a.W = w;
   a.C = c; a.y_cs = c; a.y_co = 0; a.d_cs = c; a.d_co = 0; a.dy_cs = c; a.dy_co = 0; a.count = (double)n * hh * w;
-  if (relu && pool) CHK((launch_bn_bwd<true, true>(a, st)));
-  else if (relu) CHK((launch_bn_bwd<true, false>(a, st)));
-  else CHK((launch_bn_bwd<false, false>(a, st)));
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, sums_dev, dgamma_dev, dbeta_dev, c);
-  HIPCHK(hipGetLastError());
+  float* k12 = nullptr;
+  HIPCHK(hipMallocAsync((void**)&k12, 2 * c * sizeof(float), st));
+  a.k12 = k12;
+  if (relu && pool) CHK((launch_bn_bwd<true, true>(a, k12, dgamma_dev, dbeta_dev, st)));
+  else if (relu) CHK((launch_bn_bwd<true, false>(a, k12, dgamma_dev, dbeta_dev, st)));
+  else CHK((launch_bn_bwd<false, false>(a, k12, dgamma_dev, dbeta_dev, st)));
+  HIPCHK(hipFreeAsync(k12, st));
   return 0;
 }
 
