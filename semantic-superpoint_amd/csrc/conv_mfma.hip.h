@@ -29,6 +29,14 @@ struct ConvArgs {
   const float* in_scale;  // [Cin] (IN_MODE != 0)
   const float* in_shift;
   double* stats;          // [NREP][2*Cout] sum, sumsq of the (biased) conv output, or nullptr
+  // second, independent problem of identical shape and weights (the other view of the pair): nprob == 2 splits
+  // the persistent grid by XCD (0-3 -> problem 0, 4-7 -> problem 1) so that the 30x40 maps fill the chip
+  const float* in2;
+  float* out2;
+  const float* in_scale2;
+  const float* in_shift2;
+  double* stats2;
+  int nprob;
   int N, H, W;
   int Cin, in_cs, in_co;
   int Cout, out_cs, out_co;
@@ -136,10 +144,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int per_cob = nslot / a.ncob;           // blocks per (XCD, cob)
   const int cob = slot % a.ncob, jj = slot / a.ncob;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  const int per_t = (ntiles + 7) >> 3;
-  const int t_end = min(ntiles, (xcd + 1) * per_t);
-  int tile = xcd * per_t + jj;
+  const int xpp = 8 / a.nprob;                  // XCDs per problem
+  const int prob = xcd / xpp, xl = xcd - prob * xpp;
+  const int per_t = (ntiles + xpp - 1) / xpp;
+  const int t_end = min(ntiles, (xl + 1) * per_t);
+  int tile = xl * per_t + jj;
   if (jj >= per_cob || tile >= t_end) return;   // whole block exits before any barrier
+  const float* const p_in = prob ? a.in2 : a.in;
+  float* const p_out = prob ? a.out2 : a.out;
+  const float* const p_scale = prob ? a.in_scale2 : a.in_scale;
+  const float* const p_shift = prob ? a.in_shift2 : a.in_shift;
+  double* const p_stats = prob ? a.stats2 : a.stats;
 
   int pr, pc;
   mpix<SW>(li, pr, pc);
@@ -186,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const bool cvalid_ = c0_ < a.Cin;                                                                   \
     if (IN_MODE != 0) {                                                                                 \
       const int cc_ = cvalid_ ? c0_ : 0;                                                                \
-      psc = *reinterpret_cast<const f32x4*>(a.in_scale + cc_);                                          \
-      psh = *reinterpret_cast<const f32x4*>(a.in_shift + cc_);                                          \
+      psc = *reinterpret_cast<const f32x4*>(p_scale + cc_);                                             \
+      psh = *reinterpret_cast<const f32x4*>(p_shift + cc_);                                             \
     }                                                                                                   \
     if (IN_MODE != 2) {                                                                                 \
       const int soff_ = (CHUNK) * CK * 4;                                                               \
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 4096, 0)); \
   }
 
-  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in), 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
   const bool partial_k = (a.Cin % CK) != 0;  // last K-chunk has channel quads beyond Cin (65/133-channel dY)
 
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll 2
           for (int pp = tid >> 2; pp < G::HT * G::WT; pp += 64) {
             const int r = pp / G::WT, c = pp - r * G::WT;
-            const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs, coff,
+            const float4 v = load_in<IN_MODE>(p_in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs, coff,
                                               cvalid, sc4, sh4);
             *reinterpret_cast<float4*>(sA + (r * G::RP + c) * CS + q4 * 4) = v;
           }
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int orow = (wave * 2 + mt) * SH + rr;
             const float v = acc[mt][nt][r] + bias_v[nt];
             smem[(orow * G::TW + cc) * NB + nt * 32 + li] = v;
-            if (a.stats != nullptr && covalid[nt] && (full || (ty0 + orow < a.H && tx0 + cc < a.W))) {
+            if (p_stats != nullptr && covalid[nt] && (full || (ty0 + orow < a.H && tx0 + cc < a.W))) {
               ssum[nt] += v;
               ssq[nt] += v * v;
             }
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         const int oy = ty0 + orow, ox = tx0 + ocol;
         if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(smem + lp * NB + q16 * 4);
-          float* p = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
+          float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
           if (nvalid == 4) {
             *reinterpret_cast<f32x4*>(p) = v;
           } else {
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     tile = next_tile;
   }
 
-  if (a.stats != nullptr) {
+  if (p_stats != nullptr) {
     __syncthreads();
     float* red = smem;  // [4 waves][2 nt][32][2]
 #pragma unroll
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int w = 0; w < 4; ++w) t += red[((w * 2 + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
       const int co = cob * NB + ch;
       if (co < a.Cout)
-        unsafeAtomicAdd(a.stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
+        unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
     }
   }
 }
@@ -396,10 +411,16 @@ struct WgradArgs {
   float* partial;         // [ncib*ncob*nsplit][TAPS][64][64]
   const float* in_scale;
   const float* in_shift;
+  // second problem (other view of the pair) accumulated into the SAME weight gradient: tiles [ntiles, 2*ntiles)
+  const float* in2;
+  const float* dout2;
+  const float* in_scale2;
+  const float* in_shift2;
+  int nprob;
   int N, H, W;
   int Cin, in_cs, in_co;
   int Cout, dout_cs, dout_co;
-  int tiles_x, tiles_y, ntiles;  // per-image tiles and total tiles
+  int tiles_x, tiles_y, ntiles;  // per-image tiles and total tiles of ONE problem
   int ncib, ncob, nsplit;
 };
 
@@ -414,7 +435,7 @@ struct WgradGeom {
   static constexpr int P = TH * TW;  // 64
   static constexpr int X_FLOATS = HT * WT * 64;
   static constexpr int D_FLOATS = P * 64;
-  static constexpr int LDS_BYTES = (X_FLOATS + D_FLOATS + 128) * 4;  // + scale/shift of the 64 input channels
+  static constexpr int LDS_BYTES = (X_FLOATS + D_FLOATS + 256) * 4;  // + scale/shift of the 64 input channels x 2 problems
 };
 
 // Block = 4 waves = (ci half, co half); 2 blocks per CU (51 KB LDS, <= 256 registers incl. 144 accumulators).
@@ -438,8 +459,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
   bid /= a.nsplit;
   const int cob = bid % a.ncob;
   const int cib = bid / a.ncob;
-  const int per = (a.ntiles + a.nsplit - 1) / a.nsplit;
-  const int t_begin = split * per, t_end = min(a.ntiles, t_begin + per);
+  const int tot_tiles = a.ntiles * a.nprob;
+  const int per = (tot_tiles + a.nsplit - 1) / a.nsplit;
+  const int t_begin = split * per, t_end = min(tot_tiles, t_begin + per);
 
   f32x16 acc[G::TAPS];
 #pragma unroll
@@ -452,14 +474,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
   const bool civalid = ci0 < a.Cin;
   // BN scale/shift of this block's 64 input channels live in LDS (frees 8 VGPRs of a 256-register kernel)
   float* sS = smem + G::X_FLOATS + G::D_FLOATS;
-  if (IN_MODE != 0 && tid < 16) {
+  if (IN_MODE != 0 && tid < 32) {
+    const int pr = tid >> 4;  // problem 0 / 1
     f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
-    if (civalid) {
-      sc0 = *reinterpret_cast<const f32x4*>(a.in_scale + ci0);
-      sh0 = *reinterpret_cast<const f32x4*>(a.in_shift + ci0);
+    if (civalid && pr < a.nprob) {
+      sc0 = *reinterpret_cast<const f32x4*>((pr ? a.in_scale2 : a.in_scale) + ci0);
+      sh0 = *reinterpret_cast<const f32x4*>((pr ? a.in_shift2 : a.in_shift) + ci0);
     }
-    *reinterpret_cast<f32x4*>(sS + q16 * 4) = sc0;
-    *reinterpret_cast<f32x4*>(sS + 64 + q16 * 4) = sh0;
+    *reinterpret_cast<f32x4*>(sS + pr * 128 + q16 * 4) = sc0;
+    *reinterpret_cast<f32x4*>(sS + pr * 128 + 64 + q16 * 4) = sh0;
   }
   const int co0 = cob * 64 + q16 * 4;
   const bool covalid = co0 < a.Cout;
@@ -471,7 +494,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
 
 #define SSP_WG_ISSUE(TILE)                                                                                    \
   {                                                                                                           \
-    const int tx_ = (TILE) % a.tiles_x, t2_ = (TILE) / a.tiles_x;                                             \
+    const int pr_ = (TILE) >= a.ntiles ? 1 : 0;                                                               \
+    const int tl_ = (TILE) - pr_ * a.ntiles;                                                                  \
+    const float* const pin_ = pr_ ? a.in2 : a.in;                                                             \
+    const float* const pdo_ = pr_ ? a.dout2 : a.dout;                                                         \
+    const int tx_ = tl_ % a.tiles_x, t2_ = tl_ / a.tiles_x;                                                   \
     const int ty0_ = (t2_ % a.tiles_y) * G::TH, tx0_ = tx_ * G::TW, n_ = t2_ / a.tiles_y;                     \
     xmask = 0; dmask = 0;                                                                                     \
     if (IN_MODE != 2) {                                                                                       \
@@ -481,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
         const int gy = ty0_ + r - G::PAD, gx = tx0_ + c - G::PAD;                                             \
         const bool ok = pp < G::HT * G::WT && civalid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
         const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + ci0 : (size_t)0;   \
-        xreg[i] = *reinterpret_cast<const f32x4*>(a.in + off);                                                \
+        xreg[i] = *reinterpret_cast<const f32x4*>(pin_ + off);                                                \
         xmask |= (ok ? 1u : 0u) << i;                                                                         \
       }                                                                                                       \
     }                                                                                                         \
@@ -491,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
       const int gy = ty0_ + r, gx = tx0_ + c;                                                                 \
       const bool ok = covalid && gy < a.H && gx < a.W;                                                        \
       const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.dout_cs + a.dout_co + co0 : (size_t)0; \
-      dreg[i] = *reinterpret_cast<const f32x4*>(a.dout + off);                                                \
+      dreg[i] = *reinterpret_cast<const f32x4*>(pdo_ + off);                                                  \
       dmask |= (ok ? 1u : 0u) << i;                                                                           \
     }                                                                                                         \
   }
@@ -500,10 +527,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // all waves finished reading the previous tile's LDS image
     {
+      const int cur_prob = tile >= a.ntiles ? 1 : 0;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (IN_MODE != 0) {  // written before the first barrier above by threads 0..15
-        sc = *reinterpret_cast<const f32x4*>(sS + q16 * 4);
-        sh = *reinterpret_cast<const f32x4*>(sS + 64 + q16 * 4);
+      if (IN_MODE != 0) {  // written before the first barrier above by threads 0..31
+        sc = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + q16 * 4);
+        sh = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + 64 + q16 * 4);
       }
       if (IN_MODE != 2) {
 #pragma unroll
@@ -522,14 +550,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
           }
         }
       } else {
-        int t = tile;
+        int t = tile - cur_prob * a.ntiles;
+        const float* const pin = cur_prob ? a.in2 : a.in;
         const int tx = t % a.tiles_x;
         t /= a.tiles_x;
         const int ty0 = (t % a.tiles_y) * G::TH, tx0 = tx * G::TW, n = t / a.tiles_y;
         const float4 sc4 = make_float4(sc[0], sc[1], sc[2], sc[3]), sh4 = make_float4(sh[0], sh[1], sh[2], sh[3]);
         for (int pp = tid >> 4; pp < G::HT * G::WT; pp += 16) {
           const int r = pp / G::WT, c = pp - r * G::WT;
-          const float4 v = load_in<IN_MODE>(a.in, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs,
+          const float4 v = load_in<IN_MODE>(pin, n, ty0 + r - G::PAD, tx0 + c - G::PAD, a.H, a.W, a.in_cs,
                                             a.in_co + ci0, civalid, sc4, sh4);
           *reinterpret_cast<float4*>(sX + pp * 64 + q16 * 4) = v;
         }

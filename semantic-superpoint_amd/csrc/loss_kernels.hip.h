@@ -41,9 +41,10 @@ struct StepAccum {
   double mask_cnt[2];   // mask.sum() per view
   double sem_sum[2];    // sum of NLL over non-ignored pixels
   double sem_cnt[2];    // number of non-ignored pixels
-  double pos_sum[64];   // per image: sum_k max(0, 1 - <a,b>)
-  double neg_sum[64];   // per image: sum max(0, <a,b> - 0.2)
-  unsigned int nnz[64]; // per image: number of non-zero non-match hinges
+  double pos_sum[64 * 16];   // per image x 16 replicas: sum_k max(0, 1 - <a,b>)
+  double neg_sum[64 * 16];   // per image x 16 replicas: sum max(0, <a,b> - 0.2)
+  unsigned int nnz[64 * 16]; // per image x 16 replicas: number of non-zero non-match hinges
+  unsigned int nnz_img[64];  // per image totals (desc_counts_kernel), read by the backward kernels
   float coef_det, coef_pos, coef_neg, coef_sem;  // d total / d (loss_det sum), d/d pos mean, d/d neg mean, d/d sem sum
 };
 
@@ -176,6 +177,8 @@ __device__ __forceinline__ void atomic_add4(float* p, float4 v) {
   atomicAdd(p + 3, v.w);
 }
 
+// Channel mapping: lane l holds channels l, l+64, l+128, l+192, so every load AND every atomic instruction of a wave
+// covers 256 contiguous bytes (with 4 consecutive channels per lane the scatter hit each cache line 4 times).
 template <bool BWD>
 __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict__ desc_a, const float* __restrict__ desc_b,
                                                          const int32_t* __restrict__ match_a,
@@ -186,29 +189,36 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
   const int lane = threadIdx.x & 63;
   if (w >= B * n_match) return;
   const int img = w / n_match;
-  const size_t base = (size_t)img * Hc * Wc * 256 + lane * 4;
+  const size_t base = (size_t)img * Hc * Wc * 256 + lane;
   const Bilin ba = bilin_setup(match_a[w], Hc, Wc), bb = bilin_setup(match_b[w], Hc, Wc);
-  auto ld = [&](const float* d, int i) { return *reinterpret_cast<const float4*>(d + base + (size_t)i * 256); };
-  float4 va = make_float4(0, 0, 0, 0), vb = va;
+  float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
   // torch accumulates nw, ne, sw, se in this order
-  va = f4_fma(ba.w00, ld(desc_a, ba.i00), va); va = f4_fma(ba.w01, ld(desc_a, ba.i01), va);
-  va = f4_fma(ba.w10, ld(desc_a, ba.i10), va); va = f4_fma(ba.w11, ld(desc_a, ba.i11), va);
-  vb = f4_fma(bb.w00, ld(desc_b, bb.i00), vb); vb = f4_fma(bb.w01, ld(desc_b, bb.i01), vb);
-  vb = f4_fma(bb.w10, ld(desc_b, bb.i10), vb); vb = f4_fma(bb.w11, ld(desc_b, bb.i11), vb);
-  const float dot = wave_sum(va.x * vb.x + va.y * vb.y + va.z * vb.z + va.w * vb.w);
+  const int ia[4] = {ba.i00, ba.i01, ba.i10, ba.i11}, ib[4] = {bb.i00, bb.i01, bb.i10, bb.i11};
+  const float wa[4] = {ba.w00, ba.w01, ba.w10, ba.w11}, wb[4] = {bb.w00, bb.w01, bb.w10, bb.w11};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      va[j] = fmaf(wa[k], desc_a[base + (size_t)ia[k] * 256 + 64 * j], va[j]);
+      vb[j] = fmaf(wb[k], desc_b[base + (size_t)ib[k] * 256 + 64 * j], vb[j]);
+    }
+  const float dot = wave_sum(va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2] + va[3] * vb[3]);
   const float hinge = fmaxf(1.f - dot, 0.f);
   if (!BWD) {
-    // n_match is a multiple of 4 in every config: the 4 waves of a block belong to one image
-    if (lane == 0) unsafeAtomicAdd(&acc->pos_sum[img], (double)hinge);
+    if (lane == 0) unsafeAtomicAdd(&acc->pos_sum[img * 16 + ((w >> 2) & 15)], (double)hinge);  // 16 replicas / image
   } else if (hinge > 0.f) {
     const float c = -acc->coef_pos / ((float)n_match * (float)B);  // d total / d dot
-    const float4 ga = make_float4(c * vb.x, c * vb.y, c * vb.z, c * vb.w);
-    const float4 gb = make_float4(c * va.x, c * va.y, c * va.z, c * va.w);
-    auto sc = [&](float* d, int i, float wgt, float4 g) {
-      if (wgt != 0.f) atomic_add4(d + base + (size_t)i * 256, make_float4(wgt * g.x, wgt * g.y, wgt * g.z, wgt * g.w));
-    };
-    sc(dd_a, ba.i00, ba.w00, ga); sc(dd_a, ba.i01, ba.w01, ga); sc(dd_a, ba.i10, ba.w10, ga); sc(dd_a, ba.i11, ba.w11, ga);
-    sc(dd_b, bb.i00, bb.w00, gb); sc(dd_b, bb.i01, bb.w01, gb); sc(dd_b, bb.i10, bb.w10, gb); sc(dd_b, bb.i11, bb.w11, gb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (wa[k] != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(dd_a + base + (size_t)ia[k] * 256 + 64 * j, wa[k] * c * vb[j]);
+      }
+      if (wb[k] != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(dd_b + base + (size_t)ib[k] * 256 + 64 * j, wb[k] * c * va[j]);
+      }
+    }
   }
 }
 
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256) void desc_nonmatch_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < 4; ++i) ga[i] = make_float4(0, 0, 0, 0);
   float wgt = 0.f;
-  if (BWD) wgt = acc->coef_neg / (((float)acc->nnz[img] + 1.f) * (float)B);
+  if (BWD) wgt = acc->coef_neg / (((float)acc->nnz_img[img] + 1.f) * (float)B);
   float hsum = 0.f;
   unsigned cnt = 0;
   const int32_t* nm = nonmatch_b + (size_t)w * n_non;
@@ -272,8 +282,9 @@ __global__ __launch_bounds__(256) void desc_nonmatch_kernel(const float* __restr
     hsum = wave_sum(hsum);
     float c = wave_sum((float)cnt);
     if (lane == 0) {
-      unsafeAtomicAdd(&acc->neg_sum[img], (double)hsum);
-      atomicAdd(&acc->nnz[img], (unsigned)(c + 0.5f));
+      const int rep = img * 16 + ((w >> 2) & 15);  // 16 replicas / image: ~60 instead of 1000 atomics per address
+      unsafeAtomicAdd(&acc->neg_sum[rep], (double)hsum);
+      atomicAdd(&acc->nnz[rep], (unsigned)(c + 0.5f));
     }
   } else {
     // sum the 4 lane groups' contributions to d a_k, then one atomic per channel
@@ -288,12 +299,21 @@ __global__ __launch_bounds__(256) void desc_nonmatch_kernel(const float* __restr
   }
 }
 
+// per-image totals of the non-zero hinge counts (between the forward and backward descriptor kernels)
+__global__ void desc_counts_kernel(StepAccum* acc, int B) {
+  const int i = threadIdx.x;
+  if (i >= B) return;
+  unsigned nz = 0;
+  for (int r = 0; r < 16; ++r) nz += acc->nnz[i * 16 + r];
+  acc->nnz_img[i] = nz;
+}
+
 // ---- MultiTaskLoss coefficients (before the loss kernels) and scalars / eta gradient (after) ----
 __global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta, int multi_task, float lambda_loss,
                                   float lamda_d, int semantic) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < 2; ++i) acc->det_sum[i] = acc->mask_cnt[i] = acc->sem_sum[i] = acc->sem_cnt[i] = 0.0;
-  for (int i = 0; i < 64; ++i) {
+  for (int i = 0; i < 64 * 16; ++i) {
     acc->pos_sum[i] = acc->neg_sum[i] = 0.0;
     acc->nnz[i] = 0u;
   }
@@ -319,8 +339,13 @@ __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ 
   float pos = 0.f, neg = 0.f, ldesc = 0.f;
   if (lambda_loss > 0.f) {
     for (int i = 0; i < B; ++i) {
-      const float p = (float)acc->pos_sum[i] / (float)n_match;
-      const float q = (float)acc->neg_sum[i] / ((float)acc->nnz[i] + 1.f);
+      double ps = 0, ns = 0;
+      for (int r = 0; r < 16; ++r) {
+        ps += acc->pos_sum[i * 16 + r];
+        ns += acc->neg_sum[i * 16 + r];
+      }
+      const float p = (float)ps / (float)n_match;
+      const float q = (float)ns / ((float)acc->nnz_img[i] + 1.f);
       pos += p;
       neg += q;
       ldesc += lamda_d * p + q;
@@ -357,8 +382,15 @@ __global__ void sparse_loss_means_kernel(const StepAccum* acc, float* out, int B
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float pos = 0.f, neg = 0.f;
   for (int i = 0; i < B; ++i) {
-    pos += (float)acc->pos_sum[i] / (float)n_match;
-    neg += (float)acc->neg_sum[i] / ((float)acc->nnz[i] + 1.f);
+    double ps = 0, ns = 0;
+    unsigned nz = 0;
+    for (int r = 0; r < 16; ++r) {
+      ps += acc->pos_sum[i * 16 + r];
+      ns += acc->neg_sum[i * 16 + r];
+      nz += acc->nnz[i * 16 + r];
+    }
+    pos += (float)ps / (float)n_match;
+    neg += (float)ns / ((float)nz + 1.f);
   }
   out[0] = pos / (float)B;
   out[1] = neg / (float)B;

@@ -74,6 +74,7 @@ struct Slot {
   float* dsemi;     // [B*cells*80]
   float* ddesc;     // [B*cells*256]
   float* dsout;     // [B*cells*SOUT_CS] gradient wrt convSout output (ssmall)
+  float *gP, *gQ;   // backward ping-pong buffers of this slot (dOut / dY)
   const float* x;   // input image of the last forward (caller-owned)
   void* stats_region;
   size_t stats_bytes;
@@ -92,7 +93,6 @@ struct ssp_handle {
   size_t ws_bytes;
   Slot slot[2];
   float *wpk_fwd, *wpk_bwd, *wpk_heads_bwd;
-  float *gP, *gQ;    // backward ping-pong buffers
   float* partial;    // wgrad partial slabs
   size_t partial_floats;
   StepAccum* accum;
@@ -224,8 +224,10 @@ static size_t carve(ssp_handle* h, void* base) {
     }
   }
   const size_t big = (size_t)B * H * W * 64;
-  h->gP = c.take<float>(big);
-  h->gQ = c.take<float>(big);
+  for (int s = 0; s < 2; ++s) {
+    h->slot[s].gP = c.take<float>(big);
+    h->slot[s].gQ = c.take<float>(big);
+  }
   h->partial_floats = (size_t)1024 * 9 * 4096;
   h->partial = c.take<float>(h->partial_floats);
   h->accum = c.take<StepAccum>(1);
@@ -274,6 +276,10 @@ struct ConvCall {
   float* out; int out_cs, out_co, cout;
   const float* in_scale; const float* in_shift; double* stats;
   int N, H, W, ks, in_mode, nchunks, ncob;
+  // optional second problem (same shapes / weights): the other view of the pair
+  int nprob = 1;
+  const float* in2 = nullptr; float* out2 = nullptr;
+  const float* in_scale2 = nullptr; const float* in_shift2 = nullptr; double* stats2 = nullptr;
 };
 
 static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int prof_family = 0) {
@@ -281,6 +287,8 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   a.in = c.in; a.wpk = c.wpk; a.bias = c.bias; a.out = c.out; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.stats = c.stats; a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
   a.Cout = c.cout; a.out_cs = c.out_cs; a.out_co = c.out_co; a.nchunks = c.nchunks; a.ncob = c.ncob;
+  a.nprob = c.nprob; a.in2 = c.in2; a.out2 = c.out2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
+  a.stats2 = c.stats2;
   {
     auto clampu = [](double v) { return v > 4294967295.0 ? 4294967295u : (unsigned)v; };
     const double in_px = (double)c.N * c.H * c.W * (c.in_mode == 2 ? 4 : 1);
@@ -297,8 +305,8 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   int nblocks = std::max(8, (2 * n_cu) / 8 * 8);
   if (getenv("SSP_CONV_GRID")) nblocks = atoi(getenv("SSP_CONV_GRID"));  // perf-debug only
   if ((nblocks / 8) < c.ncob) return fail(-3, "too many output-channel blocks (%d) for the persistent grid", c.ncob);
-  const double flops = 2.0 * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
-  const double bytes = 4.0 * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
+  const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
+  const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
   int fam = prof_family;
   if (prof_family == SSP_PROF_CONV3X3_FWD && h && h->prof_family == SSP_PROF_CONV_BIG_FWD && c.H * c.W >= 240 * 320 &&
       c.cin == 64)
@@ -333,6 +341,9 @@ struct WgradCall {
   const float* in_scale; const float* in_shift;
   float* dw;  // OIHW gradient, accumulated
   int N, H, W, ks, in_mode;
+  int nprob = 1;  // optional second problem accumulated into the same gradient
+  const float* in2 = nullptr; const float* dout2 = nullptr;
+  const float* in_scale2 = nullptr; const float* in_shift2 = nullptr;
 };
 
 static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_t partial_floats, int n_cu,
@@ -341,6 +352,7 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.in = c.in; a.dout = c.dout; a.partial = partial; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
   a.Cout = c.cout; a.dout_cs = c.dout_cs; a.dout_co = c.dout_co;
+  a.nprob = c.nprob; a.in2 = c.in2; a.dout2 = c.dout2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
   const bool wide = (c.W % 32) == 0;
   const int TH = wide ? 2 : 8, TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
@@ -350,14 +362,14 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   const int taps = c.ks * c.ks;
   int nsplit = (2 * n_cu) / pairs / 8 * 8;  // 2 blocks per CU; multiple of 8: blocks sharing tiles share an XCD
   if (nsplit < 1) nsplit = 1;
-  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  if (nsplit > a.ntiles * a.nprob) nsplit = a.ntiles * a.nprob;
   while ((size_t)pairs * nsplit * taps * 4096 > partial_floats && nsplit > 1) --nsplit;
   if ((size_t)pairs * nsplit * taps * 4096 > partial_floats) return fail(-4, "wgrad scratch too small");
   a.nsplit = nsplit;
   const int nblocks = pairs * nsplit;
   {
-    const double flops = 2.0 * c.N * c.H * c.W * (double)c.cin * c.cout * taps;
-    const double bytes = 4.0 * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
+    const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * taps;
+    const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
     ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes);
 #define WG_CASE(KS_, M_)                                                              \
   if (c.ks == KS_ && c.in_mode == M_) {                                               \
@@ -528,175 +540,211 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
   return 0;
 }
 
-static int conv_layer_fwd(ssp_handle* h, Slot& S, int l, int src, int N, int H, int W, int in_mode, int train,
+// One or two activation slots processed together: the two views of a pair are independent problems of identical
+// shape that share the weights, so the MFMA kernels take both in ONE launch (conv: XCDs 0-3 / 4-7; wgrad: one
+// gradient accumulated over both) while the BatchNorm statistics stay per view (Train_model_heatmap_all.py:258,262).
+struct SlotSet {
+  int n;
+  Slot* s[2];
+};
+
+static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int N, int H, int W, int in_mode, int train,
                           hipStream_t st) {
   const LayerDesc& d = h->L[l];
+  Slot& A = *SS.s[0];
   ConvCall c;
-  c.in = S.Y[src]; c.in_cs = S.y_cs[src]; c.in_co = S.y_co[src]; c.cin = d.cin;
+  c.in = A.Y[src]; c.in_cs = A.y_cs[src]; c.in_co = A.y_co[src]; c.cin = d.cin;
   c.wpk = h->wpk_fwd + d.pk_fwd; c.bias = P(h, d.b_off);
-  c.out = S.Y[l]; c.out_cs = S.y_cs[l]; c.out_co = S.y_co[l]; c.cout = d.cout;
-  c.in_scale = S.bn[src].scale; c.in_shift = S.bn[src].shift;
-  c.stats = (d.bn && train) ? S.bn[l].stats : nullptr;
+  c.out = A.Y[l]; c.out_cs = A.y_cs[l]; c.out_co = A.y_co[l]; c.cout = d.cout;
+  c.in_scale = A.bn[src].scale; c.in_shift = A.bn[src].shift;
+  c.stats = (d.bn && train) ? A.bn[l].stats : nullptr;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = in_mode; c.nchunks = d.nchunks_fwd; c.ncob = d.ncob_fwd;
+  if (SS.n == 2) {
+    Slot& B = *SS.s[1];
+    c.nprob = 2; c.in2 = B.Y[src]; c.out2 = B.Y[l]; c.in_scale2 = B.bn[src].scale; c.in_shift2 = B.bn[src].shift;
+    c.stats2 = (d.bn && train) ? B.bn[l].stats : nullptr;
+  }
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
-  if (d.bn) CHK(bn_finalize(h, S, l, (double)N * H * W, train, st));
+  if (d.bn)
+    for (int k = 0; k < SS.n; ++k) CHK(bn_finalize(h, *SS.s[k], l, (double)N * H * W, train, st));  // view 0 then 1
   return 0;
 }
 
-static int run_forward(ssp_handle* h, int slot, const float* x, int N, int H, int W, int train, bool for_backward,
-                       hipStream_t st, bool repack = true) {
-  Slot& S = h->slot[slot];
-  S.N = N; S.H = H; S.W = W; S.x = x;
-  HIPCHK(hipMemsetAsync(S.stats_region, 0, S.stats_bytes, st));
-  S.bsums_dirty = false;
-  if (repack) CHK(pack_all(h, for_backward, st));
-  // layer 0: direct 1->64 conv
-  {
+static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs, int N, int H, int W, int train,
+                       bool for_backward, hipStream_t st) {
+  for (int k = 0; k < SS.n; ++k) {
+    Slot& S = *SS.s[k];
+    S.N = N; S.H = H; S.W = W; S.x = xs[k];
+    HIPCHK(hipMemsetAsync(S.stats_region, 0, S.stats_bytes, st));
+    S.bsums_dirty = false;
+  }
+  CHK(pack_all(h, for_backward, st));
+  // layer 0: direct 1->64 conv (HBM-bound; one launch per view)
+  for (int k = 0; k < SS.n; ++k) {
+    Slot& S = *SS.s[k];
     const LayerDesc& d = h->L[0];
     const long npix = (long)N * H * W;
-    hipLaunchKernelGGL(conv0_direct_kernel, dim3(cdiv(npix, 16 * C0_ITERS)), dim3(256), 0, st, x, P(h, d.w_off),
+    hipLaunchKernelGGL(conv0_direct_kernel, dim3(cdiv(npix, 16 * C0_ITERS)), dim3(256), 0, st, S.x, P(h, d.w_off),
                        P(h, d.b_off), S.Y[0], train ? S.bn[0].stats : nullptr, N, H, W);
     HIPCHK(hipGetLastError());
     CHK(bn_finalize(h, S, 0, (double)npix, train, st));
   }
   for (int l = 1; l < 8; ++l) {
     int lh, lw; layer_res(l, H, W, lh, lw);
-    CHK(conv_layer_fwd(h, S, l, l - 1, N, lh, lw, layer_in_mode(l), train, st));
+    CHK(conv_layer_fwd(h, SS, l, l - 1, N, lh, lw, layer_in_mode(l), train, st));
   }
   const int Hc = H / 8, Wc = W / 8;
-  CHK(conv_layer_fwd(h, S, L_PA, 7, N, Hc, Wc, 1, train, st));
-  CHK(conv_layer_fwd(h, S, L_DA, 7, N, Hc, Wc, 1, train, st));
-  CHK(conv_layer_fwd(h, S, L_PB, L_PA, N, Hc, Wc, 1, train, st));
-  CHK(conv_layer_fwd(h, S, L_DB, L_DA, N, Hc, Wc, 1, train, st));
+  CHK(conv_layer_fwd(h, SS, L_PA, 7, N, Hc, Wc, 1, train, st));
+  CHK(conv_layer_fwd(h, SS, L_DA, 7, N, Hc, Wc, 1, train, st));
+  CHK(conv_layer_fwd(h, SS, L_PB, L_PA, N, Hc, Wc, 1, train, st));
+  CHK(conv_layer_fwd(h, SS, L_DB, L_DA, N, Hc, Wc, 1, train, st));
   if (h->nheads == 3) {
-    CHK(conv_layer_fwd(h, S, L_DS, 7, N, Hc, Wc, 1, train, st));
-    CHK(conv_layer_fwd(h, S, L_SOUT, L_DS, N, Hc, Wc, 1, train, st));
+    CHK(conv_layer_fwd(h, SS, L_DS, 7, N, Hc, Wc, 1, train, st));
+    CHK(conv_layer_fwd(h, SS, L_SOUT, L_DS, N, Hc, Wc, 1, train, st));
   }
   const int ncells = N * Hc * Wc;
-  hipLaunchKernelGGL(desc_normalize_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_DB], S.bn[L_DB].scale,
-                     S.bn[L_DB].shift, S.desc, S.inv_norm, ncells, S.y_cs[L_DB], S.y_co[L_DB]);
+  for (int k = 0; k < SS.n; ++k) {
+    Slot& S = *SS.s[k];
+    hipLaunchKernelGGL(desc_normalize_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_DB], S.bn[L_DB].scale,
+                       S.bn[L_DB].shift, S.desc, S.inv_norm, ncells, S.y_cs[L_DB], S.y_co[L_DB]);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// backward of a conv+BN(+ReLU) layer: dOut (grad wrt the activated [pooled] output, in `dout`) ->
-// parameter gradients and, unless l == 0, the gradient wrt the layer's (activated) input in `din`.
-static int layer_backward(ssp_handle* h, Slot& S, int l, int src, const float* dout, int d_cs, int d_co, bool relu,
-                          bool pool_after, float* dy, int dy_cs, int dy_co, float* din, int din_cs, int din_co, int N, int H, int W, int in_mode, hipStream_t st) {
+// BatchNorm(+ReLU(+pool)) backward of layer l for one view: dout -> dy (+ dgamma, dbeta, conv-bias gradient)
+static int bn_layer_backward(ssp_handle* h, Slot& S, int l, const float* dout, int d_cs, int d_co, bool relu,
+                             bool pool_after, float* dy, int dy_cs, int dy_co, int N, int H, int W, hipStream_t st) {
   const LayerDesc& d = h->L[l];
-  if (d.bn) {
-    BnBwdArgs a;
-    a.y = S.Y[l]; a.dout = dout; a.dy = dy; a.scale = S.bn[l].scale; a.shift = S.bn[l].shift; a.mean = S.bn[l].mean;
-    a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums; a.dbias = Gd(h, d.b_off);
-    a.N = N; a.H = H; a.W = W; a.C = d.cout; a.y_cs = S.y_cs[l]; a.y_co = S.y_co[l]; a.d_cs = d_cs; a.d_co = d_co;
-    a.dy_cs = dy_cs; a.dy_co = dy_co; a.count = (double)N * H * W;
-    a.k12 = S.bn[l].k12;
-    float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
-    if (l == 0) {
-      // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised)
-      const long npix = (long)N * H * W;
-      const int nb = std::min(cdiv(npix, 16), 1024);
-      hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(64), 0, st, a.sums, S.bn[l].k12, dg, db, a.dbias, a.gamma, a.invstd,
-                         64, a.count);
-      hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, Gd(h, d.w_off));
-    } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, S.bn[l].k12, dg, db, st)));
-    else if (relu) CHK((launch_bn_bwd<true, false>(a, S.bn[l].k12, dg, db, st)));
-    else CHK((launch_bn_bwd<false, false>(a, S.bn[l].k12, dg, db, st)));
-    HIPCHK(hipGetLastError());
-  }
-  if (l == 0) return 0;
+  BnBwdArgs a;
+  a.y = S.Y[l]; a.dout = dout; a.dy = dy; a.scale = S.bn[l].scale; a.shift = S.bn[l].shift; a.mean = S.bn[l].mean;
+  a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums; a.dbias = Gd(h, d.b_off);
+  a.N = N; a.H = H; a.W = W; a.C = d.cout; a.y_cs = S.y_cs[l]; a.y_co = S.y_co[l]; a.d_cs = d_cs; a.d_co = d_co;
+  a.dy_cs = dy_cs; a.dy_co = dy_co; a.count = (double)N * H * W;
+  a.k12 = S.bn[l].k12;
+  float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
+  if (l == 0) {
+    // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised)
+    const long npix = (long)N * H * W;
+    const int nb = std::min(cdiv(npix, 16), 1024);
+    hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(64), 0, st, a.sums, S.bn[l].k12, dg, db, a.dbias, a.gamma, a.invstd,
+                       64, a.count);
+    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, Gd(h, d.w_off));
+  } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, S.bn[l].k12, dg, db, st)));
+  else if (relu) CHK((launch_bn_bwd<true, false>(a, S.bn[l].k12, dg, db, st)));
+  else CHK((launch_bn_bwd<false, false>(a, S.bn[l].k12, dg, db, st)));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// weight gradient (both views in one launch) and data gradient (both views in one launch) of conv layer l, given
+// dY of each view in dy[k] (channel stride dy_cs, offset dy_co); the data gradient goes to din[k].
+static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src, float* const* dy, int dy_cs, int dy_co,
+                               float* const* din, int din_cs, int din_co, int N, int H, int W, int in_mode,
+                               hipStream_t st) {
+  const LayerDesc& d = h->L[l];
+  Slot& A = *SS.s[0];
   WgradCall w;
-  w.in = S.Y[src]; w.in_cs = S.y_cs[src]; w.in_co = S.y_co[src]; w.cin = d.cin;
-  w.dout = dy; w.dout_cs = dy_cs; w.dout_co = dy_co; w.cout = d.cout;
-  w.in_scale = S.bn[src].scale; w.in_shift = S.bn[src].shift; w.dw = Gd(h, d.w_off);
+  w.in = A.Y[src]; w.in_cs = A.y_cs[src]; w.in_co = A.y_co[src]; w.cin = d.cin;
+  w.dout = dy[0]; w.dout_cs = dy_cs; w.dout_co = dy_co; w.cout = d.cout;
+  w.in_scale = A.bn[src].scale; w.in_shift = A.bn[src].shift; w.dw = Gd(h, d.w_off);
   w.N = N; w.H = H; w.W = W; w.ks = d.ks; w.in_mode = in_mode;
-  CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
   ConvCall c;
-  c.in = dy; c.in_cs = dy_cs; c.in_co = dy_co; c.cin = (int)align_up(d.cout, 4);
+  c.in = dy[0]; c.in_cs = dy_cs; c.in_co = dy_co; c.cin = (int)align_up(d.cout, 4);
   c.wpk = h->wpk_bwd + d.pk_bwd; c.bias = nullptr;
-  c.out = din; c.out_cs = din_cs; c.out_co = din_co; c.cout = d.cin;
+  c.out = din[0]; c.out_cs = din_cs; c.out_co = din_co; c.cout = d.cin;
   c.in_scale = nullptr; c.in_shift = nullptr; c.stats = nullptr;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 0; c.nchunks = d.nchunks_bwd; c.ncob = d.ncob_bwd;
+  if (SS.n == 2) {
+    Slot& B = *SS.s[1];
+    w.nprob = 2; w.in2 = B.Y[src]; w.dout2 = dy[1]; w.in_scale2 = B.bn[src].scale; w.in_shift2 = B.bn[src].shift;
+    c.nprob = 2; c.in2 = dy[1]; c.out2 = din[1];
+  }
+  CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_DGRAD : 0));
   return 0;
 }
 
-// dsemi: [cells][80] grad wrt semi (post bnPb); draw_desc: [cells][256] grad wrt bnDb output (pre-normalisation);
-// dsout: [cells][sout_cs] grad wrt convSout output (ssmall) or nullptr.
-static int run_backward(ssp_handle* h, int slot, const float* dsemi, const float* draw_desc, const float* dsout,
-                        hipStream_t st) {
-  Slot& S = h->slot[slot];
-  const int N = S.N, H = S.H, W = S.W, Hc = H / 8, Wc = W / 8;
+// dsemi[k]: [cells][80] grad wrt semi (post bnPb); draw_desc[k]: [cells][256] grad wrt bnDb output (pre-normalisation);
+// dsout[k]: [cells][sout_cs] grad wrt convSout output (ssmall).  A null entry means "no gradient from that head" and
+// must be null for every view of the set.
+static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
+                        float* const* dsout, hipStream_t st) {
+  Slot& S0 = *SS.s[0];
+  const int N = S0.N, H = S0.H, W = S0.W, Hc = H / 8, Wc = W / 8;
   const int hcs = 256 * h->nheads;
-  // zero the backward fp64 sums (interleaved with the forward stats: clear only the bsums halves)
-  // the forward's single memset of the statistics region also cleared the backward sums; clear them again only
-  // when this slot is back-propagated a second time (autograd retain_graph)
-  if (S.bsums_dirty) {
-    for (int l = 0; l < h->nlayers; ++l)
-      HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * (size_t)h->L[l].cout * NREP * sizeof(double), st));
+  const bool has_semi = dsemi[0] != nullptr, has_desc = draw_desc[0] != nullptr;
+  const bool has_sem = dsout[0] != nullptr && h->nheads == 3;
+  float *gP[2] = {nullptr, nullptr}, *gQ[2] = {nullptr, nullptr};
+  for (int k = 0; k < SS.n; ++k) {
+    Slot& S = *SS.s[k];
+    gP[k] = S.gP; gQ[k] = S.gQ;
+    // the forward's single memset of the statistics region also cleared the backward sums; clear them again only
+    // when this slot is back-propagated a second time (autograd retain_graph)
+    if (S.bsums_dirty) {
+      for (int l = 0; l < h->nlayers; ++l)
+        HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * (size_t)h->L[l].cout * NREP * sizeof(double), st));
+    }
+    S.bsums_dirty = true;
+    if (!has_semi || !has_desc || (h->nheads == 3 && !has_sem))
+      HIPCHK(hipMemsetAsync(S.gP, 0, (size_t)N * Hc * Wc * hcs * sizeof(float), st));
   }
-  S.bsums_dirty = true;
-  float* dHeadsAct = h->gP;  // grad wrt relu(bn(conv{Pa,Da,DS})) [cells][hcs]
-  float* dYtmp = h->gQ;
-  const bool has_semi = dsemi != nullptr, has_desc = draw_desc != nullptr, has_sem = dsout != nullptr && h->nheads == 3;
-  if (!has_semi || !has_desc || (h->nheads == 3 && !has_sem))
-    HIPCHK(hipMemsetAsync(dHeadsAct, 0, (size_t)N * Hc * Wc * hcs * sizeof(float), st));
-  // 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only)
-  if (has_semi)
-    CHK(layer_backward(h, S, L_PB, L_PA, dsemi, 80, 0, false, false, dYtmp, 80, 0, dHeadsAct, hcs, 0, N, Hc, Wc, 1, st));
-  if (has_desc)
-    CHK(layer_backward(h, S, L_DB, L_DA, draw_desc, 256, 0, false, false, dYtmp, 256, 0, dHeadsAct, hcs, 256, N, Hc, Wc, 1, st));
+  // ---- 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only); gP = dHeadsAct [cells][hcs], gQ = dY scratch ----
+  float* dact[2] = {gP[0], gP[1]};
+  if (has_semi) {
+    for (int k = 0; k < SS.n; ++k)
+      CHK(bn_layer_backward(h, *SS.s[k], L_PB, dsemi[k], 80, 0, false, false, gQ[k], 80, 0, N, Hc, Wc, st));
+    CHK(conv_layer_backward(h, SS, L_PB, L_PA, gQ, 80, 0, dact, hcs, 0, N, Hc, Wc, 1, st));
+  }
+  if (has_desc) {
+    for (int k = 0; k < SS.n; ++k)
+      CHK(bn_layer_backward(h, *SS.s[k], L_DB, draw_desc[k], 256, 0, false, false, gQ[k], 256, 0, N, Hc, Wc, st));
+    CHK(conv_layer_backward(h, SS, L_DB, L_DA, gQ, 256, 0, dact, hcs, 256, N, Hc, Wc, 1, st));
+  }
   if (has_sem) {
     const LayerDesc& d = h->L[L_SOUT];
     const int ncells = N * Hc * Wc;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, 64)), dim3(256), 0, st, dsout, Gd(h, d.b_off), ncells, d.cout,
-                       h->sout_cs);
+    for (int k = 0; k < SS.n; ++k)
+      hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, 64)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), ncells, d.cout,
+                         h->sout_cs);
     HIPCHK(hipGetLastError());
-    CHK(layer_backward(h, S, L_SOUT, L_DS, nullptr, 0, 0, false, false, const_cast<float*>(dsout), h->sout_cs, 0,
-                       dHeadsAct, hcs, 512, N, Hc, Wc, 1, st));
+    CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st));
   }
-  // 3x3 heads: BN+ReLU backward into dYtmp [cells][hcs], then wgrad + dgrad (accumulated into dOut7)
-  float* dOut = h->gP;
+  // ---- 3x3 heads: BN+ReLU backward gP -> gQ [cells][hcs]; weight gradients; ONE data-gradient conv over the
+  // concatenated dY channels (sums the heads' contributions) gQ -> gP [cells][128] ----
   {
     const int heads[3] = {L_PA, L_DA, L_DS};
-    for (int k = 0; k < h->nheads; ++k) {
-      const int l = heads[k];
-      const LayerDesc& d = h->L[l];
-      BnBwdArgs a;
-      a.y = S.Y[l]; a.dout = dHeadsAct; a.dy = dYtmp; a.scale = S.bn[l].scale; a.shift = S.bn[l].shift;
-      a.mean = S.bn[l].mean; a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums;
-      a.dbias = Gd(h, d.b_off); a.N = N; a.H = Hc; a.W = Wc; a.C = 256; a.y_cs = hcs; a.y_co = 256 * k; a.d_cs = hcs;
-      a.d_co = 256 * k; a.dy_cs = hcs; a.dy_co = 256 * k; a.count = (double)N * Hc * Wc;
-      a.k12 = S.bn[l].k12;
-      CHK((launch_bn_bwd<true, false>(a, S.bn[l].k12, Gd(h, d.g_off), Gd(h, d.be_off), st)));
-    }
-    for (int k = 0; k < h->nheads; ++k) {
-      const int l = heads[k];
-      const LayerDesc& d = h->L[l];
+    for (int hk = 0; hk < h->nheads; ++hk)
+      for (int k = 0; k < SS.n; ++k)
+        CHK(bn_layer_backward(h, *SS.s[k], heads[hk], gP[k], hcs, 256 * hk, true, false, gQ[k], hcs, 256 * hk, N, Hc, Wc, st));
+    for (int hk = 0; hk < h->nheads; ++hk) {
+      const LayerDesc& d = h->L[heads[hk]];
       WgradCall w;
-      w.in = S.Y[7]; w.in_cs = 128; w.in_co = 0; w.cin = 128; w.dout = dYtmp; w.dout_cs = hcs; w.dout_co = 256 * k;
-      w.cout = 256; w.in_scale = S.bn[7].scale; w.in_shift = S.bn[7].shift; w.dw = Gd(h, d.w_off);
+      w.in = S0.Y[7]; w.in_cs = 128; w.in_co = 0; w.cin = 128; w.dout = gQ[0]; w.dout_cs = hcs; w.dout_co = 256 * hk;
+      w.cout = 256; w.in_scale = S0.bn[7].scale; w.in_shift = S0.bn[7].shift; w.dw = Gd(h, d.w_off);
       w.N = N; w.H = Hc; w.W = Wc; w.ks = 3; w.in_mode = 1;
+      if (SS.n == 2) {
+        Slot& B = *SS.s[1];
+        w.nprob = 2; w.in2 = B.Y[7]; w.dout2 = gQ[1]; w.in_scale2 = B.bn[7].scale; w.in_shift2 = B.bn[7].shift;
+      }
       CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
     }
-    {  // data gradient of the 3x3 heads: ONE conv over the concatenated dY channels (sums the heads' contributions)
-      ConvCall c;
-      c.in = dYtmp; c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = h->wpk_heads_bwd; c.bias = nullptr;
-      c.out = dOut; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
-      c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = 16 * h->nheads;
-      c.ncob = 2;
-      CHK(launch_conv(h, c, st, SSP_PROF_CONV3X3_DGRAD));
-    }
+    ConvCall c;
+    c.in = gQ[0]; c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = h->wpk_heads_bwd; c.bias = nullptr;
+    c.out = gP[0]; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
+    c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = 16 * h->nheads; c.ncob = 2;
+    if (SS.n == 2) { c.nprob = 2; c.in2 = gQ[1]; c.out2 = gP[1]; }
+    CHK(launch_conv(h, c, st, SSP_PROF_CONV3X3_DGRAD));
   }
-  // encoder
+  // ---- encoder: dOut (gP) -> dY (gQ) -> weight gradient + data gradient (gP) ----
   for (int l = 7; l >= 0; --l) {
     int lh, lw; layer_res(l, H, W, lh, lw);
     const bool pool_after = (l == 1 || l == 3 || l == 5);
     const int C = h->L[l].cout;
-    const int cin = h->L[l].cin;
-    CHK(layer_backward(h, S, l, l - 1, dOut, C, 0, true, pool_after, dYtmp, C, 0, dOut, cin, 0, N, lh, lw,
-                       l > 0 ? layer_in_mode(l) : 0, st));
+    for (int k = 0; k < SS.n; ++k)
+      CHK(bn_layer_backward(h, *SS.s[k], l, gP[k], C, 0, true, pool_after, gQ[k], C, 0, N, lh, lw, st));
+    if (l > 0) CHK(conv_layer_backward(h, SS, l, l - 1, gQ, C, 0, gP, h->L[l].cin, 0, N, lh, lw, layer_in_mode(l), st));
   }
   return 0;
 }
@@ -712,7 +760,11 @@ int ssp_forward(ssp_handle* h, int slot, const float* x_dev, int n, int height, 
   if ((size_t)height * width != (size_t)h->cfg.height * h->cfg.width && (size_t)n * height * width > (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width)
     return fail(-1, "forward shape too large");
   hipStream_t st = (hipStream_t)stream;
-  CHK(run_forward(h, slot, x_dev, n, height, width, train, h->buf.grads_dev != nullptr, st));
+  {
+    SlotSet SS{1, {&h->slot[slot], nullptr}};
+    const float* xs[2] = {x_dev, nullptr};
+    CHK(run_forward(h, SS, xs, n, height, width, train, h->buf.grads_dev != nullptr, st));
+  }
   Slot& S = h->slot[slot];
   const int HW = (height / 8) * (width / 8);
   if (semi_dev) {
@@ -763,7 +815,11 @@ int ssp_backward(ssp_handle* h, int slot, const float* dsemi_dev, const float* d
     dso = S.dsout;
   }
   HIPCHK(hipGetLastError());
-  return run_backward(h, slot, ds, dd, dso, st);
+  SlotSet SS{1, {&h->slot[slot], nullptr}};
+  const float* dss[2] = {ds, nullptr};
+  const float* dds[2] = {dd, nullptr};
+  float* dsos[2] = {const_cast<float*>(dso), nullptr};
+  return run_backward(h, SS, dss, dds, dsos, st);
 }
 
 int ssp_adam_step(ssp_handle* h, float lr, int step, void* stream) {
@@ -795,8 +851,11 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   const int ncells = B * Hc * Wc;
   hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
                      in->lamda_d, (int)semantic);
-  CHK(run_forward(h, 0, in->image_dev, B, H, W, 1, in->train != 0, st));
-  CHK(run_forward(h, 1, in->warped_image_dev, B, H, W, 1, in->train != 0, st, /*repack=*/false));  // same parameters
+  SlotSet SS{2, {&h->slot[0], &h->slot[1]}};
+  {
+    const float* xs[2] = {in->image_dev, in->warped_image_dev};
+    CHK(run_forward(h, SS, xs, B, H, W, 1, in->train != 0, st));
+  }
   const float* masks[2] = {in->valid_mask_dev, in->warped_valid_mask_dev};
   const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
   const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
@@ -837,6 +896,7 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
     hipLaunchKernelGGL((desc_nonmatch_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc,
                        in->match_a_dev, in->nonmatch_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc,
                        h->cfg.n_match, h->cfg.n_non);
+    hipLaunchKernelGGL(desc_counts_kernel, dim3(1), dim3(64), 0, st, h->accum, B);
     if (in->train) {
       HIPCHK(hipMemsetAsync(A.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
       HIPCHK(hipMemsetAsync(Bs.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
@@ -857,10 +917,10 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
                      in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train);
   HIPCHK(hipGetLastError());
   if (in->train) {
-    for (int v = 0; v < 2; ++v) {
-      Slot& S = h->slot[v];
-      CHK(run_backward(h, v, S.dsemi, use_desc ? S.ddesc : nullptr, semantic ? S.dsout : nullptr, st));
-    }
+    const float* dss[2] = {h->slot[0].dsemi, h->slot[1].dsemi};
+    const float* dds[2] = {use_desc ? h->slot[0].ddesc : nullptr, use_desc ? h->slot[1].ddesc : nullptr};
+    float* dsos[2] = {semantic ? h->slot[0].dsout : nullptr, semantic ? h->slot[1].dsout : nullptr};
+    CHK(run_backward(h, SS, dss, dds, dsos, st));
   }
   return 0;
 }
@@ -971,8 +1031,8 @@ int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, siz
   const size_t cells = (size_t)h->cfg.max_batch * (h->cfg.height / 8) * (h->cfg.width / 8);
   std::string n(name);
   float* p = nullptr; size_t cnt = 0;
-  if (n == "gP") { p = h->gP; cnt = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * 64; }
-  else if (n == "gQ") { p = h->gQ; cnt = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * 64; }
+  if (n == "gP") { p = S.gP; cnt = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * 64; }
+  else if (n == "gQ") { p = S.gQ; cnt = (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width * 64; }
   else if (n == "dsemi") { p = S.dsemi; cnt = cells * 80; }
   else if (n == "ddesc") { p = S.ddesc; cnt = cells * 256; }
   else if (n == "desc") { p = S.desc; cnt = cells * 256; }
