@@ -132,6 +132,31 @@ __global__ void bn_finalize_kernel(const BnLayer L, int train, int64_t* nbt) {
   L.shift[c] = L.beta[c] - (float)mean * sc;
 }
 
+// MaxPool2d(2)(ReLU(BN(y))) materialised once per pooled layer boundary (layers 1, 3, 5): the three consumers
+// (forward conv, weight gradient of the next layer) then read a 4x smaller, already activated tensor through their
+// prefetched raw-input path instead of staging 4 loads per pixel synchronously (85-97 TF -> ~125 TF on those
+// launches).  y: [N,H,W,C] raw conv output; out: [N,H/2,W/2,C].  C % 4 == 0.
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ out,
+                                                           int N, int H, int W, int C) {
+  const int nq = C >> 2;
+  const long total = (long)N * (H / 2) * (W / 2) * nq;
+  const int Wo = W / 2, Ho = H / 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % nq);
+    const long p = idx / nq;
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((long)Wo * Ho));
+    const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + q * 4);
+    const size_t base = ((size_t)(n * H + 2 * oy) * W + 2 * ox) * C + q * 4;
+    const float4 a = xform<1>(*reinterpret_cast<const float4*>(y + base), sc, sh);
+    const float4 b = xform<1>(*reinterpret_cast<const float4*>(y + base + C), sc, sh);
+    const float4 c = xform<1>(*reinterpret_cast<const float4*>(y + base + (size_t)W * C), sc, sh);
+    const float4 d = xform<1>(*reinterpret_cast<const float4*>(y + base + (size_t)W * C + C), sc, sh);
+    *reinterpret_cast<float4*>(out + (size_t)p * C + q * 4) = max4(max4(a, b), max4(c, d));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BatchNorm (+ReLU (+2x2 max-pool)) backward, two passes over (dOut, Y):
 //   pass 1 (reduce): S1 = sum dZ, S2 = sum dZ * xhat            (fp64 atomics, [2C])

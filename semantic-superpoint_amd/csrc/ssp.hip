@@ -75,6 +75,7 @@ struct Slot {
   float* ddesc;     // [B*cells*256]
   float* dsout;     // [B*cells*SOUT_CS] gradient wrt convSout output (ssmall)
   float *gP, *gQ;   // backward ping-pong buffers of this slot (dOut / dY)
+  float* Apool[8];  // maxpool(relu(bn(Y_l))) for l = 1, 3, 5 (inputs of layers 2, 4, 6), else nullptr
   const float* x;   // input image of the last forward (caller-owned)
   void* stats_region;
   size_t stats_bytes;
@@ -190,6 +191,11 @@ static size_t carve(ssp_handle* h, void* base) {
       int lh, lw; layer_res(l, H, W, lh, lw);
       S.Y[l] = c.take<float>((size_t)B * lh * lw * h->L[l].cout);
       S.y_cs[l] = h->L[l].cout; S.y_co[l] = 0;
+    }
+    for (int l = 0; l < 8; ++l) S.Apool[l] = nullptr;
+    for (int l = 1; l <= 5; l += 2) {
+      int lh, lw; layer_res(l, H, W, lh, lw);
+      S.Apool[l] = c.take<float>((size_t)B * (lh / 2) * (lw / 2) * h->L[l].cout);
     }
     const int hcs = 256 * h->nheads;
     float* yheads = c.take<float>(cells * hcs);
@@ -552,8 +558,19 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
                           hipStream_t st) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
+  const bool pooled = in_mode == 2;  // input = materialised maxpool(relu(bn(Y_src))): raw (mode 0) for the kernel
+  if (pooled) {
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      const long total = (long)N * H * W * (d.cin / 4);
+      hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(std::min(cdiv(total, 256), 8192)), dim3(256), 0, st, S.Y[src],
+                         S.bn[src].scale, S.bn[src].shift, S.Apool[src], N, 2 * H, 2 * W, d.cin);
+    }
+    HIPCHK(hipGetLastError());
+    in_mode = 0;
+  }
   ConvCall c;
-  c.in = A.Y[src]; c.in_cs = A.y_cs[src]; c.in_co = A.y_co[src]; c.cin = d.cin;
+  c.in = pooled ? A.Apool[src] : A.Y[src]; c.in_cs = A.y_cs[src]; c.in_co = A.y_co[src]; c.cin = d.cin;
   c.wpk = h->wpk_fwd + d.pk_fwd; c.bias = P(h, d.b_off);
   c.out = A.Y[l]; c.out_cs = A.y_cs[l]; c.out_co = A.y_co[l]; c.cout = d.cout;
   c.in_scale = A.bn[src].scale; c.in_shift = A.bn[src].shift;
@@ -561,7 +578,8 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = in_mode; c.nchunks = d.nchunks_fwd; c.ncob = d.ncob_fwd;
   if (SS.n == 2) {
     Slot& B = *SS.s[1];
-    c.nprob = 2; c.in2 = B.Y[src]; c.out2 = B.Y[l]; c.in_scale2 = B.bn[src].scale; c.in_shift2 = B.bn[src].shift;
+    c.nprob = 2; c.in2 = pooled ? B.Apool[src] : B.Y[src]; c.out2 = B.Y[l]; c.in_scale2 = B.bn[src].scale;
+    c.in_shift2 = B.bn[src].shift;
     c.stats2 = (d.bn && train) ? B.bn[l].stats : nullptr;
   }
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
@@ -645,8 +663,10 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
                                hipStream_t st) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
+  const bool pooled = in_mode == 2;  // the forward materialised maxpool(relu(bn(Y_src))) in Apool[src]
+  if (pooled) in_mode = 0;
   WgradCall w;
-  w.in = A.Y[src]; w.in_cs = A.y_cs[src]; w.in_co = A.y_co[src]; w.cin = d.cin;
+  w.in = pooled ? A.Apool[src] : A.Y[src]; w.in_cs = A.y_cs[src]; w.in_co = A.y_co[src]; w.cin = d.cin;
   w.dout = dy[0]; w.dout_cs = dy_cs; w.dout_co = dy_co; w.cout = d.cout;
   w.in_scale = A.bn[src].scale; w.in_shift = A.bn[src].shift; w.dw = Gd(h, d.w_off);
   w.N = N; w.H = H; w.W = W; w.ks = d.ks; w.in_mode = in_mode;
@@ -658,7 +678,8 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 0; c.nchunks = d.nchunks_bwd; c.ncob = d.ncob_bwd;
   if (SS.n == 2) {
     Slot& B = *SS.s[1];
-    w.nprob = 2; w.in2 = B.Y[src]; w.dout2 = dy[1]; w.in_scale2 = B.bn[src].scale; w.in_shift2 = B.bn[src].shift;
+    w.nprob = 2; w.in2 = pooled ? B.Apool[src] : B.Y[src]; w.dout2 = dy[1]; w.in_scale2 = B.bn[src].scale;
+    w.in_shift2 = B.bn[src].shift;
     c.nprob = 2; c.in2 = dy[1]; c.out2 = din[1];
   }
   CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
