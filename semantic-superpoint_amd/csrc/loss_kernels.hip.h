@@ -222,16 +222,15 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
   }
 }
 
-// non-match term: one wave per match k; 4 non-matches per iteration (16 lanes each, 16 channels per lane).
+// non-match term, forward: one wave per match k; 4 non-matches per iteration (16 lanes each, 16 channels per lane).
 // a-side = integer-cell gather of image a at match_a[k] (sparse_loss.py:55-58,245), b-side = nonmatch_b.
-template <bool BWD>
-__global__ __launch_bounds__(256) void desc_nonmatch_kernel(const float* __restrict__ desc_a,
-                                                            const float* __restrict__ desc_b,
-                                                            const int32_t* __restrict__ match_a,
-                                                            const int32_t* __restrict__ nonmatch_b,
-                                                            float* __restrict__ dd_a, float* __restrict__ dd_b,
-                                                            StepAccum* __restrict__ acc, int B, int Hc, int Wc,
-                                                            int n_match, int n_non) {
+// The dot products are kept (12.8 MB at B = 32) so that the backward only touches the hard negatives.
+__global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __restrict__ desc_a,
+                                                                const float* __restrict__ desc_b,
+                                                                const int32_t* __restrict__ match_a,
+                                                                const int32_t* __restrict__ nonmatch_b,
+                                                                float* __restrict__ dots, StepAccum* __restrict__ acc,
+                                                                int B, int Hc, int Wc, int n_match, int n_non) {
   const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (w >= B * n_match) return;
@@ -242,11 +241,6 @@ __global__ __launch_bounds__(256) void desc_nonmatch_kernel(const float* __restr
   float4 a[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(ap + i * 64);
-  float4 ga[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ga[i] = make_float4(0, 0, 0, 0);
-  float wgt = 0.f;
-  if (BWD) wgt = acc->coef_neg / (((float)acc->nnz_img[img] + 1.f) * (float)B);
   float hsum = 0.f;
   unsigned cnt = 0;
   const int32_t* nm = nonmatch_b + (size_t)w * n_non;
@@ -255,47 +249,74 @@ __global__ __launch_bounds__(256) void desc_nonmatch_kernel(const float* __restr
     const bool valid = j < n_non;
     const int bi = valid ? nm[j] : 0;
     const float* bp = desc_b + ibase + (size_t)bi * 256 + l16 * 4;
-    float4 b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const float4*>(bp + i * 64);
     float d = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) d += a[i].x * b[i].x + a[i].y * b[i].y + a[i].z * b[i].z + a[i].w * b[i].w;
+    for (int i = 0; i < 4; ++i) {
+      const float4 b = *reinterpret_cast<const float4*>(bp + i * 64);
+      d += a[i].x * b.x + a[i].y * b.y + a[i].z * b.z + a[i].w * b.w;
+    }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
-    const float h = valid ? fmaxf(d - 0.2f, 0.f) : 0.f;
-    if (!BWD) {
-      if (l16 == 0) {
-        hsum += h;
-        cnt += (h != 0.f) ? 1u : 0u;
-      }
-    } else if (h > 0.f) {
-      float* gp = dd_b + ibase + (size_t)bi * 256 + l16 * 4;
+    if (l16 == 0 && valid) {
+      if (dots != nullptr) dots[(size_t)w * n_non + j] = d;
+      const float h = fmaxf(d - 0.2f, 0.f);
+      hsum += h;
+      cnt += (h != 0.f) ? 1u : 0u;
+    }
+  }
+  hsum = wave_sum(hsum);
+  const float c = wave_sum((float)cnt);
+  if (lane == 0) {
+    const int rep = img * 16 + ((w >> 2) & 15);  // 16 replicas / image: ~60 instead of 1000 atomics per address
+    unsafeAtomicAdd(&acc->neg_sum[rep], (double)hsum);
+    atomicAdd(&acc->nnz[rep], (unsigned)(c + 0.5f));
+  }
+}
+
+// non-match term, backward: one wave per match k reads its stored dot products and walks only the hard negatives
+// (dot > 0.2).  Lane l holds channels l, l+64, l+128, l+192: loads and atomics are 256 contiguous bytes per wave.
+__global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __restrict__ desc_a,
+                                                                const float* __restrict__ desc_b,
+                                                                const int32_t* __restrict__ match_a,
+                                                                const int32_t* __restrict__ nonmatch_b,
+                                                                const float* __restrict__ dots, float* __restrict__ dd_a,
+                                                                float* __restrict__ dd_b, const StepAccum* __restrict__ acc,
+                                                                int B, int Hc, int Wc, int n_match, int n_non) {
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= B * n_match) return;
+  const int img = w / n_match;
+  const size_t ibase = (size_t)img * Hc * Wc * 256 + lane;
+  const float wgt = acc->coef_neg / (((float)acc->nnz_img[img] + 1.f) * (float)B);
+  const int32_t* nm = nonmatch_b + (size_t)w * n_non;
+  const float* dk = dots + (size_t)w * n_non;
+  const int ma = match_a[w];
+  float a[4], ga[4] = {0.f, 0.f, 0.f, 0.f};
+  bool have_a = false;
+  for (int j0 = 0; j0 < n_non; j0 += 64) {
+    const int j = j0 + lane;
+    const bool hard = j < n_non && (dk[j] - 0.2f) > 0.f;
+    unsigned long long mask = __ballot(hard);
+    if (mask != 0ull && !have_a) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = desc_a[ibase + (size_t)ma * 256 + 64 * i];
+      have_a = true;
+    }
+    while (mask != 0ull) {
+      const int bit = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int bi = nm[j0 + bit];  // wave-uniform
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ga[i] = f4_fma(wgt, b[i], ga[i]);
-        atomic_add4(gp + i * 64, make_float4(wgt * a[i].x, wgt * a[i].y, wgt * a[i].z, wgt * a[i].w));
+        const float bv = desc_b[ibase + (size_t)bi * 256 + 64 * i];
+        ga[i] = fmaf(wgt, bv, ga[i]);
+        atomicAdd(dd_b + ibase + (size_t)bi * 256 + 64 * i, wgt * a[i]);
       }
     }
   }
-  if (!BWD) {
-    hsum = wave_sum(hsum);
-    float c = wave_sum((float)cnt);
-    if (lane == 0) {
-      const int rep = img * 16 + ((w >> 2) & 15);  // 16 replicas / image: ~60 instead of 1000 atomics per address
-      unsafeAtomicAdd(&acc->neg_sum[rep], (double)hsum);
-      atomicAdd(&acc->nnz[rep], (unsigned)(c + 0.5f));
-    }
-  } else {
-    // sum the 4 lane groups' contributions to d a_k, then one atomic per channel
+  if (have_a) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 g = ga[i];
-      g.x += __shfl_xor(g.x, 16); g.y += __shfl_xor(g.y, 16); g.z += __shfl_xor(g.z, 16); g.w += __shfl_xor(g.w, 16);
-      g.x += __shfl_xor(g.x, 32); g.y += __shfl_xor(g.y, 32); g.z += __shfl_xor(g.z, 32); g.w += __shfl_xor(g.w, 32);
-      if (grp == 0 && (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
-        atomic_add4(dd_a + ibase + (size_t)match_a[w] * 256 + l16 * 4 + i * 64, g);
-    }
+    for (int i = 0; i < 4; ++i) atomicAdd(dd_a + ibase + (size_t)ma * 256 + 64 * i, ga[i]);
   }
 }
 

@@ -97,6 +97,7 @@ struct ssp_handle {
   float* partial;    // wgrad partial slabs
   size_t partial_floats;
   StepAccum* accum;
+  float* dots;       // [B * n_match * n_non] non-match dot products of the current step
   int sout_cs;
   // profiling
   int prof_family;
@@ -237,6 +238,7 @@ static size_t carve(ssp_handle* h, void* base) {
   h->partial_floats = (size_t)1024 * 9 * 4096;
   h->partial = c.take<float>(h->partial_floats);
   h->accum = c.take<StepAccum>(1);
+  h->dots = c.take<float>((size_t)B * h->cfg.n_match * h->cfg.n_non);
   return align_up(c.off, 256);
 }
 
@@ -914,17 +916,17 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
     Slot &A = h->slot[0], &Bs = h->slot[1];
     hipLaunchKernelGGL((desc_match_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
                        in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
-    hipLaunchKernelGGL((desc_nonmatch_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc,
-                       in->match_a_dev, in->nonmatch_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc,
-                       h->cfg.n_match, h->cfg.n_non);
+    hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+                       in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match,
+                       h->cfg.n_non);
     hipLaunchKernelGGL(desc_counts_kernel, dim3(1), dim3(64), 0, st, h->accum, B);
     if (in->train) {
       HIPCHK(hipMemsetAsync(A.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
       HIPCHK(hipMemsetAsync(Bs.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
       hipLaunchKernelGGL((desc_match_kernel<true>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
                          in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
-      hipLaunchKernelGGL((desc_nonmatch_kernel<true>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc,
-                         in->match_a_dev, in->nonmatch_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
+      hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+                         in->nonmatch_b_dev, h->dots, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
                          h->cfg.n_non);
       for (int v = 0; v < 2; ++v) {
         Slot& S = h->slot[v];
@@ -1080,9 +1082,8 @@ int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_de
   const int nw = b * n_match;
   hipLaunchKernelGGL((desc_match_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
                      match_a_dev, match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match);
-  hipLaunchKernelGGL((desc_nonmatch_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, desc_a_nhwc_dev,
-                     desc_b_nhwc_dev, match_a_dev, nonmatch_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc,
-                     n_match, n_non);
+  hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(cdiv(nw, 4)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
+                     match_a_dev, nonmatch_b_dev, (float*)nullptr, acc, b, hc, wc, n_match, n_non);
   hipLaunchKernelGGL(sparse_loss_means_kernel, dim3(1), dim3(1), 0, st, acc, out2_dev, b, n_match);
   HIPCHK(hipGetLastError());
   HIPCHK(hipFreeAsync(acc, st));
