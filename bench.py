@@ -68,11 +68,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # debugging aid for 1-GPU boxes: SSP_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses
+    # two ranks on one device); the measured configuration is always one rank per GPU over RCCL ("nccl").
+    single_dev = os.environ.get("SSP_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if single_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import semantic_superpoint_amd as ssp
     from semantic_superpoint_amd import synth
