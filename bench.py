@@ -142,7 +142,10 @@ def main():
                 traffic = None  # HBM bytes / launch from the committed rocprofv3 PMC passes (cannot be read live)
                 tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
                 if args.arch == "sp" and (B, H, W) == (32, 240, 320) and os.path.exists(tpath):
-                    traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+                    tj = json.load(open(tpath))  # only valid for the launch structure it was profiled with
+                    if abs(tj.get("flops_per_launch_avg_gflop", 0) - pr["flops"] / pr["launches"] / 1e9) < 0.05 * tj.get(
+                            "flops_per_launch_avg_gflop", 1):
+                        traffic = round(tj["hbm_bytes_per_launch"])
                 out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (3x3 forward + data-gradient)",
                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
                                    "frac": round(ach / PEAK_FP32_MFMA_TF, 4), "traffic": traffic,

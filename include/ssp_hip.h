@@ -156,6 +156,10 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
                   float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int h,
                   int w, int c, int relu, int pool, void* stream);
 
+/* perf-debug hook: ablate bits (1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA) and grid override of
+ * conv_mfma_kernel; (0, 0) restores the product behaviour. */
+int ssp_debug_conv_knobs(int ablate, int grid);
+
 /* test hook: device pointer of an internal buffer ("gP","gQ","dsemi","ddesc","desc","dsout","Y<l>","scale<l>","shift<l>") */
 int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, size_t* nfloats);
 

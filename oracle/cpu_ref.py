@@ -397,7 +397,7 @@ class Trainer:
             loss.backward()
             self.last_grads = OrderedDict(
                 (k, None if self.sd[k].grad is None else self.sd[k].grad.clone()) for k in self.pkeys)
-            self.last_grads["eta"] = self.eta.grad.clone()
+            self.last_grads["eta"] = None if self.eta.grad is None else self.eta.grad.clone()
             if ((n_iter + 1) * B) % real == 0:  # :410-413
                 self.opt.step()
                 self.opt.zero_grad()

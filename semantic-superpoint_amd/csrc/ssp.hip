@@ -22,6 +22,7 @@
 using namespace sspk;
 
 static thread_local std::string g_err;
+static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_kernel (tools/ablate_conv.py)
 static int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -304,14 +305,14 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     a.out_bytes = clampu((double)c.N * c.H * c.W * c.out_cs * 4.0);
     a.wpk_bytes = clampu((double)c.ncob * c.nchunks * c.ks * c.ks * CK * NB * 4.0);
   }
-  a.ablate = getenv("SSP_ABLATE_CONV") ? atoi(getenv("SSP_ABLATE_CONV")) : 0;
+  a.ablate = g_dbg_ablate;
   const bool wide = (c.W % 32) == 0;
   const int TH = wide ? 8 : 32, TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
   // persistent grid: 2 blocks per CU (LDS-limited residency), a multiple of 8 (one slot set per XCD)
   const int n_cu = h ? h->n_cu : 256;
   int nblocks = std::max(8, (2 * n_cu) / 8 * 8);
-  if (getenv("SSP_CONV_GRID")) nblocks = atoi(getenv("SSP_CONV_GRID"));  // perf-debug only
+  if (g_dbg_grid > 0) nblocks = g_dbg_grid;  // perf-debug only (ssp_debug_conv_knobs)
   if ((nblocks / 8) < c.ncob) return fail(-3, "too many output-channel blocks (%d) for the persistent grid", c.ncob);
   const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
   const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
@@ -1044,6 +1045,12 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
   else if (relu) CHK((launch_bn_bwd<true, false>(a, k12, dgamma_dev, dbeta_dev, st)));
   else CHK((launch_bn_bwd<false, false>(a, k12, dgamma_dev, dbeta_dev, st)));
   HIPCHK(hipFreeAsync(k12, st));
+  return 0;
+}
+
+// perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
+int ssp_debug_conv_knobs(int ablate, int grid) {
+  g_dbg_ablate = ablate; g_dbg_grid = grid;
   return 0;
 }
 

@@ -47,7 +47,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
            "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
-           "ssp_debug_buffer", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels"]
+           "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels"]
 
 
 def load_library(path=None):
@@ -81,6 +81,7 @@ def load_library(path=None):
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.ssp_debug_conv_knobs.argtypes = [i, i]
     lib.ssp_op_warp_image.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.ssp_op_erode.argtypes = [vp, vp, i, i, i, i, vp]
     lib.ssp_op_warp_labels.argtypes = [vp, vp, vp, i, i, i, vp]

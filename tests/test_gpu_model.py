@@ -235,3 +235,80 @@ def test_device_sampler_distribution():
     assert hist.min() > 0.8 * hist.mean() and hist.max() < 1.2 * hist.mean()
     ma2, _, nm2 = e.sample_indices(Hs.to(_dev()), seed=1234)
     assert torch.equal(ma2.cpu(), ma) and torch.equal(nm2.cpu(), nm)  # deterministic in the seed
+
+
+def test_uniform_sum_loss_and_lamda_d():
+    """model.multi_task_loss: false -> loss = det + det_warp + lambda*(lamda_d*pos + neg)
+    (Train_model_heatmap_all.py:363-365) incl. its gradients, with lamda_d != 1."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    arch, B, H, W = ARCHS[0], 2, 64, 96
+    sd = C.init_state_dict(arch, seed=12)
+    sample = C.make_synthetic_pair(B, H, W, seed=13, kp_prob=0.01)
+    tr = C.Trainer(arch, sd, lr=0.001, multi_task=False, lambda_loss=0.5, lamda_d=3.0)
+    tr.real_batch_size = 10 ** 9
+    np.random.seed(1)
+    torch.manual_seed(2)
+    tr.train_val_sample(sample, n_iter=0, train=True)
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    sc = e.pair_step(_to_dev(sample), indices=_idx_to_dev(tr.aux["indices"], W // 8), train=True, lambda_loss=0.5,
+                     lamda_d=3.0, multi_task=False)
+    torch.cuda.synchronize()
+    sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+    for name in ("loss", "loss_det", "loss_det_warp", "loss_desc", "positive_dist", "negative_dist"):
+        ref = tr.scalar_dict[name]
+        assert abs(sc[name] - ref) < TOL * max(1.0, abs(ref)), (name, sc[name], ref)
+    gd = e.grad_dict()
+    assert float(gd["eta"].abs().max()) == 0.0  # eta is not in the graph of the uniform sum
+    for k in ("convDb.weight", "convPb.weight", "inc.conv.conv.3.weight"):
+        _grad_close(gd[k].cpu(), tr.last_grads[k], k)
+
+
+def test_gradient_accumulation_over_micro_batches():
+    """real_batch_size = 2 * batch_size: gradients of two micro-batches add up un-scaled before ONE Adam step
+    (Train_model_heatmap_all.py:406-413)."""
+    arch, B, H, W = ARCHS[0], 2, 64, 96
+    sd = C.init_state_dict(arch, seed=14)
+    s1 = C.make_synthetic_pair(B, H, W, seed=15, kp_prob=0.01)
+    s2 = C.make_synthetic_pair(B, H, W, seed=16, kp_prob=0.01)
+    tr = C.Trainer(arch, sd, lr=0.001)
+    tr.real_batch_size = 2 * B
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    for it, s in enumerate((s1, s2)):
+        np.random.seed(30 + it)
+        torch.manual_seed(40 + it)
+        tr.train_val_sample(s, n_iter=it, train=True)  # steps only after the second micro-batch
+        e.pair_step(_to_dev(s), indices=_idx_to_dev(tr.aux["indices"], W // 8), train=True)
+    torch.cuda.synchronize()
+    # the oracle's last_grads holds the ACCUMULATED gradient after micro-batch 2 (cloned before its optimizer step)
+    gd = e.grad_dict()
+    for k in ("convDb.weight", "convPa.weight", "down1.mpconv.1.conv.0.weight", "bnPb.weight"):
+        _grad_close(gd[k].cpu(), tr.last_grads[k], k)
+    e.adam_step(0.001)
+    torch.cuda.synchronize()
+    assert (e.eta.cpu() - tr.eta.detach()).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 64, 96), (3, 120, 160), (2, 40, 56)])
+def test_odd_shapes_forward_and_step(B, H, W):
+    """batch 1 / odd batch, cell grids that are not multiples of the tile sizes (15x20, 5x7)."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    arch = ARCHS[0]
+    sd = C.init_state_dict(arch, seed=20)
+    sample = C.make_synthetic_pair(B, H, W, seed=21, kp_prob=0.01)
+    tr = C.Trainer(arch, sd, lr=0.001)
+    np.random.seed(5)
+    torch.manual_seed(6)
+    tr.train_val_sample(sample, n_iter=0, train=True)
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    sc = e.pair_step(_to_dev(sample), indices=_idx_to_dev(tr.aux["indices"], W // 8), train=True)
+    torch.cuda.synchronize()
+    sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist"):
+        ref = tr.scalar_dict[name]
+        assert abs(sc[name] - ref) < 2e-3 * max(1.0, abs(ref)), (name, sc[name], ref)
+    gd = e.grad_dict()
+    for k in ("convDb.weight", "inc.conv.conv.0.weight", "down2.mpconv.1.conv.3.weight"):
+        _grad_close(gd[k].cpu(), tr.last_grads[k], k, l2=3e-2, mx=0.2)

@@ -10,8 +10,9 @@ w = torch.randn(C, C, 3, 3, device=dev) * 0.05
 b = torch.zeros(C, device=dev)
 sc = torch.ones(C, device=dev); sh = torch.zeros(C, device=dev)
 flops = 2.0 * N * H * W * C * C * 9
+GRID = [0]
 def run(tag, mode, abl, stats=False):
-    os.environ["SSP_ABLATE_CONV"] = str(abl)
+    L.load_library().ssp_debug_conv_knobs(int(abl), GRID[0])
     st = torch.zeros(L.NREP, 2 * C, dtype=torch.float64, device=dev) if stats else None
     for _ in range(2):
         L.op_conv(x, w, b, 3, mode, sc, sh, st)
@@ -33,6 +34,6 @@ run("no MFMA (loads+LDS+stores)", 0, 8)
 run("no MFMA, no stores", 0, 12)
 
 for g in (256, 512, 768, 1024):
-    os.environ["SSP_CONV_GRID"] = str(g)
+    GRID[0] = g
     run("full mode0, grid %d" % g, 0, 0)
     run("MFMA only, grid %d" % g, 0, 7)
