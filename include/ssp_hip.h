@@ -149,6 +149,53 @@ int ssp_op_warp_image(const float* img_dev, const float* inv_h_dev, float* out_d
 int ssp_op_erode(const float* mask_dev, float* out_dev, int b, int h, int w, int radius, void* stream);
 int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_dev, int b, int h, int w, void* stream);
 
+/* ---- homography-adaptation export (export.py:192-352) ------------------------------
+ * One image = n_views warped copies that form ONE BatchNorm batch (the reference leaves the net in train mode,
+ * models/model_wrap.py:120).  ssp_export_points replaces the body of the export loop (export.py:296-309):
+ *   fe.run(img, onlyHeatmap=True)   -> forward (detector head) + flattenDetection (utils/utils.py:515-560)
+ *   combine_heatmap                 -> export.py:49-60; unwarp_h = the matrices the reference passes as
+ *                                      `inv_homographies`, i.e. sample["homographies"] (export.py:281-284 swaps the keys)
+ *   fe.getPtsFromHeatmap            -> models/model_wrap.py:266-293 (threshold, nms_fast :129-192, border removal)
+ *   fe.soft_argmax_points           -> models/model_wrap.py:212-249 (when subpixel != 0)
+ *   pts[:top_k]                     -> export.py:303-309
+ * pts_dev[k]: [ssp_export_max_points][5] rows (x, y, confidence, sx, sy), descending confidence; the reference's
+ * float64 point is (x + sx - 2, y + sy - 2, confidence) (sx = sy = 2 when subpixel == 0); count_dev[k]: rows written.
+ * Equal confidences are ordered by the lower row-major pixel index (numpy's quicksort order is unspecified there).
+ * workspace_dev[k]: ssp_export_workspace_bytes(p) bytes per image.  heatmap_out_dev (or its entries) may be NULL. */
+typedef struct ssp_export_params {
+  int32_t n_views;       /* data.homography_adaptation.num */
+  int32_t height, width; /* multiples of 8 */
+  float conf_thresh;     /* model.detection_threshold (compared in fp32, as numpy does) */
+  int32_t nms_dist;      /* model.nms */
+  int32_t border_remove; /* SuperPointFrontend_torch.border_remove = 4 (models/model_wrap.py:70) */
+  int32_t top_k;         /* model.top_k, 0 = all */
+  int32_t subpixel;      /* model.subpixel.enable */
+} ssp_export_params;
+
+size_t ssp_export_workspace_bytes(const ssp_export_params* p);
+int ssp_export_max_points(const ssp_export_params* p);
+int ssp_export_points(ssp_handle* h, const ssp_export_params* p, int n_images, const float* const* views_dev,
+                      const float* const* masks_dev, const float* const* unwarp_h_dev, void* const* workspace_dev,
+                      float* const* heatmap_out_dev, float* const* pts_dev, int32_t* const* count_dev, void* stream);
+
+/* the stages as operators (parity tests):
+ * ssp_op_homoadapt_views  : datasets/Coco.py:279-288: n warped copies of ONE [h,w] image (inv_warp_image_batch,
+ *                           bilinear) and the nearest-warped all-ones masks (compute_valid_mask before erosion)
+ * ssp_op_flatten_detection: flattenDetection on a public NCHW `semi` [n,65,hc,wc] (times mask [n,8hc,8wc] if given)
+ * ssp_op_combine_heatmap  : combine_heatmap on heat = heatmap*mask and mask, both [n,h,w]
+ * ssp_op_heatmap_points   : getPtsFromHeatmap + soft_argmax_points + top-k on one [h,w] heatmap
+ * ssp_op_soft_argmax_points: soft_argmax_points for explicit points xy [n,2] (x, y; truncated to int) -> (sx, sy) [n,2] */
+int ssp_op_homoadapt_views(const float* img_dev, const float* inv_h_dev, float* views_dev, float* masks_dev, int n, int h,
+                           int w, void* stream);
+int ssp_op_flatten_detection(const float* semi_nchw_dev, const float* mask_dev, float* heat_dev, int n, int hc, int wc,
+                             void* stream);
+int ssp_op_combine_heatmap(const float* heat_dev, const float* mask_dev, const float* unwarp_h_dev, float* out_dev, int n,
+                           int h, int w, void* stream);
+int ssp_op_heatmap_points(const float* heat_dev, const ssp_export_params* p, void* workspace_dev, float* pts_dev,
+                          int32_t* count_dev, void* stream);
+int ssp_op_soft_argmax_points(const float* heat_dev, const float* xy_dev, float* out_dev, int n, int h, int w,
+                              void* stream);
+
 /* BatchNorm2d(train) (+ReLU (+MaxPool2d(2))) backward. y: raw conv output NHWC; dout: gradient wrt the activated
  * (and pooled) output; stats4 = scale|shift|mean|invstd ([4*C]); dgamma/dbeta/dbias are accumulated;
  * sums_dev: double [SSP_NREP][2*C] scratch. */

@@ -566,3 +566,128 @@ def make_synthetic_pair(B, H, W, seed=0, semantic=False, kp_prob=0.003, erosion=
         ws[vm.view(B, H, W) == 0] = n_classes
         s["semantic"], s["warped_sem"] = sem, ws
     return s
+
+
+# --------------------------------------------------------------------------------------
+# Homography-adaptation export: export.py:192-352
+# --------------------------------------------------------------------------------------
+def flatten_detection(semi):
+    """utils/utils.py:515-560 (batch branch): softmax over the 65 channels, drop the dustbin,
+    DepthToSpace(8) (utils/d2s.py:8-27: channel c -> pixel (c // 8, c % 8) of the cell)."""
+    dense = F.softmax(semi, dim=1)[:, :-1]
+    return F.pixel_shuffle(dense, 8)  # [B,1,H,W]
+
+
+def combine_heatmap(heatmap, unwarp_mats, mask_2D):
+    """export.py:49-60.  heatmap, mask_2D: [N,1,H,W]; unwarp_mats: [N,3,3] -- the matrices the
+    reference passes as `inv_homographies` (export.py:281-284 swaps the two sample keys, so this is
+    sample["homographies"], the inverse of the matrix each view was produced with).  0/0 -> NaN kept."""
+    heatmap = inv_warp_image_batch(heatmap * mask_2D, unwarp_mats, mode="bilinear")
+    mask_2D = inv_warp_image_batch(mask_2D, unwarp_mats, mode="bilinear")
+    return torch.sum(heatmap, dim=0) / torch.sum(mask_2D, dim=0)  # [1,H,W]
+
+
+def nms_fast(in_corners, H, W, dist_thresh):
+    """models/model_wrap.py:129-192: greedy NMS on a grid, highest confidence first, Chebyshev
+    radius dist_thresh.  in_corners: 3xN (x, y, conf).  Returns the kept corners sorted by
+    descending confidence.  Tie order follows a STABLE sort here (numpy's default quicksort is
+    unspecified for ties); fixtures are generated tie-free."""
+    n = in_corners.shape[1]
+    if n == 0:
+        return np.zeros((3, 0))
+    order = np.argsort(-in_corners[2], kind="stable")
+    corners = in_corners[:, order]
+    rc = corners[:2].round().astype(int)
+    if n == 1:
+        return np.vstack((rc, in_corners[2])).reshape(3, 1)
+    pad = dist_thresh
+    grid = np.zeros((H + 2 * pad, W + 2 * pad), dtype=np.int8)
+    grid[rc[1] + pad, rc[0] + pad] = 1
+    keep = []
+    for i in range(n):
+        x, y = rc[0, i] + pad, rc[1, i] + pad
+        if grid[y, x] == 1:
+            grid[y - pad:y + pad + 1, x - pad:x + pad + 1] = 0
+            grid[y, x] = -1
+            keep.append(i)
+    return corners[:, keep]
+
+
+def get_pts_from_heatmap(heatmap, conf_thresh, nms_dist, border_remove=4):
+    """models/model_wrap.py:266-293.  heatmap: np [H,W] -> 3xN float64 (x, y, conf), descending conf."""
+    H, W = heatmap.shape
+    ys, xs = np.where(heatmap >= conf_thresh)
+    if len(ys) == 0:
+        return np.zeros((3, 0))
+    pts = np.zeros((3, len(ys)))
+    pts[0], pts[1], pts[2] = xs, ys, heatmap[ys, xs]
+    pts = nms_fast(pts, H, W, nms_dist)
+    b = border_remove
+    drop = (pts[0] < b) | (pts[0] >= W - b) | (pts[1] < b) | (pts[1] >= H - b)
+    return pts[:, ~drop]
+
+
+def spatial_soft_argmax2d(x, eps=1e-6):
+    """torchgeometry (requirements.txt:19, unpinned; v0.1.2) contrib.SpatialSoftArgmax2d with
+    normalized_coordinates=False, restated from its published source -- the package is absent from
+    the image, so THIS function is parity unpinned.  x: [B,C,h,w] -> [B,C,2] (x, y)."""
+    B, C, h, w = x.shape
+    v = x.reshape(B, C, -1)
+    e = torch.exp(v - v.max(dim=-1, keepdim=True)[0])
+    inv = 1.0 / (e.sum(dim=-1, keepdim=True) + eps)
+    py, px = torch.meshgrid(torch.linspace(0, h - 1, h), torch.linspace(0, w - 1, w), indexing="ij")
+    ey = torch.sum((py.reshape(-1) * e) * inv, dim=-1, keepdim=True)
+    ex = torch.sum((px.reshape(-1) * e) * inv, dim=-1, keepdim=True)
+    return torch.cat([ex, ey], dim=-1)
+
+
+def soft_argmax_points(heatmap, pts, patch_size=5):
+    """models/model_wrap.py:212-249 + utils/losses.py:53-61,64-91,138-142: 5x5 patches of the
+    zero-padded heatmap around each point, normalised to sum 1 (+1e-6), log, soft-argmax;
+    the point moves by (dx, dy) - patch_size // 2.  pts: 3xN float64 -> 3xN float64."""
+    pts = pts.T.copy()  # [N,3]
+    if pts.shape[0] == 0:
+        return pts.T
+    r = patch_size // 2
+    hp = np.pad(np.asarray(heatmap, dtype=np.float32), r, "constant")
+    patches = np.stack([hp[int(p[1]):int(p[1]) + patch_size, int(p[0]):int(p[0]) + patch_size] for p in pts])
+    pt = torch.tensor(patches, dtype=torch.float32).view(-1, 1, patch_size * patch_size)
+    pt = pt / (pt.sum(dim=-1, keepdim=True) + 1e-6)
+    pt = pt.view(-1, 1, patch_size, patch_size)
+    pt[pt < 0] = 1e-6
+    dxdy = spatial_soft_argmax2d(torch.log(pt))  # [N,1,2]
+    pts[:, :2] = pts[:, :2] + dxdy.numpy().reshape(-1, 2) - r
+    return pts.T
+
+
+def homo_adapt_sample(img, n_views, rs, erosion_radius=0, **params):
+    """datasets/Coco.py:258-292: n_views random homographies (the first one replaced by the identity),
+    warped copies of `img` [H,W] and their valid masks.  Returns the keys the export loop reads."""
+    H, W = img.shape
+    hs = np.stack([np.linalg.inv(sample_homography(rs, **params)) for _ in range(n_views)])
+    hs[0] = np.identity(3)
+    homographies = torch.tensor(hs, dtype=torch.float32)
+    inv_h = torch.stack([torch.inverse(homographies[i]) for i in range(n_views)])
+    views = inv_warp_image_batch(img.view(1, 1, H, W).repeat(n_views, 1, 1, 1), inv_h, mode="bilinear")
+    mask = compute_valid_mask((H, W), inv_h, erosion_radius=erosion_radius)
+    return {"image": views, "valid_mask": mask.view(n_views, 1, H, W), "homographies": homographies,
+            "inv_homographies": inv_h, "image_2D": img.view(1, H, W)}
+
+
+def export_points(sd, sample, arch="SuperPointNet_gauss2", conf_thresh=0.015, nms_dist=4, top_k=600, subpixel=True,
+                  border_remove=4, n_classes=133):
+    """The per-image body of export_detector_homoAdapt_gpu (export.py:274-318).  BatchNorm runs in
+    TRAIN mode over the n_views batch (SuperPointFrontend_torch.loadModel leaves `net.eval()`
+    commented out, models/model_wrap.py:120) and so also moves the running statistics in `sd`."""
+    with torch.no_grad():
+        out = forward(sd, sample["image"], arch, train=True, n_classes=n_classes)
+        heat = flatten_detection(out["semi"])
+        agg = combine_heatmap(heat, sample["homographies"], sample["valid_mask"])  # [1,H,W]
+    hm = agg.squeeze().numpy()
+    pts = get_pts_from_heatmap(hm, conf_thresh, nms_dist, border_remove)
+    if subpixel:
+        pts = soft_argmax_points(hm, pts)
+    pts = pts.transpose()
+    if top_k and pts.shape[0] > top_k:
+        pts = pts[:top_k]
+    return {"heatmap": agg, "views_heatmap": heat, "pts": pts}

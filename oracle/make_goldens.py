@@ -342,11 +342,71 @@ def g7_warps():
     np.savez_compressed(os.path.join(OUT, "g7_warps.npz"), **save)
 
 
+def g8_export():
+    """Homography-adaptation export (export.py:274-318) through the real SuperPointFrontend_torch /
+    combine_heatmap / getPtsFromHeatmap / soft_argmax_points on random-init weights."""
+    R.install()
+    import export as E
+    from models.model_wrap import SuperPointFrontend_torch
+    from utils.utils import flattenDetection
+    cases = (("sp_64x96_v6", "SuperPointNet_gauss2", 64, 96, 6, 0.0152, 0, 40, 3),
+             ("ssp_48x64_v5", "SuperPointNet_gauss2_ssmall", 48, 64, 5, 0.015, 2, 0, 4),
+             ("sp_120x160_v4", "SuperPointNet_gauss2", 120, 160, 4, 0.0155, 0, 600, 5))
+    for name, arch, H, W, nv, thr, erosion, top_k, seed in cases:
+        rs = np.random.RandomState(100 + seed)
+        img = torch.from_numpy(rs.uniform(0, 1, (H, W)).astype(np.float32))
+        sample = C.homo_adapt_sample(img, nv, rs, erosion_radius=erosion)
+        sd0 = C.init_state_dict(arch, seed=seed)
+        cfg = {"model": {"subpixel": {"enable": True}}}
+        fe = SuperPointFrontend_torch(config=cfg, weights_path="", nms_dist=4, conf_thresh=thr, nn_thresh=0.7,
+                                      cuda=False, device="cpu", load=False)
+        fe.net = ref_net(arch, sd0)  # stays in train mode, as the reference leaves it (model_wrap.py:120)
+        with torch.no_grad():
+            heat = fe.run(sample["image"], onlyHeatmap=True, train=False)
+            # export.py:281-284 binds sample["homographies"] to the name `inv_homographies`
+            agg = E.combine_heatmap(heat, sample["homographies"].unsqueeze(0), sample["valid_mask"], device="cpu")
+        pts_nms = fe.getPtsFromHeatmap(agg.detach().cpu().squeeze())
+        fe.heatmap = agg
+        pts = fe.soft_argmax_points([pts_nms])[0].transpose()
+        if top_k and pts.shape[0] > top_k:
+            pts = pts[:top_k]
+        conf = pts_nms[2]
+        assert len(np.unique(conf)) == len(conf), "G8: tie among kept points, pick another seed"
+        hm = npy(agg).squeeze()
+        cand = hm[hm >= thr]
+        # equal-confidence candidates only matter to the greedy order when they can suppress each other
+        cm = np.where(hm >= thr, hm, -1.0)
+        for dy in range(-4, 5):
+            for dx in range(-4, 5):
+                if (dy, dx) > (0, 0):
+                    a = cm[max(dy, 0):H + min(dy, 0), max(dx, 0):W + min(dx, 0)]
+                    b = cm[max(-dy, 0):H + min(-dy, 0), max(-dx, 0):W + min(-dx, 0)]
+                    assert not np.any((a == b) & (a > 0)), "G8: tie inside an NMS window, pick another seed"
+        # oracle == reference
+        sd = C.to_torch(C.init_state_dict(arch, seed=seed))
+        o = C.export_points(sd, sample, arch, conf_thresh=thr, nms_dist=4, top_k=top_k, subpixel=True)
+        close(o["views_heatmap"], heat, 1e-6, "G8 views heatmap " + name)
+        close(o["heatmap"], agg, 1e-6, "G8 aggregate " + name)
+        o_nms = C.get_pts_from_heatmap(hm, thr, 4)  # on the reference's own aggregate: bit-exact
+        assert np.array_equal(o_nms, pts_nms), "G8 nms " + name
+        o_sub = C.soft_argmax_points(hm, o_nms).transpose()
+        assert np.array_equal(o_sub[:len(pts)], pts), "G8 subpixel/top-k " + name
+        rsd = fe.net.state_dict()
+        for k in ("bnPb.running_mean", "bnPb.running_var", "inc.conv.conv.1.running_var"):
+            close(sd[k], rsd[k], 1e-5, "G8 running stats " + k)
+        print("  %s: %d candidates, %d kept, %d exported" % (name, len(cand), pts_nms.shape[1], len(pts)))
+        np.savez_compressed(os.path.join(OUT, "g8_export_%s.npz" % name), arch=arch, seed=seed, thr=thr,
+                            erosion=erosion, top_k=top_k, img=npy(img), homographies=npy(sample["homographies"]),
+                            inv_homographies=npy(sample["inv_homographies"]), views=npy(sample["image"]),
+                            valid_mask=npy(sample["valid_mask"]), views_heatmap=npy(heat), aggregate=hm,
+                            pts_nms=pts_nms, pts=pts, bnPb_running_var=npy(rsd["bnPb.running_var"]))
+
+
 def main():
     assert R.available(), "reference not mounted"
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step):
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export):
         fn()
         print(fn.__name__, "done")
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

@@ -78,6 +78,25 @@ def install():
             import tqdm  # noqa: F401
         except Exception:
             _stub("tqdm", tqdm=lambda x, *a, **k: x)
+    if "imageio" not in sys.modules:  # export.py:18 (only imread, never reached by the fixtures)
+        try:
+            import imageio  # noqa: F401
+        except Exception:
+            _stub("imageio", imread=None)
+    if "torchgeometry" not in sys.modules:
+        # utils/losses.py:129-135 calls tgm.contrib.SpatialSoftArgmax2d; the package is absent, so the stub
+        # forwards to the oracle's restatement of its published algorithm: that ONE sub-step of the export
+        # fixtures is therefore self-referential ("parity unpinned", see oracle/cpu_ref.py).
+        class SpatialSoftArgmax2d:
+            def __init__(self, normalized_coordinates=True):
+                assert not normalized_coordinates
+
+            def __call__(self, x):
+                from oracle import cpu_ref
+                return cpu_ref.spatial_soft_argmax2d(x)
+
+        tgm = _stub("torchgeometry")
+        tgm.contrib = _stub("torchgeometry.contrib", SpatialSoftArgmax2d=SpatialSoftArgmax2d)
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
     # the trainer imports a module that the reference repo itself does not contain

@@ -17,6 +17,7 @@
 #include "conv_mfma.hip.h"
 #include "loss_kernels.hip.h"
 #include "pair_kernels.hip.h"
+#include "export_kernels.hip.h"
 #include "sem_kernels.hip.h"
 
 using namespace sspk;
@@ -592,7 +593,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
 }
 
 static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs, int N, int H, int W, int train,
-                       bool for_backward, hipStream_t st) {
+                       bool for_backward, hipStream_t st, bool detector_only = false) {
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     S.N = N; S.H = H; S.W = W; S.x = xs[k];
@@ -616,6 +617,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   }
   const int Hc = H / 8, Wc = W / 8;
   CHK(conv_layer_fwd(h, SS, L_PA, 7, N, Hc, Wc, 1, train, st));
+  if (detector_only) return conv_layer_fwd(h, SS, L_PB, L_PA, N, Hc, Wc, 1, train, st);
   CHK(conv_layer_fwd(h, SS, L_DA, 7, N, Hc, Wc, 1, train, st));
   CHK(conv_layer_fwd(h, SS, L_PB, L_PA, N, Hc, Wc, 1, train, st));
   CHK(conv_layer_fwd(h, SS, L_DB, L_DA, N, Hc, Wc, 1, train, st));
@@ -1023,6 +1025,142 @@ int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_d
   hipLaunchKernelGGL(warp_labels_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, labels_dev, h_dev, out_dev,
                      b, hh, w);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- homography-adaptation export ----
+static int export_cap(const ssp_export_params* p) {
+  const int d = p->nms_dist + 1;
+  return cdiv(p->height, d) * cdiv(p->width, d);  // kept points are pairwise more than nms_dist apart (Chebyshev)
+}
+static int export_cap2(const ssp_export_params* p) {
+  int c = 1;
+  while (c < export_cap(p)) c <<= 1;
+  return c;
+}
+static int export_check(const ssp_export_params* p) {
+  if (!p || p->n_views < 1 || p->height < 8 || p->width < 8 || p->height % 8 || p->width % 8)
+    return fail(-1, "export: n_views >= 1 and height/width multiples of 8 are required");
+  if (p->nms_dist < 0 || p->nms_dist > 64 || p->border_remove < 0 || p->top_k < 0)
+    return fail(-1, "export: nms_dist in [0,64], border_remove >= 0, top_k >= 0 required");
+  return 0;
+}
+struct ExportWs {
+  float *heat, *agg;
+  PointsWork pw;
+  size_t bytes;
+};
+static ExportWs export_carve(const ssp_export_params* p, void* base) {
+  Carver c{reinterpret_cast<char*>(base), 0};
+  const size_t hw = (size_t)p->height * p->width;
+  ExportWs w;
+  w.heat = c.take<float>(hw * p->n_views);
+  w.agg = c.take<float>(hw);
+  w.pw.state = c.take<uint8_t>(hw);
+  w.pw.cand[0] = c.take<int32_t>(hw);
+  w.pw.cand[1] = c.take<int32_t>(hw);
+  w.pw.keys = c.take<uint64_t>(export_cap2(p));
+  w.pw.counters = c.take<int32_t>(16);
+  w.bytes = align_up(c.off, 256);
+  return w;
+}
+
+size_t ssp_export_workspace_bytes(const ssp_export_params* p) {
+  if (export_check(p)) return 0;
+  return export_carve(p, nullptr).bytes;
+}
+
+int ssp_export_max_points(const ssp_export_params* p) {
+  if (export_check(p)) return -1;
+  const int cap = export_cap(p);
+  return p->top_k > 0 ? std::min(cap, p->top_k) : cap;
+}
+
+int ssp_op_homoadapt_views(const float* img_dev, const float* inv_h_dev, float* views_dev, float* masks_dev, int n, int hh,
+                           int w, void* stream) {
+  const long tot = (long)n * hh * w;
+  hipLaunchKernelGGL(homoadapt_views_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, img_dev, inv_h_dev,
+                     views_dev, masks_dev, n, hh, w);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_flatten_detection(const float* semi_nchw_dev, const float* mask_dev, float* heat_dev, int n, int hc, int wc,
+                             void* stream) {
+  const int ncells = n * hc * wc;
+  hipLaunchKernelGGL(flatten_detection_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, (hipStream_t)stream, semi_nchw_dev,
+                     (const float*)nullptr, (const float*)nullptr, mask_dev, heat_dev, ncells, hc, wc, (long)65 * hc * wc,
+                     1L, (long)hc * wc);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_combine_heatmap(const float* heat_dev, const float* mask_dev, const float* unwarp_h_dev, float* out_dev, int n,
+                           int hh, int w, void* stream) {
+  hipLaunchKernelGGL(combine_heatmap_kernel, dim3(cdiv((long)hh * w, 64)), dim3(256), 0, (hipStream_t)stream, heat_dev,
+                     mask_dev, unwarp_h_dev, out_dev, n, hh, w);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int heatmap_points(const float* heat, const ssp_export_params* p, const PointsWork& pw, float* pts, int32_t* count,
+                          hipStream_t st) {
+  const int hw = p->height * p->width;
+  HIPCHK(hipMemsetAsync(pw.counters, 0, 16 * sizeof(int32_t), st));
+  hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, st, heat, p->conf_thresh, pw, hw);
+  hipLaunchKernelGGL(nms_points_kernel, dim3(1), dim3(1024), 0, st, heat, pw, p->height, p->width, p->nms_dist,
+                     p->border_remove, p->top_k, p->subpixel, export_cap(p), export_cap2(p), pts, count);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_heatmap_points(const float* heat_dev, const ssp_export_params* p, void* workspace_dev, float* pts_dev,
+                          int32_t* count_dev, void* stream) {
+  CHK(export_check(p));
+  if (!heat_dev || !workspace_dev || !pts_dev || !count_dev) return fail(-1, "heatmap_points: null pointer");
+  return heatmap_points(heat_dev, p, export_carve(p, workspace_dev).pw, pts_dev, count_dev, (hipStream_t)stream);
+}
+
+int ssp_op_soft_argmax_points(const float* heat_dev, const float* xy_dev, float* out_dev, int n, int hh, int w,
+                              void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(soft_argmax_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, heat_dev, xy_dev,
+                     out_dev, n, hh, w);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_export_points(ssp_handle* h, const ssp_export_params* p, int n_images, const float* const* views_dev,
+                      const float* const* masks_dev, const float* const* unwarp_h_dev, void* const* workspace_dev,
+                      float* const* heatmap_out_dev, float* const* pts_dev, int32_t* const* count_dev, void* stream) {
+  if (!h || !h->bound) return fail(-1, "handle not bound");
+  CHK(export_check(p));
+  if (n_images < 1 || n_images > 2) return fail(-1, "export: 1 or 2 images per call");
+  if (p->n_views > h->cfg.max_batch || (size_t)p->n_views * p->height * p->width >
+                                           (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width)
+    return fail(-1, "export: %d views of %dx%d exceed the configured engine size", p->n_views, p->height, p->width);
+  for (int k = 0; k < n_images; ++k)
+    if (!views_dev[k] || !masks_dev[k] || !unwarp_h_dev[k] || !workspace_dev[k] || !pts_dev[k] || !count_dev[k])
+      return fail(-1, "export: null pointer for image %d", k);
+  hipStream_t st = (hipStream_t)stream;
+  SlotSet SS{n_images, {&h->slot[0], n_images == 2 ? &h->slot[1] : nullptr}};
+  const float* xs[2] = {views_dev[0], n_images == 2 ? views_dev[1] : nullptr};
+  // BatchNorm in train mode over the views of ONE image (models/model_wrap.py:120 leaves net.eval() commented out);
+  // only the detector head is evaluated -- the export discards the descriptors (export.py:296)
+  CHK(run_forward(h, SS, xs, p->n_views, p->height, p->width, 1, false, st, true));
+  const int Hc = p->height / 8, Wc = p->width / 8, ncells = p->n_views * Hc * Wc;
+  for (int k = 0; k < n_images; ++k) {
+    Slot& S = h->slot[k];
+    ExportWs w = export_carve(p, workspace_dev[k]);
+    float* agg = heatmap_out_dev && heatmap_out_dev[k] ? heatmap_out_dev[k] : w.agg;
+    hipLaunchKernelGGL(flatten_detection_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
+                       S.bn[L_PB].shift, masks_dev[k], w.heat, ncells, Hc, Wc, (long)Hc * Wc * S.y_cs[L_PB],
+                       (long)S.y_cs[L_PB], 1L);
+    hipLaunchKernelGGL(combine_heatmap_kernel, dim3(cdiv((long)p->height * p->width, 64)), dim3(256), 0, st, w.heat,
+                       masks_dev[k], unwarp_h_dev[k], agg, p->n_views, p->height, p->width);
+    HIPCHK(hipGetLastError());
+    CHK(heatmap_points(agg, p, w.pw, pts_dev[k], count_dev[k], st));
+  }
   return 0;
 }
 

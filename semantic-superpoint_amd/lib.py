@@ -41,13 +41,20 @@ class SspPairInputs(C.Structure):
                 ("lamda_d", C.c_float), ("multi_task", C.c_int), ("train", C.c_int)]
 
 
+class SspExportParams(C.Structure):
+    _fields_ = [("n_views", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("conf_thresh", C.c_float),
+                ("nms_dist", C.c_int32), ("border_remove", C.c_int32), ("top_k", C.c_int32), ("subpixel", C.c_int32)]
+
+
 _lib = None
 
 EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ssp_bn_channel_count",
            "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
            "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
-           "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels"]
+           "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
+           "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
+           "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points"]
 
 
 def load_library(path=None):
@@ -88,6 +95,16 @@ def load_library(path=None):
     lib.ssp_op_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
     lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
+    ep = C.POINTER(SspExportParams)
+    lib.ssp_export_workspace_bytes.argtypes = [ep]
+    lib.ssp_export_workspace_bytes.restype = C.c_size_t
+    lib.ssp_export_max_points.argtypes = [ep]
+    lib.ssp_export_points.argtypes = [vp, ep, i] + [C.POINTER(vp)] * 7 + [vp]
+    lib.ssp_op_homoadapt_views.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.ssp_op_flatten_detection.argtypes = [vp, vp, vp, i, i, i, vp]
+    lib.ssp_op_combine_heatmap.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.ssp_op_heatmap_points.argtypes = [vp, ep, vp, vp, vp, vp]
+    lib.ssp_op_soft_argmax_points.argtypes = [vp, vp, vp, i, i, i, vp]
     _lib = lib
     return lib
 
@@ -330,6 +347,38 @@ class Engine:
             _check(self.lib.ssp_pair_step(self.h, C.byref(inp), _ptr(self.scalars), _stream()))
         return self.scalars
 
+    def export_points(self, views, masks, unwarp_h, conf_thresh=0.015, nms_dist=4, top_k=600, subpixel=True,
+                      border_remove=4, want_heatmap=False):
+        """Homography-adaptation export of 1 or 2 images (export.py:296-309).  views/masks: lists of [n,1,H,W] (or
+        [n,H,W]) device tensors -- one BatchNorm batch each; unwarp_h: list of [n,3,3] (sample["homographies"]).
+        Returns a list of dicts {"pts": device [count,5] rows (x, y, conf, sx, sy), "count": device int32,
+        "heatmap": [H,W] or None}; no host synchronisation happens here."""
+        k = len(views)
+        n, hh, ww = views[0].shape[0], views[0].shape[-2], views[0].shape[-1]
+        p = SspExportParams(n, hh, ww, float(np.float32(conf_thresh)), int(nms_dist), int(border_remove),
+                            int(top_k or 0), int(bool(subpixel)))
+        for t in list(views) + list(masks) + list(unwarp_h):
+            _need_gpu(t, "export tensor")
+            assert t.dtype == torch.float32 and t.shape[0] == n
+        wsb = self.lib.ssp_export_workspace_bytes(C.byref(p))
+        cap = self.lib.ssp_export_max_points(C.byref(p))
+        if wsb == 0 or cap < 0:
+            _check(-1)
+        key = (n, hh, ww, int(nms_dist), int(top_k or 0))
+        if getattr(self, "_export_ws_key", None) != key:
+            self._export_ws = [torch.empty(wsb, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self._export_ws_key = key
+        f32 = dict(dtype=torch.float32, device=self.device)
+        pts = [torch.empty(max(cap, 1), 5, **f32) for _ in range(k)]
+        cnt = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(k)]
+        hm = [torch.empty(hh, ww, **f32) if want_heatmap else None for _ in range(k)]
+        arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() if t is not None else None for t in ts])  # noqa: E731
+        self._keep_export = (views, masks, unwarp_h)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_export_points(self.h, C.byref(p), k, arr(views), arr(masks), arr(unwarp_h),
+                                              arr(self._export_ws[:k]), arr(hm), arr(pts), arr(cnt), _stream()))
+        return [{"pts": pts[j], "count": cnt[j], "heatmap": hm[j]} for j in range(k)]
+
     def debug_buffer(self, slot, name, shape):
         """Test hook: copy of an internal NHWC buffer as a torch tensor of `shape`."""
         p, n = C.c_void_p(), C.c_size_t()
@@ -454,4 +503,87 @@ def op_warp_labels(labels, hn):
     out = torch.empty_like(labels)
     with torch.cuda.device(labels.device):
         _check(lib.ssp_op_warp_labels(_ptr(labels), _ptr(hn), _ptr(out), B, H, W, _stream()))
+    return out
+
+
+# ---- homography-adaptation export operators ----
+def op_homoadapt_views(img, inv_h):
+    """datasets/Coco.py:279-288 on the device: img [H,W], inv_h [n,3,3] -> (views [n,1,H,W], masks [n,1,H,W])."""
+    lib = load_library()
+    _need_gpu(img, "img")
+    inv_h = inv_h.to(img.device, torch.float32).contiguous()
+    n, (H, W) = inv_h.shape[0], img.shape[-2:]
+    views = torch.empty(n, 1, H, W, dtype=torch.float32, device=img.device)
+    masks = torch.empty_like(views)
+    with torch.cuda.device(img.device):
+        _check(lib.ssp_op_homoadapt_views(_ptr(img), _ptr(inv_h), _ptr(views), _ptr(masks), n, H, W, _stream()))
+    return views, masks
+
+
+def op_flatten_detection(semi, mask=None):
+    """flattenDetection (utils/utils.py:515-560) of semi [n,65,Hc,Wc] -> [n,1,8Hc,8Wc], times mask if given."""
+    lib = load_library()
+    _need_gpu(semi, "semi")
+    n, c, Hc, Wc = semi.shape
+    assert c == 65
+    out = torch.empty(n, 1, Hc * 8, Wc * 8, dtype=torch.float32, device=semi.device)
+    if mask is not None:
+        _need_gpu(mask, "mask")
+    with torch.cuda.device(semi.device):
+        _check(lib.ssp_op_flatten_detection(_ptr(semi), _ptr(mask), _ptr(out), n, Hc, Wc, _stream()))
+    return out
+
+
+def op_combine_heatmap(heat, mask, unwarp_h):
+    """combine_heatmap (export.py:49-60); heat must already be heatmap*mask.  -> [H,W]"""
+    lib = load_library()
+    _need_gpu(heat, "heat")
+    _need_gpu(mask, "mask")
+    unwarp_h = unwarp_h.to(heat.device, torch.float32).contiguous()
+    n, (H, W) = heat.shape[0], heat.shape[-2:]
+    out = torch.empty(H, W, dtype=torch.float32, device=heat.device)
+    with torch.cuda.device(heat.device):
+        _check(lib.ssp_op_combine_heatmap(_ptr(heat), _ptr(mask), _ptr(unwarp_h), _ptr(out), n, H, W, _stream()))
+    return out
+
+
+def op_heatmap_points(heatmap, conf_thresh, nms_dist=4, border_remove=4, top_k=0, subpixel=False):
+    """getPtsFromHeatmap (+ soft_argmax_points, top-k) on the device.  Returns a float64 numpy [N,3] array of
+    (x, y, conf), assembled exactly like models/model_wrap.py:245 (x + sx - 2 in float64)."""
+    lib = load_library()
+    _need_gpu(heatmap, "heatmap")
+    H, W = heatmap.shape
+    p = SspExportParams(1, H, W, float(np.float32(conf_thresh)), int(nms_dist), int(border_remove), int(top_k or 0),
+                        int(bool(subpixel)))
+    wsb, cap = lib.ssp_export_workspace_bytes(C.byref(p)), lib.ssp_export_max_points(C.byref(p))
+    if wsb == 0 or cap < 0:
+        _check(-1)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=heatmap.device)
+    pts = torch.empty(max(cap, 1), 5, dtype=torch.float32, device=heatmap.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=heatmap.device)
+    with torch.cuda.device(heatmap.device):
+        _check(lib.ssp_op_heatmap_points(_ptr(heatmap), C.byref(p), _ptr(ws), _ptr(pts), _ptr(cnt), _stream()))
+    return points_to_numpy(pts, cnt, subpixel)
+
+
+def op_soft_argmax_points(heatmap, xy):
+    """(sx, sy) in [0,4] of the 5x5 soft-argmax around each (x, y) of xy [n,2] (device float32) -> device [n,2]."""
+    lib = load_library()
+    _need_gpu(heatmap, "heatmap")
+    _need_gpu(xy, "xy")
+    H, W = heatmap.shape
+    out = torch.empty(xy.shape[0], 2, dtype=torch.float32, device=heatmap.device)
+    with torch.cuda.device(heatmap.device):
+        _check(lib.ssp_op_soft_argmax_points(_ptr(heatmap), _ptr(xy), _ptr(out), xy.shape[0], H, W, _stream()))
+    return out
+
+
+def points_to_numpy(pts, count, subpixel):
+    """Device rows (x, y, conf, sx, sy) -> the reference's float64 [N,3] `pts` (one host synchronisation)."""
+    n = int(count.item())
+    a = pts[:n].cpu().numpy()
+    out = np.zeros((n, 3), dtype=np.float64)
+    out[:, 0], out[:, 1], out[:, 2] = a[:, 0], a[:, 1], a[:, 2]
+    if subpixel:
+        out[:, :2] = out[:, :2] + a[:, 3:5] - 2
     return out

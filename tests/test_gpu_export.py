@@ -1,0 +1,238 @@
+"""GPU: homography-adaptation export -- the HIP kernels through the C ABI against the
+CPU oracle and the G8 fixtures generated from the real reference (SuperPointFrontend_torch / combine_heatmap).
+Bars: point extraction (threshold, greedy NMS, border, order, top-k) bit-exact on identical heatmaps; heatmaps within
+1e-5 of the reference (detector probabilities, fp32); soft-argmax offsets within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as C
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+G8 = ("sp_64x96_v6", "ssp_48x64_v5", "sp_120x160_v4")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (run through gpurun)"
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _oracle_pts(hm, thr, dist=4, border=4, top_k=0, subpixel=False):
+    pts = C.get_pts_from_heatmap(hm, np.float32(thr), dist, border)
+    if subpixel:
+        pts = C.soft_argmax_points(hm, pts)
+    pts = pts.transpose()
+    return pts[:top_k] if top_k and pts.shape[0] > top_k else pts
+
+
+@pytest.mark.parametrize("name", G8)
+def test_views_and_masks(name):
+    from semantic_superpoint_amd import lib as L
+    g = G.load("g8_export_%s.npz" % name)
+    views, masks = L.op_homoadapt_views(t(g["img"]).to(_dev()), t(g["inv_homographies"]))
+    # white-noise image: |d img / d pixel| ~ 1, fp32 source coordinates carry a few 1e-6 pixels of rounding
+    assert (views.cpu() - t(g["views"])).abs().max() < 5e-5
+    if int(g["erosion"]) > 0:
+        masks = L.op_erode(masks, int(g["erosion"]))
+    assert float((masks.cpu() != t(g["valid_mask"])).float().mean()) < 1e-3  # nearest ties at .5 may flip
+
+
+@pytest.mark.parametrize("name", G8)
+def test_flatten_and_combine(name):
+    from semantic_superpoint_amd import lib as L
+    g = G.load("g8_export_%s.npz" % name)
+    dev = _dev()
+    sd = C.to_torch(C.init_state_dict(str(g["arch"]), seed=int(g["seed"])))
+    with torch.no_grad():
+        semi = C.forward(sd, t(g["views"]), str(g["arch"]), train=True)["semi"]
+    heat = L.op_flatten_detection(semi.to(dev).contiguous())
+    assert (heat.cpu() - t(g["views_heatmap"])).abs().max() < 1e-6
+    mask = t(g["valid_mask"]).to(dev)
+    masked = L.op_flatten_detection(semi.to(dev).contiguous(), mask)
+    assert torch.equal(masked, heat * mask)
+    agg = L.op_combine_heatmap(masked, mask, t(g["homographies"]))
+    # random-weight heatmaps jump by ~0.1 between neighbouring pixels; fp32 source coordinates differ by ~1e-5 px
+    assert (agg.cpu() - t(g["aggregate"])).abs().max() < 5e-6
+
+
+@pytest.mark.parametrize("name", G8)
+def test_points_from_reference_aggregate(name):
+    """Same heatmap in, same points out: (x, y, conf) bit-exact, soft-argmax within 1e-5, same top-k cut."""
+    from semantic_superpoint_amd import lib as L
+    g = G.load("g8_export_%s.npz" % name)
+    hm = t(g["aggregate"]).to(_dev())
+    nms = L.op_heatmap_points(hm, float(g["thr"]), 4, 4)
+    assert np.array_equal(nms, g["pts_nms"].T)
+    sub = L.op_heatmap_points(hm, float(g["thr"]), 4, 4, top_k=int(g["top_k"]), subpixel=True)
+    assert sub.shape == g["pts"].shape
+    assert np.array_equal(sub[:, 2], g["pts"][:, 2])
+    assert np.abs(sub[:, :2] - g["pts"][:, :2]).max() < 1e-5
+
+
+def _heatmaps(rs):
+    H, W = 240, 320
+    peaky = np.exp(3.0 * rs.randn(H, W)).astype(np.float32)
+    peaky /= peaky.max()
+    yield "peaky", peaky, 0.015, 4, 4
+    yield "dense_uniform", rs.uniform(0, 1, (H, W)).astype(np.float32), 0.5, 4, 4
+    yield "all_candidates", rs.uniform(0.1, 1, (H, W)).astype(np.float32), 0.015, 4, 4
+    ramp = (np.arange(H)[:, None] * W + np.arange(W)[None, :]).astype(np.float32) / (H * W) + 0.1  # one long chain
+    yield "ramp", ramp, 0.015, 4, 4
+    yield "constant_ties", np.full((H, W), 0.25, np.float32), 0.015, 4, 4  # ties: lower row-major index wins
+    q = np.round(rs.uniform(0, 1, (H, W)) * 8).astype(np.float32) / 8  # many ties inside NMS windows
+    yield "quantised_ties", q, 0.2, 4, 4
+    yield "dist1_border0", rs.uniform(0, 1, (48, 64)).astype(np.float32), 0.3, 1, 0
+    yield "dist8", rs.uniform(0, 1, (96, 128)).astype(np.float32), 0.3, 8, 2
+    yield "big_480x640", rs.uniform(0, 1, (480, 640)).astype(np.float32), 0.7, 4, 4
+    nanmap = rs.uniform(0, 1, (64, 96)).astype(np.float32)
+    nanmap[rs.uniform(size=nanmap.shape) < 0.3] = np.nan  # 0/0 of combine_heatmap where no view covers a pixel
+    yield "with_nan", nanmap, 0.3, 4, 4
+    yield "empty", np.zeros((64, 96), np.float32), 0.015, 4, 4
+    one = np.zeros((64, 96), np.float32)
+    one[30, 40] = 0.9
+    yield "single", one, 0.015, 4, 4
+
+
+def test_greedy_nms_matches_sequential_oracle():
+    """The parallel fixed-point NMS reproduces nms_fast's sequential greedy result, including ties (stable order)."""
+    from semantic_superpoint_amd import lib as L
+    rs = np.random.RandomState(5)
+    for name, hm, thr, dist, border in _heatmaps(rs):
+        mine = L.op_heatmap_points(t(hm).to(_dev()), thr, dist, border)
+        ref = _oracle_pts(hm, thr, dist, border)
+        assert mine.shape == ref.shape, (name, mine.shape, ref.shape)
+        assert np.array_equal(mine, ref), name
+        # size-independent properties: kept points pairwise farther than dist, every candidate is covered
+        if len(mine):
+            xy = mine[:, :2].astype(np.int64)
+            assert np.all(np.diff(mine[:, 2]) <= 0), name
+            if len(xy) < 4000:
+                d = np.abs(xy[:, None, :] - xy[None, :, :]).max(-1)
+                np.fill_diagonal(d, 10 ** 6)
+                assert d.min() > dist, name
+
+
+def test_top_k_and_subpixel_on_random_heatmap():
+    from semantic_superpoint_amd import lib as L
+    rs = np.random.RandomState(6)
+    hm = np.exp(2.0 * rs.randn(120, 160)).astype(np.float32)
+    hm /= hm.max()
+    ref = _oracle_pts(hm, 0.015, 4, 4, top_k=100, subpixel=True)
+    mine = L.op_heatmap_points(t(hm).to(_dev()), 0.015, 4, 4, top_k=100, subpixel=True)
+    assert mine.shape == ref.shape == (100, 3)
+    assert np.array_equal(mine[:, 2], ref[:, 2])
+    assert np.abs(mine[:, :2] - ref[:, :2]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", G8)
+def test_fused_export_against_reference(name):
+    """Engine.export_points (forward + flatten + combine + points in one call) on the fixture's views."""
+    from semantic_superpoint_amd.lib import Engine, points_to_numpy
+    g = G.load("g8_export_%s.npz" % name)
+    dev = _dev()
+    arch, thr, top_k = str(g["arch"]), float(g["thr"]), int(g["top_k"])
+    n, _, H, W = g["views"].shape
+    e = Engine(arch, n, H, W, dev, with_grad=False)
+    e.load_state_dict(C.init_state_dict(arch, seed=int(g["seed"])))
+    views, masks, hms = (t(g[k]).to(dev).contiguous() for k in ("views", "valid_mask", "homographies"))
+    out = e.export_points([views], [masks], [hms], conf_thresh=thr, nms_dist=4, top_k=top_k, subpixel=True,
+                          want_heatmap=True)[0]
+    agg = out["heatmap"].cpu().numpy()
+    assert np.abs(agg - g["aggregate"]).max() < 1e-5
+    # BatchNorm ran in train mode over the views: running statistics move exactly as in the reference
+    assert (e.state_dict()["bnPb.running_var"].cpu() - t(g["bnPb_running_var"])).abs().max() < 1e-4
+    # points: exactly what the reference's extraction gives on THIS aggregate ...
+    mine = points_to_numpy(out["pts"], out["count"], True)
+    ref = _oracle_pts(agg, thr, 4, 4, top_k=top_k, subpixel=True)
+    assert mine.shape == ref.shape
+    assert np.array_equal(mine[:, 2], ref[:, 2])
+    assert np.abs(mine[:, :2] - ref[:, :2]).max() < 1e-5
+    # ... and nearly all of the reference's exported points (fp32 noise may flip a near-tie or a threshold case)
+    gold = {(int(round(x)), int(round(y))) for x, y, _ in g["pts"]}
+    hit = sum((int(round(x)), int(round(y))) in gold for x, y, _ in mine)
+    assert hit >= 0.9 * len(gold), (hit, len(gold))
+
+
+def test_two_images_per_call_match_single_calls():
+    """The pair launch (one BatchNorm batch per image) gives each image the result of a call of its own."""
+    from semantic_superpoint_amd.lib import Engine, points_to_numpy
+    dev = _dev()
+    arch, n, H, W = "SuperPointNet_gauss2", 6, 64, 96
+    rs = np.random.RandomState(9)
+    samples = [C.homo_adapt_sample(t(rs.uniform(0, 1, (H, W)).astype(np.float32)), n, rs) for _ in range(2)]
+    views = [s["image"].to(dev).contiguous() for s in samples]
+    masks = [s["valid_mask"].to(dev).contiguous() for s in samples]
+    hms = [s["homographies"].to(dev).contiguous() for s in samples]
+    sd = C.init_state_dict(arch, seed=3)
+    e = Engine(arch, n, H, W, dev, with_grad=False)
+    e.load_state_dict(sd)
+    both = e.export_points(views, masks, hms, conf_thresh=0.0152, top_k=0, subpixel=False, want_heatmap=True)
+    for k in range(2):
+        e.load_state_dict(sd)
+        one = e.export_points(views[k:k + 1], masks[k:k + 1], hms[k:k + 1], conf_thresh=0.0152, top_k=0, subpixel=False,
+                              want_heatmap=True)[0]
+        assert (one["heatmap"] - both[k]["heatmap"]).abs().max() < 1e-6
+        a, b = points_to_numpy(one["pts"], one["count"], False), points_to_numpy(both[k]["pts"], both[k]["count"], False)
+        sa, sb = {tuple(r[:2]) for r in a}, {tuple(r[:2]) for r in b}
+        assert len(sa & sb) >= 0.95 * max(len(sa), 1)
+        # oracle end to end on the same views
+        o = C.export_points(C.to_torch(C.init_state_dict(arch, seed=3)), samples[k], arch, conf_thresh=np.float32(0.0152),
+                            top_k=0, subpixel=False)
+        assert (o["heatmap"].squeeze() - both[k]["heatmap"].cpu()).abs().max() < 1e-5
+
+
+def test_dropin_frontend_and_combine_heatmap():
+    """The reference's call sequence (export.py:296-309) through the drop-in names."""
+    from semantic_superpoint_amd import export as X
+    from semantic_superpoint_amd.models.SuperPointNet_gauss2 import SuperPointNet_gauss2
+    g = G.load("g8_export_sp_64x96_v6.npz")
+    dev = _dev()
+    thr, top_k = float(g["thr"]), int(g["top_k"])
+    cfg = {"model": {"name": "SuperPointNet_gauss2", "params": {}, "subpixel": {"enable": True}}}
+    fe = X.SuperPointFrontend_torch(cfg, "", nms_dist=4, conf_thresh=thr, nn_thresh=0.7, device=dev, load=False)
+    net = SuperPointNet_gauss2()
+    net.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in C.init_state_dict("SuperPointNet_gauss2", seed=int(g["seed"])).items()})
+    fe.net = net.to(dev)
+    img, mask = t(g["views"]).to(dev), t(g["valid_mask"]).to(dev)
+    heat = fe.run(img, onlyHeatmap=True, train=False)
+    assert (heat.cpu() - t(g["views_heatmap"])).abs().max() < 1e-5
+    outputs = X.combine_heatmap(heat, t(g["homographies"]).unsqueeze(0).to(dev), mask, device=dev)
+    assert outputs.shape == (1, 64, 96)
+    assert (outputs.cpu().squeeze() - t(g["aggregate"])).abs().max() < 1e-5
+    # identical heatmap in -> identical points out, through the reference's method names
+    fe.heatmap = t(g["aggregate"])
+    pts = fe.getPtsFromHeatmap(t(g["aggregate"]))
+    assert np.array_equal(pts, g["pts_nms"])
+    sub = fe.soft_argmax_points([pts])[0].transpose()[:top_k]
+    assert np.abs(sub - g["pts"]).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        fe.run(img, onlyHeatmap=False)
+    # nms_fast on an explicit corner list
+    rs = np.random.RandomState(2)
+    flat = rs.choice(64 * 96, 500, replace=False)
+    corners = np.stack([flat % 96, flat // 96, rs.uniform(0.01, 1, 500)]).astype(np.float64)
+    corners[2] = corners[2].astype(np.float32)
+    kept, inds = fe.nms_fast(corners, 64, 96, 4)
+    assert np.array_equal(kept, C.nms_fast(corners, 64, 96, 4))
+    assert np.array_equal(corners[:, inds], kept)
+    # the fused exporter on the same sample
+    ex = X.HomoAdaptExporter(fe.net, dev, thr, 4, top_k, True)
+    pts2, hms = ex([{"image": img, "valid_mask": mask, "homographies": t(g["homographies"])}], want_heatmap=True)
+    assert (hms[0].cpu() - t(g["aggregate"])).abs().max() < 1e-5
+    assert pts2[0].shape[1] == 3 and len(pts2[0]) <= top_k
+
+
+def test_export_refuses_bad_arguments():
+    from semantic_superpoint_amd.lib import Engine
+    dev = _dev()
+    e = Engine("SuperPointNet_gauss2", 4, 32, 48, dev, with_grad=False)
+    v = torch.zeros(6, 1, 32, 48, device=dev)
+    with pytest.raises(RuntimeError):  # more views than the engine was sized for
+        e.export_points([v], [v], [torch.eye(3, device=dev).repeat(6, 1, 1)])
+    with pytest.raises(RuntimeError):  # host tensors: no CPU fallback
+        e.export_points([v.cpu()[:4]], [v.cpu()[:4]], [torch.eye(3).repeat(4, 1, 1)])

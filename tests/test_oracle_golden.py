@@ -148,3 +148,52 @@ def test_erode_ellipse_shape():
     m[10, 10] = 0
     e = C.erode_ellipse(m, 3)
     assert e.sum() == 400 - k.sum()
+
+
+G8 = ("sp_64x96_v6", "ssp_48x64_v5", "sp_120x160_v4")
+
+
+def g8_sample(g):
+    return {"image": t(g["views"]), "valid_mask": t(g["valid_mask"]), "homographies": t(g["homographies"]),
+            "inv_homographies": t(g["inv_homographies"])}
+
+
+@pytest.mark.parametrize("name", G8)
+def test_g8_export(name):
+    """Homography-adaptation export: oracle vs the reference's SuperPointFrontend_torch/combine_heatmap outputs."""
+    g = G.load("g8_export_%s.npz" % name)
+    arch, thr, top_k = str(g["arch"]), float(g["thr"]), int(g["top_k"])
+    # dataset side (Coco.py:258-292): views and masks from the image and the homographies
+    inv = t(g["inv_homographies"])
+    H, W = g["img"].shape
+    views = C.inv_warp_image_batch(t(g["img"]).view(1, 1, H, W).repeat(inv.shape[0], 1, 1, 1), inv)
+    assert (views - t(g["views"])).abs().max() < 1e-6
+    assert torch.equal(C.compute_valid_mask((H, W), inv, int(g["erosion"])).view(-1, 1, H, W), t(g["valid_mask"]))
+    sd = C.to_torch(C.init_state_dict(arch, seed=int(g["seed"])))
+    o = C.export_points(sd, g8_sample(g), arch, conf_thresh=thr, nms_dist=4, top_k=top_k, subpixel=True)
+    assert (o["views_heatmap"] - t(g["views_heatmap"])).abs().max() < 1e-6
+    assert (o["heatmap"].squeeze() - t(g["aggregate"])).abs().max() < 1e-6
+    assert (sd["bnPb.running_var"] - t(g["bnPb_running_var"])).abs().max() < 1e-5
+    # point extraction on the reference's own aggregate: bit-exact
+    nms = C.get_pts_from_heatmap(g["aggregate"], thr, 4)
+    assert np.array_equal(nms, g["pts_nms"])
+    sub = C.soft_argmax_points(g["aggregate"], nms).transpose()
+    if top_k and sub.shape[0] > top_k:
+        sub = sub[:top_k]
+    assert np.array_equal(sub, g["pts"])
+
+
+def test_nms_fast_edge_cases():
+    """models/model_wrap.py:151-155 (0 / 1 corners), border removal and the all-below-threshold heatmap."""
+    assert C.get_pts_from_heatmap(np.zeros((16, 24), np.float32), 0.015, 4).shape == (3, 0)
+    hm = np.zeros((16, 24), np.float32)
+    hm[8, 10] = 0.5
+    assert np.array_equal(C.get_pts_from_heatmap(hm, 0.015, 4), np.array([[10.0], [8.0], [0.5]]))
+    hm[2, 10] = 0.9  # inside the 4-pixel border: survives NMS (and suppresses nothing here) but is dropped
+    assert np.array_equal(C.get_pts_from_heatmap(hm, 0.015, 4), np.array([[10.0], [8.0], [0.5]]))
+    hm[6, 12] = 0.7  # suppressed by the border point (10, 2) BEFORE that one is dropped, so (10, 8) still survives
+    assert np.array_equal(C.get_pts_from_heatmap(hm, 0.015, 4)[:2].T, np.array([[10.0, 8.0]]))
+    hm[2, 10] = 0.0  # without it (12, 6) wins over (10, 8), which is within Chebyshev distance 4
+    assert np.array_equal(C.get_pts_from_heatmap(hm, 0.015, 4)[:2].T, np.array([[12.0, 6.0]]))
+    hm[:] = np.nan  # 0/0 of combine_heatmap where no view covers a pixel
+    assert C.get_pts_from_heatmap(hm, 0.015, 4).shape == (3, 0)
