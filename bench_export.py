@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench_export.py - images/s of the homography-adaptation export (BASELINE.json
+configs[4]) on N MI355X, one process per GPU, images sharded over ranks with no collective ("weak" scaling).
+
+A step = TWO images (one ssp_export_points call): for each image n_views warped copies + valid masks are produced on
+the device from the resident image (datasets/Coco.py:258-292), the detector head runs over them as one train-mode
+BatchNorm batch, softmax -> depth-to-space, masked un-warp accumulation (export.py:49-60), greedy NMS, soft-argmax
+refinement and top-k (models/model_wrap.py:129-293) -- the body of export.py:274-318 without the file I/O.  The point
+lists stay on the device; one host read of the two counts closes the step (the reference reads the whole heatmap).
+
+`python bench_export.py [--gpus N] [--steps K] [--warmup W] [--height 240 --width 320 --views 100]` prints ONE JSON
+line on rank 0 (same fields as bench.py).  bench.py remains the headline (pair training step) benchmark.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PEAK_FP32_MFMA_TF = 157.3
+GFLOP_FWD_DET_240x320 = 12.1609  # encoder + convPa + convPb of one 240x320 view
+
+
+def cpu_baseline(arch, H, W, views, thr):
+    """The oracle's export_points on ONE image on the host cores (bounded sample)."""
+    import numpy as np
+    import torch
+    from oracle import cpu_ref as C
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    rs = np.random.RandomState(3)
+    v = min(views, 25)  # bounded: the forward dominates and is linear in the number of views
+    img = torch.from_numpy(rs.uniform(0, 1, (H, W)).astype(np.float32))
+    t0 = time.perf_counter()
+    sample = C.homo_adapt_sample(img, v, rs)
+    sd = C.to_torch(C.init_state_dict(arch, seed=0))
+    C.export_points(sd, sample, arch, conf_thresh=np.float32(thr), nms_dist=4, top_k=600, subpixel=True)
+    dt = (time.perf_counter() - t0) * views / v
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle/cpu_ref.py homo_adapt_sample + export_points, %s %dx%d, %d of %d views timed and scaled "
+                      "linearly (%.1f s/image)" % (arch, H, W, v, views, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--arch", default="sp", choices=["sp", "ssp"])
+    ap.add_argument("--views", type=int, default=100)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--thresh", type=float, default=0.0155)  # random-init logits: softmax ~ 1/65 = 0.01538
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also time the stages separately (extra, untimed pass)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_export.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from semantic_superpoint_amd import lib as L
+    from semantic_superpoint_amd import synth
+
+    arch = "SuperPointNet_gauss2" if args.arch == "sp" else "SuperPointNet_gauss2_ssmall"
+    n, H, W = args.views, args.height, args.width
+    eng = L.Engine(arch, n, H, W, dev, with_grad=False)
+    eng.load_state_dict(synth.default_init_state_dict(L.layer_table(arch), seed=0))
+    rs = np.random.RandomState(1000 + rank)
+    g = torch.Generator().manual_seed(1000 + rank)
+    imgs = [torch.rand(H, W, generator=g).to(dev) for _ in range(2)]
+
+    def homographies():
+        hs = np.stack([np.linalg.inv(synth.sample_homography(rs, **synth.WARP_PARAMS)) for _ in range(n)])
+        hs[0] = np.identity(3)
+        hs = torch.from_numpy(hs.astype(np.float32))
+        return hs.to(dev), torch.inverse(hs).contiguous().to(dev)
+
+    hom = [homographies() for _ in range(2)]  # host-side sampling stays outside the timed region (as in the loader)
+    torch.cuda.synchronize()
+
+    def step():
+        vm = [L.op_homoadapt_views(imgs[k], hom[k][1]) for k in range(2)]
+        outs = eng.export_points([v for v, _ in vm], [m for _, m in vm], [hom[k][0] for k in range(2)],
+                                 conf_thresh=args.thresh, nms_dist=4, top_k=600, subpixel=True)
+        return [int(o["count"].item()) for o in outs]  # the host needs the counts to slice the point lists
+
+    for _ in range(args.warmup):
+        counts = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        eng.profile_enable("conv3x3_fwd")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ips = world * 2 * args.steps / dt
+        gf = GFLOP_FWD_DET_240x320 * (H * W) / (240.0 * 320.0) * n
+        out = {"metric": "images/sec, homography-adaptation export (%d views/image, %dx%d)" % (n, H, W),
+               "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s homography-adaptation export, %d views of %dx%d per image, 2 images per step, "
+                                      "threshold %.4f, nms 4, top-k 600, soft-argmax" % (arch, n, H, W, args.thresh),
+                          "parallelism": "images sharded over %d rank(s), no collective" % world},
+               "views_per_s": round(ips * n, 1), "forward_tflops": round(ips * gf / 1e3, 2),
+               "points_last_step": counts}
+        pr = eng.profile_read()
+        if pr["launches"] > 0 and pr["ms"] > 0:
+            ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (3x3 forward)", "achieved": round(ach, 2),
+                               "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TF, 4),
+                               "traffic": None, "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
+                               "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4)}
+        eng.profile_enable("none")
+        if args.stages:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            vm = [L.op_homoadapt_views(imgs[k], hom[k][1]) for k in range(2)]
+            ev[1].record()
+            eng.export_points([v for v, _ in vm], [m for _, m in vm], [hom[k][0] for k in range(2)],
+                              conf_thresh=args.thresh, nms_dist=4, top_k=600, subpixel=True)
+            ev[2].record()
+            torch.cuda.synchronize()
+            out["stage_ms"] = {"views": round(ev[0].elapsed_time(ev[1]), 3),
+                               "export_points": round(ev[1].elapsed_time(ev[2]), 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(arch, H, W, n, args.thresh)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,7 +42,7 @@ struct ConvArgs {
   int Cout, out_cs, out_co;
   int tiles_x, tiles_y;
   int nchunks, ncob;
-  unsigned in_bytes, out_bytes, wpk_bytes;  // sizes for the buffer resource descriptors (clamped to 2^32-1)
+  unsigned in_bytes, out_bytes, wpk_bytes;  // buffer descriptor ranges: in_bytes = bytes of ONE input image
   int ablate;             // perf-debug only (tools/ablate_conv.py): 1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA
 };
 
@@ -192,8 +192,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       const int r = pp / G::WT, c = pp - r * G::WT;                                                      \
       const int gy = ld_ty0 + r - G::PAD, gx = ld_tx0 + c - G::PAD;                                      \
       const bool ok = pp < G::HT * G::WT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
-      hoff[i] = ok ? (unsigned)(((ld_n * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + q4 * 4) * 4u : OOB;  \
+      hoff[i] = ok ? (unsigned)((gy * a.W + gx) * a.in_cs + a.in_co + q4 * 4) * 4u : OOB;                \
     }                                                                                                    \
+    /* one descriptor per image: 32-bit offsets stay inside it whatever the batch size */               \
+    rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in) + (size_t)ld_n * img_floats, 0, \
+                                                a.in_bytes, 0x00020000);                                 \
   }
 #define SSP_ISSUE_LOADS(CHUNK)                                                                          \
   if (!(a.ablate & 1)) {                                                                                \
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 4096, 0)); \
   }
 
-  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in), 0, a.in_bytes, 0x00020000);
+  const size_t img_floats = (size_t)a.H * a.W * a.in_cs;
+  __amdgpu_buffer_rsrc_t rsrc_in;
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
   const bool partial_k = (a.Cin % CK) != 0;  // last K-chunk has channel quads beyond Cin (65/133-channel dY)
 

@@ -118,7 +118,7 @@ struct PointsWork {       // device scratch of one image (ssp_export_workspace_b
   uint8_t* state;         // [H*W] 0 = empty / suppressed, 1 = undecided, 2 = kept
   int32_t* cand[2];       // [H*W] undecided lists (ping-pong)
   uint64_t* keys;         // [cap2] sort keys of the kept points, cap2 = power of two
-  int32_t* counters;      // [0] = number of candidates
+  int32_t* counters;      // [1] = number of kept points inside the border band
 };
 
 enum { ST_EMPTY = 0, ST_UNDECIDED = 1, ST_KEPT = 2 };
@@ -174,27 +174,115 @@ __global__ void soft_argmax_points_kernel(const float* __restrict__ heat, const 
   out[2 * i + 1] = sy;
 }
 
-// state[i] = heat[i] >= thresh (NaN compares false); candidates are appended to cand[0] in arbitrary order
-__global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__ heat, float thresh, PointsWork w, int HW) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= HW) return;
-  const bool c = heat[i] >= thresh;
-  w.state[i] = c ? ST_UNDECIDED : ST_EMPTY;
-  if (c) w.cand[0][atomicAdd(w.counters, 1)] = i;
+__device__ __forceinline__ uint8_t ld_state(const uint8_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_state(uint8_t* p, uint8_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a kept point inside the border band still suppresses its neighbours but is not exported (model_wrap.py:286-292)
+__device__ __forceinline__ void push_kept(const PointsWork& w, int i, int x, int y, float v, int H, int W, int border,
+                                          int cap2) {
+  if (x >= border && x < W - border && y >= border && y < H - border) {
+    const int pos = atomicAdd(w.counters + 1, 1);
+    if (pos < cap2) w.keys[pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+  }
 }
 
-// One block of 1024 threads per heatmap: greedy NMS rounds, border removal, descending bitonic sort, soft-argmax
-// refinement and top-k.  pts: [cap][5] = (x, y, confidence, soft-argmax x in [0,4], soft-argmax y in [0,4]);
-// the host adds (sx - 2, sy - 2) in float64 like models/model_wrap.py:245.  count: number of rows written.
+// state[i] = heat[i] >= thresh (NaN compares false); also clears the sort keys
+__global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__ heat, float thresh, PointsWork w, int HW,
+                                                       int cap2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < cap2) w.keys[i] = 0ull;
+  if (i >= HW) return;
+  w.state[i] = heat[i] >= thresh ? ST_UNDECIDED : ST_EMPTY;
+}
+
+// Tiled rounds: one block per 32x32 tile, one thread per pixel, the tile and a halo of `dist` pixels (values + states)
+// in LDS.  A block iterates until its own candidates are decided; halo candidates belong to neighbouring blocks and
+// are re-read from HBM every pass.  States only ever move UNDECIDED -> {EMPTY, KEPT} and a candidate is decided only
+// once all its higher-priority neighbours are, so stale halo reads merely delay a decision.  A block that makes no
+// progress for `max_idle` passes (its neighbours are not resident) gives up; nms_points_kernel finishes the rest.
+constexpr int NMS_TILE = 32, NMS_MAX_HALO = 8, NMS_PITCH_MAX = NMS_TILE + 2 * NMS_MAX_HALO;
+
+__global__ __launch_bounds__(1024) void nms_tiles_kernel(const float* __restrict__ heat, PointsWork w, int H, int W, int dist,
+                                                         int border, int cap2, int max_idle) {
+  __shared__ float sv[NMS_PITCH_MAX * NMS_PITCH_MAX];
+  __shared__ uint8_t ss[NMS_PITCH_MAX * NMS_PITCH_MAX];
+  __shared__ int pending, progress;
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + NMS_TILE - 1) / NMS_TILE;
+  const int tx0 = (blockIdx.x % tiles_x) * NMS_TILE, ty0 = (blockIdx.x / tiles_x) * NMS_TILE;
+  const int P = NMS_TILE + 2 * dist;
+  for (int k = tid; k < P * P; k += 1024) {
+    const int gy = ty0 - dist + k / P, gx = tx0 - dist + k % P;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    sv[k] = in ? heat[gy * W + gx] : 0.f;
+    ss[k] = in ? ld_state(w.state + gy * W + gx) : (uint8_t)ST_EMPTY;
+  }
+  const int lx = tid & 31, ly = tid >> 5, gx = tx0 + lx, gy = ty0 + ly;
+  const int c = (ly + dist) * P + lx + dist, gi = gy * W + gx;
+  __syncthreads();
+  bool mine = gx < W && gy < H && ss[c] == ST_UNDECIDED;
+  const float v = sv[c];
+  int idle = 0;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) { pending = 0; progress = 0; }
+    __syncthreads();
+    if (mine) {
+      bool kill = false, wait = false;
+      for (int dy = -dist; dy <= dist && !kill; ++dy) {
+        const int row = c + dy * P;
+        for (int dx = -dist; dx <= dist; ++dx) {
+          const uint8_t s = ss[row + dx];
+          if (s == ST_EMPTY || (dy == 0 && dx == 0)) continue;
+          if (s == ST_KEPT) { kill = true; break; }
+          const float vj = sv[row + dx];
+          if (vj > v || (vj == v && (dy < 0 || (dy == 0 && dx < 0)))) wait = true;  // lower row-major index wins ties
+        }
+      }
+      if (kill || !wait) {
+        const uint8_t ns = kill ? ST_EMPTY : ST_KEPT;
+        ss[c] = ns;
+        st_state(w.state + gi, ns);
+        if (!kill) push_kept(w, gi, gx, gy, v, H, W, border, cap2);
+        mine = false;
+        progress = 1;
+      } else {
+        pending = 1;
+      }
+    }
+    __syncthreads();
+    if (!pending) break;
+    for (int k = tid; k < P * P; k += 1024) {
+      const int py = k / P, px = k % P;
+      if (py >= dist && py < dist + NMS_TILE && px >= dist && px < dist + NMS_TILE) continue;  // interior: ours
+      if (ss[k] != ST_UNDECIDED) continue;
+      const uint8_t s = ld_state(w.state + (ty0 - dist + py) * W + tx0 - dist + px);
+      if (s != ST_UNDECIDED) { ss[k] = s; progress = 1; }
+    }
+    __syncthreads();
+    if (progress) idle = 0;
+    else if (++idle > max_idle) break;
+  }
+}
+
+// One block of 1024 threads per heatmap: finishes whatever the tiled rounds left undecided (everything when
+// dist > NMS_MAX_HALO), then border removal, descending bitonic sort, soft-argmax refinement and top-k.
+// pts: [cap][5] = (x, y, confidence, soft-argmax x in [0,4], soft-argmax y in [0,4]); the host adds (sx - 2, sy - 2)
+// in float64 like models/model_wrap.py:245.  count: number of rows written.
 __global__ __launch_bounds__(1024) void nms_points_kernel(const float* __restrict__ heat, PointsWork w, int H, int W,
                                                           int dist, int border, int top_k, int subpixel, int cap,
                                                           int cap2, float* __restrict__ pts, int32_t* __restrict__ count) {
-  __shared__ int n_next, n_kept;
+  __shared__ int n_next;
   const int tid = threadIdx.x;
-  volatile uint8_t* state = w.state;
-  int n = w.counters[0];
-  if (tid == 0) n_kept = 0;
-  for (int i = tid; i < cap2; i += 1024) w.keys[i] = 0ull;
+  if (tid == 0) n_next = 0;
+  __syncthreads();
+  for (int i = tid; i < H * W; i += 1024)
+    if (ld_state(w.state + i) == ST_UNDECIDED) w.cand[0][atomicAdd(&n_next, 1)] = i;
+  __syncthreads();
+  int n = n_next;
   int cur = 0;
   __syncthreads();
   while (n > 0) {
@@ -211,7 +299,7 @@ __global__ __launch_bounds__(1024) void nms_points_kernel(const float* __restric
       for (int yy = y0; yy <= y1 && !kill; ++yy) {
         for (int xx = x0; xx <= x1; ++xx) {
           const int j = yy * W + xx;
-          const uint8_t s = state[j];
+          const uint8_t s = ld_state(w.state + j);
           if (s == ST_EMPTY || j == i) continue;
           if (s == ST_KEPT) { kill = true; break; }
           const float vj = heat[j];
@@ -219,13 +307,10 @@ __global__ __launch_bounds__(1024) void nms_points_kernel(const float* __restric
         }
       }
       if (kill) {
-        state[i] = ST_EMPTY;
+        st_state(w.state + i, ST_EMPTY);
       } else if (!wait) {
-        state[i] = ST_KEPT;
-        if (x >= border && x < W - border && y >= border && y < H - border) {
-          const int pos = atomicAdd(&n_kept, 1);
-          if (pos < cap2) w.keys[pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
-        }
+        st_state(w.state + i, ST_KEPT);
+        push_kept(w, i, x, y, v, H, W, border, cap2);
       } else {
         nl[atomicAdd(&n_next, 1)] = i;
       }
@@ -235,6 +320,8 @@ __global__ __launch_bounds__(1024) void nms_points_kernel(const float* __restric
     cur ^= 1;
     __syncthreads();
   }
+  __threadfence();
+  const int n_kept = __hip_atomic_load(w.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // descending sort: confidence (positive floats order like their bit patterns), then ascending pixel index
   int p2 = 1;
   const int nk = min(n_kept, cap2);

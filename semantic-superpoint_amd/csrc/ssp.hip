@@ -300,11 +300,17 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   a.nprob = c.nprob; a.in2 = c.in2; a.out2 = c.out2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
   a.stats2 = c.stats2;
   {
-    auto clampu = [](double v) { return v > 4294967295.0 ? 4294967295u : (unsigned)v; };
-    const double in_px = (double)c.N * c.H * c.W * (c.in_mode == 2 ? 4 : 1);
-    a.in_bytes = clampu(in_px * c.in_cs * 4.0);
-    a.out_bytes = clampu((double)c.N * c.H * c.W * c.out_cs * 4.0);
-    a.wpk_bytes = clampu((double)c.ncob * c.nchunks * c.ks * c.ks * CK * NB * 4.0);
+    // the input is read through one buffer descriptor PER IMAGE (32-bit byte offsets inside it); element indices of
+    // whole tensors are 32-bit in the element-wise kernels
+    const double in_img = (double)c.H * c.W * (c.in_mode == 2 ? 4 : 1) * c.in_cs * 4.0;
+    const double in_el = (double)c.N * c.H * c.W * (c.in_mode == 2 ? 4 : 1) * c.in_cs;
+    const double out_el = (double)c.N * c.H * c.W * c.out_cs;
+    if (in_img > 2147483647.0 || in_el > 2147483647.0 || out_el > 2147483647.0)
+      return fail(-3, "conv tensor [%d,%d,%d,%d] exceeds 2^31 elements: lower the batch", c.N, c.H, c.W,
+                  std::max(c.in_cs, c.out_cs));
+    a.in_bytes = (unsigned)in_img;
+    a.out_bytes = (unsigned)(out_el * 4.0 > 4294967295.0 ? 4294967295.0 : out_el * 4.0);
+    a.wpk_bytes = (unsigned)((double)c.ncob * c.nchunks * c.ks * c.ks * CK * NB * 4.0);
   }
   a.ablate = g_dbg_ablate;
   const bool wide = (c.W % 32) == 0;
@@ -435,7 +441,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   if (cfg->arch != SSP_ARCH_GAUSS2 && cfg->arch != SSP_ARCH_GAUSS2_SSMALL) return fail(-1, "unknown arch %d", cfg->arch);
   if (cfg->height % 8 || cfg->width % 8 || cfg->height <= 0 || cfg->width <= 0)
     return fail(-1, "height/width must be positive multiples of 8 (got %dx%d)", cfg->height, cfg->width);
-  if (cfg->max_batch < 1 || cfg->max_batch > 64) return fail(-1, "max_batch must be in 1..64");
+  if (cfg->max_batch < 1 || cfg->max_batch > 1024) return fail(-1, "max_batch must be in 1..1024");
   if (cfg->arch == SSP_ARCH_GAUSS2_SSMALL && cfg->n_classes > 192) return fail(-1, "n_classes must be <= 192");
   ssp_handle* h = new ssp_handle();
   h->cfg = *cfg;
@@ -866,7 +872,8 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   if (!in || !scalars_dev) return fail(-1, "null argument");
   if (in->train && !h->buf.grads_dev) return fail(-1, "train step needs a gradient buffer");
   const int B = in->batch, H = h->cfg.height, W = h->cfg.width, Hc = H / 8, Wc = W / 8;
-  if (B < 1 || B > h->cfg.max_batch) return fail(-1, "batch %d out of range", B);
+  if (B < 1 || B > h->cfg.max_batch || B > 64)
+    return fail(-1, "pair-step batch %d out of range (1..min(max_batch, 64))", B);
   const bool semantic = h->nheads == 3;
   if (semantic && (!in->semantic_dev || !in->warped_semantic_dev)) return fail(-1, "semantic labels required for the ssmall model");
   const bool use_desc = in->lambda_loss > 0.f;
@@ -1107,7 +1114,12 @@ static int heatmap_points(const float* heat, const ssp_export_params* p, const P
                           hipStream_t st) {
   const int hw = p->height * p->width;
   HIPCHK(hipMemsetAsync(pw.counters, 0, 16 * sizeof(int32_t), st));
-  hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, st, heat, p->conf_thresh, pw, hw);
+  const int cap2 = export_cap2(p);
+  hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(std::max(hw, cap2), 256)), dim3(256), 0, st, heat, p->conf_thresh, pw, hw,
+                     cap2);
+  if (p->nms_dist <= NMS_MAX_HALO)
+    hipLaunchKernelGGL(nms_tiles_kernel, dim3(cdiv(p->width, NMS_TILE) * cdiv(p->height, NMS_TILE)), dim3(1024), 0, st,
+                       heat, pw, p->height, p->width, p->nms_dist, p->border_remove, cap2, 512);
   hipLaunchKernelGGL(nms_points_kernel, dim3(1), dim3(1024), 0, st, heat, pw, p->height, p->width, p->nms_dist,
                      p->border_remove, p->top_k, p->subpixel, export_cap(p), export_cap2(p), pts, count);
   HIPCHK(hipGetLastError());
