@@ -196,6 +196,17 @@ int ssp_op_heatmap_points(const float* heat_dev, const ssp_export_params* p, voi
 int ssp_op_soft_argmax_points(const float* heat_dev, const float* xy_dev, float* out_dev, int n, int h, int w,
                               void* stream);
 
+/* ---- logging branch of train_val_sample (Train_model_heatmap_all.py:447-568) ------
+ * ssp_detector_heatmap: get_heatmap (Train_model_frontend_all.py:664-669) = flattenDetection of the detector logits
+ *                       of the last forward / pair step in `slot` (0 = image, 1 = warped image) -> heat [n,h,w].
+ * ssp_op_heatmap_nms  : heatmap_to_nms / heatmap_nms (Train_model_heatmap_all.py:574-587,693-707) for n_maps heatmaps
+ *                       [n_maps,h,w] (p->top_k / subpixel / n_views ignored) and batch_precision_recall's terms
+ *                       (:614-622, utils/utils.py:929-941): nms_map_dev [n_maps,h,w] 0/1 (optional),
+ *                       pr_dev [n_maps][2] = (precision, recall) against labels_dev [n_maps,h,w] (both optional). */
+int ssp_detector_heatmap(ssp_handle* h, int slot, float* heat_dev, void* stream);
+int ssp_op_heatmap_nms(const float* heat_dev, const ssp_export_params* p, int n_maps, void* workspace_dev,
+                       const float* labels_dev, float* nms_map_dev, float* pr_dev, void* stream);
+
 /* BatchNorm2d(train) (+ReLU (+MaxPool2d(2))) backward. y: raw conv output NHWC; dout: gradient wrt the activated
  * (and pooled) output; stats4 = scale|shift|mean|invstd ([4*C]); dgamma/dbeta/dbias are accumulated;
  * sums_dev: double [SSP_NREP][2*C] scratch. */

@@ -691,3 +691,28 @@ def export_points(sd, sample, arch="SuperPointNet_gauss2", conf_thresh=0.015, nm
     if top_k and pts.shape[0] > top_k:
         pts = pts[:top_k]
     return {"heatmap": agg, "views_heatmap": heat, "pts": pts}
+
+
+# --------------------------------------------------------------------------------------
+# Logging branch of train_val_sample: Train_model_heatmap_all.py:447-568
+# --------------------------------------------------------------------------------------
+def heatmap_nms(heatmap, nms_dist=4, conf_thresh=0.015):
+    """Train_model_heatmap_all.py:693-707 (+ utils/utils.py:581-609): 0/1 map of the NMS survivors."""
+    hm = np.asarray(heatmap, dtype=np.float32).squeeze()
+    pts = get_pts_from_heatmap(hm, np.float32(conf_thresh), nms_dist, border_remove=4)
+    out = np.zeros_like(hm)
+    out[pts[1].astype(int), pts[0].astype(int)] = 1
+    return out
+
+
+def precision_recall(pred, labels):
+    """utils/utils.py:929-941 precisionRecall_torch."""
+    tp = torch.sum(pred * labels)
+    return {"precision": tp / (torch.sum(pred) + 1e-6), "recall": tp / (torch.sum(labels) + 1e-6)}
+
+
+def batch_precision_recall(batch_pred, batch_labels):
+    """Train_model_heatmap_all.py:614-622: per-image precision / recall, averaged over the batch."""
+    prs = [precision_recall(batch_pred[i], batch_labels[i]) for i in range(batch_labels.shape[0])]
+    return {"precision": float(np.mean([float(p["precision"]) for p in prs])),
+            "recall": float(np.mean([float(p["recall"]) for p in prs]))}

@@ -402,11 +402,36 @@ def g8_export():
                             pts_nms=pts_nms, pts=pts, bnPb_running_var=npy(rsd["bnPb.running_var"]))
 
 
+def g9_logging():
+    """heatmap_to_nms + batch_precision_recall of the logging branch (Train_model_heatmap_all.py:574-622,693-707)."""
+    R.install()
+    import Train_model_heatmap_all as T
+    from utils.utils import flattenDetection
+    rs = np.random.RandomState(77)
+    B, H, W = 3, 64, 96
+    semi = torch.from_numpy((2.0 * rs.randn(B, 65, H // 8, W // 8)).astype(np.float32))
+    heat = flattenDetection(semi)
+    close(C.flatten_detection(semi), heat, 1e-7, "G9 heatmap")
+    labels = torch.from_numpy((rs.uniform(size=(B, 1, H, W)) < 0.02).astype(np.float32))
+    # make the labels overlap the detections so that precision / recall are not trivially ~0
+    nms_ref = np.stack([T.Train_model_heatmap_all.heatmap_nms(h) for h in npy(heat)])
+    labels[:, 0][torch.from_numpy(nms_ref).bool() & torch.from_numpy(rs.uniform(size=(B, H, W)) < 0.5)] = 1
+    pr_ref = T.Train_model_heatmap_all.batch_precision_recall(torch.from_numpy(nms_ref[:, None]).float(), labels)
+    nms_o = np.stack([C.heatmap_nms(h) for h in npy(heat)])
+    assert np.array_equal(nms_o, nms_ref), "G9 nms map"
+    pr_o = C.batch_precision_recall(torch.from_numpy(nms_o[:, None]), labels)
+    close(pr_o["precision"], float(pr_ref["precision"]), 1e-7, "G9 precision")
+    close(pr_o["recall"], float(pr_ref["recall"]), 1e-7, "G9 recall")
+    np.savez_compressed(os.path.join(OUT, "g9_logging.npz"), semi=npy(semi), heat=npy(heat), labels=npy(labels),
+                        nms=nms_ref.astype(np.uint8), precision=float(pr_ref["precision"]),
+                        recall=float(pr_ref["recall"]))
+
+
 def main():
     assert R.available(), "reference not mounted"
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export):
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging):
         fn()
         print(fn.__name__, "done")
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

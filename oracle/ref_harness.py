@@ -55,6 +55,9 @@ def install():
         raise RuntimeError("reference not present at %s" % REF_ROOT)
     if not hasattr(collections, "Mapping"):  # utils/tools.py:18 uses the py<3.10 alias
         collections.Mapping = collections.abc.Mapping
+    import numpy as _np
+    if not hasattr(_np, "int"):  # Train_model_heatmap_all.py:706 uses the alias numpy removed in 1.24
+        _np.int = int
     if "cv2" not in sys.modules:
         _stub("cv2", __version__="0.0-stub")
     if "torchvision" not in sys.modules:

@@ -201,8 +201,20 @@ class Train_model_heatmap_all(object):
                             "negative_dist": s["negative_dist"]}
         if cfg["data"].get("semantic", False):
             self.scalar_dict["eta_sem"] = eta[2]
+        if n_iter % cfg["tensorboard_interval"] == 0 or task == "val":
+            self.log_precision_recall(eng, dev, B, H, W)
         self.tb_scalar_dict(self.scalar_dict, task)
         return float(s["loss"])
+
+    def log_precision_recall(self, eng, dev, B, H, W):
+        """Logging branch (Train_model_heatmap_all.py:447-568): flattenDetection of the un-warped view's logits,
+        heatmap_nms with its hard-wired defaults (nms_dist=4, conf_thresh=0.015: :693 ignores the config),
+        batch_precision_recall against labels_2D (:614-622).  The tensorboard image overlays are not produced."""
+        heat = eng.detector_heatmap(0, B, H, W)
+        nms, pr = L.op_heatmap_nms(heat, dev["labels_2D"].float().contiguous(), conf_thresh=0.015, nms_dist=4)
+        prm = pr.cpu().numpy().mean(axis=0)
+        self.scalar_dict.update({"precision": float(prm[0]), "recall": float(prm[1])})
+        self.images_dict = {"heatmap_org_nms_batch": nms.unsqueeze(1)}
 
     def tb_scalar_dict(self, losses, task="training"):
         if self._writer is None:

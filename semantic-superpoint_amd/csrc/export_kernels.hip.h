@@ -357,4 +357,36 @@ __global__ __launch_bounds__(1024) void nms_points_kernel(const float* __restric
   if (tid == 0) *count = nout;
 }
 
+// Logging branch of train_val_sample (Train_model_heatmap_all.py:447-568): heatmap_nms (:693-707) turns the kept
+// points into a 0/1 map, precisionRecall_torch (utils/utils.py:929-941) compares it with the label map:
+//   precision = sum(pred * labels) / (sum(pred) + 1e-6), recall = sum(pred * labels) / (sum(labels) + 1e-6).
+// One block per image.  nms_map (optional) must be zero-filled; pts/count come from nms_points_kernel.
+__global__ __launch_bounds__(256) void nms_map_pr_kernel(const float* __restrict__ pts, const int32_t* __restrict__ count,
+                                                         const float* __restrict__ labels, float* __restrict__ nms_map,
+                                                         float* __restrict__ pr, int H, int W) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, n = *count;
+  float tp = 0.f, nl = 0.f;
+  for (int r = tid; r < n; r += 256) {
+    const int x = (int)pts[r * 5], y = (int)pts[r * 5 + 1];
+    if (nms_map) nms_map[y * W + x] = 1.f;
+    if (labels) tp += labels[y * W + x];
+  }
+  if (labels)
+    for (int i = tid; i < H * W; i += 256) nl += labels[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    tp += __shfl_xor(tp, o);
+    nl += __shfl_xor(nl, o);
+  }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = tp; red[1][tid >> 6] = nl; }
+  __syncthreads();
+  if (tid == 0 && pr) {
+    tp = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    nl = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    pr[0] = tp / ((float)n + 1e-6f);
+    pr[1] = tp / (nl + 1e-6f);
+  }
+}
+
 }  // namespace sspk

@@ -1053,7 +1053,8 @@ static int export_check(const ssp_export_params* p) {
   return 0;
 }
 struct ExportWs {
-  float *heat, *agg;
+  float *heat, *agg, *pts;
+  int32_t* count;
   PointsWork pw;
   size_t bytes;
 };
@@ -1068,6 +1069,8 @@ static ExportWs export_carve(const ssp_export_params* p, void* base) {
   w.pw.cand[1] = c.take<int32_t>(hw);
   w.pw.keys = c.take<uint64_t>(export_cap2(p));
   w.pw.counters = c.take<int32_t>(16);
+  w.pts = c.take<float>((size_t)export_cap(p) * 5);
+  w.count = c.take<int32_t>(16);
   w.bytes = align_up(c.off, 256);
   return w;
 }
@@ -1131,6 +1134,39 @@ int ssp_op_heatmap_points(const float* heat_dev, const ssp_export_params* p, voi
   CHK(export_check(p));
   if (!heat_dev || !workspace_dev || !pts_dev || !count_dev) return fail(-1, "heatmap_points: null pointer");
   return heatmap_points(heat_dev, p, export_carve(p, workspace_dev).pw, pts_dev, count_dev, (hipStream_t)stream);
+}
+
+int ssp_op_heatmap_nms(const float* heat_dev, const ssp_export_params* p, int n_maps, void* workspace_dev,
+                       const float* labels_dev, float* nms_map_dev, float* pr_dev, void* stream) {
+  CHK(export_check(p));
+  if (!heat_dev || !workspace_dev || n_maps < 1) return fail(-1, "heatmap_nms: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  ssp_export_params q = *p;
+  q.top_k = 0; q.subpixel = 0;
+  const ExportWs w = export_carve(&q, workspace_dev);
+  const size_t hw = (size_t)p->height * p->width;
+  if (nms_map_dev) HIPCHK(hipMemsetAsync(nms_map_dev, 0, hw * n_maps * sizeof(float), st));
+  for (int k = 0; k < n_maps; ++k) {
+    CHK(heatmap_points(heat_dev + k * hw, &q, w.pw, w.pts, w.count, st));
+    hipLaunchKernelGGL(nms_map_pr_kernel, dim3(1), dim3(256), 0, st, w.pts, w.count,
+                       labels_dev ? labels_dev + k * hw : nullptr, nms_map_dev ? nms_map_dev + k * hw : nullptr,
+                       pr_dev ? pr_dev + 2 * k : nullptr, p->height, p->width);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_detector_heatmap(ssp_handle* h, int slot, float* heat_dev, void* stream) {
+  if (!h || !h->bound) return fail(-1, "handle not bound");
+  if (slot < 0 || slot > 1 || !heat_dev) return fail(-1, "detector_heatmap: bad argument");
+  Slot& S = h->slot[slot];
+  if (S.N <= 0) return fail(-1, "detector_heatmap: slot %d holds no forward", slot);
+  const int Hc = S.H / 8, Wc = S.W / 8, ncells = S.N * Hc * Wc;
+  hipLaunchKernelGGL(flatten_detection_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, (hipStream_t)stream, S.Y[L_PB],
+                     S.bn[L_PB].scale, S.bn[L_PB].shift, (const float*)nullptr, heat_dev, ncells, Hc, Wc,
+                     (long)Hc * Wc * S.y_cs[L_PB], (long)S.y_cs[L_PB], 1L);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int ssp_op_soft_argmax_points(const float* heat_dev, const float* xy_dev, float* out_dev, int n, int hh, int w,

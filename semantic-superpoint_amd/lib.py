@@ -54,7 +54,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
            "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
            "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
-           "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points"]
+           "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms"]
 
 
 def load_library(path=None):
@@ -105,6 +105,8 @@ def load_library(path=None):
     lib.ssp_op_combine_heatmap.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_heatmap_points.argtypes = [vp, ep, vp, vp, vp, vp]
     lib.ssp_op_soft_argmax_points.argtypes = [vp, vp, vp, i, i, i, vp]
+    lib.ssp_detector_heatmap.argtypes = [vp, i, vp, vp]
+    lib.ssp_op_heatmap_nms.argtypes = [vp, ep, i, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -379,6 +381,13 @@ class Engine:
                                               arr(self._export_ws[:k]), arr(hm), arr(pts), arr(cnt), _stream()))
         return [{"pts": pts[j], "count": cnt[j], "heatmap": hm[j]} for j in range(k)]
 
+    def detector_heatmap(self, slot, n, hh, ww):
+        """flattenDetection of the detector logits left in `slot` by the last forward / pair step -> [n,1,hh,ww]."""
+        out = torch.empty(n, 1, hh, ww, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ssp_detector_heatmap(self.h, slot, _ptr(out), _stream()))
+        return out
+
     def debug_buffer(self, slot, name, shape):
         """Test hook: copy of an internal NHWC buffer as a torch tensor of `shape`."""
         p, n = C.c_void_p(), C.c_size_t()
@@ -564,6 +573,27 @@ def op_heatmap_points(heatmap, conf_thresh, nms_dist=4, border_remove=4, top_k=0
     with torch.cuda.device(heatmap.device):
         _check(lib.ssp_op_heatmap_points(_ptr(heatmap), C.byref(p), _ptr(ws), _ptr(pts), _ptr(cnt), _stream()))
     return points_to_numpy(pts, cnt, subpixel)
+
+
+def op_heatmap_nms(heat, labels=None, conf_thresh=0.015, nms_dist=4, border_remove=4, want_map=True):
+    """heatmap_to_nms + the per-image terms of batch_precision_recall on the device.  heat, labels: [B,1,H,W] (or
+    [B,H,W]).  Returns (nms_map [B,H,W] or None, pr [B,2] = (precision, recall) or None) as device tensors."""
+    lib = load_library()
+    _need_gpu(heat, "heat")
+    B, (H, W) = heat.shape[0], heat.shape[-2:]
+    p = SspExportParams(1, H, W, float(np.float32(conf_thresh)), int(nms_dist), int(border_remove), 0, 0)
+    wsb = lib.ssp_export_workspace_bytes(C.byref(p))
+    if wsb == 0:
+        _check(-1)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=heat.device)
+    if labels is not None:
+        _need_gpu(labels, "labels")
+        assert labels.numel() == heat.numel() and labels.dtype == torch.float32
+    nms = torch.empty(B, H, W, dtype=torch.float32, device=heat.device) if want_map else None
+    pr = torch.empty(B, 2, dtype=torch.float32, device=heat.device) if labels is not None else None
+    with torch.cuda.device(heat.device):
+        _check(lib.ssp_op_heatmap_nms(_ptr(heat), C.byref(p), B, _ptr(ws), _ptr(labels), _ptr(nms), _ptr(pr), _stream()))
+    return nms, pr
 
 
 def op_soft_argmax_points(heatmap, xy):

@@ -236,3 +236,57 @@ def test_export_refuses_bad_arguments():
         e.export_points([v], [v], [torch.eye(3, device=dev).repeat(6, 1, 1)])
     with pytest.raises(RuntimeError):  # host tensors: no CPU fallback
         e.export_points([v.cpu()[:4]], [v.cpu()[:4]], [torch.eye(3).repeat(4, 1, 1)])
+
+
+def test_logging_branch_nms_map_and_precision_recall():
+    """heatmap_to_nms + batch_precision_recall against the reference's G9 arrays."""
+    from semantic_superpoint_amd import lib as L
+    g = G.load("g9_logging.npz")
+    dev = _dev()
+    heat = L.op_flatten_detection(t(g["semi"]).to(dev))
+    assert (heat.cpu() - t(g["heat"])).abs().max() < 1e-6
+    nms, pr = L.op_heatmap_nms(t(g["heat"]).to(dev), t(g["labels"]).to(dev))
+    assert np.array_equal(nms.cpu().numpy(), g["nms"].astype(np.float32))
+    prm = pr.cpu().numpy().mean(axis=0)
+    assert abs(prm[0] - float(g["precision"])) < 1e-6 and abs(prm[1] - float(g["recall"])) < 1e-6
+    nms2, none = L.op_heatmap_nms(t(g["heat"]).to(dev))
+    assert none is None and torch.equal(nms2, nms)
+
+
+def test_trainer_logs_precision_recall():
+    """The drop-in trainer's logging branch: precision / recall of the un-warped view vs the oracle on the same step."""
+    from semantic_superpoint_amd.Train_model_heatmap_all import Train_model_heatmap_all
+    dev = _dev()
+    B, H, W = 2, 64, 96
+    cfg = {"data": {"dataset": "Coco", "semantic": False, "gaussian_label": {"enable": False},
+                    "warped_pair": {"enable": True}},
+           "model": {"name": "SuperPointNet_gauss2", "params": {}, "batch_size": B, "real_batch_size": B,
+                     "learning_rate": 1e-3, "lambda_loss": 1, "multi_task_loss": True,
+                     "sparse_loss": {"enable": True, "params": {"num_matching_attempts": 1000,
+                                                                "num_masked_non_matches_per_match": 100,
+                                                                "lamda_d": 1, "dist": "cos", "method": "2d"}}},
+           "retrain": True, "reset_iter": True, "train_iter": 10, "validation_interval": 5, "tensorboard_interval": 2,
+           "save_interval": 100, "ssp_sampler": "reference"}
+    agent = Train_model_heatmap_all(cfg, device=dev)
+    agent.loadModel()
+    sd = C.init_state_dict("SuperPointNet_gauss2", seed=4)
+    agent.net.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    agent.dataParallel()
+    sample = C.make_synthetic_pair(B, H, W, seed=8)
+    agent.train_val_sample(sample, n_iter=1, train=True)
+    assert "precision" not in agent.scalar_dict  # 1 % tensorboard_interval != 0
+    state = {k: v.detach().cpu().clone() for k, v in agent.net.state_dict().items()}
+    agent.train_val_sample(sample, n_iter=2, train=True)
+    assert {"precision", "recall"} <= set(agent.scalar_dict)
+    # oracle: forward of the un-warped view with the weights the step started from (train-mode BatchNorm)
+    with torch.no_grad():
+        semi = C.forward(C.to_torch(state), sample["image"], "SuperPointNet_gauss2", train=True)["semi"]
+    heat = C.flatten_detection(semi).numpy()
+    nms = np.stack([C.heatmap_nms(h) for h in heat])
+    mine = agent.images_dict["heatmap_org_nms_batch"].cpu().numpy()[:, 0]
+    assert float((mine != nms).mean()) < 2e-3  # fp32 noise at the 0.015 threshold / near-ties may flip a few points
+    pr = C.batch_precision_recall(t(nms[:, None]), sample["labels_2D"])
+    assert abs(agent.scalar_dict["precision"] - pr["precision"]) < 0.02
+    assert abs(agent.scalar_dict["recall"] - pr["recall"]) < 0.02
+    agent.train_val_sample(sample, n_iter=3, train=False)  # validation always logs
+    assert {"precision", "recall"} <= set(agent.scalar_dict)

@@ -197,3 +197,14 @@ def test_nms_fast_edge_cases():
     assert np.array_equal(C.get_pts_from_heatmap(hm, 0.015, 4)[:2].T, np.array([[12.0, 6.0]]))
     hm[:] = np.nan  # 0/0 of combine_heatmap where no view covers a pixel
     assert C.get_pts_from_heatmap(hm, 0.015, 4).shape == (3, 0)
+
+
+def test_g9_logging_branch():
+    """heatmap_to_nms + batch_precision_recall (Train_model_heatmap_all.py:574-622,693-707) vs the reference."""
+    g = G.load("g9_logging.npz")
+    heat = C.flatten_detection(t(g["semi"]))
+    assert (heat - t(g["heat"])).abs().max() < 1e-7
+    nms = np.stack([C.heatmap_nms(h) for h in g["heat"]])
+    assert np.array_equal(nms, g["nms"].astype(np.float32))
+    pr = C.batch_precision_recall(t(nms[:, None]), t(g["labels"]))
+    assert abs(pr["precision"] - float(g["precision"])) < 1e-7 and abs(pr["recall"] - float(g["recall"])) < 1e-7
