@@ -15,6 +15,7 @@
 
 #include "bn_kernels.hip.h"
 #include "conv_mfma.hip.h"
+#include "conv_wino.hip.h"
 #include "loss_kernels.hip.h"
 #include "pair_kernels.hip.h"
 #include "export_kernels.hip.h"
@@ -24,6 +25,10 @@ using namespace sspk;
 
 static thread_local std::string g_err;
 static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_kernel (tools/ablate_conv.py)
+static int g_conv_algo = 1;  // ssp_set_conv_algo: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) where eligible
+// 3x3 convolutions whose input channels fill whole 16-channel K-chunks run as Winograd F(2x2,3x3)
+static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo == 1 && ks == 3 && conv_cin % CK == 0; }
+static inline int pk_taps(int ks) { return ks == 3 ? WC : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
 static int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -148,8 +153,9 @@ static void build_layers(ssp_handle* h) {
     const int taps = d.ks * d.ks;
     d.nchunks_fwd = cdiv(d.cin, CK); d.ncob_fwd = cdiv(d.cout, NB);
     d.nchunks_bwd = cdiv(d.cout, CK); d.ncob_bwd = cdiv(d.cin, NB);
-    d.pk_fwd = pf; pf += (size_t)d.ncob_fwd * d.nchunks_fwd * taps * CK * NB;
-    d.pk_bwd = pb; pb += (size_t)d.ncob_bwd * d.nchunks_bwd * taps * CK * NB;
+    (void)taps;
+    d.pk_fwd = pf; pf += (size_t)d.ncob_fwd * d.nchunks_fwd * pk_taps(d.ks) * CK * NB;
+    d.pk_bwd = pb; pb += (size_t)d.ncob_bwd * d.nchunks_bwd * pk_taps(d.ks) * CK * NB;
   }
   h->n_params = off; h->n_bn_ch = bnch; h->n_bn = nbn;
 }
@@ -182,12 +188,12 @@ static size_t carve(ssp_handle* h, void* base) {
   size_t pf = 0, pb = 0;
   for (int i = 0; i < h->nlayers; ++i) {
     const LayerDesc& d = h->L[i];
-    pf = d.pk_fwd + (size_t)d.ncob_fwd * d.nchunks_fwd * d.ks * d.ks * CK * NB;
-    pb = d.pk_bwd + (size_t)d.ncob_bwd * d.nchunks_bwd * d.ks * d.ks * CK * NB;
+    pf = d.pk_fwd + (size_t)d.ncob_fwd * d.nchunks_fwd * pk_taps(d.ks) * CK * NB;
+    pb = d.pk_bwd + (size_t)d.ncob_bwd * d.nchunks_bwd * pk_taps(d.ks) * CK * NB;
   }
   h->wpk_fwd = c.take<float>(pf);
   h->wpk_bwd = c.take<float>(pb);
-  h->wpk_heads_bwd = c.take<float>((size_t)2 * 16 * h->nheads * 9 * CK * NB);
+  h->wpk_heads_bwd = c.take<float>((size_t)2 * 16 * h->nheads * WC * CK * NB);
   for (int s = 0; s < 2; ++s) {
     Slot& S = h->slot[s];
     for (int l = 0; l < 8; ++l) {
@@ -290,7 +296,21 @@ struct ConvCall {
   int nprob = 1;
   const float* in2 = nullptr; float* out2 = nullptr;
   const float* in_scale2 = nullptr; const float* in_shift2 = nullptr; double* stats2 = nullptr;
+  bool wino = false;  // wpk holds pack_weights_wino_kernel's image: run conv_wino_kernel
 };
+
+template <int IN_MODE, bool WIDE>
+static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_wino_kernel<IN_MODE, WIDE>;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), WINO_LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 
 static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int prof_family = 0) {
   ConvArgs a;
@@ -310,15 +330,16 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
                   std::max(c.in_cs, c.out_cs));
     a.in_bytes = (unsigned)in_img;
     a.out_bytes = (unsigned)(out_el * 4.0 > 4294967295.0 ? 4294967295.0 : out_el * 4.0);
-    a.wpk_bytes = (unsigned)((double)c.ncob * c.nchunks * c.ks * c.ks * CK * NB * 4.0);
+    a.wpk_bytes = (unsigned)((double)c.ncob * c.nchunks * (c.wino ? WC : c.ks * c.ks) * CK * NB * 4.0);
   }
   a.ablate = g_dbg_ablate;
   const bool wide = (c.W % 32) == 0;
   const int TH = wide ? 8 : 32, TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
-  // persistent grid: 2 blocks per CU (LDS-limited residency), a multiple of 8 (one slot set per XCD)
+  // persistent grid: 2 blocks per CU (LDS-limited residency; Winograd: 1), a multiple of 8 (one slot set per XCD)
   const int n_cu = h ? h->n_cu : 256;
-  int nblocks = std::max(8, (2 * n_cu) / 8 * 8);
+  if (c.wino && (c.ks != 3 || c.in_mode == 2 || c.cin % CK)) return fail(-3, "Winograd conv needs ks 3, Cin %% 16 == 0");
+  int nblocks = std::max(8, ((c.wino ? 1 : 2) * n_cu) / 8 * 8);
   if (g_dbg_grid > 0) nblocks = g_dbg_grid;  // perf-debug only (ssp_debug_conv_knobs)
   if ((nblocks / 8) < c.ncob) return fail(-3, "too many output-channel blocks (%d) for the persistent grid", c.ncob);
   const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
@@ -328,6 +349,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
       c.cin == 64)
     fam = SSP_PROF_CONV_BIG_FWD;
   ProfScope ps(h, fam, st, flops, bytes);
+  if (c.wino) {
+    if (c.in_mode == 0) return wide ? launch_wino_t<0, true>(a, nblocks, st) : launch_wino_t<0, false>(a, nblocks, st);
+    return wide ? launch_wino_t<1, true>(a, nblocks, st) : launch_wino_t<1, false>(a, nblocks, st);
+  }
 #define CONV_CASE(KS_, M_)                                                          \
   if (c.ks == KS_ && c.in_mode == M_) {                                             \
     return wide ? launch_conv_t<KS_, M_, 1, 32>(a, nblocks, st) : launch_conv_t<KS_, M_, 4, 8>(a, nblocks, st); \
@@ -402,10 +427,17 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   return 0;
 }
 
-static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, hipStream_t st) {
+static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino, hipStream_t st) {
   const int taps = ks * ks;
   const int conv_cin = tf ? cout_w : cin_w, conv_cout = tf ? cin_w : cout_w;
   const int nchunks = cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
+  if (wino) {
+    const int total = ncob * nchunks * WB_FLOATS;
+    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
+                       nchunks, 0, 0, ncob, nchunks);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   const int total = ncob * nchunks * taps * CK * NB;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, ks, tf,
                      nchunks, 0, 0, ncob, nchunks);
@@ -541,15 +573,21 @@ static int bn_finalize(ssp_handle* h, Slot& S, int l, double count, int train, h
 static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
   for (int l = 1; l < h->nlayers; ++l) {
     const LayerDesc& d = h->L[l];
-    CHK(launch_pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, st));
-    if (with_bwd) CHK(launch_pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, st));
+    CHK(launch_pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wino_ok(d.ks, d.cin), st));
+    if (with_bwd)
+      CHK(launch_pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wino_ok(d.ks, d.cout), st));
   }
   if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
     const int heads[3] = {L_PA, L_DA, L_DS};
-    const int total = 2 * 16 * 9 * CK * NB;
+    const bool wino = wino_ok(3, 256 * h->nheads);
+    const int total = 2 * 16 * (wino ? WC : 9) * CK * NB;
     for (int k = 0; k < h->nheads; ++k) {
-      hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, P(h, h->L[heads[k]].w_off),
-                         h->wpk_heads_bwd, 256, 128, 3, 1, 16 * h->nheads, 16 * k, 0, 2, 16);
+      if (wino)
+        hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
+                           P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 16 * h->nheads, 16 * k, 0, 2, 16);
+      else
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, P(h, h->L[heads[k]].w_off),
+                           h->wpk_heads_bwd, 256, 128, 3, 1, 16 * h->nheads, 16 * k, 0, 2, 16);
     }
     HIPCHK(hipGetLastError());
   }
@@ -581,7 +619,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
   }
   ConvCall c;
   c.in = pooled ? A.Apool[src] : A.Y[src]; c.in_cs = A.y_cs[src]; c.in_co = A.y_co[src]; c.cin = d.cin;
-  c.wpk = h->wpk_fwd + d.pk_fwd; c.bias = P(h, d.b_off);
+  c.wpk = h->wpk_fwd + d.pk_fwd; c.bias = P(h, d.b_off); c.wino = wino_ok(d.ks, d.cin);
   c.out = A.Y[l]; c.out_cs = A.y_cs[l]; c.out_co = A.y_co[l]; c.cout = d.cout;
   c.in_scale = A.bn[src].scale; c.in_shift = A.bn[src].shift;
   c.stats = (d.bn && train) ? A.bn[l].stats : nullptr;
@@ -683,7 +721,7 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
   w.N = N; w.H = H; w.W = W; w.ks = d.ks; w.in_mode = in_mode;
   ConvCall c;
   c.in = dy[0]; c.in_cs = dy_cs; c.in_co = dy_co; c.cin = (int)align_up(d.cout, 4);
-  c.wpk = h->wpk_bwd + d.pk_bwd; c.bias = nullptr;
+  c.wpk = h->wpk_bwd + d.pk_bwd; c.bias = nullptr; c.wino = wino_ok(d.ks, d.cout);
   c.out = din[0]; c.out_cs = din_cs; c.out_co = din_co; c.cout = d.cin;
   c.in_scale = nullptr; c.in_shift = nullptr; c.stats = nullptr;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 0; c.nchunks = d.nchunks_bwd; c.ncob = d.ncob_bwd;
@@ -763,7 +801,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
       CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
     }
     ConvCall c;
-    c.in = gQ[0]; c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = h->wpk_heads_bwd; c.bias = nullptr;
+    c.in = gQ[0]; c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = h->wpk_heads_bwd; c.bias = nullptr; c.wino = wino_ok(3, hcs);
     c.out = gP[0]; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
     c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = 16 * h->nheads; c.ncob = 2;
     if (SS.n == 2) { c.nprob = 2; c.in2 = gQ[1]; c.out2 = gP[1]; }
@@ -979,18 +1017,18 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
                 int cin, int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
                 double* stats_dev, int transpose_flip, void* workspace_dev, size_t workspace_bytes, void* stream) {
   // with transpose_flip the weight tensor is [cin_conv... see header]: w is OIHW with O = (tf ? cin : cout)
-  const int taps = ksize * ksize;
+  const bool wino = wino_ok(ksize, cin) && in_mode != 2;
   const int nchunks = cdiv(cin, CK), ncob = cdiv(cout, NB);
-  const size_t need = (size_t)ncob * nchunks * taps * CK * NB * sizeof(float);
+  const size_t need = (size_t)ncob * nchunks * pk_taps(ksize) * CK * NB * sizeof(float);
   if (workspace_bytes < need) return fail(-4, "ssp_op_conv workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   float* wpk = reinterpret_cast<float*>(workspace_dev);
-  if (!transpose_flip) CHK(launch_pack(w_oihw_dev, wpk, cout, cin, ksize, 0, st));
-  else CHK(launch_pack(w_oihw_dev, wpk, cin, cout, ksize, 1, st));
+  if (!transpose_flip) CHK(launch_pack(w_oihw_dev, wpk, cout, cin, ksize, 0, wino, st));
+  else CHK(launch_pack(w_oihw_dev, wpk, cin, cout, ksize, 1, wino, st));
   ConvCall c;
   c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.wpk = wpk; c.bias = bias_dev; c.out = out_dev; c.out_cs = cout;
   c.out_co = 0; c.cout = cout; c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.stats = stats_dev; c.N = n;
-  c.H = hh; c.W = w; c.ks = ksize; c.in_mode = in_mode; c.nchunks = nchunks; c.ncob = ncob;
+  c.H = hh; c.W = w; c.ks = ksize; c.in_mode = in_mode; c.nchunks = nchunks; c.ncob = ncob; c.wino = wino;
   return launch_conv(nullptr, c, st, 0);
 }
 
@@ -1235,6 +1273,12 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 }
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
+int ssp_set_conv_algo(int algo) {
+  if (algo != 0 && algo != 1) return fail(-1, "conv algo must be 0 (direct implicit GEMM) or 1 (Winograd F(2x2,3x3))");
+  g_conv_algo = algo;
+  return 0;
+}
+
 int ssp_debug_conv_knobs(int ablate, int grid) {
   g_dbg_ablate = ablate; g_dbg_grid = grid;
   return 0;

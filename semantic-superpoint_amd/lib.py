@@ -52,7 +52,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
            "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
-           "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
+           "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_set_conv_algo", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
            "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
            "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms"]
 
@@ -89,6 +89,7 @@ def load_library(path=None):
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.ssp_debug_conv_knobs.argtypes = [i, i]
+    lib.ssp_set_conv_algo.argtypes = [i]
     lib.ssp_op_warp_image.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.ssp_op_erode.argtypes = [vp, vp, i, i, i, i, vp]
     lib.ssp_op_warp_labels.argtypes = [vp, vp, vp, i, i, i, vp]
@@ -109,6 +110,11 @@ def load_library(path=None):
     lib.ssp_op_heatmap_nms.argtypes = [vp, ep, i, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
+
+
+def set_conv_algo(algo):
+    """0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) for the eligible 3x3 convolutions (default)."""
+    _check(load_library().ssp_set_conv_algo(int(algo)))
 
 
 def _check(rc):
@@ -416,7 +422,7 @@ def op_conv(x_nhwc, w_oihw, bias, ksize, in_mode=0, in_scale=None, in_shift=None
     H, W = (Hin // 2, Win // 2) if in_mode == 2 else (Hin, Win)
     cout = w_oihw.shape[1] if transpose_flip else w_oihw.shape[0]
     out = torch.empty(N, H, W, cout, dtype=torch.float32, device=x_nhwc.device)
-    ws = torch.empty(((cin + 15) // 16) * ((cout + 63) // 64) * ksize * ksize * 16 * 64 * 4 + 1024, dtype=torch.uint8,
+    ws = torch.empty(((cin + 15) // 16) * ((cout + 63) // 64) * (16 if ksize == 3 else 1) * 16 * 64 * 4 + 1024, dtype=torch.uint8,
                      device=x_nhwc.device)
     with torch.cuda.device(x_nhwc.device):
         _check(lib.ssp_op_conv(_ptr(x_nhwc), _ptr(w_oihw), _ptr(bias), _ptr(out), N, H, W, cin, cout, ksize, in_mode,

@@ -176,7 +176,7 @@ def test_two_images_per_call_match_single_calls():
         e.load_state_dict(sd)
         one = e.export_points(views[k:k + 1], masks[k:k + 1], hms[k:k + 1], conf_thresh=0.0152, top_k=0, subpixel=False,
                               want_heatmap=True)[0]
-        assert (one["heatmap"] - both[k]["heatmap"]).abs().max() < 1e-6
+        assert (one["heatmap"] - both[k]["heatmap"]).abs().max() < 5e-6
         a, b = points_to_numpy(one["pts"], one["count"], False), points_to_numpy(both[k]["pts"], both[k]["count"], False)
         sa, sb = {tuple(r[:2]) for r in a}, {tuple(r[:2]) for r in b}
         assert len(sa & sb) >= 0.95 * max(len(sa), 1)

@@ -11,6 +11,8 @@ b = torch.zeros(C, device=dev)
 sc = torch.ones(C, device=dev); sh = torch.zeros(C, device=dev)
 flops = 2.0 * N * H * W * C * C * 9
 GRID = [0]
+if len(sys.argv) > 1:
+    L.set_conv_algo(int(sys.argv[1]))  # 0 direct, 1 Winograd
 def run(tag, mode, abl, stats=False):
     L.load_library().ssp_debug_conv_knobs(int(abl), GRID[0])
     st = torch.zeros(L.NREP, 2 * C, dtype=torch.float64, device=dev) if stats else None
@@ -33,7 +35,7 @@ run("no loads/LDS writes/stores (MFMA+ds_read)", 0, 7)
 run("no MFMA (loads+LDS+stores)", 0, 8)
 run("no MFMA, no stores", 0, 12)
 
-for g in (256, 512, 768, 1024):
+for g in ((256, 512, 768, 1024) if len(sys.argv) < 2 or sys.argv[1] == "0" else ()):
     GRID[0] = g
     run("full mode0, grid %d" % g, 0, 0)
     run("MFMA only, grid %d" % g, 0, 7)
