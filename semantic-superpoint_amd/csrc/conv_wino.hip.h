@@ -4,18 +4,22 @@
 //
 // The 16 element-wise products are 16 independent GEMMs [tiles x Cin] x [Cin x Cout]: 16 multiplies per 2x2 outputs
 // instead of 36, i.e. 2.25x fewer MFMA FLOPs than the direct implicit GEMM of conv_mfma_kernel for the same
-// (algorithmic) convolution, still in exact fp32 arithmetic (the transforms only add and halve).
+// (algorithmic) convolution, still in fp32 arithmetic throughout (the transforms only add and halve).
 //
-// Block = 256 threads = 4 waves, ONE block per CU (144 KB of LDS, 256 accumulator registers per lane):
+// Block = 512 threads = 8 waves (2 per SIMD), ONE block per CU (150 KB of LDS):
 //   output tile 8x32 (WIDE) or 32x8 pixels = 64 Winograd tiles x 64 output channels;
-//   wave w owns M-tile (w >> 1) (32 tiles) x N-tile (w & 1) (32 channels) for ALL 16 components: 16 x f32x16 acc.
-// Per 16-channel K-chunk a thread (tile = tid >> 2, channel quad = tid & 3) loads its 4x4 patch (16 x b128, BatchNorm
-// + ReLU of the producer applied on the way, zero outside the image), transforms it in registers and writes the 16
-// components to LDS as [component][tile][CS]; the pre-transformed weights G g G^T arrive packed as
-// [cob][chunk][component][g][h][64][4] (pack_weights_wino_kernel), the same fragment layout as conv_mfma_kernel with
-// "tap" replaced by "component".  The output transform runs on the accumulators (each lane holds all 16 components of
-// its 16 tiles), then the tile goes through LDS for 16-byte stores exactly like conv_mfma_kernel.
-// Same persistent XCD-aware grid, dual-problem launches, register-staged prefetch and BatchNorm partial sums.
+//   wave w = (M-tile w >> 2 (32 tiles), N-tile (w >> 1) & 1 (32 channels), component half w & 1): 8 x f32x16 acc.
+// Per 16-channel K-chunk:
+//   1. the raw (TH+2) x (TW+2) halo (340 pixels x 16 channels) and the 64 KB of pre-transformed weights
+//      (pack_weights_wino_kernel, [cob][chunk][component][g][h][64][4]) are prefetched into registers while the MFMAs
+//      of the previous chunk run, then written to LDS (BatchNorm + ReLU of the producer applied once per element here);
+//   2. thread (tile, channel quad, row half) reads 3 x 4 raw pixels from LDS, forms its two rows of V = B^T d B and
+//      writes 8 components to sA[component][tile][16] (quad index XOR-swizzled by (tile >> 1) & 3 instead of padding);
+//   3. 64 MFMAs per wave on fragments read with ds_read_b128 exactly like conv_mfma_kernel ("tap" -> "component").
+// Epilogue: each lane holds 8 components (two rows of the 4x4 product matrix) of its 16 tiles; the two component
+// halves write their partial outputs to two LDS staging tiles, which are summed on the way to the 16-byte stores;
+// the BatchNorm partial sums are taken from the summed values.  Persistent XCD-aware grid and dual-problem launches
+// as in conv_mfma_kernel.
 #pragma once
 #include "conv_mfma.hip.h"
 
@@ -23,22 +27,33 @@ namespace sspk {
 
 constexpr int WC = 16;                          // Winograd components
 constexpr int WTILES = 64;                      // 2x2-output tiles per block
-constexpr int WA_FLOATS = WC * WTILES * CS;     // transformed input chunk  (81920 B)
-constexpr int WB_FLOATS = WC * CK * NB;         // transformed weight chunk (65536 B)
-constexpr int WINO_LDS_BYTES = (WA_FLOATS + WB_FLOATS) * 4;
+constexpr int WA_FLOATS = WC * WTILES * CK;     // transformed input chunk  (64 KB, swizzled, no padding)
+constexpr int WB_FLOATS = WC * CK * NB;         // transformed weight chunk (64 KB)
+constexpr int WHALO = 340;                      // (8+2) x (32+2) = (32+2) x (8+2) raw halo pixels
+constexpr int WR_FLOATS = WHALO * CK;           // raw halo chunk (21.25 KB)
+constexpr int WINO_LDS_BYTES = (WA_FLOATS + WB_FLOATS + WR_FLOATS) * 4;
+constexpr int WINO_THREADS = 512;
+
+// raw halo pixel p, channel quad q -> float offset in sR: pixel pairs share a 128-byte row and the slot inside the row
+// alternates from pair to pair, so that the stride-2 pixel reads of the transform spread over all banks
+__device__ __forceinline__ int wino_raw_off(int p, int q) {
+  return (((p >> 1) << 1) + ((p ^ (p >> 1)) & 1)) * CK + q * 4;
+}
 
 template <int IN_MODE, bool WIDE>
-__global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs a) {
   constexpr int TTX = WIDE ? 16 : 4;            // tiles per block row
   constexpr int TH = WIDE ? 8 : 32, TW = WIDE ? 32 : 8;
+  constexpr int HC = TW + 2;                    // halo columns
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
   float* sB = smem + WA_FLOATS;
+  float* sR = smem + WA_FLOATS + WB_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int mt = wave >> 1, nt = wave & 1;
+  const int chalf = wave & 1, nt = (wave >> 1) & 1, mt = wave >> 2;
 
   // ---- work assignment (as conv_mfma_kernel) ----
   const int nslot = gridDim.x >> 3;
@@ -58,15 +73,26 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
   const float* const p_shift = prob ? a.in_shift2 : a.in_shift;
   double* const p_stats = prob ? a.stats2 : a.stats;
 
-  // ---- staging role: one (tile, channel quad) per thread ----
-  const int q4 = tid & 3, st_slot = tid >> 2;
-  const int st_ty = st_slot / TTX, st_tx = st_slot % TTX;
+  // ---- staging roles ----
+  const int q4 = tid & 3;
+  // raw halo: items tid + 512 k (k < 3), item = pixel * 4 + quad
+  int rp[3], rr[3], rc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rp[k] = (tid + WINO_THREADS * k) >> 2;
+    rr[k] = rp[k] / HC;
+    rc[k] = rp[k] - rr[k] * HC;
+  }
+  const bool r2 = tid + 2 * WINO_THREADS < WHALO * 4;  // the third item exists
+  // transform: (tile, quad, row half)
+  const int t_tile = (tid >> 2) & 63, t_half = tid >> 8;
+  const int t_ty = t_tile / TTX, t_tx = t_tile % TTX;
   const int pixb = a.in_cs * 4, rowb = a.W * pixb;
-  f32x4 hreg[16], wreg[16];
+  f32x4 hreg[3], wreg[8];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   constexpr unsigned OOB = 0x80000000u;
-  int ld_n, ld_ty0, ld_tx0, vbase;
-  unsigned pmask;  // bit 4*i+j: patch pixel (i, j) lies inside the image
+  int ld_n, ld_ty0, ld_tx0;
+  unsigned hoff[3];
   const size_t img_floats = (size_t)a.H * a.W * a.in_cs;
   __amdgpu_buffer_rsrc_t rsrc_in;
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
@@ -76,15 +102,11 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
     ld_tx0 = tx_ * TW;                                                                                   \
     ld_ty0 = (t2_ % a.tiles_y) * TH;                                                                     \
     ld_n = t2_ / a.tiles_y;                                                                              \
-    const int py0_ = ld_ty0 + 2 * st_ty - 1, px0_ = ld_tx0 + 2 * st_tx - 1;                              \
-    unsigned rm_ = 0, cm_ = 0;                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-      rm_ |= ((unsigned)(py0_ + i) < (unsigned)a.H ? 1u : 0u) << i;                                      \
-      cm_ |= ((unsigned)(px0_ + i) < (unsigned)a.W ? 1u : 0u) << i;                                      \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                      \
+      const int gy = ld_ty0 - 1 + rr[k], gx = ld_tx0 - 1 + rc[k];                                        \
+      const bool ok = (k < 2 || r2) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;     \
+      hoff[k] = ok ? (unsigned)(gy * rowb + gx * pixb + (a.in_co + q4 * 4) * 4) : OOB;                   \
     }                                                                                                    \
-    pmask = 0;                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) pmask |= (((rm_ >> i) & 1u) ? cm_ : 0u) << (4 * i);    \
-    vbase = py0_ * rowb + px0_ * pixb + (a.in_co + q4 * 4) * 4;                                          \
     rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in) + (size_t)ld_n * img_floats, 0, \
                                                 a.in_bytes, 0x00020000);                                 \
   }
@@ -95,69 +117,95 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
       psh = *reinterpret_cast<const f32x4*>(p_shift + (CHUNK) * CK + q4 * 4);                            \
     }                                                                                                    \
     const int soff_ = (CHUNK) * CK * 4;                                                                  \
-    _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                     \
-      const unsigned vo_ = ((pmask >> k) & 1u) ? (unsigned)(vbase + (k >> 2) * rowb + (k & 3) * pixb) : OOB; \
-      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo_, soff_, 0)); \
-    }                                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                        \
+      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], soff_, 0)); \
     const int wbase_ = (cob * a.nchunks + (CHUNK)) * WB_FLOATS * 4;                                      \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j)                                                       \
-      wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 4096, 0)); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                        \
+      wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 8192, 0)); \
   }
 
   WINO_DECODE_TILE(tile)
   WINO_ISSUE_LOADS(0)
 
-  float ssum = 0.f, ssq = 0.f;
+  // MFMA fragment offsets: A = sA[(comp * 64 + tile) * 16 + ((quad ^ swz) * 4)], quad = 2 g + lh
+  const int m_tile = mt * 32 + li;
+  const int swz = (m_tile >> 1) & 3;
+  const int a_off0 = (chalf * 8 * WTILES + m_tile) * CK + ((lh ^ swz) << 2);
+  const int a_off1 = (chalf * 8 * WTILES + m_tile) * CK + (((2 + lh) ^ swz) << 2);
+  const int b_off = (chalf * 8 * (CK / 8) * 2 * NB + lh * NB + nt * 32 + li) * 4;
+  // transform offsets
+  const int t_swz = (t_tile >> 1) & 3;
+  float* const t_dst = sA + ((2 * t_half * 4) * WTILES + t_tile) * CK + ((q4 ^ t_swz) << 2);
+  int t_src[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t_src[i * 4 + j] = wino_raw_off((2 * t_ty + t_half + i) * HC + 2 * t_tx + j, q4);
+
+  // per-thread BatchNorm partial sums of channel quad (tid & 15)
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
   const int co_l = cob * NB + nt * 32 + li;
-  const bool covalid = co_l < a.Cout;
-  const float bias_v = (a.bias != nullptr && covalid) ? a.bias[co_l] : 0.f;
-  const int a_off = (mt * 32 + li) * CS + lh * 4;
-  const int b_off = (lh * NB + nt * 32 + li) * 4;
+  const float bias_v = (a.bias != nullptr && co_l < a.Cout) ? a.bias[co_l] : 0.f;
 
   for (;;) {  // ---- one output tile per iteration ----
     const int n = ld_n, ty0 = ld_ty0, tx0 = ld_tx0;
-    const unsigned cmask = pmask;  // validity of the patch that is in the registers now
+    unsigned hmask = 0;  // validity of the raw items in the registers now
+#pragma unroll
+    for (int k = 0; k < 3; ++k) hmask |= (hoff[k] != OOB ? 1u : 0u) << k;
     const int next_tile = tile + per_cob;
     const bool has_next = next_tile < t_end;
 
-    f32x16 acc[WC];
+    f32x16 acc[8];
 #pragma unroll
-    for (int c = 0; c < WC; ++c)
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-      __syncthreads();  // every wave has finished reading the LDS image of the previous step
+      __syncthreads();  // every wave has finished the MFMA reads (sA, sB) and the transform reads (sR)
       if (!(a.ablate & 2)) {
-        // BatchNorm + ReLU of the producer, zero padding, then V = B^T d B per channel -- in place in hreg
-        if (IN_MODE != 0) {
+        // raw halo -> LDS with BatchNorm + ReLU of the producer (zero outside the image), weights -> LDS
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 3; ++k) {
+          if (k < 2 || r2) {
+            f32x4 v = hreg[k];
+            if (IN_MODE != 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hreg[k][e] = fmaxf(fmaf(hreg[k][e], psc[e], psh[e]), 0.f);
-            if (!((cmask >> k) & 1u)) hreg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], psc[e], psh[e]), 0.f);
+              if (!((hmask >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            *reinterpret_cast<f32x4*>(sR + wino_raw_off(rp[k], q4)) = v;
           }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {  // rows: T = B^T d
-          const f32x4 d0 = hreg[j], d1 = hreg[4 + j], d2 = hreg[8 + j], d3 = hreg[12 + j];
-          hreg[j] = d0 - d2;
-          hreg[4 + j] = d1 + d2;
-          hreg[8 + j] = d2 - d1;
-          hreg[12 + j] = d1 - d3;
-        }
-        float* dst = sA + st_slot * CS + q4 * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // columns: V = T B, written straight to LDS
-          const f32x4 t0 = hreg[i * 4], t1 = hreg[i * 4 + 1], t2 = hreg[i * 4 + 2], t3 = hreg[i * 4 + 3];
-          *reinterpret_cast<f32x4*>(dst + (i * 4 + 0) * WTILES * CS) = t0 - t2;
-          *reinterpret_cast<f32x4*>(dst + (i * 4 + 1) * WTILES * CS) = t1 + t2;
-          *reinterpret_cast<f32x4*>(dst + (i * 4 + 2) * WTILES * CS) = t2 - t1;
-          *reinterpret_cast<f32x4*>(dst + (i * 4 + 3) * WTILES * CS) = t1 - t3;
         }
         f32x4* wdst = reinterpret_cast<f32x4*>(sB);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wdst[tid + 256 * j] = wreg[j];
+        for (int j = 0; j < 8; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];
+      }
+      __syncthreads();
+      if (!(a.ablate & 2)) {
+        // two rows of V = B^T d B for (tile, quad): half 0 -> V rows 0, 1 from d rows 0..2; half 1 -> rows 2, 3 from 1..3
+        f32x4 ta[4], tb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(sR + t_src[j]);
+          const f32x4 y = *reinterpret_cast<const f32x4*>(sR + t_src[4 + j]);
+          const f32x4 z = *reinterpret_cast<const f32x4*>(sR + t_src[8 + j]);
+          if (t_half == 0) {
+            ta[j] = x - z;  // T0 = d0 - d2
+            tb[j] = y + z;  // T1 = d1 + d2
+          } else {
+            ta[j] = y - x;  // T2 = d2 - d1
+            tb[j] = x - z;  // T3 = d1 - d3
+          }
+        }
+        *reinterpret_cast<f32x4*>(t_dst + 0 * WTILES * CK) = ta[0] - ta[2];
+        *reinterpret_cast<f32x4*>(t_dst + 1 * WTILES * CK) = ta[1] + ta[2];
+        *reinterpret_cast<f32x4*>(t_dst + 2 * WTILES * CK) = ta[2] - ta[1];
+        *reinterpret_cast<f32x4*>(t_dst + 3 * WTILES * CK) = ta[1] - ta[3];
+        *reinterpret_cast<f32x4*>(t_dst + 4 * WTILES * CK) = tb[0] - tb[2];
+        *reinterpret_cast<f32x4*>(t_dst + 5 * WTILES * CK) = tb[1] + tb[2];
+        *reinterpret_cast<f32x4*>(t_dst + 6 * WTILES * CK) = tb[2] - tb[1];
+        *reinterpret_cast<f32x4*>(t_dst + 7 * WTILES * CK) = tb[1] - tb[3];
       }
       __syncthreads();
       {
@@ -167,14 +215,15 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
         WINO_ISSUE_LOADS(nxt)
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- MFMA: 16 components x 2 k-groups x 4 k-pairs ----
+      // ---- MFMA: 8 components x 2 k-groups x 4 k-pairs ----
       if (!(a.ablate & 8))
 #pragma unroll
-      for (int c = 0; c < WC; c += 2) {
+      for (int c = 0; c < 8; c += 2) {
 #pragma unroll
         for (int g = 0; g < CK / 8; ++g) {
-          const float4 a0 = *reinterpret_cast<const float4*>(sA + a_off + c * WTILES * CS + g * 8);
-          const float4 a1 = *reinterpret_cast<const float4*>(sA + a_off + (c + 1) * WTILES * CS + g * 8);
+          const int ao = g ? a_off1 : a_off0;
+          const float4 a0 = *reinterpret_cast<const float4*>(sA + ao + c * WTILES * CK);
+          const float4 a1 = *reinterpret_cast<const float4*>(sA + ao + (c + 1) * WTILES * CK);
           const float4 b0 = *reinterpret_cast<const float4*>(sB + b_off + (c * (CK / 8) + g) * 2 * NB * 4);
           const float4 b1 = *reinterpret_cast<const float4*>(sB + b_off + ((c + 1) * (CK / 8) + g) * 2 * NB * 4);
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[c], 0, 0, 0);
@@ -189,36 +238,37 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
       }
     }
 
-    // ---- tile epilogue: output transform on the accumulators, LDS transpose, 16-byte stores ----
+    // ---- tile epilogue ----
+    // lane: co = nt*32 + li, tiles m = (r&3) + 8*(r>>2) + 4*lh of M-tile mt, components (2*chalf + {0,1}, 0..3).
+    // S = A^T M: s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 (per column); half 0 holds rows 0, 1 and half 1 rows 2, 3, so each
+    // half contributes (s0, s1) = (M0 + M1, M1) resp. (M2, -M2 - M3); the partial outputs Y = S A meet in the store loop.
     if (!(a.ablate & 4)) {
       const bool full = (ty0 + TH <= a.H) && (tx0 + TW <= a.W);
-      __syncthreads();
+      __syncthreads();  // MFMA reads of sA / sB finished: the two staging tiles (one per half) may overwrite them
+      if (!(a.ablate & 32)) {
+        float* const stg = smem + chalf * (TH * TW * NB);
+        const float bz = chalf == 0 ? bias_v : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int sl = mt * 32 + m;
-        const int ty = sl / TTX, tx = sl % TTX;
-        float s0[4], s1[4];
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int sl = mt * 32 + m;
+          const int ty = sl / TTX, tx = sl % TTX;
+          float s0[4], s1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s0[j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-          s1[j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
-        }
-        const float y00 = s0[0] + s0[1] + s0[2] + bias_v, y01 = s0[1] - s0[2] - s0[3] + bias_v;
-        const float y10 = s1[0] + s1[1] + s1[2] + bias_v, y11 = s1[1] - s1[2] - s1[3] + bias_v;
-        const int orow = 2 * ty, ocol = 2 * tx;
-        float* o = smem + (orow * TW + ocol) * NB + nt * 32 + li;
-        o[0] = y00;
-        o[NB] = y01;
-        o[TW * NB] = y10;
-        o[TW * NB + NB] = y11;
-        if (p_stats != nullptr && covalid) {
-          const bool r0 = full || ty0 + orow < a.H, r1 = full || ty0 + orow + 1 < a.H;
-          const bool c0 = full || tx0 + ocol < a.W, c1 = full || tx0 + ocol + 1 < a.W;
-          if (r0 && c0) { ssum += y00; ssq += y00 * y00; }
-          if (r0 && c1) { ssum += y01; ssq += y01 * y01; }
-          if (r1 && c0) { ssum += y10; ssq += y10 * y10; }
-          if (r1 && c1) { ssum += y11; ssq += y11 * y11; }
+          for (int j = 0; j < 4; ++j) {
+            if (chalf == 0) {
+              s0[j] = acc[j][r] + acc[4 + j][r];
+              s1[j] = acc[4 + j][r];
+            } else {
+              s0[j] = acc[j][r];
+              s1[j] = -acc[j][r] - acc[4 + j][r];
+            }
+          }
+          float* o = stg + ((2 * ty) * TW + 2 * tx) * NB + nt * 32 + li;
+          o[0] = s0[0] + s0[1] + s0[2] + bz;
+          o[NB] = s0[1] - s0[2] - s0[3] + bz;
+          o[TW * NB] = s1[0] + s1[1] + s1[2] + bz;
+          o[TW * NB + NB] = s1[1] - s1[2] - s1[3] + bz;
         }
       }
       __syncthreads();
@@ -226,12 +276,16 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
       const int co4 = cob * NB + q16 * 4;
       const int nvalid = min(4, a.Cout - co4);
 #pragma unroll 4
-      for (int k = 0; k < (TH * TW) / 16; ++k) {
-        const int lp = (tid >> 4) + 16 * k;
+      for (int k = 0; k < (TH * TW * 16) / WINO_THREADS; ++k) {
+        const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
         const int orow = lp / TW, ocol = lp - orow * TW;
         const int oy = ty0 + orow, ox = tx0 + ocol;
         if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(smem + lp * NB + q16 * 4);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(smem + lp * NB + q16 * 4) +
+                          *reinterpret_cast<const f32x4*>(smem + TH * TW * NB + lp * NB + q16 * 4);
+          ssum += v;
+          ssq += v * v;
+          if (a.ablate & 16) continue;
           float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
           if (nvalid == 4) {
             *reinterpret_cast<f32x4*>(p) = v;
@@ -249,17 +303,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
 
   if (p_stats != nullptr) {
     __syncthreads();
-    float* red = smem;  // [4 waves][32][2]
-    const float s = ssum + __shfl_xor(ssum, 32), q = ssq + __shfl_xor(ssq, 32);
-    if (lh == 0) {
-      red[(wave * 32 + li) * 2 + 0] = s;
-      red[(wave * 32 + li) * 2 + 1] = q;
-    }
+    float* red = smem;  // [32 pixel groups][16 quads][8]
+    *reinterpret_cast<f32x4*>(red + tid * 8) = ssum;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = ssq;
     __syncthreads();
     if (tid < 128) {
-      const int ch = tid >> 1, which = tid & 1;  // ch in 0..63: N-tile ch >> 5 is held by waves (ch >> 5) and 2 + (ch >> 5)
-      const int w0 = ch >> 5;
-      const float t = red[(w0 * 32 + (ch & 31)) * 2 + which] + red[((w0 + 2) * 32 + (ch & 31)) * 2 + which];
+      const int ch = tid >> 1, which = tid & 1;  // channel ch of the block: quad ch >> 2, element ch & 3
+      float t = 0.f;
+      for (int gq = 0; gq < WINO_THREADS / 16; ++gq) t += red[(gq * 16 + (ch >> 2)) * 8 + which * 4 + (ch & 3)];
       const int co = cob * NB + ch;
       if (co < a.Cout)
         unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);

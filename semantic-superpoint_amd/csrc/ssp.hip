@@ -307,7 +307,7 @@ static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), WINO_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -34,6 +34,9 @@ run("no global loads, no stores", 0, 5)
 run("no loads/LDS writes/stores (MFMA+ds_read)", 0, 7)
 run("no MFMA (loads+LDS+stores)", 0, 8)
 run("no MFMA, no stores", 0, 12)
+run("no global stores only (16)", 0, 16)
+run("no LDS epilogue passes (32)", 0, 32)
+run("no LDS epilogue, no global stores (48)", 0, 48)
 
 for g in ((256, 512, 768, 1024) if len(sys.argv) < 2 or sys.argv[1] == "0" else ()):
     GRID[0] = g
