@@ -34,10 +34,11 @@ constexpr int WR_FLOATS = WHALO * CK;           // raw halo chunk (21.25 KB)
 constexpr int WINO_LDS_BYTES = (WA_FLOATS + WB_FLOATS + WR_FLOATS) * 4;
 constexpr int WINO_THREADS = 512;
 
-// raw halo pixel p, channel quad q -> float offset in sR: pixel pairs share a 128-byte row and the slot inside the row
-// alternates from pair to pair, so that the stride-2 pixel reads of the transform spread over all banks
-__device__ __forceinline__ int wino_raw_off(int p, int q) {
-  return (((p >> 1) << 1) + ((p ^ (p >> 1)) & 1)) * CK + q * 4;
+// raw halo pixel (r, c) of an HC-column halo (HC even), channel quad q -> float offset in sR: the column pair c >> 1
+// shares a 128-byte row and the slot inside it alternates from pair to pair, so that the stride-2 pixel reads of the
+// transform spread over all banks; rows are HC * CK floats apart
+__device__ __forceinline__ int wino_raw_off(int r, int c, int q, int HC) {
+  return ((r * (HC >> 1) + (c >> 1)) * 2 + ((c ^ (c >> 1)) & 1)) * CK + q * 4;
 }
 
 template <int IN_MODE, bool WIDE>
@@ -76,12 +77,12 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
   // ---- staging roles ----
   const int q4 = tid & 3;
   // raw halo: items tid + 512 k (k < 3), item = pixel * 4 + quad
-  int rp[3], rr[3], rc[3];
+  int rrc[3], r_lds[3];  // (row | col << 8) of the item's halo pixel, its float offset in sR
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    rp[k] = (tid + WINO_THREADS * k) >> 2;
-    rr[k] = rp[k] / HC;
-    rc[k] = rp[k] - rr[k] * HC;
+    const int p = (tid + WINO_THREADS * k) >> 2, r = p / HC, c = p - r * HC;
+    rrc[k] = r | (c << 8);
+    r_lds[k] = wino_raw_off(r, c, q4, HC);
   }
   const bool r2 = tid + 2 * WINO_THREADS < WHALO * 4;  // the third item exists
   // transform: (tile, quad, row half)
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
     ld_ty0 = (t2_ % a.tiles_y) * TH;                                                                     \
     ld_n = t2_ / a.tiles_y;                                                                              \
     _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                      \
-      const int gy = ld_ty0 - 1 + rr[k], gx = ld_tx0 - 1 + rc[k];                                        \
+      const int gy = ld_ty0 - 1 + (rrc[k] & 255), gx = ld_tx0 - 1 + (rrc[k] >> 8);                       \
       const bool ok = (k < 2 || r2) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;     \
       hoff[k] = ok ? (unsigned)(gy * rowb + gx * pixb + (a.in_co + q4 * 4) * 4) : OOB;                   \
     }                                                                                                    \
@@ -136,11 +137,10 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
   // transform offsets
   const int t_swz = (t_tile >> 1) & 3;
   float* const t_dst = sA + ((2 * t_half * 4) * WTILES + t_tile) * CK + ((q4 ^ t_swz) << 2);
-  int t_src[12];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t_src[i * 4 + j] = wino_raw_off((2 * t_ty + t_half + i) * HC + 2 * t_tx + j, q4);
+  // raw pixels (row 2 t_ty + t_half + i, column 2 t_tx + j): columns 0 / 3 sit in slot (t_tx & 1) of the column pairs
+  // t_tx / t_tx + 1, columns 1 / 2 in the other slot; rows are HC * CK floats apart
+  const int t_src_s = wino_raw_off(2 * t_ty + t_half, 2 * t_tx, q4, HC);
+  const int t_src_n = wino_raw_off(2 * t_ty + t_half, 2 * t_tx + 1, q4, HC);
 
   // per-thread BatchNorm partial sums of channel quad (tid & 15)
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], psc[e], psh[e]), 0.f);
               if (!((hmask >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            *reinterpret_cast<f32x4*>(sR + wino_raw_off(rp[k], q4)) = v;
+            *reinterpret_cast<f32x4*>(sR + r_lds[k]) = v;
           }
         }
         f32x4* wdst = reinterpret_cast<f32x4*>(sB);
@@ -187,9 +187,10 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
         f32x4 ta[4], tb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(sR + t_src[j]);
-          const f32x4 y = *reinterpret_cast<const f32x4*>(sR + t_src[4 + j]);
-          const f32x4 z = *reinterpret_cast<const f32x4*>(sR + t_src[8 + j]);
+          const float* src = sR + ((j == 0 || j == 3) ? t_src_s : t_src_n) + (j >= 2 ? 2 * CK : 0);
+          const f32x4 x = *reinterpret_cast<const f32x4*>(src);
+          const f32x4 y = *reinterpret_cast<const f32x4*>(src + HC * CK);
+          const f32x4 z = *reinterpret_cast<const f32x4*>(src + 2 * HC * CK);
           if (t_half == 0) {
             ta[j] = x - z;  // T0 = d0 - d2
             tb[j] = y + z;  // T1 = d1 + d2
