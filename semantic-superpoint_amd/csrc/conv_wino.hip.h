@@ -322,6 +322,235 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
 #undef WINO_DECODE_TILE
 #undef WINO_ISSUE_LOADS
 
+// ------------------------------------------------------------------------------------------------
+// Winograd weight gradient F(3x3, 2x2) (the transpose of F(2x2, 3x3)):
+//   dW(3x3) = G^T [ sum over 2x2-output tiles (B^T d B) (.) (A dy A^T) ] G      d: 4x4 input patch, dy: 2x2 dY tile
+// 16 multiplies per tile and (ci, co) instead of 36.  The 16 component products are GEMMs over K = tiles:
+// block = 8 waves, owns a 64 ci x 64 co slab of all 16 components (wave = (co half, component row i): 4 components x
+// 2 M-tiles = 128 accumulator registers) and walks a contiguous range of 128-pixel block tiles (32 Winograd tiles) of
+// BOTH views.  LDS holds only the RAW input halo and dY tile ([pixel][64 channels], BatchNorm + ReLU of the producer
+// applied on the way in); both transforms run in registers between the LDS reads and the MFMAs:
+//   lane (li, lh): k = lh selects the tile of the pair, one ds_read_b64 gives channels 2 li, 2 li + 1 = the rows li of
+//   M-tiles 0 / 1;  T[i][c] = d[ra][c] +- d[rb][c],  V[i][j] from T[i][0..3];  D[i][j] from the 2x2 dY values of co.
+// The partial slabs [block][component][ci][co] are summed over the splits, transformed with G^T . G and accumulated
+// into the OIHW gradient by wgrad_wino_reduce_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool WIDE>
+struct WgradWinoGeom {
+  static constexpr int TH = WIDE ? 4 : 16, TW = WIDE ? 32 : 8;  // 128 output pixels = 32 tiles per step
+  static constexpr int TTX = TW / 2;
+  static constexpr int HT = TH + 2, WT = TW + 2;
+  static constexpr int X_FLOATS = HT * WT * 64, D_FLOATS = TH * TW * 64;
+  static constexpr int LDS_BYTES = (X_FLOATS + D_FLOATS + 256) * 4;
+};
+
+template <int IN_MODE, bool WIDE>
+__global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
+  using G = WgradWinoGeom<WIDE>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem;
+  float* sD = smem + G::X_FLOATS;
+  float* sS = smem + G::X_FLOATS + G::D_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int coh = wave & 1, irow = wave >> 1;
+
+  int bid = blockIdx.x;
+  const int split = bid % a.nsplit;
+  bid /= a.nsplit;
+  const int cob = bid % a.ncob;
+  const int cib = bid / a.ncob;
+  const int tot_tiles = a.ntiles * a.nprob;
+  const int per = (tot_tiles + a.nsplit - 1) / a.nsplit;
+  const int t_begin = split * per, t_end = min(tot_tiles, t_begin + per);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][e][r] = 0.f;
+
+  const int q16 = tid & 15;
+  const int ci0 = cib * 64 + q16 * 4;
+  const bool civalid = ci0 < a.Cin;
+  if (IN_MODE != 0 && tid < 32) {
+    const int pr = tid >> 4;
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
+    if (civalid && pr < a.nprob) {
+      sc0 = *reinterpret_cast<const f32x4*>((pr ? a.in_scale2 : a.in_scale) + ci0);
+      sh0 = *reinterpret_cast<const f32x4*>((pr ? a.in_shift2 : a.in_shift) + ci0);
+    }
+    *reinterpret_cast<f32x4*>(sS + pr * 128 + q16 * 4) = sc0;
+    *reinterpret_cast<f32x4*>(sS + pr * 128 + 64 + q16 * 4) = sh0;
+  }
+  const int co0 = cob * 64 + q16 * 4;
+  const bool covalid = co0 < a.Cout;
+
+  constexpr int NX = (G::HT * G::WT + 31) / 32;  // halo pixels per thread (pp = (tid >> 4) + 32 i)
+  constexpr int ND = G::TH * G::TW / 32;
+  f32x4 xreg[NX], dreg[ND];
+  unsigned xmask = 0, dmask = 0;
+
+#define WGW_ISSUE(TILE)                                                                                       \
+  {                                                                                                           \
+    const int pr_ = (TILE) >= a.ntiles ? 1 : 0;                                                               \
+    const int tl_ = (TILE) - pr_ * a.ntiles;                                                                  \
+    const float* const pin_ = pr_ ? a.in2 : a.in;                                                             \
+    const float* const pdo_ = pr_ ? a.dout2 : a.dout;                                                         \
+    const int tx_ = tl_ % a.tiles_x, t2_ = tl_ / a.tiles_x;                                                   \
+    const int ty0_ = (t2_ % a.tiles_y) * G::TH, tx0_ = tx_ * G::TW, n_ = t2_ / a.tiles_y;                     \
+    xmask = 0; dmask = 0;                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                          \
+      const int pp = (tid >> 4) + 32 * i;                                                                     \
+      const int r = pp / G::WT, c = pp - r * G::WT;                                                           \
+      const int gy = ty0_ + r - 1, gx = tx0_ + c - 1;                                                         \
+      const bool ok = pp < G::HT * G::WT && civalid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
+      const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + ci0 : (size_t)0;     \
+      xreg[i] = *reinterpret_cast<const f32x4*>(pin_ + off);                                                  \
+      xmask |= (ok ? 1u : 0u) << i;                                                                           \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                          \
+      const int pp = (tid >> 4) + 32 * i;                                                                     \
+      const int r = pp / G::TW, c = pp - r * G::TW;                                                           \
+      const int gy = ty0_ + r, gx = tx0_ + c;                                                                 \
+      const bool ok = covalid && gy < a.H && gx < a.W;                                                        \
+      const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.dout_cs + a.dout_co + co0 : (size_t)0; \
+      dreg[i] = *reinterpret_cast<const f32x4*>(pdo_ + off);                                                  \
+      dmask |= (ok ? 1u : 0u) << i;                                                                           \
+    }                                                                                                         \
+  }
+
+  // per-wave constants of component row i:  T[i][c] = d[ra][c] + sg d[rb][c];  R[q] = c0 dy[0][q] + c1 dy[1][q]
+  const int ra = irow == 0 ? 0 : irow == 2 ? 2 : 1;
+  const int rb = irow == 2 ? 1 : irow == 3 ? 3 : 2;
+  const float sg = irow == 1 ? 1.f : -1.f;
+  const float c0 = irow == 3 ? 0.f : 1.f;
+  const float c1 = irow == 0 ? 0.f : irow == 1 ? 1.f : -1.f;
+
+  if (t_begin < t_end) WGW_ISSUE(t_begin)
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();  // all waves finished reading the previous tile's LDS image
+    {
+      const int cur_prob = tile >= a.ntiles ? 1 : 0;
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (IN_MODE != 0) {
+        sc = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + q16 * 4);
+        sh = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + 64 + q16 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int pp = (tid >> 4) + 32 * i;
+        if (pp < G::HT * G::WT) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if ((xmask >> i) & 1u) {
+            v = xreg[i];
+            if (IN_MODE != 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+            }
+          }
+          *reinterpret_cast<f32x4*>(sX + pp * 64 + q16 * 4) = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int pp = (tid >> 4) + 32 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((dmask >> i) & 1u) v = dreg[i];
+        *reinterpret_cast<f32x4*>(sD + pp * 64 + q16 * 4) = v;
+      }
+    }
+    __syncthreads();
+    {
+      const int nxt = min(tile + 1, t_end - 1);  // unconditional prefetch (redundant on the last tile)
+      WGW_ISSUE(nxt)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 2
+    for (int s = 0; s < 16; ++s) {
+      const int t = 2 * s + lh;  // K index -> Winograd tile of this block tile
+      const int ty = t / G::TTX, tx = t - ty * G::TTX;
+      const float* xa = sX + ((2 * ty + ra) * G::WT + 2 * tx) * 64 + 2 * li;
+      const float* xb = sX + ((2 * ty + rb) * G::WT + 2 * tx) * 64 + 2 * li;
+      f32x2 T[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x2 u = *reinterpret_cast<const f32x2*>(xa + c * 64), w = *reinterpret_cast<const f32x2*>(xb + c * 64);
+        T[c][0] = fmaf(sg, w[0], u[0]);
+        T[c][1] = fmaf(sg, w[1], u[1]);
+      }
+      const f32x2 V0 = T[0] - T[2], V1 = T[1] + T[2], V2 = T[2] - T[1], V3 = T[1] - T[3];
+      const float* db = sD + ((2 * ty) * G::TW + 2 * tx) * 64 + coh * 32 + li;
+      const float r0 = c0 * db[0] + c1 * db[G::TW * 64];
+      const float r1 = c0 * db[64] + c1 * db[G::TW * 64 + 64];
+      const float D0 = r0, D1 = r0 + r1, D2 = r0 - r1, D3 = -r1;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[0], D0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[1], D0, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[0], D1, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[1], D1, acc[1][1], 0, 0, 0);
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[0], D2, acc[2][0], 0, 0, 0);
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[1], D2, acc[2][1], 0, 0, 0);
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[0], D3, acc[3][0], 0, 0, 0);
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[1], D3, acc[3][1], 0, 0, 0);
+    }
+  }
+#undef WGW_ISSUE
+  // partial slab: [blk][component][ci 64][co 64]; M-tile e, row m <-> input channel 2 m + e
+  float* dst = a.partial + (size_t)blockIdx.x * WC * 4096;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        dst[(irow * 4 + j) * 4096 + (2 * m + e) * 64 + coh * 32 + li] = acc[j][e][r];
+      }
+}
+
+// Sums the 16-component partial slabs over the splits, applies dW = G^T M G and ACCUMULATES into the OIHW gradient.
+// block = 256 threads = 64 consecutive co x 4 split groups, one input channel per block row.
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                int Cin, int Cout, int ncob, int nsplit) {
+  __shared__ float red[4][WC][64];
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int cob = blockIdx.x % ncob, ci = blockIdx.x / ncob;
+  const int co = cob * 64 + o, cib = ci >> 6;
+  float m[WC];
+#pragma unroll
+  for (int c = 0; c < WC; ++c) m[c] = 0.f;
+  const float* src = partial + (size_t)((cib * ncob + cob) * nsplit) * WC * 4096 + (ci & 63) * 64 + o;
+  for (int k = grp; k < nsplit; k += 4)
+#pragma unroll
+    for (int c = 0; c < WC; ++c) m[c] += src[((size_t)k * WC + c) * 4096];
+#pragma unroll
+  for (int c = 0; c < WC; ++c) red[grp][c][o] = m[c];
+  __syncthreads();
+  if (grp != 0 || co >= Cout) return;
+#pragma unroll
+  for (int c = 0; c < WC; ++c) m[c] = (red[0][c][o] + red[1][c][o]) + (red[2][c][o] + red[3][c][o]);
+  float p[3][4];  // P = G^T M
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p[0][j] = m[0 * 4 + j] + 0.5f * (m[1 * 4 + j] + m[2 * 4 + j]);
+    p[1][j] = 0.5f * (m[1 * 4 + j] - m[2 * 4 + j]);
+    p[2][j] = 0.5f * (m[1 * 4 + j] + m[2 * 4 + j]) + m[3 * 4 + j];
+  }
+  float* out = dw + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    out[u * 3 + 0] += p[u][0] + 0.5f * (p[u][1] + p[u][2]);
+    out[u * 3 + 1] += 0.5f * (p[u][1] - p[u][2]);
+    out[u * 3 + 2] += 0.5f * (p[u][1] + p[u][2]) + p[u][3];
+  }
+}
+
 // OIHW 3x3 weights -> U = G g G^T in the LDS image of conv_wino_kernel: [cob][chunk][component][g][h][64][4].
 // transpose_flip: the data-gradient convolution (input channels = Cout_w, output = Cin_w, taps mirrored).
 __global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout_w, int Cin_w,

@@ -376,6 +376,20 @@ static int launch_wgrad_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
+template <int IN_MODE, bool WIDE>
+static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) {
+  using G = WgradWinoGeom<WIDE>;
+  static bool attr_set = false;
+  auto kern = wgrad_wino_kernel<IN_MODE, WIDE>;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), G::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 struct WgradCall {
   const float* in; int in_cs, in_co, cin;
   const float* dout; int dout_cs, dout_co, cout;
@@ -395,13 +409,15 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.Cout = c.cout; a.dout_cs = c.dout_cs; a.dout_co = c.dout_co;
   a.nprob = c.nprob; a.in2 = c.in2; a.dout2 = c.dout2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
   const bool wide = (c.W % 32) == 0;
-  const int TH = wide ? 2 : 8, TW = wide ? 32 : 8;
+  // Winograd F(3x3,2x2): 3x3 filters on even-sized maps with a prefetchable (non-pooled) input
+  const bool wino = g_conv_algo == 1 && c.ks == 3 && c.in_mode != 2 && c.H % 2 == 0 && c.W % 2 == 0;
+  const int TH = wino ? (wide ? 4 : 16) : (wide ? 2 : 8), TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
   a.ntiles = c.N * a.tiles_x * a.tiles_y;
   a.ncib = cdiv(c.cin, 64); a.ncob = cdiv(c.cout, 64);
   const int pairs = a.ncib * a.ncob;
-  const int taps = c.ks * c.ks;
-  int nsplit = (2 * n_cu) / pairs / 8 * 8;  // 2 blocks per CU; multiple of 8: blocks sharing tiles share an XCD
+  const int taps = wino ? WC : c.ks * c.ks;  // slabs per partial block
+  int nsplit = ((wino ? 1 : 2) * n_cu) / pairs / 8 * 8;  // blocks per CU; multiple of 8: blocks sharing tiles share an XCD
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.ntiles * a.nprob) nsplit = a.ntiles * a.nprob;
   while ((size_t)pairs * nsplit * taps * 4096 > partial_floats && nsplit > 1) --nsplit;
@@ -409,9 +425,17 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.nsplit = nsplit;
   const int nblocks = pairs * nsplit;
   {
-    const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * taps;
+    const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
     const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
     ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes);
+    if (wino) {
+      if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_t<0, true>(a, nblocks, st) : launch_wgrad_wino_t<0, false>(a, nblocks, st)));
+      else CHK((wide ? launch_wgrad_wino_t<1, true>(a, nblocks, st) : launch_wgrad_wino_t<1, false>(a, nblocks, st)));
+      hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
+                         a.ncob, nsplit);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
 #define WG_CASE(KS_, M_)                                                              \
   if (c.ks == KS_ && c.in_mode == M_) {                                               \
     CHK((wide ? launch_wgrad_t<KS_, M_, 1, 32>(a, nblocks, st) : launch_wgrad_t<KS_, M_, 4, 8>(a, nblocks, st))); \
