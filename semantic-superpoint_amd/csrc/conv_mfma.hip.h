@@ -426,6 +426,7 @@ struct WgradArgs {
   int Cout, dout_cs, dout_co;
   int tiles_x, tiles_y, ntiles;  // per-image tiles and total tiles of ONE problem
   int ncib, ncob, nsplit;
+  int ablate;  // perf-debug only (wgrad_wino_kernel): 1 no global loads, 2 no LDS writes, 8 no MFMA loop, 64 no LDS reads
 };
 
 template <int KS, int SH, int SW>

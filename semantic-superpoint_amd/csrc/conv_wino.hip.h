@@ -397,31 +397,45 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
   f32x4 xreg[NX], dreg[ND];
   unsigned xmask = 0, dmask = 0;
 
+  // halo / dY raster positions of this thread's staging slots (slot i = pixel (tid >> 4) + 32 i), packed r | c << 8
+  int xrc[NX], drc[ND];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int pp = (tid >> 4) + 32 * i, r = pp / G::WT;
+    xrc[i] = pp < G::HT * G::WT ? (r | ((pp - r * G::WT) << 8)) : 0xFFFF;  // 0xFFFF: r = 255 is never inside the image
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int pp = (tid >> 4) + 32 * i, r = pp / G::TW;
+    drc[i] = r | ((pp - r * G::TW) << 8);
+  }
+  const int xpix = a.in_cs * 4, xrow = a.W * xpix, dpix = a.dout_cs * 4, drow = a.W * dpix;
+  const int xq = civalid ? (a.in_co + ci0) * 4 : -1, dq = covalid ? (a.dout_co + co0) * 4 : -1;
+  constexpr unsigned OOB = 0x80000000u;
+  // one buffer descriptor per image (32-bit offsets inside it); an offset beyond num_records returns 0
 #define WGW_ISSUE(TILE)                                                                                       \
-  {                                                                                                           \
+  if (!(a.ablate & 1)) {                                                                                      \
     const int pr_ = (TILE) >= a.ntiles ? 1 : 0;                                                               \
     const int tl_ = (TILE) - pr_ * a.ntiles;                                                                  \
-    const float* const pin_ = pr_ ? a.in2 : a.in;                                                             \
-    const float* const pdo_ = pr_ ? a.dout2 : a.dout;                                                         \
     const int tx_ = tl_ % a.tiles_x, t2_ = tl_ / a.tiles_x;                                                   \
     const int ty0_ = (t2_ % a.tiles_y) * G::TH, tx0_ = tx_ * G::TW, n_ = t2_ / a.tiles_y;                     \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
+        const_cast<float*>(pr_ ? a.in2 : a.in) + (size_t)n_ * a.H * a.W * a.in_cs, 0, a.H * xrow, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
+        const_cast<float*>(pr_ ? a.dout2 : a.dout) + (size_t)n_ * a.H * a.W * a.dout_cs, 0, a.H * drow, 0x00020000); \
     xmask = 0; dmask = 0;                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                          \
-      const int pp = (tid >> 4) + 32 * i;                                                                     \
-      const int r = pp / G::WT, c = pp - r * G::WT;                                                           \
-      const int gy = ty0_ + r - 1, gx = tx0_ + c - 1;                                                         \
-      const bool ok = pp < G::HT * G::WT && civalid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
-      const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + ci0 : (size_t)0;     \
-      xreg[i] = *reinterpret_cast<const f32x4*>(pin_ + off);                                                  \
+      const int gy = ty0_ - 1 + (xrc[i] & 255), gx = tx0_ - 1 + (xrc[i] >> 8);                                \
+      const bool ok = xq >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;                \
+      xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
+          rx_, ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB, 0, 0));                                     \
       xmask |= (ok ? 1u : 0u) << i;                                                                           \
     }                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                          \
-      const int pp = (tid >> 4) + 32 * i;                                                                     \
-      const int r = pp / G::TW, c = pp - r * G::TW;                                                           \
-      const int gy = ty0_ + r, gx = tx0_ + c;                                                                 \
-      const bool ok = covalid && gy < a.H && gx < a.W;                                                        \
-      const size_t off = ok ? ((size_t)(n_ * a.H + gy) * a.W + gx) * a.dout_cs + a.dout_co + co0 : (size_t)0; \
-      dreg[i] = *reinterpret_cast<const f32x4*>(pdo_ + off);                                                  \
+      const int gy = ty0_ + (drc[i] & 255), gx = tx0_ + (drc[i] >> 8);                                        \
+      const bool ok = dq >= 0 && gy < a.H && gx < a.W;                                                        \
+      dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
+          rd_, ok ? (unsigned)(gy * drow + gx * dpix + dq) : OOB, 0, 0));                                     \
       dmask |= (ok ? 1u : 0u) << i;                                                                           \
     }                                                                                                         \
   }
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
   if (t_begin < t_end) WGW_ISSUE(t_begin)
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // all waves finished reading the previous tile's LDS image
-    {
+    if (!(a.ablate & 2)) {
       const int cur_prob = tile >= a.ntiles ? 1 : 0;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (IN_MODE != 0) {
@@ -472,6 +486,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
       WGW_ISSUE(nxt)
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (!(a.ablate & 8))
 #pragma unroll 2
     for (int s = 0; s < 16; ++s) {
       const int t = 2 * s + lh;  // K index -> Winograd tile of this block tile

@@ -408,9 +408,12 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.cin; a.in_cs = c.in_cs; a.in_co = c.in_co;
   a.Cout = c.cout; a.dout_cs = c.dout_cs; a.dout_co = c.dout_co;
   a.nprob = c.nprob; a.in2 = c.in2; a.dout2 = c.dout2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
+  a.ablate = g_dbg_ablate;
   const bool wide = (c.W % 32) == 0;
   // Winograd F(3x3,2x2): 3x3 filters on even-sized maps with a prefetchable (non-pooled) input
   const bool wino = g_conv_algo == 1 && c.ks == 3 && c.in_mode != 2 && c.H % 2 == 0 && c.W % 2 == 0;
+  if (wino && ((double)c.H * c.W * std::max(c.in_cs, c.dout_cs) * 4.0 > 2147483647.0))
+    return fail(-3, "wgrad: one image [%d,%d,%d] exceeds 2 GiB", c.H, c.W, std::max(c.in_cs, c.dout_cs));
   const int TH = wino ? (wide ? 4 : 16) : (wide ? 2 : 8), TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
   a.ntiles = c.N * a.tiles_x * a.tiles_y;
