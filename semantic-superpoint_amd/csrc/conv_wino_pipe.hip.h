@@ -1,0 +1,411 @@
+// Winograd F(2x2, 3x3) convolution, software-pipelined variant of conv_wino_kernel (same math, same tile / wave
+// decomposition, see conv_wino.hip.h): the K loop runs in 8-channel STAGES with double-buffered LDS images, so that
+// the staging of stage g+1 is interleaved with the MFMAs of stage g instead of stalling the matrix pipe:
+//
+//   stage g, first half : 16 MFMAs / wave on (sA[g&1], sB[g&1])  ||  raw halo (g+1) -> sR, weights (g+1) -> sB[~g&1],
+//                                                                    global loads of stage g+2 into the freed registers
+//   barrier
+//   stage g, second half: 16 MFMAs / wave                          ||  transform sR -> sA[~g&1]
+//   barrier
+//
+// LDS: 2 x (32 KB transformed input + 32 KB transformed weights) + 10.6 KB raw halo = 138.6 KB, one block per CU.
+// The flat stage index runs over (tile, 8-channel chunk) pairs of the block's persistent tile list, so the pipeline
+// never drains between tiles; the tile epilogue (output transform, the two component halves meeting in ONE 64 KB
+// staging tile = the just-consumed sA/sB pair, 16-byte stores, BatchNorm sums) sits between two stages.
+// Weights: pack_weights_wino8_kernel, [cob][chunk8][component][h][64][4].
+#pragma once
+#include "conv_wino.hip.h"
+
+namespace sspk {
+
+constexpr int PK = 8;                              // channels per stage
+constexpr int PA_FLOATS = WC * WTILES * PK;        // 8192 floats = 32 KB
+constexpr int PB_FLOATS = WC * PK * NB;            // 8192 floats = 32 KB
+constexpr int PR_FLOATS = WHALO * PK;              // 2720 floats
+constexpr int PIPE_LDS_BYTES = (2 * (PA_FLOATS + PB_FLOATS) + PR_FLOATS) * 4;
+
+// raw halo pixel p (raster index), quad q (0/1) -> float offset in sR: 4 pixels share a 128-byte row and are rotated by
+// the row index, so that the stride-2 pixel reads of the transform hit 4 different 32-byte slots
+__device__ __forceinline__ int pipe_raw_off(int p, int q) { return ((p & ~3) + ((p + (p >> 2)) & 3)) * PK + q * 4; }
+
+template <int IN_MODE, bool WIDE>
+__global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const ConvArgs a) {
+  constexpr int TTX = WIDE ? 16 : 4;
+  constexpr int TH = WIDE ? 8 : 32, TW = WIDE ? 32 : 8;
+  constexpr int HC = TW + 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // [sA0][sB0][sA1][sB1][sR]: each (sA, sB) pair doubles as the 64 KB output staging tile of the epilogue
+  float* const sR = smem + 2 * (PA_FLOATS + PB_FLOATS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int chalf = wave & 1, nt = (wave >> 1) & 1, mt = wave >> 2;
+
+  // ---- work assignment (as conv_mfma_kernel) ----
+  const int nslot = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_cob = nslot / a.ncob;
+  const int cob = slot % a.ncob, jj = slot / a.ncob;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const int xpp = 8 / a.nprob;
+  const int prob = xcd / xpp, xl = xcd - prob * xpp;
+  const int per_t = (ntiles + xpp - 1) / xpp;
+  const int t_end = min(ntiles, (xl + 1) * per_t);
+  const int tile0 = xl * per_t + jj;
+  if (jj >= per_cob || tile0 >= t_end) return;
+  const float* const p_in = prob ? a.in2 : a.in;
+  float* const p_out = prob ? a.out2 : a.out;
+  const float* const p_scale = prob ? a.in_scale2 : a.in_scale;
+  const float* const p_shift = prob ? a.in_shift2 : a.in_shift;
+  double* const p_stats = prob ? a.stats2 : a.stats;
+  const int nst = a.Cin / PK;                                  // stages per tile
+  const int my_tiles = (t_end - tile0 + per_cob - 1) / per_cob;
+  const int nstages = my_tiles * nst;
+
+  // ---- staging roles ----
+  const int q2 = tid & 1;
+  // raw halo items tid + 512 k (k < 2), item = pixel * 2 + quad
+  int rrc[2], r_lds[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = (tid + WINO_THREADS * k) >> 1, r = p / HC, c = p - r * HC;
+    rrc[k] = r | (c << 8);
+    r_lds[k] = pipe_raw_off(p, q2);
+  }
+  const bool r1 = tid + WINO_THREADS < WHALO * 2;  // the second item exists
+  // transform: (quad, tile, V row)
+  const int t_tile = (tid >> 1) & 63, t_row = tid >> 7;
+  const int t_ty = t_tile / TTX, t_tx = t_tile % TTX;
+  const int t_ra = t_row == 0 ? 0 : t_row == 2 ? 2 : 1;   // T[i] = d[ra] + sg d[rb]
+  const int t_rb = t_row == 2 ? 1 : t_row == 3 ? 3 : 2;
+  const float t_sg = t_row == 1 ? 1.f : -1.f;
+  const int t_dst = ((t_row * 4) * WTILES + t_tile) * PK + ((q2 ^ ((t_tile >> 2) & 1)) << 2);
+  const int pixb = a.in_cs * 4, rowb = a.W * pixb;
+  f32x4 hreg[2], wreg[4];
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned hoff[2] = {OOB, OOB};
+  const size_t img_floats = (size_t)a.H * a.W * a.in_cs;
+  __amdgpu_buffer_rsrc_t rsrc_in;
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
+
+  // load cursor: the (tile, chunk) whose global loads are issued next
+  int ld_tile = tile0, ld_chunk = 0;
+#define PIPE_ISSUE_LOADS()                                                                                  \
+  {                                                                                                         \
+    if (ld_chunk == 0) {                                                                                    \
+      const int tt_ = min(ld_tile, t_end - 1);  /* past the end: harmless redundant loads of the last tile */ \
+      const int tx_ = tt_ % a.tiles_x, t2_ = tt_ / a.tiles_x;                                               \
+      const int ty0_ = (t2_ % a.tiles_y) * TH, tx0_ = tx_ * TW, n_ = t2_ / a.tiles_y;                       \
+      _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                       \
+        const int gy = ty0_ - 1 + (rrc[k] & 255), gx = tx0_ - 1 + (rrc[k] >> 8);                            \
+        const bool ok = (k == 0 || r1) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;     \
+        hoff[k] = ok ? (unsigned)(gy * rowb + gx * pixb + (a.in_co + q2 * 4) * 4) : OOB;                    \
+      }                                                                                                     \
+      rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in) + (size_t)n_ * img_floats, 0,    \
+                                                  a.in_bytes, 0x00020000);                                  \
+    }                                                                                                       \
+    if (IN_MODE != 0) {                                                                                     \
+      psc = *reinterpret_cast<const f32x4*>(p_scale + ld_chunk * PK + q2 * 4);                              \
+      psh = *reinterpret_cast<const f32x4*>(p_shift + ld_chunk * PK + q2 * 4);                              \
+    }                                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                           \
+      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], ld_chunk * PK * 4, 0)); \
+    const int wbase_ = (cob * nst + ld_chunk) * PB_FLOATS * 4;                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
+      wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 8192, 0)); \
+    if (++ld_chunk == nst) { ld_chunk = 0; ld_tile += per_cob; }                                            \
+  }
+  // registers -> LDS for the stage whose loads are in the registers (buffer index B)
+#define PIPE_WRITE_STAGE(B)                                                                                 \
+  {                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                         \
+      if (k == 0 || r1) {                                                                                   \
+        f32x4 v = hreg[k];                                                                                  \
+        if (IN_MODE != 0) {                                                                                 \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], psc[e], psh[e]), 0.f);      \
+          if (hoff[k] == OOB) v = f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+        }                                                                                                   \
+        *reinterpret_cast<f32x4*>(sR + r_lds[k]) = v;                                                       \
+      }                                                                                                     \
+    }                                                                                                       \
+    f32x4* wdst = reinterpret_cast<f32x4*>(smem + (B) * (PA_FLOATS + PB_FLOATS) + PA_FLOATS);               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];                   \
+  }
+  // MFMA fragment offsets (floats, relative to the buffer base)
+  const int m_tile = mt * 32 + li;
+  const int a_off = (chalf * 8 * WTILES + m_tile) * PK + ((lh ^ ((m_tile >> 2) & 1)) << 2);
+  const int b_off = PA_FLOATS + ((chalf * 8 * 2 + lh) * NB + nt * 32 + li) * 4;
+
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+  const int co_l = cob * NB + nt * 32 + li;
+  const float bias_v = (a.bias != nullptr && co_l < a.Cout) ? a.bias[co_l] : 0.f;
+
+  // transform source offsets of the two raw rows of this thread's V row (the rotation depends on the raster index)
+  int t_u[4], t_w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t_u[j] = pipe_raw_off((2 * t_ty + t_ra) * HC + 2 * t_tx + j, q2);
+    t_w[j] = pipe_raw_off((2 * t_ty + t_rb) * HC + 2 * t_tx + j, q2);
+  }
+  // one V row (4 components) of (tile, quad): sR -> sA of buffer B
+#define PIPE_TRANSFORM(B)                                                                                   \
+  {                                                                                                         \
+    f32x4 t[4];                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+      const f32x4 u = *reinterpret_cast<const f32x4*>(sR + t_u[j]);                                         \
+      const f32x4 w = *reinterpret_cast<const f32x4*>(sR + t_w[j]);                                         \
+      t[j] = u + t_sg * w;                                                                                  \
+    }                                                                                                       \
+    float* d_ = smem + (B) * (PA_FLOATS + PB_FLOATS) + t_dst;                                               \
+    *reinterpret_cast<f32x4*>(d_ + 0 * WTILES * PK) = t[0] - t[2];                                          \
+    *reinterpret_cast<f32x4*>(d_ + 1 * WTILES * PK) = t[1] + t[2];                                          \
+    *reinterpret_cast<f32x4*>(d_ + 2 * WTILES * PK) = t[2] - t[1];                                          \
+    *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = t[1] - t[3];                                          \
+  }
+
+  // ---- prologue: stage 0 into buffer 0, loads of stage 1 in flight ----
+  PIPE_ISSUE_LOADS()
+  PIPE_WRITE_STAGE(0)
+  __syncthreads();
+  PIPE_TRANSFORM(0)
+  PIPE_ISSUE_LOADS()
+  __syncthreads();
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  // components C and C + 1 of this wave's half: fragment reads, then 2 x 4 MFMAs on two alternating accumulators.
+  // The staging work of the next stage is sliced BETWEEN the MFMA groups (fenced with sched_barrier so that the
+  // compiler keeps the order): a wave that has just issued an MFMA group owns the issue slots of the ~250 cycles the
+  // matrix pipe needs for it and for the group of the other wave of its SIMD.
+#define PIPE_FRAG(C)                                                                                        \
+  const float4 a0_##C = *reinterpret_cast<const float4*>(cA + a_off + (C) * WTILES * PK);                   \
+  const float4 a1_##C = *reinterpret_cast<const float4*>(cA + a_off + ((C) + 1) * WTILES * PK);             \
+  const float4 b0_##C = *reinterpret_cast<const float4*>(cA + b_off + (C) * 2 * NB * 4);                    \
+  const float4 b1_##C = *reinterpret_cast<const float4*>(cA + b_off + ((C) + 1) * 2 * NB * 4);
+#define PIPE_MFMA_LO(C)                                                                                     \
+  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.x, b0_##C.x, acc[C], 0, 0, 0);                       \
+  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.x, b1_##C.x, acc[(C) + 1], 0, 0, 0);           \
+  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.y, b0_##C.y, acc[C], 0, 0, 0);                       \
+  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.y, b1_##C.y, acc[(C) + 1], 0, 0, 0);
+#define PIPE_MFMA_HI(C)                                                                                     \
+  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.z, b0_##C.z, acc[C], 0, 0, 0);                       \
+  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.z, b1_##C.z, acc[(C) + 1], 0, 0, 0);           \
+  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.w, b0_##C.w, acc[C], 0, 0, 0);                       \
+  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.w, b1_##C.w, acc[(C) + 1], 0, 0, 0);
+#define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  int tile = tile0, chunk = 0;
+  for (int g = 0; g < nstages; ++g) {
+    const int buf = g & 1;
+    const float* const cA = smem + buf * (PA_FLOATS + PB_FLOATS);
+    float* const nB = smem + (buf ^ 1) * (PA_FLOATS + PB_FLOATS);
+    // ---- first half: components 0..3 of this wave's half || registers (stage g+1) -> LDS, loads of stage g+2 ----
+    {
+      PIPE_FRAG(0)
+      PIPE_FENCE();
+      PIPE_MFMA_LO(0)
+      PIPE_FENCE();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {  // raw halo of stage g+1 -> sR (BatchNorm + ReLU of the producer, zero padding)
+        if (k == 0 || r1) {
+          f32x4 v = hreg[k];
+          if (IN_MODE != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], psc[e], psh[e]), 0.f);
+            if (hoff[k] == OOB) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          *reinterpret_cast<f32x4*>(sR + r_lds[k]) = v;
+        }
+      }
+      PIPE_FENCE();
+      PIPE_MFMA_HI(0)
+      PIPE_FENCE();
+      PIPE_FRAG(2)
+      f32x4* wdst = reinterpret_cast<f32x4*>(nB + PA_FLOATS);  // weights of stage g+1 -> sB of the other buffer
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];
+      PIPE_FENCE();
+      PIPE_MFMA_LO(2)
+      PIPE_FENCE();
+      PIPE_ISSUE_LOADS()
+      PIPE_FENCE();
+      PIPE_MFMA_HI(2)
+    }
+    __syncthreads();
+    // ---- second half: components 4..7 || transform of stage g+1: sR -> sA of the other buffer ----
+    {
+      PIPE_FRAG(4)
+      f32x4 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(sR + t_u[j]);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sR + t_w[j]);
+        t[j] = u + t_sg * w;
+      }
+      PIPE_FENCE();
+      PIPE_MFMA_LO(4)
+      PIPE_FENCE();
+      float* d_ = nB + t_dst;
+      *reinterpret_cast<f32x4*>(d_ + 0 * WTILES * PK) = t[0] - t[2];
+      *reinterpret_cast<f32x4*>(d_ + 1 * WTILES * PK) = t[1] + t[2];
+      PIPE_FENCE();
+      PIPE_MFMA_HI(4)
+      PIPE_FENCE();
+      PIPE_FRAG(6)
+      *reinterpret_cast<f32x4*>(d_ + 2 * WTILES * PK) = t[2] - t[1];
+      *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = t[1] - t[3];
+      PIPE_FENCE();
+      PIPE_MFMA_LO(6)
+      PIPE_MFMA_HI(6)
+    }
+    __syncthreads();
+
+    if (++chunk == nst) {
+      // ---- tile epilogue: the consumed (sA, sB) pair of this stage is the 64 KB staging tile ----
+      const int tx_i = tile % a.tiles_x, t2 = tile / a.tiles_x;
+      const int ty0 = (t2 % a.tiles_y) * TH, tx0 = tx_i * TW, n = t2 / a.tiles_y;
+      const bool full = (ty0 + TH <= a.H) && (tx0 + TW <= a.W);
+      float* const stg = smem + buf * (PA_FLOATS + PB_FLOATS);
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == chalf) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int sl = mt * 32 + m;
+            const int ty = sl / TTX, tx = sl % TTX;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (chalf == 0) {
+                s0[j] = acc[j][r] + acc[4 + j][r];
+                s1[j] = acc[4 + j][r];
+              } else {
+                s0[j] = acc[j][r];
+                s1[j] = -acc[j][r] - acc[4 + j][r];
+              }
+            }
+            float* o = stg + ((2 * ty) * TW + 2 * tx) * NB + nt * 32 + li;
+            const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+            const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            if (pass == 0) {
+              o[0] = y00 + bias_v;
+              o[NB] = y01 + bias_v;
+              o[TW * NB] = y10 + bias_v;
+              o[TW * NB + NB] = y11 + bias_v;
+            } else {
+              o[0] += y00;
+              o[NB] += y01;
+              o[TW * NB] += y10;
+              o[TW * NB + NB] += y11;
+            }
+          }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+      const int q16 = tid & 15;
+      const int co4 = cob * NB + q16 * 4;
+      const int nvalid = min(4, a.Cout - co4);
+#pragma unroll 4
+      for (int k = 0; k < (TH * TW * 16) / WINO_THREADS; ++k) {
+        const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
+        const int orow = lp / TW, ocol = lp - orow * TW;
+        const int oy = ty0 + orow, ox = tx0 + ocol;
+        if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(stg + lp * NB + q16 * 4);
+          ssum += v;
+          ssq += v * v;
+          float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
+          if (nvalid == 4) {
+            *reinterpret_cast<f32x4*>(p) = v;
+          } else {
+            p[0] = v[0];
+            if (nvalid > 1) p[1] = v[1];
+            if (nvalid > 2) p[2] = v[2];
+          }
+        }
+      }
+      __syncthreads();  // the staging tile is the next-but-one stage's (sA, sB) image
+      chunk = 0;
+      tile += per_cob;
+    }
+  }
+#undef PIPE_ISSUE_LOADS
+#undef PIPE_WRITE_STAGE
+#undef PIPE_TRANSFORM
+#undef PIPE_FRAG
+#undef PIPE_MFMA_LO
+#undef PIPE_MFMA_HI
+#undef PIPE_FENCE
+
+  if (p_stats != nullptr) {
+    __syncthreads();
+    float* red = smem;
+    *reinterpret_cast<f32x4*>(red + tid * 8) = ssum;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = ssq;
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid >> 1, which = tid & 1;
+      float t = 0.f;
+      for (int gq = 0; gq < WINO_THREADS / 16; ++gq) t += red[(gq * 16 + (ch >> 2)) * 8 + which * 4 + (ch & 3)];
+      const int co = cob * NB + ch;
+      if (co < a.Cout)
+        unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
+    }
+  }
+}
+
+// OIHW 3x3 weights -> U = G g G^T in the LDS image of conv_wino_pipe_kernel: [cob][chunk8][component][h][64][4]
+__global__ void pack_weights_wino8_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout_w, int Cin_w,
+                                          int transpose_flip, int nchunks_total, int chunk_off, int cob_off, int ncob,
+                                          int nchunks) {
+  const int per_chunk = PB_FLOATS;
+  const int total = ncob * nchunks * per_chunk;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int t = idx;
+  const int e = t & 3;
+  t >>= 2;
+  const int nn = t & 63;
+  t >>= 6;
+  const int h = t & 1;
+  t >>= 1;
+  const int comp = t % WC;
+  t /= WC;
+  const int chunk = t % nchunks;
+  const int cob = t / nchunks;
+  const int co = cob * NB + nn;
+  const int ci = chunk * PK + h * 4 + e;
+  float k[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float v = 0.f;
+      if (!transpose_flip) {
+        if (co < Cout_w && ci < Cin_w) v = w[(((size_t)co * Cin_w + ci) * 3 + ky) * 3 + kx];
+      } else {
+        if (co < Cin_w && ci < Cout_w) v = w[(((size_t)ci * Cin_w + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+      }
+      k[ky][kx] = v;
+    }
+  const int i = comp >> 2, j = comp & 3;
+  float r[3];
+#pragma unroll
+  for (int x = 0; x < 3; ++x)
+    r[x] = i == 0 ? k[0][x] : i == 1 ? 0.5f * (k[0][x] + k[1][x] + k[2][x]) : i == 2 ? 0.5f * (k[0][x] - k[1][x] + k[2][x]) : k[2][x];
+  const float u = j == 0 ? r[0] : j == 1 ? 0.5f * (r[0] + r[1] + r[2]) : j == 2 ? 0.5f * (r[0] - r[1] + r[2]) : r[2];
+  dst[((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * per_chunk + ((comp * 2 + h) * NB + nn) * 4 + e] = u;
+}
+
+}  // namespace sspk

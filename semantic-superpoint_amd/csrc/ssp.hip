@@ -16,6 +16,7 @@
 #include "bn_kernels.hip.h"
 #include "conv_mfma.hip.h"
 #include "conv_wino.hip.h"
+#include "conv_wino_pipe.hip.h"
 #include "loss_kernels.hip.h"
 #include "pair_kernels.hip.h"
 #include "export_kernels.hip.h"
@@ -25,9 +26,11 @@ using namespace sspk;
 
 static thread_local std::string g_err;
 static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_kernel (tools/ablate_conv.py)
-static int g_conv_algo = 1;  // ssp_set_conv_algo: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) where eligible
+// ssp_set_conv_algo: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) where eligible (software-pipelined kernel),
+// 2 = Winograd, un-pipelined kernel (conv_wino_kernel; kept for A/B measurements)
+static int g_conv_algo = 1;
 // 3x3 convolutions whose input channels fill whole 16-channel K-chunks run as Winograd F(2x2,3x3)
-static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo == 1 && ks == 3 && conv_cin % CK == 0; }
+static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks == 3 && conv_cin % CK == 0; }
 static inline int pk_taps(int ks) { return ks == 3 ? WC : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
 static int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -300,6 +303,19 @@ struct ConvCall {
 };
 
 template <int IN_MODE, bool WIDE>
+static int launch_wino_pipe_t(const ConvArgs& a, int nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_wino_pipe_kernel<IN_MODE, WIDE>;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), PIPE_LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int IN_MODE, bool WIDE>
 static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   static bool attr_set = false;
   auto kern = conv_wino_kernel<IN_MODE, WIDE>;
@@ -349,6 +365,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
       c.cin == 64)
     fam = SSP_PROF_CONV_BIG_FWD;
   ProfScope ps(h, fam, st, flops, bytes);
+  if (c.wino && g_conv_algo == 1) {
+    if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true>(a, nblocks, st) : launch_wino_pipe_t<0, false>(a, nblocks, st);
+    return wide ? launch_wino_pipe_t<1, true>(a, nblocks, st) : launch_wino_pipe_t<1, false>(a, nblocks, st);
+  }
   if (c.wino) {
     if (c.in_mode == 0) return wide ? launch_wino_t<0, true>(a, nblocks, st) : launch_wino_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_t<1, true>(a, nblocks, st) : launch_wino_t<1, false>(a, nblocks, st);
@@ -411,7 +431,7 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.ablate = g_dbg_ablate;
   const bool wide = (c.W % 32) == 0;
   // Winograd F(3x3,2x2): 3x3 filters on even-sized maps with a prefetchable (non-pooled) input
-  const bool wino = g_conv_algo == 1 && c.ks == 3 && c.in_mode != 2 && c.H % 2 == 0 && c.W % 2 == 0;
+  const bool wino = g_conv_algo != 0 && c.ks == 3 && c.in_mode != 2 && c.H % 2 == 0 && c.W % 2 == 0;
   if (wino && ((double)c.H * c.W * std::max(c.in_cs, c.dout_cs) * 4.0 > 2147483647.0))
     return fail(-3, "wgrad: one image [%d,%d,%d] exceeds 2 GiB", c.H, c.W, std::max(c.in_cs, c.dout_cs));
   const int TH = wino ? (wide ? 4 : 16) : (wide ? 2 : 8), TW = wide ? 32 : 8;
@@ -460,8 +480,12 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   const int nchunks = cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
   if (wino) {
     const int total = ncob * nchunks * WB_FLOATS;
-    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
-                       nchunks, 0, 0, ncob, nchunks);
+    if (g_conv_algo == 1)  // 8-channel stages of the pipelined kernel: twice as many chunks of half the size
+      hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
+                         2 * nchunks, 0, 0, ncob, 2 * nchunks);
+    else
+      hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
+                         nchunks, 0, 0, ncob, nchunks);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -609,7 +633,10 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
     const bool wino = wino_ok(3, 256 * h->nheads);
     const int total = 2 * 16 * (wino ? WC : 9) * CK * NB;
     for (int k = 0; k < h->nheads; ++k) {
-      if (wino)
+      if (wino && g_conv_algo == 1)
+        hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
+                           P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
+      else if (wino)
         hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 16 * h->nheads, 16 * k, 0, 2, 16);
       else
@@ -1301,7 +1328,8 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo != 0 && algo != 1) return fail(-1, "conv algo must be 0 (direct implicit GEMM) or 1 (Winograd F(2x2,3x3))");
+  if (algo < 0 || algo > 2)
+    return fail(-1, "conv algo must be 0 (direct implicit GEMM), 1 (Winograd, pipelined) or 2 (Winograd, un-pipelined)");
   g_conv_algo = algo;
   return 0;
 }
