@@ -237,20 +237,24 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       PIPE_FENCE();
       PIPE_MFMA_HI(2)
     }
+    // the fragments of components 4, 5 come from the SAME buffer: read them before the barrier so that the matrix pipe
+    // restarts right after it
+    PIPE_FRAG(4)
     __syncthreads();
     // ---- second half: components 4..7 || transform of stage g+1: sR -> sA of the other buffer ----
     {
-      PIPE_FRAG(4)
-      f32x4 t[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(sR + t_u[j]);
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sR + t_w[j]);
-        t[j] = u + t_sg * w;
-      }
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(sR + t_u[0]), w0 = *reinterpret_cast<const f32x4*>(sR + t_w[0]);
+      const f32x4 u1 = *reinterpret_cast<const f32x4*>(sR + t_u[1]), w1 = *reinterpret_cast<const f32x4*>(sR + t_w[1]);
+      const f32x4 u2 = *reinterpret_cast<const f32x4*>(sR + t_u[2]), w2 = *reinterpret_cast<const f32x4*>(sR + t_w[2]);
+      const f32x4 u3 = *reinterpret_cast<const f32x4*>(sR + t_u[3]), w3 = *reinterpret_cast<const f32x4*>(sR + t_w[3]);
       PIPE_FENCE();
       PIPE_MFMA_LO(4)
       PIPE_FENCE();
+      f32x4 t[4];
+      t[0] = u0 + t_sg * w0;
+      t[1] = u1 + t_sg * w1;
+      t[2] = u2 + t_sg * w2;
+      t[3] = u3 + t_sg * w3;
       float* d_ = nB + t_dst;
       *reinterpret_cast<f32x4*>(d_ + 0 * WTILES * PK) = t[0] - t[2];
       *reinterpret_cast<f32x4*>(d_ + 1 * WTILES * PK) = t[1] + t[2];
