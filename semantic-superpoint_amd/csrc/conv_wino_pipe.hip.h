@@ -275,71 +275,68 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       const int tx_i = tile % a.tiles_x, t2 = tile / a.tiles_x;
       const int ty0 = (t2 % a.tiles_y) * TH, tx0 = tx_i * TW, n = t2 / a.tiles_y;
       const bool full = (ty0 + TH <= a.H) && (tx0 + TW <= a.W);
-      float* const stg = smem + buf * (PA_FLOATS + PB_FLOATS);
+      // Two rounds over the tile halves (bit 4 of the tile slot = accumulator registers 0..7 / 8..15): in each round
+      // BOTH component halves write their partial outputs of 32 tiles to two 32 KB staging half-tiles, which meet in
+      // the 16-byte store loop.  Compact tile index csl = (sl & 15) | (sl >> 5) << 4.
+      float* const stg = smem + buf * (PA_FLOATS + PB_FLOATS) + chalf * (TH * TW * NB / 2);
+      const float bz = chalf == 0 ? bias_v : 0.f;
+      const int q16 = tid & 15;
+      const int co4 = cob * NB + q16 * 4;
+      const int nvalid = min(4, a.Cout - co4);
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        if (pass == chalf) {
+      for (int rd = 0; rd < 2; ++rd) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int sl = mt * 32 + m;
-            const int ty = sl / TTX, tx = sl % TTX;
-            float s0[4], s1[4];
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = rd * 8 + r8;
+          const int csl = ((r8 & 3) + 8 * (r8 >> 2) + 4 * lh) | (mt << 4);
+          const int cty = csl / TTX, ctx = csl % TTX;
+          float s0[4], s1[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (chalf == 0) {
-                s0[j] = acc[j][r] + acc[4 + j][r];
-                s1[j] = acc[4 + j][r];
-              } else {
-                s0[j] = acc[j][r];
-                s1[j] = -acc[j][r] - acc[4 + j][r];
-              }
-            }
-            float* o = stg + ((2 * ty) * TW + 2 * tx) * NB + nt * 32 + li;
-            const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-            const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-            if (pass == 0) {
-              o[0] = y00 + bias_v;
-              o[NB] = y01 + bias_v;
-              o[TW * NB] = y10 + bias_v;
-              o[TW * NB + NB] = y11 + bias_v;
+          for (int j = 0; j < 4; ++j) {
+            if (chalf == 0) {
+              s0[j] = acc[j][r] + acc[4 + j][r];
+              s1[j] = acc[4 + j][r];
             } else {
-              o[0] += y00;
-              o[NB] += y01;
-              o[TW * NB] += y10;
-              o[TW * NB + NB] += y11;
+              s0[j] = acc[j][r];
+              s1[j] = -acc[j][r] - acc[4 + j][r];
+            }
+          }
+          float* o = stg + ((2 * cty) * TW + 2 * ctx) * NB + nt * 32 + li;
+          o[0] = s0[0] + s0[1] + s0[2] + bz;
+          o[NB] = s0[1] - s0[2] - s0[3] + bz;
+          o[TW * NB] = s1[0] + s1[1] + s1[2] + bz;
+          o[TW * NB + NB] = s1[1] - s1[2] - s1[3] + bz;
+        }
+        __syncthreads();
+        const float* const s0p = smem + buf * (PA_FLOATS + PB_FLOATS);
+#pragma unroll
+        for (int k = 0; k < (TH * TW * 8) / WINO_THREADS; ++k) {
+          const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;  // compact pixel of the half tile
+          const int crow = lp / TW, ccol = lp - crow * TW;
+          const int csl = (crow >> 1) * TTX + (ccol >> 1);
+          const int sl = (csl & 15) | (rd << 4) | ((csl >> 4) << 5);
+          const int oy = ty0 + 2 * (sl / TTX) + (crow & 1), ox = tx0 + ccol;
+          if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4) +
+                            *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4);
+            ssum += v;
+            ssq += v * v;
+            float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
+            if (nvalid == 4) {
+              *reinterpret_cast<f32x4*>(p) = v;
+            } else {
+              p[0] = v[0];
+              if (nvalid > 1) p[1] = v[1];
+              if (nvalid > 2) p[2] = v[2];
             }
           }
         }
-        __syncthreads();
+        __syncthreads();  // round 1 / the next-but-one stage overwrite the staging half-tiles
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-      const int q16 = tid & 15;
-      const int co4 = cob * NB + q16 * 4;
-      const int nvalid = min(4, a.Cout - co4);
-#pragma unroll 4
-      for (int k = 0; k < (TH * TW * 16) / WINO_THREADS; ++k) {
-        const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
-        const int orow = lp / TW, ocol = lp - orow * TW;
-        const int oy = ty0 + orow, ox = tx0 + ocol;
-        if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(stg + lp * NB + q16 * 4);
-          ssum += v;
-          ssq += v * v;
-          float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
-          if (nvalid == 4) {
-            *reinterpret_cast<f32x4*>(p) = v;
-          } else {
-            p[0] = v[0];
-            if (nvalid > 1) p[1] = v[1];
-            if (nvalid > 2) p[2] = v[2];
-          }
-        }
-      }
-      __syncthreads();  // the staging tile is the next-but-one stage's (sA, sB) image
       chunk = 0;
       tile += per_cob;
     }
