@@ -8,7 +8,7 @@ statistics), label ops, detector / sparse-descriptor (/ segmentation) losses wit
 multi-task loss, backward, gradient all-reduce (N > 1), Adam.  Rank 0 prints ONE JSON line.
 
 Workload = BASELINE.json configs[1]: SuperPointNet_gauss2, 240x320, batch 32 per GPU, fp32 (use --arch ssp for
-configs[2]).  `roofline`: conv_wino_kernel (all 3x3 forward + data-gradient launches, 2/3 of the step's FLOPs, run as
+configs[2]).  `roofline`: conv_wino_pipe_kernel (all 3x3 forward + data-gradient launches, 2/3 of the step's FLOPs, run as
 Winograd F(2x2,3x3) in fp32), algorithmic FLOPs / HIP-event time measured live on the launch stream.  `cpu_baseline`: the oracle
 (oracle/cpu_ref.py, a restatement pinned against the reference) timed on this host's cores, rank 0, N = 1 only.
 """
@@ -146,7 +146,7 @@ def main():
                     if abs(tj.get("flops_per_launch_avg_gflop", 0) - pr["flops"] / pr["launches"] / 1e9) < 0.05 * tj.get(
                             "flops_per_launch_avg_gflop", 1):
                         traffic = round(tj["hbm_bytes_per_launch"])
-                out["roofline"] = {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 forward + data-gradient, Winograd "
+                out["roofline"] = {"bound": "mfma", "kernel": "conv_wino_pipe_kernel (3x3 forward + data-gradient, Winograd "
                                                               "F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
                                    "frac": round(ach / PEAK_FP32_MFMA_TF, 4),
