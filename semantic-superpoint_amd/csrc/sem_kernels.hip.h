@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void sem_count_kernel(const int64_t* __restric
 // wave walks the 64 pixels (bilinear weights / label broadcast from the lane that owns the pixel), softmax is
 // two wave reductions per pixel, and d(convSout) of the 4 corners accumulates in 12 registers per lane that are
 // flushed with 12 atomics per lane and tile.  sem_cnt[view] must be final before a BWD launch.
-template <bool BWD>
+// MODE bit 0: accumulate the loss sum, bit 1: accumulate d(convSout); the training step does both in ONE pass (3).
+template <int MODE>
 __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ sout, const int64_t* __restrict__ labels,
                                                      float* __restrict__ dsout, StepAccum* __restrict__ acc, int view,
                                                      int B, int Hc, int Wc, int H, int W, int C, int cs) {
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
   const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int TX = Wc + 1, TY = Hc + 1;
   const long ntile = (long)B * TX * TY;
+  constexpr bool FWD = (MODE & 1) != 0, BWD = (MODE & 2) != 0;
   float nll_acc = 0.f;
   const float g = BWD ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
   for (long tile = (long)blockIdx.x * 4 + wave_in_blk; tile < ntile; tile += (long)gridDim.x * 4) {
@@ -100,12 +102,13 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
         se += e[j];
       }
       se = wave_sum(se);
-      if (!BWD) {
+      if (FWD) {
         const int lj = label >> 6;  // wave-uniform
         const float lsel = lj == 0 ? l[0] : (lj == 1 ? l[1] : l[2]);
         const float ll = __shfl(lsel, label & 63);
         nll_acc += (mx + logf(se)) - ll;  // identical in every lane; lane 0's copy is used
-      } else {
+      }
+      if (BWD) {
         const float inv = 1.f / se;
         const float w4[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
 #pragma unroll
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
         }
     }
   }
-  if (!BWD) {
+  if (FWD) {
     const float tot = block_sum_of_waves(nll_acc, red);
     if (threadIdx.x == 0) unsafeAtomicAdd(&acc->sem_sum[view], (double)tot);
   }

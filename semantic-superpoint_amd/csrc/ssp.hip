@@ -1003,11 +1003,12 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
       hipLaunchKernelGGL(sem_count_kernel, dim3(1024), dim3(256), 0, st, sems[v], npx, h->cfg.n_classes, h->accum, v);
     for (int v = 0; v < 2; ++v) {
       Slot& S = h->slot[v];
-      hipLaunchKernelGGL((sem_ce_kernel<false>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], (float*)nullptr,
-                         h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
-      if (in->train) {
+      if (in->train) {  // loss sum and d(convSout) in one pass (coef_sem: step_begin_kernel, sem_cnt: sem_count_kernel)
         HIPCHK(hipMemsetAsync(S.dsout, 0, (size_t)ncells * h->sout_cs * sizeof(float), st));
-        hipLaunchKernelGGL((sem_ce_kernel<true>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
+        hipLaunchKernelGGL((sem_ce_kernel<3>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
+                           h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
+      } else {
+        hipLaunchKernelGGL((sem_ce_kernel<1>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], (float*)nullptr,
                            h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
       }
     }
