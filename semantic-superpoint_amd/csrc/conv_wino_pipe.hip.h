@@ -22,7 +22,8 @@ constexpr int PK = 8;                              // channels per stage
 constexpr int PA_FLOATS = WC * WTILES * PK;        // 8192 floats = 32 KB
 constexpr int PB_FLOATS = WC * PK * NB;            // 8192 floats = 32 KB
 constexpr int PR_FLOATS = WHALO * PK;              // 2720 floats
-constexpr int PIPE_LDS_BYTES = (2 * (PA_FLOATS + PB_FLOATS) + PR_FLOATS) * 4;
+constexpr int PS_FLOATS = 2 * 1024;                // BatchNorm scale | shift of up to 1024 input channels
+constexpr int PIPE_LDS_BYTES = (2 * (PA_FLOATS + PB_FLOATS) + PR_FLOATS + PS_FLOATS) * 4;
 
 // raw halo pixel p (raster index), quad q (0/1) -> float offset in sR: 4 pixels share a 128-byte row and are rotated by
 // the row index, so that the stride-2 pixel reads of the transform hit 4 different 32-byte slots
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // [sA0][sB0][sA1][sB1][sR]: each (sA, sB) pair doubles as the 64 KB output staging tile of the epilogue
   float* const sR = smem + 2 * (PA_FLOATS + PB_FLOATS);
+  float* const sS = sR + PR_FLOATS;  // scale[Cin] | shift[Cin] of the producer's BatchNorm (IN_MODE 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
                                                   a.in_bytes, 0x00020000);                                  \
     }                                                                                                       \
     if (IN_MODE != 0) {                                                                                     \
-      psc = *reinterpret_cast<const f32x4*>(p_scale + ld_chunk * PK + q2 * 4);                              \
-      psh = *reinterpret_cast<const f32x4*>(p_shift + ld_chunk * PK + q2 * 4);                              \
+      psc = *reinterpret_cast<const f32x4*>(sS + ld_chunk * PK + q2 * 4);                                   \
+      psh = *reinterpret_cast<const f32x4*>(sS + 1024 + ld_chunk * PK + q2 * 4);                            \
     }                                                                                                       \
     _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                           \
       hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], ld_chunk * PK * 4, 0)); \
@@ -165,6 +167,13 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = t[1] - t[3];                                          \
   }
 
+  if (IN_MODE != 0) {
+    for (int c = tid; c < a.Cin; c += WINO_THREADS) {
+      sS[c] = p_scale[c];
+      sS[1024 + c] = p_shift[c];
+    }
+    __syncthreads();
+  }
   // ---- prologue: stage 0 into buffer 0, loads of stage 1 in flight ----
   PIPE_ISSUE_LOADS()
   PIPE_WRITE_STAGE(0)
