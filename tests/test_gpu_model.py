@@ -312,3 +312,29 @@ def test_odd_shapes_forward_and_step(B, H, W):
     gd = e.grad_dict()
     for k in ("convDb.weight", "inc.conv.conv.0.weight", "down2.mpconv.1.conv.3.weight"):
         _grad_close(gd[k].cpu(), tr.last_grads[k], k, l2=3e-2, mx=0.2)
+
+
+@pytest.mark.parametrize("algo", [0, 2])
+def test_conv_algorithms_agree_on_a_training_step(algo):
+    """ssp_set_conv_algo: the direct implicit-GEMM kernels (0) and the un-pipelined Winograd kernels (2) give the
+    losses and gradients of the default (pipelined Winograd, 1) on the same step (fp32 everywhere; only the summation
+    order / the Winograd transforms differ)."""
+    from semantic_superpoint_amd import lib as L
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    arch, B, H, W = "SuperPointNet_gauss2", 2, 64, 96
+    sd = C.init_state_dict(arch, seed=21)
+    sample = _to_dev(C.make_synthetic_pair(B, H, W, seed=6, kp_prob=0.005))
+    out = {}
+    try:
+        for a in (1, algo):
+            L.set_conv_algo(a)
+            e = _engine(arch, B, H, W, sd)
+            e.zero_grad()
+            sc = e.pair_step(sample, indices=None, seed=3, train=True)
+            torch.cuda.synchronize()
+            out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), e.grads.clone().cpu())
+    finally:
+        L.set_conv_algo(1)
+    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist"):
+        assert abs(out[1][0][name] - out[algo][0][name]) < 1e-4 * max(1.0, abs(out[1][0][name])), name
+    _grad_close(out[algo][1], out[1][1], "flat gradient, algo %d vs 1" % algo)

@@ -27,6 +27,16 @@ def _ref_input(x_nhwc, in_mode, sc, sh):
     return x
 
 
+@pytest.fixture(params=[1, 0, 2], ids=["winograd_pipelined", "direct", "winograd_unpipelined"])
+def conv_algo(request):
+    """ssp_set_conv_algo: every convolution / weight-gradient operator test runs under the three implementations
+    (1 = default: software-pipelined Winograd; 0 = direct implicit GEMM; 2 = Winograd without the software pipeline)."""
+    from semantic_superpoint_amd import lib as L
+    L.set_conv_algo(request.param)
+    yield request.param
+    L.set_conv_algo(1)
+
+
 CONV_CASES = [
     # N, H, W, cin, cout, ks, in_mode   (H,W = conv resolution; the input is 2H x 2W for in_mode 2)
     (2, 16, 64, 64, 64, 3, 1),    # wide tiles (8x32), full tiles
@@ -38,11 +48,15 @@ CONV_CASES = [
     (2, 30, 40, 256, 65, 1, 1),   # convPb: 1x1, cout tail
     (1, 4, 6, 256, 256, 1, 1),    # convDb
     (1, 16, 32, 256, 133, 1, 0),  # 1x1 raw input, wide
+    (1, 9, 11, 64, 64, 3, 1),     # odd map: partial 2x2 Winograd tiles at the right / bottom edge
+    (2, 14, 20, 32, 64, 3, 0),    # 32 input channels (four 8-channel stages), narrow partial tiles
+    (1, 8, 32, 48, 70, 3, 1),     # Cin = 48, cout tail (70 = 64 + 6)
+    (3, 10, 64, 16, 64, 3, 0),    # Cin = 16: two stages per tile, many tiles per block
 ]
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,ks,mode", CONV_CASES)
-def test_conv_forward(N, H, W, cin, cout, ks, mode):
+def test_conv_forward(N, H, W, cin, cout, ks, mode, conv_algo):
     from semantic_superpoint_amd import lib as L
     dev = _dev()
     rs = np.random.RandomState(N * 1000 + H * 10 + cout + ks + mode)
@@ -66,7 +80,7 @@ def test_conv_forward(N, H, W, cin, cout, ks, mode):
 
 @pytest.mark.parametrize("N,H,W,cin,cout,ks", [(2, 16, 32, 64, 64, 3), (1, 30, 40, 128, 256, 3), (2, 6, 8, 256, 65, 1),
                                                  (1, 8, 32, 64, 128, 3)])
-def test_conv_dgrad(N, H, W, cin, cout, ks):
+def test_conv_dgrad(N, H, W, cin, cout, ks, conv_algo):
     """data gradient = conv with transposed/flipped weights; `cin/cout` are those of the FORWARD conv."""
     from semantic_superpoint_amd import lib as L
     dev = _dev()
@@ -86,8 +100,11 @@ def test_conv_dgrad(N, H, W, cin, cout, ks):
 
 @pytest.mark.parametrize("N,H,W,cin,cout,ks,mode", [(2, 16, 64, 64, 64, 3, 1), (2, 30, 40, 128, 128, 3, 1),
                                                       (2, 8, 32, 64, 128, 3, 2), (1, 12, 24, 128, 256, 3, 0),
-                                                      (2, 30, 40, 256, 64, 1, 1), (3, 5, 8, 256, 256, 1, 0)])
-def test_conv_wgrad(N, H, W, cin, cout, ks, mode):
+                                                      (2, 30, 40, 256, 64, 1, 1), (3, 5, 8, 256, 256, 1, 0),
+                                                      (1, 9, 11, 64, 64, 3, 1),     # odd map (direct kernel)
+                                                      (2, 10, 12, 48, 70, 3, 0),    # even map, ragged tiles, tails
+                                                      (1, 36, 64, 64, 64, 3, 1)])   # several block tiles per image
+def test_conv_wgrad(N, H, W, cin, cout, ks, mode, conv_algo):
     from semantic_superpoint_amd import lib as L
     dev = _dev()
     rs = np.random.RandomState(11 + cin + cout + mode)
