@@ -307,8 +307,9 @@ def multi_task_loss(eta, det, pos, neg, sem=None):
 # --------------------------------------------------------------------------------------
 def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lambda_loss=1.0, lamda_d=1.0,
                 multi_task=True, gaussian=True, n_match=1000, n_non=100, np_rng=np.random, torch_gen=None,
-                train=True):
-    """Forward of both views + all losses.  Returns (loss, scalars dict, aux dict)."""
+                train=True, dense=None):
+    """Forward of both views + all losses.  Returns (loss, scalars dict, aux dict).
+    dense: None (sparse descriptor loss) or the dict of model.dense_loss.params (Train_model_heatmap_all.py:131-137)."""
     semantic = arch.endswith("ssmall")
     out = forward(sd, sample["image"], arch, train=train)
     out_w = forward(sd, sample["warped_img"], arch, train=train)  # separate BN statistics (:258,262)
@@ -323,7 +324,13 @@ def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lamb
     zero = torch.zeros(())
     loss_sem = sem_loss(out["sem"], sample["semantic"]) if semantic else zero
     loss_sem_w = sem_loss(out_w["sem"], sample["warped_sem"]) if semantic else zero
-    if lambda_loss > 0:
+    if lambda_loss > 0 and dense is not None:
+        # :340-350: mask_valid = the warped view's cell mask; `lambda_d` of the config is swallowed by **config
+        loss_desc, _, pos, neg = descriptor_loss_dense(
+            out["desc"], out_w["desc"], sample["homographies"], mask_valid=m3w.unsqueeze(1),
+            lamda_d=float(dense.get("lamda_d", 250)), descriptor_dist=float(dense.get("descriptor_dist", 4)))
+        used = None
+    elif lambda_loss > 0:
         loss_desc, pos, neg, used = batch_descriptor_loss_sparse(
             out["desc"], out_w["desc"], sample["homographies"], indices, lamda_d, n_match, n_non, np_rng, torch_gen)
     else:
@@ -716,3 +723,45 @@ def batch_precision_recall(batch_pred, batch_labels):
     prs = [precision_recall(batch_pred[i], batch_labels[i]) for i in range(batch_labels.shape[0])]
     return {"precision": float(np.mean([float(p["precision"]) for p in prs])),
             "recall": float(np.mean([float(p["recall"]) for p in prs]))}
+
+
+# --------------------------------------------------------------------------------------
+# Dense descriptor loss: utils/utils.py:779-893, selected by
+# model.dense_loss.enable (Train_model_heatmap_all.py:131-137, call :348-350)
+# --------------------------------------------------------------------------------------
+def descriptor_loss_dense(desc, desc_w, homographies, mask_valid=None, cell_size=8, lamda_d=250.0, descriptor_dist=4.0):
+    """desc, desc_w: [B,256,Hc,Wc]; homographies [B,3,3] (normalised, image -> warped); mask_valid [B,1,Hc,Wc] = the
+    warped view's cell mask.  Returns (loss_desc, mask [B,Hc,Wc,Hc,Wc], pos_sum, neg_sum).
+    Reference quirks kept: the shipped configs spell the weight `lambda_d`, which descriptor_loss swallows in **config,
+    so lamda_d stays at its default 250; pos_sum / neg_sum (what the multi-task loss sees) ignore mask_valid, only
+    loss_desc applies it; normalisation = B * (mask_valid.sum() + 1) * Hc * Wc ("bug in normalization", :884)."""
+    B, D, Hc, Wc = desc.shape
+    H, W = Hc * cell_size, Wc * cell_size
+    with torch.no_grad():
+        shape = torch.tensor([H, W], dtype=torch.float32)
+        cy, cx = torch.meshgrid(torch.arange(Hc), torch.arange(Wc), indexing="ij")
+        coor = torch.stack((cy, cx), dim=2).float() * cell_size + cell_size // 2  # [Hc,Wc,2] (y, x) cell centres
+        flat = coor.view(-1, 2)
+        nrm = flat / shape * 2 - 1                                               # normPts
+        xy = torch.stack((nrm[:, 1], nrm[:, 0]), dim=1)
+        pts = torch.cat((xy, torch.ones(xy.shape[0], 1)), dim=1)                 # warp_points (batched)
+        w = torch.tensordot(homographies.float(), pts.t(), dims=([2], [0])).transpose(1, 2)  # [B,N,3]
+        w = w[:, :, :2] / w[:, :, 2:]
+        wyx = torch.stack((w[:, :, 1], w[:, :, 0]), dim=2)
+        wyx = (wyx + 1) * shape / 2                                              # denormPts
+        wyx = wyx.view(B, Hc, Wc, 1, 1, 2)
+        dist = torch.norm(coor.view(1, 1, 1, Hc, Wc, 2) - wyx, dim=-1)
+        mask = (dist <= descriptor_dist).float()
+    a = desc.permute(0, 2, 3, 1).reshape(B, Hc, Wc, 1, 1, D)
+    b = desc_w.permute(0, 2, 3, 1).reshape(B, 1, 1, Hc, Wc, D)
+    dot = (a * b).sum(dim=-1)
+    pos = torch.clamp(1.0 - dot, min=0.0)
+    neg = torch.clamp(dot - 0.2, min=0.0)
+    if mask_valid is None:
+        mask_valid = torch.ones(B, 1, Hc, Wc)
+    mv = mask_valid.view(B, 1, 1, Hc, Wc)
+    normalization = B * (mv.sum() + 1) * Hc * Wc
+    loss = ((lamda_d * mask * pos + (1 - mask) * neg) * mv).sum() / normalization
+    pos_sum = (lamda_d * mask * pos / normalization).sum()
+    neg_sum = ((1 - mask) * neg / normalization).sum()
+    return loss, mask, pos_sum, neg_sum

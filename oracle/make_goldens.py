@@ -240,15 +240,25 @@ def g6_train_step():
     """G6: full train_val_sample (2 forwards + losses + backward + Adam) on the reference vs oracle."""
     cases = [("sp_64x96", "SuperPointNet_gauss2", 64, 96, dict()),
              ("ssp_64x96", "SuperPointNet_gauss2_ssmall", 64, 96, dict()),
-             ("magicpoint_32x48", "SuperPointNet_gauss2", 32, 48, dict(lambda_loss=0, warp_only_det=True))]
+             ("magicpoint_32x48", "SuperPointNet_gauss2", 32, 48, dict(lambda_loss=0, warp_only_det=True)),
+             ("sp_dense_64x96", "SuperPointNet_gauss2", 64, 96, dict(dense=True)),
+             ("sp_dense_uniform_64x96", "SuperPointNet_gauss2", 64, 96, dict(dense=True, multi_task=False))]
+    only = os.environ.get("SSP_G6_ONLY")
     for tag, arch, H, W, opt in cases:
+        if only and only not in tag:
+            continue
         semantic = arch.endswith("ssmall")
         lam = opt.get("lambda_loss", 1)
-        cfg = R.base_config(semantic=semantic, H=H, W=W, batch=2, lr=0.001, lambda_loss=lam)
+        cfg = R.base_config(semantic=semantic, H=H, W=W, batch=2, lr=0.001, lambda_loss=lam,
+                            multi_task=opt.get("multi_task", True))
+        kw = dict(lambda_loss=float(lam), multi_task=opt.get("multi_task", True))
+        if opt.get("dense"):  # the shipped spelling `lambda_d` is swallowed by descriptor_loss(**config): lamda_d = 250
+            cfg["model"]["dense_loss"] = {"enable": True, "params": {"descriptor_dist": 4, "lambda_d": 800}}
+            kw["dense"] = {"descriptor_dist": 4, "lambda_d": 800}
         sd = C.init_state_dict(arch, seed=23)
         agent = R.make_trainer(cfg, sd)
         sample = C.make_synthetic_pair(2, H, W, seed=31, semantic=semantic, kp_prob=0.01)
-        tr = C.Trainer(arch, sd, lr=0.001, lambda_loss=float(lam))
+        tr = C.Trainer(arch, sd, lr=0.001, **kw)
         steps = {}
         noisy = {conv + ".bias" for conv, bn, _, _, _ in C.layer_table(arch) if bn is not None}
         for it in range(2):
@@ -275,7 +285,7 @@ def g6_train_step():
         np.random.seed(100); torch.manual_seed(200)
         agent2.real_batch_size = 10 ** 9  # never step: leaves .grad in place
         agent2.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=1, train=True)
-        tr2 = C.Trainer(arch, sd, lr=0.001, lambda_loss=float(lam))
+        tr2 = C.Trainer(arch, sd, lr=0.001, **kw)
         tr2.real_batch_size = 10 ** 9
         np.random.seed(100); torch.manual_seed(200)
         tr2.train_val_sample(sample, n_iter=1, train=True)
@@ -293,8 +303,11 @@ def g6_train_step():
                 close(g, go, 2e-4 * scale + 1e-6, "G6 %s grad %s" % (tag, k))
             save["grad_norm/" + k] = np.float32(g.norm().item())
             save["grad_slice/" + k] = npy(g.reshape(-1)[:64])
-        save["grad/eta"] = npy(agent2.multi_task_loss.eta.grad)
-        close(agent2.multi_task_loss.eta.grad, tr2.last_grads["eta"], 1e-5, "G6 eta grad")
+        if agent2.multi_task_loss.eta.grad is not None:
+            save["grad/eta"] = npy(agent2.multi_task_loss.eta.grad)
+            close(agent2.multi_task_loss.eta.grad, tr2.last_grads["eta"], 1e-5, "G6 eta grad")
+        else:
+            assert tr2.last_grads["eta"] is None
         for i, idx in enumerate(tr2.aux["indices"] or []):
             save["idx/uv_a%d" % i] = npy(idx["uv_a"]).astype(np.int16)
             save["idx/uv_b%d" % i] = npy(idx["uv_b"]).astype(np.int16)
@@ -340,6 +353,48 @@ def g7_warps():
         save["wlabels%d" % i] = npy(lr)
         save["Hcell%d" % i] = npy(scale_homography_torch(Hs[i], (30, 40)))
     np.savez_compressed(os.path.join(OUT, "g7_warps.npz"), **save)
+
+
+def g10_dense_loss():
+    """Dense descriptor loss (utils/utils.py:779-893) with the reference's autograd gradients."""
+    R.install()
+    from utils.utils import descriptor_loss
+    for name, B, Hc, Wc, seed in (("small", 2, 6, 8, 3), ("full", 2, 30, 40, 5)):
+        rs = np.random.RandomState(seed)
+        d = rs.randn(B, 256, Hc, Wc).astype(np.float32)
+        dw = (0.8 * d + 0.6 * rs.randn(B, 256, Hc, Wc)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        dw /= np.linalg.norm(dw, axis=1, keepdims=True)
+        Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(B)]).astype(np.float32))
+        mv = torch.from_numpy((rs.uniform(size=(B, 1, Hc, Wc)) > 0.15).astype(np.float32))
+        out = {}
+        for who, fn in (("ref", lambda a, b: descriptor_loss(a, b, Hs, mask_valid=mv, device="cpu", descriptor_dist=4,
+                                                             lambda_d=800)),
+                        ("oracle", lambda a, b: C.descriptor_loss_dense(a, b, Hs, mv, lamda_d=250.0, descriptor_dist=4.0))):
+            a = torch.from_numpy(d).requires_grad_(True)
+            b = torch.from_numpy(dw).requires_grad_(True)
+            loss, mask, pos, neg = fn(a, b)
+            g_loss = torch.autograd.grad(loss, (a, b), retain_graph=True)
+            g_mt = torch.autograd.grad(0.5 * (pos + neg), (a, b))  # what the multi-task loss differentiates
+            out[who] = (loss, mask, pos, neg, g_loss, g_mt)
+        r, o = out["ref"], out["oracle"]
+        for i in (0, 2, 3):
+            close(r[i], o[i], 1e-6 * max(1.0, abs(float(r[i]))), "G10 %s scalar %d" % (name, i))
+        assert torch.equal(r[1], o[1]), "G10 mask"
+        for k in range(2):
+            close(r[4][k], o[4][k], 1e-7, "G10 grad loss")
+            close(r[5][k], o[5][k], 1e-7, "G10 grad multi-task")
+        save = dict(seed=seed, homographies=npy(Hs), mask_valid=npy(mv), loss=float(r[0]), pos_sum=float(r[2]),
+                    neg_sum=float(r[3]), mask_sum=float(r[1].sum()))
+        if name == "small":
+            save.update(desc=d, desc_w=dw, mask=npy(r[1]).astype(np.uint8), g_loss_a=npy(r[4][0]), g_loss_b=npy(r[4][1]),
+                        g_mt_a=npy(r[5][0]), g_mt_b=npy(r[5][1]))
+        else:  # inputs are regenerated from the seed (tests/golden_util.py:g10_inputs); gradients as norms + slices
+            for nm, t_ in (("g_loss_a", r[4][0]), ("g_loss_b", r[4][1]), ("g_mt_a", r[5][0]), ("g_mt_b", r[5][1])):
+                save[nm + "_norm"] = np.float32(t_.norm().item())
+                save[nm + "_slice"] = npy(t_.reshape(-1)[::977][:256])
+        np.savez_compressed(os.path.join(OUT, "g10_dense_loss_%s.npz" % name), **save)
+        print("  G10", name, "loss %.5f pos %.5f neg %.3e positives %d" % (float(r[0]), float(r[2]), float(r[3]), int(r[1].sum())))
 
 
 def g8_export():
@@ -431,7 +486,7 @@ def main():
     assert R.available(), "reference not mounted"
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging):
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss):
         fn()
         print(fn.__name__, "done")
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

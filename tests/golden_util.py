@@ -36,3 +36,14 @@ def sample_from(g):
         if k.startswith("in/"):
             s[k[3:]] = torch.from_numpy(v)
     return s
+
+
+def g10_inputs(seed, B, Hc, Wc):
+    """Regenerates the descriptor maps of g10_dense_loss_*.npz (same draws as oracle/make_goldens.py:g10_dense_loss).
+    NOTE: the generator draws the homographies and the mask AFTER the maps from the same stream; those are stored."""
+    rs = np.random.RandomState(seed)
+    d = rs.randn(B, 256, Hc, Wc).astype(np.float32)
+    dw = (0.8 * d + 0.6 * rs.randn(B, 256, Hc, Wc)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dw /= np.linalg.norm(dw, axis=1, keepdims=True)
+    return d, dw

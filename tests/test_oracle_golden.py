@@ -116,14 +116,20 @@ def test_g7_warps():
         assert (C.scale_homography(Hs[i], (30, 40)) - t(g["Hcell%d" % i])).abs().max() < 1e-5
 
 
+DENSE = {"descriptor_dist": 4, "lambda_d": 800}  # the shipped spelling; descriptor_loss swallows it: lamda_d = 250
+
+
 @pytest.mark.parametrize("tag,arch,lam", [("sp_64x96", ARCHS[0], 1.0), ("ssp_64x96", ARCHS[1], 1.0),
-                                          ("magicpoint_32x48", ARCHS[0], 0.0)])
+                                          ("magicpoint_32x48", ARCHS[0], 0.0), ("sp_dense_64x96", ARCHS[0], 1.0),
+                                          ("sp_dense_uniform_64x96", ARCHS[0], 1.0)])
 def test_g6_train_step(tag, arch, lam):
     g = G.load("g6_step_%s.npz" % tag)
     sample = G.sample_from(g)
     sd = C.init_state_dict(arch, seed=23)
-    idx = G.indices_from(g, "idx/", 2) if lam > 0 else None
-    tr = C.Trainer(arch, sd, lr=0.001, lambda_loss=lam)
+    dense = "dense" in tag
+    idx = G.indices_from(g, "idx/", 2) if lam > 0 and not dense else None
+    kw = dict(dense=DENSE, multi_task="uniform" not in tag) if dense else {}
+    tr = C.Trainer(arch, sd, lr=0.001, lambda_loss=lam, **kw)
     # the step is taken: the reference's scalar_dict holds the LIVE eta parameter, i.e. its logged
     # eta_* are post-step values (Train_model_heatmap_all.py:415-441 after :410-413)
     tr.train_val_sample(sample, n_iter=1, train=True, indices=idx)
@@ -134,6 +140,9 @@ def test_g6_train_step(tag, arch, lam):
     noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
     for k, gr in tr.last_grads.items():
         if k == "eta":
+            if gr is None:  # uniform sum: eta is not in the graph
+                assert "grad/eta" not in g
+                continue
             assert (gr - t(g["grad/eta"])).abs().max() < 1e-5
         elif gr is not None and k not in noisy:
             n = float(g["grad_norm/" + k])
@@ -208,3 +217,23 @@ def test_g9_logging_branch():
     assert np.array_equal(nms, g["nms"].astype(np.float32))
     pr = C.batch_precision_recall(t(nms[:, None]), t(g["labels"]))
     assert abs(pr["precision"] - float(g["precision"])) < 1e-7 and abs(pr["recall"] - float(g["recall"])) < 1e-7
+
+
+def test_g10_dense_descriptor_loss():
+    """Dense descriptor loss (utils/utils.py:779-893) and its autograd gradients vs the reference."""
+    g = G.load("g10_dense_loss_small.npz")
+    a = t(g["desc"]).clone().requires_grad_(True)
+    b = t(g["desc_w"]).clone().requires_grad_(True)
+    loss, mask, pos, neg = C.descriptor_loss_dense(a, b, t(g["homographies"]), t(g["mask_valid"]))
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 and abs(float(pos) - float(g["pos_sum"])) < 1e-6
+    assert abs(float(neg) - float(g["neg_sum"])) < 1e-8
+    assert np.array_equal(mask.numpy().astype(np.uint8), g["mask"])
+    ga, gb = torch.autograd.grad(loss, (a, b), retain_graph=True)
+    assert (ga - t(g["g_loss_a"])).abs().max() < 1e-7 and (gb - t(g["g_loss_b"])).abs().max() < 1e-7
+    ga, gb = torch.autograd.grad(0.5 * (pos + neg), (a, b))
+    assert (ga - t(g["g_mt_a"])).abs().max() < 1e-7 and (gb - t(g["g_mt_b"])).abs().max() < 1e-7
+    f = G.load("g10_dense_loss_full.npz")
+    d, dw = G.g10_inputs(int(f["seed"]), 2, 30, 40)
+    loss, mask, pos, neg = C.descriptor_loss_dense(t(d), t(dw), t(f["homographies"]), t(f["mask_valid"]))
+    assert abs(float(loss) - float(f["loss"])) < 1e-6 and abs(float(pos) - float(f["pos_sum"])) < 1e-6
+    assert float(mask.sum()) == float(f["mask_sum"])
