@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
+    ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
+                    help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
     args = ap.parse_args()
 
     import torch
@@ -88,7 +90,8 @@ def main():
 
     arch = "SuperPointNet_gauss2" if args.arch == "sp" else "SuperPointNet_gauss2_ssmall"
     B, H, W = args.batch, args.height, args.width
-    eng = Engine(arch, B, H, W, dev)
+    dense = {"descriptor_dist": 4, "lambda_d": 800} if args.desc_loss == "dense" else None
+    eng = Engine(arch, B, H, W, dev, dense_loss=dense is not None)
     eng.load_state_dict(synth.default_init_state_dict(layer_table(arch), seed=0))  # identical replicas
     sample = synth.make_pair(B, H, W, dev, seed=100 + rank, semantic=arch.endswith("ssmall"))
     torch.cuda.synchronize()
@@ -96,7 +99,7 @@ def main():
     def step(it):
         eng.zero_grad()
         eng.pair_step(sample, indices=None, seed=(it * 1000003 + rank * 7919 + 1), train=True, lambda_loss=1.0,
-                      lamda_d=1.0, multi_task=True)
+                      lamda_d=1.0, multi_task=True, dense=dense)
         if world > 1:  # data parallel: one all-reduce of the flat fp32 gradient bucket (incl. eta), then mean
             dist.all_reduce(eng.grads)
             eng.grads.div_(world)
@@ -129,8 +132,9 @@ def main():
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s pair step %dx%d, batch %d per GPU, fp32, sparse loss 1000x100, Adam"
-                                      % (arch, H, W, B), "parallelism": "dp%d" % world,
+               "config": {"workload": "%s pair step %dx%d, batch %d per GPU, fp32, %s, Adam"
+                                      % (arch, H, W, B, "sparse loss 1000x100" if dense is None else
+                                         "dense descriptor loss (1200x1200 per image)"), "parallelism": "dp%d" % world,
                           "global_batch": world * B},
                "step_tflops": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3, 2),
                "step_frac_of_fp32_mfma_peak": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3 / (PEAK_FP32_MFMA_TF * world), 4),

@@ -14,6 +14,7 @@
  *                       utils/utils.py:408-440, getMasks Train_model_frontend_all.py:373-386,
  *                       detector_loss :155-179, sem_loss :181-193, batch_descriptor_loss_sparse
  *                       utils/loss_functions/sparse_loss.py:267-284, MultiTaskLoss :46-77, backward)
+ *                       or, with ssp_pair_inputs.dense_loss, the dense descriptor_loss utils/utils.py:779-893
  *   ssp_adam_step    <- optimizer.step() of Train_model_frontend_all.py:183-198 (Adam, constant LR)
  *   ssp_sample_indices <- the stochastic half of descriptor_loss_sparse (sparse_loss.py:184-246,
  *                       correspondence_finder.py:191-320), device RNG
@@ -41,6 +42,8 @@ typedef struct {
   int width;     /* W, multiple of 8 */
   int n_match;   /* num_matching_attempts (1000) */
   int n_non;     /* num_masked_non_matches_per_match (100) */
+  int dense_loss; /* 1: reserve the [B, cells, cells] coefficient matrix of the dense descriptor loss
+                     (model.dense_loss.enable, utils/utils.py:779-893) in the workspace */
 } ssp_config;
 
 /* Device buffers bound once after create (all float32 unless noted).
@@ -80,6 +83,12 @@ typedef struct {
   float lamda_d;                 /* sparse_loss.params.lamda_d */
   int multi_task;                /* model.multi_task_loss */
   int train;                     /* 1: accumulate gradients; 0: forward + losses only */
+  /* dense descriptor loss instead of the sparse one (Train_model_heatmap_all.py:131-137,348-350): no indices needed.
+   * dense_lamda_d: descriptor_loss's `lamda_d` (250: the shipped configs spell it `lambda_d`, which the reference
+   * swallows in **config); descriptor_dist: dense_loss.params.descriptor_dist (4) */
+  int dense_loss;
+  float dense_lamda_d;
+  float descriptor_dist;
 } ssp_pair_inputs;
 
 /* indices into the float scalars[SSP_N_SCALARS] array filled by ssp_pair_step (the reference's
@@ -232,6 +241,15 @@ int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, siz
 int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,
                        const int32_t* match_b_dev, const int32_t* nonmatch_b_dev, int b, int hc, int wc, int n_match,
                        int n_non, float* out2_dev, void* stream);
+
+/* Dense descriptor loss as an operator (utils/utils.py:779-893) on NHWC descriptor maps [B][hc*wc][256]:
+ * out3_dev = {loss_desc, pos_sum, neg_sum}; with dda_dev / ddb_dev (both or none) also the gradients of
+ * scale * loss_desc (multi_task == 0) or scale * (pos_sum + neg_sum) (multi_task != 0) wrt both maps.
+ * scratch: 64 KiB + B * cells * cells floats when gradients are requested. */
+int ssp_op_dense_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const float* homographies_dev,
+                      const float* valid_dev, int b, int hc, int wc, float lamda_d, float descriptor_dist, int multi_task,
+                      float scale, void* scratch_dev, size_t scratch_bytes, float* out3_dev, float* dda_dev,
+                      float* ddb_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,14 +90,16 @@ class Train_model_heatmap_all(object):
         self.real_batch_size = m["real_batch_size"]
         self.max_iter = self.config["train_iter"]
         self.gaussian = bool(self.config["data"]["gaussian_label"]["enable"])
-        if m.get("dense_loss", {}).get("enable", False):
-            raise NotImplementedError("dense descriptor loss (utils/utils.py:779-893) is outside the accelerated path")
-        if not m.get("sparse_loss", {}).get("enable", False):
-            raise KeyError("model.sparse_loss.enable must be true")
-        self.desc_params = m["sparse_loss"]["params"]
-        if self.desc_params.get("method", "2d") != "2d" or self.desc_params.get("dist", "cos") != "cos":
-            raise NotImplementedError("only sparse_loss method='2d', dist='cos' (all shipped configs) is accelerated")
-        self.desc_loss_type = "sparse"
+        if m.get("dense_loss", {}).get("enable", False):  # Train_model_heatmap_all.py:131-137: dense wins over sparse
+            self.desc_params = m["dense_loss"].get("params") or {}
+            self.desc_loss_type = "dense"
+        elif m.get("sparse_loss", {}).get("enable", False):
+            self.desc_params = m["sparse_loss"]["params"]
+            if self.desc_params.get("method", "2d") != "2d" or self.desc_params.get("dist", "cos") != "cos":
+                raise NotImplementedError("only sparse_loss method='2d', dist='cos' (all shipped configs) is accelerated")
+            self.desc_loss_type = "sparse"
+        else:
+            raise KeyError("model.dense_loss.enable or model.sparse_loss.enable must be true")
         self.sampler = self.config.get("ssp_sampler", "device")  # "device" | "reference" (host RNG streams)
         self.n_iter = 0
         self.net = None
@@ -136,6 +138,8 @@ class Train_model_heatmap_all(object):
         if name not in _MODELS:
             raise KeyError("model %r is not on the accelerated path" % name)
         self.net = _MODELS[name](**params).to(self.device)
+        if self.desc_loss_type == "dense":  # the engine reserves the [B, cells, cells] coefficient matrix
+            self.net._engine_kwargs = {"dense_loss": True}
         n_iter = 0
         if not self.config.get("retrain", True) and self.config.get("pretrained"):
             path = self.config["pretrained"]
@@ -181,12 +185,18 @@ class Train_model_heatmap_all(object):
                 dev[k] = dev[k].float()
         lam = float(m["lambda_loss"])
         idx = None
-        if lam > 0 and self.sampler == "reference":
+        dense = None
+        if self.desc_loss_type == "dense":
+            # descriptor_loss(**desc_params): only `descriptor_dist` and `lamda_d` are named parameters, so the shipped
+            # `lambda_d: 800` falls into **config and the weight stays 250 (utils/utils.py:779-790)
+            dense = {"lamda_d": float(self.desc_params.get("lamda_d", 250)),
+                     "descriptor_dist": float(self.desc_params.get("descriptor_dist", 4))}
+        if lam > 0 and dense is None and self.sampler == "reference":
             idx = tuple(t.to(self.device) for t in sample_sparse_indices_host(
                 sample["homographies"], H // 8, W // 8, eng.n_match, eng.n_non))
         sc = eng.pair_step(dev, indices=idx, seed=int(cfg.get("ssp_seed", 0)) * 1000003 + n_iter, train=train,
                            lambda_loss=lam, lamda_d=float(self.desc_params.get("lamda_d", 1)),
-                           multi_task=bool(m["multi_task_loss"]), gaussian=self.gaussian)
+                           multi_task=bool(m["multi_task_loss"]), gaussian=self.gaussian, dense=dense)
         if train and ((n_iter + 1) * B) % self.real_batch_size == 0:
             parallel.allreduce_mean_(eng.grads)
             eng.adam_step(self.learning_rate)

@@ -45,6 +45,7 @@ struct StepAccum {
   double neg_sum[64 * 16];   // per image x 16 replicas: sum max(0, <a,b> - 0.2)
   unsigned int nnz[64 * 16]; // per image x 16 replicas: number of non-zero non-match hinges
   unsigned int nnz_img[64];  // per image totals (desc_counts_kernel), read by the backward kernels
+  double dense_sum[64 * 16]; // dense descriptor loss: replicas of sum (pos + neg) * valid (pos_sum / neg_sum hold the rest)
   float coef_det, coef_pos, coef_neg, coef_sem;  // d total / d (loss_det sum), d/d pos mean, d/d neg mean, d/d sem sum
 };
 
@@ -335,7 +336,7 @@ __global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta,
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < 2; ++i) acc->det_sum[i] = acc->mask_cnt[i] = acc->sem_sum[i] = acc->sem_cnt[i] = 0.0;
   for (int i = 0; i < 64 * 16; ++i) {
-    acc->pos_sum[i] = acc->neg_sum[i] = 0.0;
+    acc->pos_sum[i] = acc->neg_sum[i] = acc->dense_sum[i] = 0.0;
     acc->nnz[i] = 0u;
   }
   if (multi_task) {
@@ -353,12 +354,23 @@ __global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta,
 
 __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ eta, float* __restrict__ deta,
                                 float* __restrict__ scal, int B, int n_match, int multi_task, float lambda_loss,
-                                float lamda_d, int semantic, int train) {
+                                float lamda_d, int semantic, int train, int dense, int cells) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float det0 = (float)acc->det_sum[0] / ((float)acc->mask_cnt[0] + 1e-5f);
   const float det1 = (float)acc->det_sum[1] / ((float)acc->mask_cnt[1] + 1e-5f);
   float pos = 0.f, neg = 0.f, ldesc = 0.f;
-  if (lambda_loss > 0.f) {
+  if (lambda_loss > 0.f && dense) {  // utils/utils.py:884-890
+    double ps = 0, ns = 0, ls = 0;
+    for (int i = 0; i < 64 * 16; ++i) {
+      ps += acc->pos_sum[i];
+      ns += acc->neg_sum[i];
+      ls += acc->dense_sum[i];
+    }
+    const double norm = (double)B * (acc->mask_cnt[1] + 1.0) * (double)cells;
+    pos = (float)(ps / norm);
+    neg = (float)(ns / norm);
+    ldesc = (float)(ls / norm);
+  } else if (lambda_loss > 0.f) {
     for (int i = 0; i < B; ++i) {
       double ps = 0, ns = 0;
       for (int r = 0; r < 16; ++r) {

@@ -18,6 +18,7 @@
 #include "conv_wino.hip.h"
 #include "conv_wino_pipe.hip.h"
 #include "loss_kernels.hip.h"
+#include "dense_loss.hip.h"
 #include "pair_kernels.hip.h"
 #include "export_kernels.hip.h"
 #include "sem_kernels.hip.h"
@@ -108,6 +109,7 @@ struct ssp_handle {
   size_t partial_floats;
   StepAccum* accum;
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
+  float* dense_coef; // [B * cells * cells] d total / d dot of the dense descriptor loss (cfg.dense_loss), else nullptr
   int sout_cs;
   // profiling
   int prof_family;
@@ -263,6 +265,10 @@ static size_t carve(ssp_handle* h, void* base) {
   h->partial = c.take<float>(h->partial_floats);
   h->accum = c.take<StepAccum>(1);
   h->dots = c.take<float>((size_t)B * h->cfg.n_match * h->cfg.n_non);
+  {
+    const size_t pc = (size_t)(H / 8) * (W / 8);
+    h->dense_coef = h->cfg.dense_loss ? c.take_skewed<float>((size_t)std::min(B, 64) * pc * pc) : nullptr;
+  }
   // size query (base == nullptr): the skewed tensors are placed relative to the absolute address, so a bound base that
   // is not 4 MiB aligned shifts the whole layout by < 4 MiB
   return align_up(c.off, 256) + (base ? 0 : ((size_t)4 << 20));
@@ -984,7 +990,9 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   const bool semantic = h->nheads == 3;
   if (semantic && (!in->semantic_dev || !in->warped_semantic_dev)) return fail(-1, "semantic labels required for the ssmall model");
   const bool use_desc = in->lambda_loss > 0.f;
-  if (use_desc && (!in->match_a_dev || !in->match_b_dev || !in->nonmatch_b_dev))
+  const bool dense = use_desc && in->dense_loss != 0;
+  if (dense && !h->dense_coef) return fail(-1, "dense descriptor loss needs a handle created with ssp_config.dense_loss = 1");
+  if (use_desc && !dense && (!in->match_a_dev || !in->match_b_dev || !in->nonmatch_b_dev))
     return fail(-1, "sparse-loss indices required (call ssp_sample_indices or pass the reference's indices)");
   hipStream_t st = (hipStream_t)stream;
   const float* eta = h->buf.params_dev + h->n_params;
@@ -1029,7 +1037,26 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
     }
     HIPCHK(hipGetLastError());
   }
-  if (use_desc) {
+  if (dense) {  // utils/utils.py:779-893: Gram matrix + loss sums + d total / d dot, then the two backward GEMMs
+    Slot &A = h->slot[0], &Bs = h->slot[1];
+    const int pc = Hc * Wc;
+    DenseArgs da;
+    da.da = A.desc; da.db = Bs.desc; da.hn = in->homographies_dev; da.valid = Bs.cellmask;
+    da.coef = in->train ? h->dense_coef : nullptr; da.acc = h->accum; da.B = B; da.Hc = Hc; da.Wc = Wc;
+    da.lamda_d = in->dense_lamda_d; da.dist = in->descriptor_dist; da.multi_task = in->multi_task;
+    hipLaunchKernelGGL(dense_dots_kernel, dim3(cdiv(pc, 64), cdiv(pc, 64), B), dim3(256), 0, st, da);
+    if (in->train) {
+      hipLaunchKernelGGL((dense_grad_kernel<false>), dim3(4, cdiv(pc, 64), B), dim3(256), 0, st, h->dense_coef, Bs.desc,
+                         A.ddesc, pc);
+      hipLaunchKernelGGL((dense_grad_kernel<true>), dim3(4, cdiv(pc, 64), B), dim3(256), 0, st, h->dense_coef, A.desc,
+                         Bs.ddesc, pc);
+      for (int v = 0; v < 2; ++v) {
+        Slot& S = h->slot[v];
+        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.desc, S.inv_norm, S.ddesc, ncells);
+      }
+    }
+    HIPCHK(hipGetLastError());
+  } else if (use_desc) {
     const int nw = B * h->cfg.n_match;
     Slot &A = h->slot[0], &Bs = h->slot[1];
     hipLaunchKernelGGL((desc_match_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
@@ -1055,7 +1082,7 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   }
   hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, st, h->accum, eta,
                      in->train ? h->buf.grads_dev + h->n_params : (float*)nullptr, scalars_dev, B, h->cfg.n_match,
-                     in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train);
+                     in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train, (int)dense, Hc * Wc);
   HIPCHK(hipGetLastError());
   if (in->train) {
     const float* dss[2] = {h->slot[0].dsemi, h->slot[1].dsemi};
@@ -1376,6 +1403,31 @@ int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, siz
   else return fail(-1, "unknown buffer %s", name);
   *ptr = p;
   if (nfloats) *nfloats = cnt;
+  return 0;
+}
+
+int ssp_op_dense_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const float* homographies_dev,
+                      const float* valid_dev, int b, int hc, int wc, float lamda_d, float descriptor_dist, int multi_task,
+                      float scale, void* scratch_dev, size_t scratch_bytes, float* out3_dev, float* dda_dev,
+                      float* ddb_dev, void* stream) {
+  const int pc = hc * wc;
+  const bool grad = dda_dev != nullptr && ddb_dev != nullptr;
+  const size_t need = align_up(sizeof(StepAccum), 256) + (grad ? (size_t)b * pc * pc * sizeof(float) : 0);
+  if (scratch_bytes < need) return fail(-4, "ssp_op_dense_loss scratch too small (%zu < %zu)", scratch_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  StepAccum* acc = reinterpret_cast<StepAccum*>(scratch_dev);
+  float* coef = grad ? reinterpret_cast<float*>(reinterpret_cast<char*>(scratch_dev) + align_up(sizeof(StepAccum), 256)) : nullptr;
+  hipLaunchKernelGGL(dense_op_prep_kernel, dim3(1), dim3(256), 0, st, acc, valid_dev, b * pc, scale);
+  DenseArgs da;
+  da.da = desc_a_nhwc_dev; da.db = desc_b_nhwc_dev; da.hn = homographies_dev; da.valid = valid_dev; da.coef = coef;
+  da.acc = acc; da.B = b; da.Hc = hc; da.Wc = wc; da.lamda_d = lamda_d; da.dist = descriptor_dist; da.multi_task = multi_task;
+  hipLaunchKernelGGL(dense_dots_kernel, dim3(cdiv(pc, 64), cdiv(pc, 64), b), dim3(256), 0, st, da);
+  if (grad) {
+    hipLaunchKernelGGL((dense_grad_kernel<false>), dim3(4, cdiv(pc, 64), b), dim3(256), 0, st, coef, desc_b_nhwc_dev, dda_dev, pc);
+    hipLaunchKernelGGL((dense_grad_kernel<true>), dim3(4, cdiv(pc, 64), b), dim3(256), 0, st, coef, desc_a_nhwc_dev, ddb_dev, pc);
+  }
+  hipLaunchKernelGGL(dense_op_finish_kernel, dim3(1), dim3(1), 0, st, acc, out3_dev, b, pc);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -23,7 +23,7 @@ PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "co
 
 class SspConfig(C.Structure):
     _fields_ = [("arch", C.c_int), ("n_classes", C.c_int), ("max_batch", C.c_int), ("height", C.c_int),
-                ("width", C.c_int), ("n_match", C.c_int), ("n_non", C.c_int)]
+                ("width", C.c_int), ("n_match", C.c_int), ("n_non", C.c_int), ("dense_loss", C.c_int)]
 
 
 class SspBuffers(C.Structure):
@@ -38,7 +38,8 @@ class SspPairInputs(C.Structure):
                 ("warped_valid_mask_dev", C.c_void_p), ("homographies_dev", C.c_void_p), ("semantic_dev", C.c_void_p),
                 ("warped_semantic_dev", C.c_void_p), ("match_a_dev", C.c_void_p), ("match_b_dev", C.c_void_p),
                 ("nonmatch_b_dev", C.c_void_p), ("seed", C.c_uint64), ("lambda_loss", C.c_float),
-                ("lamda_d", C.c_float), ("multi_task", C.c_int), ("train", C.c_int)]
+                ("lamda_d", C.c_float), ("multi_task", C.c_int), ("train", C.c_int), ("dense_loss", C.c_int),
+                ("dense_lamda_d", C.c_float), ("descriptor_dist", C.c_float)]
 
 
 class SspExportParams(C.Structure):
@@ -54,7 +55,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
            "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_set_conv_algo", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
            "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
-           "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms"]
+           "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms", "ssp_op_dense_loss"]
 
 
 def load_library(path=None):
@@ -108,6 +109,7 @@ def load_library(path=None):
     lib.ssp_op_soft_argmax_points.argtypes = [vp, vp, vp, i, i, i, vp]
     lib.ssp_detector_heatmap.argtypes = [vp, i, vp, vp]
     lib.ssp_op_heatmap_nms.argtypes = [vp, ep, i, vp, vp, vp, vp, vp]
+    lib.ssp_op_dense_loss.argtypes = [vp, vp, vp, vp, i, i, i, f, f, i, f, vp, C.c_size_t, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -188,7 +190,7 @@ class Engine:
     """One libssp handle plus its torch-owned device buffers (one per GPU / stream)."""
 
     def __init__(self, arch, max_batch, height, width, device, n_classes=133, n_match=1000, n_non=100,
-                 with_grad=True):
+                 with_grad=True, dense_loss=False):
         self.lib = load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -196,7 +198,8 @@ class Engine:
         self.arch, self.n_classes = arch, n_classes
         self.max_batch, self.height, self.width = max_batch, height, width
         self.n_match, self.n_non = n_match, n_non
-        cfg = SspConfig(ARCHS[arch], n_classes, max_batch, height, width, n_match, n_non)
+        self.dense_loss = bool(dense_loss)
+        cfg = SspConfig(ARCHS[arch], n_classes, max_batch, height, width, n_match, n_non, int(self.dense_loss))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(self.lib.ssp_create(C.byref(cfg), C.byref(h)))
@@ -326,9 +329,12 @@ class Engine:
         return ma, mb, nm
 
     def pair_step(self, sample, indices=None, seed=0, train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True,
-                  gaussian=True):
+                  gaussian=True, dense=None):
         """`sample`: dict of device tensors with the reference's keys (Train_model_heatmap_all.py:212-251).
         indices: (match_a, match_b, nonmatch_b) int32 device tensors or None (device sampler with `seed`).
+        dense: None (sparse descriptor loss) or the model.dense_loss.params dict (dense descriptor loss,
+        utils/utils.py:779-893; keys lamda_d (default 250: the shipped `lambda_d` spelling is ignored by the reference
+        too) and descriptor_dist (4)); needs an Engine created with dense_loss=True.
         Returns the device tensor of SSP_N_SCALARS floats (no host sync)."""
         img = sample["image"]
         B = img.shape[0]
@@ -341,7 +347,9 @@ class Engine:
         if not Hm.is_contiguous():
             Hm = Hm.contiguous()
         _need_gpu(Hm, "homographies")
-        if lambda_loss > 0 and indices is None:
+        if dense is not None and not self.dense_loss:
+            raise RuntimeError("create the Engine with dense_loss=True to use the dense descriptor loss")
+        if lambda_loss > 0 and indices is None and dense is None:
             indices = self.sample_indices(Hm, seed)
         ma, mb, nm = indices if indices is not None else (None, None, None)
         sem = sample.get("semantic") if self.arch.endswith("ssmall") else None
@@ -349,7 +357,8 @@ class Engine:
         inp = SspPairInputs(B, _ptr(img), _ptr(sample["warped_img"]), _ptr(lab), _ptr(labw), _ptr(sample["valid_mask"]),
                             _ptr(sample["warped_valid_mask"]), _ptr(Hm), _ptr(sem), _ptr(semw), _ptr(ma), _ptr(mb),
                             _ptr(nm), int(seed), float(lambda_loss), float(lamda_d), int(bool(multi_task)),
-                            int(bool(train)))
+                            int(bool(train)), int(dense is not None),
+                            float((dense or {}).get("lamda_d", 250.0)), float((dense or {}).get("descriptor_dist", 4.0)))
         self._keep = (req, Hm, indices, sem, semw)  # keep alive until the stream has consumed them
         with torch.cuda.device(self.device):
             _check(self.lib.ssp_pair_step(self.h, C.byref(inp), _ptr(self.scalars), _stream()))
@@ -470,6 +479,32 @@ def op_sparse_loss(desc_a_nchw, desc_b_nchw, match_a, match_b, nonmatch_b):
                                       match_a.shape[1], nonmatch_b.shape[1] // match_a.shape[1], _ptr(out), _stream()))
     torch.cuda.synchronize()
     return float(out[0]), float(out[1])
+
+
+def op_dense_loss(desc_a_nchw, desc_b_nchw, homographies, mask_valid, lamda_d=250.0, descriptor_dist=4.0, grad=None):
+    """Dense descriptor loss (utils/utils.py:779-893) of NCHW descriptor maps.  Returns (loss, pos_sum, neg_sum) and,
+    with grad = ("loss", scale) or ("multi_task", scale), the gradients of scale * loss_desc resp.
+    scale * (pos_sum + neg_sum) wrt both maps (NCHW)."""
+    lib = load_library()
+    _need_gpu(desc_a_nchw, "desc")
+    B, D, Hc, Wc = desc_a_nchw.shape
+    dev = desc_a_nchw.device
+    a = desc_a_nchw.permute(0, 2, 3, 1).contiguous()
+    b = desc_b_nchw.permute(0, 2, 3, 1).contiguous()
+    hm = homographies.to(dev, torch.float32).contiguous()
+    mv = mask_valid.to(dev, torch.float32).reshape(B, Hc * Wc).contiguous()
+    out = torch.zeros(3, dtype=torch.float32, device=dev)
+    da = torch.empty_like(a) if grad else None
+    db = torch.empty_like(b) if grad else None
+    scratch = torch.empty(65536 + (B * (Hc * Wc) ** 2 * 4 if grad else 0), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.ssp_op_dense_loss(_ptr(a), _ptr(b), _ptr(hm), _ptr(mv), B, Hc, Wc, float(lamda_d), float(descriptor_dist),
+                                     int(bool(grad and grad[0] == "multi_task")), float(grad[1]) if grad else 0.0,
+                                     _ptr(scratch), scratch.numel(), _ptr(out), _ptr(da), _ptr(db), _stream()))
+    o = out.cpu().tolist()
+    if not grad:
+        return o[0], o[1], o[2]
+    return (o[0], o[1], o[2]), da.permute(0, 3, 1, 2).contiguous(), db.permute(0, 3, 1, 2).contiguous()
 
 
 def op_bn_bwd(y_nhwc, dout_nhwc, gamma, scale, shift, mean, invstd, relu=True, pool=False):

@@ -84,7 +84,7 @@ class SspNetBase(nn.Module):
         assert n is not None, "engine not created yet: run a forward first"
         sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
         self._release_engine()
-        e = L.Engine(self.ARCH, n, h, w, device, n_classes=self.n_classes)
+        e = L.Engine(self.ARCH, n, h, w, device, n_classes=self.n_classes, **getattr(self, "_engine_kwargs", {}))
         e.load_state_dict(sd)
         own = dict(self.named_parameters())
         bufs = dict(self.named_buffers())
