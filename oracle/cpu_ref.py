@@ -411,7 +411,7 @@ class Trainer:
         else:
             with torch.no_grad():
                 loss, scal, aux = pair_losses(self.sd, self.eta, sample, self.arch, indices, **args)
-        self.scalar_dict = {k: float(v) for k, v in scal.items()}
+        self.scalar_dict = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in scal.items()}
         self.aux = aux
         return float(loss)
 
