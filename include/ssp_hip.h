@@ -158,6 +158,26 @@ int ssp_op_warp_image(const float* img_dev, const float* inv_h_dev, float* out_d
 int ssp_op_erode(const float* mask_dev, float* out_dev, int b, int h, int w, int radius, void* stream);
 int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_dev, int b, int h, int w, void* stream);
 
+/* Pair construction for real data:
+ * ssp_op_sample_homographies: sample_homography_np (utils/homographies.py:12-141) with the keys of
+ *     `warped_pair.params` + the inversion of datasets/Coco.py:342-350, counter-based device RNG (distribution-level
+ *     equivalent of the numpy / scipy streams); h_dev = `homographies` (image -> warped), inv_h_dev = `inv_homographies`.
+ * ssp_op_warp_labels_full : warpLabels(..., bilinear=True) (datasets/data_tools.py:37-63) on a keypoint map:
+ *     labels [b,1,h,w], res [b,2,h,w] (warped - round(warped) at the rounded position), labels_bi [b,1,h,w]
+ *     (get_labels_bi :26-34); any output may be NULL; last-write-wins scatters like torch.
+ * ssp_op_sem_finalize     : datasets/Coco_sem.py:447-448: float class map -> int64, invalid pixels -> n_classes. */
+typedef struct ssp_homography_params {
+  int32_t perspective, scaling, rotation, translation, allow_artifacts;
+  int32_t n_scales, n_angles; /* 5, 25 */
+  float scaling_amplitude, perspective_amplitude_x, perspective_amplitude_y, patch_ratio, max_angle, translation_overflow;
+} ssp_homography_params;
+int ssp_op_sample_homographies(uint64_t seed, const ssp_homography_params* p, int b, float* h_dev, float* inv_h_dev,
+                               void* stream);
+int ssp_op_warp_labels_full(const float* labels_dev, const float* h_dev, float* labels_out_dev, float* res_out_dev,
+                            float* bi_out_dev, int b, int h, int w, void* stream);
+int ssp_op_sem_finalize(const float* sem_warped_dev, const float* valid_dev, int64_t* out_dev, size_t n, int n_classes,
+                        void* stream);
+
 /* ---- homography-adaptation export (export.py:192-352) ------------------------------
  * One image = n_views warped copies that form ONE BatchNorm batch (the reference leaves the net in train mode,
  * models/model_wrap.py:120).  ssp_export_points replaces the body of the export loop (export.py:296-309):

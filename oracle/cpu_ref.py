@@ -765,3 +765,40 @@ def descriptor_loss_dense(desc, desc_w, homographies, mask_valid=None, cell_size
     pos_sum = (lamda_d * mask * pos / normalization).sum()
     neg_sum = ((1 - mask) * neg / normalization).sum()
     return loss, mask, pos_sum, neg_sum
+
+
+# --------------------------------------------------------------------------------------
+# Pair construction for real data: the remaining label products of
+# datasets/data_tools.py:37-63 warpLabels(bilinear=True) and the semantic map of datasets/Coco_sem.py:406-450
+# --------------------------------------------------------------------------------------
+def warp_labels_full(pnts_xy, H, W, homography):
+    """warpLabels(pnts, H, W, homography, bilinear=True): returns (labels [1,H,W], res [2,H,W] = warped point minus its
+    rounded position, written at the rounded position, labels_bi [1,H,W] = the 4-neighbour bilinear splat of
+    get_labels_bi, :26-34).  Scatters are last-write-wins (torch index_put), so results are only defined when no two
+    points land on the same pixel."""
+    Hpix = scale_homography(homography.float(), (H, W))
+    wp_all = warp_points(pnts_xy.long().float(), Hpix)
+    # get_labels_bi works on ALL warped points, filtering the 4 extrapolated neighbours afterwards
+    pi = wp_all.long().float()
+    ext = torch.cat((pi, torch.stack((pi[:, 0], pi[:, 1] + 1), 1), torch.stack((pi[:, 0] + 1, pi[:, 1]), 1), pi + 1), 0)
+    rx, ry = (wp_all - pi)[:, 0], (wp_all - pi)[:, 1]
+    wts = torch.cat(((1 - rx) * (1 - ry), (1 - rx) * ry, rx * (1 - ry), rx * ry), 0)
+    ext, keep = filter_points(ext, (W, H))
+    bi = torch.zeros(H, W)
+    q = ext.round().long()
+    bi[q[:, 1], q[:, 0]] = wts[keep]
+    wp, _ = filter_points(wp_all, (W, H))
+    lab = torch.zeros(H, W)
+    q = wp.round().long()
+    lab[q[:, 1], q[:, 0]] = 1
+    res = torch.zeros(H, W, 2)
+    res[q[:, 1], q[:, 0], :] = wp - wp.round()
+    return lab.view(1, H, W), res.permute(2, 0, 1).contiguous(), bi.view(1, H, W)
+
+
+def warp_semantic(sem, inv_homography, valid_mask, n_classes=133):
+    """datasets/Coco_sem.py:406-450: bilinear warp of the class-id map as floats, invalid pixels -> n_classes."""
+    w = inv_warp_image_batch(sem.float().view(1, 1, *sem.shape[-2:]), inv_homography.view(1, 3, 3)).view(sem.shape[-2:])
+    w = w.clone()
+    w[valid_mask.view(sem.shape[-2:]) == 0] = n_classes
+    return w

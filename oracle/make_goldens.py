@@ -397,6 +397,42 @@ def g10_dense_loss():
         print("  G10", name, "loss %.5f pos %.5f neg %.3e positives %d" % (float(r[0]), float(r[2]), float(r[3]), int(r[1].sum())))
 
 
+def g11_pair_labels():
+    """warpLabels(bilinear=True) products (labels, res, labels_bi) on point sets without pixel collisions."""
+    R.install()
+    from datasets.data_tools import warpLabels
+    rs = np.random.RandomState(19)
+    H, W = 48, 64
+    save = {}
+    k = 0
+    while k < 3:
+        Hm = torch.from_numpy(np.linalg.inv(C.sample_homography(rs)).astype(np.float32))
+        pts = torch.nonzero(torch.from_numpy(rs.uniform(size=(H, W)) < 0.01)).flip(1)
+        ref = warpLabels(pts, H, W, Hm, bilinear=True)
+        # collision-free: every point and every splat target lands on its own pixel (scatter order is undefined else)
+        wp = ref["warped_pnts"]
+        q = wp.round().long()
+        flat = (q[:, 1] * W + q[:, 0]).numpy()
+        lab_o, res_o, bi_o = C.warp_labels_full(pts, H, W, Hm)
+        # the 4 splat targets of all points must be distinct pixels too
+        from utils.utils import warp_points as _wp, homography_scaling_torch as _hs, filter_points as _fp
+        wall = _wp(torch.stack((pts[:, 0], pts[:, 1]), dim=1).long(), _hs(Hm, H, W))
+        pi = wall.long().float()
+        ext = torch.cat((pi, torch.stack((pi[:, 0], pi[:, 1] + 1), 1), torch.stack((pi[:, 0] + 1, pi[:, 1]), 1), pi + 1), 0)
+        ext = _fp(ext, torch.tensor([W, H]))
+        eflat = (ext[:, 1].long() * W + ext[:, 0].long()).numpy()
+        if len(np.unique(flat)) != len(flat) or len(np.unique(eflat)) != len(eflat):
+            continue
+        assert torch.equal(ref["labels_bi"], bi_o), "G11 labels_bi"
+        assert torch.equal(ref["labels"], lab_o), "G11 labels"
+        assert torch.equal(ref["res"].permute(2, 0, 1), res_o), "G11 res"
+        save["H%d" % k] = npy(Hm); save["pts%d" % k] = npy(pts).astype(np.int16)
+        save["labels%d" % k] = npy(ref["labels"]); save["res%d" % k] = npy(ref["res"].permute(2, 0, 1))
+        save["bi%d" % k] = npy(ref["labels_bi"])
+        k += 1
+    np.savez_compressed(os.path.join(OUT, "g11_pair_labels.npz"), **save)
+
+
 def g8_export():
     """Homography-adaptation export (export.py:274-318) through the real SuperPointFrontend_torch /
     combine_heatmap / getPtsFromHeatmap / soft_argmax_points on random-init weights."""
@@ -486,7 +522,7 @@ def main():
     assert R.available(), "reference not mounted"
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss):
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss, g11_pair_labels):
         fn()
         print(fn.__name__, "done")
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

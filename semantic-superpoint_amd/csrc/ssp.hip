@@ -1347,6 +1347,45 @@ int ssp_export_points(ssp_handle* h, const ssp_export_params* p, int n_images, c
   return 0;
 }
 
+// ---- pair construction for real data ----
+int ssp_op_sample_homographies(uint64_t seed, const ssp_homography_params* p, int b, float* h_dev, float* inv_h_dev,
+                               void* stream) {
+  if (!p || !h_dev || !inv_h_dev || b < 1) return fail(-1, "sample_homographies: bad argument");
+  if (p->n_scales < 0 || p->n_scales > 16 || p->n_angles < 0 || p->n_angles > 63 || p->patch_ratio <= 0.f || p->patch_ratio > 1.f)
+    return fail(-1, "sample_homographies: n_scales <= 16, n_angles <= 63, 0 < patch_ratio <= 1 required");
+  HomographyParams q;
+  q.perspective = p->perspective; q.scaling = p->scaling; q.rotation = p->rotation; q.translation = p->translation;
+  q.allow_artifacts = p->allow_artifacts; q.n_scales = p->n_scales; q.n_angles = p->n_angles;
+  q.scaling_amplitude = p->scaling_amplitude; q.perspective_amplitude_x = p->perspective_amplitude_x;
+  q.perspective_amplitude_y = p->perspective_amplitude_y; q.patch_ratio = p->patch_ratio; q.max_angle = p->max_angle;
+  q.translation_overflow = p->translation_overflow;
+  hipLaunchKernelGGL(sample_homographies_kernel, dim3(cdiv(b, 64)), dim3(64), 0, (hipStream_t)stream, seed, q, h_dev,
+                     inv_h_dev, b);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_warp_labels_full(const float* labels_dev, const float* h_dev, float* labels_out_dev, float* res_out_dev,
+                            float* bi_out_dev, int b, int hh, int w, void* stream) {
+  const long n = (long)b * hh * w;
+  hipStream_t st = (hipStream_t)stream;
+  if (labels_out_dev) HIPCHK(hipMemsetAsync(labels_out_dev, 0, n * sizeof(float), st));
+  if (res_out_dev) HIPCHK(hipMemsetAsync(res_out_dev, 0, 2 * n * sizeof(float), st));
+  if (bi_out_dev) HIPCHK(hipMemsetAsync(bi_out_dev, 0, n * sizeof(float), st));
+  hipLaunchKernelGGL(warp_labels_full_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, labels_dev, h_dev, labels_out_dev,
+                     res_out_dev, bi_out_dev, b, hh, w);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_sem_finalize(const float* sem_warped_dev, const float* valid_dev, int64_t* out_dev, size_t n, int n_classes,
+                        void* stream) {
+  hipLaunchKernelGGL(sem_finalize_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, sem_warped_dev,
+                     valid_dev, out_dev, (long)n, n_classes);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // BatchNorm(+ReLU(+2x2 max-pool)) backward as an operator: y [N,H,W,C] raw conv output, dout = gradient wrt the
 // activated (pooled when pool=1: [N,H/2,W/2,C]) output; stats4 = {scale, shift, mean, invstd} each [C].
 // Outputs: dy [N,H,W,C], dgamma/dbeta/dbias [C] (accumulated), sums_dev: double[2C] scratch.

@@ -42,6 +42,14 @@ class SspPairInputs(C.Structure):
                 ("dense_lamda_d", C.c_float), ("descriptor_dist", C.c_float)]
 
 
+class SspHomographyParams(C.Structure):
+    _fields_ = [("perspective", C.c_int32), ("scaling", C.c_int32), ("rotation", C.c_int32), ("translation", C.c_int32),
+                ("allow_artifacts", C.c_int32), ("n_scales", C.c_int32), ("n_angles", C.c_int32),
+                ("scaling_amplitude", C.c_float), ("perspective_amplitude_x", C.c_float),
+                ("perspective_amplitude_y", C.c_float), ("patch_ratio", C.c_float), ("max_angle", C.c_float),
+                ("translation_overflow", C.c_float)]
+
+
 class SspExportParams(C.Structure):
     _fields_ = [("n_views", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("conf_thresh", C.c_float),
                 ("nms_dist", C.c_int32), ("border_remove", C.c_int32), ("top_k", C.c_int32), ("subpixel", C.c_int32)]
@@ -55,7 +63,8 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
            "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_set_conv_algo", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
            "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
-           "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms", "ssp_op_dense_loss"]
+           "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms", "ssp_op_dense_loss",
+           "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize"]
 
 
 def load_library(path=None):
@@ -109,6 +118,9 @@ def load_library(path=None):
     lib.ssp_op_soft_argmax_points.argtypes = [vp, vp, vp, i, i, i, vp]
     lib.ssp_detector_heatmap.argtypes = [vp, i, vp, vp]
     lib.ssp_op_heatmap_nms.argtypes = [vp, ep, i, vp, vp, vp, vp, vp]
+    lib.ssp_op_sample_homographies.argtypes = [C.c_uint64, C.POINTER(SspHomographyParams), i, vp, vp, vp]
+    lib.ssp_op_warp_labels_full.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
+    lib.ssp_op_sem_finalize.argtypes = [vp, vp, vp, C.c_size_t, i, vp]
     lib.ssp_op_dense_loss.argtypes = [vp, vp, vp, vp, i, i, i, f, f, i, f, vp, C.c_size_t, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -657,4 +669,48 @@ def points_to_numpy(pts, count, subpixel):
     out[:, 0], out[:, 1], out[:, 2] = a[:, 0], a[:, 1], a[:, 2]
     if subpixel:
         out[:, :2] = out[:, :2] + a[:, 3:5] - 2
+    return out
+
+
+# ---- pair construction for real data ----
+def op_sample_homographies(B, seed, device, perspective=True, scaling=True, rotation=True, translation=True, n_scales=5,
+                           n_angles=25, scaling_amplitude=0.1, perspective_amplitude_x=0.1, perspective_amplitude_y=0.1,
+                           patch_ratio=0.5, max_angle=np.pi / 2, allow_artifacts=False, translation_overflow=0.0):
+    """B homographies with the keyword names / defaults of utils/homographies.py:sample_homography_np, drawn on the
+    device.  Returns (homographies, inv_homographies) [B,3,3] as the dataset stores them (Coco.py:342-350)."""
+    lib = load_library()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("op_sample_homographies needs a HIP device")
+    p = SspHomographyParams(int(perspective), int(scaling), int(rotation), int(translation), int(allow_artifacts),
+                            int(n_scales), int(n_angles), float(scaling_amplitude), float(perspective_amplitude_x),
+                            float(perspective_amplitude_y), float(patch_ratio), float(max_angle), float(translation_overflow))
+    h = torch.empty(B, 3, 3, dtype=torch.float32, device=device)
+    inv = torch.empty_like(h)
+    with torch.cuda.device(device):
+        _check(lib.ssp_op_sample_homographies(int(seed), C.byref(p), B, _ptr(h), _ptr(inv), _stream()))
+    return h, inv
+
+
+def op_warp_labels_full(labels, hn):
+    """warpLabels(bilinear=True) on a keypoint map [B,1,H,W]: (labels [B,1,H,W], res [B,2,H,W], labels_bi [B,1,H,W])."""
+    lib = load_library()
+    _need_gpu(labels, "labels")
+    hn = hn.to(labels.device, torch.float32).contiguous()
+    B, _, H, W = labels.shape
+    lab = torch.empty_like(labels)
+    res = torch.empty(B, 2, H, W, dtype=torch.float32, device=labels.device)
+    bi = torch.empty_like(labels)
+    with torch.cuda.device(labels.device):
+        _check(lib.ssp_op_warp_labels_full(_ptr(labels), _ptr(hn), _ptr(lab), _ptr(res), _ptr(bi), B, H, W, _stream()))
+    return lab, res, bi
+
+
+def op_sem_finalize(sem_warped, valid, n_classes=133):
+    lib = load_library()
+    _need_gpu(sem_warped, "sem")
+    _need_gpu(valid, "valid")
+    out = torch.empty(sem_warped.shape, dtype=torch.int64, device=sem_warped.device)
+    with torch.cuda.device(sem_warped.device):
+        _check(lib.ssp_op_sem_finalize(_ptr(sem_warped), _ptr(valid), _ptr(out), sem_warped.numel(), int(n_classes), _stream()))
     return out

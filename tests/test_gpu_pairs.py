@@ -1,0 +1,111 @@
+"""GPU: pair construction for real data: warpLabels(bilinear=True) products against
+the reference's arrays (G11), the semantic warp against the oracle, the device homography sampler through its
+distributional properties (its RNG stream differs from numpy / scipy by construction), and make_pairs end to end."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as C
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+WARP = dict(translation=True, rotation=True, scaling=True, perspective=True, scaling_amplitude=0.2,
+            perspective_amplitude_x=0.2, perspective_amplitude_y=0.2, patch_ratio=0.85, max_angle=1.57, allow_artifacts=True)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (run through gpurun)"
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_warp_labels_full_golden():
+    """labels bit-exact; residuals / bilinear weights within fp32 rounding of the analytic T^-1 H T."""
+    from semantic_superpoint_amd import lib as L
+    g = G.load("g11_pair_labels.npz")
+    for k in range(3):
+        H, W = g["labels%d" % k].shape[1:]
+        lab = torch.zeros(1, 1, H, W)
+        pts = t(g["pts%d" % k].astype(np.int64))
+        lab[0, 0, pts[:, 1], pts[:, 0]] = 1
+        out, res, bi = L.op_warp_labels_full(lab.to(_dev()), t(g["H%d" % k]).view(1, 3, 3))
+        assert float((out.cpu()[0] != t(g["labels%d" % k])).float().sum()) <= 2, k  # a rounding tie may move a point
+        same = (out.cpu()[0] == t(g["labels%d" % k])).expand(2, -1, -1)
+        assert ((res.cpu()[0] - t(g["res%d" % k])).abs() * same).max() < 1e-3
+        assert (bi.cpu()[0] - t(g["bi%d" % k])).abs().max() < 2e-3, k
+
+
+def test_semantic_warp_and_invalid_class():
+    from semantic_superpoint_amd import lib as L
+    rs = np.random.RandomState(4)
+    H, W = 40, 56
+    sem = torch.from_numpy(rs.randint(0, 134, (1, H, W)))
+    Hm = t(np.linalg.inv(C.sample_homography(rs, **WARP)).astype(np.float32)).view(1, 3, 3)
+    inv = torch.inverse(Hm).contiguous()
+    vm = C.compute_valid_mask((H, W), inv, erosion_radius=3)
+    ref = C.warp_semantic(sem[0], inv[0], vm[0]).long()
+    dev = _dev()
+    sw = L.op_warp_image(sem.float().view(1, 1, H, W).to(dev), inv)
+    out = L.op_sem_finalize(sw.view(1, H, W), vm.to(dev), 133).cpu()[0]
+    assert float((out != ref).float().mean()) < 2e-3  # fp32 source coordinates: a truncated value may differ by one class id
+    assert torch.equal(out[vm[0] == 0], torch.full_like(out[vm[0] == 0], 133))
+
+
+def test_device_homography_sampler_properties():
+    from semantic_superpoint_amd import lib as L
+    dev = _dev()
+    B = 4096
+    hs, inv = L.op_sample_homographies(B, 7, dev, **WARP)
+    hs2, _ = L.op_sample_homographies(B, 7, dev, **WARP)
+    assert torch.equal(hs, hs2)                                   # deterministic per seed
+    hs3, _ = L.op_sample_homographies(B, 8, dev, **WARP)
+    assert not torch.equal(hs, hs3)
+    eye = torch.eye(3, device=dev).expand(B, 3, 3)
+    assert ((hs @ inv) - eye).abs().max() < 1e-3                   # homographies / inv_homographies are inverses
+    # moments of the sampled (= inv) matrices against the host restatement of sample_homography_np
+    rs = np.random.RandomState(1)
+    host = np.stack([C.sample_homography(rs, **WARP) for _ in range(4096)])
+    dv = inv.cpu().numpy()
+    for idx, tol in (((0, 0), 0.06), ((1, 1), 0.06), ((0, 2), 0.06), ((1, 2), 0.06), ((0, 1), 0.08), ((2, 0), 0.05)):
+        m_h, m_d = host[:, idx[0], idx[1]].mean(), dv[:, idx[0], idx[1]].mean()
+        s_h, s_d = host[:, idx[0], idx[1]].std(), dv[:, idx[0], idx[1]].std()
+        assert abs(m_h - m_d) < tol and abs(s_h - s_d) < tol + 0.15 * s_h, (idx, m_h, m_d, s_h, s_d)
+    # no-artifact mode keeps the warped patch corners inside the unit square (utils/homographies.py:61-107)
+    strict = dict(WARP, allow_artifacts=False, patch_ratio=0.5, scaling_amplitude=0.1, perspective_amplitude_x=0.1,
+                  perspective_amplitude_y=0.1)
+    _, inv_s = L.op_sample_homographies(1024, 3, dev, **strict)
+    corners = torch.tensor([[-1.0, -1, 1], [-1, 1, 1], [1, 1, 1], [1, -1, 1]], device=dev).t()
+    w = inv_s @ corners
+    xy = w[:, :2] / w[:, 2:]
+    assert float(xy.abs().max()) <= 1.0 + 1e-4
+
+
+def test_make_pairs_trains():
+    """make_pairs output feeds the pair step; shapes / dtypes / value ranges of the reference's sample dict."""
+    from semantic_superpoint_amd import pairs
+    from semantic_superpoint_amd.lib import Engine, SCALAR_NAMES
+    dev = _dev()
+    B, H, W = 4, 64, 96
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(B, 1, H, W, generator=g).to(dev)
+    lab = (torch.rand(B, 1, H, W, generator=g) < 0.01).float().to(dev)
+    sem = torch.randint(0, 134, (B, H, W), generator=g).to(dev)
+    s = pairs.make_pairs(img, lab, seed=5, warp_params=WARP, erosion_radius=3, semantic=sem)
+    for k in ("warped_img", "warped_labels", "warped_labels_bi", "warped_valid_mask", "warped_labels_gaussian"):
+        assert s[k].shape == (B, 1, H, W) and s[k].dtype == torch.float32
+    assert s["warped_res"].shape == (B, 2, H, W) and s["warped_sem"].dtype == torch.int64
+    assert float(s["warped_res"].abs().max()) <= 0.5 + 1e-6
+    assert set(torch.unique(s["warped_labels"]).tolist()) <= {0.0, 1.0}
+    assert int(s["warped_sem"].max()) <= 133 and bool((s["warped_sem"][s["warped_valid_mask"][:, 0] == 0] == 133).all())
+    # same construction as the oracle's on the device-sampled homographies
+    i = 1
+    ref_w = C.inv_warp_image_batch(img[i:i + 1].cpu(), s["inv_homographies"][i:i + 1].cpu())
+    assert (ref_w - s["warped_img"][i:i + 1].cpu()).abs().max() < 1e-4
+    e = Engine("SuperPointNet_gauss2_ssmall", B, H, W, dev)
+    e.load_state_dict(C.init_state_dict("SuperPointNet_gauss2_ssmall", seed=2))
+    e.zero_grad()
+    sc = dict(zip(SCALAR_NAMES, e.pair_step(s, seed=1, train=True, gaussian=False).cpu().tolist()))
+    assert np.isfinite(sc["loss"]) and sc["loss_sem_warp"] > 0 and float(e.grads.abs().sum()) > 0

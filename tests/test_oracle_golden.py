@@ -237,3 +237,13 @@ def test_g10_dense_descriptor_loss():
     loss, mask, pos, neg = C.descriptor_loss_dense(t(d), t(dw), t(f["homographies"]), t(f["mask_valid"]))
     assert abs(float(loss) - float(f["loss"])) < 1e-6 and abs(float(pos) - float(f["pos_sum"])) < 1e-6
     assert float(mask.sum()) == float(f["mask_sum"])
+
+
+def test_g11_pair_labels():
+    """warpLabels(bilinear=True) products vs the reference (collision-free point sets)."""
+    g = G.load("g11_pair_labels.npz")
+    for k in range(3):
+        H, W = g["labels%d" % k].shape[1:]
+        lab, res, bi = C.warp_labels_full(t(g["pts%d" % k].astype(np.int64)), H, W, t(g["H%d" % k]))
+        assert torch.equal(lab, t(g["labels%d" % k])) and torch.equal(res, t(g["res%d" % k]))
+        assert torch.equal(bi, t(g["bi%d" % k]))
