@@ -290,3 +290,45 @@ def test_trainer_logs_precision_recall():
     assert abs(agent.scalar_dict["recall"] - pr["recall"]) < 0.02
     agent.train_val_sample(sample, n_iter=3, train=False)  # validation always logs
     assert {"precision", "recall"} <= set(agent.scalar_dict)
+
+
+def test_full_size_export_properties():
+    """BASELINE configs[4] size (100 views of 240x320): size-independent properties instead of an oracle run.
+    (1) identical calls give identical points; (2) with identity homographies and full masks every view is the same
+    image, so the aggregate equals any single view's heatmap; (3) exported points are sorted, inside the border band and
+    pairwise farther apart than the NMS distance."""
+    from semantic_superpoint_amd import lib as L
+    from semantic_superpoint_amd.lib import Engine, points_to_numpy
+    dev = _dev()
+    arch, n, H, W = "SuperPointNet_gauss2", 100, 240, 320
+    e = Engine(arch, n, H, W, dev, with_grad=False)
+    sd = C.init_state_dict(arch, seed=12)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(H, W, generator=g).to(dev)
+    eye = torch.eye(3, device=dev).repeat(n, 1, 1).contiguous()
+    views, masks = L.op_homoadapt_views(img, eye)
+    # the identity warp still goes through linspace / unnormalise in fp32: views are copies of each other, not of img
+    assert torch.equal(views[0], views[57]) and (views[0, 0] - img).abs().max() < 1e-4 and float(masks.min()) == 1.0
+    outs = []
+    for _ in range(2):
+        e.load_state_dict(sd)
+        o = e.export_points([views], [masks], [eye], conf_thresh=0.0156, nms_dist=4, top_k=600, subpixel=True,
+                            want_heatmap=True)[0]
+        outs.append((points_to_numpy(o["pts"], o["count"], True), o["heatmap"].clone()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # single-view heatmap of the same BatchNorm batch (all views identical -> batch statistics = this view's)
+    e.load_state_dict(sd)
+    semi = e.forward(views, train=True, want=("semi",))["semi"]
+    single = L.op_flatten_detection(semi[:1].contiguous())[0, 0]
+    assert (outs[0][1] - single).abs().max() < 1e-5
+    pts = outs[0][0]
+    assert 0 < len(pts) <= 600 and np.all(np.diff(pts[:, 2]) <= 0)
+    xy = np.round(pts[:, :2] - (pts[:, :2] - np.round(pts[:, :2])))  # integer positions (soft-argmax moves < 2 px)
+    nms = points_to_numpy(e.export_points([views], [masks], [eye], conf_thresh=0.0156, nms_dist=4, top_k=600,
+                                          subpixel=False)[0]["pts"][:len(pts)], torch.tensor([len(pts)]), False)
+    q = nms[:, :2].astype(np.int64)
+    assert q[:, 0].min() >= 4 and q[:, 0].max() < W - 4 and q[:, 1].min() >= 4 and q[:, 1].max() < H - 4
+    d = np.abs(q[:, None, :] - q[None, :, :]).max(-1)
+    np.fill_diagonal(d, 10 ** 6)
+    assert d.min() > 4
+    assert np.abs(pts[:, :2] - nms[:, :2]).max() <= 2.0 + 1e-6
