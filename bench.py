@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_PAIR = {"SuperPointNet_gauss2": 77.98, "SuperPointNet_gauss2_ssmall": 82.72}
 PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3 line)
 
 
 def cpu_baseline(arch, H, W, batch=8, steps=1):
@@ -58,6 +59,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3],
+                    help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
+                         "un-pipelined, 3 = Winograd with bf16 matrix-core operands (reduced precision: reported as dtype bf16)")
     ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
                     help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
     args = ap.parse_args()
@@ -90,6 +94,7 @@ def main():
 
     arch = "SuperPointNet_gauss2" if args.arch == "sp" else "SuperPointNet_gauss2_ssmall"
     B, H, W = args.batch, args.height, args.width
+    ssp.lib.set_conv_algo(args.conv_algo)
     dense = {"descriptor_dist": 4, "lambda_d": 800} if args.desc_loss == "dense" else None
     eng = Engine(arch, B, H, W, dev, dense_loss=dense is not None)
     eng.load_state_dict(synth.default_init_state_dict(layer_table(arch), seed=0))  # identical replicas
@@ -131,9 +136,11 @@ def main():
         out = {"metric": "image-pairs/sec at 240x320 bs32 (pair training step)", "value": round(pairs_s, 2),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s pair step %dx%d, batch %d per GPU, fp32, %s, Adam"
-                                      % (arch, H, W, B, "sparse loss 1000x100" if dense is None else
+               "vs_baseline": None, "dtype": "bf16" if args.conv_algo == 3 else "f32", "data": "synthetic",
+               "config": {"workload": "%s pair step %dx%d, batch %d per GPU, %s, %s, Adam"
+                                      % (arch, H, W, B, "fp32" if args.conv_algo != 3 else
+                                         "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)",
+                                         "sparse loss 1000x100" if dense is None else
                                          "dense descriptor loss (1200x1200 per image)"), "parallelism": "dp%d" % world,
                           "global_batch": world * B},
                "step_tflops": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3, 2),
@@ -145,19 +152,20 @@ def main():
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
                 traffic = None  # HBM bytes / launch from the committed rocprofv3 PMC passes (cannot be read live)
                 tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-                if args.arch == "sp" and (B, H, W) == (32, 240, 320) and os.path.exists(tpath):
+                if args.arch == "sp" and (B, H, W) == (32, 240, 320) and args.conv_algo == 1 and os.path.exists(tpath):
                     tj = json.load(open(tpath))  # only valid for the launch structure it was profiled with
                     if abs(tj.get("flops_per_launch_avg_gflop", 0) - pr["flops"] / pr["launches"] / 1e9) < 0.05 * tj.get(
                             "flops_per_launch_avg_gflop", 1):
                         traffic = round(tj["hbm_bytes_per_launch"])
+                peak = PEAK_BF16_MFMA_TF if args.conv_algo == 3 else PEAK_FP32_MFMA_TF
                 out["roofline"] = {"bound": "mfma", "kernel": "conv_wino_pipe_kernel (3x3 forward + data-gradient, Winograd "
                                                               "F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
-                                   "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                                   "frac": round(ach / PEAK_FP32_MFMA_TF, 4),
+                                   "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4),
                                    "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / time; Winograd executes "
                                            "16/36 of them on the matrix cores, so frac may exceed 1",
                                    "executed_tflops": round(ach * 16.0 / 36.0, 2),
-                                   "executed_frac": round(ach * 16.0 / 36.0 / PEAK_FP32_MFMA_TF, 4), "traffic": traffic,
+                                   "executed_frac": round(ach * 16.0 / 36.0 / peak, 4), "traffic": traffic,
                                    "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                    "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4),
                                    "flops_per_launch_avg": round(pr["flops"] / pr["launches"] / 1e9, 3)}

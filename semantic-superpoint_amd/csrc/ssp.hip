@@ -17,6 +17,7 @@
 #include "conv_mfma.hip.h"
 #include "conv_wino.hip.h"
 #include "conv_wino_pipe.hip.h"
+#include "conv_wino_bf16.hip.h"
 #include "loss_kernels.hip.h"
 #include "dense_loss.hip.h"
 #include "pair_kernels.hip.h"
@@ -28,7 +29,8 @@ using namespace sspk;
 static thread_local std::string g_err;
 static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_kernel (tools/ablate_conv.py)
 // ssp_set_conv_algo: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) where eligible (software-pipelined kernel),
-// 2 = Winograd, un-pipelined kernel (conv_wino_kernel; kept for A/B measurements)
+// 2 = Winograd, un-pipelined kernel (conv_wino_kernel; kept for A/B measurements),
+// 3 = Winograd with bf16 matrix-core operands (conv_wino_bf16_kernel: opt-in reduced precision, BASELINE configs[3])
 static int g_conv_algo = 1;
 // 3x3 convolutions whose input channels fill whole 16-channel K-chunks run as Winograd F(2x2,3x3)
 static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks == 3 && conv_cin % CK == 0; }
@@ -337,6 +339,19 @@ static int launch_wino_pipe_t(const ConvArgs& a, int nblocks, hipStream_t st) {
 }
 
 template <int IN_MODE, bool WIDE>
+static int launch_wino_bf16_t(const ConvArgs& a, int nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_wino_bf16_kernel<IN_MODE, WIDE>;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BF16_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), BF16_LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int IN_MODE, bool WIDE>
 static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   static bool attr_set = false;
   auto kern = conv_wino_kernel<IN_MODE, WIDE>;
@@ -386,6 +401,11 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
       c.cin == 64)
     fam = SSP_PROF_CONV_BIG_FWD;
   ProfScope ps(h, fam, st, flops, bytes);
+  if (c.wino && g_conv_algo == 3) {
+    a.wpk_bytes /= 2;  // bf16 weights
+    if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true>(a, nblocks, st) : launch_wino_bf16_t<0, false>(a, nblocks, st);
+    return wide ? launch_wino_bf16_t<1, true>(a, nblocks, st) : launch_wino_bf16_t<1, false>(a, nblocks, st);
+  }
   if (c.wino && g_conv_algo == 1) {
     if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true>(a, nblocks, st) : launch_wino_pipe_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_pipe_t<1, true>(a, nblocks, st) : launch_wino_pipe_t<1, false>(a, nblocks, st);
@@ -422,6 +442,20 @@ static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) 
   using G = WgradWinoGeom<WIDE>;
   static bool attr_set = false;
   auto kern = wgrad_wino_kernel<IN_MODE, WIDE>;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), G::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int IN_MODE, bool WIDE>
+static int launch_wgrad_wino_bf16_t(const WgradArgs& a, int nblocks, hipStream_t st) {
+  using G = WgradWinoGeom<WIDE>;
+  static bool attr_set = false;
+  auto kern = wgrad_wino_bf16_kernel<IN_MODE, WIDE>;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_set = true;
@@ -472,9 +506,14 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
     const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
     const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
     ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes);
-    if (wino) {
+    if (wino && g_conv_algo == 3) {
+      if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false>(a, nblocks, st)));
+      else CHK((wide ? launch_wgrad_wino_bf16_t<1, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false>(a, nblocks, st)));
+    } else if (wino) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_t<0, true>(a, nblocks, st) : launch_wgrad_wino_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_t<1, true>(a, nblocks, st) : launch_wgrad_wino_t<1, false>(a, nblocks, st)));
+    }
+    if (wino) {
       hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
                          a.ncob, nsplit);
       HIPCHK(hipGetLastError());
@@ -501,7 +540,10 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   const int nchunks = cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
   if (wino) {
     const int total = ncob * nchunks * WB_FLOATS;
-    if (g_conv_algo == 1)  // 8-channel stages of the pipelined kernel: twice as many chunks of half the size
+    if (g_conv_algo == 3)
+      hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w,
+                         reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks);
+    else if (g_conv_algo == 1)  // 8-channel stages of the pipelined kernel: twice as many chunks of half the size
       hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
                          2 * nchunks, 0, 0, ncob, 2 * nchunks);
     else
@@ -654,7 +696,11 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
     const bool wino = wino_ok(3, 256 * h->nheads);
     const int total = 2 * 16 * (wino ? WC : 9) * CK * NB;
     for (int k = 0; k < h->nheads; ++k) {
-      if (wino && g_conv_algo == 1)
+      if (wino && g_conv_algo == 3)
+        hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
+                           P(h, h->L[heads[k]].w_off), reinterpret_cast<__bf16*>(h->wpk_heads_bwd), 256, 128, 1,
+                           32 * h->nheads, 32 * k, 0, 2, 32);
+      else if (wino && g_conv_algo == 1)
         hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
       else if (wino)
@@ -1410,8 +1456,8 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 2)
-    return fail(-1, "conv algo must be 0 (direct implicit GEMM), 1 (Winograd, pipelined) or 2 (Winograd, un-pipelined)");
+  if (algo < 0 || algo > 3)
+    return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined) or 3 (Winograd, bf16 operands)");
   g_conv_algo = algo;
   return 0;
 }
