@@ -27,9 +27,58 @@ __device__ __forceinline__ void reduce_by_column(float (&v)[NV], float* smem, in
 // ------------------------------------------------------------------------------------------------
 // First layer: Conv2d(1, 64, 3, padding=1) on the grayscale image (models/unet_parts.py:14, in_ch = 1).
 // K = 9: HBM-bound (writes 256 B per pixel).  16 lanes per pixel, float4 of channels per lane.
-// Also accumulates the BatchNorm sums.  grid: ceil(npix / (16 * PIX_ITERS)), block 256.
+// Also accumulates the BatchNorm sums.
 // ------------------------------------------------------------------------------------------------
-constexpr int C0_ITERS = 64;
+// Row-based work split (a block owns image rows, its 16 pixel lanes walk along x): no per-pixel integer division,
+// the row tests are wave-uniform.  grid: l0_grid(N * H), block 256.
+constexpr int L0_UNROLL = 4;        // pixels in flight per thread, pass 1
+constexpr int L0_UNROLL_APPLY = 4;  // pass 2 (2 was slower: 281 vs 236 us per view)
+static inline int l0_grid(long rows) {
+  const long per = (rows + 1023) / 1024;
+  return (int)((rows + per - 1) / per);
+}
+
+// the 3x3 neighbourhood of pixel (row, ox) of a one-channel image, zero-padded.  Every load is unconditional from
+// a clamped (always valid) address and zeroed afterwards: `cond ? load : 0` compiles to one exec-masked branch and
+// one s_waitcnt per tap, which serialises the nine latencies (measured: 306 us vs 150 us per view for pass 2).
+__device__ __forceinline__ void l0_taps(const float* __restrict__ xr, int ox, bool up, bool down, int W, float (&xv)[9]) {
+  const bool l = ox > 0, r = ox < W - 1;
+  const int xl = l ? ox - 1 : ox, xq = r ? ox + 1 : ox;
+  const int ru = up ? -W : 0, rd = down ? W : 0;
+  const float t0 = xr[ru + xl], t1 = xr[ru + ox], t2 = xr[ru + xq];
+  const float t3 = xr[xl], t4 = xr[ox], t5 = xr[xq];
+  const float t6 = xr[rd + xl], t7 = xr[rd + ox], t8 = xr[rd + xq];
+  xv[0] = (up && l) ? t0 : 0.f;
+  xv[1] = up ? t1 : 0.f;
+  xv[2] = (up && r) ? t2 : 0.f;
+  xv[3] = l ? t3 : 0.f;
+  xv[4] = t4;
+  xv[5] = r ? t5 : 0.f;
+  xv[6] = (down && l) ? t6 : 0.f;
+  xv[7] = down ? t7 : 0.f;
+  xv[8] = (down && r) ? t8 : 0.f;
+}
+
+// four output channels of the first layer in registers; y() is THE fma chain of the layer (forward and the
+// recomputation in its BatchNorm backward must agree bit for bit, or the ReLU mask would differ)
+struct L0Conv {
+  float w[4][9], b[4];
+  __device__ __forceinline__ void load(const float* __restrict__ wt, const float* __restrict__ bias, int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      b[i] = bias[c0 + i];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) w[i][t] = wt[(c0 + i) * 9 + t];
+    }
+  }
+  __device__ __forceinline__ float y(int i, const float (&xv)[9]) const {
+    float o = b[i];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o = fmaf(xv[t], w[i][t], o);
+    return o;
+  }
+};
+
 __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            double* __restrict__ stats, int N, int H, int W) {
@@ -37,39 +86,27 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
   const int tid = threadIdx.x;
   const int q = tid & 15;      // channel quad
   const int pl = tid >> 4;     // pixel lane 0..15
-  float wr[4][9];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wr[c][t] = w[(q * 4 + c) * 9 + t];
-  const float4 bv = *reinterpret_cast<const float4*>(bias + q * 4);
-  const long npix = (long)N * H * W;
+  L0Conv cv;
+  cv.load(w, bias, q * 4);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const long base = (long)blockIdx.x * 16 * C0_ITERS;
-  for (int it = 0; it < C0_ITERS; ++it) {
-    const long p = base + it * 16 + pl;
-    if (p >= npix) break;
-    const int xx = (int)(p % W);
-    const int yy = (int)((p / W) % H);
-    const float* xi = x + p;
-    float v[9];
+  const int rows = N * H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int oy = row % H;
+    const bool up = oy > 0, down = oy < H - 1;
+    const float* xr = x + (size_t)row * W;
+    float* orow = out + (size_t)row * W * 64 + q * 4;
+    for (int ox = pl; ox < W; ox += 16) {
+      float v[9];
+      l0_taps(xr, ox, up, down, W, v);
+      float o[4];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+      for (int c = 0; c < 4; ++c) o[c] = cv.y(c, v);
+      *reinterpret_cast<float4*>(orow + (size_t)ox * 64) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int gy = yy + dy - 1, gx = xx + dx - 1;
-        v[dy * 3 + dx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? xi[(dy - 1) * W + (dx - 1)] : 0.f;
+      for (int c = 0; c < 4; ++c) {
+        acc[c] += o[c];
+        acc[4 + c] += o[c] * o[c];
       }
-    float o[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) o[c] = fmaf(v[t], wr[c][t], o[c]);
-    *reinterpret_cast<float4*>(out + p * 64 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      acc[c] += o[c];
-      acc[4 + c] += o[c] * o[c];
     }
   }
   if (stats != nullptr) {
@@ -328,17 +365,145 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
   }
 }
 
-// Layer 0 (Conv2d(1,64,3) + BN + ReLU): pass 2 of the BatchNorm backward FUSED with the first layer's weight
-// gradient.  dY0 is consumed in registers (dW0[co][tap] += dY0[p][co] * x[p+tap], db0 += dY0) and never written:
-// the input image needs no data gradient, so nothing else reads dY0.  Saves one 629 MB write and one 629 MB read
-// per view at B = 32 compared with bn_bwd apply + a separate weight-gradient kernel.
+// Pass 1 of a POOLED layer from the pooled activation the forward materialised (apool = maxpool(relu(z)), 1/4 of
+// the pixels) instead of Y: the only window position with dZ != 0 is the arg-max, where z == apool > 0, so
+// S1 = sum dOut*[apool > 0] and S2 = sum dOut*[apool > 0]*xhat with xhat = (z - beta)/gamma (z = gamma*xhat + beta).
+// Reads 2 x 1/4 tensors instead of 1/4 + 1.  Channels with gamma == 0 (xhat not recoverable from z) take the
+// window scan over Y like bn_bwd_kernel<true, true, false>.  C % 4 == 0.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs a, const float* __restrict__ apool,
+                                                                 const float* __restrict__ beta) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int nq = a.C >> 2, rows = 256 / nq;
+  const int q = tid % nq, pl = tid / nq;
+  const int c0 = q * 4;
+  const int Ho = a.H / 2, Wo = a.W / 2;
+  const long npix = (long)a.N * Ho * Wo;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pl < rows) {
+    float bev[4], igv[4], scv[4], shv[4], muv[4], isv[4];
+    bool degenerate = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g = a.gamma[c0 + i];
+      bev[i] = beta[c0 + i];
+      igv[i] = g != 0.f ? 1.f / g : 0.f;
+      degenerate |= g == 0.f;
+      scv[i] = a.scale[c0 + i]; shv[i] = a.shift[c0 + i]; muv[i] = a.mean[c0 + i]; isv[i] = a.invstd[c0 + i];
+    }
+    for (long p = (long)blockIdx.x * rows + pl; p < npix; p += (long)gridDim.x * rows) {
+      const float4 d4 = *reinterpret_cast<const float4*>(a.dout + (size_t)p * a.d_cs + a.d_co + c0);
+      const float4 z4 = *reinterpret_cast<const float4*>(apool + (size_t)p * a.C + c0);
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
+      if (!degenerate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dz = zv[i] > 0.f ? dv[i] : 0.f;
+          acc[i] += dz;
+          acc[4 + i] += dz * ((zv[i] - bev[i]) * igv[i]);
+        }
+      } else {
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((long)Wo * Ho));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float best = -1.f, yb = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const size_t yo = ((size_t)(n * a.H + 2 * oy + (k >> 1)) * a.W + 2 * ox + (k & 1));
+            const float yv = a.y[yo * a.y_cs + a.y_co + c0 + i];
+            const float av = fmaxf(fmaf(yv, scv[i], shv[i]), 0.f);
+            if (av > best) { best = av; yb = yv; }
+          }
+          const float dz = best > 0.f ? dv[i] : 0.f;
+          acc[i] += dz;
+          acc[4 + i] += dz * ((yb - muv[i]) * isv[i]);
+        }
+      }
+    }
+  }
+  reduce_by_column<8>(acc, red, nq);
+  if (tid < nq) {
+    double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 2 * a.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsafeAtomicAdd(sm + c0 + i, (double)acc[i]);
+      unsafeAtomicAdd(sm + a.C + c0 + i, (double)acc[4 + i]);
+    }
+  }
+}
+
+// Layer 0 (Conv2d(1,64,3) + BN + ReLU).  Both passes RECOMPUTE the layer's conv output y0 from the one-channel
+// input image (L0Conv::y, 9 fma per value) instead of reading it back: 629 MB less HBM traffic per pass and view at
+// B = 32.  Row-based like conv0_direct_kernel; L0_UNROLL pixels per thread are loaded before the arithmetic.
+// pass 1: S1 = sum dZ, S2 = sum dZ * xhat over one view (reads dOut only)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a, const float* __restrict__ x,
+                                                               const float* __restrict__ w0,
+                                                               const float* __restrict__ b0) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int q = tid & 15, pl = tid >> 4;
+  const int c0 = q * 4;
+  L0Conv cv;
+  cv.load(w0, b0, c0);
+  float scv[4], shv[4], muv[4], isv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    scv[i] = a.scale[c0 + i]; shv[i] = a.shift[c0 + i]; muv[i] = a.mean[c0 + i]; isv[i] = a.invstd[c0 + i];
+  }
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int rows = a.N * a.H, W = a.W;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int oy = row % a.H;
+    const bool up = oy > 0, down = oy < a.H - 1;
+    const float* xr = x + (size_t)row * W;
+    const float* drow = a.dout + (size_t)row * W * 64 + c0;
+    for (int ox0 = pl; ox0 < W; ox0 += 16 * L0_UNROLL) {
+      float4 d4[L0_UNROLL];
+      float xv[L0_UNROLL][9];
+#pragma unroll
+      for (int j = 0; j < L0_UNROLL; ++j) {
+        const bool ok = ox0 + 16 * j < W;
+        const int ox = ok ? ox0 + 16 * j : W - 1;  // clamped: the loads stay branch-free
+        const float4 d = *reinterpret_cast<const float4*>(drow + (size_t)ox * 64);
+        d4[j] = ok ? d : make_float4(0.f, 0.f, 0.f, 0.f);  // dZ == 0 past the end of the row
+        l0_taps(xr, ox, up, down, W, xv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < L0_UNROLL; ++j) {
+        const float dv[4] = {d4[j].x, d4[j].y, d4[j].z, d4[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float yv = cv.y(i, xv[j]);
+          const float z = fmaf(yv, scv[i], shv[i]);
+          const float dz = z > 0.f ? dv[i] : 0.f;
+          acc[i] += dz;
+          acc[4 + i] += dz * ((yv - muv[i]) * isv[i]);
+        }
+      }
+    }
+  }
+  reduce_by_column<8>(acc, red, 16);
+  if (tid < 16) {
+    double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsafeAtomicAdd(sm + c0 + i, (double)acc[i]);
+      unsafeAtomicAdd(sm + 64 + c0 + i, (double)acc[4 + i]);
+    }
+  }
+}
+
+// pass 2 FUSED with the first layer's weight gradient.  dY0 is consumed in registers (dW0[co][tap] += dY0[p][co] *
+// x[p+tap]) and never written: the input image needs no data gradient, so nothing else reads dY0.
 __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a, const float* __restrict__ x,
+                                                              const float* __restrict__ w0, const float* __restrict__ b0,
                                                               float* __restrict__ dw) {
   __shared__ float red[256 * 10];
   const int tid = threadIdx.x;
-  const int q = tid & 15, pl = tid >> 4;  // channel quad, pixel lane (16 pixels per block iteration)
+  const int q = tid & 15, pl = tid >> 4;  // channel quad, pixel lane
   const int c0 = q * 4;
-  const long npix = (long)a.N * a.H * a.W;
+  L0Conv cv;
+  cv.load(w0, b0, c0);
   float scv[4], shv[4], muv[4], isv[4], k1v[4], k2v[4], gsv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -347,33 +512,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a,
     k2v[i] = a.k12[64 + c0 + i];
     gsv[i] = a.gamma[c0 + i] * isv[i];
   }
-  float wacc[4][9], bacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float wacc[4][9];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int t = 0; t < 9; ++t) wacc[i][t] = 0.f;
-  for (long p = (long)blockIdx.x * 16 + pl; p < npix; p += (long)gridDim.x * 16) {
-    const int ox = (int)(p % a.W), oy = (int)((p / a.W) % a.H);
-    const float4 d4 = *reinterpret_cast<const float4*>(a.dout + (size_t)p * 64 + c0);
-    const float4 y4 = *reinterpret_cast<const float4*>(a.y + (size_t)p * 64 + c0);
-    const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
-    float xv[9];
+  const int rows = a.N * a.H, W = a.W;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int oy = row % a.H;
+    const bool up = oy > 0, down = oy < a.H - 1;
+    const float* xr = x + (size_t)row * W;
+    const float* drow = a.dout + (size_t)row * W * 64 + c0;
+    for (int ox0 = pl; ox0 < W; ox0 += 16 * L0_UNROLL_APPLY) {
+      float4 d4[L0_UNROLL_APPLY];
+      float xv[L0_UNROLL_APPLY][9];
+      bool ok[L0_UNROLL_APPLY];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int gy = oy + dy - 1, gx = ox + dx - 1;
-        xv[dy * 3 + dx] = ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? x[p + (dy - 1) * a.W + (dx - 1)] : 0.f;
+      for (int j = 0; j < L0_UNROLL_APPLY; ++j) {
+        ok[j] = ox0 + 16 * j < W;
+        const int ox = ok[j] ? ox0 + 16 * j : W - 1;  // clamped: the loads stay branch-free
+        d4[j] = *reinterpret_cast<const float4*>(drow + (size_t)ox * 64);
+        l0_taps(xr, ox, up, down, W, xv[j]);
       }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float z = fmaf(yv[i], scv[i], shv[i]);
-      const float dz = z > 0.f ? dv[i] : 0.f;
-      const float xh = (yv[i] - muv[i]) * isv[i];
-      const float g = gsv[i] * (dz - k1v[i] - xh * k2v[i]);
-      bacc[i] += g;
+      for (int j = 0; j < L0_UNROLL_APPLY; ++j) {
+        const float dv[4] = {d4[j].x, d4[j].y, d4[j].z, d4[j].w};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wacc[i][t] = fmaf(g, xv[t], wacc[i][t]);
+        for (int i = 0; i < 4; ++i) {
+          const float yv = cv.y(i, xv[j]);
+          const float z = fmaf(yv, scv[i], shv[i]);
+          const float dz = z > 0.f ? dv[i] : 0.f;
+          const float xh = (yv - muv[i]) * isv[i];
+          const float g = ok[j] ? gsv[i] * (dz - k1v[i] - xh * k2v[i]) : 0.f;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) wacc[i][t] = fmaf(g, xv[j][t], wacc[i][t]);
+        }
+      }
     }
   }
   // block reduction over the 16 pixel lanes, one channel of the quad at a time: [256][10] floats
@@ -382,15 +556,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a,
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) red[tid * 10 + t] = wacc[i][t];
-    red[tid * 10 + 9] = bacc[i];
     __syncthreads();
-    if (tid < 160) {  // 16 quads x 10 values
+    if (tid < 160) {  // 16 quads x 10 slots
       const int qq = tid / 10, t = tid - qq * 10;
-      float sum = 0.f;
+      if (t < 9) {
+        float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sum += red[(r * 16 + qq) * 10 + t];
-      const int co = qq * 4 + i;
-      if (t < 9) atomicAdd(dw + co * 9 + t, sum);
+        for (int r = 0; r < 16; ++r) sum += red[(r * 16 + qq) * 10 + t];
+        atomicAdd(dw + (qq * 4 + i) * 9 + t, sum);
+      }
     }
   }
 }

@@ -771,7 +771,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     Slot& S = *SS.s[k];
     const LayerDesc& d = h->L[0];
     const long npix = (long)N * H * W;
-    hipLaunchKernelGGL(conv0_direct_kernel, dim3(cdiv(npix, 16 * C0_ITERS)), dim3(256), 0, st, S.x, P(h, d.w_off),
+    hipLaunchKernelGGL(conv0_direct_kernel, dim3(l0_grid((long)N * H)), dim3(256), 0, st, S.x, P(h, d.w_off),
                        P(h, d.b_off), S.Y[0], train ? S.bn[0].stats : nullptr, N, H, W);
     HIPCHK(hipGetLastError());
     CHK(bn_finalize(h, S, 0, (double)npix, train, st));
@@ -813,12 +813,22 @@ static int bn_layer_backward(ssp_handle* h, Slot& S, int l, const float* dout, i
   float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
   if (l == 0) {
     // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised)
-    const long npix = (long)N * H * W;
-    const int nb = std::min(cdiv(npix, 16), 1024);
-    hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb), dim3(256), 0, st, a);
+    const int nb = l0_grid((long)N * H);
+    // (both passes recompute Y0 from the image instead of reading S.Y[0])
+    hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, P(h, d.w_off), P(h, d.b_off));
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(64), 0, st, a.sums, S.bn[l].k12, dg, db, a.dbias, a.gamma, a.invstd,
                        64, a.count);
-    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, Gd(h, d.w_off));
+    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, P(h, d.w_off), P(h, d.b_off),
+                       Gd(h, d.w_off));
+  } else if (relu && pool_after && S.Apool[l] != nullptr && d.cout % 4 == 0 && d_cs == d.cout && d_co == 0) {
+    // pass 1 from the pooled activation (1/4 of Y's bytes), pass 2 over Y
+    const long npix = (long)N * (H / 2) * (W / 2);
+    const int rows = 256 / (d.cout / 4);
+    const int nb = std::max(1, std::min(cdiv(npix, rows), 1024));
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb), dim3(256), 0, st, a, S.Apool[l], P(h, d.be_off));
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a.C, 64)), dim3(64), 0, st, a.sums, S.bn[l].k12, dg, db, a.dbias, a.gamma,
+                       a.invstd, a.C, a.count);
+    hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb), dim3(256), 0, st, a);
   } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, S.bn[l].k12, dg, db, st)));
   else if (relu) CHK((launch_bn_bwd<true, false>(a, S.bn[l].k12, dg, db, st)));
   else CHK((launch_bn_bwd<false, false>(a, S.bn[l].k12, dg, db, st)));

@@ -115,6 +115,42 @@ def test_backward_vs_oracle(arch):
         _grad_close(mine, r, k)
 
 
+def test_backward_with_zero_gamma_in_pooled_layers():
+    """The pooled layers' BatchNorm-backward sums are taken from the pooled activation (xhat = (z - beta)/gamma);
+    channels with gamma == 0 must fall back to the scan over Y (all four window values tie at relu(beta))."""
+    arch, B, H, W = ARCHS[0], 2, 32, 48
+    sd = C.init_state_dict(arch, seed=9)
+    rs = np.random.RandomState(5)
+    for k in ("inc.conv.conv.4", "down1.mpconv.1.conv.4", "down2.mpconv.1.conv.4"):
+        g = np.array(sd[k + ".weight"], dtype=np.float32, copy=True)
+        b = np.array(sd[k + ".bias"], dtype=np.float32, copy=True)
+        g[[1, 6, 7, 33]] = 0.0
+        b[[1, 6]] = 0.3     # relu(beta) > 0: the first window element wins the tie
+        b[[7, 33]] = -0.2   # dead channel
+        sd[k + ".weight"], sd[k + ".bias"] = g, b
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32))
+    tsd = C.to_torch(sd, requires_grad=True)
+    ref = C.forward(tsd, x, arch)
+    gs = {k: torch.from_numpy(rs.randn(*ref[k].shape).astype(np.float32)) for k in ref}
+    sum((ref[k] * gs[k]).sum() for k in ref).backward()
+    e = _engine(arch, B, H, W, sd)
+    dev = _dev()
+    e.forward(x.to(dev), slot=0, train=True, want=())
+    e.zero_grad()
+    e.backward(0, gs["semi"].to(dev), gs["desc"].to(dev), None)
+    torch.cuda.synchronize()
+    gd = e.grad_dict()
+    zeroed = [1, 6, 7, 33]
+    for layer in ("inc.conv.conv.4", "down1.mpconv.1.conv.4", "down2.mpconv.1.conv.4"):
+        for k in (layer + ".weight", layer + ".bias"):
+            r, mine = tsd[k].grad, gd[k].cpu()
+            # the zeroed channels exactly (no ReLU flips possible there: z == beta), the rest statistically
+            assert (mine[zeroed] - r[zeroed]).abs().max() <= 1e-4 * float(r.abs().max()), k
+            _grad_close(mine, r, k, l2=5e-2, mx=0.1)
+    for k in ("inc.conv.conv.3.weight", "inc.conv.conv.0.weight", "down1.mpconv.1.conv.0.weight"):
+        _grad_close(gd[k].cpu(), tsd[k].grad, k, l2=5e-2, mx=0.1)
+
+
 def _to_dev(sample):
     return {k: v.to(_dev()).contiguous() for k, v in sample.items()}
 
