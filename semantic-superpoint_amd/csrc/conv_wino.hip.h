@@ -41,6 +41,16 @@ __device__ __forceinline__ int wino_raw_off(int r, int c, int q, int HC) {
   return ((r * (HC >> 1) + (c >> 1)) * 2 + ((c ^ (c >> 1)) & 1)) * CK + q * 4;
 }
 
+// relu(v * scale + shift) of a loaded quad, 0 for zero-padding pixels: two packed fmas + one v_med3 per element
+// (clamp to [0, +inf] or, for padding, to [0, 0]) instead of fma + max + select, on the staging path of the MFMA loop
+__device__ __forceinline__ f32x4 bn_relu_quad(f32x4 v, f32x4 sc, f32x4 sh, bool padding) {
+  const float hi = padding ? 0.f : __builtin_inff();
+  v = __builtin_elementwise_fma(v, sc, sh);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, hi);
+  return v;
+}
+
 template <int IN_MODE, bool WIDE>
 __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs a) {
   constexpr int TTX = WIDE ? 16 : 4;            // tiles per block row
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
   constexpr int NX = (G::HT * G::WT + 31) / 32;  // halo pixels per thread (pp = (tid >> 4) + 32 i)
   constexpr int ND = G::TH * G::TW / 32;
   f32x4 xreg[NX], dreg[ND];
-  unsigned xmask = 0, dmask = 0;
+  unsigned xmask = 0;
 
   // halo / dY raster positions of this thread's staging slots (slot i = pixel (tid >> 4) + 32 i), packed r | c << 8
   int xrc[NX], drc[ND];
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
         const_cast<float*>(pr_ ? a.in2 : a.in) + (size_t)n_ * a.H * a.W * a.in_cs, 0, a.H * xrow, 0x00020000); \
     const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
         const_cast<float*>(pr_ ? a.dout2 : a.dout) + (size_t)n_ * a.H * a.W * a.dout_cs, 0, a.H * drow, 0x00020000); \
-    xmask = 0; dmask = 0;                                                                                     \
+    xmask = 0;                                                                                                \
     _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                          \
       const int gy = ty0_ - 1 + (xrc[i] & 255), gx = tx0_ - 1 + (xrc[i] >> 8);                                \
       const bool ok = xq >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;                \
@@ -436,7 +446,6 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
       const bool ok = dq >= 0 && gy < a.H && gx < a.W;                                                        \
       dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
           rd_, ok ? (unsigned)(gy * drow + gx * dpix + dq) : OOB, 0, 0));                                     \
-      dmask |= (ok ? 1u : 0u) << i;                                                                           \
     }                                                                                                         \
   }
 
@@ -461,23 +470,15 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
       for (int i = 0; i < NX; ++i) {
         const int pp = (tid >> 4) + 32 * i;
         if (pp < G::HT * G::WT) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if ((xmask >> i) & 1u) {
-            v = xreg[i];
-            if (IN_MODE != 0) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
-            }
-          }
+          f32x4 v = xreg[i];  // 0 from the buffer load where the pixel / channel quad is outside
+          if (IN_MODE != 0) v = bn_relu_quad(v, sc, sh, !((xmask >> i) & 1u));
           *reinterpret_cast<f32x4*>(sX + pp * 64 + q16 * 4) = v;
         }
       }
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         const int pp = (tid >> 4) + 32 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((dmask >> i) & 1u) v = dreg[i];
-        *reinterpret_cast<f32x4*>(sD + pp * 64 + q16 * 4) = v;
+        *reinterpret_cast<f32x4*>(sD + pp * 64 + q16 * 4) = dreg[i];  // 0 where outside
       }
     }
     __syncthreads();

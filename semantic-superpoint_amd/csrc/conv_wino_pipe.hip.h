@@ -125,10 +125,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                         \
       if (k == 0 || r1) {                                                                                   \
         f32x4 v = hreg[k];                                                                                  \
-        if (IN_MODE != 0) {                                                                                 \
-          _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], psc[e], psh[e]), 0.f);      \
-          if (hoff[k] == OOB) v = f32x4{0.f, 0.f, 0.f, 0.f};                                                \
-        }                                                                                                   \
+        if (IN_MODE != 0) v = bn_relu_quad(v, psc, psh, hoff[k] == OOB);                                    \
         *reinterpret_cast<f32x4*>(sR + r_lds[k]) = v;                                                       \
       }                                                                                                     \
     }                                                                                                       \
@@ -224,11 +221,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       for (int k = 0; k < 2; ++k) {  // raw halo of stage g+1 -> sR (BatchNorm + ReLU of the producer, zero padding)
         if (k == 0 || r1) {
           f32x4 v = hreg[k];
-          if (IN_MODE != 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], psc[e], psh[e]), 0.f);
-            if (hoff[k] == OOB) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+          if (IN_MODE != 0) v = bn_relu_quad(v, psc, psh, hoff[k] == OOB);
           *reinterpret_cast<f32x4*>(sR + r_lds[k]) = v;
         }
       }
