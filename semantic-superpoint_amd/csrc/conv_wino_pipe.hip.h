@@ -16,6 +16,10 @@
 #pragma once
 #include "conv_wino.hip.h"
 
+#ifndef PIPE_ABL
+#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 2 no staging, 4 no barriers, 8 no MFMA
+#endif
+
 namespace sspk {
 
 constexpr int PK = 8;                              // channels per stage
@@ -29,6 +33,31 @@ constexpr int PIPE_LDS_BYTES = (2 * (PA_FLOATS + PB_FLOATS) + PR_FLOATS + PS_FLO
 // the row index, so that the stride-2 pixel reads of the transform hit 4 different 32-byte slots
 __device__ __forceinline__ int pipe_raw_off(int p, int q) { return ((p & ~3) + ((p + (p >> 2)) & 3)) * PK + q * 4; }
 
+// Output transform of one epilogue round for one wave: its 8 components (rows 0,1 or rows 2,3 of M) of accumulator
+// registers rd*8 .. rd*8+7 -> partial outputs Y = A^T M A (2x2 pixels per tile) in the staging half-tile `o`.
+// CHALF 0: rows 0,1 -> top = m0 + m1, bottom = m1;  CHALF 1: rows 2,3 -> top = m2, bottom = -m2 - m3.
+template <int CHALF, int TTX, int TW>
+__device__ __forceinline__ void pipe_out_rows(const f32x16 (&acc)[8], int rd, int lh, int mt, float* __restrict__ o) {
+#pragma unroll
+  for (int r8 = 0; r8 < 8; r8 += 2) {
+    const int r = rd * 8 + r8;
+    f32x2 top[4], bot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 a = {acc[j][r], acc[j][r + 1]}, b = {acc[4 + j][r], acc[4 + j][r + 1]};
+      if (CHALF == 0) { top[j] = a + b; bot[j] = b; }
+      else { top[j] = a; bot[j] = -(a + b); }
+    }
+    const f32x2 y00 = top[0] + top[1] + top[2], y01 = top[1] - top[2] - top[3];
+    const f32x2 y10 = bot[0] + bot[1] + bot[2], y11 = bot[1] - bot[2] - bot[3];
+    const int csl = ((r8 & 3) + 8 * (r8 >> 2) + 4 * lh) | (mt << 4);  // even r8: tiles csl, csl + 1 are x neighbours
+    const int cty = csl / TTX, ctx = csl % TTX;
+    float* p = o + ((2 * cty) * TW + 2 * ctx) * NB;
+    p[0] = y00[0]; p[NB] = y01[0]; p[2 * NB] = y00[1]; p[3 * NB] = y01[1];
+    p[TW * NB] = y10[0]; p[TW * NB + NB] = y11[0]; p[TW * NB + 2 * NB] = y10[1]; p[TW * NB + 3 * NB] = y11[1];
+  }
+}
+
 template <int IN_MODE, bool WIDE>
 __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const ConvArgs a) {
   constexpr int TTX = WIDE ? 16 : 4;
@@ -40,7 +69,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   float* const sS = sR + PR_FLOATS;  // scale[Cin] | shift[Cin] of the producer's BatchNorm (IN_MODE 1)
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the per-wave roles below become uniform branches
   const int li = lane & 31, lh = lane >> 5;
   const int chalf = wave & 1, nt = (wave >> 1) & 1, mt = wave >> 2;
 
@@ -179,11 +209,14 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   PIPE_ISSUE_LOADS()
   __syncthreads();
 
+  // component (1,1) (accumulator 5 of the first component half) starts at the conv bias: it enters all four outputs
+  // of a tile with coefficient +1, which saves the bias adds of the epilogue
+  const float acc5_init = chalf == 0 ? bias_v : 0.f;
   f32x16 acc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[c][r] = c == 5 ? acc5_init : 0.f;
 
   // components C and C + 1 of this wave's half: fragment reads, then 2 x 4 MFMAs on two alternating accumulators.
   // The staging work of the next stage is sliced BETWEEN the MFMA groups (fenced with sched_barrier so that the
@@ -195,15 +228,17 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   const float4 b0_##C = *reinterpret_cast<const float4*>(cA + b_off + (C) * 2 * NB * 4);                    \
   const float4 b1_##C = *reinterpret_cast<const float4*>(cA + b_off + ((C) + 1) * 2 * NB * 4);
 #define PIPE_MFMA_LO(C)                                                                                     \
+  if (!(PIPE_ABL & 8)) {                                                                                    \
   acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.x, b0_##C.x, acc[C], 0, 0, 0);                       \
   acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.x, b1_##C.x, acc[(C) + 1], 0, 0, 0);           \
   acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.y, b0_##C.y, acc[C], 0, 0, 0);                       \
-  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.y, b1_##C.y, acc[(C) + 1], 0, 0, 0);
+  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.y, b1_##C.y, acc[(C) + 1], 0, 0, 0); }
 #define PIPE_MFMA_HI(C)                                                                                     \
+  if (!(PIPE_ABL & 8)) {                                                                                    \
   acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.z, b0_##C.z, acc[C], 0, 0, 0);                       \
   acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.z, b1_##C.z, acc[(C) + 1], 0, 0, 0);           \
   acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_##C.w, b0_##C.w, acc[C], 0, 0, 0);                       \
-  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.w, b1_##C.w, acc[(C) + 1], 0, 0, 0);
+  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.w, b1_##C.w, acc[(C) + 1], 0, 0, 0); }
 #define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
   int tile = tile0, chunk = 0;
@@ -217,6 +252,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       PIPE_FENCE();
       PIPE_MFMA_LO(0)
       PIPE_FENCE();
+      if (!(PIPE_ABL & 2))
 #pragma unroll
       for (int k = 0; k < 2; ++k) {  // raw halo of stage g+1 -> sR (BatchNorm + ReLU of the producer, zero padding)
         if (k == 0 || r1) {
@@ -230,21 +266,28 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       PIPE_FENCE();
       PIPE_FRAG(2)
       f32x4* wdst = reinterpret_cast<f32x4*>(nB + PA_FLOATS);  // weights of stage g+1 -> sB of the other buffer
+      if (!(PIPE_ABL & 2))
 #pragma unroll
       for (int j = 0; j < 4; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];
       PIPE_FENCE();
       PIPE_MFMA_LO(2)
       PIPE_FENCE();
-      PIPE_ISSUE_LOADS()
+      if (!(PIPE_ABL & 2)) PIPE_ISSUE_LOADS()
       PIPE_FENCE();
       PIPE_MFMA_HI(2)
     }
     // the fragments of components 4, 5 come from the SAME buffer: read them before the barrier so that the matrix pipe
     // restarts right after it
     PIPE_FRAG(4)
-    __syncthreads();
+    if (!(PIPE_ABL & 4)) __syncthreads();
     // ---- second half: components 4..7 || transform of stage g+1: sR -> sA of the other buffer ----
-    {
+    if (PIPE_ABL & 2) {
+      PIPE_MFMA_LO(4)
+      PIPE_MFMA_HI(4)
+      PIPE_FRAG(6)
+      PIPE_MFMA_LO(6)
+      PIPE_MFMA_HI(6)
+    } else {
       const f32x4 u0 = *reinterpret_cast<const f32x4*>(sR + t_u[0]), w0 = *reinterpret_cast<const f32x4*>(sR + t_w[0]);
       const f32x4 u1 = *reinterpret_cast<const f32x4*>(sR + t_u[1]), w1 = *reinterpret_cast<const f32x4*>(sR + t_w[1]);
       const f32x4 u2 = *reinterpret_cast<const f32x4*>(sR + t_u[2]), w2 = *reinterpret_cast<const f32x4*>(sR + t_w[2]);
@@ -270,9 +313,12 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       PIPE_MFMA_LO(6)
       PIPE_MFMA_HI(6)
     }
-    __syncthreads();
+    if (!(PIPE_ABL & 4)) __syncthreads();
 
     if (++chunk == nst) {
+      if (PIPE_ABL & 1) {
+        if (tid == 1023) p_out[0] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][0] + acc[5][0] + acc[6][0] + acc[7][0];
+      } else {
       // ---- tile epilogue: the consumed (sA, sB) pair of this stage is the 64 KB staging tile ----
       const int tx_i = tile % a.tiles_x, t2 = tile / a.tiles_x;
       const int ty0 = (t2 % a.tiles_y) * TH, tx0 = tx_i * TW, n = t2 / a.tiles_y;
@@ -281,34 +327,15 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       // BOTH component halves write their partial outputs of 32 tiles to two 32 KB staging half-tiles, which meet in
       // the 16-byte store loop.  Compact tile index csl = (sl & 15) | (sl >> 5) << 4.
       float* const stg = smem + buf * (PA_FLOATS + PB_FLOATS) + chalf * (TH * TW * NB / 2);
-      const float bz = chalf == 0 ? bias_v : 0.f;
       const int q16 = tid & 15;
       const int co4 = cob * NB + q16 * 4;
       const int nvalid = min(4, a.Cout - co4);
 #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-          const int r = rd * 8 + r8;
-          const int csl = ((r8 & 3) + 8 * (r8 >> 2) + 4 * lh) | (mt << 4);
-          const int cty = csl / TTX, ctx = csl % TTX;
-          float s0[4], s1[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (chalf == 0) {
-              s0[j] = acc[j][r] + acc[4 + j][r];
-              s1[j] = acc[4 + j][r];
-            } else {
-              s0[j] = acc[j][r];
-              s1[j] = -acc[j][r] - acc[4 + j][r];
-            }
-          }
-          float* o = stg + ((2 * cty) * TW + 2 * ctx) * NB + nt * 32 + li;
-          o[0] = s0[0] + s0[1] + s0[2] + bz;
-          o[NB] = s0[1] - s0[2] - s0[3] + bz;
-          o[TW * NB] = s1[0] + s1[1] + s1[2] + bz;
-          o[TW * NB + NB] = s1[1] - s1[2] - s1[3] + bz;
-        }
+        // accumulator registers in pairs (r, r + 1) = Winograd tiles (ctx, ctx + 1): packed adds.  The conv bias is
+        // already inside component (1,1) (accumulator 5 of the first half), which enters all four outputs with +1.
+        if (chalf == 0) pipe_out_rows<0, TTX, TW>(acc, rd, lh, mt, stg + nt * 32 + li);
+        else pipe_out_rows<1, TTX, TW>(acc, rd, lh, mt, stg + nt * 32 + li);
         __syncthreads();
         const float* const s0p = smem + buf * (PA_FLOATS + PB_FLOATS);
 #pragma unroll
@@ -323,6 +350,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
                             *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4);
             ssum += v;
             ssq += v * v;
+            if (PIPE_ABL & 16) continue;
             float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
             if (nvalid == 4) {
               *reinterpret_cast<f32x4*>(p) = v;
@@ -335,10 +363,11 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
         }
         __syncthreads();  // round 1 / the next-but-one stage overwrite the staging half-tiles
       }
+      }
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[c][r] = c == 5 ? acc5_init : 0.f;
       chunk = 0;
       tile += per_cob;
     }
