@@ -17,7 +17,8 @@
 #include "conv_wino.hip.h"
 
 #ifndef PIPE_ABL
-#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 2 no staging, 4 no barriers, 8 no MFMA
+#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 2 no staging, 4 no barriers, 8 no MFMA,
+                    // 16 no global stores, 32 no output transform, 64 no input transform, 128 no weight LDS write, 256 no halo LDS write, 512 no global loads
 #endif
 
 namespace sspk {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
 
   // load cursor: the (tile, chunk) whose global loads are issued next
   int ld_tile = tile0, ld_chunk = 0;
-#define PIPE_ISSUE_LOADS()                                                                                  \
+#define PIPE_ISSUE_HALO()                                                                                   \
   {                                                                                                         \
     if (ld_chunk == 0) {                                                                                    \
       const int tt_ = min(ld_tile, t_end - 1);  /* past the end: harmless redundant loads of the last tile */ \
@@ -144,11 +145,16 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     }                                                                                                       \
     _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                           \
       hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], ld_chunk * PK * 4, 0)); \
+  }
+  // weights of the same (tile, chunk); advances the load cursor
+#define PIPE_ISSUE_W()                                                                                      \
+  {                                                                                                         \
     const int wbase_ = (cob * nst + ld_chunk) * PB_FLOATS * 4;                                              \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
       wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 8192, 0)); \
     if (++ld_chunk == nst) { ld_chunk = 0; ld_tile += per_cob; }                                            \
   }
+#define PIPE_ISSUE_LOADS() { PIPE_ISSUE_HALO() PIPE_ISSUE_W() }
   // registers -> LDS for the stage whose loads are in the registers (buffer index B)
 #define PIPE_WRITE_STAGE(B)                                                                                 \
   {                                                                                                         \
@@ -246,13 +252,12 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     const int buf = g & 1;
     const float* const cA = smem + buf * (PA_FLOATS + PB_FLOATS);
     float* const nB = smem + (buf ^ 1) * (PA_FLOATS + PB_FLOATS);
-    // ---- first half: components 0..3 of this wave's half || registers (stage g+1) -> LDS, loads of stage g+2 ----
+    // ---- first half: components 0..3 of this wave's half || raw halo (stage g+1) -> sR, halo loads of stage g+2 ----
     {
       PIPE_FRAG(0)
       PIPE_FENCE();
       PIPE_MFMA_LO(0)
       PIPE_FENCE();
-      if (!(PIPE_ABL & 2))
 #pragma unroll
       for (int k = 0; k < 2; ++k) {  // raw halo of stage g+1 -> sR (BatchNorm + ReLU of the producer, zero padding)
         if (k == 0 || r1) {
@@ -265,29 +270,18 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       PIPE_MFMA_HI(0)
       PIPE_FENCE();
       PIPE_FRAG(2)
-      f32x4* wdst = reinterpret_cast<f32x4*>(nB + PA_FLOATS);  // weights of stage g+1 -> sB of the other buffer
-      if (!(PIPE_ABL & 2))
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];
+      PIPE_ISSUE_HALO()  // a full stage ahead of their use
       PIPE_FENCE();
       PIPE_MFMA_LO(2)
-      PIPE_FENCE();
-      if (!(PIPE_ABL & 2)) PIPE_ISSUE_LOADS()
-      PIPE_FENCE();
       PIPE_MFMA_HI(2)
     }
     // the fragments of components 4, 5 come from the SAME buffer: read them before the barrier so that the matrix pipe
     // restarts right after it
     PIPE_FRAG(4)
-    if (!(PIPE_ABL & 4)) __syncthreads();
-    // ---- second half: components 4..7 || transform of stage g+1: sR -> sA of the other buffer ----
-    if (PIPE_ABL & 2) {
-      PIPE_MFMA_LO(4)
-      PIPE_MFMA_HI(4)
-      PIPE_FRAG(6)
-      PIPE_MFMA_LO(6)
-      PIPE_MFMA_HI(6)
-    } else {
+    __syncthreads();
+    // ---- second half: components 4..7 || transform of stage g+1: sR -> sA, weights (g+1) -> sB of the other buffer,
+    // weight loads of stage g+2 ----
+    {
       const f32x4 u0 = *reinterpret_cast<const f32x4*>(sR + t_u[0]), w0 = *reinterpret_cast<const f32x4*>(sR + t_w[0]);
       const f32x4 u1 = *reinterpret_cast<const f32x4*>(sR + t_u[1]), w1 = *reinterpret_cast<const f32x4*>(sR + t_w[1]);
       const f32x4 u2 = *reinterpret_cast<const f32x4*>(sR + t_u[2]), w2 = *reinterpret_cast<const f32x4*>(sR + t_w[2]);
@@ -311,6 +305,12 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = t[1] - t[3];
       PIPE_FENCE();
       PIPE_MFMA_LO(6)
+      PIPE_FENCE();
+      f32x4* wdst = reinterpret_cast<f32x4*>(nB + PA_FLOATS);  // weights of stage g+1 -> sB of the other buffer
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];
+      PIPE_ISSUE_W()
+      PIPE_FENCE();
       PIPE_MFMA_HI(6)
     }
     if (!(PIPE_ABL & 4)) __syncthreads();
@@ -373,6 +373,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     }
   }
 #undef PIPE_ISSUE_LOADS
+#undef PIPE_ISSUE_HALO
+#undef PIPE_ISSUE_W
 #undef PIPE_WRITE_STAGE
 #undef PIPE_TRANSFORM
 #undef PIPE_FRAG
