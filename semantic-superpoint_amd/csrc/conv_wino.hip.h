@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
   float* sR = smem + WA_FLOATS + WB_FLOATS;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar wave roles
   const int li = lane & 31, lh = lane >> 5;
   const int chalf = wave & 1, nt = (wave >> 1) & 1, mt = wave >> 2;
 
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
   float* sS = smem + G::X_FLOATS + G::D_FLOATS;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar wave roles
   const int li = lane & 31, lh = lane >> 5;
   const int coh = wave & 1, irow = wave >> 1;
 
