@@ -35,37 +35,34 @@ __global__ __launch_bounds__(256) void sem_count_kernel(const int64_t* __restric
 
 // Fused bilinear upsample (align_corners=False) + log-softmax + NLL (+ gradient), one wave per 8x8 pixel tile
 // shifted by (4,4): all 64 pixels of such a tile interpolate between the same 4 source cells.
-// Lanes hold CLASSES (c = lane + 64*j, j < 3): the 4 corner logit vectors live in 12 registers per lane, the
-// wave walks the 64 pixels (bilinear weights / label broadcast from the lane that owns the pixel), softmax is
-// two wave reductions per pixel, and d(convSout) of the 4 corners accumulates in 12 registers per lane that are
-// flushed with 12 atomics per lane and tile.  sem_cnt[view] must be final before a BWD launch.
+//   pass A (lanes = PIXELS): the wave walks the C classes; the 4 corner logits of a class are wave-uniform (scalar
+//     loads), every lane interpolates its own pixel and accumulates sum_c exp(l_c - m) and l_label.  The shift m is
+//     not the exact maximum but the bound sum_k w_k max_c corner_k[c] >= max_c l_c (the weights are >= 0 and sum to
+//     1), which costs 4 wave reductions per TILE instead of 2 per pixel; log-sum-exp is shift invariant.
+//   pass B (lanes = CLASSES, c = lane + 64 j, j < 3; gradient only): the wave walks the counted pixels (weights,
+//     label, m and g / sum broadcast with v_readlane), d(convSout) of the 4 corners accumulates in 12 registers per
+//     lane that are flushed with 12 atomics per lane and tile.  sem_cnt[view] must be final before a BWD launch.
 // MODE bit 0: accumulate the loss sum, bit 1: accumulate d(convSout); the training step does both in ONE pass (3).
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {  // src_lane wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ sout, const int64_t* __restrict__ labels,
                                                      float* __restrict__ dsout, StepAccum* __restrict__ acc, int view,
                                                      int B, int Hc, int Wc, int H, int W, int C, int cs) {
   __shared__ float red[4];
-  const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int TX = Wc + 1, TY = Hc + 1;
-  const long ntile = (long)B * TX * TY;
+  const int ntile = B * TX * TY;
   constexpr bool FWD = (MODE & 1) != 0, BWD = (MODE & 2) != 0;
-  float nll_acc = 0.f;
+  float nll_acc = 0.f;  // per lane (= per pixel slot of the tiles this wave visits)
   const float g = BWD ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
-  for (long tile = (long)blockIdx.x * 4 + wave_in_blk; tile < ntile; tile += (long)gridDim.x * 4) {
-    const int tx = (int)(tile % TX) - 1, ty = (int)((tile / TX) % TY) - 1, n = (int)(tile / ((long)TX * TY));
+  for (int tile = blockIdx.x * 4 + wave_in_blk; tile < ntile; tile += gridDim.x * 4) {
+    const int tx = tile % TX - 1, ty = (tile / TX) % TY - 1, n = tile / (TX * TY);
     const int cy0 = max(ty, 0), cy1 = min(ty + 1, Hc - 1), cx0 = max(tx, 0), cx1 = min(tx + 1, Wc - 1);
     const int cidx[4] = {cy0 * Wc + cx0, cy0 * Wc + cx1, cy1 * Wc + cx0, cy1 * Wc + cx1};
-    // corner logits of this lane's classes
-    float cv[4][3];
-    bool cok[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int c = lane + 64 * j;
-      cok[j] = c < C;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) cv[k][j] = cok[j] ? sout[((size_t)n * Hc * Wc + cidx[k]) * cs + c] : 0.f;
-    }
-    // this lane's pixel: weights and label
+    // this lane's pixel: bilinear weights and label
     const int y = 8 * ty + 4 + (lane >> 3), x = 8 * tx + 4 + (lane & 7);
     const bool inside = y >= 0 && y < H && x >= 0 && x < W;
     int label_l = C;
@@ -76,50 +73,61 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
       up_src(x, Wc, W, a0, a1, wx1_l);
       label_l = (int)labels[((size_t)n * H + y) * W + x];
     }
-    const unsigned long long counted_mask = __ballot(inside && label_l != C);
-    float dacc[4][3];
+    const bool counted = inside && label_l != C;
+    const unsigned long long counted_mask = __ballot(counted);
+    if (counted_mask == 0ull) continue;  // wave-uniform: ignored / outside pixels contribute nothing
+    const float wy0_l = 1.f - wy1_l, wx0_l = 1.f - wx1_l;
+    const float w4_l[4] = {wy0_l * wx0_l, wy0_l * wx1_l, wy1_l * wx0_l, wy1_l * wx1_l};
+    const float* cp[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) cp[k] = sout + ((size_t)n * Hc * Wc + cidx[k]) * cs;
+    // corner logits of this lane's classes (pass B) and their maxima over the classes (the shift of pass A)
+    float cv[4][3];
+    bool cok[3];
+    float m_l = 0.f;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) dacc[k][j] = 0.f;
-    for (int p = 0; p < 64; ++p) {
-      if (!((counted_mask >> p) & 1ull)) continue;  // wave-uniform: ignored / outside pixels contribute nothing
-      const float wy1 = __shfl(wy1_l, p), wx1 = __shfl(wx1_l, p);
-      const int label = __shfl(label_l, p);
-      const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-      float l[3];
+    for (int j = 0; j < 3; ++j) cok[j] = lane + 64 * j < C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        l[j] = wy0 * (wx0 * cv[0][j] + wx1 * cv[1][j]) + wy1 * (wx0 * cv[2][j] + wx1 * cv[3][j]);
-        if (cok[j]) mx = fmaxf(mx, l[j]);
+        cv[k][j] = cok[j] ? cp[k][lane + 64 * j] : 0.f;
+        if (cok[j]) mx = fmaxf(mx, cv[k][j]);
       }
-      mx = wave_max(mx);
-      float e[3], se = 0.f;
+      m_l = fmaf(w4_l[k], wave_max(mx), m_l);
+    }
+    // ---- pass A: lanes = pixels ----
+    float se = 0.f, ll = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+      const float l = fmaf(w4_l[0], cp[0][c], fmaf(w4_l[1], cp[1][c], fmaf(w4_l[2], cp[2][c], w4_l[3] * cp[3][c])));
+      se += __expf(l - m_l);
+      ll = c == label_l ? l : ll;
+    }
+    if (FWD && counted) nll_acc += (m_l + logf(se)) - ll;
+    if (BWD) {
+      // ---- pass B: lanes = classes ----
+      const float gi_l = g / se;
+      float dacc[4][3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        e[j] = cok[j] ? expf(l[j] - mx) : 0.f;
-        se += e[j];
-      }
-      se = wave_sum(se);
-      if (FWD) {
-        const int lj = label >> 6;  // wave-uniform
-        const float lsel = lj == 0 ? l[0] : (lj == 1 ? l[1] : l[2]);
-        const float ll = __shfl(lsel, label & 63);
-        nll_acc += (mx + logf(se)) - ll;  // identical in every lane; lane 0's copy is used
-      }
-      if (BWD) {
-        const float inv = 1.f / se;
-        const float w4[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dacc[k][j] = 0.f;
+      for (unsigned long long rest = counted_mask; rest != 0ull; rest &= rest - 1ull) {
+        const int p = __builtin_ctzll(rest);
+        const float w4[4] = {lane_bcast(w4_l[0], p), lane_bcast(w4_l[1], p), lane_bcast(w4_l[2], p), lane_bcast(w4_l[3], p)};
+        const float m = lane_bcast(m_l, p), gi = lane_bcast(gi_l, p);
+        const int label = __builtin_amdgcn_readlane(label_l, p);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const float d = g * (e[j] * inv - ((lane + 64 * j == label) ? 1.f : 0.f));
+          const float l = fmaf(w4[0], cv[0][j], fmaf(w4[1], cv[1][j], fmaf(w4[2], cv[2][j], w4[3] * cv[3][j])));
+          const float e = cok[j] ? __expf(l - m) : 0.f;
+          const float d = fmaf(e, gi, (lane + 64 * j == label) ? -g : 0.f);
 #pragma unroll
           for (int k = 0; k < 4; ++k) dacc[k][j] = fmaf(w4[k], d, dacc[k][j]);
         }
       }
-    }
-    if (BWD && counted_mask != 0ull) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if (cok[j]) {
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
     }
   }
   if (FWD) {
-    const float tot = block_sum_of_waves(nll_acc, red);
+    const float tot = block_sum_of_waves(wave_sum(nll_acc), red);
     if (threadIdx.x == 0) unsafeAtomicAdd(&acc->sem_sum[view], (double)tot);
   }
 }
