@@ -246,7 +246,8 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 /* Algorithm of the 3x3 forward / data-gradient convolutions whose input channels are a multiple of 16 (process-wide;
  * takes effect at the next forward, which re-packs the weights): 1 (default) = Winograd F(2x2,3x3) on the fp32 matrix
  * cores (2.25x fewer multiplies, fp32 throughout, results within ~1e-6 relative of the direct form; software-pipelined
- * kernel), 2 = the same without the software pipeline (A/B measurements), 0 = direct implicit GEMM,
+ * kernel whose weight fragments come straight from L2), 5 = the same pipeline with the weights staged through LDS,
+ * 2 = Winograd without the software pipeline (both for A/B measurements), 0 = direct implicit GEMM,
  * 3 = EXPERIMENTAL reduced precision: the Winograd kernels with bf16 matrix-core operands (fp32 storage, transforms,
  * accumulation and master weights); outputs within ~4e-3 relative RMS of fp32, gradients of the first layers up to
  * ~25 % off per step; never used for a reported fp32 number. */

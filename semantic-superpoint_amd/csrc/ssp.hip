@@ -325,10 +325,10 @@ struct ConvCall {
   bool wino = false;  // wpk holds pack_weights_wino_kernel's image: run conv_wino_kernel
 };
 
-template <int IN_MODE, bool WIDE>
+template <int IN_MODE, bool WIDE, bool GB = false>
 static int launch_wino_pipe_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_wino_pipe_kernel<IN_MODE, WIDE>;
+  auto kern = conv_wino_pipe_kernel<IN_MODE, WIDE, GB>;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES));
     attr_set = true;
@@ -406,7 +406,11 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true>(a, nblocks, st) : launch_wino_bf16_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_bf16_t<1, true>(a, nblocks, st) : launch_wino_bf16_t<1, false>(a, nblocks, st);
   }
-  if (c.wino && g_conv_algo == 1) {
+  if (c.wino && g_conv_algo == 1) {  // pipelined Winograd, weight fragments straight from L2 (default)
+    if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true, true>(a, nblocks, st) : launch_wino_pipe_t<0, false, true>(a, nblocks, st);
+    return wide ? launch_wino_pipe_t<1, true, true>(a, nblocks, st) : launch_wino_pipe_t<1, false, true>(a, nblocks, st);
+  }
+  if (c.wino && g_conv_algo == 5) {  // the same pipeline with the weights staged through LDS
     if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true>(a, nblocks, st) : launch_wino_pipe_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_pipe_t<1, true>(a, nblocks, st) : launch_wino_pipe_t<1, false>(a, nblocks, st);
   }
@@ -543,7 +547,7 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
     if (g_conv_algo == 3)
       hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w,
                          reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks);
-    else if (g_conv_algo == 1)  // 8-channel stages of the pipelined kernel: twice as many chunks of half the size
+    else if (g_conv_algo == 1 || g_conv_algo == 5)  // 8-channel stages of the pipelined kernel: twice as many chunks of half the size
       hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
                          2 * nchunks, 0, 0, ncob, 2 * nchunks);
     else
@@ -700,7 +704,7 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
         hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), reinterpret_cast<__bf16*>(h->wpk_heads_bwd), 256, 128, 1,
                            32 * h->nheads, 32 * k, 0, 2, 32);
-      else if (wino && g_conv_algo == 1)
+      else if (wino && (g_conv_algo == 1 || g_conv_algo == 5))
         hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
       else if (wino)
@@ -1466,8 +1470,9 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 3)
-    return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined) or 3 (Winograd, bf16 operands)");
+  if (algo < 0 || algo > 5 || algo == 4)
+    return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
+                    "operands) or 5 (Winograd, pipelined, weights staged through LDS)");
   g_conv_algo = algo;
   return 0;
 }
