@@ -17,7 +17,7 @@
 #include "conv_wino.hip.h"
 
 #ifndef PIPE_ABL
-#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 2 no staging, 4 no barriers, 8 no MFMA,
+#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 2 no staging, 4 no barriers, 8 no MFMA, 1024 cycle-stamp trace,
                     // 16 no global stores, 32 no output transform, 64 no input transform, 128 no weight LDS write, 256 no halo LDS write, 512 no global loads
 #endif
 
@@ -263,9 +263,19 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.w, b1_##C[3], acc[(C) + 1], 0, 0, 0); }
 #define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+#if PIPE_ABL & 1024  // cycle stamps of every wave of block 8 -> the stats buffer (tools/ablate_pipe.py trace)
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+  unsigned long long ets[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // epilogue, per round: start, transform done, barrier passed, stores issued
+#define PIPE_TS(V) V = __builtin_amdgcn_s_memtime();
+#define PIPE_ETS(I) ets[I] = __builtin_amdgcn_s_memtime();
+#else
+#define PIPE_TS(V)
+#define PIPE_ETS(I)
+#endif
   int tile = tile0, chunk = 0;
   for (int g = 0; g < nstages; ++g) {
     const int buf = g & 1;
+    PIPE_TS(ts0)
     const float* const cA = smem + buf * (PA_FLOATS + PB_FLOATS);
     float* const nB = smem + (buf ^ 1) * (PA_FLOATS + PB_FLOATS);
     // ---- first half: components 0..3 of this wave's half || raw halo (stage g+1) -> sR, halo loads of stage g+2 ----
@@ -297,7 +307,9 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     // restarts right after it
     PIPE_FRAG(4, bA0, bA1)
     PIPE_BLOAD(bB0, bB1, 6, chunk)
+    PIPE_TS(ts1)
     __syncthreads();
+    PIPE_TS(ts2)
     // ---- second half: components 4..7 || transform of stage g+1: sR -> sA, weights (g+1) -> sB of the other buffer,
     // weight loads of stage g+2 ----
     {
@@ -334,7 +346,14 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       PIPE_FENCE();
       PIPE_MFMA_HI(6)
     }
+    PIPE_TS(ts3)
     if (!(PIPE_ABL & 4)) __syncthreads();
+#if PIPE_ABL & 1024
+    if (blockIdx.x == 8 && lane == 0 && g < 100 && p_stats != nullptr) {
+      unsigned long long* q = reinterpret_cast<unsigned long long*>(p_stats) + (g * 8 + wave) * 4;
+      q[0] = ts0; q[1] = ts1; q[2] = ts2; q[3] = ts3;
+    }
+#endif
 
     if (++chunk == nst) {
       if (PIPE_ABL & 1) {
@@ -355,9 +374,12 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       for (int rd = 0; rd < 2; ++rd) {
         // accumulator registers in pairs (r, r + 1) = Winograd tiles (ctx, ctx + 1): packed adds.  The conv bias is
         // already inside component (1,1) (accumulator 5 of the first half), which enters all four outputs with +1.
+        PIPE_ETS(rd * 4 + 0)
         if (chalf == 0) pipe_out_rows<0, TTX, TW>(acc, rd, lh, mt, stg + nt * 32 + li);
         else pipe_out_rows<1, TTX, TW>(acc, rd, lh, mt, stg + nt * 32 + li);
+        PIPE_ETS(rd * 4 + 1)
         __syncthreads();
+        PIPE_ETS(rd * 4 + 2)
         const float* const s0p = smem + buf * (PA_FLOATS + PB_FLOATS);
 #pragma unroll
         for (int k = 0; k < (TH * TW * 8) / WINO_THREADS; ++k) {
@@ -382,9 +404,17 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
             }
           }
         }
+        PIPE_ETS(rd * 4 + 3)
         __syncthreads();  // round 1 / the next-but-one stage overwrite the staging half-tiles
       }
       }
+#if PIPE_ABL & 1024
+      if (blockIdx.x == 8 && lane == 0 && g < 100 && p_stats != nullptr) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(p_stats) + 3200 + ((g / nst) * 8 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = ets[i];
+      }
+#endif
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -404,7 +434,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
 #undef PIPE_MFMA_HI
 #undef PIPE_FENCE
 
-  if (p_stats != nullptr) {
+  if (p_stats != nullptr && !(PIPE_ABL & 1024)) {
     __syncthreads();
     float* red = smem;
     *reinterpret_cast<f32x4*>(red + tid * 8) = ssum;

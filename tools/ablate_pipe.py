@@ -17,6 +17,40 @@ if sys.argv[1] == "build":
 elif sys.argv[1] == "run":
     for v in VARIANTS:
         subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(v)])
+elif sys.argv[1] == "trace":
+    # PIPE_ABL=1024 build: per-wave cycle stamps of block 8 at the stage boundaries (stage start, before / after the
+    # mid-stage barrier, before the end-of-stage barrier)
+    sys.path.insert(0, ROOT)
+    import numpy as np, torch
+    from semantic_superpoint_amd import lib as L
+    L.load_library(os.path.join(CSRC, "abl_1024.so"))
+    dev = torch.device("cuda:0")
+    N, H, W, C = 32, 240, 320, 64
+    x = torch.randn(N, H, W, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+    b = torch.zeros(C, device=dev); sc = torch.ones(C, device=dev); sh = torch.zeros(C, device=dev)
+    for mode in (0, 1):
+        st = torch.zeros(L.NREP, 2 * C, dtype=torch.float64, device=dev)
+        for _ in range(3): L.op_conv(x, w, b, 3, mode, sc, sh, st)
+        st.zero_(); L.op_conv(x, w, b, 3, mode, sc, sh, st); torch.cuda.synchronize()
+        t = st.cpu().numpy().view(np.int64).reshape(-1)[:100 * 8 * 4].reshape(100, 8, 4)
+        t0 = t[:, :, 0]
+        print("mode %d: stage period (wave 0), stages 8..40:" % mode, np.diff(t0[8:41, 0]).tolist())
+        for g in range(16, 25):
+            rows = []
+            for wv in range(8):
+                a0, a1, a2, a3 = t[g, wv]
+                nxt = t[g + 1, wv, 0]
+                rows.append("w%d[%4d|%3d|%4d|%4d]" % (wv, a1 - a0, a2 - a1, a3 - a2, nxt - a3))
+            print("  stage %2d (half1 | mid barrier | half2 | end barrier+epilogue): " % g + " ".join(rows))
+        print("  stage starts relative to wave 0:", (t0[16:24] - t0[16:24, :1]).tolist())
+        e = st.cpu().numpy().view(np.int64).reshape(-1)[3200:3200 + 12 * 8 * 8].reshape(12, 8, 8)
+        for ti in (2, 3):
+            base = t[ti * 8 + 7, :, 3]  # ts3 of the tile's last stage
+            print("  tile %d epilogue, per wave [ts3->start | r0 transform | r0 barrier | r0 stores | r0 barrier+ | r1 transform | r1 barrier | r1 stores | ->next stage]:" % ti)
+            for wv in range(8):
+                v = e[ti, wv]
+                nxt = t[ti * 8 + 8, wv, 0]
+                print("    w%d" % wv, [int(v[0] - base[wv]), int(v[1] - v[0]), int(v[2] - v[1]), int(v[3] - v[2]), int(v[4] - v[3]), int(v[5] - v[4]), int(v[6] - v[5]), int(v[7] - v[6]), int(nxt - v[7])])
 else:
     sys.path.insert(0, ROOT)
     import torch
