@@ -133,7 +133,7 @@ def main():
     if rank == 0:
         scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
         pairs_s = world * B * args.steps / dt
-        out = {"metric": "image-pairs/sec at 240x320 bs32 (pair training step)", "value": round(pairs_s, 2),
+        out = {"metric": "image-pairs/sec at %dx%d bs%d (pair training step)" % (H, W, B), "value": round(pairs_s, 2),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16" if args.conv_algo == 3 else "f32", "data": "synthetic",

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m
 // Device sampler for the sparse descriptor loss (distribution-level equivalent of the reference's
 // numpy/torch CPU sampling; parity tests pass the reference's own indices instead).
 // ------------------------------------------------------------------------------------------------
-constexpr int SAMPLER_MAX_CELLS = 2048;
+constexpr int SAMPLER_MAX_CELLS = 8192;  // 480x640 has 4800 cells; the sort runs on cap = max(2048, next power of two) keys
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -216,9 +216,10 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 // One block of 1024 threads per image.  match_a/match_b: [B][n_match] cell indices (u + v*Wc).
 __global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __restrict__ Hn, uint64_t seed,
                                                               int32_t* __restrict__ match_a, int32_t* __restrict__ match_b,
-                                                              int Hc, int Wc, int n_match) {
-  __shared__ uint64_t key[SAMPLER_MAX_CELLS];  // (random key << 32) | (cell_a << 16 ... ) packed below
-  __shared__ int32_t cellb[SAMPLER_MAX_CELLS];
+                                                              int Hc, int Wc, int n_match, int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sampler_smem[];  // 12 bytes per key slot
+  uint64_t* const key = reinterpret_cast<uint64_t*>(sampler_smem);  // (random key << 32) | cell_a
+  int32_t* const cellb = reinterpret_cast<int32_t*>(key + cap);
   __shared__ float Hs[9];
   __shared__ int nvalid;
   const int img = blockIdx.x, tid = threadIdx.x;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __res
     nvalid = 0;
   }
   __syncthreads();
-  for (int i = tid; i < SAMPLER_MAX_CELLS; i += 1024) {
+  for (int i = tid; i < cap; i += 1024) {
     uint64_t k = ~0ull;
     int32_t cb = 0;
     if (i < ncell) {
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __res
   }
   __syncthreads();
   // bitonic sort of the keys (ascending): valid cells come first in random order
-  for (int k2 = 2; k2 <= SAMPLER_MAX_CELLS; k2 <<= 1) {
+  for (int k2 = 2; k2 <= cap; k2 <<= 1) {
     for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < SAMPLER_MAX_CELLS; i += 1024) {
+      for (int i = tid; i < cap; i += 1024) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const bool up = (i & k2) == 0;

@@ -1161,8 +1161,16 @@ int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, 
   if (Hc * Wc > SAMPLER_MAX_CELLS) return fail(-1, "sampler supports at most %d cells", SAMPLER_MAX_CELLS);
   if (h->cfg.n_match > SAMPLER_MAX_CELLS) return fail(-1, "n_match too large for the device sampler");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sample_matches_kernel, dim3(batch), dim3(1024), 0, st, homographies_dev, seed, match_a_dev,
-                     match_b_dev, Hc, Wc, h->cfg.n_match);
+  int cap = 2048;  // power of two >= cells and >= n_match (2048 for every reference configuration)
+  while (cap < Hc * Wc || cap < h->cfg.n_match) cap <<= 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_matches_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SAMPLER_MAX_CELLS * 12));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sample_matches_kernel, dim3(batch), dim3(1024), (size_t)cap * 12, st, homographies_dev, seed, match_a_dev,
+                     match_b_dev, Hc, Wc, h->cfg.n_match, cap);
   const long tot = (long)batch * h->cfg.n_match * h->cfg.n_non;
   hipLaunchKernelGGL(sample_nonmatches_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, seed, nonmatch_b_dev, tot, Hc, Wc);
   HIPCHK(hipGetLastError());
