@@ -248,11 +248,13 @@ def test_sparse_loss_golden_full():
     assert abs(pos - float(g["pos"])) < 1e-4 and abs(neg - float(g["neg"])) < 1e-4
 
 
-def test_device_sampler_distribution():
+@pytest.mark.parametrize("B,H,W", [(4, 240, 320), (2, 480, 640)])
+def test_device_sampler_distribution(B, H, W):
     """ssp_sample_indices: every sampled match is a valid correspondence of the oracle, matches are distinct
-    when >= n_match candidates exist, non-matches are uniform over the grid."""
+    when >= n_match candidates exist, non-matches are uniform over the grid.  480x640 (4800 cells) exercises the
+    8192-key sort."""
     from semantic_superpoint_amd.lib import Engine
-    B, H, W = 4, 240, 320
+    Hc, Wc = H // 8, W // 8
     e = Engine("SuperPointNet_gauss2", B, H, W, _dev(), with_grad=False)
     rs = np.random.RandomState(2)
     Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(B)]).astype(np.float32))
@@ -260,15 +262,16 @@ def test_device_sampler_distribution():
     torch.cuda.synchronize()
     ma, mb, nm = ma.cpu(), mb.cpu(), nm.cpu()
     for i in range(B):
-        uv_a, uv_b = C.cell_matches(Hs[i], 30, 40)
-        valid = {int(a[0] + a[1] * 40): int(b[0] + b[1] * 40) for a, b in zip(uv_a, uv_b)}
+        uv_a, uv_b = C.cell_matches(Hs[i], Hc, Wc)
+        valid = {int(a[0] + a[1] * Wc): int(b[0] + b[1] * Wc) for a, b in zip(uv_a, uv_b)}
         bad = sum(1 for a, b in zip(ma[i].tolist(), mb[i].tolist()) if valid.get(a, -1) != b)
-        assert bad <= 2, bad  # rounding ties at .5 may differ (H_cell computed analytically on device)
+        assert bad <= 2 * (Hc * Wc) // 1200, bad  # rounding ties at .5 may differ (H_cell computed analytically on device)
         if len(valid) >= 1000:
             assert len(set(ma[i].tolist())) == 1000
-    assert nm.min() >= 0 and nm.max() < 1200
-    hist = torch.bincount(nm.reshape(-1).long(), minlength=1200).float()
-    assert hist.min() > 0.8 * hist.mean() and hist.max() < 1.2 * hist.mean()
+    assert nm.min() >= 0 and nm.max() < Hc * Wc
+    hist = torch.bincount(nm.reshape(-1).long(), minlength=Hc * Wc).float()
+    m = float(hist.mean())  # Poisson counts: every cell within 5 sigma of the mean
+    assert float(hist.min()) > m - 5 * m ** 0.5 and float(hist.max()) < m + 5 * m ** 0.5
     ma2, _, nm2 = e.sample_indices(Hs.to(_dev()), seed=1234)
     assert torch.equal(ma2.cpu(), ma) and torch.equal(nm2.cpu(), nm)  # deterministic in the seed
 
