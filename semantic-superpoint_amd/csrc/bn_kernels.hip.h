@@ -79,9 +79,15 @@ struct L0Conv {
   }
 };
 
-__global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           double* __restrict__ stats, int N, int H, int W) {
+__global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           double* __restrict__ stats0, double* __restrict__ stats1, int N,
+                                                           int H, int W) {
+  // blockIdx.y = view of the pair
+  const float* __restrict__ x = blockIdx.y ? x1 : x0;
+  float* __restrict__ out = blockIdx.y ? out1 : out0;
+  double* __restrict__ stats = blockIdx.y ? stats1 : stats0;
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x;
   const int q = tid & 15;      // channel quad
@@ -140,33 +146,37 @@ struct BnLayer {
   double count;
 };
 
-__global__ void bn_finalize_kernel(const BnLayer L, int train, int64_t* nbt) {
+__global__ void bn_finalize_kernel(const BnLayer L0, const BnLayer L1, int nviews, int train, int64_t* nbt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= L.C) return;
-  double mean, var;
-  if (train) {
-    double s1 = 0, s2 = 0;
-    for (int r = 0; r < NREP; ++r) {
-      s1 += L.stats[(size_t)r * 2 * L.C + c];
-      s2 += L.stats[(size_t)r * 2 * L.C + L.C + c];
+  if (c >= L0.C) return;
+  for (int v = 0; v < nviews; ++v) {  // view 0 then view 1: the running statistics are updated in the reference's order
+    const BnLayer& L = v ? L1 : L0;
+
+    double mean, var;
+    if (train) {
+      double s1 = 0, s2 = 0;
+      for (int r = 0; r < NREP; ++r) {
+        s1 += L.stats[(size_t)r * 2 * L.C + c];
+        s2 += L.stats[(size_t)r * 2 * L.C + L.C + c];
+      }
+      mean = s1 / L.count;
+      var = s2 / L.count - mean * mean;
+      if (var < 0) var = 0;
+      const double unbiased = L.count > 1 ? var * L.count / (L.count - 1) : var;
+      L.running_mean[c] = (float)(0.9 * (double)L.running_mean[c] + 0.1 * mean);
+      L.running_var[c] = (float)(0.9 * (double)L.running_var[c] + 0.1 * unbiased);
+      if (c == 0 && nbt != nullptr) *nbt += 1;
+    } else {
+      mean = L.running_mean[c];
+      var = L.running_var[c];
     }
-    mean = s1 / L.count;
-    var = s2 / L.count - mean * mean;
-    if (var < 0) var = 0;
-    const double unbiased = L.count > 1 ? var * L.count / (L.count - 1) : var;
-    L.running_mean[c] = (float)(0.9 * (double)L.running_mean[c] + 0.1 * mean);
-    L.running_var[c] = (float)(0.9 * (double)L.running_var[c] + 0.1 * unbiased);
-    if (c == 0 && nbt != nullptr) *nbt += 1;
-  } else {
-    mean = L.running_mean[c];
-    var = L.running_var[c];
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float sc = L.gamma[c] * invstd;
+    L.mean[c] = (float)mean;
+    L.invstd[c] = invstd;
+    L.scale[c] = sc;
+    L.shift[c] = L.beta[c] - (float)mean * sc;
   }
-  const float invstd = (float)(1.0 / sqrt(var + 1e-5));
-  const float sc = L.gamma[c] * invstd;
-  L.mean[c] = (float)mean;
-  L.invstd[c] = invstd;
-  L.scale[c] = sc;
-  L.shift[c] = L.beta[c] - (float)mean * sc;
 }
 
 // MaxPool2d(2)(ReLU(BN(y))) materialised once per pooled layer boundary (layers 1, 3, 5): the three consumers
@@ -214,13 +224,16 @@ struct BnBwdArgs {
   double* sums;      // [NREP][2C] pass-1 accumulators
   const float* k12;  // [2C] S1/n, S2/n reduced over the replicas by bn_bwd_sums_kernel (pass 2 input)
   float* dbias;      // conv bias gradient (accumulated) or nullptr
+  const float* x;      // layer 0 only: the one-channel input image (y0 is recomputed from it)
+  const float* apool;  // pooled layers: maxpool(relu(bn(y))) materialised by the forward
   int N, H, W, C;
   int y_cs, y_co, d_cs, d_co, dy_cs, dy_co;
   double count;
 };
 
 template <bool RELU, bool POOL, bool APPLY>
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const BnBwdArgs a1) {
+  const BnBwdArgs& a = blockIdx.y ? a1 : a0;  // the two views of a pair ride one launch
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x;
   const int nq = (a.C + 3) / 4;                 // channel quads
@@ -370,8 +383,10 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 // S1 = sum dOut*[apool > 0] and S2 = sum dOut*[apool > 0]*xhat with xhat = (z - beta)/gamma (z = gamma*xhat + beta).
 // Reads 2 x 1/4 tensors instead of 1/4 + 1.  Channels with gamma == 0 (xhat not recoverable from z) take the
 // window scan over Y like bn_bwd_kernel<true, true, false>.  C % 4 == 0.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs a, const float* __restrict__ apool,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs a0, const BnBwdArgs a1,
                                                                  const float* __restrict__ beta) {
+  const BnBwdArgs& a = blockIdx.y ? a1 : a0;
+  const float* __restrict__ apool = a.apool;
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x;
   const int nq = a.C >> 2, rows = 256 / nq;
@@ -436,9 +451,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs
 // input image (L0Conv::y, 9 fma per value) instead of reading it back: 629 MB less HBM traffic per pass and view at
 // B = 32.  Row-based like conv0_direct_kernel; L0_UNROLL pixels per thread are loaded before the arithmetic.
 // pass 1: S1 = sum dZ, S2 = sum dZ * xhat over one view (reads dOut only)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a0, const BnBwdArgs a1,
                                                                const float* __restrict__ w0,
                                                                const float* __restrict__ b0) {
+  const BnBwdArgs& a = blockIdx.y ? a1 : a0;
+  const float* __restrict__ x = a.x;
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x;
   const int q = tid & 15, pl = tid >> 4;
@@ -495,9 +512,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
 
 // pass 2 FUSED with the first layer's weight gradient.  dY0 is consumed in registers (dW0[co][tap] += dY0[p][co] *
 // x[p+tap]) and never written: the input image needs no data gradient, so nothing else reads dY0.
-__global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0, const BnBwdArgs a1,
                                                               const float* __restrict__ w0, const float* __restrict__ b0,
                                                               float* __restrict__ dw) {
+  const BnBwdArgs& a = blockIdx.y ? a1 : a0;
+  const float* __restrict__ x = a.x;
   __shared__ float red[256 * 10];
   const int tid = threadIdx.x;
   const int q = tid & 15, pl = tid >> 4;  // channel quad, pixel lane
@@ -572,26 +591,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a,
 // Between the two passes: reduce the NREP replicas of the fp64 sums ONCE (one thread per channel) into
 // k12 = {S1/n, S2/n} for pass 2, and accumulate dgamma += S2, dbeta += S1.  (Letting every pass-2 thread sum the
 // 32 replicas itself cost a fixed ~110 us per launch: 2.6 ms per step in the first profiles.)
-__global__ void bn_bwd_sums_kernel(const double* __restrict__ sums, float* __restrict__ k12, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta, float* __restrict__ dbias, const float* __restrict__ gamma,
-                                   const float* __restrict__ invstd, int C, double count) {
+__global__ void bn_bwd_sums_kernel(const BnBwdArgs a0, const BnBwdArgs a1, int nviews, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int r = 0; r < NREP; ++r) {
-    s1 += sums[(size_t)r * 2 * C + c];
-    s2 += sums[(size_t)r * 2 * C + C + c];
+  if (c >= a0.C) return;
+  for (int v = 0; v < nviews; ++v) {  // the views accumulate into the same gradients: one after the other in this thread
+    const BnBwdArgs& a = v ? a1 : a0;
+    const int C = a.C;
+    double s1 = 0, s2 = 0;
+    for (int r = 0; r < NREP; ++r) {
+      s1 += a.sums[(size_t)r * 2 * C + c];
+      s2 += a.sums[(size_t)r * 2 * C + C + c];
+    }
+    const float k1 = (float)(s1 / a.count), k2 = (float)(s2 / a.count);
+    float* k12 = const_cast<float*>(a.k12);
+    k12[c] = k1;
+    k12[C + c] = k2;
+    if (dbeta != nullptr) dbeta[c] += (float)s1;
+    if (dgamma != nullptr) dgamma[c] += (float)s2;
+    // Gradient of the conv bias that feeds this BatchNorm: sum_p dY = gamma*invstd*(S1 - n*k1 - k2*sum xhat) == 0 in
+    // exact arithmetic (the reference's autograd produces rounding noise here).  It is
+    // evaluated from the sums (what is left is the fp32 rounding of k1) instead of by one float atomic per channel
+    // and block in pass 2, which cost ~110 us per launch through same-address contention.
+    if (a.dbias != nullptr) a.dbias[c] += a.gamma[c] * a.invstd[c] * (float)(s1 - a.count * (double)k1);
   }
-  const float k1 = (float)(s1 / count), k2 = (float)(s2 / count);
-  k12[c] = k1;
-  k12[C + c] = k2;
-  if (dbeta != nullptr) dbeta[c] += (float)s1;
-  if (dgamma != nullptr) dgamma[c] += (float)s2;
-  // Gradient of the conv bias that feeds this BatchNorm: sum_p dY = gamma*invstd*(S1 - n*k1 - k2*sum xhat) == 0 in
-  // exact arithmetic (the reference's autograd produces rounding noise here).  It is
-  // evaluated from the sums (what is left is the fp32 rounding of k1) instead of by one float atomic per channel
-  // and block in pass 2, which cost ~110 us per launch through same-address contention.
-  if (dbias != nullptr) dbias[c] += gamma[c] * invstd[c] * (float)(s1 - count * (double)k1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -563,18 +563,19 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   return 0;
 }
 
-// pass 1 (sums) -> replica reduction + dgamma/dbeta -> pass 2 (apply)
+// pass 1 (sums) -> replica reduction + dgamma/dbeta -> pass 2 (apply); a[0 .. nviews-1] ride the same launches
 template <bool RELU, bool POOL>
-static int launch_bn_bwd(const BnBwdArgs& a, float* k12, float* dgamma, float* dbeta, hipStream_t st) {
+static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* dbeta, hipStream_t st) {
   // a.dbias (conv bias gradient, may be null) is produced by bn_bwd_sums_kernel
-  const int nq = (a.C + 3) / 4, rows = 256 / nq;
-  const long npix = (long)a.N * (POOL ? a.H / 2 : a.H) * (POOL ? a.W / 2 : a.W);
+  const BnBwdArgs& a0 = a[0];
+  const BnBwdArgs& a1 = a[nviews - 1];
+  const int nq = (a0.C + 3) / 4, rows = 256 / nq;
+  const long npix = (long)a0.N * (POOL ? a0.H / 2 : a0.H) * (POOL ? a0.W / 2 : a0.W);
   int nb = cdiv(npix, rows);
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a.C, 64)), dim3(64), 0, st, a.sums, k12, dgamma, dbeta, a.dbias, a.gamma,
-                     a.invstd, a.C, a.count);
-  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a0.C, 64)), dim3(64), 0, st, a0, a1, nviews, dgamma, dbeta);
+  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -674,16 +675,20 @@ int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops
 static const float* P(const ssp_handle* h, size_t off) { return h->buf.params_dev + off; }
 static float* Gd(const ssp_handle* h, size_t off) { return h->buf.grads_dev + off; }
 
-static int bn_finalize(ssp_handle* h, Slot& S, int l, double count, int train, hipStream_t st) {
+// BatchNorm statistics -> affine of layer l for every view of the set, ONE launch (view 0 then view 1 in the same thread)
+static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, double count, int train, hipStream_t st) {
   const LayerDesc& d = h->L[l];
-  BnLayer b;
-  b.stats = S.bn[l].stats; b.gamma = P(h, d.g_off); b.beta = P(h, d.be_off);
-  b.running_mean = h->buf.bn_running_dev + d.bn_ch_off;
-  b.running_var = h->buf.bn_running_dev + h->n_bn_ch + d.bn_ch_off;
-  b.scale = S.bn[l].scale; b.shift = S.bn[l].shift; b.mean = S.bn[l].mean; b.invstd = S.bn[l].invstd;
-  b.C = d.cout; b.count = count;
+  BnLayer b[2];
+  for (int k = 0; k < nviews; ++k) {
+    Slot& S = *slots[k];
+    b[k].stats = S.bn[l].stats; b[k].gamma = P(h, d.g_off); b[k].beta = P(h, d.be_off);
+    b[k].running_mean = h->buf.bn_running_dev + d.bn_ch_off;
+    b[k].running_var = h->buf.bn_running_dev + h->n_bn_ch + d.bn_ch_off;
+    b[k].scale = S.bn[l].scale; b[k].shift = S.bn[l].shift; b[k].mean = S.bn[l].mean; b[k].invstd = S.bn[l].invstd;
+    b[k].C = d.cout; b[k].count = count;
+  }
   int64_t* nbt = h->buf.num_batches_tracked_dev ? h->buf.num_batches_tracked_dev + d.bn_index : nullptr;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, b, train, nbt);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, b[0], b[nviews - 1], nviews, train, nbt);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -756,8 +761,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
     c.stats2 = (d.bn && train) ? B.bn[l].stats : nullptr;
   }
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
-  if (d.bn)
-    for (int k = 0; k < SS.n; ++k) CHK(bn_finalize(h, *SS.s[k], l, (double)N * H * W, train, st));  // view 0 then 1
+  if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));  // view 0 then 1 inside the kernel
   return 0;
 }
 
@@ -770,15 +774,15 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     S.bsums_dirty = false;
   }
   CHK(pack_all(h, for_backward, st));
-  // layer 0: direct 1->64 conv (HBM-bound; one launch per view)
-  for (int k = 0; k < SS.n; ++k) {
-    Slot& S = *SS.s[k];
+  // layer 0: direct 1->64 conv (HBM-bound; the views ride one launch, blockIdx.y)
+  {
     const LayerDesc& d = h->L[0];
-    const long npix = (long)N * H * W;
-    hipLaunchKernelGGL(conv0_direct_kernel, dim3(l0_grid((long)N * H)), dim3(256), 0, st, S.x, P(h, d.w_off),
-                       P(h, d.b_off), S.Y[0], train ? S.bn[0].stats : nullptr, N, H, W);
+    Slot &S0 = *SS.s[0], &S1 = *SS.s[SS.n - 1];
+    hipLaunchKernelGGL(conv0_direct_kernel, dim3(l0_grid((long)N * H), SS.n), dim3(256), 0, st, S0.x, S1.x, P(h, d.w_off),
+                       P(h, d.b_off), S0.Y[0], S1.Y[0], train ? S0.bn[0].stats : nullptr, train ? S1.bn[0].stats : nullptr,
+                       N, H, W);
     HIPCHK(hipGetLastError());
-    CHK(bn_finalize(h, S, 0, (double)npix, train, st));
+    CHK(bn_finalize(h, SS.s, SS.n, 0, (double)N * H * W, train, st));
   }
   for (int l = 1; l < 8; ++l) {
     int lh, lw; layer_res(l, H, W, lh, lw);
@@ -804,38 +808,45 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   return 0;
 }
 
-// BatchNorm(+ReLU(+pool)) backward of layer l for one view: dout -> dy (+ dgamma, dbeta, conv-bias gradient)
-static int bn_layer_backward(ssp_handle* h, Slot& S, int l, const float* dout, int d_cs, int d_co, bool relu,
-                             bool pool_after, float* dy, int dy_cs, int dy_co, int N, int H, int W, hipStream_t st) {
+// BatchNorm(+ReLU(+pool)) backward of layer l for every view of the set in the same launches: dout[k] -> dy[k]
+// (+ dgamma, dbeta, conv-bias gradient, accumulated over the views)
+static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const float* const* dout, int d_cs, int d_co, bool relu,
+                             bool pool_after, float* const* dy, int dy_cs, int dy_co, int N, int H, int W, hipStream_t st) {
   const LayerDesc& d = h->L[l];
-  BnBwdArgs a;
-  a.y = S.Y[l]; a.dout = dout; a.dy = dy; a.scale = S.bn[l].scale; a.shift = S.bn[l].shift; a.mean = S.bn[l].mean;
-  a.invstd = S.bn[l].invstd; a.gamma = P(h, d.g_off); a.sums = S.bn[l].bsums; a.dbias = Gd(h, d.b_off);
-  a.N = N; a.H = H; a.W = W; a.C = d.cout; a.y_cs = S.y_cs[l]; a.y_co = S.y_co[l]; a.d_cs = d_cs; a.d_co = d_co;
-  a.dy_cs = dy_cs; a.dy_co = dy_co; a.count = (double)N * H * W;
-  a.k12 = S.bn[l].k12;
+  BnBwdArgs a[2];
+  bool have_pool = true;
+  for (int k = 0; k < SS.n; ++k) {
+    Slot& S = *SS.s[k];
+    BnBwdArgs& v = a[k];
+    v.y = S.Y[l]; v.dout = dout[k]; v.dy = dy[k]; v.scale = S.bn[l].scale; v.shift = S.bn[l].shift; v.mean = S.bn[l].mean;
+    v.invstd = S.bn[l].invstd; v.gamma = P(h, d.g_off); v.sums = S.bn[l].bsums; v.dbias = Gd(h, d.b_off);
+    v.x = S.x; v.apool = l < 8 ? S.Apool[l] : nullptr;
+    v.N = N; v.H = H; v.W = W; v.C = d.cout; v.y_cs = S.y_cs[l]; v.y_co = S.y_co[l]; v.d_cs = d_cs; v.d_co = d_co;
+    v.dy_cs = dy_cs; v.dy_co = dy_co; v.count = (double)N * H * W;
+    v.k12 = S.bn[l].k12;
+    have_pool = have_pool && v.apool != nullptr;
+  }
+  const BnBwdArgs &a0 = a[0], &a1 = a[SS.n - 1];
   float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
   if (l == 0) {
-    // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised)
+    // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised);
+    // both passes recompute Y0 from the image instead of reading S.Y[0]
     const int nb = l0_grid((long)N * H);
-    // (both passes recompute Y0 from the image instead of reading S.Y[0])
-    hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, P(h, d.w_off), P(h, d.b_off));
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(64), 0, st, a.sums, S.bn[l].k12, dg, db, a.dbias, a.gamma, a.invstd,
-                       64, a.count);
-    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb), dim3(256), 0, st, a, S.x, P(h, d.w_off), P(h, d.b_off),
+    hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.w_off), P(h, d.b_off));
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(64), 0, st, a0, a1, SS.n, dg, db);
+    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                        Gd(h, d.w_off));
-  } else if (relu && pool_after && S.Apool[l] != nullptr && d.cout % 4 == 0 && d_cs == d.cout && d_co == 0) {
+  } else if (relu && pool_after && have_pool && d.cout % 4 == 0 && d_cs == d.cout && d_co == 0) {
     // pass 1 from the pooled activation (1/4 of Y's bytes), pass 2 over Y
     const long npix = (long)N * (H / 2) * (W / 2);
     const int rows = 256 / (d.cout / 4);
     const int nb = std::max(1, std::min(cdiv(npix, rows), 1024));
-    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb), dim3(256), 0, st, a, S.Apool[l], P(h, d.be_off));
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a.C, 64)), dim3(64), 0, st, a.sums, S.bn[l].k12, dg, db, a.dbias, a.gamma,
-                       a.invstd, a.C, a.count);
-    hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb), dim3(256), 0, st, a);
-  } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, S.bn[l].k12, dg, db, st)));
-  else if (relu) CHK((launch_bn_bwd<true, false>(a, S.bn[l].k12, dg, db, st)));
-  else CHK((launch_bn_bwd<false, false>(a, S.bn[l].k12, dg, db, st)));
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, a0, a1, SS.n, dg, db);
+    hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
+  } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st)));
+  else if (relu) CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st)));
+  else CHK((launch_bn_bwd<false, false>(a, SS.n, dg, db, st)));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -898,13 +909,11 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
   // ---- 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only); gP = dHeadsAct [cells][hcs], gQ = dY scratch ----
   float* dact[2] = {gP[0], gP[1]};
   if (has_semi) {
-    for (int k = 0; k < SS.n; ++k)
-      CHK(bn_layer_backward(h, *SS.s[k], L_PB, dsemi[k], 80, 0, false, false, gQ[k], 80, 0, N, Hc, Wc, st));
+    CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQ, 80, 0, N, Hc, Wc, st));
     CHK(conv_layer_backward(h, SS, L_PB, L_PA, gQ, 80, 0, dact, hcs, 0, N, Hc, Wc, 1, st));
   }
   if (has_desc) {
-    for (int k = 0; k < SS.n; ++k)
-      CHK(bn_layer_backward(h, *SS.s[k], L_DB, draw_desc[k], 256, 0, false, false, gQ[k], 256, 0, N, Hc, Wc, st));
+    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQ, 256, 0, N, Hc, Wc, st));
     CHK(conv_layer_backward(h, SS, L_DB, L_DA, gQ, 256, 0, dact, hcs, 256, N, Hc, Wc, 1, st));
   }
   if (has_sem) {
@@ -921,8 +930,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
   {
     const int heads[3] = {L_PA, L_DA, L_DS};
     for (int hk = 0; hk < h->nheads; ++hk)
-      for (int k = 0; k < SS.n; ++k)
-        CHK(bn_layer_backward(h, *SS.s[k], heads[hk], gP[k], hcs, 256 * hk, true, false, gQ[k], hcs, 256 * hk, N, Hc, Wc, st));
+      CHK(bn_layer_backward(h, SS, heads[hk], gP, hcs, 256 * hk, true, false, gQ, hcs, 256 * hk, N, Hc, Wc, st));
     for (int hk = 0; hk < h->nheads; ++hk) {
       const LayerDesc& d = h->L[heads[hk]];
       WgradCall w;
@@ -947,8 +955,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     int lh, lw; layer_res(l, H, W, lh, lw);
     const bool pool_after = (l == 1 || l == 3 || l == 5);
     const int C = h->L[l].cout;
-    for (int k = 0; k < SS.n; ++k)
-      CHK(bn_layer_backward(h, *SS.s[k], l, gP[k], C, 0, true, pool_after, gQ[k], C, 0, N, lh, lw, st));
+    CHK(bn_layer_backward(h, SS, l, gP, C, 0, true, pool_after, gQ, C, 0, N, lh, lw, st));
     if (l > 0) CHK(conv_layer_backward(h, SS, l, l - 1, gQ, C, 0, gP, h->L[l].cin, 0, N, lh, lw, layer_in_mode(l), st));
   }
   return 0;
@@ -1468,10 +1475,10 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
   a.C = c; a.y_cs = c; a.y_co = 0; a.d_cs = c; a.d_co = 0; a.dy_cs = c; a.dy_co = 0; a.count = (double)n * hh * w;
   float* k12 = nullptr;
   HIPCHK(hipMallocAsync((void**)&k12, 2 * c * sizeof(float), st));
-  a.k12 = k12;
-  if (relu && pool) CHK((launch_bn_bwd<true, true>(a, k12, dgamma_dev, dbeta_dev, st)));
-  else if (relu) CHK((launch_bn_bwd<true, false>(a, k12, dgamma_dev, dbeta_dev, st)));
-  else CHK((launch_bn_bwd<false, false>(a, k12, dgamma_dev, dbeta_dev, st)));
+  a.k12 = k12; a.x = nullptr; a.apool = nullptr;
+  if (relu && pool) CHK((launch_bn_bwd<true, true>(&a, 1, dgamma_dev, dbeta_dev, st)));
+  else if (relu) CHK((launch_bn_bwd<true, false>(&a, 1, dgamma_dev, dbeta_dev, st)));
+  else CHK((launch_bn_bwd<false, false>(&a, 1, dgamma_dev, dbeta_dev, st)));
   HIPCHK(hipFreeAsync(k12, st));
   return 0;
 }
