@@ -452,12 +452,11 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
 }
 
 // OIHW 3x3 weights -> U = G g G^T in the LDS image of conv_wino_pipe_kernel: [cob][chunk8][component][h][64][4]
-__global__ void pack_weights_wino8_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout_w, int Cin_w,
-                                          int transpose_flip, int nchunks_total, int chunk_off, int cob_off, int ncob,
-                                          int nchunks) {
+__device__ __forceinline__ void pack_wino8_element(const float* __restrict__ w, float* __restrict__ dst, int Cout_w,
+                                                   int Cin_w, int transpose_flip, int nchunks_total, int chunk_off,
+                                                   int cob_off, int ncob, int nchunks, int idx) {
   const int per_chunk = PB_FLOATS;
   const int total = ncob * nchunks * per_chunk;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int t = idx;
   const int e = t & 3;
@@ -492,6 +491,34 @@ __global__ void pack_weights_wino8_kernel(const float* __restrict__ w, float* __
     r[x] = i == 0 ? k[0][x] : i == 1 ? 0.5f * (k[0][x] + k[1][x] + k[2][x]) : i == 2 ? 0.5f * (k[0][x] - k[1][x] + k[2][x]) : k[2][x];
   const float u = j == 0 ? r[0] : j == 1 ? 0.5f * (r[0] + r[1] + r[2]) : j == 2 ? 0.5f * (r[0] - r[1] + r[2]) : r[2];
   dst[((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * per_chunk + ((comp * 2 + h) * NB + nn) * 4 + e] = u;
+}
+
+__global__ void pack_weights_wino8_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout_w, int Cin_w,
+                                          int transpose_flip, int nchunks_total, int chunk_off, int cob_off, int ncob,
+                                          int nchunks) {
+  pack_wino8_element(w, dst, Cout_w, Cin_w, transpose_flip, nchunks_total, chunk_off, cob_off, ncob, nchunks,
+                     blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// All 3x3 layers of the network (forward and data-gradient images) in ONE launch: the weights change at every optimizer
+// step, so they are re-packed per forward; 20 launches of ~5 us each were 0.7 % of the pair step.
+struct PackJob {
+  const float* w;
+  float* dst;
+  int cout_w, cin_w, tf, nchunks_total, chunk_off, cob_off, ncob, nchunks;
+  int block0;  // first block of this job (256 elements per block)
+};
+constexpr int PACK_MAX_JOBS = 32;
+struct PackJobs {
+  int n;
+  PackJob j[PACK_MAX_JOBS];
+};
+__global__ void pack_weights_wino8_multi_kernel(const PackJobs J) {
+  int k = 0;
+  while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;  // wave-uniform linear search, <= 32 jobs
+  const PackJob& q = J.j[k];
+  pack_wino8_element(q.w, q.dst, q.cout_w, q.cin_w, q.tf, q.nchunks_total, q.chunk_off, q.cob_off, q.ncob, q.nchunks,
+                     ((int)blockIdx.x - q.block0) * blockDim.x + threadIdx.x);
 }
 
 }  // namespace sspk

@@ -694,11 +694,31 @@ static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, dou
 }
 
 static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
+  // default algorithm: every Winograd image (3x3 layers forward + data gradient, concatenated heads) in one launch
+  const bool multi = g_conv_algo == 1 || g_conv_algo == 5;
+  PackJobs J;
+  J.n = 0;
+  int nblocks = 0;
+  auto add_job = [&](const float* w, float* dst, int cout_w, int cin_w, int tf, int nchunks_total, int chunk_off, int cob_off,
+                     int ncob, int nchunks) {
+    PackJob& q = J.j[J.n++];
+    q.w = w; q.dst = dst; q.cout_w = cout_w; q.cin_w = cin_w; q.tf = tf; q.nchunks_total = nchunks_total;
+    q.chunk_off = chunk_off; q.cob_off = cob_off; q.ncob = ncob; q.nchunks = nchunks; q.block0 = nblocks;
+    nblocks += cdiv((long)ncob * nchunks * PB_FLOATS, 256);
+  };
+  auto pack = [&](const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino) -> int {
+    if (multi && wino && J.n < PACK_MAX_JOBS) {
+      const int conv_cin = tf ? cout_w : cin_w, conv_cout = tf ? cin_w : cout_w;
+      const int nchunks = 2 * cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
+      add_job(w, dst, cout_w, cin_w, tf, nchunks, 0, 0, ncob, nchunks);
+      return 0;
+    }
+    return launch_pack(w, dst, cout_w, cin_w, ks, tf, wino, st);
+  };
   for (int l = 1; l < h->nlayers; ++l) {
     const LayerDesc& d = h->L[l];
-    CHK(launch_pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wino_ok(d.ks, d.cin), st));
-    if (with_bwd)
-      CHK(launch_pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wino_ok(d.ks, d.cout), st));
+    CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wino_ok(d.ks, d.cin)));
+    if (with_bwd) CHK(pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wino_ok(d.ks, d.cout)));
   }
   if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
     const int heads[3] = {L_PA, L_DA, L_DS};
@@ -709,7 +729,9 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
         hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), reinterpret_cast<__bf16*>(h->wpk_heads_bwd), 256, 128, 1,
                            32 * h->nheads, 32 * k, 0, 2, 32);
-      else if (wino && (g_conv_algo == 1 || g_conv_algo == 5))
+      else if (wino && multi && J.n < PACK_MAX_JOBS)
+        add_job(P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
+      else if (wino && multi)
         hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
       else if (wino)
@@ -719,6 +741,10 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
         hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, P(h, h->L[heads[k]].w_off),
                            h->wpk_heads_bwd, 256, 128, 3, 1, 16 * h->nheads, 16 * k, 0, 2, 16);
     }
+    HIPCHK(hipGetLastError());
+  }
+  if (J.n > 0) {
+    hipLaunchKernelGGL(pack_weights_wino8_multi_kernel, dim3(nblocks), dim3(256), 0, st, J);
     HIPCHK(hipGetLastError());
   }
   return 0;
