@@ -532,11 +532,10 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
 
 // Sums the 16-component partial slabs over the splits, applies dW = G^T M G and ACCUMULATES into the OIHW gradient.
 // block = 256 threads = 64 consecutive co x 4 split groups, one input channel per block row.
-__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                int Cin, int Cout, int ncob, int nsplit) {
-  __shared__ float red[4][WC][64];
+__device__ __forceinline__ void wgrad_wino_reduce_block(const float* __restrict__ partial, float* __restrict__ dw, int Cin,
+                                                        int Cout, int ncob, int nsplit, int bid, float (*red)[WC][64]) {
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int cob = blockIdx.x % ncob, ci = blockIdx.x / ncob;
+  const int cob = bid % ncob, ci = bid / ncob;
   const int co = cob * 64 + o, cib = ci >> 6;
   float m[WC];
 #pragma unroll
@@ -565,6 +564,33 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __r
     out[u * 3 + 1] += 0.5f * (p[u][1] - p[u][2]);
     out[u * 3 + 2] += 0.5f * (p[u][1] + p[u][2]) + p[u][3];
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                int Cin, int Cout, int ncob, int nsplit) {
+  __shared__ float red[4][WC][64];
+  wgrad_wino_reduce_block(partial, dw, Cin, Cout, ncob, nsplit, blockIdx.x, red);
+}
+
+// The reductions of ALL Winograd weight-gradient launches of a backward pass in one launch (each wgrad launch keeps its
+// own slice of the partial-slab buffer until then): 9 launches of ~20 us less per step.
+struct WredJob {
+  const float* partial;
+  float* dw;
+  int cin, cout, ncob, nsplit;
+  int block0;
+};
+constexpr int WRED_MAX_JOBS = 16;
+struct WredJobs {
+  int n;
+  WredJob j[WRED_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_multi_kernel(const WredJobs J) {
+  __shared__ float red[4][WC][64];
+  int k = 0;
+  while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;
+  const WredJob& q = J.j[k];
+  wgrad_wino_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, red);
 }
 
 // OIHW 3x3 weights -> U = G g G^T in the LDS image of conv_wino_kernel: [cob][chunk][component][g][h][64][4].

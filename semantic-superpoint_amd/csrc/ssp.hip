@@ -107,8 +107,10 @@ struct ssp_handle {
   size_t ws_bytes;
   Slot slot[2];
   float *wpk_fwd, *wpk_bwd, *wpk_heads_bwd;
-  float* partial;    // wgrad partial slabs
+  float* partial;    // wgrad partial slabs: every Winograd wgrad launch of a backward pass gets its own slice ...
   size_t partial_floats;
+  size_t partial_used = 0;  // ... and the slices are reduced into the gradients by ONE launch (flush_wgrad_reduce)
+  WredJobs rjobs{};
   StepAccum* accum;
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
   float* dense_coef; // [B * cells * cells] d total / d dot of the dense descriptor loss (cfg.dense_loss), else nullptr
@@ -263,7 +265,7 @@ static size_t carve(ssp_handle* h, void* base) {
     h->slot[s].gP = c.take_skewed<float>(big);
     h->slot[s].gQ = c.take_skewed<float>(big);
   }
-  h->partial_floats = (size_t)1024 * 9 * 4096;
+  h->partial_floats = (size_t)1024 * 9 * 4096 * 5;  // 10 Winograd launches of 256 blocks x 16 slabs (755 MB)
   h->partial = c.take<float>(h->partial_floats);
   h->accum = c.take<StepAccum>(1);
   h->dots = c.take<float>((size_t)B * h->cfg.n_match * h->cfg.n_non);
@@ -480,6 +482,18 @@ struct WgradCall {
   const float* in_scale2 = nullptr; const float* in_shift2 = nullptr;
 };
 
+// sums the pending partial slabs of the deferred Winograd weight-gradient launches into the OIHW gradients
+static int flush_wgrad_reduce(ssp_handle* h, hipStream_t st) {
+  if (h == nullptr || h->rjobs.n == 0) { if (h) h->partial_used = 0; return 0; }
+  const WredJob& last = h->rjobs.j[h->rjobs.n - 1];
+  const int nblocks = last.block0 + last.ncob * last.cin;
+  hipLaunchKernelGGL(wgrad_wino_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, h->rjobs);
+  HIPCHK(hipGetLastError());
+  h->rjobs.n = 0;
+  h->partial_used = 0;
+  return 0;
+}
+
 static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_t partial_floats, int n_cu,
                         hipStream_t st) {
   WgradArgs a;
@@ -506,6 +520,20 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   if ((size_t)pairs * nsplit * taps * 4096 > partial_floats) return fail(-4, "wgrad scratch too small");
   a.nsplit = nsplit;
   const int nblocks = pairs * nsplit;
+  // engine launches (partial == the handle's buffer): Winograd slabs stay in their own slice until flush_wgrad_reduce
+  const bool deferred = wino && h != nullptr && partial == h->partial;
+  if (deferred) {
+    const size_t need = (size_t)pairs * nsplit * taps * 4096;
+    if (h->partial_used + need > partial_floats || h->rjobs.n == WRED_MAX_JOBS) CHK(flush_wgrad_reduce(h, st));
+    a.partial = partial + h->partial_used;
+    WredJob& q = h->rjobs.j[h->rjobs.n];
+    q.partial = a.partial; q.dw = c.dw; q.cin = c.cin; q.cout = c.cout; q.ncob = a.ncob; q.nsplit = nsplit;
+    q.block0 = h->rjobs.n ? h->rjobs.j[h->rjobs.n - 1].block0 + h->rjobs.j[h->rjobs.n - 1].ncob * h->rjobs.j[h->rjobs.n - 1].cin : 0;
+    ++h->rjobs.n;
+    h->partial_used += need;
+  } else if (h != nullptr && partial == h->partial && h->rjobs.n > 0) {
+    CHK(flush_wgrad_reduce(h, st));  // an immediate-reduce launch reuses the buffer from its start
+  }
   {
     const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
     const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
@@ -518,8 +546,9 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
       else CHK((wide ? launch_wgrad_wino_t<1, true>(a, nblocks, st) : launch_wgrad_wino_t<1, false>(a, nblocks, st)));
     }
     if (wino) {
-      hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
-                         a.ncob, nsplit);
+      if (!deferred)
+        hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
+                           a.ncob, nsplit);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -984,7 +1013,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     CHK(bn_layer_backward(h, SS, l, gP, C, 0, true, pool_after, gQ, C, 0, N, lh, lw, st));
     if (l > 0) CHK(conv_layer_backward(h, SS, l, l - 1, gQ, C, 0, gP, h->L[l].cin, 0, N, lh, lw, layer_in_mode(l), st));
   }
-  return 0;
+  return flush_wgrad_reduce(h, st);  // all Winograd weight-gradient slabs -> OIHW gradients, one launch
 }
 
 extern "C" {
