@@ -603,7 +603,7 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
   int nb = cdiv(npix, rows);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a0.C, 64)), dim3(64), 0, st, a0, a1, nviews, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a0.C * 32, 256)), dim3(256), 0, st, a0, a1, nviews, dgamma, dbeta);
   hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   HIPCHK(hipGetLastError());
   return 0;
@@ -717,7 +717,7 @@ static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, dou
     b[k].C = d.cout; b[k].count = count;
   }
   int64_t* nbt = h->buf.num_batches_tracked_dev ? h->buf.num_batches_tracked_dev + d.bn_index : nullptr;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, b[0], b[nviews - 1], nviews, train, nbt);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, b[0], b[nviews - 1], nviews, train, nbt);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -888,7 +888,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     // both passes recompute Y0 from the image instead of reading S.Y[0]
     const int nb = l0_grid((long)N * H);
     hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.w_off), P(h, d.b_off));
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(64), 0, st, a0, a1, SS.n, dg, db);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                        Gd(h, d.w_off));
   } else if (relu && pool_after && have_pool && d.cout % 4 == 0 && d_cs == d.cout && d_co == 0) {
@@ -897,7 +897,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const int rows = 256 / (d.cout / 4);
     const int nb = std::max(1, std::min(cdiv(npix, rows), 1024));
     hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout, 64)), dim3(64), 0, st, a0, a1, SS.n, dg, db);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
   } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st)));
   else if (relu) CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st)));
