@@ -242,6 +242,9 @@ struct BnBwdArgs {
   float* dbias;      // conv bias gradient (accumulated) or nullptr
   const float* x;      // layer 0 only: the one-channel input image (y0 is recomputed from it)
   const float* apool;  // pooled layers: maxpool(relu(bn(y))) materialised by the forward
+  const float* beta;   // pooled layers (pass 1 from apool)
+  int pool_fix;        // pass 1 came from the data-gradient conv's epilogue (pooled layer): channels with gamma == 0 get
+                       // their S2 from a scan over Y in bn_bwd_sums_kernel (xhat is not recoverable from apool there)
   int N, H, W, C;
   int y_cs, y_co, d_cs, d_co, dy_cs, dy_co;
   double count;
@@ -618,6 +621,22 @@ __global__ void bn_bwd_sums_kernel(const BnBwdArgs a0, const BnBwdArgs a1, int n
     const int C = a.C;
     double s1, s2;
     replica_sums(a.sums, C, c, r, s1, s2);
+    if (a.pool_fix && a.gamma[c] == 0.f) {
+      // degenerate channel of a pooled layer: z == beta everywhere, the first window element is the arg-max
+      double part = 0.0;
+      if (a.beta[c] > 0.f) {
+        const int Ho = a.H / 2, Wo = a.W / 2;
+        const long npool = (long)a.N * Ho * Wo;
+        for (long p = r; p < npool; p += 32) {
+          const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((long)Wo * Ho));
+          const float y0 = a.y[((size_t)(n * a.H + 2 * oy) * a.W + 2 * ox) * a.y_cs + a.y_co + c];
+          part += (double)(a.dout[(size_t)p * a.d_cs + a.d_co + c] * ((y0 - a.mean[c]) * a.invstd[c]));
+        }
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o);
+      s2 = part;
+    }
     if (!writer) continue;
     const float k1 = (float)(s1 / a.count), k2 = (float)(s2 / a.count);
     float* k12 = const_cast<float*>(a.k12);

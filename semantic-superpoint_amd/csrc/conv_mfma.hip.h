@@ -44,6 +44,21 @@ struct ConvArgs {
   int nchunks, ncob;
   unsigned in_bytes, out_bytes, wpk_bytes;  // buffer descriptor ranges: in_bytes = bytes of ONE input image
   int ablate;             // perf-debug only (tools/ablate_conv.py): 1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA
+  // Data-gradient launches of conv_wino_pipe_kernel: pass 1 of the BatchNorm backward of the layer BELOW (whose activation
+  // gradient this launch produces) accumulated in the epilogue into `stats` (= that layer's backward sums, same
+  // [NREP][2 C] layout as the forward statistics): S1 = sum dZ, S2 = sum dZ * xhat.
+  //   bnr_mode 1: ReLU layer,        dZ = out * [y * scale + shift > 0], xhat = (y - mean) * invstd,  bnr_t = y
+  //   bnr_mode 2: ReLU + 2x2 max-pool, dZ = out * [apool > 0],           xhat = (apool - beta) / gamma, bnr_t = apool
+  // bnr_t has the geometry of `out` ([N,H,W,bnr_cs], channel offset bnr_co); bnr_p*[k] = per-channel parameter arrays of
+  // problem k: mode 1 {scale, shift, mean, invstd}, mode 2 {beta, gamma, -, -}.
+  int bnr_mode = 0;
+  const float* bnr_t = nullptr;
+  const float* bnr_t2 = nullptr;
+  int bnr_cs = 0, bnr_co = 0;
+  const float* bnr_p0[2] = {nullptr, nullptr};
+  const float* bnr_p1[2] = {nullptr, nullptr};
+  const float* bnr_p2[2] = {nullptr, nullptr};
+  const float* bnr_p3[2] = {nullptr, nullptr};
 };
 
 // lane/row index m (0..31) of an MFMA M-tile -> pixel (r,c) inside the SH x SW sub-rectangle.

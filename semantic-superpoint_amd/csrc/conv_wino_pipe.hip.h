@@ -221,7 +221,26 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       sS[1024 + c] = p_shift[c];
     }
     __syncthreads();
+  } else if (a.bnr_mode != 0) {
+    // fused BatchNorm-backward sums (ConvArgs::bnr_*): the four per-channel parameters of this block's 64 output channels.
+    // mode 1: {scale, shift, invstd, -mean * invstd} (xhat = y * invstd - mean * invstd); mode 2: {beta, 1 / gamma, -, -}
+    if (tid < NB) {
+      const int co_ = cob * NB + tid;
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+      if (co_ < a.Cout) {
+        if (a.bnr_mode == 1) {
+          const float is_ = a.bnr_p3[prob][co_];
+          q0 = a.bnr_p0[prob][co_]; q1 = a.bnr_p1[prob][co_]; q2 = is_; q3 = -a.bnr_p2[prob][co_] * is_;
+        } else {
+          const float g_ = a.bnr_p1[prob][co_];
+          q0 = a.bnr_p0[prob][co_]; q1 = g_ != 0.f ? 1.f / g_ : 0.f;
+        }
+      }
+      sS[tid] = q0; sS[NB + tid] = q1; sS[2 * NB + tid] = q2; sS[3 * NB + tid] = q3;
+    }
+    __syncthreads();
   }
+  const float* const p_bnr = prob ? a.bnr_t2 : a.bnr_t;
   // ---- prologue: stage 0 into buffer 0, loads of stage 1 in flight ----
   PIPE_ISSUE_LOADS()
   PIPE_WRITE_STAGE(0)
@@ -391,8 +410,28 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
           if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4) +
                             *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4);
-            ssum += v;
-            ssq += v * v;
+            if (IN_MODE == 0 && a.bnr_mode != 0) {
+              // BatchNorm-backward sums of the layer below (see ConvArgs::bnr_mode): v is its activation gradient
+              const f32x4 t = *reinterpret_cast<const f32x4*>(p_bnr + ((size_t)(n * a.H + oy) * a.W + ox) * a.bnr_cs + a.bnr_co + co4);
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(sS + q16 * 4), q1 = *reinterpret_cast<const f32x4*>(sS + NB + q16 * 4);
+              f32x4 dz, xh;
+              if (a.bnr_mode == 1) {
+                const f32x4 q2 = *reinterpret_cast<const f32x4*>(sS + 2 * NB + q16 * 4), q3 = *reinterpret_cast<const f32x4*>(sS + 3 * NB + q16 * 4);
+                const f32x4 z = __builtin_elementwise_fma(t, q0, q1);
+                xh = __builtin_elementwise_fma(t, q2, q3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? v[e] : 0.f;
+              } else {
+                xh = (t - q0) * q1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = t[e] > 0.f ? v[e] : 0.f;
+              }
+              ssum += dz;
+              ssq = __builtin_elementwise_fma(dz, xh, ssq);
+            } else {
+              ssum += v;
+              ssq += v * v;
+            }
             if (PIPE_ABL & 16) continue;
             float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
             if (nvalid == 4) {

@@ -111,6 +111,7 @@ struct ssp_handle {
   size_t partial_floats;
   size_t partial_used = 0;  // ... and the slices are reduced into the gradients by ONE launch (flush_wgrad_reduce)
   WredJobs rjobs{};
+  bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
   StepAccum* accum;
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
   float* dense_coef; // [B * cells * cells] d total / d dot of the dense descriptor loss (cfg.dense_loss), else nullptr
@@ -325,7 +326,17 @@ struct ConvCall {
   const float* in2 = nullptr; float* out2 = nullptr;
   const float* in_scale2 = nullptr; const float* in_shift2 = nullptr; double* stats2 = nullptr;
   bool wino = false;  // wpk holds pack_weights_wino_kernel's image: run conv_wino_kernel
+  // data-gradient launches: BatchNorm-backward sums of the layer below fused into the epilogue (ConvArgs::bnr_*);
+  // honoured by the pipelined Winograd kernel only - can_fuse_bnr() tells the caller
+  int bnr_mode = 0;
+  const float* bnr_t[2] = {nullptr, nullptr};
+  int bnr_cs = 0, bnr_co = 0;
+  const float* bnr_p[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
 };
+static bool can_fuse_bnr(const ConvCall& c) {
+  return c.wino && (g_conv_algo == 1 || g_conv_algo == 5) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
+         c.out_cs % 4 == 0;
+}
 
 template <int IN_MODE, bool WIDE, bool GB = false>
 static int launch_wino_pipe_t(const ConvArgs& a, int nblocks, hipStream_t st) {
@@ -373,6 +384,13 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   a.Cout = c.cout; a.out_cs = c.out_cs; a.out_co = c.out_co; a.nchunks = c.nchunks; a.ncob = c.ncob;
   a.nprob = c.nprob; a.in2 = c.in2; a.out2 = c.out2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
   a.stats2 = c.stats2;
+  if (c.bnr_mode != 0) {
+    if (!can_fuse_bnr(c)) return fail(-3, "fused BatchNorm-backward sums need the pipelined Winograd kernel");
+    a.bnr_mode = c.bnr_mode; a.bnr_t = c.bnr_t[0]; a.bnr_t2 = c.bnr_t[1]; a.bnr_cs = c.bnr_cs; a.bnr_co = c.bnr_co;
+    for (int k = 0; k < 2; ++k) {
+      a.bnr_p0[k] = c.bnr_p[0][k]; a.bnr_p1[k] = c.bnr_p[1][k]; a.bnr_p2[k] = c.bnr_p[2][k]; a.bnr_p3[k] = c.bnr_p[3][k];
+    }
+  }
   {
     // the input is read through one buffer descriptor PER IMAGE (32-bit byte offsets inside it); element indices of
     // whole tensors are 32-bit in the element-wise kernels
@@ -594,7 +612,8 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
 
 // pass 1 (sums) -> replica reduction + dgamma/dbeta -> pass 2 (apply); a[0 .. nviews-1] ride the same launches
 template <bool RELU, bool POOL>
-static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* dbeta, hipStream_t st) {
+static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* dbeta, hipStream_t st,
+                         bool sums_done = false) {
   // a.dbias (conv bias gradient, may be null) is produced by bn_bwd_sums_kernel
   const BnBwdArgs& a0 = a[0];
   const BnBwdArgs& a1 = a[nviews - 1];
@@ -602,7 +621,8 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
   const long npix = (long)a0.N * (POOL ? a0.H / 2 : a0.H) * (POOL ? a0.W / 2 : a0.W);
   int nb = cdiv(npix, rows);
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
+  if (!sums_done)  // else: pass 1 was accumulated by the data-gradient conv that produced dOut
+    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a0.C * 32, 256)), dim3(256), 0, st, a0, a1, nviews, dgamma, dbeta);
   hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   HIPCHK(hipGetLastError());
@@ -875,12 +895,16 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     BnBwdArgs& v = a[k];
     v.y = S.Y[l]; v.dout = dout[k]; v.dy = dy[k]; v.scale = S.bn[l].scale; v.shift = S.bn[l].shift; v.mean = S.bn[l].mean;
     v.invstd = S.bn[l].invstd; v.gamma = P(h, d.g_off); v.sums = S.bn[l].bsums; v.dbias = Gd(h, d.b_off);
-    v.x = S.x; v.apool = l < 8 ? S.Apool[l] : nullptr;
+    v.x = S.x; v.apool = l < 8 ? S.Apool[l] : nullptr; v.beta = P(h, d.be_off); v.pool_fix = 0;
     v.N = N; v.H = H; v.W = W; v.C = d.cout; v.y_cs = S.y_cs[l]; v.y_co = S.y_co[l]; v.d_cs = d_cs; v.d_co = d_co;
     v.dy_cs = dy_cs; v.dy_co = dy_co; v.count = (double)N * H * W;
     v.k12 = S.bn[l].k12;
     have_pool = have_pool && v.apool != nullptr;
   }
+  const bool fused = h->bsums_fused[l];  // pass 1 already sits in bsums (conv_layer_backward of the layer above)
+  h->bsums_fused[l] = false;
+  if (fused && pool_after)
+    for (int k = 0; k < SS.n; ++k) a[k].pool_fix = 1;
   const BnBwdArgs &a0 = a[0], &a1 = a[SS.n - 1];
   float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
   if (l == 0) {
@@ -896,14 +920,40 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const long npix = (long)N * (H / 2) * (W / 2);
     const int rows = 256 / (d.cout / 4);
     const int nb = std::max(1, std::min(cdiv(npix, rows), 1024));
-    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
+    if (!fused) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
-  } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st)));
-  else if (relu) CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st)));
+  } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st, fused)));
+  else if (relu) CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused)));
   else CHK((launch_bn_bwd<false, false>(a, SS.n, dg, db, st)));
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// Ask the data-gradient conv `c` (output = gradient wrt the activation of layer src) to accumulate pass 1 of layer src's
+// BatchNorm backward in its epilogue; records the fact for bn_layer_backward(src).
+static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, ConvCall& c) {
+  if (src < 1 || !h->L[src].bn || !can_fuse_bnr(c) || c.out_co != 0 || c.out_cs != c.cout || c.cout != h->L[src].cout) return;
+  const LayerDesc& ds = h->L[src];
+  for (int k = 0; k < SS.n; ++k) {
+    Slot& S = *SS.s[k];
+    if (pooled) {
+      if (S.Apool[src] == nullptr) return;
+      c.bnr_t[k] = S.Apool[src];
+      c.bnr_p[0][k] = P(h, ds.be_off); c.bnr_p[1][k] = P(h, ds.g_off);
+    } else {
+      c.bnr_t[k] = S.Y[src];
+      c.bnr_p[0][k] = S.bn[src].scale; c.bnr_p[1][k] = S.bn[src].shift; c.bnr_p[2][k] = S.bn[src].mean;
+      c.bnr_p[3][k] = S.bn[src].invstd;
+    }
+  }
+  c.bnr_mode = pooled ? 2 : 1;
+  c.bnr_cs = pooled ? ds.cout : SS.s[0]->y_cs[src];
+  c.bnr_co = pooled ? 0 : SS.s[0]->y_co[src];
+  if (c.bnr_cs % 4 != 0 || c.bnr_co % 4 != 0) { c.bnr_mode = 0; return; }
+  c.stats = SS.s[0]->bn[src].bsums;
+  if (SS.n == 2) c.stats2 = SS.s[1]->bn[src].bsums;
+  h->bsums_fused[src] = true;
 }
 
 // weight gradient (both views in one launch) and data gradient (both views in one launch) of conv layer l, given
@@ -932,6 +982,7 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
     w.in_shift2 = B.bn[src].shift;
     c.nprob = 2; c.in2 = dy[1]; c.out2 = din[1];
   }
+  if (d.ks == 3 && src < 8) setup_bnr(h, SS, src, pooled, c);  // layer src: BatchNorm + ReLU (+ pool) of the encoder
   CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_DGRAD : 0));
   return 0;
@@ -1003,6 +1054,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     c.out = gP[0]; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
     c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = 16 * h->nheads; c.ncob = 2;
     if (SS.n == 2) { c.nprob = 2; c.in2 = gQ[1]; c.out2 = gP[1]; }
+    setup_bnr(h, SS, 7, false, c);
     CHK(launch_conv(h, c, st, SSP_PROF_CONV3X3_DGRAD));
   }
   // ---- encoder: dOut (gP) -> dY (gQ) -> weight gradient + data gradient (gP) ----
@@ -1530,7 +1582,7 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
   a.C = c; a.y_cs = c; a.y_co = 0; a.d_cs = c; a.d_co = 0; a.dy_cs = c; a.dy_co = 0; a.count = (double)n * hh * w;
   float* k12 = nullptr;
   HIPCHK(hipMallocAsync((void**)&k12, 2 * c * sizeof(float), st));
-  a.k12 = k12; a.x = nullptr; a.apool = nullptr;
+  a.k12 = k12; a.x = nullptr; a.apool = nullptr; a.beta = nullptr; a.pool_fix = 0;
   if (relu && pool) CHK((launch_bn_bwd<true, true>(&a, 1, dgamma_dev, dbeta_dev, st)));
   else if (relu) CHK((launch_bn_bwd<true, false>(&a, 1, dgamma_dev, dbeta_dev, st)));
   else CHK((launch_bn_bwd<false, false>(&a, 1, dgamma_dev, dbeta_dev, st)));
