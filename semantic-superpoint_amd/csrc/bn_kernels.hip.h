@@ -199,9 +199,16 @@ __global__ void bn_finalize_kernel(const BnLayer L0, const BnLayer L1, int nview
 // (forward conv, weight gradient of the next layer) then read a 4x smaller, already activated tensor through their
 // prefetched raw-input path instead of staging 4 loads per pixel synchronously (85-97 TF -> ~125 TF on those
 // launches).  y: [N,H,W,C] raw conv output; out: [N,H/2,W/2,C].  C % 4 == 0.
-__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, float* __restrict__ out,
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y0, const float* __restrict__ scale0,
+                                                           const float* __restrict__ shift0, float* __restrict__ out0,
+                                                           const float* __restrict__ y1, const float* __restrict__ scale1,
+                                                           const float* __restrict__ shift1, float* __restrict__ out1,
                                                            int N, int H, int W, int C) {
+  // blockIdx.y = view of the pair
+  const float* __restrict__ y = blockIdx.y ? y1 : y0;
+  const float* __restrict__ scale = blockIdx.y ? scale1 : scale0;
+  const float* __restrict__ shift = blockIdx.y ? shift1 : shift0;
+  float* __restrict__ out = blockIdx.y ? out1 : out0;
   const int nq = C >> 2;
   const long total = (long)N * (H / 2) * (W / 2) * nq;
   const int Wo = W / 2, Ho = H / 2;

@@ -813,11 +813,12 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
   Slot& A = *SS.s[0];
   const bool pooled = in_mode == 2;  // input = materialised maxpool(relu(bn(Y_src))): raw (mode 0) for the kernel
   if (pooled) {
-    for (int k = 0; k < SS.n; ++k) {
-      Slot& S = *SS.s[k];
+    {
+      Slot &S0 = *SS.s[0], &S1 = *SS.s[SS.n - 1];
       const long total = (long)N * H * W * (d.cin / 4);
-      hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(std::min(cdiv(total, 256), 8192)), dim3(256), 0, st, S.Y[src],
-                         S.bn[src].scale, S.bn[src].shift, S.Apool[src], N, 2 * H, 2 * W, d.cin);
+      hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(std::min(cdiv(total, 256), 8192), SS.n), dim3(256), 0, st, S0.Y[src],
+                         S0.bn[src].scale, S0.bn[src].shift, S0.Apool[src], S1.Y[src], S1.bn[src].scale, S1.bn[src].shift,
+                         S1.Apool[src], N, 2 * H, 2 * W, d.cin);
     }
     HIPCHK(hipGetLastError());
     in_mode = 0;
