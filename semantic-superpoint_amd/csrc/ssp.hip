@@ -1000,6 +1000,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
   const bool has_semi = dsemi[0] != nullptr, has_desc = draw_desc[0] != nullptr;
   const bool has_sem = dsout[0] != nullptr && h->nheads == 3;
   float *gP[2] = {nullptr, nullptr}, *gQ[2] = {nullptr, nullptr};
+  for (int l = 0; l < 16; ++l) h->bsums_fused[l] = false;
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     gP[k] = S.gP; gQ[k] = S.gQ;
