@@ -72,7 +72,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or _build.LIB
+    path = path or os.environ.get("SSP_HIP_LIB") or _build.LIB  # SSP_HIP_LIB: A/B builds of the kernels (tools/)
     if not os.path.exists(path):
         path = _build.build()
     lib = C.CDLL(path)
