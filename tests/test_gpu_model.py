@@ -115,9 +115,20 @@ def test_backward_vs_oracle(arch):
         _grad_close(mine, r, k)
 
 
-def test_backward_with_zero_gamma_in_pooled_layers():
-    """The pooled layers' BatchNorm-backward sums are taken from the pooled activation (xhat = (z - beta)/gamma);
-    channels with gamma == 0 must fall back to the scan over Y (all four window values tie at relu(beta))."""
+@pytest.mark.parametrize("algo", [1, 0])
+def test_backward_with_zero_gamma_in_pooled_layers(algo):
+    """The pooled layers' BatchNorm-backward sums are taken from the pooled activation (xhat = (z - beta)/gamma) - inside
+    the data-gradient conv's epilogue (default algorithm) or by bn_bwd_reduce_pool_kernel (algo 0); channels with
+    gamma == 0 must fall back to a scan over Y (all four window values tie at relu(beta))."""
+    from semantic_superpoint_amd import lib as L
+    L.set_conv_algo(algo)
+    try:
+        _zero_gamma_case()
+    finally:
+        L.set_conv_algo(1)
+
+
+def _zero_gamma_case():
     arch, B, H, W = ARCHS[0], 2, 32, 48
     sd = C.init_state_dict(arch, seed=9)
     rs = np.random.RandomState(5)
