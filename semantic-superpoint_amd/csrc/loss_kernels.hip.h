@@ -333,12 +333,14 @@ __global__ void desc_counts_kernel(StepAccum* acc, int B) {
 // ---- MultiTaskLoss coefficients (before the loss kernels) and scalars / eta gradient (after) ----
 __global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta, int multi_task, float lambda_loss,
                                   float lamda_d, int semantic) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int i = 0; i < 2; ++i) acc->det_sum[i] = acc->mask_cnt[i] = acc->sem_sum[i] = acc->sem_cnt[i] = 0.0;
-  for (int i = 0; i < 64 * 16; ++i) {
+  // one wave (launched with 64 threads): the 4 x 1024 replica slots are cleared in parallel (a single thread took 17 us)
+  if (blockIdx.x != 0) return;
+  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
     acc->pos_sum[i] = acc->neg_sum[i] = acc->dense_sum[i] = 0.0;
     acc->nnz[i] = 0u;
   }
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 2; ++i) acc->det_sum[i] = acc->mask_cnt[i] = acc->sem_sum[i] = acc->sem_cnt[i] = 0.0;
   if (multi_task) {
     acc->coef_det = expf(-eta[0]);
     acc->coef_pos = 0.5f * expf(-eta[1]);
@@ -355,16 +357,40 @@ __global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta,
 __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ eta, float* __restrict__ deta,
                                 float* __restrict__ scal, int B, int n_match, int multi_task, float lambda_loss,
                                 float lamda_d, int semantic, int train, int dense, int cells) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave (launched with 64 threads): lane i reduces the replicas of image i (sparse loss) or a slice of the 1024
+  // replica slots (dense loss); thread 0 then combines in the order of the former single-thread loop
+  if (blockIdx.x != 0) return;
+  __shared__ float s_p[64], s_q[64];
+  __shared__ double s_d[3][64];
+  const int li = threadIdx.x;
+  if (lambda_loss > 0.f && dense) {
+    double ps = 0, ns = 0, ls = 0;
+    for (int i = li; i < 64 * 16; i += 64) {
+      ps += acc->pos_sum[i];
+      ns += acc->neg_sum[i];
+      ls += acc->dense_sum[i];
+    }
+    s_d[0][li] = ps; s_d[1][li] = ns; s_d[2][li] = ls;
+  } else if (lambda_loss > 0.f && li < B) {
+    double ps = 0, ns = 0;
+    for (int r = 0; r < 16; ++r) {
+      ps += acc->pos_sum[li * 16 + r];
+      ns += acc->neg_sum[li * 16 + r];
+    }
+    s_p[li] = (float)ps / (float)n_match;
+    s_q[li] = (float)ns / ((float)acc->nnz_img[li] + 1.f);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const float det0 = (float)acc->det_sum[0] / ((float)acc->mask_cnt[0] + 1e-5f);
   const float det1 = (float)acc->det_sum[1] / ((float)acc->mask_cnt[1] + 1e-5f);
   float pos = 0.f, neg = 0.f, ldesc = 0.f;
   if (lambda_loss > 0.f && dense) {  // utils/utils.py:884-890
     double ps = 0, ns = 0, ls = 0;
-    for (int i = 0; i < 64 * 16; ++i) {
-      ps += acc->pos_sum[i];
-      ns += acc->neg_sum[i];
-      ls += acc->dense_sum[i];
+    for (int i = 0; i < 64; ++i) {
+      ps += s_d[0][i];
+      ns += s_d[1][i];
+      ls += s_d[2][i];
     }
     const double norm = (double)B * (acc->mask_cnt[1] + 1.0) * (double)cells;
     pos = (float)(ps / norm);
@@ -372,13 +398,7 @@ __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ 
     ldesc = (float)(ls / norm);
   } else if (lambda_loss > 0.f) {
     for (int i = 0; i < B; ++i) {
-      double ps = 0, ns = 0;
-      for (int r = 0; r < 16; ++r) {
-        ps += acc->pos_sum[i * 16 + r];
-        ns += acc->neg_sum[i * 16 + r];
-      }
-      const float p = (float)ps / (float)n_match;
-      const float q = (float)ns / ((float)acc->nnz_img[i] + 1.f);
+      const float p = s_p[i], q = s_q[i];
       pos += p;
       neg += q;
       ldesc += lamda_d * p + q;

@@ -1173,7 +1173,7 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
   hipStream_t st = (hipStream_t)stream;
   const float* eta = h->buf.params_dev + h->n_params;
   const int ncells = B * Hc * Wc;
-  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
                      in->lamda_d, (int)semantic);
   SlotSet SS{2, {&h->slot[0], &h->slot[1]}};
   {
@@ -1256,7 +1256,7 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
     }
     HIPCHK(hipGetLastError());
   }
-  hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, st, h->accum, eta,
+  hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(64), 0, st, h->accum, eta,
                      in->train ? h->buf.grads_dev + h->n_params : (float*)nullptr, scalars_dev, B, h->cfg.n_match,
                      in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train, (int)dense, Hc * Wc);
   HIPCHK(hipGetLastError());
