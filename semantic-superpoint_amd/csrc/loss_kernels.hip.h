@@ -10,20 +10,41 @@
 
 namespace sspk {
 
+// Wave-wide reductions on the DPP data path (cross-lane moves inside the VALU, ~8 cycles each) instead of six
+// ds_bpermute round trips through the LDS unit (~100 cycles each): xor 1, xor 2 inside the quads, mirror inside half
+// rows and rows (every lane then holds its 16-lane row total), row_bcast15 / row_bcast31 accumulate the rows into lane
+// 63, v_readlane broadcasts.  The result is identical in every lane.
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, float identity, Op op) {
+  auto dpp = [&](float x, int ctrl_sel) {
+    const int xi = __float_as_int(x), idn = __float_as_int(identity);
+    int r;
+    switch (ctrl_sel) {
+      case 0: r = __builtin_amdgcn_update_dpp(idn, xi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+      case 1: r = __builtin_amdgcn_update_dpp(idn, xi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+      case 2: r = __builtin_amdgcn_update_dpp(idn, xi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+      case 3: r = __builtin_amdgcn_update_dpp(idn, xi, 0x140, 0xF, 0xF, false); break;  // row_mirror
+      case 4: r = __builtin_amdgcn_update_dpp(idn, xi, 0x142, 0xA, 0xF, false); break;  // row_bcast15 -> rows 1, 3
+      default: r = __builtin_amdgcn_update_dpp(idn, xi, 0x143, 0xC, 0xF, false); break; // row_bcast31 -> rows 2, 3
+    }
+    return __int_as_float(r);
+  };
+  v = op(v, dpp(v, 0));
+  v = op(v, dpp(v, 1));
+  v = op(v, dpp(v, 2));
+  v = op(v, dpp(v, 3));
+  v = op(v, dpp(v, 4));
+  v = op(v, dpp(v, 5));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  return wave_reduce(v, 0.f, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  return wave_reduce(v, -__builtin_inff(), [](float a, float b) { return fmaxf(a, b); });
 }
 __device__ __forceinline__ float wave_prod(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v *= __shfl_xor(v, o);
-  return v;
+  return wave_reduce(v, 1.f, [](float a, float b) { return a * b; });
 }
 
 // block (4 waves) sum of a per-wave value held by lane 0 of each wave; result valid in thread 0
