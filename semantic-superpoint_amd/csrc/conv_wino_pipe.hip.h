@@ -2,16 +2,19 @@
 // decomposition, see conv_wino.hip.h): the K loop runs in 8-channel STAGES with double-buffered LDS images, so that
 // the staging of stage g+1 is interleaved with the MFMAs of stage g instead of stalling the matrix pipe:
 //
-//   stage g, first half : 16 MFMAs / wave on (sA[g&1], sB[g&1])  ||  raw halo (g+1) -> sR, weights (g+1) -> sB[~g&1],
-//                                                                    global loads of stage g+2 into the freed registers
+//   stage g, first half : 16 MFMAs / wave on sA[g&1]  ||  raw halo (g+1): registers -> sR; halo loads of stage g+2
 //   barrier
-//   stage g, second half: 16 MFMAs / wave                          ||  transform sR -> sA[~g&1]
+//   stage g, second half: 16 MFMAs / wave             ||  transform sR -> sA[~g&1]
 //   barrier
 //
-// LDS: 2 x (32 KB transformed input + 32 KB transformed weights) + 10.6 KB raw halo = 138.6 KB, one block per CU.
+// The weight (B) fragments come straight from L2 into the MFMA operand registers, one component pair ahead (template
+// parameter GB, default; GB = false stages them through sB like the input: conv algo 5).
+// LDS: 2 x (32 KB transformed input + 32 KB sB = epilogue staging / LDS-staged weights) + 10.6 KB raw halo + 8 KB
+// BatchNorm parameters = 146.6 KB, one block per CU.
 // The flat stage index runs over (tile, 8-channel chunk) pairs of the block's persistent tile list, so the pipeline
 // never drains between tiles; the tile epilogue (output transform, the two component halves meeting in ONE 64 KB
-// staging tile = the just-consumed sA/sB pair, 16-byte stores, BatchNorm sums) sits between two stages.
+// staging tile = the just-consumed sA/sB pair, 16-byte stores, BatchNorm statistics - forward: of the output; data
+// gradient: pass 1 of the BatchNorm backward of the layer below, ConvArgs::bnr_mode) sits between two stages.
 // Weights: pack_weights_wino8_kernel, [cob][chunk8][component][h][64][4].
 #pragma once
 #include "conv_wino.hip.h"
