@@ -188,16 +188,34 @@ __global__ void sem_upsample_bwd_nchw_kernel(const float* __restrict__ dsem, flo
   dsout[((size_t)n * Hc * Wc + cy * Wc + cx) * cs + c] += s;
 }
 
-// column sums of an NHWC matrix [rows][cs] -> out[C] (accumulated): convSout bias gradient
+// column sums of an NHWC matrix [rows][cs] -> out[C] (accumulated): convSout bias gradient.
+// block = 256 threads = 64 float4 column quads x 4 row lanes (rows are read as contiguous float4 runs); a block owns
+// COLSUM_ROWS rows; the row lanes meet in LDS, one atomic per column and block.  cs % 4 == 0, cs <= 256.
+constexpr int COLSUM_ROWS = 512;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m, float* __restrict__ out, int rows, int C,
                                                      int cs) {
-  // block handles 64 rows; thread t handles columns t, t+256, ...
-  const int r0 = blockIdx.x * 64;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int r = r0; r < min(r0 + 64, rows); ++r) s += m[(size_t)r * cs + c];
-    atomicAdd(out + c, s);
+  __shared__ float4 red[4][64];
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(r0 + COLSUM_ROWS, rows);
+  for (int q = threadIdx.x & 63; q * 4 < cs; q += 64) {  // one pass per 256 columns (one for every shipped model)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(m + (size_t)r * cs + q * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    red[rl][q & 63] = s;
   }
+  __syncthreads();
+  if (rl == 0)
+    for (int q = threadIdx.x & 63; q * 4 < cs; q += 64) {
+      // (columns beyond 256 would need one LDS round per pass; cs <= 256 is asserted on the host)
+      const float4 a = red[0][q & 63], b = red[1][q & 63], c = red[2][q & 63], d = red[3][q & 63];
+      const float t[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                          (a.w + b.w) + (c.w + d.w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < C) atomicAdd(out + q * 4 + e, t[e]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1027,8 +1027,9 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
   if (has_sem) {
     const LayerDesc& d = h->L[L_SOUT];
     const int ncells = N * Hc * Wc;
+    if (h->sout_cs > 256) return fail(-3, "segmentation head: more than 256 classes are not supported by colsum_kernel");
     for (int k = 0; k < SS.n; ++k)
-      hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, 64)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), ncells, d.cout,
+      hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, COLSUM_ROWS)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), ncells, d.cout,
                          h->sout_cs);
     HIPCHK(hipGetLastError());
     CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st));
