@@ -1,21 +1,37 @@
 #!/usr/bin/env python3
 """bench.py - image-pairs/s of the Semantic-SuperPoint pair training step on N MI355X (one process per GPU).
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched through
-torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment, RCCL backend).  A step is one
-full pair-training step on one batch of synthetic pairs already resident in HBM: 2 forwards (separate BatchNorm
-statistics), label ops, detector / sparse-descriptor (/ segmentation) losses with on-device index sampling,
-multi-task loss, backward, gradient all-reduce (N > 1), Adam.  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.
+  * launched under torch.distributed.run (WORLD_SIZE set): this process is one rank; WORLD_SIZE must equal --gpus;
+  * launched bare with --gpus N > 1: the parent - BEFORE anything touches the GPU - starts N fresh child processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relays rank 0's JSON line and exits non-zero if
+    any child fails (it never re-executes itself: children are ordinary subprocesses);
+  * N = 1 runs in-process, so `rocprofv3 ... -- python3 bench.py` has no hop between the profiler and the kernels.
 
-Workload = BASELINE.json configs[1]: SuperPointNet_gauss2, 240x320, batch 32 per GPU, fp32 (use --arch ssp for
-configs[2]).  `roofline`: conv_wino_pipe_kernel (all 3x3 forward + data-gradient launches, 2/3 of the step's FLOPs, run as
-Winograd F(2x2,3x3) in fp32), algorithmic FLOPs / HIP-event time measured live on the launch stream.  `cpu_baseline`: the oracle
-(oracle/cpu_ref.py, a restatement pinned against the reference) timed on this host's cores, rank 0, N = 1 only.
+Workload = BASELINE.json's north star, configs[2]: SuperPointNet_gauss2_ssmall (Semantic-SuperPoint: encoder + detector
++ descriptor + segmentation heads, uncertainty-weighted multi-task loss), 240x320, batch 32 per GPU, fp32
+(`--arch sp` = configs[1]).  A step is one full pair-training step on one batch of synthetic pairs already resident in
+HBM: 2 forwards (separate BatchNorm statistics), label ops, detector / sparse-descriptor / segmentation losses with
+on-device index sampling, multi-task loss, backward, gradient all-reduce (N > 1, overlapped with the tail of the
+backward pass), Adam.  Rank 0 prints ONE JSON line.
+
+`roofline`: the dominant kernel family conv_wino_pipe_kernel (all 3x3 forward + data-gradient launches, 2/3 of the
+step's FLOPs, Winograd F(2x2,3x3) in fp32): algorithmic FLOPs / HIP-event time measured live on the launch stream.
+`roofline.traffic`: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE)
+collected in THIS run by two short profiled child runs of the same command (`--traffic live`, the default at N = 1 when
+rocprofv3 is on PATH; null if that fails).  `cpu_baseline`: the oracle (oracle/cpu_ref.py, a restatement pinned against
+the reference) timed on this host's cores, rank 0, N = 1 only: batch 32, 1 warm-up + 3 timed steps.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,12 +40,13 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_PAIR = {"SuperPointNet_gauss2": 77.98, "SuperPointNet_gauss2_ssmall": 82.72}
 PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3 line)
+DOMINANT_KERNEL = "conv_wino_pipe_kernel"
 
 
-def cpu_baseline(arch, H, W, batch=8, steps=1):
-    """Oracle pair step on the host cores (bounded sample).  PyTorch's CPU kernels stop scaling (and the
-    oracle's Python loops thrash) far below the 256 hardware threads of the GPU host, so the baseline uses
-    min(cores, 32) threads - measured faster than 256 - and reports that number as `cores`."""
+def cpu_baseline(arch, H, W, batch=32, steps=3):
+    """Oracle pair step on the host cores (bounded sample: 1 warm-up + `steps` timed steps at the benchmark batch).
+    PyTorch's CPU kernels stop scaling (and the oracle's Python loops thrash) far below the 256 hardware threads of the
+    GPU host, so the baseline uses min(cores, 32) threads - measured faster than 256 - and reports that as `cores`."""
     import torch
     from oracle import cpu_ref as C
     cores = min(os.cpu_count() or 1, 32)
@@ -47,31 +64,126 @@ def cpu_baseline(arch, H, W, batch=8, steps=1):
                       % (arch, H, W, batch, steps, dt)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--arch", default="sp", choices=["sp", "ssp"])
+    ap.add_argument("--arch", default="ssp", choices=["sp", "ssp"],
+                    help="ssp = SuperPointNet_gauss2_ssmall (north star, configs[2]); sp = SuperPointNet_gauss2 (configs[1])")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5],
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6],
                     help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
-                         "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 matrix-core operands (reduced precision: reported as dtype bf16)")
+                         "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
+                         "matrix-core operands (reduced precision: reported as dtype bf16)")
     ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
                     help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
-    args = ap.parse_args()
+    ap.add_argument("--graph", action="store_true", help="replay the pair step as a hipGraph (ssp_pair_step_graph)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: one blocking all-reduce after the whole backward instead of the overlapped split bucket")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "none"],
+                    help="roofline.traffic: live = two rocprofv3 --pmc child runs of this command (FETCH_SIZE, WRITE_SIZE) "
+                         "before the timed run; auto = live when N = 1, rocprofv3 is on PATH and the roofline leg is on")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of --traffic live
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks (the parent never touches the GPU)
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# roofline.traffic measured in this run: rocprofv3 PMC passes over a short child run of the same workload
+# ------------------------------------------------------------------------------------------------
+def live_traffic(args):
+    """HBM bytes per launch of the dominant kernel: (2 x FETCH_SIZE + WRITE_SIZE) KB -> bytes, separate PMC passes, FETCH
+    doubled (gfx950 counts wide coalesced reads at half: MI355X_MICROARCH.md section HBM).  Returns (bytes or None, note)."""
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None, "rocprofv3 not on PATH"
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "1", "--gpus", "1",
+             "--arch", args.arch, "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
+             "--conv-algo", str(args.conv_algo), "--desc-loss", args.desc_loss, "--no-cpu-baseline", "--no-roofline",
+             "--traffic", "none"]
+    tot, launches = {}, {}
+    tmp = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.PIPE, text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s timed out" % ctr
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (ctr, r.returncode)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "no counter_collection.csv from rocprofv3"
+            s, seen = 0.0, set()
+            for row in csv.DictReader(open(files[0])):
+                if DOMINANT_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    s += float(row["Counter_Value"])
+                    seen.add(row["Dispatch_Id"])
+            tot[ctr], launches[ctr] = s, len(seen)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not launches.get("FETCH_SIZE") or launches["FETCH_SIZE"] != launches.get("WRITE_SIZE"):
+        return None, "PMC passes saw different launch counts: %s" % launches
+    n = launches["FETCH_SIZE"]
+    hbm = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / n
+    return hbm, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of a 1+1-step child run in this job, %d launches); "
+                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches" % n)
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))  # nothing below has run: the parent never initialises the GPU
+    world = int(world_env) if world_env is not None else 1
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    traffic, traffic_note = None, "not collected"
+    want_live = args.traffic == "live" or (args.traffic == "auto" and not args.no_roofline and not args.pmc_child)
+    if want_live and world == 1:
+        traffic, traffic_note = live_traffic(args)  # child processes; this process has not touched the GPU yet
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # debugging aid for 1-GPU boxes: SSP_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses
@@ -89,7 +201,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import semantic_superpoint_amd as ssp
-    from semantic_superpoint_amd import synth
+    from semantic_superpoint_amd import parallel, synth
     from semantic_superpoint_amd.lib import Engine, layer_table, SCALAR_NAMES
 
     arch = "SuperPointNet_gauss2" if args.arch == "sp" else "SuperPointNet_gauss2_ssmall"
@@ -100,27 +212,50 @@ def main():
     eng.load_state_dict(synth.default_init_state_dict(layer_table(arch), seed=0))  # identical replicas
     sample = synth.make_pair(B, H, W, dev, seed=100 + rank, semantic=arch.endswith("ssmall"))
     torch.cuda.synchronize()
+    rccl_ranks = 1
+    if world > 1:  # prove the collective spans all ranks before timing anything
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        rccl_ranks = int(round(float(t.item())))
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
+
+    stream = torch.cuda.Stream(device=dev) if args.graph else None  # stream capture needs a non-default stream
 
     def step(it):
+        kw = dict(indices=None, seed=(it * 1000003 + rank * 7919 + 1), train=True, lambda_loss=1.0, lamda_d=1.0,
+                  multi_task=True, dense=dense, graph=args.graph)
         eng.zero_grad()
-        eng.pair_step(sample, indices=None, seed=(it * 1000003 + rank * 7919 + 1), train=True, lambda_loss=1.0,
-                      lamda_d=1.0, multi_task=True, dense=dense)
-        if world > 1:  # data parallel: one all-reduce of the flat fp32 gradient bucket (incl. eta), then mean
-            dist.all_reduce(eng.grads)
-            eng.grads.div_(world)
-        eng.adam_step(args.lr)
+        if world > 1 and not args.no_overlap:
+            parallel.pair_step_overlapped(eng, sample, args.lr, **kw)
+        else:
+            eng.pair_step(sample, **kw)
+            if world > 1:  # one blocking all-reduce of the flat fp32 gradient bucket (incl. eta), then the mean
+                dist.all_reduce(eng.grads)
+                eng.adam_step(args.lr, grad_scale=1.0 / world)
+            else:
+                eng.adam_step(args.lr)
 
-    for it in range(args.warmup):
-        step(it)
+    def run(n, first):
+        if stream is None:
+            for it in range(n):
+                step(first + it)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                for it in range(n):
+                    step(first + it)
+            torch.cuda.current_stream().wait_stream(stream)
+
+    run(args.warmup, 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    if not args.no_roofline and rank == 0:
+    profiled = not args.no_roofline and rank == 0 and not args.graph  # hipEvents cannot be recorded into a capture
+    if profiled:
         eng.profile_enable("conv3x3_all")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for it in range(args.steps):
-        step(args.warmup + it)
+    run(args.steps, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -133,45 +268,45 @@ def main():
     if rank == 0:
         scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
         pairs_s = world * B * args.steps / dt
+        reduced = args.conv_algo == 3
         out = {"metric": "image-pairs/sec at %dx%d bs%d (pair training step)" % (H, W, B), "value": round(pairs_s, 2),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16" if args.conv_algo == 3 else "f32", "data": "synthetic",
-               "config": {"workload": "%s pair step %dx%d, batch %d per GPU, %s, %s, Adam"
-                                      % (arch, H, W, B, "fp32" if args.conv_algo != 3 else
+               "vs_baseline": None, "dtype": "bf16" if reduced else "f32", "data": "synthetic",
+               "config": {"workload": "%s pair step %dx%d, batch %d per GPU, %s, %s, Adam%s"
+                                      % (arch, H, W, B, "fp32" if not reduced else
                                          "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)",
                                          "sparse loss 1000x100" if dense is None else
-                                         "dense descriptor loss (1200x1200 per image)"), "parallelism": "dp%d" % world,
-                          "global_batch": world * B},
+                                         "dense descriptor loss (1200x1200 per image)",
+                                         ", hipGraph replay" if args.graph else ""),
+                          "parallelism": "dp%d" % world, "global_batch": world * B,
+                          "allreduce": ("none" if world == 1 else "one bucket after backward" if args.no_overlap else
+                                        "split bucket, early part overlapped with the backward of the 240x320 layers")},
+               "rccl_ranks": rccl_ranks,
                "step_tflops": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3, 2),
                "step_frac_of_fp32_mfma_peak": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3 / (PEAK_FP32_MFMA_TF * world), 4),
                "final_loss": round(scal["loss"], 4)}
-        if not args.no_roofline:
+        if profiled:
             pr = eng.profile_read()
             if pr["launches"] > 0 and pr["ms"] > 0:
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
-                traffic = None  # HBM bytes / launch from the committed rocprofv3 PMC passes (cannot be read live)
-                tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-                if args.arch == "sp" and (B, H, W) == (32, 240, 320) and args.conv_algo == 1 and os.path.exists(tpath):
-                    tj = json.load(open(tpath))  # only valid for the launch structure it was profiled with
-                    if abs(tj.get("flops_per_launch_avg_gflop", 0) - pr["flops"] / pr["launches"] / 1e9) < 0.05 * tj.get(
-                            "flops_per_launch_avg_gflop", 1):
-                        traffic = round(tj["hbm_bytes_per_launch"])
-                peak = PEAK_BF16_MFMA_TF if args.conv_algo == 3 else PEAK_FP32_MFMA_TF
+                peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
                 out["roofline"] = {"bound": "mfma", "kernel": "conv_wino_pipe_kernel (3x3 forward + data-gradient, Winograd "
                                                               "F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4),
                                    "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / time; Winograd executes "
-                                           "16/36 of them on the matrix cores, so frac may exceed 1",
+                                           "16/36 of them on the matrix cores, so frac may exceed 1: executed_frac is the "
+                                           "hardware fraction of the matrix-core peak",
                                    "executed_tflops": round(ach * 16.0 / 36.0, 2),
-                                   "executed_frac": round(ach * 16.0 / 36.0 / peak, 4), "traffic": traffic,
+                                   "executed_frac": round(ach * 16.0 / 36.0 / peak, 4),
+                                   "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_note,
                                    "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                    "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4),
                                    "flops_per_launch_avg": round(pr["flops"] / pr["launches"] / 1e9, 3)}
             eng.profile_enable("none")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(arch, H, W)
+            out["cpu_baseline"] = cpu_baseline(arch, H, W, batch=B)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

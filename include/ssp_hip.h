@@ -37,7 +37,8 @@ enum { SSP_NREP = 32 }; /* replicas of each fp64 statistics accumulator (spreads
 typedef struct {
   int arch;      /* SSP_ARCH_* */
   int n_classes; /* 133 for the ssmall seg head; ignored for gauss2 */
-  int max_batch; /* largest N of any forward */
+  int max_batch; /* largest N of any forward (1..1024); ssp_pair_step additionally requires batch <= 64
+                    (fixed per-image accumulator arrays of the sparse / dense descriptor loss) */
   int height;    /* H, multiple of 8 */
   int width;     /* W, multiple of 8 */
   int n_match;   /* num_matching_attempts (1000) */
@@ -119,6 +120,27 @@ int ssp_backward(ssp_handle* h, int slot, const float* dsemi_dev, const float* d
 int ssp_zero_grad(ssp_handle* h, void* stream);
 int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, void* stream);
 int ssp_adam_step(ssp_handle* h, float lr, int step, void* stream);
+/* the same Adam step on grads * grad_scale (data parallel: 1 / world_size after an all-reduce SUM; grads_dev is left
+ * untouched, so gradient accumulation over micro-batches keeps working) */
+int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, void* stream);
+
+/* ---- data-parallel overlap ("all-reduce overlapped with encoder backward") ------------------
+ * ssp_pair_step_phase: phase 0 = ssp_pair_step.  Phase 1 runs the step up to the point where every gradient from
+ * ssp_grad_early_offset(h) to the end of the flat vector (encoder layers >= 2, all heads, eta: 97.7 % of the bytes) is
+ * FINAL; phase 2 runs the rest of the backward pass (the two 240x320 layers, 40 % of the backward time).  Between the
+ * two calls the host starts the all-reduce of the early bucket on another stream; it overlaps with phase 2. */
+int ssp_pair_step_phase(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, int phase, void* stream);
+size_t ssp_grad_early_offset(const ssp_handle* h); /* first float of the early-final gradient bucket */
+
+/* ---- hipGraph form of the pair step (north star: "one graph per image pair") --------------------------------------
+ * The first call with a given (inputs, phase, algorithm) signature captures the launches of ssp_pair_step_phase into a
+ * hipGraph on `stream` (must not be the default stream); later calls replay it with ONE hipGraphLaunch.  With
+ * sample_indices != 0 the device index sampler (ssp_sample_indices into in->match_a/match_b/nonmatch_b_dev, which must
+ * be caller-owned buffers of the usual sizes) is part of the graph; its seed `in->seed` is kept in device memory and may
+ * change from call to call.  Everything else of `in` is part of the signature.  Up to 16 graphs are cached per handle;
+ * ssp_bind drops them.  ssp_profile_enable must be off (hipEvents cannot be recorded into the capture). */
+int ssp_pair_step_graph(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, int phase, int sample_indices,
+                        void* stream);
 int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
                        int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream);
 
@@ -146,6 +168,12 @@ int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw
  * (Train_model_frontend_all.py:373-386) -> cellmask [B,H/8,W/8]; either pair of pointers may be NULL. */
 int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* target_dev, float* cellmask_dev, int b,
                   int h, int w, void* stream);
+
+/* detector_loss (Train_model_heatmap_all.py:155-179, softmax branch) as an operator: semi NHWC [b][h/8*w/8][cs] (65 logits,
+ * channel stride cs >= 65), labels2d / mask2d [b,1,h,w] -> loss_dev[0] and (optional) d loss / d semi in the same layout.
+ * scratch: 64 KiB + 4 bytes per cell. */
+int ssp_op_detector_loss(const float* semi_nhwc_dev, int cs, const float* labels2d_dev, const float* mask2d_dev, int b, int h,
+                         int w, void* scratch_dev, size_t scratch_bytes, float* loss_dev, float* dsemi_nhwc_dev, void* stream);
 
 /* ---- pair construction on the device (dataset side of the reference, datasets/Coco.py:341-392) ----
  * ssp_op_warp_image : inv_warp_image_batch (utils/utils.py:347-385): out[p] = sample(img, inv_h * p), p on the
@@ -243,8 +271,8 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
                   float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int h,
                   int w, int c, int relu, int pool, void* stream);
 
-/* Algorithm of the 3x3 forward / data-gradient convolutions whose input channels are a multiple of 16 (process-wide;
- * takes effect at the next forward, which re-packs the weights): 1 (default) = Winograd F(2x2,3x3) on the fp32 matrix
+/* Algorithm of the 3x3 forward / data-gradient convolutions whose input channels are a multiple of 16 (process-wide
+ * DEFAULT, copied into a handle at ssp_create; takes effect at the next forward, which re-packs the weights): 1 (default) = Winograd F(2x2,3x3) on the fp32 matrix
  * cores (2.25x fewer multiplies, fp32 throughout, results within ~1e-6 relative of the direct form; software-pipelined
  * kernel whose weight fragments come straight from L2), 5 = the same pipeline with the weights staged through LDS,
  * 2 = Winograd without the software pipeline (both for A/B measurements), 0 = direct implicit GEMM,
@@ -252,6 +280,9 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
  * accumulation and master weights); outputs within ~4e-3 relative RMS of fp32, gradients of the first layers up to
  * ~25 % off per step; never used for a reported fp32 number. */
 int ssp_set_conv_algo(int algo);
+/* the same choice for ONE handle (a new handle starts with the process-wide value of ssp_set_conv_algo, which also
+ * governs the handle-less ssp_op_conv / ssp_op_conv_wgrad) */
+int ssp_handle_set_conv_algo(ssp_handle* h, int algo);
 
 /* perf-debug hook: ablate bits (1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA) and grid override of
  * conv_mfma_kernel; (0, 0) restores the product behaviour. */

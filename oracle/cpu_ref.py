@@ -104,7 +104,7 @@ def param_keys(arch, n_classes=133):
 # --------------------------------------------------------------------------------------
 # Model forward  (models/unet_parts.py:10-48; SuperPointNet_gauss2.py:42-69; _ssmall.py:58-99)
 # --------------------------------------------------------------------------------------
-def _conv_bn(x, sd, conv, bn, k, train, relu):
+def _conv_bn(x, sd, conv, bn, k, train, relu, forced=None):
     y = F.conv2d(x, sd[conv + ".weight"], sd[conv + ".bias"], padding=k // 2)
     if bn is not None:
         # nn.BatchNorm2d defaults: eps 1e-5, momentum 0.1
@@ -112,27 +112,40 @@ def _conv_bn(x, sd, conv, bn, k, train, relu):
                          sd[bn + ".bias"], training=train, momentum=0.1, eps=1e-5)
         if train:
             sd[bn + ".num_batches_tracked"] += 1
+    if relu and forced is not None:  # test hook: the ReLU gate is dictated by the caller (see forward)
+        return y * forced["relu"][conv].to(y.dtype)
     return F.relu(y) if relu else y
 
 
-def forward(sd, x, arch="SuperPointNet_gauss2", train=True, n_classes=133, return_x4=False):
+def _forced_pool(h, idx):
+    """2x2 max-pool whose winner is dictated: idx [N,C,H/2,W/2] in 0..3 (row-major position inside the window)."""
+    N, C, H, W = h.shape
+    win = h.view(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H // 2, W // 2, 4)
+    return torch.gather(win, 4, idx.long().unsqueeze(-1)).squeeze(-1)
+
+
+def forward(sd, x, arch="SuperPointNet_gauss2", train=True, n_classes=133, return_x4=False, forced=None):
     """x [N,1,H,W] -> {"semi","desc"[,"sem"]}.  `sd` is a dict of torch tensors; BN running
     statistics are updated in place when train=True (module default; the reference never calls
-    .eval() while training: SURVEY.md section 7 'Hard parts')."""
+    .eval() while training: SURVEY.md section 7 'Hard parts').
+    forced (test hook, not reference behaviour): {"relu": {conv name: 0/1 gate [N,C,H,W]}, "pool": {layer index:
+    winner index [N,C,H/2,W/2]}} replaces the data-dependent ReLU gates and max-pool winners by the given ones, which
+    makes the network a smooth function of its parameters: used to show that the end-to-end gradient differences
+    between the HIP path and the oracle come from gate flips of activations within rounding distance of 0 only."""
     t = layer_table(arch, n_classes)
     h = x
     for i, (conv, bn, cin, cout, k) in enumerate(t[:8]):
         if i in (2, 4, 6):  # down = MaxPool2d(2) -> double_conv   (unet_parts.py:41-44)
-            h = F.max_pool2d(h, 2)
-        h = _conv_bn(h, sd, conv, bn, k, train, relu=True)
+            h = F.max_pool2d(h, 2) if forced is None else _forced_pool(h, forced["pool"][i])
+        h = _conv_bn(h, sd, conv, bn, k, train, relu=True, forced=forced)
     x4 = h
-    cPa = _conv_bn(x4, sd, "convPa", "bnPa", 3, train, relu=True)
+    cPa = _conv_bn(x4, sd, "convPa", "bnPa", 3, train, relu=True, forced=forced)
     semi = _conv_bn(cPa, sd, "convPb", "bnPb", 1, train, relu=False)
-    cDa = _conv_bn(x4, sd, "convDa", "bnDa", 3, train, relu=True)
+    cDa = _conv_bn(x4, sd, "convDa", "bnDa", 3, train, relu=True, forced=forced)
     desc = _conv_bn(cDa, sd, "convDb", "bnDb", 1, train, relu=False)
     out = {}
     if arch.endswith("ssmall"):
-        s = _conv_bn(x4, sd, "convDS", "bnS1", 3, train, relu=True)
+        s = _conv_bn(x4, sd, "convDS", "bnS1", 3, train, relu=True, forced=forced)
         s = _conv_bn(s, sd, "convSout", None, 1, train, relu=False)
         out["sem"] = F.interpolate(s, x.shape[2:], mode="bilinear", align_corners=False)
     dn = torch.norm(desc, p=2, dim=1)  # SuperPointNet_gauss2.py:64-65 (no epsilon)
@@ -307,12 +320,13 @@ def multi_task_loss(eta, det, pos, neg, sem=None):
 # --------------------------------------------------------------------------------------
 def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lambda_loss=1.0, lamda_d=1.0,
                 multi_task=True, gaussian=True, n_match=1000, n_non=100, np_rng=np.random, torch_gen=None,
-                train=True, dense=None):
+                train=True, dense=None, forced=None):
     """Forward of both views + all losses.  Returns (loss, scalars dict, aux dict).
     dense: None (sparse descriptor loss) or the dict of model.dense_loss.params (Train_model_heatmap_all.py:131-137)."""
     semantic = arch.endswith("ssmall")
-    out = forward(sd, sample["image"], arch, train=train)
-    out_w = forward(sd, sample["warped_img"], arch, train=train)  # separate BN statistics (:258,262)
+    out = forward(sd, sample["image"], arch, train=train, forced=None if forced is None else forced[0])
+    out_w = forward(sd, sample["warped_img"], arch, train=train,  # separate BN statistics (:258,262)
+                    forced=None if forced is None else forced[1])
     lab = sample["labels_2D_gaussian"] if gaussian else sample["labels_2D"]
     lab_w = sample["warped_labels_gaussian"] if gaussian else sample["warped_labels"]
     l3 = labels2Dto3D(lab).float()
@@ -572,6 +586,53 @@ def make_synthetic_pair(B, H, W, seed=0, semantic=False, kp_prob=0.003, erosion=
         ws = inv_warp_image_batch(sem.float().unsqueeze(1), inv_t, mode="bilinear").squeeze(1).long()
         ws[vm.view(B, H, W) == 0] = n_classes
         s["semantic"], s["warped_sem"] = sem, ws
+    return s
+
+
+def make_compact_pair(B, H, W, seed=0, semantic=False, kp_prob=0.003, erosion=3, n_classes=133, block=16):
+    """make_synthetic_pair whose tensors survive a compact fixture: images on the 8-bit grid k / 255 (the warped image
+    is re-quantised after the warp), semantic maps constant on block x block tiles.  `compact_to_npz` / `compact_from_npz`
+    store / restore the sample as uint8 / packed arrays (full-size golden steps stay well below 1 MB)."""
+    rs = np.random.RandomState(seed)
+    s = make_synthetic_pair(B, H, W, seed=seed, semantic=False, kp_prob=kp_prob, erosion=erosion)
+    q = lambda t: torch.round(t.clamp(0, 1) * 255.0) / 255.0  # noqa: E731
+    img = q(s["image"])
+    s["image"] = img
+    s["warped_img"] = q(inv_warp_image_batch(img, s["inv_homographies"]))
+    if semantic:
+        coarse = rs.randint(0, n_classes + 1, size=(B, (H + block - 1) // block, (W + block - 1) // block))
+        sem = torch.from_numpy(np.kron(coarse, np.ones((block, block), dtype=np.int64))[:, :H, :W].astype(np.int64)).contiguous()
+        ws = inv_warp_image_batch(sem.float().unsqueeze(1), s["inv_homographies"], mode="nearest").squeeze(1).long()
+        ws[s["warped_valid_mask"].view(B, H, W) == 0] = n_classes
+        s["semantic"], s["warped_sem"] = sem, ws
+    return s
+
+
+def compact_to_npz(s):
+    out = {"in/image_u8": np.round(s["image"].numpy() * 255.0).astype(np.uint8),
+           "in/warped_img_u8": np.round(s["warped_img"].numpy() * 255.0).astype(np.uint8),
+           "in/homographies": s["homographies"].numpy(), "in/inv_homographies": s["inv_homographies"].numpy()}
+    for k in ("labels_2D", "warped_labels", "valid_mask", "warped_valid_mask"):
+        out["in/%s_bits" % k] = np.packbits(s[k].numpy().astype(np.uint8))
+    if "semantic" in s:
+        out["in/semantic_u8"] = s["semantic"].numpy().astype(np.uint8)
+        out["in/warped_sem_u8"] = s["warped_sem"].numpy().astype(np.uint8)
+    out["in/shape"] = np.array(s["image"].shape, dtype=np.int32)
+    return out
+
+
+def compact_from_npz(z):
+    B, _, H, W = (int(v) for v in z["in/shape"])
+    s = {"image": torch.from_numpy(z["in/image_u8"].astype(np.float32)) / 255.0,
+         "warped_img": torch.from_numpy(z["in/warped_img_u8"].astype(np.float32)) / 255.0,
+         "homographies": torch.from_numpy(z["in/homographies"]), "inv_homographies": torch.from_numpy(z["in/inv_homographies"])}
+    for k in ("labels_2D", "warped_labels", "valid_mask", "warped_valid_mask"):
+        bits = np.unpackbits(z["in/%s_bits" % k])[:B * H * W]
+        s[k] = torch.from_numpy(bits.astype(np.float32)).view(B, 1, H, W)
+    s["labels_2D_gaussian"], s["warped_labels_gaussian"] = s["labels_2D"].clone(), s["warped_labels"].clone()
+    if "in/semantic_u8" in z:
+        s["semantic"] = torch.from_numpy(z["in/semantic_u8"].astype(np.int64))
+        s["warped_sem"] = torch.from_numpy(z["in/warped_sem_u8"].astype(np.int64))
     return s
 
 

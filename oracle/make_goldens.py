@@ -518,11 +518,83 @@ def g9_logging():
                         recall=float(pr_ref["recall"]))
 
 
+def g12_full_size_step():
+    """G12: the pair step at the BENCHMARK resolution (240x320, B = 2) on the real reference: scalars of two optimizer
+    steps, per-tensor gradient norms + 64-element slices of the first step, post-step eta, and - SURVEY.md section 8c G1 -
+    per-channel checksums + strided slices of the first train-mode forward.  Inputs are stored compactly
+    (cpu_ref.compact_to_npz: 8-bit images, bit-packed labels / masks, block-constant semantic maps)."""
+    for tag, arch in (("sp", "SuperPointNet_gauss2"), ("ssp", "SuperPointNet_gauss2_ssmall")):
+        H, W = 240, 320
+        semantic = arch.endswith("ssmall")
+        cfg = R.base_config(semantic=semantic, H=H, W=W, batch=2, lr=0.001, lambda_loss=1, multi_task=True)
+        sd = C.init_state_dict(arch, seed=29)
+        sample = C.make_compact_pair(2, H, W, seed=41, semantic=semantic)
+        save = C.compact_to_npz(sample)
+        # forward checksums (reference network, train mode, fresh running statistics)
+        net = ref_net(arch, sd)
+        with torch.no_grad():
+            o = net(sample["image"])
+        po = C.forward(C.to_torch(sd), sample["image"], arch)
+        for k in o:
+            close(o[k], po[k], 2e-6, "G12 %s forward %s" % (tag, k))
+        save["fwd/semi_chsum"] = npy(o["semi"].double().sum(dim=(2, 3)))
+        save["fwd/desc_chsum"] = npy(o["desc"].double().sum(dim=(2, 3)))
+        save["fwd/semi_s"] = npy(o["semi"][:, ::4, ::3, ::4])
+        save["fwd/desc_s"] = npy(o["desc"][:, ::16, ::3, ::4])
+        if semantic:
+            save["fwd/sem_chsum"] = npy(o["sem"].double().sum(dim=(2, 3)))
+            save["fwd/sem_s"] = npy(o["sem"][:, ::19, ::24, ::32])
+        # two optimizer steps on the reference, mirrored by the oracle
+        agent = R.make_trainer(cfg, sd)
+        tr = C.Trainer(arch, sd, lr=0.001, lambda_loss=1.0, multi_task=True)
+        for it in range(2):  # the SAME RNG seeds in both steps: one stored index set serves both
+            np.random.seed(100); torch.manual_seed(200)
+            agent.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=it + 1, train=True)
+            sc_ref = {k: float(v) for k, v in agent.scalar_dict.items()}
+            np.random.seed(100); torch.manual_seed(200)
+            tr.train_val_sample(sample, n_iter=it + 1, train=True)
+            for k in sc_ref:
+                close(sc_ref[k], tr.scalar_dict[k], 2e-5 * max(1.0, abs(sc_ref[k])), "G12 %s scalar %s it%d" % (tag, k, it))
+                save["step%d/%s" % (it, k)] = np.float32(sc_ref[k])
+            for i, idx in enumerate(tr.aux["indices"]):
+                for nm in ("uv_a", "uv_b", "nm_b"):
+                    arr = npy(idx[nm]).astype(np.int16)
+                    if it == 0:
+                        save["idx/%s%d" % (nm, i)] = arr
+                    else:
+                        assert np.array_equal(save["idx/%s%d" % (nm, i)], arr)
+        save["post/eta"] = npy(agent.multi_task_loss.eta)
+        close(agent.multi_task_loss.eta, tr.eta, 1e-5, "G12 eta")
+        # gradients of the first step (no optimizer step)
+        agent2 = R.make_trainer(cfg, sd)
+        agent2.real_batch_size = 10 ** 9
+        np.random.seed(100); torch.manual_seed(200)
+        agent2.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=1, train=True)
+        tr2 = C.Trainer(arch, sd, lr=0.001, lambda_loss=1.0, multi_task=True)
+        tr2.real_batch_size = 10 ** 9
+        np.random.seed(100); torch.manual_seed(200)
+        tr2.train_val_sample(sample, n_iter=1, train=True)
+        noisy = {conv + ".bias" for conv, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+        for k, p in agent2.net.named_parameters():
+            g, go = p.grad, tr2.last_grads[k]
+            scale = max(1e-6, float(g.abs().max()))
+            if k not in noisy:
+                close(g, go, 5e-4 * scale + 1e-6, "G12 %s grad %s" % (tag, k))
+            save["grad_norm/" + k] = np.float32(g.norm().item())
+            save["grad_slice/" + k] = npy(g.reshape(-1)[:64])
+        save["grad/eta"] = npy(agent2.multi_task_loss.eta.grad)
+        np.savez_compressed(os.path.join(OUT, "g12_step_%s_240x320.npz" % tag), **save)
+        print("G12", tag, "ok;", os.path.getsize(os.path.join(OUT, "g12_step_%s_240x320.npz" % tag)), "bytes")
+
+
 def main():
     assert R.available(), "reference not mounted"
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss, g11_pair_labels):
+    only = os.environ.get("SSP_GOLDEN_ONLY")  # e.g. SSP_GOLDEN_ONLY=g12 regenerates one family
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss, g11_pair_labels, g12_full_size_step):
+        if only and not fn.__name__.startswith(only):
+            continue
         fn()
         print(fn.__name__, "done")
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

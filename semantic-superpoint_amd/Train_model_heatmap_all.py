@@ -8,8 +8,11 @@ Deliberate behaviours kept from the reference (SURVEY.md section 8a row a14 / se
   * gradients accumulate un-scaled over micro-batches until ((n_iter+1)*batch) % real_batch_size == 0;
   * scalar_dict["eta_*"] are read AFTER the optimizer step (the reference logs the live parameter);
   * validation (train=False) runs BatchNorm in train mode under no_grad, i.e. it updates running statistics.
-Not reproduced (out of the accelerated path): the tensorboard image / precision-recall branch every
-`tensorboard_interval` steps (Train_model_heatmap_all.py:447-568) - scalars are still logged.
+Logging branch (every `tensorboard_interval` steps and in validation, Train_model_heatmap_all.py:447-568): the
+precision / recall scalars and the NMS map are produced on the device (`log_precision_recall`); the tensorboard image
+overlays of that branch are not drawn.
+Data parallel (one process per GPU, torch.distributed initialised by the launcher): the gradient all-reduce of the
+optimizer step is split in two buckets and overlapped with the tail of the backward pass (parallel.pair_step_overlapped).
 """
 import copy
 import logging
@@ -140,15 +143,35 @@ class Train_model_heatmap_all(object):
         self.net = _MODELS[name](**params).to(self.device)
         if self.desc_loss_type == "dense":  # the engine reserves the [B, cells, cells] coefficient matrix
             self.net._engine_kwargs = {"dense_loss": True}
+        else:
+            # descriptor_loss_sparse(**desc_params) (sparse_loss.py:65-72): defaults 1000 attempts, 10 masked
+            # non-matches per match, lamda_d 250; the shipped configs set 600-1000 x 100 x 1
+            n_match = int(self.desc_params.get("num_matching_attempts", 1000))
+            n_non = int(self.desc_params.get("num_masked_non_matches_per_match", 10))
+            if not (1 <= n_match <= L.SAMPLER_MAX_MATCHES) or not (1 <= n_non <= 4096):
+                raise ValueError("sparse_loss.params: num_matching_attempts must be in 1..%d and "
+                                 "num_masked_non_matches_per_match in 1..4096 (got %d, %d)"
+                                 % (L.SAMPLER_MAX_MATCHES, n_match, n_non))
+            self.net._engine_kwargs = {"n_match": n_match, "n_non": n_non}
+        # the engine is sized once for the larger of the training / validation batch, so that a validation batch
+        # never re-creates it (re-creation carries the optimizer state over, but costs a workspace allocation)
+        self.net._engine_min_batch = max(int(self.config["model"].get("batch_size", 1)),
+                                         int(self.config["model"].get("eval_batch_size", 1)))
         n_iter = 0
+        self._resume = None
         if not self.config.get("retrain", True) and self.config.get("pretrained"):
             path = self.config["pretrained"]
-            ckpt = torch.load(path, map_location="cpu")
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
             if path[-4:] == ".pth":
                 self.net.load_state_dict(ckpt)
             else:
                 self.net.load_state_dict(ckpt["model_state_dict"])
                 n_iter = ckpt.get("n_iter", 0)
+                # The reference loads the optimizer state here (utils/loader.py:190-194) and then THROWS IT AWAY:
+                # dataParallel() builds a fresh Adam (Train_model_frontend_all.py:171-181) and MultiTaskLoss.eta is not
+                # in the checkpoint at all.  `ssp_restore_optimizer: true` resumes Adam (m, v, step) and eta instead.
+                if self.config.get("ssp_restore_optimizer", False):
+                    self._resume = {"optimizer_state_dict": ckpt.get("optimizer_state_dict"), "eta": ckpt.get("eta")}
         self.n_iter = 0 if self.config.get("reset_iter", True) else n_iter
         self.learning_rate = self.config["model"]["learning_rate"]
         return self.net
@@ -159,10 +182,13 @@ class Train_model_heatmap_all(object):
         self._adam_reset = True
 
     def _engine_for(self, B, H, W):
-        e = self.net.engine(B, H, W, self.device)
+        e = self.net.engine(max(B, getattr(self.net, "_engine_min_batch", 1)), H, W, self.device)
         if getattr(self, "_adam_reset", True):
             e.adam_m.zero_(); e.adam_v.zero_(); e.adam_t = 0
             e.zero_grad()
+            if getattr(self, "_resume", None):
+                L.load_optimizer_state(e, self._resume.get("optimizer_state_dict"), self._resume.get("eta"))
+                self._resume = None
             parallel.broadcast_(e.params)
             parallel.broadcast_(e.bn_running)
             self._adam_reset = False
@@ -194,13 +220,16 @@ class Train_model_heatmap_all(object):
         if lam > 0 and dense is None and self.sampler == "reference":
             idx = tuple(t.to(self.device) for t in sample_sparse_indices_host(
                 sample["homographies"], H // 8, W // 8, eng.n_match, eng.n_non))
-        sc = eng.pair_step(dev, indices=idx, seed=int(cfg.get("ssp_seed", 0)) * 1000003 + n_iter, train=train,
-                           lambda_loss=lam, lamda_d=float(self.desc_params.get("lamda_d", 1)),
-                           multi_task=bool(m["multi_task_loss"]), gaussian=self.gaussian, dense=dense)
-        if train and ((n_iter + 1) * B) % self.real_batch_size == 0:
-            parallel.allreduce_mean_(eng.grads)
-            eng.adam_step(self.learning_rate)
+        # rank-offset sampler seed; lamda_d defaults to descriptor_loss_sparse's 250
+        seed = (int(cfg.get("ssp_seed", 0)) * 1000003 + n_iter) * 64 + parallel.rank()
+        kw = dict(indices=idx, seed=seed, train=train, lambda_loss=lam, lamda_d=float(self.desc_params.get("lamda_d", 250)),
+                  multi_task=bool(m["multi_task_loss"]), gaussian=self.gaussian, dense=dense)
+        opt_step = train and ((n_iter + 1) * B) % self.real_batch_size == 0
+        if opt_step:  # all-reduce (world > 1) overlapped with the tail of the backward pass, then fused Adam
+            sc = parallel.pair_step_overlapped(eng, dev, self.learning_rate, **kw)
             eng.zero_grad()
+        else:
+            sc = eng.pair_step(dev, **kw)
         vals = sc.cpu().tolist()  # the single host sync of the step (the reference syncs on every .item())
         s = dict(zip(L.SCALAR_NAMES, vals))
         eta = eng.eta.cpu().tolist()
@@ -253,10 +282,14 @@ class Train_model_heatmap_all(object):
         """Checkpoint in the reference's wire format {n_iter, model_state_dict, optimizer_state_dict, loss}
         -> <save_path>/superPointNet_<n_iter>_checkpoint.pth.tar (utils/utils.py:134-140)."""
         eng = self.net.engine()
+        path = Path(self.save_path) / ("superPointNet_%d_checkpoint.pth.tar" % self.n_iter)  # file: n_iter; dict: n_iter + 1
+        if parallel.rank() != 0:  # replicas are identical: one writer
+            return path
         os.makedirs(self.save_path, exist_ok=True)
+        # optimizer_state_dict has the layout of torch.optim.Adam(list(net.parameters()) + [eta]).state_dict()
+        # (Train_model_frontend_all.py:183-198), so reference-side tooling can load it; "eta" is an extra key
         state = {"n_iter": self.n_iter + 1, "model_state_dict": {k: v.detach().cpu() for k, v in self.net.state_dict().items()},
-                 "optimizer_state_dict": {"adam_m": eng.adam_m.cpu(), "adam_v": eng.adam_v.cpu(), "step": eng.adam_t},
+                 "optimizer_state_dict": L.optimizer_state_dict(eng, self.learning_rate),
                  "loss": getattr(self, "loss", None), "eta": eng.eta.cpu()}
-        path = Path(self.save_path) / ("superPointNet_%d_checkpoint.pth.tar" % (self.n_iter + 1))
         torch.save(state, path)
         return path

@@ -738,4 +738,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// the same step on g * gscale (data parallel: gscale = 1 / world after the all-reduce SUM), leaving g untouched
+__global__ void adam_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                   float* __restrict__ v, long n, float lr, float bc1, float bc2_sqrt, float gscale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = 0.9f * m[i] + 0.1f * gi;
+  const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
 }  // namespace sspk

@@ -452,6 +452,20 @@ __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ 
 }
 
 // operator-level helper: mean positive / negative distances of batch_descriptor_loss_sparse
+// operator form of the detector loss (ssp_op_detector_loss): accumulator reset / final division
+__global__ void detector_op_prep_kernel(StepAccum* acc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  acc->det_sum[0] = acc->mask_cnt[0] = 0.0;
+  acc->coef_det = 1.f;
+}
+__global__ void fill_affine_identity_kernel(float* p, int c) {  // p[0..c) = 1 (scale), p[c..2c) = 0 (shift)
+  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) p[i] = i < c ? 1.f : 0.f;
+}
+__global__ void detector_op_finish_kernel(const StepAccum* acc, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out[0] = (float)acc->det_sum[0] / ((float)acc->mask_cnt[0] + 1e-5f);
+}
+
 __global__ void sparse_loss_means_kernel(const StepAccum* acc, float* out, int B, int n_match) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float pos = 0.f, neg = 0.f;

@@ -232,7 +232,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 // One block of 1024 threads per image.  match_a/match_b: [B][n_match] cell indices (u + v*Wc).
-__global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __restrict__ Hn, uint64_t seed,
+__global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __restrict__ Hn, uint64_t seed_arg,
+                                                              const uint64_t* __restrict__ seed_dev,
                                                               int32_t* __restrict__ match_a, int32_t* __restrict__ match_b,
                                                               int Hc, int Wc, int n_match, int cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sampler_smem[];  // 12 bytes per key slot
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __res
   __shared__ int nvalid;
   const int img = blockIdx.x, tid = threadIdx.x;
   const int ncell = Hc * Wc;
+  const uint64_t seed = seed_arg + (seed_dev ? *seed_dev : 0);  // captured steps keep the seed in device memory
   if (tid == 0) {
     // H_cell = inv(T) @ H @ T, T = [[2/Wc,0,-1],[0,2/Hc,-1],[0,0,1]]  (utils/homographies.py:270-276)
     const float* h = Hn + img * 9;
@@ -306,9 +308,11 @@ __global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __res
   }
 }
 
-__global__ void sample_nonmatches_kernel(uint64_t seed, int32_t* __restrict__ nm, long total, int Hc, int Wc) {
+__global__ void sample_nonmatches_kernel(uint64_t seed_arg, const uint64_t* __restrict__ seed_dev, int32_t* __restrict__ nm,
+                                         long total, int Hc, int Wc) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  const uint64_t seed = seed_arg + (seed_dev ? *seed_dev : 0);  // captured steps keep the seed in device memory
   const uint64_t r = splitmix64(seed ^ 0x5EED5EEDull ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
   const float u1 = (float)(uint32_t)(r >> 40) * (1.f / 16777216.f);          // 24 bits -> [0,1)
   const float u2 = (float)(uint32_t)((r >> 16) & 0xFFFFFF) * (1.f / 16777216.f);

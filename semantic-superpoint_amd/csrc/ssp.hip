@@ -31,7 +31,8 @@ static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_k
 // ssp_set_conv_algo: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) where eligible (software-pipelined kernel),
 // 2 = Winograd, un-pipelined kernel (conv_wino_kernel; kept for A/B measurements),
 // 3 = Winograd with bf16 matrix-core operands (conv_wino_bf16_kernel: opt-in reduced precision, BASELINE configs[3])
-static int g_conv_algo = 1;
+static int g_default_conv_algo = 1;             // process default: new handles and the handle-less ssp_op_* calls
+static thread_local int g_conv_algo = 1;        // algorithm of the call in flight (AlgoScope: the handle's, else the default)
 // 3x3 convolutions whose input channels fill whole 16-channel K-chunks run as Winograd F(2x2,3x3)
 static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks == 3 && conv_cin % CK == 0; }
 static inline int pk_taps(int ks) { return ks == 3 ? WC : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
@@ -54,6 +55,18 @@ static int fail(int code, const char* fmt, ...) {
     int r_ = (x);          \
     if (r_ != 0) return r_; \
   } while (0)
+
+// hipFuncSetAttribute is per device: one flag per (kernel instantiation, device)
+struct AttrOnce {
+  bool done[64] = {};
+  bool need() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -116,6 +129,11 @@ struct ssp_handle {
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
   float* dense_coef; // [B * cells * cells] d total / d dot of the dense descriptor loss (cfg.dense_loss), else nullptr
   int sout_cs;
+  int conv_algo;     // ssp_handle_set_conv_algo (initialised from the process default of ssp_set_conv_algo)
+  // captured pair steps (ssp_pair_step_graph): one executable graph per (phase, input signature)
+  struct GraphEntry { std::vector<unsigned char> key; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
+  uint64_t* graph_seed;  // device word: sampler seed of the captured steps (set by a one-thread kernel before each replay)
   // profiling
   int prof_family;
   std::vector<hipEvent_t> ev_pool;
@@ -123,6 +141,12 @@ struct ssp_handle {
   double prof_flops, prof_bytes;
   int64_t prof_launches;
   int n_cu;
+};
+
+struct AlgoScope {  // makes the handle's conv algorithm the current one for the duration of an entry point
+  int prev;
+  explicit AlgoScope(const ssp_handle* h) : prev(g_conv_algo) { g_conv_algo = h ? h->conv_algo : g_default_conv_algo; }
+  ~AlgoScope() { g_conv_algo = prev; }
 };
 
 enum { L_PA = 8, L_PB = 9, L_DA = 10, L_DB = 11, L_DS = 12, L_SOUT = 13 };
@@ -269,6 +293,7 @@ static size_t carve(ssp_handle* h, void* base) {
   h->partial_floats = (size_t)1024 * 9 * 4096 * 5;  // 10 Winograd launches of 256 blocks x 16 slabs (755 MB)
   h->partial = c.take<float>(h->partial_floats);
   h->accum = c.take<StepAccum>(1);
+  h->graph_seed = c.take<uint64_t>(1);
   h->dots = c.take<float>((size_t)B * h->cfg.n_match * h->cfg.n_non);
   {
     const size_t pc = (size_t)(H / 8) * (W / 8);
@@ -304,11 +329,10 @@ struct ProfScope {
 template <int KS, int IN_MODE, int SH, int SW>
 static int launch_conv_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   using G = ConvGeom<KS, SH, SW>;
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   auto kern = conv_mfma_kernel<KS, IN_MODE, SH, SW>;
-  if (!attr_set) {
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
@@ -340,11 +364,10 @@ static bool can_fuse_bnr(const ConvCall& c) {
 
 template <int IN_MODE, bool WIDE, bool GB = false>
 static int launch_wino_pipe_t(const ConvArgs& a, int nblocks, hipStream_t st) {
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   auto kern = conv_wino_pipe_kernel<IN_MODE, WIDE, GB>;
-  if (!attr_set) {
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), PIPE_LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
@@ -353,11 +376,10 @@ static int launch_wino_pipe_t(const ConvArgs& a, int nblocks, hipStream_t st) {
 
 template <int IN_MODE, bool WIDE>
 static int launch_wino_bf16_t(const ConvArgs& a, int nblocks, hipStream_t st) {
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   auto kern = conv_wino_bf16_kernel<IN_MODE, WIDE>;
-  if (!attr_set) {
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BF16_LDS_BYTES));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), BF16_LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
@@ -366,11 +388,10 @@ static int launch_wino_bf16_t(const ConvArgs& a, int nblocks, hipStream_t st) {
 
 template <int IN_MODE, bool WIDE>
 static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   auto kern = conv_wino_kernel<IN_MODE, WIDE>;
-  if (!attr_set) {
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
@@ -450,11 +471,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
 template <int KS, int IN_MODE, int SH, int SW>
 static int launch_wgrad_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using G = WgradGeom<KS, SH, SW>;
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   auto kern = wgrad_mfma_kernel<KS, IN_MODE, SH, SW>;
-  if (!attr_set) {
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
@@ -464,11 +484,10 @@ static int launch_wgrad_t(const WgradArgs& a, int nblocks, hipStream_t st) {
 template <int IN_MODE, bool WIDE>
 static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using G = WgradWinoGeom<WIDE>;
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   auto kern = wgrad_wino_kernel<IN_MODE, WIDE>;
-  if (!attr_set) {
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), G::LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
@@ -478,11 +497,10 @@ static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) 
 template <int IN_MODE, bool WIDE>
 static int launch_wgrad_wino_bf16_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using G = WgradWinoGeom<WIDE>;
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   auto kern = wgrad_wino_bf16_kernel<IN_MODE, WIDE>;
-  if (!attr_set) {
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), G::LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
@@ -648,6 +666,8 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   if (h->cfg.n_classes <= 0) h->cfg.n_classes = 133;
   if (h->cfg.n_match <= 0) h->cfg.n_match = 1000;
   if (h->cfg.n_non <= 0) h->cfg.n_non = 100;
+  h->conv_algo = g_default_conv_algo;
+  AlgoScope algo(h);
   build_layers(h);
   h->bound = false;
   h->ws_bytes = carve(h, nullptr);
@@ -664,6 +684,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
 void ssp_destroy(ssp_handle* h) {
   if (!h) return;
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   delete h;
 }
 
@@ -677,6 +698,8 @@ int ssp_bind(ssp_handle* h, const ssp_buffers* b, void* stream) {
   if (!b->params_dev || !b->bn_running_dev || !b->workspace_dev) return fail(-1, "params, bn_running and workspace are required");
   if (b->workspace_bytes < h->ws_bytes) return fail(-1, "workspace too small: %zu < %zu", b->workspace_bytes, h->ws_bytes);
   h->buf = *b;
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);  // captured pointers are stale after a re-bind
+  h->graphs.clear();
   carve(h, b->workspace_dev);
   // padding channels (65->80, n_classes->sout_cs) must read as zero forever: clear everything once
   HIPCHK(hipMemsetAsync(b->workspace_dev, 0, h->ws_bytes, (hipStream_t)stream));
@@ -992,18 +1015,33 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
 // dsemi[k]: [cells][80] grad wrt semi (post bnPb); draw_desc[k]: [cells][256] grad wrt bnDb output (pre-normalisation);
 // dsout[k]: [cells][sout_cs] grad wrt convSout output (ssmall).  A null entry means "no gradient from that head" and
 // must be null for every view of the set.
+// part: 0 = everything; 1 = heads + encoder layers 7..EARLY_SPLIT_LAYER, then the pending weight-gradient slabs are
+// reduced, so every gradient from layer EARLY_SPLIT_LAYER's conv weight to the end of the flat vector is FINAL (the
+// early all-reduce bucket, ssp_grad_early_offset); 2 = the remaining layers EARLY_SPLIT_LAYER-1..0 (their dOut sits in gP).
+enum { EARLY_SPLIT_LAYER = 2 };
 static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
-                        float* const* dsout, hipStream_t st) {
+                        float* const* dsout, hipStream_t st, int part = 0) {
   Slot& S0 = *SS.s[0];
   const int N = S0.N, H = S0.H, W = S0.W, Hc = H / 8, Wc = W / 8;
   const int hcs = 256 * h->nheads;
   const bool has_semi = dsemi[0] != nullptr, has_desc = draw_desc[0] != nullptr;
   const bool has_sem = dsout[0] != nullptr && h->nheads == 3;
   float *gP[2] = {nullptr, nullptr}, *gQ[2] = {nullptr, nullptr};
+  for (int k = 0; k < SS.n; ++k) { gP[k] = SS.s[k]->gP; gQ[k] = SS.s[k]->gQ; }
+  auto encoder = [&](int l_hi, int l_lo) -> int {  // dOut (gP) -> dY (gQ) -> weight gradient + data gradient (gP)
+    for (int l = l_hi; l >= l_lo; --l) {
+      int lh, lw; layer_res(l, H, W, lh, lw);
+      const bool pool_after = (l == 1 || l == 3 || l == 5);
+      const int C = h->L[l].cout;
+      CHK(bn_layer_backward(h, SS, l, gP, C, 0, true, pool_after, gQ, C, 0, N, lh, lw, st));
+      if (l > 0) CHK(conv_layer_backward(h, SS, l, l - 1, gQ, C, 0, gP, h->L[l].cin, 0, N, lh, lw, layer_in_mode(l), st));
+    }
+    return flush_wgrad_reduce(h, st);  // the pending Winograd weight-gradient slabs -> OIHW gradients, one launch
+  };
+  if (part == 2) return encoder(EARLY_SPLIT_LAYER - 1, 0);
   for (int l = 0; l < 16; ++l) h->bsums_fused[l] = false;
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
-    gP[k] = S.gP; gQ[k] = S.gQ;
     // the forward's single memset of the statistics region also cleared the backward sums; clear them again only
     // when this slot is back-propagated a second time (autograd retain_graph)
     if (S.bsums_dirty) {
@@ -1060,15 +1098,9 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     setup_bnr(h, SS, 7, false, c);
     CHK(launch_conv(h, c, st, SSP_PROF_CONV3X3_DGRAD));
   }
-  // ---- encoder: dOut (gP) -> dY (gQ) -> weight gradient + data gradient (gP) ----
-  for (int l = 7; l >= 0; --l) {
-    int lh, lw; layer_res(l, H, W, lh, lw);
-    const bool pool_after = (l == 1 || l == 3 || l == 5);
-    const int C = h->L[l].cout;
-    CHK(bn_layer_backward(h, SS, l, gP, C, 0, true, pool_after, gQ, C, 0, N, lh, lw, st));
-    if (l > 0) CHK(conv_layer_backward(h, SS, l, l - 1, gQ, C, 0, gP, h->L[l].cin, 0, N, lh, lw, layer_in_mode(l), st));
-  }
-  return flush_wgrad_reduce(h, st);  // all Winograd weight-gradient slabs -> OIHW gradients, one launch
+  // ---- encoder ----
+  if (part == 1) return encoder(7, EARLY_SPLIT_LAYER);
+  return encoder(7, 0);
 }
 
 extern "C" {
@@ -1077,6 +1109,7 @@ int ssp_forward(ssp_handle* h, int slot, const float* x_dev, int n, int height, 
                 float* desc_dev, float* sem_dev, void* stream) {
   if (!h || !h->bound) return fail(-1, "handle not bound");
   if (slot < 0 || slot > 1) return fail(-1, "slot must be 0 or 1");
+  AlgoScope algo(h);
   if (n < 1 || n > h->cfg.max_batch || height > h->cfg.height || width > h->cfg.width || height % 8 || width % 8)
     return fail(-1, "forward shape [%d,1,%d,%d] exceeds the configured maximum or is not a multiple of 8", n, height, width);
   if ((size_t)height * width != (size_t)h->cfg.height * h->cfg.width && (size_t)n * height * width > (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width)
@@ -1113,6 +1146,7 @@ int ssp_backward(ssp_handle* h, int slot, const float* dsemi_dev, const float* d
                  void* stream) {
   if (!h || !h->bound || !h->buf.grads_dev) return fail(-1, "handle not bound with a gradient buffer");
   if (slot < 0 || slot > 1) return fail(-1, "slot must be 0 or 1");
+  AlgoScope algo(h);
   hipStream_t st = (hipStream_t)stream;
   Slot& S = h->slot[slot];
   const int N = S.N, Hc = S.H / 8, Wc = S.W / 8, HW = Hc * Wc, ncells = N * HW;
@@ -1157,9 +1191,23 @@ int ssp_adam_step(ssp_handle* h, float lr, int step, void* stream) {
   return 0;
 }
 
-int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, void* stream) {
+}  // extern "C"
+
+// phase 0: the whole step; 1: everything up to the point where the early gradient bucket is final; 2: the rest of the
+// backward pass (encoder layers below EARLY_SPLIT_LAYER)
+static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, int phase, hipStream_t st_in) {
+  void* stream = st_in;
   if (!h || !h->bound) return fail(-1, "handle not bound");
   if (!in || !scalars_dev) return fail(-1, "null argument");
+  if (phase < 0 || phase > 2) return fail(-1, "pair-step phase must be 0, 1 or 2");
+  AlgoScope algo(h);
+  if (phase == 2) {
+    if (!in->train) return 0;
+    SlotSet SS2{2, {&h->slot[0], &h->slot[1]}};
+    const float* none[2] = {nullptr, nullptr};
+    float* nonef[2] = {nullptr, nullptr};
+    return run_backward(h, SS2, none, none, nonef, (hipStream_t)stream, 2);
+  }
   if (in->train && !h->buf.grads_dev) return fail(-1, "train step needs a gradient buffer");
   const int B = in->batch, H = h->cfg.height, W = h->cfg.width, Hc = H / 8, Wc = W / 8;
   if (B < 1 || B > h->cfg.max_batch || B > 64)
@@ -1265,33 +1313,126 @@ int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, 
     const float* dss[2] = {h->slot[0].dsemi, h->slot[1].dsemi};
     const float* dds[2] = {use_desc ? h->slot[0].ddesc : nullptr, use_desc ? h->slot[1].ddesc : nullptr};
     float* dsos[2] = {semantic ? h->slot[0].dsout : nullptr, semantic ? h->slot[1].dsout : nullptr};
-    CHK(run_backward(h, SS, dss, dds, dsos, st));
+    CHK(run_backward(h, SS, dss, dds, dsos, st, phase));
   }
   return 0;
 }
 
-int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
-                       int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream) {
+static int sample_indices_impl(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, const uint64_t* seed_dev,
+                               int32_t* match_a_dev, int32_t* match_b_dev, int32_t* nonmatch_b_dev, hipStream_t st) {
   if (!h) return fail(-1, "null handle");
   if (batch < 1 || batch > 64) return fail(-1, "batch out of range");
   const int Hc = h->cfg.height / 8, Wc = h->cfg.width / 8;
   if (Hc * Wc > SAMPLER_MAX_CELLS) return fail(-1, "sampler supports at most %d cells", SAMPLER_MAX_CELLS);
   if (h->cfg.n_match > SAMPLER_MAX_CELLS) return fail(-1, "n_match too large for the device sampler");
-  hipStream_t st = (hipStream_t)stream;
   int cap = 2048;  // power of two >= cells and >= n_match (2048 for every reference configuration)
   while (cap < Hc * Wc || cap < h->cfg.n_match) cap <<= 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_matches_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                SAMPLER_MAX_CELLS * 12));
-    attr_set = true;
   }
-  hipLaunchKernelGGL(sample_matches_kernel, dim3(batch), dim3(1024), (size_t)cap * 12, st, homographies_dev, seed, match_a_dev,
-                     match_b_dev, Hc, Wc, h->cfg.n_match, cap);
+  hipLaunchKernelGGL(sample_matches_kernel, dim3(batch), dim3(1024), (size_t)cap * 12, st, homographies_dev, seed, seed_dev,
+                     match_a_dev, match_b_dev, Hc, Wc, h->cfg.n_match, cap);
   const long tot = (long)batch * h->cfg.n_match * h->cfg.n_non;
-  hipLaunchKernelGGL(sample_nonmatches_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, seed, nonmatch_b_dev, tot, Hc, Wc);
+  hipLaunchKernelGGL(sample_nonmatches_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, seed, seed_dev, nonmatch_b_dev, tot, Hc,
+                     Wc);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+__global__ void set_seed_kernel(uint64_t* dst, uint64_t v) { *dst = v; }
+
+extern "C" {
+
+int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, void* stream) {
+  if (!h || !h->bound || !h->buf.grads_dev || !h->buf.adam_m_dev || !h->buf.adam_v_dev)
+    return fail(-1, "handle not bound with gradient and Adam state buffers");
+  if (step < 1) return fail(-1, "Adam step index starts at 1");
+  const long n = (long)h->n_params + 3;
+  const float bc1 = 1.f - powf(0.9f, (float)step);
+  const float bc2 = 1.f - powf(0.999f, (float)step);
+  hipLaunchKernelGGL(adam_scaled_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, h->buf.params_dev,
+                     h->buf.grads_dev, h->buf.adam_m_dev, h->buf.adam_v_dev, n, lr, bc1, sqrtf(bc2), grad_scale);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
+  if (!h) return fail(-1, "null handle");
+  if (algo < 0 || algo > 5 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3 or 5 (see ssp_set_conv_algo)");
+  h->conv_algo = algo;
+  return 0;
+}
+
+int ssp_pair_step(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, void* stream) {
+  return pair_step_impl(h, in, scalars_dev, 0, (hipStream_t)stream);
+}
+
+int ssp_pair_step_phase(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, int phase, void* stream) {
+  return pair_step_impl(h, in, scalars_dev, phase, (hipStream_t)stream);
+}
+
+size_t ssp_grad_early_offset(const ssp_handle* h) { return h ? h->L[EARLY_SPLIT_LAYER].w_off : 0; }
+
+// Captured form of ssp_pair_step_phase (north star: "one graph per image pair"): the first call with a given input
+// signature records the launches of [device index sampling (sample_indices != 0) +] the pair step into a hipGraph; later
+// calls replay it.  The sampler seed lives in device memory so that it can change between replays.
+int ssp_pair_step_graph(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, int phase, int sample_indices,
+                        void* stream) {
+  if (!h || !h->bound) return fail(-1, "handle not bound");
+  if (!in || !scalars_dev) return fail(-1, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (st == nullptr) return fail(-1, "ssp_pair_step_graph needs a non-default stream (stream capture)");
+  // key = everything a captured launch depends on except the seed (kept in device memory)
+  std::vector<unsigned char> key(sizeof(ssp_pair_inputs) + sizeof(void*) + 3 * sizeof(int));
+  {
+    ssp_pair_inputs k;
+    memcpy(&k, in, sizeof(k));  // bytewise (padding included: the caller's struct is the key)
+    k.seed = 0;
+    memcpy(key.data(), &k, sizeof(k));
+    memcpy(key.data() + sizeof(k), &scalars_dev, sizeof(void*));
+    const int extra[3] = {phase, sample_indices, h->conv_algo};
+    memcpy(key.data() + sizeof(k) + sizeof(void*), extra, sizeof(extra));
+  }
+  hipGraphExec_t exec = nullptr;
+  for (auto& g : h->graphs)
+    if (g.key == key) { exec = g.exec; break; }
+  if (exec == nullptr) {
+    if (h->prof_family != 0) return fail(-1, "ssp_pair_step_graph: disable ssp_profile_enable before capturing");
+    if (h->graphs.size() >= 16) {  // inputs that change every step defeat the cache: drop the oldest entry
+      (void)hipGraphExecDestroy(h->graphs.front().exec);
+      h->graphs.erase(h->graphs.begin());
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    if (sample_indices && phase != 2) {
+      if (!in->match_a_dev || !in->match_b_dev || !in->nonmatch_b_dev) rc = fail(-1, "graph step: index buffers required");
+      else rc = sample_indices_impl(h, in->homographies_dev, in->batch, 0, h->graph_seed, const_cast<int32_t*>(in->match_a_dev),
+                                    const_cast<int32_t*>(in->match_b_dev), const_cast<int32_t*>(in->nonmatch_b_dev), st);
+    }
+    if (rc == 0) rc = pair_step_impl(h, in, scalars_dev, phase, st);
+    const hipError_t ce = hipStreamEndCapture(st, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return fail(-2, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) return fail(-2, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    h->graphs.push_back({key, exec});
+  }
+  if (sample_indices && phase != 2) {
+    hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, st, h->graph_seed, in->seed);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipGraphLaunch(exec, st));
+  return 0;
+}
+
+int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
+                       int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream) {
+  return sample_indices_impl(h, homographies_dev, batch, seed, nullptr, match_a_dev, match_b_dev, nonmatch_b_dev,
+                             (hipStream_t)stream);
 }
 
 // ---- operator-level entry points ------------------------------------------------------------------
@@ -1299,6 +1440,7 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
                 int cin, int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
                 double* stats_dev, int transpose_flip, void* workspace_dev, size_t workspace_bytes, void* stream) {
   // with transpose_flip the weight tensor is [cin_conv... see header]: w is OIHW with O = (tf ? cin : cout)
+  AlgoScope algo(nullptr);
   const bool wino = wino_ok(ksize, cin) && in_mode != 2;
   const int nchunks = cdiv(cin, CK), ncob = cdiv(cout, NB);
   const size_t need = (size_t)ncob * nchunks * pk_taps(ksize) * CK * NB * sizeof(float);
@@ -1317,6 +1459,7 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
 int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw_dev, int n, int hh, int w, int cin,
                       int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream) {
+  AlgoScope algo(nullptr);
   WgradCall c;
   c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.dout = dout_dev; c.dout_cs = cout; c.dout_co = 0; c.cout = cout;
   c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.dw = dw_oihw_dev; c.N = n; c.H = hh; c.W = w; c.ks = ksize;
@@ -1504,6 +1647,7 @@ int ssp_export_points(ssp_handle* h, const ssp_export_params* p, int n_images, c
   if (!h || !h->bound) return fail(-1, "handle not bound");
   CHK(export_check(p));
   if (n_images < 1 || n_images > 2) return fail(-1, "export: 1 or 2 images per call");
+  AlgoScope algo(h);
   if (p->n_views > h->cfg.max_batch || (size_t)p->n_views * p->height * p->width >
                                            (size_t)h->cfg.max_batch * h->cfg.height * h->cfg.width)
     return fail(-1, "export: %d views of %dx%d exceed the configured engine size", p->n_views, p->height, p->width);
@@ -1598,7 +1742,7 @@ int ssp_set_conv_algo(int algo) {
   if (algo < 0 || algo > 5 || algo == 4)
     return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
                     "operands) or 5 (Winograd, pipelined, weights staged through LDS)");
-  g_conv_algo = algo;
+  g_default_conv_algo = algo;
   return 0;
 }
 
@@ -1672,6 +1816,27 @@ int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_de
   hipLaunchKernelGGL(sparse_loss_means_kernel, dim3(1), dim3(1), 0, st, acc, out2_dev, b, n_match);
   HIPCHK(hipGetLastError());
   HIPCHK(hipFreeAsync(acc, st));
+  return 0;
+}
+
+int ssp_op_detector_loss(const float* semi_nhwc_dev, int cs, const float* labels2d_dev, const float* mask2d_dev, int b, int hh,
+                         int w, void* scratch_dev, size_t scratch_bytes, float* loss_dev, float* dsemi_nhwc_dev, void* stream) {
+  if (hh % 8 || w % 8 || cs < 65) return fail(-1, "detector_loss: H, W multiples of 8 and channel stride >= 65 required");
+  const int ncells = b * (hh / 8) * (w / 8);
+  const size_t need = align_up(sizeof(StepAccum), 256) + (size_t)(ncells + 65 * 2) * sizeof(float);
+  if (scratch_bytes < need) return fail(-4, "ssp_op_detector_loss scratch too small (%zu < %zu)", scratch_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  StepAccum* acc = reinterpret_cast<StepAccum*>(scratch_dev);
+  float* cellmask = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch_dev) + align_up(sizeof(StepAccum), 256));
+  float* ones = cellmask + ncells;  // identity BatchNorm affine: scale 1 | shift 0
+  hipLaunchKernelGGL(detector_op_prep_kernel, dim3(1), dim3(64), 0, st, acc);
+  hipLaunchKernelGGL(fill_affine_identity_kernel, dim3(1), dim3(128), 0, st, ones, 65);
+  hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, st, mask2d_dev, cellmask,
+                     &acc->mask_cnt[0], b, hh, w);
+  hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024)), dim3(256), 0, st, semi_nhwc_dev, ones,
+                     ones + 65, labels2d_dev, cellmask, dsemi_nhwc_dev, acc, 0, b, hh, w, cs);
+  hipLaunchKernelGGL(detector_op_finish_kernel, dim3(1), dim3(64), 0, st, acc, loss_dev);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -38,5 +38,18 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_locked():
+    """build() when stale, with an exclusive file lock so that the ranks of one node do not compile concurrently."""
+    if not _stale():
+        return LIB
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return build()  # re-checks _stale() under the lock
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -18,6 +18,7 @@ SCALAR_NAMES = ["loss", "loss_det", "loss_det_warp", "loss_desc", "loss_sem", "l
                 "negative_dist", "eta_det", "eta_desc", "eta_sem"]
 N_SCALARS = 16
 NREP = 32  # SSP_NREP
+SAMPLER_MAX_MATCHES = 8192  # SAMPLER_MAX_CELLS of csrc/sem_kernels.hip.h (bitonic sort capacity of the device sampler)
 PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4, "conv3x3_all": 5}
 
 
@@ -64,17 +65,23 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_set_conv_algo", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
            "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
            "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms", "ssp_op_dense_loss",
-           "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize"]
+           "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
+           "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
+           "ssp_op_detector_loss"]
 
 
 def load_library(path=None):
-    """dlopen csrc/libssp_hip.so (building it first when stale). Raises if it is missing."""
+    """dlopen csrc/libssp_hip.so.  Without an explicit path (argument or SSP_HIP_LIB) the in-tree library is rebuilt
+    first when it is missing or older than its sources (hipbuild.build_locked(): serialised across ranks by a file
+    lock).  Raises if the library cannot be produced: there is no fallback."""
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or os.environ.get("SSP_HIP_LIB") or _build.LIB  # SSP_HIP_LIB: A/B builds of the kernels (tools/)
+    path = path or os.environ.get("SSP_HIP_LIB")  # SSP_HIP_LIB: A/B builds of the kernels (tools/)
+    if path is None:
+        path = _build.build_locked()
     if not os.path.exists(path):
-        path = _build.build()
+        raise RuntimeError("libssp_hip.so not found at %s" % path)
     lib = C.CDLL(path)
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     lib.ssp_last_error.restype = C.c_char_p
@@ -91,6 +98,13 @@ def load_library(path=None):
     lib.ssp_zero_grad.argtypes = [vp, vp]
     lib.ssp_pair_step.argtypes = [vp, C.POINTER(SspPairInputs), vp, vp]
     lib.ssp_adam_step.argtypes = [vp, f, i, vp]
+    lib.ssp_adam_step_scaled.argtypes = [vp, f, i, f, vp]
+    lib.ssp_pair_step_phase.argtypes = [vp, C.POINTER(SspPairInputs), vp, i, vp]
+    lib.ssp_pair_step_graph.argtypes = [vp, C.POINTER(SspPairInputs), vp, i, i, vp]
+    lib.ssp_grad_early_offset.argtypes = [vp]
+    lib.ssp_grad_early_offset.restype = C.c_size_t
+    lib.ssp_handle_set_conv_algo.argtypes = [vp, i]
+    lib.ssp_op_detector_loss.argtypes = [vp, i, vp, vp, i, i, i, vp, C.c_size_t, vp, vp, vp]
     lib.ssp_sample_indices.argtypes = [vp, vp, i, C.c_uint64, vp, vp, vp, vp]
     lib.ssp_profile_enable.argtypes = [vp, i]
     lib.ssp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -127,7 +141,8 @@ def load_library(path=None):
 
 
 def set_conv_algo(algo):
-    """0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) for the eligible 3x3 convolutions (default)."""
+    """Process-wide default (new Engines, handle-less operators): 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3)
+    for the eligible 3x3 convolutions (default).  `Engine.set_conv_algo` changes one engine."""
     _check(load_library().ssp_set_conv_algo(int(algo)))
 
 
@@ -323,10 +338,23 @@ class Engine:
         with torch.cuda.device(self.device):
             _check(self.lib.ssp_zero_grad(self.h, _stream()))
 
-    def adam_step(self, lr):
+    def adam_step(self, lr, grad_scale=None):
+        """Fused Adam over the flat vector; grad_scale (e.g. 1 / world_size after an all-reduce SUM) scales the
+        gradient inside the kernel without touching `grads`."""
         self.adam_t += 1
         with torch.cuda.device(self.device):
-            _check(self.lib.ssp_adam_step(self.h, float(lr), self.adam_t, _stream()))
+            if grad_scale is None:
+                _check(self.lib.ssp_adam_step(self.h, float(lr), self.adam_t, _stream()))
+            else:
+                _check(self.lib.ssp_adam_step_scaled(self.h, float(lr), self.adam_t, float(grad_scale), _stream()))
+
+    def set_conv_algo(self, algo):
+        _check(self.lib.ssp_handle_set_conv_algo(self.h, int(algo)))
+
+    @property
+    def early_offset(self):
+        """First element of the gradient bucket that is final after phase 1 of a split pair step."""
+        return int(self.lib.ssp_grad_early_offset(self.h))
 
     def sample_indices(self, homographies, seed):
         _need_gpu(homographies, "homographies")
@@ -341,39 +369,86 @@ class Engine:
         return ma, mb, nm
 
     def pair_step(self, sample, indices=None, seed=0, train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True,
-                  gaussian=True, dense=None):
+                  gaussian=True, dense=None, phase=0, graph=False):
         """`sample`: dict of device tensors with the reference's keys (Train_model_heatmap_all.py:212-251).
         indices: (match_a, match_b, nonmatch_b) int32 device tensors or None (device sampler with `seed`).
         dense: None (sparse descriptor loss) or the model.dense_loss.params dict (dense descriptor loss,
         utils/utils.py:779-893; keys lamda_d (default 250: the shipped `lambda_d` spelling is ignored by the reference
         too) and descriptor_dist (4)); needs an Engine created with dense_loss=True.
+        phase: 0 whole step; 1 / 2 = the two halves of ssp_pair_step_phase (data-parallel overlap; call 2 with the
+        same arguments).  graph=True replays the step as a hipGraph (ssp_pair_step_graph; needs a non-default
+        current stream; the device sampler then fills persistent index buffers inside the graph).
         Returns the device tensor of SSP_N_SCALARS floats (no host sync)."""
         img = sample["image"]
-        B = img.shape[0]
+        B, c1, H, W = img.shape
         lab = sample["labels_2D_gaussian"] if gaussian else sample["labels_2D"]
         labw = sample["warped_labels_gaussian"] if gaussian else sample["warped_labels"]
         req = [img, sample["warped_img"], lab, labw, sample["valid_mask"], sample["warped_valid_mask"]]
         for t in req:
             _need_gpu(t, "sample tensor")
+            if t.dtype != torch.float32 or tuple(t.shape) != (B, 1, H, W):
+                raise ValueError("pair-step image / label / mask tensors must be float32 [B,1,H,W] = %s, got %s %s"
+                                 % ((B, 1, H, W), t.dtype, tuple(t.shape)))
+        if (H, W) != (self.height, self.width) or B > self.max_batch:
+            raise ValueError("pair step [%d,1,%d,%d] does not match the engine (%d x %dx%d)"
+                             % (B, H, W, self.max_batch, self.height, self.width))
         Hm = sample["homographies"].to(torch.float32)
         if not Hm.is_contiguous():
             Hm = Hm.contiguous()
         _need_gpu(Hm, "homographies")
+        if tuple(Hm.shape) != (B, 3, 3):
+            raise ValueError("homographies must be [B,3,3]")
         if dense is not None and not self.dense_loss:
             raise RuntimeError("create the Engine with dense_loss=True to use the dense descriptor loss")
+        sample_in_graph = False
         if lambda_loss > 0 and indices is None and dense is None:
-            indices = self.sample_indices(Hm, seed)
-        ma, mb, nm = indices if indices is not None else (None, None, None)
-        sem = sample.get("semantic") if self.arch.endswith("ssmall") else None
-        semw = sample.get("warped_sem") if self.arch.endswith("ssmall") else None
+            if graph:  # persistent buffers: the captured sampler writes them
+                if getattr(self, "_graph_idx", None) is None or self._graph_idx[0].shape[0] != B:
+                    i32 = dict(dtype=torch.int32, device=self.device)
+                    self._graph_idx = (torch.zeros(B, self.n_match, **i32), torch.zeros(B, self.n_match, **i32),
+                                       torch.zeros(B, self.n_match * self.n_non, **i32))
+                indices = self._graph_idx
+                sample_in_graph = True
+            elif phase != 2:
+                indices = self._last_idx = self.sample_indices(Hm, seed)
+            else:
+                indices = self._last_idx
+        if indices is not None:
+            ma, mb, nm = indices
+            for t, shp in ((ma, (B, self.n_match)), (mb, (B, self.n_match)), (nm, (B, self.n_match * self.n_non))):
+                _need_gpu(t, "sparse-loss indices")
+                if t.dtype != torch.int32 or tuple(t.shape) != shp:
+                    raise ValueError("sparse-loss indices must be int32 %s, got %s %s" % (shp, t.dtype, tuple(t.shape)))
+        else:
+            ma = mb = nm = None
+        sem = semw = None
+        if self.arch.endswith("ssmall"):
+            sem, semw = sample.get("semantic"), sample.get("warped_sem")
+            for t in (sem, semw):
+                if t is None:
+                    raise KeyError("the ssmall model needs sample['semantic'] and sample['warped_sem']")
+                _need_gpu(t, "semantic labels")
+                if t.dtype != torch.int64 or tuple(t.shape) != (B, H, W):
+                    raise ValueError("semantic labels must be int64 [B,H,W] = %s, got %s %s"
+                                     % ((B, H, W), t.dtype, tuple(t.shape)))
+            if getattr(self, "check_label_range", False):  # one host sync: off by default (torch raises here too)
+                for t in (sem, semw):
+                    if int(t.min()) < 0 or int(t.max()) > self.n_classes:
+                        raise ValueError("semantic label outside [0, %d]" % self.n_classes)
         inp = SspPairInputs(B, _ptr(img), _ptr(sample["warped_img"]), _ptr(lab), _ptr(labw), _ptr(sample["valid_mask"]),
                             _ptr(sample["warped_valid_mask"]), _ptr(Hm), _ptr(sem), _ptr(semw), _ptr(ma), _ptr(mb),
-                            _ptr(nm), int(seed), float(lambda_loss), float(lamda_d), int(bool(multi_task)),
-                            int(bool(train)), int(dense is not None),
+                            _ptr(nm), int(seed) & 0xFFFFFFFFFFFFFFFF, float(lambda_loss), float(lamda_d),
+                            int(bool(multi_task)), int(bool(train)), int(dense is not None),
                             float((dense or {}).get("lamda_d", 250.0)), float((dense or {}).get("descriptor_dist", 4.0)))
         self._keep = (req, Hm, indices, sem, semw)  # keep alive until the stream has consumed them
         with torch.cuda.device(self.device):
-            _check(self.lib.ssp_pair_step(self.h, C.byref(inp), _ptr(self.scalars), _stream()))
+            if graph:
+                _check(self.lib.ssp_pair_step_graph(self.h, C.byref(inp), _ptr(self.scalars), int(phase),
+                                                    int(sample_in_graph), _stream()))
+            elif phase == 0:
+                _check(self.lib.ssp_pair_step(self.h, C.byref(inp), _ptr(self.scalars), _stream()))
+            else:
+                _check(self.lib.ssp_pair_step_phase(self.h, C.byref(inp), _ptr(self.scalars), int(phase), _stream()))
         return self.scalars
 
     def export_points(self, views, masks, unwarp_h, conf_thresh=0.015, nms_dist=4, top_k=600, subpixel=True,
@@ -434,6 +509,50 @@ class Engine:
         return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
 
 
+# ---- optimizer state in torch.optim.Adam's wire format ----
+def optimizer_state_dict(eng, lr):
+    """state_dict() of the reference's optimizer, torch.optim.Adam(list(net.parameters()) + [eta], lr, betas=(0.9, 0.999))
+    (Train_model_frontend_all.py:183-198), filled from the engine's flat m / v vectors."""
+    state, idx = {}, 0
+    step = torch.tensor(float(eng.adam_t))
+    entries = [(shape, off) for _, shape, off in eng.layout] + [((3,), eng.n_params)]
+    for shape, off in entries:
+        n = int(np.prod(shape))
+        if eng.adam_t > 0:
+            state[idx] = {"step": step.clone(), "exp_avg": eng.adam_m[off:off + n].view(shape).detach().cpu().clone(),
+                          "exp_avg_sq": eng.adam_v[off:off + n].view(shape).detach().cpu().clone()}
+        idx += 1
+    group = {"lr": float(lr), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False,
+             "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+             "params": list(range(idx))}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_optimizer_state(eng, osd, eta=None):
+    """Inverse of optimizer_state_dict (also accepts round 1's {"adam_m", "adam_v", "step"} form); eta: 3 floats."""
+    if osd is not None and "state" in osd:
+        entries = [(shape, off) for _, shape, off in eng.layout] + [((3,), eng.n_params)]
+        steps = []
+        for idx, (shape, off) in enumerate(entries):
+            st = osd["state"].get(idx)
+            if st is None:
+                continue
+            n = int(np.prod(shape))
+            eng.adam_m[off:off + n] = torch.as_tensor(st["exp_avg"]).reshape(-1).to(eng.device, torch.float32)
+            eng.adam_v[off:off + n] = torch.as_tensor(st["exp_avg_sq"]).reshape(-1).to(eng.device, torch.float32)
+            steps.append(int(float(st["step"])))
+        if steps:
+            if len(set(steps)) != 1:
+                raise ValueError("per-parameter Adam steps differ: the fused kernel keeps one step count")
+            eng.adam_t = steps[0]
+    elif osd is not None and "adam_m" in osd:
+        eng.adam_m.copy_(torch.as_tensor(osd["adam_m"]).to(eng.device))
+        eng.adam_v.copy_(torch.as_tensor(osd["adam_v"]).to(eng.device))
+        eng.adam_t = int(osd.get("step", 0))
+    if eta is not None:
+        eng.params[eng.n_params:] = torch.as_tensor(eta).reshape(3).to(eng.device, torch.float32)
+
+
 # ---- operator-level wrappers (tests) ----
 def op_conv(x_nhwc, w_oihw, bias, ksize, in_mode=0, in_scale=None, in_shift=None, stats=None, transpose_flip=False,
             out_hw=None):
@@ -476,6 +595,24 @@ def op_labels(labels2d=None, mask2d=None):
     with torch.cuda.device(ref.device):
         _check(lib.ssp_op_labels(_ptr(labels2d), _ptr(mask2d), _ptr(tgt), _ptr(cm), B, H, W, _stream()))
     return tgt, cm
+
+
+def op_detector_loss(semi_nchw, labels2d, mask2d, grad=True):
+    """detector_loss (softmax + BCE) of public NCHW logits [B,65,Hc,Wc]; returns (loss, d loss / d semi NCHW or None)."""
+    lib = load_library()
+    _need_gpu(semi_nchw, "semi")
+    B, c, Hc, Wc = semi_nchw.shape
+    assert c == 65
+    dev = semi_nchw.device
+    x = torch.zeros(B, Hc, Wc, 80, dtype=torch.float32, device=dev)
+    x[..., :65] = semi_nchw.permute(0, 2, 3, 1)
+    d = torch.empty_like(x) if grad else None
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    scratch = torch.empty(65536 + 4 * (B * Hc * Wc + 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.ssp_op_detector_loss(_ptr(x), 80, _ptr(labels2d.contiguous()), _ptr(mask2d.contiguous()), B, Hc * 8, Wc * 8,
+                                        _ptr(scratch), scratch.numel(), _ptr(out), _ptr(d), _stream()))
+    return float(out.item()), (d[..., :65].permute(0, 3, 1, 2).contiguous() if grad else None)
 
 
 def op_sparse_loss(desc_a_nchw, desc_b_nchw, match_a, match_b, nonmatch_b):

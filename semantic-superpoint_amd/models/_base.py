@@ -83,9 +83,22 @@ class SspNetBase(nn.Module):
             return e
         assert n is not None, "engine not created yet: run a forward first"
         sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
+        # Shape-independent training state of the old engine survives the re-creation (a larger validation batch or a
+        # differently sized image must not reset Adam, MultiTaskLoss.eta or pending micro-batch gradients mid-training)
+        old = self._engine
+        carry = None
+        if old is not None and old.grads is not None and torch.device(device) == old.device:
+            carry = (old.eta.clone(), old.adam_m.clone(), old.adam_v.clone(), old.adam_t, old.grads.clone())
+        if old is not None:
+            n = max(n, old.max_batch)  # never shrink: the next training batch would re-create it again
         self._release_engine()
+        del old
         e = L.Engine(self.ARCH, n, h, w, device, n_classes=self.n_classes, **getattr(self, "_engine_kwargs", {}))
         e.load_state_dict(sd)
+        if carry is not None:
+            e.params[e.n_params:] = carry[0]
+            e.adam_m.copy_(carry[1]); e.adam_v.copy_(carry[2]); e.adam_t = carry[3]
+            e.grads.copy_(carry[4])
         own = dict(self.named_parameters())
         bufs = dict(self.named_buffers())
         self._flat_params, self._flat_offsets = [], []

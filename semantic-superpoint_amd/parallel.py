@@ -21,6 +21,10 @@ def init_from_env(backend=None, device=None):
     return rank, world
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -48,3 +52,33 @@ def shard_batch(n_items, rank=None, world=None):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pair_step_overlapped(eng, sample, lr, optimizer_step=True, **step_kwargs):
+    """One data-parallel pair step with the gradient all-reduce overlapped with the tail of the backward pass
+    (SURVEY.md section 8e).  The flat gradient vector is split at `eng.early_offset`:
+
+      phase 1 of the step (forward, losses, backward of the heads and encoder layers 7..2)
+      all-reduce(SUM) of grads[early_offset:]  -- 97.7 % of the bytes; asynchronous: RCCL runs it on its own stream,
+                                                  ordered after phase 1 by an event, while ...
+      phase 2 (backward of the two 240x320 layers, ~40 % of the backward time) runs on the compute stream
+      all-reduce(SUM) of grads[:early_offset]  -- 151 KB
+      fused Adam on grads / world
+
+    With world size 1 (or optimizer_step=False: a gradient-accumulation micro-batch) no collective is issued.
+    Returns the device scalars of the step (no host synchronisation)."""
+    w = world_size()
+    if w == 1 or not optimizer_step:
+        sc = eng.pair_step(sample, **step_kwargs)
+        if optimizer_step:
+            eng.adam_step(lr)
+        return sc
+    off = eng.early_offset
+    sc = eng.pair_step(sample, phase=1, **step_kwargs)
+    w1 = dist.all_reduce(eng.grads[off:], op=dist.ReduceOp.SUM, async_op=True)
+    eng.pair_step(sample, phase=2, **step_kwargs)
+    w2 = dist.all_reduce(eng.grads[:off], op=dist.ReduceOp.SUM, async_op=True)
+    w1.wait()
+    w2.wait()
+    eng.adam_step(lr, grad_scale=1.0 / w)
+    return sc

@@ -126,3 +126,51 @@ def test_data_parallel_helpers_gloo_world2():
     assert res[0][1] == res[1][1] == 1.5          # mean of (1, 2)
     assert res[0][2] == res[1][2] == 0.0          # broadcast from rank 0
     assert res[0][3] == (0, 4) and res[1][3] == (4, 7)
+
+
+def test_bench_gpus_flag_is_checked_and_spawns_ranks():
+    """bench.py: --gpus must match the launcher's WORLD_SIZE; bare `--gpus 2` spawns 2 ranks itself (here, without a
+    GPU, both exit with the 'needs an MI355X' message and the parent reports the failure with a non-zero code)."""
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--traffic", "none"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    if not torch.cuda.is_available():
+        assert "ranks failed" in r.stderr and "needs an MI355X" in r.stderr
+
+
+def test_optimizer_state_dict_has_torch_adam_layout():
+    """saveModel's optimizer_state_dict loads into the reference's optimizer: torch.optim.Adam(net.parameters() + [eta])."""
+    from semantic_superpoint_amd import lib as L
+
+    class FakeEngine:  # the wire format is host logic: no device needed
+        pass
+    arch = "SuperPointNet_gauss2"
+    e = FakeEngine()
+    e.layout, e.n_params = L.param_layout(arch)
+    e.adam_t = 3
+    e.adam_m = torch.arange(e.n_params + 3, dtype=torch.float32)
+    e.adam_v = torch.arange(e.n_params + 3, dtype=torch.float32) * 2
+    e.device = torch.device("cpu")
+    e.params = torch.zeros(e.n_params + 3)
+    osd = L.optimizer_state_dict(e, 0.001)
+    from semantic_superpoint_amd import models
+    net = models.SuperPointNet_gauss2()
+    eta = torch.nn.Parameter(torch.tensor([1.0, 2.0, 1.0]))
+    opt = torch.optim.Adam(list(net.parameters()) + [eta], lr=0.5, betas=(0.9, 0.999))
+    opt.load_state_dict(osd)  # raises on a layout mismatch
+    st = opt.state_dict()["state"]
+    assert len(st) == len(e.layout) + 1 and float(st[0]["step"]) == 3.0
+    assert opt.param_groups[0]["lr"] == 0.001
+    assert torch.equal(st[len(e.layout)]["exp_avg"], e.adam_m[e.n_params:])
+    e2 = FakeEngine()
+    e2.layout, e2.n_params, e2.device = e.layout, e.n_params, e.device
+    e2.adam_m, e2.adam_v, e2.params, e2.adam_t = torch.zeros_like(e.adam_m), torch.zeros_like(e.adam_v), torch.zeros_like(e.params), 0
+    L.load_optimizer_state(e2, osd, eta=[0.1, 0.2, 0.3])
+    assert torch.equal(e2.adam_m, e.adam_m) and torch.equal(e2.adam_v, e.adam_v) and e2.adam_t == 3
+    assert torch.allclose(e2.params[e.n_params:], torch.tensor([0.1, 0.2, 0.3]))

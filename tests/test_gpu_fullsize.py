@@ -1,0 +1,417 @@
+"""GPU: the pair step at the BENCHMARK size (240x320; B = 2 against the real reference's golden step, B = 32 through
+size-independent properties), the proof that end-to-end gradient differences are ReLU / max-pool gate flips only,
+the split (data-parallel overlap) and captured (hipGraph) forms of the step, and the loss gradients G3 / G5."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as C
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+ARCHS = {"sp": "SuperPointNet_gauss2", "ssp": "SuperPointNet_gauss2_ssmall"}
+SCALARS = ("loss", "loss_det", "loss_det_warp", "loss_desc", "loss_sem", "loss_sem_warp", "positive_dist", "negative_dist")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (run through gpurun)"
+    return torch.device("cuda:0")
+
+
+def _engine(arch, B, H, W, sd, **kw):
+    from semantic_superpoint_amd.lib import Engine
+    e = Engine(arch, B, H, W, _dev(), **kw)
+    e.load_state_dict(sd)
+    return e
+
+
+def _to_dev(sample):
+    return {k: v.to(_dev()).contiguous() for k, v in sample.items()}
+
+
+def _idx_to_dev(idx, Wc):
+    ma = torch.stack([(i["uv_a"][:, 0] + i["uv_a"][:, 1] * Wc) for i in idx]).to(torch.int32)
+    mb = torch.stack([(i["uv_b"][:, 0] + i["uv_b"][:, 1] * Wc) for i in idx]).to(torch.int32)
+    nm = torch.stack([i["nm_b"] for i in idx]).to(torch.int32)
+    return ma.to(_dev()).contiguous(), mb.to(_dev()).contiguous(), nm.to(_dev()).contiguous()
+
+
+def _rel(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30)), float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _noisy(arch):  # conv biases feeding a BatchNorm: exact gradient 0, both sides hold rounding noise
+    return {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+
+
+# ------------------------------------------------------------------------------------------------
+# (i) the real reference's step at 240x320 (G12)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["sp", "ssp"])
+def test_full_size_step_golden(tag):
+    """G12: forward checksums, two optimizer steps and the first step's gradients of the REAL reference at 240x320, B = 2."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    arch = ARCHS[tag]
+    g = G.load("g12_step_%s_240x320.npz" % tag)
+    sample = C.compact_from_npz(g)
+    B, _, H, W = sample["image"].shape
+    assert (H, W) == (240, 320)
+    sd = C.init_state_dict(arch, seed=29)
+    ds = _to_dev(sample)
+    # forward: per-channel checksums (sums over 1200 cells / 76800 pixels) and strided slices
+    e = _engine(arch, B, H, W, sd, with_grad=False)
+    want = ("semi", "desc", "sem") if tag == "ssp" else ("semi", "desc")
+    o = e.forward(ds["image"], slot=0, train=True, want=want)
+    torch.cuda.synchronize()
+    assert (o["semi"].cpu()[:, ::4, ::3, ::4] - torch.from_numpy(g["fwd/semi_s"])).abs().max() < 1e-3
+    assert (o["desc"].cpu()[:, ::16, ::3, ::4] - torch.from_numpy(g["fwd/desc_s"])).abs().max() < 1e-3
+    cs = o["semi"].double().sum(dim=(2, 3)).cpu()
+    assert (cs - torch.from_numpy(g["fwd/semi_chsum"])).abs().max() < 1e-3 * 1200 ** 0.5 * 4
+    cs = o["desc"].double().sum(dim=(2, 3)).cpu()
+    assert (cs - torch.from_numpy(g["fwd/desc_chsum"])).abs().max() < 1e-3
+    if tag == "ssp":
+        assert (o["sem"].cpu()[:, ::19, ::24, ::32] - torch.from_numpy(g["fwd/sem_s"])).abs().max() < 1e-3
+        cs = o["sem"].double().sum(dim=(2, 3)).cpu()
+        ref = torch.from_numpy(g["fwd/sem_chsum"])
+        assert (cs - ref).abs().max() < 2e-5 * 76800, float((cs - ref).abs().max())
+    del e
+    # the step
+    e = _engine(arch, B, H, W, sd)
+    idx = _idx_to_dev(G.indices_from(g, "idx/", B), W // 8)
+    for it in range(2):
+        e.zero_grad()
+        sc = e.pair_step(ds, indices=idx, train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True)
+        torch.cuda.synchronize()
+        sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+        for name in SCALARS:
+            ref = float(g["step%d/%s" % (it, name)])
+            assert abs(sc[name] - ref) < (2e-4 if it == 0 else 1e-3) * max(1.0, abs(ref)), (it, name, sc[name], ref)
+        if it == 0:
+            gd = e.grad_dict()
+            worst = 0.0
+            for k in C.param_keys(arch):
+                if k in _noisy(arch):
+                    continue
+                n_ref = float(g["grad_norm/" + k])
+                mine = gd[k].cpu().reshape(-1)
+                assert abs(float(mine.norm()) - n_ref) < 2e-3 * n_ref + 1e-7, (k, float(mine.norm()), n_ref)
+                sl = torch.from_numpy(g["grad_slice/" + k])
+                err = float((mine[:64] - sl).abs().max()) / (float(mine.abs().max()) + 1e-30)
+                worst = max(worst, err)
+                assert err < 5e-3, (k, err)
+            assert (gd["eta"].cpu() - torch.from_numpy(g["grad/eta"])).abs().max() < 2e-4
+        e.adam_step(0.001)
+    torch.cuda.synchronize()
+    assert (e.eta.cpu() - torch.from_numpy(g["post/eta"])).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# (iii) gate flips are the ONLY source of the end-to-end gradient differences
+# ------------------------------------------------------------------------------------------------
+def _hip_gates(e, arch, slot, B, H, W):
+    """ReLU gates and max-pool winners of the HIP forward in `slot`, recomputed from its raw convolution outputs and
+    BatchNorm affine (float64 gives the exact sign of the fp32 fma; rounding to fp32 reproduces the pooled values)."""
+    t = C.layer_table(arch)
+    relu, pool = {}, {}
+    nheads = 3 if arch.endswith("ssmall") else 2
+    res = [(H, W), (H, W), (H // 2, W // 2), (H // 2, W // 2), (H // 4, W // 4), (H // 4, W // 4), (H // 8, W // 8),
+           (H // 8, W // 8)]
+    for l in range(8):
+        hh, ww = res[l]
+        c = t[l][3]
+        y = e.debug_buffer(slot, "Y%d" % l, (B, hh, ww, c)).double()
+        z = (y * e.debug_buffer(slot, "scale%d" % l, (c,)).double() + e.debug_buffer(slot, "shift%d" % l, (c,)).double())
+        z = z.permute(0, 3, 1, 2).cpu()  # NCHW
+        relu[t[l][0]] = (z > 0)
+        if l in (1, 3, 5):  # pooled on the way into layer l + 1
+            a = torch.relu(z.float())
+            win = a.view(B, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, c, hh // 2, ww // 2, 4)
+            pool[l + 1] = win.argmax(dim=4)  # first maximum, like torch's max_pool2d and the HIP routing
+    hc, wc = H // 8, W // 8
+    yh = e.debug_buffer(slot, "Y8", (B, hc, wc, 256 * nheads)).double()
+    for k, (name, l) in enumerate((("convPa", 8), ("convDa", 10), ("convDS", 12))[:nheads]):
+        z = yh[..., 256 * k:256 * (k + 1)] * e.debug_buffer(slot, "scale%d" % l, (256,)).double() + \
+            e.debug_buffer(slot, "shift%d" % l, (256,)).double()
+        relu[name] = (z.permute(0, 3, 1, 2).cpu() > 0)
+    return {"relu": relu, "pool": pool}
+
+
+@pytest.mark.parametrize("tag", ["sp", "ssp"])
+def test_gradient_differences_are_gate_flips_only(tag):
+    """120x160, B = 2.  (a) HIP vs the plain oracle: statistical agreement (gate flips of activations within rounding
+    distance of 0 perturb the gradient).  (b) HIP vs the oracle evaluated WITH THE HIP PATH'S ReLU gates and max-pool
+    winners: agreement to 1e-4 relative L2 per tensor -> the flips are the whole difference."""
+    arch = ARCHS[tag]
+    B, H, W = 2, 120, 160
+    sd = C.init_state_dict(arch, seed=9)
+    sample = C.make_synthetic_pair(B, H, W, seed=4, semantic=(tag == "ssp"), kp_prob=0.005)
+    tr = C.Trainer(arch, sd, lr=0.001)
+    tr.real_batch_size = 10 ** 9
+    np.random.seed(50)
+    torch.manual_seed(60)
+    tr.train_val_sample(sample, n_iter=0, train=True)
+    used = tr.aux["indices"]
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    e.pair_step(_to_dev(sample), indices=_idx_to_dev(used, W // 8), train=True)
+    torch.cuda.synchronize()
+    gd = {k: v.cpu().clone() for k, v in e.grad_dict().items()}
+    forced = (_hip_gates(e, arch, 0, B, H, W), _hip_gates(e, arch, 1, B, H, W))
+    nflip = sum(int((forced[v]["relu"][k] != (C_relu > 0)).sum()) for v in range(2)
+                for k, C_relu in _oracle_preacts(sd, sample, arch, v).items())
+    tsd = C.to_torch(sd, requires_grad=True)
+    eta = torch.tensor([1.0, 2.0, 1.0], requires_grad=True)
+    loss, _, _ = C.pair_losses(tsd, eta, sample, arch, indices=used, forced=forced)
+    loss.backward()
+    worst_plain, worst_forced = 0.0, 0.0
+    for k in C.param_keys(arch):
+        if k in _noisy(arch):
+            continue
+        l2p, _ = _rel(gd[k], tr.last_grads[k])
+        l2f, mxf = _rel(gd[k], tsd[k].grad)
+        worst_plain, worst_forced = max(worst_plain, l2p), max(worst_forced, l2f)
+        assert l2p <= 2e-3, ("plain oracle", k, l2p)
+        assert l2f <= 1e-4 and mxf <= 1e-3, ("gates forced", k, l2f, mxf, "flipped gates: %d" % nflip)
+    assert (gd["eta"] - eta.grad).abs().max() < 1e-5
+    print("gate flips %d; worst rel-L2: plain %.2e, gates forced %.2e" % (nflip, worst_plain, worst_forced))
+
+
+def _oracle_preacts(sd, sample, arch, view):
+    """Pre-activation signs of the oracle's own forward (to count the flipped gates)."""
+    import torch.nn.functional as F
+    tsd = C.to_torch(sd)
+    x = sample["image"] if view == 0 else sample["warped_img"]
+    t = C.layer_table(arch)
+    out, h = {}, x
+    with torch.no_grad():
+        for i, (conv, bn, cin, cout, k) in enumerate(t[:8]):
+            if i in (2, 4, 6):
+                h = F.max_pool2d(h, 2)
+            y = F.conv2d(h, tsd[conv + ".weight"], tsd[conv + ".bias"], padding=1)
+            z = F.batch_norm(y, None, None, tsd[bn + ".weight"], tsd[bn + ".bias"], training=True, eps=1e-5)
+            out[conv] = z
+            h = F.relu(z)
+        for conv, bn in (("convPa", "bnPa"), ("convDa", "bnDa"), ("convDS", "bnS1")):
+            if conv + ".weight" in tsd:
+                y = F.conv2d(h, tsd[conv + ".weight"], tsd[conv + ".bias"], padding=1)
+                out[conv] = F.batch_norm(y, None, None, tsd[bn + ".weight"], tsd[bn + ".bias"], training=True, eps=1e-5)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# (ii) properties at the benchmarked size B = 32, 240x320
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["sp", "ssp"])
+def test_bench_size_properties(tag):
+    """B = 32 at 240x320 (BASELINE configs[1] / [2]): the persistent XCD-aware tile loops, the skewed 5 GB workspace,
+    both-views-per-launch and the deferred weight-gradient slabs take their real shape only here.
+      * Winograd (default) and direct implicit GEMM agree on every scalar and on the flat gradient;
+      * BatchNorm running statistics of two sampled channels per checked layer match a B = 32 oracle forward;
+      * 20 optimizer steps on one batch: every scalar finite, the loss falls."""
+    from semantic_superpoint_amd import synth
+    from semantic_superpoint_amd.lib import SCALAR_NAMES, layer_table
+    arch = ARCHS[tag]
+    B, H, W = 32, 240, 320
+    dev = _dev()
+    sd = synth.default_init_state_dict(layer_table(arch), seed=0)
+    sample = synth.make_pair(B, H, W, dev, seed=100, semantic=(tag == "ssp"))
+    e = _engine(arch, B, H, W, sd)
+    res = {}
+    for algo in (1, 0):
+        e.set_conv_algo(algo)
+        e.load_state_dict(sd)  # also resets the running statistics
+        e.zero_grad()
+        sc = e.pair_step(sample, indices=None, seed=7, train=True)
+        torch.cuda.synchronize()
+        res[algo] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), e.grads.clone(), e.state_dict())
+    e.set_conv_algo(1)
+    for name in SCALARS:
+        a, b = res[1][0][name], res[0][0][name]
+        assert np.isfinite(a) and abs(a - b) < 1e-4 * max(1.0, abs(a)), (name, a, b)
+    assert bool(torch.isfinite(res[1][1]).all())
+    l2, mx = _rel(res[1][1], res[0][1])
+    assert l2 < 3e-3 and mx < 3e-2, (l2, mx)  # different summation orders + gate flips, 157 M activations per layer
+    # running statistics after ONE forward of the first view... the pair step runs both views: the running buffers hold
+    # momentum-0.1 updates of view 0 then view 1 (Train_model_heatmap_all.py:258,262); the oracle does the same
+    osd = C.to_torch({k: np.asarray(v.cpu()) if torch.is_tensor(v) else np.asarray(v) for k, v in sd.items()})
+    with torch.no_grad():
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        C.forward(osd, sample["image"].cpu(), arch)
+        C.forward(osd, sample["warped_img"].cpu(), arch)
+    mine = res[1][2]
+    for k in ("inc.conv.conv.1", "inc.conv.conv.4", "down1.mpconv.1.conv.4", "down3.mpconv.1.conv.4", "bnPa", "bnDb"):
+        for ch in (3, 41):
+            for stat in ("running_mean", "running_var"):
+                a, b = float(mine[k + "." + stat][ch]), float(osd[k + "." + stat][ch])
+                assert abs(a - b) < 1e-4 * max(1.0, abs(b)), (k, stat, ch, a, b)
+    # soak
+    e.load_state_dict(sd)
+    first = last = None
+    for it in range(20):
+        e.zero_grad()
+        sc = e.pair_step(sample, indices=None, seed=1000 + it, train=True)
+        e.adam_step(0.001)
+        if it in (0, 19):
+            v = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+            assert all(np.isfinite(x) for x in v.values()), v
+            first, last = (v, last) if it == 0 else (first, v)
+    assert last["loss"] < first["loss"] - 0.05, (first["loss"], last["loss"])
+    assert bool(torch.isfinite(e.params).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# split and captured forms of the step
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["sp", "ssp"])
+def test_phases_equal_whole_step(tag):
+    """ssp_pair_step_phase 1 + 2 == ssp_pair_step bit for bit, and after phase 1 the early bucket is already final."""
+    arch = ARCHS[tag]
+    B, H, W = 2, 64, 96
+    sd = C.init_state_dict(arch, seed=3)
+    ds = _to_dev(C.make_synthetic_pair(B, H, W, seed=8, semantic=(tag == "ssp"), kp_prob=0.01))
+    e = _engine(arch, B, H, W, sd)
+    idx = e.sample_indices(ds["homographies"], 5)
+    e.zero_grad()
+    s0 = e.pair_step(ds, indices=idx, train=True).clone()
+    g0 = e.grads.clone()
+    e.load_state_dict(sd)
+    e.zero_grad()
+    s1 = e.pair_step(ds, indices=idx, train=True, phase=1).clone()
+    torch.cuda.synchronize()
+    off = e.early_offset
+    assert 0 < off < e.n_params
+    assert torch.equal(e.grads[off:], g0[off:]), "early bucket must be final after phase 1"
+    assert float(e.grads[:off].abs().max()) == 0.0
+    e.pair_step(ds, indices=idx, train=True, phase=2)
+    torch.cuda.synchronize()
+    assert torch.equal(e.grads, g0) and torch.equal(s0, s1)
+
+
+def test_graph_replay_equals_eager():
+    """ssp_pair_step_graph: three replays with different sampler seeds == the eager steps with the same seeds."""
+    arch = ARCHS["ssp"]
+    B, H, W = 2, 64, 96
+    sd = C.init_state_dict(arch, seed=3)
+    ds = _to_dev(C.make_synthetic_pair(B, H, W, seed=8, semantic=True, kp_prob=0.01))
+    ea, eb = _engine(arch, B, H, W, sd), _engine(arch, B, H, W, sd)
+    st = torch.cuda.Stream()
+    for it, seed in enumerate((11, 12, 99)):
+        ea.zero_grad()
+        sa = ea.pair_step(ds, indices=None, seed=seed, train=True)
+        ea.adam_step(0.001)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            eb.zero_grad()
+            sb = eb.pair_step(ds, indices=None, seed=seed, train=True, graph=True)
+            eb.adam_step(0.001)
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        assert torch.equal(sa, sb), (it, sa, sb)
+        assert torch.equal(ea.grads, eb.grads) and torch.equal(ea.params, eb.params), it
+        assert torch.equal(ea.bn_running, eb.bn_running)
+
+
+# ------------------------------------------------------------------------------------------------
+# data parallel: two ranks through the engine on ONE device (gloo), overlapped all-reduce
+# ------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semantic_superpoint_amd import parallel
+    from semantic_superpoint_amd.lib import Engine
+    arch, B, H, W = ARCHS["ssp"], 2, 64, 96
+    dev = torch.device("cuda:0")
+    sd = C.init_state_dict(arch, seed=3)
+    e = Engine(arch, B, H, W, dev)
+    e.load_state_dict(sd)
+    ds = {k: v.to(dev).contiguous() for k, v in C.make_synthetic_pair(B, H, W, seed=20 + rank, semantic=True, kp_prob=0.01).items()}
+    for it in range(2):
+        e.zero_grad()
+        parallel.pair_step_overlapped(e, ds, 0.001, indices=None, seed=100 * it + rank, train=True)
+        if it == 0:
+            torch.cuda.synchronize()
+            torch.save(e.grads.cpu(), os.path.join(out_dir, "gsum%d.pt" % rank))
+    torch.cuda.synchronize()
+    torch.save(e.params.cpu(), os.path.join(out_dir, "params%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_device_overlapped_allreduce(tmp_path):
+    """2 ranks on cuda:0 over gloo through the ENGINE (parallel.pair_step_overlapped): bit-identical parameters on both
+    ranks after 2 steps, and the all-reduced gradient of step 1 == the sum of the two ranks' single-rank gradients
+    (BatchNorm statistics stay per replica)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "params0.pt"), torch.load(tmp_path / "params1.pt")
+    assert torch.equal(p0, p1)
+    gs0, gs1 = torch.load(tmp_path / "gsum0.pt"), torch.load(tmp_path / "gsum1.pt")
+    assert torch.equal(gs0, gs1)
+    # single-rank reference: each rank's own gradient, summed on the host
+    arch, B, H, W = ARCHS["ssp"], 2, 64, 96
+    sd = C.init_state_dict(arch, seed=3)
+    tot = None
+    for rank in range(2):
+        e = _engine(arch, B, H, W, sd)
+        ds = _to_dev(C.make_synthetic_pair(B, H, W, seed=20 + rank, semantic=True, kp_prob=0.01))
+        e.zero_grad()
+        e.pair_step(ds, indices=None, seed=rank, train=True)
+        torch.cuda.synchronize()
+        tot = e.grads.cpu().clone() if tot is None else tot + e.grads.cpu()
+    assert (gs0 - tot).abs().max() <= 1e-6 * float(tot.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# (iv) G3 / G5: the loss gradients themselves, read through ssp_debug_buffer
+# ------------------------------------------------------------------------------------------------
+def test_detector_and_semantic_loss_gradients_vs_autograd():
+    """d loss / d semi (G3's quantity) and d loss / d convSout (G5's, through the fused bilinear upsample) of a pair step
+    against autograd of the oracle's detector_loss / sem_loss on the HIP path's own logits."""
+    import torch.nn.functional as F
+    arch = ARCHS["ssp"]
+    B, H, W = 2, 64, 96
+    Hc, Wc = H // 8, W // 8
+    sd = C.init_state_dict(arch, seed=5)
+    sample = C.make_synthetic_pair(B, H, W, seed=6, semantic=True, kp_prob=0.01)
+    sample["semantic"][0, :9, :] = 133  # ignored pixels
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    e.pair_step(_to_dev(sample), indices=None, seed=1, train=True, multi_task=False, lambda_loss=0.0)
+    torch.cuda.synchronize()
+    for v, (lab, msk, sem) in enumerate((("labels_2D_gaussian", "valid_mask", "semantic"),
+                                         ("warped_labels_gaussian", "warped_valid_mask", "warped_sem"))):
+        ypb = e.debug_buffer(v, "Y9", (B, Hc, Wc, 80))[..., :65].cpu()
+        semi = (ypb * e.debug_buffer(v, "scale9", (65,)).cpu() + e.debug_buffer(v, "shift9", (65,)).cpu())
+        semi = semi.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        C.detector_loss(semi, C.labels2Dto3D(sample[lab]).float(), C.get_masks(sample[msk])).backward()
+        mine = e.debug_buffer(v, "dsemi", (B, Hc, Wc, 80))[..., :65].permute(0, 3, 1, 2).cpu()
+        assert (mine - semi.grad).abs().max() < 1e-6 + 1e-4 * float(semi.grad.abs().max()), v
+        cs = e.debug_buffer(v, "Y13", (B, Hc, Wc, 136))[..., :133].permute(0, 3, 1, 2).contiguous().cpu().requires_grad_(True)
+        C.sem_loss(F.interpolate(cs, (H, W), mode="bilinear", align_corners=False), sample[sem]).backward()
+        mine = e.debug_buffer(v, "dsout", (B, Hc, Wc, 136))[..., :133].permute(0, 3, 1, 2).cpu()
+        assert (mine - cs.grad).abs().max() < 1e-6 + 2e-4 * float(cs.grad.abs().max()), v
+
+
+def test_golden_loss_gradients_g3():
+    """G3 (detector_loss value and d/d semi from the REAL reference, incl. the saturated logit that hits the -100 clamp)
+    through ssp_op_detector_loss.  The fixture stores the 3-D target; depth-to-space of its 64 cell channels is a 2-D label
+    map whose labels2Dto3D is that target again (cells with points sum to 1, empty cells give the dustbin)."""
+    from semantic_superpoint_amd import lib as L
+    g = G.load("g3_detector_loss.npz")
+    tgt = torch.from_numpy(g["target"])
+    B, _, Hc, Wc = tgt.shape
+    lab2d = tgt[:, :64].view(B, 8, 8, Hc, Wc).permute(0, 3, 1, 4, 2).reshape(B, 1, Hc * 8, Wc * 8).contiguous()
+    assert (C.labels2Dto3D(lab2d).float() - tgt).abs().max() < 1e-6
+    mask2d = torch.from_numpy(g["mask"]).repeat_interleave(8, 1).repeat_interleave(8, 2).unsqueeze(1).contiguous()
+    loss, dsemi = L.op_detector_loss(torch.from_numpy(g["semi"]).to(_dev()), lab2d.to(_dev()), mask2d.to(_dev()))
+    assert abs(loss - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    ref = torch.from_numpy(g["dsemi"])
+    assert (dsemi.cpu() - ref).abs().max() < 1e-6 + 1e-4 * float(ref.abs().max())

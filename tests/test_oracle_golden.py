@@ -247,3 +247,67 @@ def test_g11_pair_labels():
         lab, res, bi = C.warp_labels_full(t(g["pts%d" % k].astype(np.int64)), H, W, t(g["H%d" % k]))
         assert torch.equal(lab, t(g["labels%d" % k])) and torch.equal(res, t(g["res%d" % k]))
         assert torch.equal(bi, t(g["bi%d" % k]))
+
+
+@pytest.mark.parametrize("tag,arch", [("sp", ARCHS[0]), ("ssp", ARCHS[1])])
+def test_g12_full_size_step(tag, arch):
+    """G12: the real reference's pair step at the benchmark resolution 240x320 (B = 2): forward checksums, the first
+    step's scalars and gradients (the compact fixture round-trips its inputs exactly)."""
+    g = G.load("g12_step_%s_240x320.npz" % tag)
+    sample = C.compact_from_npz(g)
+    assert tuple(sample["image"].shape) == (2, 1, 240, 320)
+    regen = C.make_compact_pair(2, 240, 320, seed=41, semantic=(tag == "ssp"))
+    assert torch.equal(regen["labels_2D"], sample["labels_2D"]) and torch.equal(regen["image"], sample["image"])
+    sd_np = C.init_state_dict(arch, seed=29)
+    o = C.forward(C.to_torch(sd_np), sample["image"], arch)
+    assert (o["semi"].double().sum(dim=(2, 3)) - t(g["fwd/semi_chsum"])).abs().max() < 1e-2
+    assert (o["desc"][:, ::16, ::3, ::4] - t(g["fwd/desc_s"])).abs().max() < 1e-5
+    tr = C.Trainer(arch, sd_np, lr=0.001, lambda_loss=1.0, multi_task=True)
+    tr.real_batch_size = 10 ** 9
+    tr.train_val_sample(sample, n_iter=1, train=True, indices=G.indices_from(g, "idx/", 2))
+    for k in ("loss", "loss_det", "loss_det_warp", "loss_desc", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
+        ref = float(g["step0/" + k])
+        assert abs(tr.scalar_dict[k] - ref) < 5e-5 * max(1.0, abs(ref)), (k, tr.scalar_dict[k], ref)
+    for k in ("inc.conv.conv.0.weight", "inc.conv.conv.3.weight", "down2.mpconv.1.conv.0.weight", "convPb.weight", "bnDb.weight"):
+        gr = tr.last_grads[k]
+        assert abs(float(gr.norm()) - float(g["grad_norm/" + k])) < 1e-3 * float(g["grad_norm/" + k])
+        assert (gr.reshape(-1)[:64] - t(g["grad_slice/" + k])).abs().max() < 1e-3 * float(gr.abs().max()) + 1e-7
+    assert (tr.last_grads["eta"] - t(g["grad/eta"])).abs().max() < 1e-5
+
+
+def test_forced_gates_hook_is_transparent_with_own_gates():
+    """forward(forced=...) with the network's OWN ReLU gates and max-pool winners is the plain forward (values and
+    gradients): the hook used by the GPU gate-flip test changes nothing but who decides the gates."""
+    import torch.nn.functional as F
+    arch = ARCHS[1]
+    sd_np = C.init_state_dict(arch, seed=2)
+    x = t(np.random.RandomState(1).uniform(0, 1, (2, 1, 32, 48)).astype(np.float32))
+    sd = C.to_torch(sd_np, requires_grad=True)
+    ref = C.forward(sd, x, arch)
+    # own gates: recompute the pre-activations layer by layer
+    relu, pool, h = {}, {}, x
+    tb = C.layer_table(arch)
+    with torch.no_grad():
+        for i, (conv, bn, cin, cout, k) in enumerate(tb[:8]):
+            if i in (2, 4, 6):
+                N, Cc, Hh, Ww = h.shape
+                win = h.view(N, Cc, Hh // 2, 2, Ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, Cc, Hh // 2, Ww // 2, 4)
+                pool[i] = win.argmax(dim=4)
+                h = F.max_pool2d(h, 2)
+            z = F.batch_norm(F.conv2d(h, sd[conv + ".weight"], sd[conv + ".bias"], padding=1), None, None,
+                             sd[bn + ".weight"], sd[bn + ".bias"], training=True, eps=1e-5)
+            relu[conv] = z > 0
+            h = F.relu(z)
+        for conv, bn in (("convPa", "bnPa"), ("convDa", "bnDa"), ("convDS", "bnS1")):
+            z = F.batch_norm(F.conv2d(h, sd[conv + ".weight"], sd[conv + ".bias"], padding=1), None, None,
+                             sd[bn + ".weight"], sd[bn + ".bias"], training=True, eps=1e-5)
+            relu[conv] = z > 0
+    sd2 = C.to_torch(sd_np, requires_grad=True)
+    out = C.forward(sd2, x, arch, forced={"relu": relu, "pool": pool})
+    for k in ref:
+        assert (out[k] - ref[k]).abs().max() < 1e-6, k
+    w = {k: torch.randn_like(v) for k, v in ref.items()}
+    sum((ref[k] * w[k]).sum() for k in ref).backward()
+    sum((out[k] * w[k]).sum() for k in out).backward()
+    for k in ("inc.conv.conv.0.weight", "down1.mpconv.1.conv.3.weight", "convDS.weight"):
+        assert (sd[k].grad - sd2[k].grad).abs().max() < 1e-5 * float(sd[k].grad.abs().max()) + 1e-7, k
