@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_PAIR = {"SuperPointNet_gauss2": 77.98, "SuperPointNet_gauss2_ssmall": 82.72}
 PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3 line)
-DOMINANT_KERNEL = "conv_wino_pipe_kernel"
+DOMINANT_KERNEL = {0: "conv_mfma_kernel", 1: "conv_wino_pipe_kernel", 2: "conv_wino_kernel", 3: "conv_wino_bf16_kernel",
+                   5: "conv_wino_pipe_kernel", 6: "conv_wino_p2_kernel"}  # 3x3 forward + data-gradient kernel per --conv-algo
 
 
 def cpu_baseline(arch, H, W, batch=32, steps=3):
@@ -80,7 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6],
                     help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
                          "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
-                         "matrix-core operands (reduced precision: reported as dtype bf16)")
+                         "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
+                         "workgroups per CU")
     ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
                     help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
     ap.add_argument("--graph", action="store_true", help="replay the pair step as a hipGraph (ssp_pair_step_graph)")
@@ -149,7 +151,7 @@ def live_traffic(args):
                 return None, "no counter_collection.csv from rocprofv3"
             s, seen = 0.0, set()
             for row in csv.DictReader(open(files[0])):
-                if DOMINANT_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                if DOMINANT_KERNEL[args.conv_algo] in row["Kernel_Name"] and row["Counter_Name"] == ctr:
                     s += float(row["Counter_Value"])
                     seen.add(row["Dispatch_Id"])
             tot[ctr], launches[ctr] = s, len(seen)
@@ -291,15 +293,17 @@ def main():
             if pr["launches"] > 0 and pr["ms"] > 0:
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
                 peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
-                out["roofline"] = {"bound": "mfma", "kernel": "conv_wino_pipe_kernel (3x3 forward + data-gradient, Winograd "
-                                                              "F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
+                exec_ratio = 1.0 if args.conv_algo == 0 else 16.0 / 36.0  # Winograd executes 16 of 36 multiplies
+                out["roofline"] = {"bound": "mfma", "kernel": "%s (3x3 forward + data-gradient, %s on v_mfma_f32_32x32x2_f32)"
+                                                              % (DOMINANT_KERNEL[args.conv_algo], "direct implicit GEMM"
+                                                                 if args.conv_algo == 0 else "Winograd F(2x2,3x3)"),
                                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4),
                                    "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / time; Winograd executes "
                                            "16/36 of them on the matrix cores, so frac may exceed 1: executed_frac is the "
                                            "hardware fraction of the matrix-core peak",
-                                   "executed_tflops": round(ach * 16.0 / 36.0, 2),
-                                   "executed_frac": round(ach * 16.0 / 36.0 / peak, 4),
+                                   "executed_tflops": round(ach * exec_ratio, 2),
+                                   "executed_frac": round(ach * exec_ratio / peak, 4),
                                    "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_note,
                                    "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                    "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4),

@@ -17,6 +17,7 @@
 #include "conv_mfma.hip.h"
 #include "conv_wino.hip.h"
 #include "conv_wino_pipe.hip.h"
+#include "conv_wino_p2.hip.h"
 #include "conv_wino_bf16.hip.h"
 #include "loss_kernels.hip.h"
 #include "dense_loss.hip.h"
@@ -358,7 +359,7 @@ struct ConvCall {
   const float* bnr_p[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
 };
 static bool can_fuse_bnr(const ConvCall& c) {
-  return c.wino && (g_conv_algo == 1 || g_conv_algo == 5) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
+  return c.wino && (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
          c.out_cs % 4 == 0;
 }
 
@@ -370,6 +371,18 @@ static int launch_wino_pipe_t(const ConvArgs& a, int nblocks, hipStream_t st) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES));
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), PIPE_LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int IN_MODE, bool WIDE>
+static int launch_wino_p2_t(const ConvArgs& a, int nblocks, hipStream_t st) {
+  static AttrOnce attr_once;
+  auto kern = conv_wino_p2_kernel<IN_MODE, WIDE>;
+  if (attr_once.need()) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES));
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(P2_THREADS), P2_LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -426,13 +439,17 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     a.wpk_bytes = (unsigned)((double)c.ncob * c.nchunks * (c.wino ? WC : c.ks * c.ks) * CK * NB * 4.0);
   }
   a.ablate = g_dbg_ablate;
-  const bool wide = (c.W % 32) == 0;
-  const int TH = wide ? 8 : 32, TW = wide ? 32 : 8;
+  // tile geometry: second-generation Winograd kernel (algo 6): 32 tiles = 8x16 / 16x8 pixels per 4-wave workgroup;
+  // everything else: 64 tiles (Winograd) or 256 pixels (direct) = 8x32 / 32x8 per workgroup
+  const bool p2 = c.wino && g_conv_algo == 6;
+  const bool wide = p2 ? (c.W % 16) == 0 : (c.W % 32) == 0;
+  const int TH = p2 ? (wide ? 8 : 16) : (wide ? 8 : 32), TW = p2 ? (wide ? 16 : 8) : (wide ? 32 : 8);
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
-  // persistent grid: 2 blocks per CU (LDS-limited residency; Winograd: 1), a multiple of 8 (one slot set per XCD)
+  // persistent grid: 2 blocks per CU (LDS-limited residency; first-generation Winograd: 1), a multiple of 8 (one slot
+  // set per XCD)
   const int n_cu = h ? h->n_cu : 256;
   if (c.wino && (c.ks != 3 || c.in_mode == 2 || c.cin % CK)) return fail(-3, "Winograd conv needs ks 3, Cin %% 16 == 0");
-  int nblocks = std::max(8, ((c.wino ? 1 : 2) * n_cu) / 8 * 8);
+  int nblocks = std::max(8, ((c.wino && !p2 ? 1 : 2) * n_cu) / 8 * 8);
   if (g_dbg_grid > 0) nblocks = g_dbg_grid;  // perf-debug only (ssp_debug_conv_knobs)
   if ((nblocks / 8) < c.ncob) return fail(-3, "too many output-channel blocks (%d) for the persistent grid", c.ncob);
   const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
@@ -446,6 +463,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     a.wpk_bytes /= 2;  // bf16 weights
     if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true>(a, nblocks, st) : launch_wino_bf16_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_bf16_t<1, true>(a, nblocks, st) : launch_wino_bf16_t<1, false>(a, nblocks, st);
+  }
+  if (p2) {  // second-generation pipelined Winograd: two independent 4-wave workgroups per CU
+    if (c.in_mode == 0) return wide ? launch_wino_p2_t<0, true>(a, nblocks, st) : launch_wino_p2_t<0, false>(a, nblocks, st);
+    return wide ? launch_wino_p2_t<1, true>(a, nblocks, st) : launch_wino_p2_t<1, false>(a, nblocks, st);
   }
   if (c.wino && g_conv_algo == 1) {  // pipelined Winograd, weight fragments straight from L2 (default)
     if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true, true>(a, nblocks, st) : launch_wino_pipe_t<0, false, true>(a, nblocks, st);
@@ -612,7 +633,7 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
     if (g_conv_algo == 3)
       hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w,
                          reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks);
-    else if (g_conv_algo == 1 || g_conv_algo == 5)  // 8-channel stages of the pipelined kernel: twice as many chunks of half the size
+    else if (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6)  // 8-channel stages of the pipelined kernels: twice as many chunks of half the size
       hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
                          2 * nchunks, 0, 0, ncob, 2 * nchunks);
     else
@@ -767,7 +788,7 @@ static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, dou
 
 static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
   // default algorithm: every Winograd image (3x3 layers forward + data gradient, concatenated heads) in one launch
-  const bool multi = g_conv_algo == 1 || g_conv_algo == 5;
+  const bool multi = g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6;
   PackJobs J;
   J.n = 0;
   int nblocks = 0;
@@ -1360,7 +1381,7 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
-  if (algo < 0 || algo > 5 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3 or 5 (see ssp_set_conv_algo)");
+  if (algo < 0 || algo > 6 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3, 5 or 6 (see ssp_set_conv_algo)");
   h->conv_algo = algo;
   return 0;
 }
@@ -1739,9 +1760,9 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 5 || algo == 4)
+  if (algo < 0 || algo > 6 || algo == 4)
     return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
-                    "operands) or 5 (Winograd, pipelined, weights staged through LDS)");
+                    "operands), 5 (Winograd, pipelined, weights staged through LDS) or 6 (Winograd, two 4-wave workgroups per CU)");
   g_default_conv_algo = algo;
   return 0;
 }

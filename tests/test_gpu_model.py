@@ -364,7 +364,7 @@ def test_odd_shapes_forward_and_step(B, H, W):
         _grad_close(gd[k].cpu(), tr.last_grads[k], k, l2=3e-2, mx=0.2)
 
 
-@pytest.mark.parametrize("algo", [0, 2, 5])
+@pytest.mark.parametrize("algo", [0, 2, 5, 6])
 def test_conv_algorithms_agree_on_a_training_step(algo):
     """ssp_set_conv_algo: the direct implicit-GEMM kernels (0), the un-pipelined Winograd kernels (2) and the pipelined
     kernel with LDS-staged weights (5) give the
