@@ -287,6 +287,9 @@ int ssp_handle_set_conv_algo(ssp_handle* h, int algo);
 /* perf-debug hook: ablate bits (1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA) and grid override of
  * conv_mfma_kernel; (0, 0) restores the product behaviour. */
 int ssp_debug_conv_knobs(int ablate, int grid);
+/* perf-debug hook: workgroups per CU admitted by hipOccupancyMaxActiveBlocksPerMultiprocessor for a kernel family
+ * (0 conv_wino_p2_kernel, 1 conv_wino_pipe_kernel, 2 wgrad_wino_kernel); negative = error */
+int ssp_debug_occupancy(int which);
 
 /* test hook: device pointer of an internal buffer ("gP","gQ","dsemi","ddesc","desc","dsout","Y<l>","scale<l>","shift<l>") */
 int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, size_t* nfloats);

@@ -20,10 +20,30 @@
 // lane; the BatchNorm sums (forward statistics, or pass 1 of the BatchNorm backward of the layer below: ConvArgs::bnr_mode)
 // are reduce-scattered over the 32 tile lanes with 31 wave shuffles into ONE persistent register per lane.
 //
-// Stage pipeline, LDS images of the transformed input, BatchNorm + ReLU on load and the weight image
-// ([cob][chunk8][component][h][64][4], fragments straight from L2) are those of conv_wino_pipe.hip.h.
+// Stage pipeline (8 input channels per stage, transformed input double-buffered in LDS, ONE raw-halo buffer):
+//
+//   stage g, first half : MFMAs of component pairs 0, 1 on sA[g&1]  ||  transform raw(g+1): sR -> sA[~g&1]
+//   barrier A                                        (sA[~g&1] complete; sR free)
+//   stage g, second half: MFMAs of component pairs 2, 3             ||  halo (g+2): registers -> sR (BatchNorm + ReLU of
+//                                                                       the producer), halo loads (g+3) issued
+//   barrier B                                        (sR = raw(g+2) complete)
+//
+// Every MFMA operand is fetched ONE component pair (8 MFMAs = 512 cycles) ahead of its use into one of two register
+// sets: weight fragments from L2 (the packed weight image [cob][chunk8][component][h][64][4] IS the fragment layout),
+// input fragments from LDS - including the first pair of stage g+1, read from sA[~g&1] during the second half of stage g.
+// A wave therefore never waits for an LDS or L2 round trip between two MFMA groups; the first-generation kernel exposed
+// three LDS round trips per stage (tools/ablate_p2.py: the non-MFMA work of a stage was 2700 cycles long and overlapped
+// with the 4096 MFMA cycles of the two waves of a SIMD for 700 cycles only).
+// The raw halo lives in LDS as [row][pixel][8 channels] with a row stride of 592 bytes (8x16 tiles; 320 for 16x8): the
+// transform's ds_read_b128 (pixel column 2 tx + j of rows 2 ty + r over the 32 tiles of a wave) is conflict-free with
+// plain base + j * 32 byte addressing.
 #pragma once
 #include "conv_wino_pipe.hip.h"
+
+#ifndef P2_ABL
+#define P2_ABL 0  // compile-time perf ablation (tools/ablate_p2.py): 1 no epilogue, 2 no halo staging / transform, 4 no barriers
+                  // in the stage loop, 8 no MFMA, 16 no weight loads in the stage loop, 32 no fragment reads from LDS
+#endif
 
 namespace sspk {
 
@@ -31,7 +51,7 @@ constexpr int P2_THREADS = 256;
 constexpr int P2_TILES = 32;                         // Winograd tiles per workgroup
 constexpr int P2_HALO = 180;                         // (8+2) x (16+2) = (16+2) x (8+2) raw halo pixels
 constexpr int P2_A_FLOATS = WC * P2_TILES * PK;      // 4096 floats = 16 KB transformed input per buffer
-constexpr int P2_R_FLOATS = P2_HALO * PK;            // 1440 floats raw halo
+constexpr int P2_R_FLOATS = 1480;                    // raw halo: 10 rows x 592 B (8x16 tiles) / 18 rows x 320 B (16x8)
 constexpr int P2_X_FLOATS = 4 * 8 * 64 * 4;          // exchange buffer: [wave][reg group * 2 + pixel][lane][4] = 32 KB
 constexpr int P2_S_FLOATS = 2048 + NB;               // BatchNorm scale | shift of <= 1024 input channels (or bnr params), bias
 constexpr int P2_LDS_BYTES = (2 * P2_A_FLOATS + P2_R_FLOATS + P2_X_FLOATS + P2_S_FLOATS) * 4;  // 79744
@@ -84,13 +104,14 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
 
   // ---- staging roles ----
   const int q2 = tid & 1;
-  // raw halo items tid + 256 k (k < 2), item = pixel * 2 + quad
+  // raw halo items tid + 256 k (k < 2), item = pixel * 2 + quad; LDS image [row][pixel][8] floats, row stride SROW
+  constexpr int SROW = WIDE ? 148 : 80;
   int rrc[2], r_lds[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int p = (tid + P2_THREADS * k) >> 1, r = p / HC, c = p - r * HC;
     rrc[k] = r | (c << 8);
-    r_lds[k] = pipe_raw_off(p, q2);
+    r_lds[k] = r * SROW + c * PK + q2 * 4;
   }
   const bool r1 = tid + P2_THREADS < P2_HALO * 2;  // the second item exists
   // transform: (quad, tile, V row); the V row is wave-uniform
@@ -100,6 +121,8 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
   const int t_rb = t_row == 2 ? 1 : t_row == 3 ? 3 : 2;
   const float t_sg = t_row == 1 ? 1.f : -1.f;
   const int t_dst = p2_a_off(t_row * 4, t_tile, q2);
+  const int t_u = (2 * t_ty + t_ra) * SROW + 2 * t_tx * PK + q2 * 4;  // + j * PK: pixel column 2 tx + j of raw row ra
+  const int t_w = (2 * t_ty + t_rb) * SROW + 2 * t_tx * PK + q2 * 4;
   const int pixb = a.in_cs * 4, rowb = a.W * pixb;
   f32x4 hreg[2];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
@@ -149,32 +172,26 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
   const int w_voff = (lh * NB + nt * 32 + li) * 16;
   f32x4 wA0 = {0.f, 0.f, 0.f, 0.f}, wA1 = wA0, wB0 = wA0, wB1 = wA0;
 #define P2_WLOAD(S0, S1, C, CHUNK)                                                                          \
-  {                                                                                                         \
+  if (!(P2_ABL & 16) || g < 0) {                                                                            \
     const int so_ = ((cob * nst + (CHUNK)) * PB_FLOATS + (chalf * 8 + (C)) * 2 * NB * 4) * 4;               \
     S0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_, 0));         \
     S1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_ + 2 * NB * 16, 0)); \
   }
 
-  // transform source offsets of the two raw rows of this thread's V row
-  int t_u[4], t_w[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    t_u[j] = pipe_raw_off((2 * t_ty + t_ra) * HC + 2 * t_tx + j, q2);
-    t_w[j] = pipe_raw_off((2 * t_ty + t_rb) * HC + 2 * t_tx + j, q2);
-  }
-#define P2_TRANSFORM(B)                                                                                     \
+  // one V row (4 components) of (tile, quad): sR -> the transformed-input buffer DST
+#define P2_TRANSFORM_READ()                                                                                 \
+  const f32x4 u0 = *reinterpret_cast<const f32x4*>(sR + t_u), w0 = *reinterpret_cast<const f32x4*>(sR + t_w);                     \
+  const f32x4 u1 = *reinterpret_cast<const f32x4*>(sR + t_u + PK), w1 = *reinterpret_cast<const f32x4*>(sR + t_w + PK);           \
+  const f32x4 u2 = *reinterpret_cast<const f32x4*>(sR + t_u + 2 * PK), w2 = *reinterpret_cast<const f32x4*>(sR + t_w + 2 * PK);   \
+  const f32x4 u3 = *reinterpret_cast<const f32x4*>(sR + t_u + 3 * PK), w3 = *reinterpret_cast<const f32x4*>(sR + t_w + 3 * PK);
+#define P2_TRANSFORM_WRITE(DST)                                                                             \
   {                                                                                                         \
-    f32x4 t[4];                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-      const f32x4 u = *reinterpret_cast<const f32x4*>(sR + t_u[j]);                                         \
-      const f32x4 w = *reinterpret_cast<const f32x4*>(sR + t_w[j]);                                         \
-      t[j] = u + t_sg * w;                                                                                  \
-    }                                                                                                       \
-    float* d_ = smem + (B) * P2_A_FLOATS + t_dst;                                                           \
-    *reinterpret_cast<f32x4*>(d_ + 0 * P2_TILES * PK) = t[0] - t[2];                                        \
-    *reinterpret_cast<f32x4*>(d_ + 1 * P2_TILES * PK) = t[1] + t[2];                                        \
-    *reinterpret_cast<f32x4*>(d_ + 2 * P2_TILES * PK) = t[2] - t[1];                                        \
-    *reinterpret_cast<f32x4*>(d_ + 3 * P2_TILES * PK) = t[1] - t[3];                                        \
+    const f32x4 t0 = u0 + t_sg * w0, t1 = u1 + t_sg * w1, t2 = u2 + t_sg * w2, t3 = u3 + t_sg * w3;         \
+    float* d_ = (DST) + t_dst;                                                                              \
+    *reinterpret_cast<f32x4*>(d_ + 0 * P2_TILES * PK) = t0 - t2;                                            \
+    *reinterpret_cast<f32x4*>(d_ + 1 * P2_TILES * PK) = t1 + t2;                                            \
+    *reinterpret_cast<f32x4*>(d_ + 2 * P2_TILES * PK) = t2 - t1;                                            \
+    *reinterpret_cast<f32x4*>(d_ + 3 * P2_TILES * PK) = t1 - t3;                                            \
   }
 
   // ---- per-block parameters in LDS ----
@@ -207,13 +224,19 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
   }
   __syncthreads();
 
-  // ---- prologue: stage 0 into buffer 0, halo loads of stage 1 in flight ----
+  // ---- prologue: sA[0] = transformed stage 0, sR = raw halo of stage 1, halo loads of stage 2 in flight ----
+  int g = -1;  // (the ablation macros test g < 0 = prologue)
   P2_ISSUE_HALO()
   P2_WRITE_RAW()
   __syncthreads();
-  P2_TRANSFORM(0)
+  {
+    P2_TRANSFORM_READ()
+    P2_TRANSFORM_WRITE(smem)
+  }
   P2_ISSUE_HALO()
-  P2_WLOAD(wA0, wA1, 0, 0)
+  __syncthreads();
+  P2_WRITE_RAW()
+  P2_ISSUE_HALO()
   __syncthreads();
 
   f32x16 acc[8];
@@ -223,91 +246,157 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   float stat_acc = 0.f;  // lane li: which = li >> 4 (sum / weighted sum), accumulator register li & 15, summed over tiles
 
-#define P2_FRAG(C, S0, S1)                                                                                  \
-  const float4 i0_##C = *reinterpret_cast<const float4*>(cA + in_off + (C) * P2_TILES * PK);                \
-  const float4 i1_##C = *reinterpret_cast<const float4*>(cA + in_off + ((C) + 1) * P2_TILES * PK);          \
-  const f32x4 w0_##C = S0;                                                                                  \
-  const f32x4 w1_##C = S1;
-#define P2_MFMA_LO(C)                                                                                       \
-  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0_##C[0], i0_##C.x, acc[C], 0, 0, 0);                      \
-  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1_##C[0], i1_##C.x, acc[(C) + 1], 0, 0, 0);          \
-  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0_##C[1], i0_##C.y, acc[C], 0, 0, 0);                      \
-  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1_##C[1], i1_##C.y, acc[(C) + 1], 0, 0, 0);
-#define P2_MFMA_HI(C)                                                                                       \
-  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0_##C[2], i0_##C.z, acc[C], 0, 0, 0);                      \
-  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1_##C[2], i1_##C.z, acc[(C) + 1], 0, 0, 0);          \
-  acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0_##C[3], i0_##C.w, acc[C], 0, 0, 0);                      \
-  acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1_##C[3], i1_##C.w, acc[(C) + 1], 0, 0, 0);
+  // operand fetch: input fragments of component pair (C, C + 1) from the transformed-input buffer BUF, weight fragments
+  // of the same pair of 8-channel chunk CHUNK from L2
+  f32x4 fA0, fA1, fB0, fB1;
+#define P2_FREAD(F0, F1, BUF, C)                                                                            \
+  if (!(P2_ABL & 32) || g < 0) {                                                                            \
+    F0 = *reinterpret_cast<const f32x4*>((BUF) + in_off + (C) * P2_TILES * PK);                             \
+    F1 = *reinterpret_cast<const f32x4*>((BUF) + in_off + ((C) + 1) * P2_TILES * PK);                       \
+  }
+  // ONE MFMA: number I (0..7) of component pair (C, C + 1): component C + (I & 1), k pair I >> 1.  The stage body below
+  // puts a small slice of the staging work behind every single MFMA (fenced with sched_barrier so that the compiler keeps
+  // the order): a wave issues in order, so only instructions placed BETWEEN two of its MFMAs run in the shadow of the
+  // first one (64 cycles of matrix pipe = room for ~10 VALU / LDS / VMEM issues); work placed between two GROUPS of
+  // back-to-back MFMAs adds its issue time to the stage instead (tools/ablate_p2.py: MFMA-only 0.59 ms + non-MFMA-only
+  // 0.37 ms gave 0.86 ms with group-wise placement, also with two independent workgroups per CU).
+#define P2_MM(I, C, W0, W1, F0, F1)                                                                         \
+  if (!(P2_ABL & 8)) {                                                                                      \
+    if (((I) & 1) == 0) acc[C] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[(I) >> 1], F0[(I) >> 1], acc[C], 0, 0, 0);           \
+    else acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[(I) >> 1], F1[(I) >> 1], acc[(C) + 1], 0, 0, 0);              \
+  }                                                                                                         \
+  __builtin_amdgcn_sched_barrier(0);
 #define P2_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+  P2_FREAD(fA0, fA1, smem, 0)
+  P2_WLOAD(wA0, wA1, 0, 0)
+  if (P2_ABL & 32) { fB0 = fA0; fB1 = fA1; }
+  if (P2_ABL & 16) { P2_WLOAD(wB0, wB1, 2, 0) }
+
   int tile = tile0, chunk = 0;
-  for (int g = 0; g < nstages; ++g) {
+  for (g = 0; g < nstages; ++g) {
     const int buf = g & 1;
     const float* const cA = smem + buf * P2_A_FLOATS;
     float* const nA = smem + (buf ^ 1) * P2_A_FLOATS;
-    // ---- first half: components 0..3 of this wave's half || raw halo (stage g+1) -> sR, halo loads of stage g+2 ----
+    // ---- first half: component pairs 0, 1 || transform of stage g+1: sR -> the other buffer ----
     {
-      P2_FRAG(0, wA0, wA1)
+      P2_FREAD(fB0, fB1, cA, 2)
       P2_WLOAD(wB0, wB1, 2, chunk)
       P2_FENCE();
-      P2_MFMA_LO(0)
+#if !(P2_ABL & 2)
+      P2_MM(0, 0, wA0, wA1, fA0, fA1)
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(sR + t_u), w0 = *reinterpret_cast<const f32x4*>(sR + t_w);
       P2_FENCE();
-      P2_WRITE_RAW()
+      P2_MM(1, 0, wA0, wA1, fA0, fA1)
+      const f32x4 u1 = *reinterpret_cast<const f32x4*>(sR + t_u + PK), w1 = *reinterpret_cast<const f32x4*>(sR + t_w + PK);
       P2_FENCE();
-      P2_MFMA_HI(0)
+      P2_MM(2, 0, wA0, wA1, fA0, fA1)
+      const f32x4 u2 = *reinterpret_cast<const f32x4*>(sR + t_u + 2 * PK), w2 = *reinterpret_cast<const f32x4*>(sR + t_w + 2 * PK);
       P2_FENCE();
-      P2_FRAG(2, wB0, wB1)
+      P2_MM(3, 0, wA0, wA1, fA0, fA1)
+      const f32x4 u3 = *reinterpret_cast<const f32x4*>(sR + t_u + 3 * PK), w3 = *reinterpret_cast<const f32x4*>(sR + t_w + 3 * PK);
+      P2_FENCE();
+      P2_MM(4, 0, wA0, wA1, fA0, fA1)
+      const f32x4 t0 = u0 + t_sg * w0;
+      P2_FENCE();
+      P2_MM(5, 0, wA0, wA1, fA0, fA1)
+      const f32x4 t1 = u1 + t_sg * w1;
+      P2_FENCE();
+      P2_MM(6, 0, wA0, wA1, fA0, fA1)
+      const f32x4 t2 = u2 + t_sg * w2;
+      P2_FENCE();
+      P2_MM(7, 0, wA0, wA1, fA0, fA1)
+      const f32x4 t3 = u3 + t_sg * w3;
+      P2_FENCE();
+      P2_FREAD(fA0, fA1, cA, 4)
       P2_WLOAD(wA0, wA1, 4, chunk)
+      P2_FENCE();
+      float* const d_ = nA + t_dst;
+      P2_MM(0, 2, wB0, wB1, fB0, fB1)
+      *reinterpret_cast<f32x4*>(d_ + 0 * P2_TILES * PK) = t0 - t2;
+      P2_FENCE();
+      P2_MM(1, 2, wB0, wB1, fB0, fB1)
+      *reinterpret_cast<f32x4*>(d_ + 1 * P2_TILES * PK) = t1 + t2;
+      P2_FENCE();
+      P2_MM(2, 2, wB0, wB1, fB0, fB1)
+      *reinterpret_cast<f32x4*>(d_ + 2 * P2_TILES * PK) = t2 - t1;
+      P2_FENCE();
+      P2_MM(3, 2, wB0, wB1, fB0, fB1)
+      *reinterpret_cast<f32x4*>(d_ + 3 * P2_TILES * PK) = t1 - t3;
+      P2_FENCE();
+#else
+      P2_MM(0, 0, wA0, wA1, fA0, fA1) P2_MM(1, 0, wA0, wA1, fA0, fA1) P2_MM(2, 0, wA0, wA1, fA0, fA1) P2_MM(3, 0, wA0, wA1, fA0, fA1)
+      P2_MM(4, 0, wA0, wA1, fA0, fA1) P2_MM(5, 0, wA0, wA1, fA0, fA1) P2_MM(6, 0, wA0, wA1, fA0, fA1) P2_MM(7, 0, wA0, wA1, fA0, fA1)
+      P2_FREAD(fA0, fA1, cA, 4)
+      P2_WLOAD(wA0, wA1, 4, chunk)
+      P2_FENCE();
+      P2_MM(0, 2, wB0, wB1, fB0, fB1) P2_MM(1, 2, wB0, wB1, fB0, fB1) P2_MM(2, 2, wB0, wB1, fB0, fB1) P2_MM(3, 2, wB0, wB1, fB0, fB1)
+#endif
+      P2_MM(4, 2, wB0, wB1, fB0, fB1)
+      P2_MM(5, 2, wB0, wB1, fB0, fB1)
+      P2_MM(6, 2, wB0, wB1, fB0, fB1)
+      P2_MM(7, 2, wB0, wB1, fB0, fB1)
+    }
+    if (!(P2_ABL & 4)) __syncthreads();  // barrier A
+    // ---- second half: component pairs 2, 3 || halo (g+2): registers -> sR, halo loads (g+3) ----
+    {
+      P2_FREAD(fB0, fB1, cA, 6)
+      P2_WLOAD(wB0, wB1, 6, chunk)
+      P2_FENCE();
+      P2_MM(0, 4, wA0, wA1, fA0, fA1)
+#if !(P2_ABL & 2)
+      if (IN_MODE != 0) hreg[0] = bn_relu_quad(hreg[0], psc, psh, hoff[0] == OOB);
+      P2_FENCE();
+      P2_MM(1, 4, wA0, wA1, fA0, fA1)
+      *reinterpret_cast<f32x4*>(sR + r_lds[0]) = hreg[0];
+      P2_FENCE();
+      P2_MM(2, 4, wA0, wA1, fA0, fA1)
+      if (IN_MODE != 0) hreg[1] = bn_relu_quad(hreg[1], psc, psh, hoff[1] == OOB);
+      P2_FENCE();
+      P2_MM(3, 4, wA0, wA1, fA0, fA1)
+      if (r1) *reinterpret_cast<f32x4*>(sR + r_lds[1]) = hreg[1];
+      P2_FENCE();
+      P2_MM(4, 4, wA0, wA1, fA0, fA1)
       P2_ISSUE_HALO()  // a full stage ahead of their use
       P2_FENCE();
-      P2_MFMA_LO(2)
-      P2_MFMA_HI(2)
+#else
+      P2_MM(1, 4, wA0, wA1, fA0, fA1) P2_MM(2, 4, wA0, wA1, fA0, fA1) P2_MM(3, 4, wA0, wA1, fA0, fA1) P2_MM(4, 4, wA0, wA1, fA0, fA1)
+#endif
+      P2_MM(5, 4, wA0, wA1, fA0, fA1)
+      P2_MM(6, 4, wA0, wA1, fA0, fA1)
+      P2_MM(7, 4, wA0, wA1, fA0, fA1)
+      P2_FREAD(fA0, fA1, nA, 0)                                        // first pair of the next stage
+      P2_WLOAD(wA0, wA1, 0, (chunk + 1 == nst ? 0 : chunk + 1))
+      P2_FENCE();
+      P2_MM(0, 6, wB0, wB1, fB0, fB1)
+      P2_MM(1, 6, wB0, wB1, fB0, fB1)
+      P2_MM(2, 6, wB0, wB1, fB0, fB1)
+      P2_MM(3, 6, wB0, wB1, fB0, fB1)
+      P2_MM(4, 6, wB0, wB1, fB0, fB1)
+      P2_MM(5, 6, wB0, wB1, fB0, fB1)
+      P2_MM(6, 6, wB0, wB1, fB0, fB1)
+      P2_MM(7, 6, wB0, wB1, fB0, fB1)
     }
-    // the fragments of components 4, 5 come from the SAME buffer: read them before the barrier
-    P2_FRAG(4, wA0, wA1)
-    P2_WLOAD(wB0, wB1, 6, chunk)
-    __syncthreads();
-    // ---- second half: components 4..7 || transform of stage g+1: sR -> the other buffer ----
-    {
-      const f32x4 u0 = *reinterpret_cast<const f32x4*>(sR + t_u[0]), w0 = *reinterpret_cast<const f32x4*>(sR + t_w[0]);
-      const f32x4 u1 = *reinterpret_cast<const f32x4*>(sR + t_u[1]), w1 = *reinterpret_cast<const f32x4*>(sR + t_w[1]);
-      const f32x4 u2 = *reinterpret_cast<const f32x4*>(sR + t_u[2]), w2 = *reinterpret_cast<const f32x4*>(sR + t_w[2]);
-      const f32x4 u3 = *reinterpret_cast<const f32x4*>(sR + t_u[3]), w3 = *reinterpret_cast<const f32x4*>(sR + t_w[3]);
-      P2_FENCE();
-      P2_MFMA_LO(4)
-      P2_FENCE();
-      f32x4 t[4];
-      t[0] = u0 + t_sg * w0;
-      t[1] = u1 + t_sg * w1;
-      t[2] = u2 + t_sg * w2;
-      t[3] = u3 + t_sg * w3;
-      float* d_ = nA + t_dst;
-      *reinterpret_cast<f32x4*>(d_ + 0 * P2_TILES * PK) = t[0] - t[2];
-      *reinterpret_cast<f32x4*>(d_ + 1 * P2_TILES * PK) = t[1] + t[2];
-      P2_FENCE();
-      P2_MFMA_HI(4)
-      P2_FENCE();
-      P2_FRAG(6, wB0, wB1)
-      P2_WLOAD(wA0, wA1, 0, (chunk + 1 == nst ? 0 : chunk + 1))  // first pair of the next stage
-      *reinterpret_cast<f32x4*>(d_ + 2 * P2_TILES * PK) = t[2] - t[1];
-      *reinterpret_cast<f32x4*>(d_ + 3 * P2_TILES * PK) = t[1] - t[3];
-      P2_FENCE();
-      P2_MFMA_LO(6)
-      P2_MFMA_HI(6)
-    }
-    __syncthreads();
+    if (!(P2_ABL & 4)) __syncthreads();  // barrier B
 
-    if (++chunk == nst) {
-      // ---- tile epilogue ----
+    if ((P2_ABL & 1) && ++chunk == nst) {  // ablation: keep the accumulators alive, skip the epilogue
+      if (tid == 1023) p_out[0] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][0] + acc[5][0] + acc[6][0] + acc[7][0];
+      chunk = 0;
+      tile += per_cob;
+    }
+    if (!(P2_ABL & 1) && ++chunk == nst) {
+      // ---- tile epilogue (branch-free on the full-channel path: buffer loads / stores clip the out-of-image pixels) ----
       const int tx_i = tile % a.tiles_x, t2 = tile / a.tiles_x;
       const int ty0 = (t2 % a.tiles_y) * TH, tx0 = tx_i * TW, n = t2 / a.tiles_y;
       // this lane's tile; this wave finishes pixel row `chalf` of its 2x2 outputs (columns px = 0, 1)
       const int oy = ty0 + 2 * (li / TTX) + chalf, ox = tx0 + 2 * (li % TTX);
       const bool in0 = oy < a.H && ox < a.W, in1 = oy < a.H && ox + 1 < a.W;
       const int co_l = nt * 32 + 4 * lh;                 // + 8 g + e: local output channel of register 4 g + e
-      float* const orow = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + cob * NB + co_l;
-      const float* const trow = (IN_MODE == 0 && a.bnr_mode != 0)
-          ? p_bnr + ((size_t)(n * a.H + oy) * a.W + ox) * a.bnr_cs + a.bnr_co + cob * NB + co_l : nullptr;
+      const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+          p_out + (size_t)n * a.H * a.W * a.out_cs, 0, (unsigned)(a.H * a.W * a.out_cs) * 4u, 0x00020000);
+      const unsigned obase = (unsigned)(((oy * a.W + ox) * a.out_cs + a.out_co + cob * NB + co_l) * 4);
+      const unsigned ooff[2] = {in0 ? obase : OOB, in1 ? obase + (unsigned)a.out_cs * 4u : OOB};
+      const f32x4 pmask[2] = {f32x4{1.f, 1.f, 1.f, 1.f} * (in0 ? 1.f : 0.f), f32x4{1.f, 1.f, 1.f, 1.f} * (in1 ? 1.f : 0.f)};
       // output transform Y = A^T M A on this wave's two rows of M: keep[px] = partial of the own pixel row, the other
       // row's partial goes to the partner wave (same channel half, other component half)
       f32x4 keep[2][4];
@@ -338,29 +427,29 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
       for (int c = 0; c < 8; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-      // fused BatchNorm-backward sums: the layer-below tensor of this lane's two pixels, issued once the
-      // accumulators are dead (their latency overlaps the exchange barrier)
+      // fused BatchNorm-backward sums: the layer-below tensor at this lane's two pixels, issued once the accumulators
+      // are dead (the latency overlaps the exchange barrier)
       f32x4 tq[2][4];
       if (IN_MODE == 0 && a.bnr_mode != 0) {
+        const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p_bnr) + (size_t)n * a.H * a.W * a.bnr_cs, 0, (unsigned)(a.H * a.W * a.bnr_cs) * 4u, 0x00020000);
+        const unsigned tbase = (unsigned)(((oy * a.W + ox) * a.bnr_cs + a.bnr_co + cob * NB + co_l) * 4);
+        const unsigned toff[2] = {in0 ? tbase : OOB, in1 ? tbase + (unsigned)a.bnr_cs * 4u : OOB};
 #pragma unroll
         for (int px = 0; px < 2; ++px)
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const bool ok = (px ? in1 : in0) && cob * NB + co_l + 8 * gq + 3 < a.Cout;
-            tq[px][gq] = ok ? *reinterpret_cast<const f32x4*>(trow + px * a.bnr_cs + 8 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+          for (int gq = 0; gq < 4; ++gq)
+            tq[px][gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, toff[px], gq * 32, 0));
       }
       __syncthreads();
+      const bool tail = (cob + 1) * NB > a.Cout;  // block-uniform: channel quads that straddle Cout (operator tests only)
       float st[32];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + co_l + 8 * gq);
-        const int co4 = cob * NB + co_l + 8 * gq;
-        const int nvalid = min(4, a.Cout - co4);
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
           const f32x4 v = keep[px][gq] + *reinterpret_cast<const f32x4*>(xr + (gq * 2 + px) * 256) + bq;
-          const bool ok = (px ? in1 : in0) && nvalid > 0;
           f32x4 s1v, s2v;
           if (IN_MODE == 0 && a.bnr_mode != 0) {
             const f32x4 q0 = *reinterpret_cast<const f32x4*>(sS + co_l + 8 * gq), q1 = *reinterpret_cast<const f32x4*>(sS + NB + co_l + 8 * gq);
@@ -377,24 +466,26 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
 #pragma unroll
               for (int e = 0; e < 4; ++e) dz[e] = t[e] > 0.f ? v[e] : 0.f;
             }
-            s1v = dz; s2v = dz * xh;
+            s1v = dz * pmask[px]; s2v = s1v * xh;
           } else {
-            s1v = v; s2v = v * v;
+            s1v = v * pmask[px]; s2v = s1v * v;
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool oke = ok && e < nvalid;
-            if (px == 0) { st[4 * gq + e] = oke ? s1v[e] : 0.f; st[16 + 4 * gq + e] = oke ? s2v[e] : 0.f; }
-            else { st[4 * gq + e] += oke ? s1v[e] : 0.f; st[16 + 4 * gq + e] += oke ? s2v[e] : 0.f; }
+            if (px == 0) { st[4 * gq + e] = s1v[e]; st[16 + 4 * gq + e] = s2v[e]; }
+            else { st[4 * gq + e] += s1v[e]; st[16 + 4 * gq + e] += s2v[e]; }
           }
-          if (ok) {
-            float* p = orow + px * a.out_cs + 8 * gq;
-            if (nvalid >= 4) {
-              *reinterpret_cast<f32x4*>(p) = v;
-            } else {
+          if (!tail) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_out,
+                                                   ooff[px], gq * 32, 0);
+          } else {
+            const int nvalid = a.Cout - (cob * NB + co_l + 8 * gq);
+            if (ooff[px] != OOB && nvalid > 0) {
+              float* p = p_out + (size_t)n * a.H * a.W * a.out_cs + (ooff[px] >> 2) + 8 * gq;
               p[0] = v[0];
               if (nvalid > 1) p[1] = v[1];
               if (nvalid > 2) p[2] = v[2];
+              if (nvalid > 3) p[3] = v[3];
             }
           }
         }
@@ -421,10 +512,10 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
 #undef P2_ISSUE_HALO
 #undef P2_WRITE_RAW
 #undef P2_WLOAD
-#undef P2_TRANSFORM
-#undef P2_FRAG
-#undef P2_MFMA_LO
-#undef P2_MFMA_HI
+#undef P2_TRANSFORM_READ
+#undef P2_TRANSFORM_WRITE
+#undef P2_FREAD
+#undef P2_MM
 #undef P2_FENCE
 
   if (p_stats != nullptr) {

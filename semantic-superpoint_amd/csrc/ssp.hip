@@ -1767,6 +1767,28 @@ int ssp_set_conv_algo(int algo) {
   return 0;
 }
 
+// test / perf-debug hook: blocks per CU the runtime admits for a kernel family (0: conv_wino_p2_kernel<1, true>,
+// 1: conv_wino_pipe_kernel<1, true, true>, 2: wgrad_wino_kernel<1, true>)
+int ssp_debug_occupancy(int which) {
+  int n = -1;
+  hipError_t e = hipErrorInvalidValue;
+  if (which == 0) {
+    auto k = conv_wino_p2_kernel<1, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, P2_THREADS, P2_LDS_BYTES);
+  } else if (which == 1) {
+    auto k = conv_wino_pipe_kernel<1, true, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, WINO_THREADS, PIPE_LDS_BYTES);
+  } else if (which == 2) {
+    auto k = wgrad_wino_kernel<1, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WgradWinoGeom<true>::LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 512, WgradWinoGeom<true>::LDS_BYTES);
+  }
+  if (e != hipSuccess) return fail(-2, "occupancy query failed: %s", hipGetErrorString(e));
+  return n;
+}
+
 int ssp_debug_conv_knobs(int ablate, int grid) {
   g_dbg_ablate = ablate; g_dbg_grid = grid;
   return 0;

@@ -67,7 +67,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms", "ssp_op_dense_loss",
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
-           "ssp_op_detector_loss"]
+           "ssp_op_detector_loss", "ssp_debug_occupancy"]
 
 
 def load_library(path=None):
@@ -113,6 +113,7 @@ def load_library(path=None):
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.ssp_debug_conv_knobs.argtypes = [i, i]
+    lib.ssp_debug_occupancy.argtypes = [i]
     lib.ssp_set_conv_algo.argtypes = [i]
     lib.ssp_op_warp_image.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.ssp_op_erode.argtypes = [vp, vp, i, i, i, i, vp]
