@@ -325,6 +325,34 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Zero fill on the launch stream as an ordinary kernel.  The pair step clears its accumulation buffers with this instead of
+// hipMemsetAsync: inside a captured hipGraph (ssp_pair_step_graph) memset NODES of some buffers were observed not to take
+// effect on the second and later replays (ROCm 7.2, depending on the allocation layout of the process: the descriptor- and
+// segmentation-gradient buffers kept their previous contents and the atomically accumulated gradients blew up), while
+// kernel nodes replay reliably.  Grid-stride 16-byte stores: the few-hundred-KB buffers of the step are latency-bound.
+// ------------------------------------------------------------------------------------------------
+__global__ void zero_fill_kernel(uint32_t* __restrict__ p, size_t nwords) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  if ((reinterpret_cast<size_t>(p) & 15) == 0) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const size_t nq = nwords >> 2;
+    for (size_t i = tid; i < nq; i += nth) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (nq << 2) + tid; i < nwords; i += nth) p[i] = 0u;
+  } else {
+    for (size_t i = tid; i < nwords; i += nth) p[i] = 0u;
+  }
+}
+static int dev_zero(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if (bytes % 4 != 0 || (reinterpret_cast<size_t>(p) & 3) != 0) return fail(-1, "dev_zero: unaligned range");
+  const size_t nwords = bytes / 4;
+  const int nb = (int)std::min<size_t>((nwords / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), nwords);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 template <int KS, int IN_MODE, int SH, int SW>
@@ -730,7 +758,7 @@ int ssp_bind(ssp_handle* h, const ssp_buffers* b, void* stream) {
 
 int ssp_zero_grad(ssp_handle* h, void* stream) {
   if (!h || !h->bound || !h->buf.grads_dev) return fail(-1, "handle not bound with a gradient buffer");
-  HIPCHK(hipMemsetAsync(h->buf.grads_dev, 0, (h->n_params + 3) * sizeof(float), (hipStream_t)stream));
+  CHK(dev_zero(h->buf.grads_dev, (h->n_params + 3) * sizeof(float), (hipStream_t)stream));
   return 0;
 }
 
@@ -890,7 +918,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     S.N = N; S.H = H; S.W = W; S.x = xs[k];
-    HIPCHK(hipMemsetAsync(S.stats_region, 0, S.stats_bytes, st));
+    CHK(dev_zero(S.stats_region, S.stats_bytes, st));
     S.bsums_dirty = false;
   }
   CHK(pack_all(h, for_backward, st));
@@ -1067,11 +1095,11 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     // when this slot is back-propagated a second time (autograd retain_graph)
     if (S.bsums_dirty) {
       for (int l = 0; l < h->nlayers; ++l)
-        HIPCHK(hipMemsetAsync(S.bn[l].bsums, 0, 2 * (size_t)h->L[l].cout * NREP * sizeof(double), st));
+        CHK(dev_zero(S.bn[l].bsums, 2 * (size_t)h->L[l].cout * NREP * sizeof(double), st));
     }
     S.bsums_dirty = true;
     if (!has_semi || !has_desc || (h->nheads == 3 && !has_sem))
-      HIPCHK(hipMemsetAsync(S.gP, 0, (size_t)N * Hc * Wc * hcs * sizeof(float), st));
+      CHK(dev_zero(S.gP, (size_t)N * Hc * Wc * hcs * sizeof(float), st));
   }
   // ---- 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only); gP = dHeadsAct [cells][hcs], gQ = dY scratch ----
   float* dact[2] = {gP[0], gP[1]};
@@ -1185,7 +1213,7 @@ int ssp_backward(ssp_handle* h, int slot, const float* dsemi_dev, const float* d
   }
   if (dsem_dev) {
     if (h->nheads != 3) return fail(-1, "dsem given for a model without a segmentation head");
-    HIPCHK(hipMemsetAsync(S.dsout, 0, (size_t)ncells * h->sout_cs * sizeof(float), st));
+    CHK(dev_zero(S.dsout, (size_t)ncells * h->sout_cs * sizeof(float), st));
     const long tot = (long)N * h->cfg.n_classes * Hc * Wc;
     hipLaunchKernelGGL(sem_upsample_bwd_nchw_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, dsem_dev, S.dsout, N, Hc, Wc,
                        S.H, S.W, h->cfg.n_classes, h->sout_cs);
@@ -1273,7 +1301,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     for (int v = 0; v < 2; ++v) {
       Slot& S = h->slot[v];
       if (in->train) {  // loss sum and d(convSout) in one pass (coef_sem: step_begin_kernel, sem_cnt: sem_count_kernel)
-        HIPCHK(hipMemsetAsync(S.dsout, 0, (size_t)ncells * h->sout_cs * sizeof(float), st));
+        CHK(dev_zero(S.dsout, (size_t)ncells * h->sout_cs * sizeof(float), st));
         hipLaunchKernelGGL((sem_ce_kernel<3>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
                            h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
       } else {
@@ -1312,8 +1340,8 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
                        h->cfg.n_non);
     hipLaunchKernelGGL(desc_counts_kernel, dim3(1), dim3(64), 0, st, h->accum, B);
     if (in->train) {
-      HIPCHK(hipMemsetAsync(A.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
-      HIPCHK(hipMemsetAsync(Bs.ddesc, 0, (size_t)ncells * 256 * sizeof(float), st));
+      CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), st));
+      CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), st));
       hipLaunchKernelGGL((desc_match_kernel<true>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
                          in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
       hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,

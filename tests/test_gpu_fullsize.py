@@ -304,34 +304,42 @@ def test_phases_equal_whole_step(tag):
 
 
 def test_graph_replay_equals_eager():
-    """ssp_pair_step_graph: three replays with different sampler seeds == the eager steps with the same seeds."""
+    """ssp_pair_step_graph: capture + three replays with different sampler seeds == the eager steps with the same seeds.
+    Both engines start every step from the SAME state (two training runs drift apart on their own: Adam turns the
+    commit-order noise of the atomics into parameter differences of up to lr per element)."""
     arch = ARCHS["ssp"]
     B, H, W = 2, 64, 96
     sd = C.init_state_dict(arch, seed=3)
     ds = _to_dev(C.make_synthetic_pair(B, H, W, seed=8, semantic=True, kp_prob=0.01))
     ea, eb = _engine(arch, B, H, W, sd), _engine(arch, B, H, W, sd)
     st = torch.cuda.Stream()
-    for it, seed in enumerate((11, 12, 99)):
+    seen_idx = []
+    for it, seed in enumerate((11, 12, 99, 12)):
+        for name in ("params", "adam_m", "adam_v", "bn_running", "nbt"):
+            getattr(eb, name).copy_(getattr(ea, name))
+        eb.adam_t = ea.adam_t
+        torch.cuda.synchronize()
         ea.zero_grad()
-        sa = ea.pair_step(ds, indices=None, seed=seed, train=True)
+        sa = ea.pair_step(ds, indices=None, seed=seed, train=True).clone()
         ea.adam_step(0.001)
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
             eb.zero_grad()
-            sb = eb.pair_step(ds, indices=None, seed=seed, train=True, graph=True)
+            sb = eb.pair_step(ds, indices=None, seed=seed, train=True, graph=True).clone()
             eb.adam_step(0.001)
         torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
-        if it == 0:
-            first_idx = eb._graph_idx[0].cpu().clone()
+        seen_idx.append(eb._graph_idx[2].cpu().clone())
+        assert bool(torch.isfinite(ea.grads).all()), it
+        bad = [(k, float(v.abs().max())) for k, v in eb.grad_dict().items() if not bool(torch.isfinite(v).all()) or float(v.abs().max()) > 1e3]
+        assert not bad, (it, bad[:10], len(bad))
         assert (sa - sb).abs().max() < 1e-5 * max(1.0, float(sa.abs().max())), (it, sa, sb)
         l2, mx = _rel(ea.grads, eb.grads)
         assert l2 < 1e-5 and mx < 1e-4, (it, l2, mx)  # atomics: not bit-reproducible between two runs
-        assert (ea.params - eb.params).abs().max() <= 2.2e-3 * (it + 1)  # Adam: lr * sign(g) per step where g ~ 0
         l2, _ = _rel(ea.bn_running, eb.bn_running)
-        assert l2 < 1e-5
-    # a changed seed must change the sampled indices inside the captured graph
-    assert not torch.equal(eb._graph_idx[0].cpu(), first_idx)
+        assert l2 < 1e-6, (it, l2)
+    # the sampler seed lives in device memory: replays with another seed draw other indices, the same seed the same
+    assert not torch.equal(seen_idx[0], seen_idx[1]) and torch.equal(seen_idx[1], seen_idx[3])
 
 
 # ------------------------------------------------------------------------------------------------
