@@ -40,8 +40,9 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_PAIR = {"SuperPointNet_gauss2": 77.98, "SuperPointNet_gauss2_ssmall": 82.72}
 PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3 line)
-DOMINANT_KERNEL = {0: "conv_mfma_kernel", 1: "conv_wino_pipe_kernel", 2: "conv_wino_kernel", 3: "conv_wino_bf16_kernel",
-                   5: "conv_wino_pipe_kernel", 6: "conv_wino_p2_kernel"}  # 3x3 forward + data-gradient kernel per --conv-algo
+# kernels of the 3x3 forward + data-gradient launches per --conv-algo (algo 1 runs the small 30x40 maps on the p2 kernel)
+DOMINANT_KERNEL = {0: ("conv_mfma_kernel<3",), 1: ("conv_wino_pipe_kernel", "conv_wino_p2_kernel"), 2: ("conv_wino_kernel",),
+                   3: ("conv_wino_bf16_kernel",), 5: ("conv_wino_pipe_kernel",), 6: ("conv_wino_p2_kernel",)}
 
 
 def cpu_baseline(arch, H, W, batch=32, steps=3):
@@ -151,7 +152,7 @@ def live_traffic(args):
                 return None, "no counter_collection.csv from rocprofv3"
             s, seen = 0.0, set()
             for row in csv.DictReader(open(files[0])):
-                if DOMINANT_KERNEL[args.conv_algo] in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                if any(k in row["Kernel_Name"] for k in DOMINANT_KERNEL[args.conv_algo]) and row["Counter_Name"] == ctr:
                     s += float(row["Counter_Value"])
                     seen.add(row["Dispatch_Id"])
             tot[ctr], launches[ctr] = s, len(seen)
@@ -295,7 +296,7 @@ def main():
                 peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
                 exec_ratio = 1.0 if args.conv_algo == 0 else 16.0 / 36.0  # Winograd executes 16 of 36 multiplies
                 out["roofline"] = {"bound": "mfma", "kernel": "%s (3x3 forward + data-gradient, %s on v_mfma_f32_32x32x2_f32)"
-                                                              % (DOMINANT_KERNEL[args.conv_algo], "direct implicit GEMM"
+                                                              % (" + ".join(DOMINANT_KERNEL[args.conv_algo]), "direct implicit GEMM"
                                                                  if args.conv_algo == 0 else "Winograd F(2x2,3x3)"),
                                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4),

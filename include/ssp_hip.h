@@ -90,6 +90,10 @@ typedef struct {
   int dense_loss;
   float dense_lamda_d;
   float descriptor_dist;
+  /* optional [B,3,3]: the CELL-space homographies scale_homography_torch(H, (Hc, Wc)) (utils/homographies.py:270-276)
+   * computed by the caller on the host with the reference's own fp32 op sequence; used by the captured device sampler
+   * (ssp_pair_step_graph) - see ssp_sample_indices_cell */
+  const float* cell_homographies_dev;
 } ssp_pair_inputs;
 
 /* indices into the float scalars[SSP_N_SCALARS] array filled by ssp_pair_step (the reference's
@@ -143,6 +147,14 @@ int ssp_pair_step_graph(ssp_handle* h, const ssp_pair_inputs* in, float* scalars
                         void* stream);
 int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
                        int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream);
+/* Index parity: every kernel that warps integer coordinates takes the homography in the space of those coordinates.  With
+ * the *_cell / *_px entry points the caller passes T^-1 H T computed on the HOST exactly like the reference
+ * (torch.inverse(trans) @ H @ trans: scale_homography_torch / homography_scaling_torch) and the device applies the
+ * reference's own fp32 operation order (fma chain of torch's CPU matmul, correctly rounded division, round half to even):
+ * warped integer indices are then bit-identical to the reference's.  The plain entry points derive T^-1 H T analytically
+ * on the device; coordinates within ~1e-4 of a .5 boundary may then round the other way. */
+int ssp_sample_indices_cell(ssp_handle* h, const float* cell_homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
+                            int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream);
 
 /* timing hook for bench.py: when enabled, every launch of the tagged kernel family is bracketed by
  * hipEvents on `stream`; ssp_profile_read returns accumulated milliseconds, launches and FLOPs. */
@@ -185,6 +197,7 @@ int ssp_op_warp_image(const float* img_dev, const float* inv_h_dev, float* out_d
                       void* stream);
 int ssp_op_erode(const float* mask_dev, float* out_dev, int b, int h, int w, int radius, void* stream);
 int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_dev, int b, int h, int w, void* stream);
+int ssp_op_warp_labels_px(const float* labels_dev, const float* hpx_dev, float* out_dev, int b, int h, int w, void* stream);
 
 /* Pair construction for real data:
  * ssp_op_sample_homographies: sample_homography_np (utils/homographies.py:12-141) with the keys of
@@ -203,6 +216,8 @@ int ssp_op_sample_homographies(uint64_t seed, const ssp_homography_params* p, in
                                void* stream);
 int ssp_op_warp_labels_full(const float* labels_dev, const float* h_dev, float* labels_out_dev, float* res_out_dev,
                             float* bi_out_dev, int b, int h, int w, void* stream);
+int ssp_op_warp_labels_full_px(const float* labels_dev, const float* hpx_dev, float* labels_out_dev, float* res_out_dev,
+                               float* bi_out_dev, int b, int h, int w, void* stream);
 int ssp_op_sem_finalize(const float* sem_warped_dev, const float* valid_dev, int64_t* out_dev, size_t n, int n_classes,
                         void* stream);
 

@@ -205,6 +205,10 @@ class Train_model_heatmap_all(object):
         self.batch_size = B
         eng = self._engine_for(B, H, W)
         dev = {k: (v.to(self.device, non_blocking=True).contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
+        if "cell_homographies" not in dev and not sample["homographies"].is_cuda:
+            # the loader's homographies are host tensors: scale them to cell coordinates with the reference's own op
+            # sequence here, so that the device sampler's matches round exactly like descriptor_loss_sparse's
+            dev["cell_homographies"] = L.scaled_homographies(sample["homographies"], H // 8, W // 8).to(self.device)
         for k in ("image", "warped_img", "labels_2D", "warped_labels", "valid_mask", "warped_valid_mask",
                   "labels_2D_gaussian", "warped_labels_gaussian"):
             if k in dev:

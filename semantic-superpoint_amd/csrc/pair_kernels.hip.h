@@ -75,17 +75,23 @@ __global__ void erode_ellipse_kernel(const float* __restrict__ mask, float* __re
   out[idx] = v;
 }
 
-// labels: [B,1,H,W] keypoint map (non-zero = keypoint at integer (x,y)); hn: [B,3,3] normalised homography
-// (image -> warped).  out must be zero-filled.  Pixel homography = T^-1 H T, T = [[2/W,0,-1],[0,2/H,-1],[0,0,1]].
-__global__ void warp_labels_kernel(const float* __restrict__ labels, const float* __restrict__ hn, float* __restrict__ out,
-                                   int B, int H, int W) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * H * W) return;
-  if (labels[idx] == 0.f) return;
-  const int x = (int)(idx % W), y = (int)((idx / W) % H), n = (int)(idx / ((long)W * H));
-  const float* h = hn + n * 9;
+// warp_points (utils/utils.py:315-343) of ONE integer point with a PIXEL-space homography P (row-major 9 floats) in the
+// reference's own fp32 operation order: torch's CPU `homographies @ points^T` accumulates k = 0, 1, 2 as
+// fma(p2, 1, fma(p1, y, p0 * x)) (oneMKL sgemm; verified bit for bit against the oracle for 12 <= N <= 76800 points,
+// tests/test_boundary_cpu.py), then the correctly rounded division.  With P computed by the caller exactly like the
+// reference (homography_scaling_torch / scale_homography_torch on the host) the warped coordinates - and therefore every
+// rounded index derived from them - are bit-identical to the reference's.
+__device__ __forceinline__ void warp_point_exact(const float* __restrict__ P, float x, float y, float& wx, float& wy) {
+  const float X = __fadd_rn(__fmaf_rn(P[1], y, __fmul_rn(P[0], x)), P[2]);
+  const float Y = __fadd_rn(__fmaf_rn(P[4], y, __fmul_rn(P[3], x)), P[5]);
+  const float Z = __fadd_rn(__fmaf_rn(P[7], y, __fmul_rn(P[6], x)), P[8]);
+  wx = __fdiv_rn(X, Z);
+  wy = __fdiv_rn(Y, Z);
+}
+// pixel-space homography T^-1 H T computed analytically on the device (no host matrix given): same value up to fp32
+// rounding of a different operation order, so warped coordinates within ~1e-4 of a .5 boundary may round the other way
+__device__ __forceinline__ void pixel_homography_analytic(const float* __restrict__ h, int H, int W, float* __restrict__ P) {
   const float a = 2.f / (float)W, b = 2.f / (float)H;
-  // M = H @ T
   float M[9];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -93,17 +99,32 @@ __global__ void warp_labels_kernel(const float* __restrict__ labels, const float
     M[r * 3 + 1] = h[r * 3 + 1] * b;
     M[r * 3 + 2] = -h[r * 3 + 0] - h[r * 3 + 1] + h[r * 3 + 2];
   }
-  // P = T^-1 @ M, T^-1 = [[1/a,0,1/a],[0,1/b,1/b],[0,0,1]]
-  float P[9];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     P[0 * 3 + c] = (M[0 * 3 + c] + M[2 * 3 + c]) / a;
     P[1 * 3 + c] = (M[1 * 3 + c] + M[2 * 3 + c]) / b;
     P[2 * 3 + c] = M[2 * 3 + c];
   }
-  const float fx = (float)x, fy = (float)y;
-  const float X = P[0] * fx + P[1] * fy + P[2], Y = P[3] * fx + P[4] * fy + P[5], Z = P[6] * fx + P[7] * fy + P[8];
-  const float wx = X / Z, wy = Y / Z;
+}
+
+
+// labels: [B,1,H,W] keypoint map (non-zero = keypoint at integer (x,y)); hn: [B,3,3] normalised homography
+// (image -> warped).  out must be zero-filled.  Pixel homography = T^-1 H T, T = [[2/W,0,-1],[0,2/H,-1],[0,0,1]].
+__global__ void warp_labels_kernel(const float* __restrict__ labels, const float* __restrict__ hn, const float* __restrict__ hpx,
+                                   float* __restrict__ out, int B, int H, int W) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H * W) return;
+  if (labels[idx] == 0.f) return;
+  const int x = (int)(idx % W), y = (int)((idx / W) % H), n = (int)(idx / ((long)W * H));
+  float P[9];
+  if (hpx != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P[k] = hpx[n * 9 + k];
+  } else {
+    pixel_homography_analytic(hn + n * 9, H, W, P);
+  }
+  float wx, wy;
+  warp_point_exact(P, (float)x, (float)y, wx, wy);
   if (wx >= 0.f && wx <= (float)(W - 1) && wy >= 0.f && wy <= (float)(H - 1)) {
     const int qx = (int)rintf(wx), qy = (int)rintf(wy);  // torch.round: half to even
     out[((size_t)n * H + qy) * W + qx] = 1.f;
@@ -117,30 +138,21 @@ __global__ void warp_labels_kernel(const float* __restrict__ labels, const float
 //                      neighbours are range-filtered individually) receive their bilinear weight
 // All three must be zero-filled; scatters are last-write-wins like torch's index_put.
 __global__ void warp_labels_full_kernel(const float* __restrict__ labels, const float* __restrict__ hn,
-                                        float* __restrict__ out_lab, float* __restrict__ out_res,
-                                        float* __restrict__ out_bi, int B, int H, int W) {
+                                        const float* __restrict__ hpx, float* __restrict__ out_lab,
+                                        float* __restrict__ out_res, float* __restrict__ out_bi, int B, int H, int W) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * H * W) return;
   if (labels[idx] == 0.f) return;
   const int x = (int)(idx % W), y = (int)((idx / W) % H), n = (int)(idx / ((long)W * H));
-  const float* h = hn + n * 9;
-  const float a = 2.f / (float)W, b = 2.f / (float)H;
-  float M[9], P[9];
+  float P[9];
+  if (hpx != nullptr) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    M[r * 3 + 0] = h[r * 3 + 0] * a;
-    M[r * 3 + 1] = h[r * 3 + 1] * b;
-    M[r * 3 + 2] = -h[r * 3 + 0] - h[r * 3 + 1] + h[r * 3 + 2];
+    for (int k = 0; k < 9; ++k) P[k] = hpx[n * 9 + k];
+  } else {
+    pixel_homography_analytic(hn + n * 9, H, W, P);
   }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    P[0 * 3 + c] = (M[0 * 3 + c] + M[2 * 3 + c]) / a;
-    P[1 * 3 + c] = (M[1 * 3 + c] + M[2 * 3 + c]) / b;
-    P[2 * 3 + c] = M[2 * 3 + c];
-  }
-  const float fx = (float)x, fy = (float)y;
-  const float X = P[0] * fx + P[1] * fy + P[2], Y = P[3] * fx + P[4] * fy + P[5], Z = P[6] * fx + P[7] * fy + P[8];
-  const float wx = X / Z, wy = Y / Z;
+  float wx, wy;
+  warp_point_exact(P, (float)x, (float)y, wx, wy);
   const size_t img = (size_t)n * H * W;
   auto inside = [&](float px, float py) { return px >= 0.f && px <= (float)(W - 1) && py >= 0.f && py <= (float)(H - 1); };
   if (out_bi != nullptr && fabsf(wx) < 1e9f && fabsf(wy) < 1e9f) {

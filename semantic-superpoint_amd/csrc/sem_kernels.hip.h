@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "loss_kernels.hip.h"
+#include "pair_kernels.hip.h"
 
 namespace sspk {
 
@@ -232,8 +233,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 // One block of 1024 threads per image.  match_a/match_b: [B][n_match] cell indices (u + v*Wc).
-__global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __restrict__ Hn, uint64_t seed_arg,
-                                                              const uint64_t* __restrict__ seed_dev,
+__global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __restrict__ Hn, const float* __restrict__ Hcell,
+                                                              uint64_t seed_arg, const uint64_t* __restrict__ seed_dev,
                                                               int32_t* __restrict__ match_a, int32_t* __restrict__ match_b,
                                                               int Hc, int Wc, int n_match, int cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sampler_smem[];  // 12 bytes per key slot
@@ -245,20 +246,14 @@ __global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __res
   const int ncell = Hc * Wc;
   const uint64_t seed = seed_arg + (seed_dev ? *seed_dev : 0);  // captured steps keep the seed in device memory
   if (tid == 0) {
-    // H_cell = inv(T) @ H @ T, T = [[2/Wc,0,-1],[0,2/Hc,-1],[0,0,1]]  (utils/homographies.py:270-276)
-    const float* h = Hn + img * 9;
-    const float a = 2.f / Wc, b = 2.f / Hc;
-    float M[9];  // H @ T
-    for (int r = 0; r < 3; ++r) {
-      M[r * 3 + 0] = h[r * 3 + 0] * a;
-      M[r * 3 + 1] = h[r * 3 + 1] * b;
-      M[r * 3 + 2] = -h[r * 3 + 0] - h[r * 3 + 1] + h[r * 3 + 2];
-    }
-    // inv(T) = [[1/a,0,1/a],[0,1/b,1/b],[0,0,1]]
-    for (int c = 0; c < 3; ++c) {
-      Hs[0 * 3 + c] = (M[0 * 3 + c] + M[2 * 3 + c]) / a;
-      Hs[1 * 3 + c] = (M[1 * 3 + c] + M[2 * 3 + c]) / b;
-      Hs[2 * 3 + c] = M[2 * 3 + c];
+    // H_cell = inv(T) @ H @ T, T = [[2/Wc,0,-1],[0,2/Hc,-1],[0,0,1]]  (utils/homographies.py:270-276): the caller's host
+    // matrix (the reference's own op sequence -> bit-identical matches) or the analytic form
+    if (Hcell != nullptr) {
+      for (int k = 0; k < 9; ++k) Hs[k] = Hcell[img * 9 + k];
+    } else {
+      float P[9];
+      pixel_homography_analytic(Hn + img * 9, Hc, Wc, P);
+      for (int k = 0; k < 9; ++k) Hs[k] = P[k];
     }
     nvalid = 0;
   }
@@ -268,8 +263,9 @@ __global__ __launch_bounds__(1024) void sample_matches_kernel(const float* __res
     int32_t cb = 0;
     if (i < ncell) {
       const float u = (float)(i % Wc), v = (float)(i / Wc);
-      const float X = Hs[0] * u + Hs[1] * v + Hs[2], Y = Hs[3] * u + Hs[4] * v + Hs[5], Z = Hs[6] * u + Hs[7] * v + Hs[8];
-      const float ub = rintf(X / Z), vb = rintf(Y / Z);  // torch.round: half to even
+      float wu, wv;
+      warp_point_exact(Hs, u, v, wu, wv);
+      const float ub = rintf(wu), vb = rintf(wv);  // torch.round: half to even
       if (ub >= 0.f && ub <= (float)(Wc - 1) && vb >= 0.f && vb <= (float)(Hc - 1)) {
         const uint32_t r = (uint32_t)(splitmix64(seed ^ ((uint64_t)img << 40) ^ (uint64_t)i) >> 33);  // 31 bits
         k = ((uint64_t)r << 32) | (uint32_t)i;

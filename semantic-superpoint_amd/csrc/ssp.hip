@@ -469,7 +469,15 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   a.ablate = g_dbg_ablate;
   // tile geometry: second-generation Winograd kernel (algo 6): 32 tiles = 8x16 / 16x8 pixels per 4-wave workgroup;
   // everything else: 64 tiles (Winograd) or 256 pixels (direct) = 8x32 / 32x8 per workgroup
-  const bool p2 = c.wino && g_conv_algo == 6;
+  // default algorithm (1): maps with few first-generation work items per CU (the 30x40 layers: 640 items on 256 CUs =
+  // 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
+  // large maps: tools/conv_probe.py)
+  bool p2 = c.wino && g_conv_algo == 6;
+  if (c.wino && g_conv_algo == 1) {
+    const bool w1 = (c.W % 32) == 0;
+    const long items = (long)c.nprob * c.N * cdiv(c.H, w1 ? 8 : 32) * cdiv(c.W, w1 ? 32 : 8) * c.ncob;
+    p2 = items < 4L * (h ? h->n_cu : 256);
+  }
   const bool wide = p2 ? (c.W % 16) == 0 : (c.W % 32) == 0;
   const int TH = p2 ? (wide ? 8 : 16) : (wide ? 8 : 32), TW = p2 ? (wide ? 16 : 8) : (wide ? 32 : 8);
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
@@ -1367,9 +1375,11 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   return 0;
 }
 
-static int sample_indices_impl(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, const uint64_t* seed_dev,
-                               int32_t* match_a_dev, int32_t* match_b_dev, int32_t* nonmatch_b_dev, hipStream_t st) {
+static int sample_indices_impl(ssp_handle* h, const float* homographies_dev, const float* hcell_dev, int batch, uint64_t seed,
+                               const uint64_t* seed_dev, int32_t* match_a_dev, int32_t* match_b_dev, int32_t* nonmatch_b_dev,
+                               hipStream_t st) {
   if (!h) return fail(-1, "null handle");
+  if (!homographies_dev && !hcell_dev) return fail(-1, "sample_indices: homographies required");
   if (batch < 1 || batch > 64) return fail(-1, "batch out of range");
   const int Hc = h->cfg.height / 8, Wc = h->cfg.width / 8;
   if (Hc * Wc > SAMPLER_MAX_CELLS) return fail(-1, "sampler supports at most %d cells", SAMPLER_MAX_CELLS);
@@ -1381,8 +1391,8 @@ static int sample_indices_impl(ssp_handle* h, const float* homographies_dev, int
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_matches_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                SAMPLER_MAX_CELLS * 12));
   }
-  hipLaunchKernelGGL(sample_matches_kernel, dim3(batch), dim3(1024), (size_t)cap * 12, st, homographies_dev, seed, seed_dev,
-                     match_a_dev, match_b_dev, Hc, Wc, h->cfg.n_match, cap);
+  hipLaunchKernelGGL(sample_matches_kernel, dim3(batch), dim3(1024), (size_t)cap * 12, st, homographies_dev, hcell_dev, seed,
+                     seed_dev, match_a_dev, match_b_dev, Hc, Wc, h->cfg.n_match, cap);
   const long tot = (long)batch * h->cfg.n_match * h->cfg.n_non;
   hipLaunchKernelGGL(sample_nonmatches_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, seed, seed_dev, nonmatch_b_dev, tot, Hc,
                      Wc);
@@ -1458,7 +1468,8 @@ int ssp_pair_step_graph(ssp_handle* h, const ssp_pair_inputs* in, float* scalars
     int rc = 0;
     if (sample_indices && phase != 2) {
       if (!in->match_a_dev || !in->match_b_dev || !in->nonmatch_b_dev) rc = fail(-1, "graph step: index buffers required");
-      else rc = sample_indices_impl(h, in->homographies_dev, in->batch, 0, h->graph_seed, const_cast<int32_t*>(in->match_a_dev),
+      else rc = sample_indices_impl(h, in->homographies_dev, in->cell_homographies_dev, in->batch, 0, h->graph_seed,
+                                    const_cast<int32_t*>(in->match_a_dev),
                                     const_cast<int32_t*>(in->match_b_dev), const_cast<int32_t*>(in->nonmatch_b_dev), st);
     }
     if (rc == 0) rc = pair_step_impl(h, in, scalars_dev, phase, st);
@@ -1480,7 +1491,14 @@ int ssp_pair_step_graph(ssp_handle* h, const ssp_pair_inputs* in, float* scalars
 
 int ssp_sample_indices(ssp_handle* h, const float* homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
                        int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream) {
-  return sample_indices_impl(h, homographies_dev, batch, seed, nullptr, match_a_dev, match_b_dev, nonmatch_b_dev,
+  return sample_indices_impl(h, homographies_dev, nullptr, batch, seed, nullptr, match_a_dev, match_b_dev, nonmatch_b_dev,
+                             (hipStream_t)stream);
+}
+
+int ssp_sample_indices_cell(ssp_handle* h, const float* cell_homographies_dev, int batch, uint64_t seed, int32_t* match_a_dev,
+                            int32_t* match_b_dev, int32_t* nonmatch_b_dev, void* stream) {
+  if (!cell_homographies_dev) return fail(-1, "sample_indices_cell: cell homographies required");
+  return sample_indices_impl(h, nullptr, cell_homographies_dev, batch, seed, nullptr, match_a_dev, match_b_dev, nonmatch_b_dev,
                              (hipStream_t)stream);
 }
 
@@ -1538,13 +1556,20 @@ int ssp_op_erode(const float* mask_dev, float* out_dev, int b, int hh, int w, in
   return 0;
 }
 
-int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_dev, int b, int hh, int w, void* stream) {
+static int warp_labels_impl(const float* labels_dev, const float* h_dev, const float* hpx_dev, float* out_dev, int b, int hh,
+                            int w, hipStream_t st) {
   const long n = (long)b * hh * w;
-  HIPCHK(hipMemsetAsync(out_dev, 0, n * sizeof(float), (hipStream_t)stream));
-  hipLaunchKernelGGL(warp_labels_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, labels_dev, h_dev, out_dev,
-                     b, hh, w);
+  HIPCHK(hipMemsetAsync(out_dev, 0, n * sizeof(float), st));
+  hipLaunchKernelGGL(warp_labels_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, labels_dev, h_dev, hpx_dev, out_dev, b, hh, w);
   HIPCHK(hipGetLastError());
   return 0;
+}
+int ssp_op_warp_labels(const float* labels_dev, const float* h_dev, float* out_dev, int b, int hh, int w, void* stream) {
+  return warp_labels_impl(labels_dev, h_dev, nullptr, out_dev, b, hh, w, (hipStream_t)stream);
+}
+int ssp_op_warp_labels_px(const float* labels_dev, const float* hpx_dev, float* out_dev, int b, int hh, int w, void* stream) {
+  if (!hpx_dev) return fail(-1, "warp_labels_px: pixel-space homographies required");
+  return warp_labels_impl(labels_dev, nullptr, hpx_dev, out_dev, b, hh, w, (hipStream_t)stream);
 }
 
 // ---- homography-adaptation export ----
@@ -1743,17 +1768,25 @@ int ssp_op_sample_homographies(uint64_t seed, const ssp_homography_params* p, in
   return 0;
 }
 
-int ssp_op_warp_labels_full(const float* labels_dev, const float* h_dev, float* labels_out_dev, float* res_out_dev,
-                            float* bi_out_dev, int b, int hh, int w, void* stream) {
+static int warp_labels_full_impl(const float* labels_dev, const float* h_dev, const float* hpx_dev, float* labels_out_dev,
+                                 float* res_out_dev, float* bi_out_dev, int b, int hh, int w, hipStream_t st) {
   const long n = (long)b * hh * w;
-  hipStream_t st = (hipStream_t)stream;
   if (labels_out_dev) HIPCHK(hipMemsetAsync(labels_out_dev, 0, n * sizeof(float), st));
   if (res_out_dev) HIPCHK(hipMemsetAsync(res_out_dev, 0, 2 * n * sizeof(float), st));
   if (bi_out_dev) HIPCHK(hipMemsetAsync(bi_out_dev, 0, n * sizeof(float), st));
-  hipLaunchKernelGGL(warp_labels_full_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, labels_dev, h_dev, labels_out_dev,
+  hipLaunchKernelGGL(warp_labels_full_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, labels_dev, h_dev, hpx_dev, labels_out_dev,
                      res_out_dev, bi_out_dev, b, hh, w);
   HIPCHK(hipGetLastError());
   return 0;
+}
+int ssp_op_warp_labels_full(const float* labels_dev, const float* h_dev, float* labels_out_dev, float* res_out_dev,
+                            float* bi_out_dev, int b, int hh, int w, void* stream) {
+  return warp_labels_full_impl(labels_dev, h_dev, nullptr, labels_out_dev, res_out_dev, bi_out_dev, b, hh, w, (hipStream_t)stream);
+}
+int ssp_op_warp_labels_full_px(const float* labels_dev, const float* hpx_dev, float* labels_out_dev, float* res_out_dev,
+                               float* bi_out_dev, int b, int hh, int w, void* stream) {
+  if (!hpx_dev) return fail(-1, "warp_labels_full_px: pixel-space homographies required");
+  return warp_labels_full_impl(labels_dev, nullptr, hpx_dev, labels_out_dev, res_out_dev, bi_out_dev, b, hh, w, (hipStream_t)stream);
 }
 
 int ssp_op_sem_finalize(const float* sem_warped_dev, const float* valid_dev, int64_t* out_dev, size_t n, int n_classes,

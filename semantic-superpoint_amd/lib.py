@@ -40,7 +40,7 @@ class SspPairInputs(C.Structure):
                 ("warped_semantic_dev", C.c_void_p), ("match_a_dev", C.c_void_p), ("match_b_dev", C.c_void_p),
                 ("nonmatch_b_dev", C.c_void_p), ("seed", C.c_uint64), ("lambda_loss", C.c_float),
                 ("lamda_d", C.c_float), ("multi_task", C.c_int), ("train", C.c_int), ("dense_loss", C.c_int),
-                ("dense_lamda_d", C.c_float), ("descriptor_dist", C.c_float)]
+                ("dense_lamda_d", C.c_float), ("descriptor_dist", C.c_float), ("cell_homographies_dev", C.c_void_p)]
 
 
 class SspHomographyParams(C.Structure):
@@ -67,7 +67,8 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms", "ssp_op_dense_loss",
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
-           "ssp_op_detector_loss", "ssp_debug_occupancy"]
+           "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
+           "ssp_op_warp_labels_full_px"]
 
 
 def load_library(path=None):
@@ -106,6 +107,9 @@ def load_library(path=None):
     lib.ssp_handle_set_conv_algo.argtypes = [vp, i]
     lib.ssp_op_detector_loss.argtypes = [vp, i, vp, vp, i, i, i, vp, C.c_size_t, vp, vp, vp]
     lib.ssp_sample_indices.argtypes = [vp, vp, i, C.c_uint64, vp, vp, vp, vp]
+    lib.ssp_sample_indices_cell.argtypes = [vp, vp, i, C.c_uint64, vp, vp, vp, vp]
+    lib.ssp_op_warp_labels_px.argtypes = [vp, vp, vp, i, i, i, vp]
+    lib.ssp_op_warp_labels_full_px.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_profile_enable.argtypes = [vp, i]
     lib.ssp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
@@ -165,6 +169,19 @@ def _need_gpu(t, name):
         raise RuntimeError("%s must live on a HIP device: the MI355X path has no CPU fallback" % name)
     if not t.is_contiguous():
         raise RuntimeError("%s must be contiguous" % name)
+
+
+def scaled_homographies(hn, height, width):
+    """T^-1 @ H @ T with T = [[2/width, 0, -1], [0, 2/height, -1], [0, 0, 1]] for a batch of normalised homographies,
+    computed on the HOST with the reference's own fp32 op sequence (`torch.inverse(trans) @ H @ trans`, per matrix:
+    utils/utils.py:297-300 homography_scaling_torch, utils/homographies.py:270-276 scale_homography_torch), so that the
+    matrix - and with it every integer index the device derives from it - is bit-identical to the reference's.
+    (height, width) = (H, W) for pixel coordinates (warpLabels), (H/8, W/8) for cell coordinates (sparse-loss matches).
+    hn: [B,3,3] on any device (a device tensor costs one small D2H copy); returns a CPU float32 tensor [B,3,3]."""
+    h = hn.detach().to("cpu", torch.float32).reshape(-1, 3, 3)
+    trans = torch.tensor([[2.0 / width, 0.0, -1.0], [0.0, 2.0 / height, -1.0], [0.0, 0.0, 1.0]])
+    inv = torch.inverse(trans)
+    return torch.stack([inv @ m @ trans for m in h]).contiguous()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -357,7 +374,10 @@ class Engine:
         """First element of the gradient bucket that is final after phase 1 of a split pair step."""
         return int(self.lib.ssp_grad_early_offset(self.h))
 
-    def sample_indices(self, homographies, seed):
+    def sample_indices(self, homographies, seed, cell_homographies=None):
+        """Device sampler of the sparse-loss indices.  cell_homographies ([B,3,3], host or device): the reference's
+        scale_homography_torch matrices (`scaled_homographies(H, Hc, Wc)`): the sampled matches are then exact
+        correspondences of the reference (bit-identical rounding); without them T^-1 H T is derived on the device."""
         _need_gpu(homographies, "homographies")
         B = homographies.shape[0]
         i32 = dict(dtype=torch.int32, device=self.device)
@@ -365,8 +385,14 @@ class Engine:
         mb = torch.empty(B, self.n_match, **i32)
         nm = torch.empty(B, self.n_match * self.n_non, **i32)
         with torch.cuda.device(self.device):
-            _check(self.lib.ssp_sample_indices(self.h, _ptr(homographies), B, int(seed), _ptr(ma), _ptr(mb), _ptr(nm),
-                                               _stream()))
+            if cell_homographies is not None:
+                hc = cell_homographies.to(self.device, torch.float32).contiguous()
+                assert tuple(hc.shape) == (B, 3, 3)
+                self._keep_hc = hc
+                _check(self.lib.ssp_sample_indices_cell(self.h, _ptr(hc), B, int(seed), _ptr(ma), _ptr(mb), _ptr(nm), _stream()))
+            else:
+                _check(self.lib.ssp_sample_indices(self.h, _ptr(homographies), B, int(seed), _ptr(ma), _ptr(mb), _ptr(nm),
+                                                   _stream()))
         return ma, mb, nm
 
     def pair_step(self, sample, indices=None, seed=0, train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True,
@@ -411,7 +437,7 @@ class Engine:
                 indices = self._graph_idx
                 sample_in_graph = True
             elif phase != 2:
-                indices = self._last_idx = self.sample_indices(Hm, seed)
+                indices = self._last_idx = self.sample_indices(Hm, seed, sample.get("cell_homographies"))
             else:
                 indices = self._last_idx
         if indices is not None:
@@ -440,8 +466,15 @@ class Engine:
                             _ptr(sample["warped_valid_mask"]), _ptr(Hm), _ptr(sem), _ptr(semw), _ptr(ma), _ptr(mb),
                             _ptr(nm), int(seed) & 0xFFFFFFFFFFFFFFFF, float(lambda_loss), float(lamda_d),
                             int(bool(multi_task)), int(bool(train)), int(dense is not None),
-                            float((dense or {}).get("lamda_d", 250.0)), float((dense or {}).get("descriptor_dist", 4.0)))
-        self._keep = (req, Hm, indices, sem, semw)  # keep alive until the stream has consumed them
+                            float((dense or {}).get("lamda_d", 250.0)), float((dense or {}).get("descriptor_dist", 4.0)),
+                            None)
+        hcell = sample.get("cell_homographies")
+        if hcell is not None:  # the reference's own cell-space matrices (scaled_homographies): exact match indices
+            _need_gpu(hcell, "cell_homographies")
+            if hcell.dtype != torch.float32 or tuple(hcell.shape) != (B, 3, 3):
+                raise ValueError("cell_homographies must be float32 [B,3,3]")
+            inp.cell_homographies_dev = hcell.data_ptr()
+        self._keep = (req, Hm, indices, sem, semw, hcell)  # keep alive until the stream has consumed them
         with torch.cuda.device(self.device):
             if graph:
                 _check(self.lib.ssp_pair_step_graph(self.h, C.byref(inp), _ptr(self.scalars), int(phase),
@@ -695,14 +728,20 @@ def op_erode(mask, radius):
     return out
 
 
-def op_warp_labels(labels, hn):
+def op_warp_labels(labels, hn, exact=True):
+    """warpLabels on a keypoint map.  exact=True (default): the pixel-space homography is computed on the host like the
+    reference (`scaled_homographies`) -> bit-identical indices; exact=False: analytic T^-1 H T on the device (no D2H copy)."""
     lib = load_library()
     _need_gpu(labels, "labels")
-    hn = hn.to(labels.device, torch.float32).contiguous()
     B, _, H, W = labels.shape
     out = torch.empty_like(labels)
     with torch.cuda.device(labels.device):
-        _check(lib.ssp_op_warp_labels(_ptr(labels), _ptr(hn), _ptr(out), B, H, W, _stream()))
+        if exact:
+            hpx = scaled_homographies(hn, H, W).to(labels.device)
+            _check(lib.ssp_op_warp_labels_px(_ptr(labels), _ptr(hpx), _ptr(out), B, H, W, _stream()))
+        else:
+            hn = hn.to(labels.device, torch.float32).contiguous()
+            _check(lib.ssp_op_warp_labels(_ptr(labels), _ptr(hn), _ptr(out), B, H, W, _stream()))
     return out
 
 
@@ -830,17 +869,22 @@ def op_sample_homographies(B, seed, device, perspective=True, scaling=True, rota
     return h, inv
 
 
-def op_warp_labels_full(labels, hn):
-    """warpLabels(bilinear=True) on a keypoint map [B,1,H,W]: (labels [B,1,H,W], res [B,2,H,W], labels_bi [B,1,H,W])."""
+def op_warp_labels_full(labels, hn, exact=True):
+    """warpLabels(bilinear=True) on a keypoint map [B,1,H,W]: (labels [B,1,H,W], res [B,2,H,W], labels_bi [B,1,H,W]).
+    exact: see op_warp_labels."""
     lib = load_library()
     _need_gpu(labels, "labels")
-    hn = hn.to(labels.device, torch.float32).contiguous()
     B, _, H, W = labels.shape
     lab = torch.empty_like(labels)
     res = torch.empty(B, 2, H, W, dtype=torch.float32, device=labels.device)
     bi = torch.empty_like(labels)
     with torch.cuda.device(labels.device):
-        _check(lib.ssp_op_warp_labels_full(_ptr(labels), _ptr(hn), _ptr(lab), _ptr(res), _ptr(bi), B, H, W, _stream()))
+        if exact:
+            hpx = scaled_homographies(hn, H, W).to(labels.device)
+            _check(lib.ssp_op_warp_labels_full_px(_ptr(labels), _ptr(hpx), _ptr(lab), _ptr(res), _ptr(bi), B, H, W, _stream()))
+        else:
+            hn = hn.to(labels.device, torch.float32).contiguous()
+            _check(lib.ssp_op_warp_labels_full(_ptr(labels), _ptr(hn), _ptr(lab), _ptr(res), _ptr(bi), B, H, W, _stream()))
     return lab, res, bi
 
 

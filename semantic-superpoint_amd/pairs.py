@@ -29,7 +29,9 @@ def make_pairs(image, labels_2D, seed, warp_params=None, erosion_radius=3, seman
     vm = L.op_erode(L.op_warp_image(torch.ones_like(image), inv, nearest=True), erosion_radius)
     s = {"image": image, "warped_img": warped, "labels_2D": labels_2D, "warped_labels": wl, "warped_res": wres,
          "warped_labels_bi": wbi, "labels_2D_gaussian": labels_2D, "warped_labels_gaussian": wbi,
-         "valid_mask": torch.ones_like(image), "warped_valid_mask": vm, "homographies": hs, "inv_homographies": inv}
+         "valid_mask": torch.ones_like(image), "warped_valid_mask": vm, "homographies": hs, "inv_homographies": inv,
+         # cell-space matrices in the reference's op order: the device sampler's matches then round like the reference's
+         "cell_homographies": L.scaled_homographies(hs, H // 8, W // 8).to(image.device)}
     if semantic is not None:
         sw = L.op_warp_image(semantic.float().view(B, 1, H, W).contiguous(), inv)
         s["semantic"] = semantic

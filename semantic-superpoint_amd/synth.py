@@ -152,6 +152,9 @@ def make_pair(B, H, W, device, seed=0, semantic=False, kp_prob=0.003, erosion=3,
          "labels_2D_gaussian": lab.clone(), "warped_labels_gaussian": wl.clone(),
          "valid_mask": torch.ones_like(img), "warped_valid_mask": vm, "homographies": Hs.contiguous(),
          "inv_homographies": inv}
+    if torch.device(device).type == "cuda":  # exact cell-space matrices for the device sampler (lib.scaled_homographies)
+        from . import lib as L
+        s["cell_homographies"] = L.scaled_homographies(Hs, H // 8, W // 8).to(device)
     if semantic:
         sem = torch.randint(0, n_classes + 1, (B, H, W), generator=g).to(device)
         ws = warp_image(sem.float().unsqueeze(1), inv).squeeze(1).long()

@@ -174,3 +174,31 @@ def test_optimizer_state_dict_has_torch_adam_layout():
     L.load_optimizer_state(e2, osd, eta=[0.1, 0.2, 0.3])
     assert torch.equal(e2.adam_m, e.adam_m) and torch.equal(e2.adam_v, e.adam_v) and e2.adam_t == 3
     assert torch.allclose(e2.params[e.n_params:], torch.tensor([0.1, 0.2, 0.3]))
+
+
+def test_scaled_homographies_and_device_warp_order_match_the_reference_ops():
+    """Index parity: (a) lib.scaled_homographies == the oracle's restatement of
+    scale_homography_torch bit for bit; (b) the device's warp order fma(p2, 1, fma(p1, y, p0 * x)) followed by a
+    correctly rounded division is exactly what torch's CPU `homographies @ points^T` + `/` give (N >= 12 points: below
+    that oneMKL takes another path) - emulated here in float64 with explicit float32 roundings."""
+    from semantic_superpoint_amd import lib as L
+    rs = np.random.RandomState(3)
+    Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(6)]).astype(np.float32))
+    for (hh, ww) in ((30, 40), (240, 320), (60, 80)):
+        mine = L.scaled_homographies(Hs, hh, ww)
+        for i in range(Hs.shape[0]):
+            assert torch.equal(mine[i], C.scale_homography(Hs[i], (hh, ww)))
+    f32 = lambda v: v.float().double()  # noqa: E731
+    for n in (12, 230, 1200, 4800):
+        pts = torch.cat([torch.from_numpy(rs.randint(0, 320, (n, 2))).float(), torch.ones(n, 1)], 1)
+        for P in L.scaled_homographies(Hs, 240, 320):
+            ref = (P.view(3, 3) @ pts.t()).t()
+            ref_xy = ref[:, :2] / ref[:, 2:]
+            a, x, y = P.double(), pts[:, 0].double(), pts[:, 1].double()
+            rows = []
+            for r in range(3):
+                t = f32(a[r, 0] * x)
+                t = f32(a[r, 1] * y + t)          # fma: one rounding
+                rows.append(f32(t + a[r, 2]))     # fma(p2, 1, t) == t + p2 rounded once
+            wx, wy = (rows[0] / rows[2]).float(), (rows[1] / rows[2]).float()
+            assert torch.equal(wx, ref_xy[:, 0]) and torch.equal(wy, ref_xy[:, 1]), n

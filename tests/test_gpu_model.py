@@ -269,16 +269,22 @@ def test_device_sampler_distribution(B, H, W):
     e = Engine("SuperPointNet_gauss2", B, H, W, _dev(), with_grad=False)
     rs = np.random.RandomState(2)
     Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(B)]).astype(np.float32))
-    ma, mb, nm = e.sample_indices(Hs.to(_dev()), seed=1234)
+    from semantic_superpoint_amd.lib import scaled_homographies
+    ma, mb, nm = e.sample_indices(Hs.to(_dev()), seed=1234, cell_homographies=scaled_homographies(Hs, Hc, Wc))
+    ma_a, mb_a, _ = e.sample_indices(Hs.to(_dev()), seed=1234)  # analytic T^-1 H T on the device
     torch.cuda.synchronize()
     ma, mb, nm = ma.cpu(), mb.cpu(), nm.cpu()
     for i in range(B):
         uv_a, uv_b = C.cell_matches(Hs[i], Hc, Wc)
         valid = {int(a[0] + a[1] * Wc): int(b[0] + b[1] * Wc) for a, b in zip(uv_a, uv_b)}
-        bad = sum(1 for a, b in zip(ma[i].tolist(), mb[i].tolist()) if valid.get(a, -1) != b)
-        assert bad <= 2 * (Hc * Wc) // 1200, bad  # rounding ties at .5 may differ (H_cell computed analytically on device)
+        # host-scaled cell homography: EVERY sampled pair is a correspondence of the reference, none is missing
+        assert all(valid.get(a, -1) == b for a, b in zip(ma[i].tolist(), mb[i].tolist())), i
         if len(valid) >= 1000:
             assert len(set(ma[i].tolist())) == 1000
+        else:
+            assert set(ma[i].tolist()) == set(valid.keys())
+        bad = sum(1 for a, b in zip(ma_a[i].cpu().tolist(), mb_a[i].cpu().tolist()) if valid.get(a, -1) != b)
+        assert bad <= 2 * (Hc * Wc) // 1200, bad  # analytic form: rounding ties at .5 may differ
     assert nm.min() >= 0 and nm.max() < Hc * Wc
     hist = torch.bincount(nm.reshape(-1).long(), minlength=Hc * Wc).float()
     m = float(hist.mean())  # Poisson counts: every cell within 5 sigma of the mean
