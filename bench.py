@@ -42,7 +42,8 @@ PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3 line)
 # kernels of the 3x3 forward + data-gradient launches per --conv-algo (algo 1 runs the small 30x40 maps on the p2 kernel)
 DOMINANT_KERNEL = {0: ("conv_mfma_kernel<3",), 1: ("conv_wino_pipe_kernel", "conv_wino_p2_kernel"), 2: ("conv_wino_kernel",),
-                   3: ("conv_wino_bf16_kernel",), 5: ("conv_wino_pipe_kernel",), 6: ("conv_wino_p2_kernel",)}
+                   3: ("conv_wino_bf16_kernel",), 5: ("conv_wino_pipe_kernel",), 6: ("conv_wino_p2_kernel",),
+                   7: ("conv_wino_bf16_kernel",)}
 
 
 def cpu_baseline(arch, H, W, batch=32, steps=3):
@@ -79,11 +80,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6],
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7],
                     help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
                          "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
                          "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
-                         "workgroups per CU")
+                         "workgroups per CU, 7 = Winograd with split-bf16 (hi + lo, 16 significant bits) operands: reported "
+                         "as dtype bf16x2")
     ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
                     help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
     ap.add_argument("--graph", action="store_true", help="replay the pair step as a hipGraph (ssp_pair_step_graph)")
@@ -271,14 +273,16 @@ def main():
     if rank == 0:
         scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
         pairs_s = world * B * args.steps / dt
-        reduced = args.conv_algo == 3
+        reduced = args.conv_algo in (3, 7)
+        prec = {3: ("bf16", "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)"),
+                7: ("bf16x2", "split-bf16 (hi + lo = 16 significant bits) matrix-core operands, three bf16 MFMAs per product / "
+                              "fp32 accumulate + master (NOT the headline precision)")}.get(args.conv_algo, ("f32", "fp32"))
         out = {"metric": "image-pairs/sec at %dx%d bs%d (pair training step)" % (H, W, B), "value": round(pairs_s, 2),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16" if reduced else "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": prec[0], "data": "synthetic",
                "config": {"workload": "%s pair step %dx%d, batch %d per GPU, %s, %s, Adam%s"
-                                      % (arch, H, W, B, "fp32" if not reduced else
-                                         "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)",
+                                      % (arch, H, W, B, prec[1],
                                          "sparse loss 1000x100" if dense is None else
                                          "dense descriptor loss (1200x1200 per image)",
                                          ", hipGraph replay" if args.graph else ""),
@@ -294,7 +298,8 @@ def main():
             if pr["launches"] > 0 and pr["ms"] > 0:
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
                 peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
-                exec_ratio = 1.0 if args.conv_algo == 0 else 16.0 / 36.0  # Winograd executes 16 of 36 multiplies
+                # Winograd executes 16 of 36 multiplies; the split-bf16 mode three bf16 MFMAs per product block
+                exec_ratio = 1.0 if args.conv_algo == 0 else (3.0 if args.conv_algo == 7 else 1.0) * 16.0 / 36.0
                 out["roofline"] = {"bound": "mfma", "kernel": "%s (3x3 forward + data-gradient, %s on v_mfma_f32_32x32x2_f32)"
                                                               % (" + ".join(DOMINANT_KERNEL[args.conv_algo]), "direct implicit GEMM"
                                                                  if args.conv_algo == 0 else "Winograd F(2x2,3x3)"),

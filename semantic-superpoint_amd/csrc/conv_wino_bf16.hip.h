@@ -4,7 +4,14 @@
 // into LDS and v_mfma_f32_32x32x8_bf16 (K = 8 = one 8-channel stage per instruction, fp32 accumulation) instead of four
 // v_mfma_f32_32x32x2_f32.  Activations, transforms, BatchNorm, bias, statistics and the outputs stay fp32 ("bf16
 // compute / fp32 master", BASELINE configs[3]).  LDS: 2 x (16 KB input + 16 KB weights) + raw halo + scale/shift +
-// a dedicated 64 KB staging tile = 147 KB.  Weights: pack_weights_wino8_bf16_kernel, [cob][chunk8][component][co][8 k].
+// a dedicated 64 KB staging tile = 147 KB.  Weights: pack_weights_wino8_bf16_kernel, [cob][chunk8][part][component][co][8 k].
+//
+// NT = 2 (ssp_set_conv_algo(7), "bf16x2"): every operand element x is carried as TWO bf16 values, hi = bf16(x) and
+// lo = bf16(x - hi), i.e. 16 significant bits, and a product a * b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi
+// (three matrix-core instructions, fp32 accumulation; the dropped a_lo b_lo term is 2^-16 of the product).  The rounding
+// error of a product falls from 2^-9 to ~2^-16, below the cancellation in the Winograd output transform that makes the
+// one-term mode useless for gradients.  LDS: 2 x 2 x (16 KB + 16 KB) + raw halo + scale/shift =
+// 147 KB; the epilogue stages in the consumed 64 KB buffer like the fp32 kernel.
 #pragma once
 #include "conv_wino_pipe.hip.h"
 
@@ -15,18 +22,27 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int QA_FLOATS = WC * WTILES * PK / 2;   // 16 KB of bf16
 constexpr int QB_FLOATS = WC * PK * NB / 2;       // 16 KB of bf16
 constexpr int BF16_LDS_BYTES = (2 * (QA_FLOATS + QB_FLOATS) + PR_FLOATS + PS_FLOATS + 8 * 32 * NB) * 4;
+constexpr int BF16X2_LDS_BYTES = (2 * 2 * (QA_FLOATS + QB_FLOATS) + PR_FLOATS + PS_FLOATS) * 4;
 
-template <int IN_MODE, bool WIDE>
+// hi / lo split of four fp32 values into bf16 (round to nearest even both times)
+__device__ __forceinline__ void bf16_split(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+  hi = __builtin_convertvector(v, bf16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+}
+
+template <int IN_MODE, bool WIDE, int NT = 1>
 __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const ConvArgs a) {
+  constexpr int BUF_FLOATS = NT * (QA_FLOATS + QB_FLOATS);   // [A parts][B parts]
+  constexpr int B_BASE = NT * QA_FLOATS;
   constexpr int TTX = WIDE ? 16 : 4;
   constexpr int TH = WIDE ? 8 : 32, TW = WIDE ? 32 : 8;
   constexpr int HC = TW + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // [sA0][sB0][sA1][sB1][sR][sS][staging]: bf16 images are half the size of the fp32 kernel's, so the epilogue has its
   // own 64 KB staging tile
-  float* const sR = smem + 2 * (QA_FLOATS + QB_FLOATS);
+  float* const sR = smem + 2 * BUF_FLOATS;
   float* const sS = sR + PR_FLOATS;  // scale[Cin] | shift[Cin] of the producer's BatchNorm (IN_MODE 1)
-  float* const sStage = sS + PS_FLOATS;
+  float* const sStageDedicated = sS + PS_FLOATS;  // NT == 1 only
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
   const float t_sg = t_row == 1 ? 1.f : -1.f;
   const int t_dst = ((t_row * 4) * WTILES + t_tile) * 4 + q2 * 2;  // float units: 8 bf16 = 16 bytes per (component, tile)
   const int pixb = a.in_cs * 4, rowb = a.W * pixb;
-  f32x4 hreg[2], wreg[2];
+  f32x4 hreg[2], wreg[2 * NT];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   constexpr unsigned OOB = 0x80000000u;
   unsigned hoff[2] = {OOB, OOB};
@@ -103,8 +119,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
     }                                                                                                       \
     _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                           \
       hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], ld_chunk * PK * 4, 0)); \
-    const int wbase_ = (cob * nst + ld_chunk) * QB_FLOATS * 4;                                              \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+    const int wbase_ = (cob * nst + ld_chunk) * NT * QB_FLOATS * 4;                                         \
+    _Pragma("unroll") for (int j = 0; j < 2 * NT; ++j)                                                      \
       wreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase_ + j * 8192, 0)); \
     if (++ld_chunk == nst) { ld_chunk = 0; ld_tile += per_cob; }                                            \
   }
@@ -121,13 +137,13 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
         *reinterpret_cast<f32x4*>(sR + r_lds[k]) = v;                                                       \
       }                                                                                                     \
     }                                                                                                       \
-    f32x4* wdst = reinterpret_cast<f32x4*>(smem + (B) * (QA_FLOATS + QB_FLOATS) + QA_FLOATS);               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];                   \
+    f32x4* wdst = reinterpret_cast<f32x4*>(smem + (B) * BUF_FLOATS + B_BASE);                               \
+    _Pragma("unroll") for (int j = 0; j < 2 * NT; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];              \
   }
   // MFMA fragment offsets (floats, relative to the buffer base)
   const int m_tile = mt * 32 + li;
   const int a_off = (chalf * 8 * WTILES + m_tile) * 4 + lh * 2;                 // lane: 4 bf16 = k 4 lh .. 4 lh + 3
-  const int b_off = QA_FLOATS + (chalf * 8 * NB + nt * 32 + li) * 4 + lh * 2;   // sB[component][co][8 k] bf16
+  const int b_off = B_BASE + (chalf * 8 * NB + nt * 32 + li) * 4 + lh * 2;      // sB[part][component][co][8 k] bf16
 
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
   const int co_l = cob * NB + nt * 32 + li;
@@ -140,6 +156,19 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
     t_u[j] = pipe_raw_off((2 * t_ty + t_ra) * HC + 2 * t_tx + j, q2);
     t_w[j] = pipe_raw_off((2 * t_ty + t_rb) * HC + 2 * t_tx + j, q2);
   }
+  // four transformed values -> the bf16 image(s) of the buffer: hi part, and the lo part QA_FLOATS further (NT == 2)
+#define PIPE_STORE_V(DST, VAL)                                                                              \
+  {                                                                                                         \
+    const f32x4 v__ = (VAL);                                                                                \
+    if (NT == 1) {                                                                                          \
+      *reinterpret_cast<bf16x4*>(DST) = __builtin_convertvector(v__, bf16x4);                               \
+    } else {                                                                                                \
+      bf16x4 hi__, lo__;                                                                                    \
+      bf16_split(v__, hi__, lo__);                                                                          \
+      *reinterpret_cast<bf16x4*>(DST) = hi__;                                                               \
+      *reinterpret_cast<bf16x4*>((DST) + QA_FLOATS) = lo__;                                                 \
+    }                                                                                                       \
+  }
   // one V row (4 components) of (tile, quad): sR -> sA of buffer B
 #define PIPE_TRANSFORM(B)                                                                                   \
   {                                                                                                         \
@@ -149,11 +178,11 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
       const f32x4 w = *reinterpret_cast<const f32x4*>(sR + t_w[j]);                                         \
       t[j] = u + t_sg * w;                                                                                  \
     }                                                                                                       \
-    float* d_ = smem + (B) * (QA_FLOATS + QB_FLOATS) + t_dst;                                               \
-    *reinterpret_cast<bf16x4*>(d_ + 0 * WTILES * 4) = __builtin_convertvector(t[0] - t[2], bf16x4);         \
-    *reinterpret_cast<bf16x4*>(d_ + 1 * WTILES * 4) = __builtin_convertvector(t[1] + t[2], bf16x4);         \
-    *reinterpret_cast<bf16x4*>(d_ + 2 * WTILES * 4) = __builtin_convertvector(t[2] - t[1], bf16x4);         \
-    *reinterpret_cast<bf16x4*>(d_ + 3 * WTILES * 4) = __builtin_convertvector(t[1] - t[3], bf16x4);         \
+    float* d_ = smem + (B) * BUF_FLOATS + t_dst;                                                            \
+    PIPE_STORE_V(d_ + 0 * WTILES * 4, t[0] - t[2])                                                          \
+    PIPE_STORE_V(d_ + 1 * WTILES * 4, t[1] + t[2])                                                          \
+    PIPE_STORE_V(d_ + 2 * WTILES * 4, t[2] - t[1])                                                          \
+    PIPE_STORE_V(d_ + 3 * WTILES * 4, t[1] - t[3])                                                          \
   }
 
   if (IN_MODE != 0) {
@@ -183,10 +212,20 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
   // matrix pipe needs for it and for the group of the other wave of its SIMD.
 #define PIPE_FRAG(C)                                                                                        \
   const s16x4 a0_##C = *reinterpret_cast<const s16x4*>(cA + a_off + (C) * WTILES * 4);                      \
-  const s16x4 a1_##C = *reinterpret_cast<const s16x4*>(cA + a_off + ((C) + 1) * WTILES * 4);                \
+  const s16x4 a1_##C = *reinterpret_cast<const s16x4*>(cA + a_off + ((C) + 1) * WTILES * 4);               \
   const s16x4 b0_##C = *reinterpret_cast<const s16x4*>(cA + b_off + (C) * NB * 4);                          \
-  const s16x4 b1_##C = *reinterpret_cast<const s16x4*>(cA + b_off + ((C) + 1) * NB * 4);
+  const s16x4 b1_##C = *reinterpret_cast<const s16x4*>(cA + b_off + ((C) + 1) * NB * 4);                    \
+  const s16x4 a0l_##C = NT == 2 ? *reinterpret_cast<const s16x4*>(cA + QA_FLOATS + a_off + (C) * WTILES * 4) : a0_##C;          \
+  const s16x4 a1l_##C = NT == 2 ? *reinterpret_cast<const s16x4*>(cA + QA_FLOATS + a_off + ((C) + 1) * WTILES * 4) : a1_##C;    \
+  const s16x4 b0l_##C = NT == 2 ? *reinterpret_cast<const s16x4*>(cA + QB_FLOATS + b_off + (C) * NB * 4) : b0_##C;              \
+  const s16x4 b1l_##C = NT == 2 ? *reinterpret_cast<const s16x4*>(cA + QB_FLOATS + b_off + ((C) + 1) * NB * 4) : b1_##C;
 #define PIPE_MFMA_LO(C)                                                                                     \
+  if (NT == 2) {  /* small terms first */                                                                   \
+    acc[C] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a0l_##C, b0_##C, acc[C], 0, 0, 0);                    \
+    acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1l_##C, b1_##C, acc[(C) + 1], 0, 0, 0);        \
+    acc[C] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a0_##C, b0l_##C, acc[C], 0, 0, 0);                    \
+    acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1_##C, b1l_##C, acc[(C) + 1], 0, 0, 0);        \
+  }                                                                                                         \
   acc[C] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a0_##C, b0_##C, acc[C], 0, 0, 0);                       \
   acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1_##C, b1_##C, acc[(C) + 1], 0, 0, 0);
 #define PIPE_MFMA_HI(C)
@@ -195,8 +234,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
   int tile = tile0, chunk = 0;
   for (int g = 0; g < nstages; ++g) {
     const int buf = g & 1;
-    const float* const cA = smem + buf * (QA_FLOATS + QB_FLOATS);
-    float* const nB = smem + (buf ^ 1) * (QA_FLOATS + QB_FLOATS);
+    const float* const cA = smem + buf * BUF_FLOATS;
+    float* const nB = smem + (buf ^ 1) * BUF_FLOATS;
     // ---- first half: components 0..3 of this wave's half || registers (stage g+1) -> LDS, loads of stage g+2 ----
     {
       PIPE_FRAG(0)
@@ -219,9 +258,9 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
       PIPE_MFMA_HI(0)
       PIPE_FENCE();
       PIPE_FRAG(2)
-      f32x4* wdst = reinterpret_cast<f32x4*>(nB + QA_FLOATS);  // weights of stage g+1 -> sB of the other buffer
+      f32x4* wdst = reinterpret_cast<f32x4*>(nB + B_BASE);  // weights of stage g+1 -> sB of the other buffer
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];
+      for (int j = 0; j < 2 * NT; ++j) wdst[tid + WINO_THREADS * j] = wreg[j];
       PIPE_FENCE();
       PIPE_MFMA_LO(2)
       PIPE_FENCE();
@@ -248,14 +287,14 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
       t[2] = u2 + t_sg * w2;
       t[3] = u3 + t_sg * w3;
       float* d_ = nB + t_dst;
-      *reinterpret_cast<bf16x4*>(d_ + 0 * WTILES * 4) = __builtin_convertvector(t[0] - t[2], bf16x4);
-      *reinterpret_cast<bf16x4*>(d_ + 1 * WTILES * 4) = __builtin_convertvector(t[1] + t[2], bf16x4);
+      PIPE_STORE_V(d_ + 0 * WTILES * 4, t[0] - t[2])
+      PIPE_STORE_V(d_ + 1 * WTILES * 4, t[1] + t[2])
       PIPE_FENCE();
       PIPE_MFMA_HI(4)
       PIPE_FENCE();
       PIPE_FRAG(6)
-      *reinterpret_cast<bf16x4*>(d_ + 2 * WTILES * 4) = __builtin_convertvector(t[2] - t[1], bf16x4);
-      *reinterpret_cast<bf16x4*>(d_ + 3 * WTILES * 4) = __builtin_convertvector(t[1] - t[3], bf16x4);
+      PIPE_STORE_V(d_ + 2 * WTILES * 4, t[2] - t[1])
+      PIPE_STORE_V(d_ + 3 * WTILES * 4, t[1] - t[3])
       PIPE_FENCE();
       PIPE_MFMA_LO(6)
       PIPE_MFMA_HI(6)
@@ -270,6 +309,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
       // Two rounds over the tile halves (bit 4 of the tile slot = accumulator registers 0..7 / 8..15): in each round
       // BOTH component halves write their partial outputs of 32 tiles to two 32 KB staging half-tiles, which meet in
       // the 16-byte store loop.  Compact tile index csl = (sl & 15) | (sl >> 5) << 4.
+      // staging tile: dedicated (NT == 1: the bf16 images are too small) or the consumed 64 KB buffer (NT == 2)
+      float* const sStage = NT == 1 ? sStageDedicated : smem + buf * BUF_FLOATS;
       float* const stg = sStage + chalf * (TH * TW * NB / 2);
       const float bz = chalf == 0 ? bias_v : 0.f;
       const int q16 = tid & 15;
@@ -336,6 +377,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
 #undef PIPE_ISSUE_LOADS
 #undef PIPE_WRITE_STAGE
 #undef PIPE_TRANSFORM
+#undef PIPE_STORE_V
 #undef PIPE_FRAG
 #undef PIPE_MFMA_LO
 #undef PIPE_MFMA_HI
@@ -362,7 +404,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
 // transformed input values V and the transformed dY values D rounded to bf16 in registers and one
 // v_mfma_f32_32x32x8_bf16 per 8 Winograd tiles (K = tiles; lane half lh supplies 4 consecutive tiles) instead of four
 // fp32 MFMAs per tile pair; fp32 accumulation, fp32 partial slabs, the same reduce kernel.
-template <int IN_MODE, bool WIDE>
+// NT = 2: hi + lo split of both operands in registers, three MFMAs per product block (see conv_wino_bf16_kernel).
+template <int IN_MODE, bool WIDE, int NT = 1>
 __global__ __launch_bounds__(512) void wgrad_wino_bf16_kernel(const WgradArgs a) {
   using G = WgradWinoGeom<WIDE>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -505,7 +548,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_bf16_kernel(const WgradArgs a)
     if (!(a.ablate & 8))
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {  // 8 Winograd tiles per MFMA: lane half lh supplies tiles 8 s + 4 lh .. + 3
-      bf16x4 Vb[4][2], Db[4];
+      bf16x4 Vb[4][2], Db[4], Vl[4][2], Dl[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int t = 8 * s + 4 * lh + tt;
@@ -519,20 +562,34 @@ __global__ __launch_bounds__(512) void wgrad_wino_bf16_kernel(const WgradArgs a)
           T[c][0] = fmaf(sg, w[0], u[0]);
           T[c][1] = fmaf(sg, w[1], u[1]);
         }
-        const f32x2 V0 = T[0] - T[2], V1 = T[1] + T[2], V2 = T[2] - T[1], V3 = T[1] - T[3];
+        const f32x2 V[4] = {T[0] - T[2], T[1] + T[2], T[2] - T[1], T[1] - T[3]};
         const float* db = sD + ((2 * ty) * G::TW + 2 * tx) * 64 + coh * 32 + li;
         const float r0 = c0 * db[0] + c1 * db[G::TW * 64];
         const float r1 = c0 * db[64] + c1 * db[G::TW * 64 + 64];
-        Vb[0][0][tt] = (__bf16)V0[0]; Vb[0][1][tt] = (__bf16)V0[1];
-        Vb[1][0][tt] = (__bf16)V1[0]; Vb[1][1][tt] = (__bf16)V1[1];
-        Vb[2][0][tt] = (__bf16)V2[0]; Vb[2][1][tt] = (__bf16)V2[1];
-        Vb[3][0][tt] = (__bf16)V3[0]; Vb[3][1][tt] = (__bf16)V3[1];
-        Db[0][tt] = (__bf16)r0; Db[1][tt] = (__bf16)(r0 + r1); Db[2][tt] = (__bf16)(r0 - r1); Db[3][tt] = (__bf16)(-r1);
+        const float Dv[4] = {r0, r0 + r1, r0 - r1, -r1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const __bf16 hi = (__bf16)V[j][e];
+            Vb[j][e][tt] = hi;
+            if (NT == 2) Vl[j][e][tt] = (__bf16)(V[j][e] - (float)hi);
+          }
+          const __bf16 dh = (__bf16)Dv[j];
+          Db[j][tt] = dh;
+          if (NT == 2) Dl[j][tt] = (__bf16)(Dv[j] - (float)dh);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, Vb[j][0]), __builtin_bit_cast(s16x4, Db[j]), acc[j][0], 0, 0, 0);
-        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, Vb[j][1]), __builtin_bit_cast(s16x4, Db[j]), acc[j][1], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (NT == 2) {  // small terms first
+            acc[j][e] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, Vl[j][e]), __builtin_bit_cast(s16x4, Db[j]), acc[j][e], 0, 0, 0);
+            acc[j][e] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, Vb[j][e]), __builtin_bit_cast(s16x4, Dl[j]), acc[j][e], 0, 0, 0);
+          }
+          acc[j][e] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, Vb[j][e]), __builtin_bit_cast(s16x4, Db[j]), acc[j][e], 0, 0, 0);
+        }
       }
     }
   }
@@ -551,10 +608,11 @@ __global__ __launch_bounds__(512) void wgrad_wino_bf16_kernel(const WgradArgs a)
 }
 
 
-// OIHW 3x3 weights -> bf16(G g G^T) in the LDS image of conv_wino_bf16_kernel: [cob][chunk8][component][co 64][k 8]
+// OIHW 3x3 weights -> bf16(G g G^T) in the LDS image of conv_wino_bf16_kernel: [cob][chunk8][part][component][co 64][k 8]
+// (parts = 1: the bf16 value; parts = 2: hi = bf16(u), lo = bf16(u - hi))
 __global__ void pack_weights_wino8_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cout_w, int Cin_w,
                                                int transpose_flip, int nchunks_total, int chunk_off, int cob_off, int ncob,
-                                               int nchunks) {
+                                               int nchunks, int parts) {
   const int per_chunk = WC * NB * PK;
   const int total = ncob * nchunks * per_chunk;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -589,7 +647,10 @@ __global__ void pack_weights_wino8_bf16_kernel(const float* __restrict__ w, __bf
   for (int x = 0; x < 3; ++x)
     r[x] = i == 0 ? k[0][x] : i == 1 ? 0.5f * (k[0][x] + k[1][x] + k[2][x]) : i == 2 ? 0.5f * (k[0][x] - k[1][x] + k[2][x]) : k[2][x];
   const float u = j == 0 ? r[0] : j == 1 ? 0.5f * (r[0] + r[1] + r[2]) : j == 2 ? 0.5f * (r[0] - r[1] + r[2]) : r[2];
-  dst[((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * per_chunk + (comp * NB + nn) * PK + kk] = (__bf16)u;
+  const size_t o = ((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * parts * per_chunk + (comp * NB + nn) * PK + kk;
+  const __bf16 hi = (__bf16)u;
+  dst[o] = hi;
+  if (parts == 2) dst[o + per_chunk] = (__bf16)(u - (float)hi);
 }
 
 }  // namespace sspk

@@ -415,14 +415,15 @@ static int launch_wino_p2_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
-template <int IN_MODE, bool WIDE>
+template <int IN_MODE, bool WIDE, int NT = 1>
 static int launch_wino_bf16_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   static AttrOnce attr_once;
-  auto kern = conv_wino_bf16_kernel<IN_MODE, WIDE>;
+  auto kern = conv_wino_bf16_kernel<IN_MODE, WIDE, NT>;
+  constexpr int lds = NT == 1 ? BF16_LDS_BYTES : BF16X2_LDS_BYTES;
   if (attr_once.need()) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BF16_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), BF16_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WINO_THREADS), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -500,6 +501,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true>(a, nblocks, st) : launch_wino_bf16_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_bf16_t<1, true>(a, nblocks, st) : launch_wino_bf16_t<1, false>(a, nblocks, st);
   }
+  if (c.wino && g_conv_algo == 7) {  // bf16x2: hi + lo parts (the image has the size of the fp32 one)
+    if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true, 2>(a, nblocks, st) : launch_wino_bf16_t<0, false, 2>(a, nblocks, st);
+    return wide ? launch_wino_bf16_t<1, true, 2>(a, nblocks, st) : launch_wino_bf16_t<1, false, 2>(a, nblocks, st);
+  }
   if (p2) {  // second-generation pipelined Winograd: two independent 4-wave workgroups per CU
     if (c.in_mode == 0) return wide ? launch_wino_p2_t<0, true>(a, nblocks, st) : launch_wino_p2_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_p2_t<1, true>(a, nblocks, st) : launch_wino_p2_t<1, false>(a, nblocks, st);
@@ -551,11 +556,11 @@ static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) 
   return 0;
 }
 
-template <int IN_MODE, bool WIDE>
+template <int IN_MODE, bool WIDE, int NT = 1>
 static int launch_wgrad_wino_bf16_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using G = WgradWinoGeom<WIDE>;
   static AttrOnce attr_once;
-  auto kern = wgrad_wino_bf16_kernel<IN_MODE, WIDE>;
+  auto kern = wgrad_wino_bf16_kernel<IN_MODE, WIDE, NT>;
   if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   }
@@ -634,6 +639,9 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
     if (wino && g_conv_algo == 3) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_bf16_t<1, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false>(a, nblocks, st)));
+    } else if (wino && g_conv_algo == 7) {
+      if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true, 2>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false, 2>(a, nblocks, st)));
+      else CHK((wide ? launch_wgrad_wino_bf16_t<1, true, 2>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false, 2>(a, nblocks, st)));
     } else if (wino) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_t<0, true>(a, nblocks, st) : launch_wgrad_wino_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_t<1, true>(a, nblocks, st) : launch_wgrad_wino_t<1, false>(a, nblocks, st)));
@@ -666,9 +674,10 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   const int nchunks = cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
   if (wino) {
     const int total = ncob * nchunks * WB_FLOATS;
-    if (g_conv_algo == 3)
+    if (g_conv_algo == 3 || g_conv_algo == 7)
       hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w,
-                         reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks);
+                         reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks,
+                         g_conv_algo == 7 ? 2 : 1);
     else if (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6)  // 8-channel stages of the pipelined kernels: twice as many chunks of half the size
       hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
                          2 * nchunks, 0, 0, ncob, 2 * nchunks);
@@ -854,10 +863,10 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
     const bool wino = wino_ok(3, 256 * h->nheads);
     const int total = 2 * 16 * (wino ? WC : 9) * CK * NB;
     for (int k = 0; k < h->nheads; ++k) {
-      if (wino && g_conv_algo == 3)
+      if (wino && (g_conv_algo == 3 || g_conv_algo == 7))
         hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), reinterpret_cast<__bf16*>(h->wpk_heads_bwd), 256, 128, 1,
-                           32 * h->nheads, 32 * k, 0, 2, 32);
+                           32 * h->nheads, 32 * k, 0, 2, 32, g_conv_algo == 7 ? 2 : 1);
       else if (wino && multi && J.n < PACK_MAX_JOBS)
         add_job(P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
       else if (wino && multi)
@@ -1419,7 +1428,7 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
-  if (algo < 0 || algo > 6 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3, 5 or 6 (see ssp_set_conv_algo)");
+  if (algo < 0 || algo > 7 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3, 5, 6 or 7 (see ssp_set_conv_algo)");
   h->conv_algo = algo;
   return 0;
 }
@@ -1821,9 +1830,10 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 6 || algo == 4)
+  if (algo < 0 || algo > 7 || algo == 4)
     return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
-                    "operands), 5 (Winograd, pipelined, weights staged through LDS) or 6 (Winograd, two 4-wave workgroups per CU)");
+                    "operands), 5 (Winograd, pipelined, weights staged through LDS), 6 (Winograd, two 4-wave workgroups per CU) "
+                    "or 7 (Winograd, split-bf16 hi + lo operands)");
   g_default_conv_algo = algo;
   return 0;
 }

