@@ -43,7 +43,7 @@ PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3
 # kernels of the 3x3 forward + data-gradient launches per --conv-algo (algo 1 runs the small 30x40 maps on the p2 kernel)
 DOMINANT_KERNEL = {0: ("conv_mfma_kernel<3",), 1: ("conv_wino_pipe_kernel", "conv_wino_p2_kernel"), 2: ("conv_wino_kernel",),
                    3: ("conv_wino_bf16_kernel",), 5: ("conv_wino_pipe_kernel",), 6: ("conv_wino_p2_kernel",),
-                   7: ("conv_wino_bf16_kernel",)}
+                   7: ("conv_wino_bf16_kernel",), 8: ("conv_wino_bf16_kernel",)}
 
 
 def cpu_baseline(arch, H, W, batch=32, steps=3):
@@ -80,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7],
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8],
                     help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
                          "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
                          "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
@@ -273,10 +273,13 @@ def main():
     if rank == 0:
         scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
         pairs_s = world * B * args.steps / dt
-        reduced = args.conv_algo in (3, 7)
+        reduced = args.conv_algo in (3, 7, 8)
         prec = {3: ("bf16", "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)"),
                 7: ("bf16x2", "split-bf16 (hi + lo = 16 significant bits) matrix-core operands, three bf16 MFMAs per product / "
-                              "fp32 accumulate + master (NOT the headline precision)")}.get(args.conv_algo, ("f32", "fp32"))
+                              "fp32 accumulate + master (NOT the headline precision)"),
+                8: ("bf16", "mixed bf16: forward convolutions with split-bf16 (hi + lo) operands, data / weight gradients with "
+                            "bf16 operands; fp32 accumulate, BatchNorm, master weights, Adam (NOT the headline precision)")
+                }.get(args.conv_algo, ("f32", "fp32"))
         out = {"metric": "image-pairs/sec at %dx%d bs%d (pair training step)" % (H, W, B), "value": round(pairs_s, 2),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -299,7 +302,7 @@ def main():
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
                 peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
                 # Winograd executes 16 of 36 multiplies; the split-bf16 mode three bf16 MFMAs per product block
-                exec_ratio = 1.0 if args.conv_algo == 0 else (3.0 if args.conv_algo == 7 else 1.0) * 16.0 / 36.0
+                exec_ratio = 1.0 if args.conv_algo == 0 else {7: 3.0, 8: 2.0}.get(args.conv_algo, 1.0) * 16.0 / 36.0
                 out["roofline"] = {"bound": "mfma", "kernel": "%s (3x3 forward + data-gradient, %s on v_mfma_f32_32x32x2_f32)"
                                                               % (" + ".join(DOMINANT_KERNEL[args.conv_algo]), "direct implicit GEMM"
                                                                  if args.conv_algo == 0 else "Winograd F(2x2,3x3)"),

@@ -36,6 +36,11 @@ static int g_default_conv_algo = 1;             // process default: new handles 
 static thread_local int g_conv_algo = 1;        // algorithm of the call in flight (AlgoScope: the handle's, else the default)
 // 3x3 convolutions whose input channels fill whole 16-channel K-chunks run as Winograd F(2x2,3x3)
 static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks == 3 && conv_cin % CK == 0; }
+// bf16 Winograd modes: number of bf16 parts per operand element.  3: one part everywhere; 7: hi + lo everywhere;
+// 8 (mixed): hi + lo in the FORWARD convolutions (the activations every later layer and the ReLU gates depend on), one
+// part in the data-gradient and weight-gradient kernels (unbiased 2^-9 noise on the gradients, like any bf16 training)
+static inline bool bf16_algo() { return g_conv_algo == 3 || g_conv_algo == 7 || g_conv_algo == 8; }
+static inline int bf16_parts(bool backward) { return g_conv_algo == 7 || (g_conv_algo == 8 && !backward) ? 2 : 1; }
 static inline int pk_taps(int ks) { return ks == 3 ? WC : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
 static int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -379,6 +384,7 @@ struct ConvCall {
   const float* in2 = nullptr; float* out2 = nullptr;
   const float* in_scale2 = nullptr; const float* in_shift2 = nullptr; double* stats2 = nullptr;
   bool wino = false;  // wpk holds pack_weights_wino_kernel's image: run conv_wino_kernel
+  bool backward = false;  // data-gradient launch (selects the operand precision of the mixed bf16 mode)
   // data-gradient launches: BatchNorm-backward sums of the layer below fused into the epilogue (ConvArgs::bnr_*);
   // honoured by the pipelined Winograd kernel only - can_fuse_bnr() tells the caller
   int bnr_mode = 0;
@@ -496,12 +502,13 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
       c.cin == 64)
     fam = SSP_PROF_CONV_BIG_FWD;
   ProfScope ps(h, fam, st, flops, bytes);
-  if (c.wino && g_conv_algo == 3) {
-    a.wpk_bytes /= 2;  // bf16 weights
-    if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true>(a, nblocks, st) : launch_wino_bf16_t<0, false>(a, nblocks, st);
-    return wide ? launch_wino_bf16_t<1, true>(a, nblocks, st) : launch_wino_bf16_t<1, false>(a, nblocks, st);
-  }
-  if (c.wino && g_conv_algo == 7) {  // bf16x2: hi + lo parts (the image has the size of the fp32 one)
+  if (c.wino && bf16_algo()) {
+    if (bf16_parts(c.backward) == 1) {
+      a.wpk_bytes /= 2;  // one bf16 part: half the bytes of the fp32 image
+      if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true>(a, nblocks, st) : launch_wino_bf16_t<0, false>(a, nblocks, st);
+      return wide ? launch_wino_bf16_t<1, true>(a, nblocks, st) : launch_wino_bf16_t<1, false>(a, nblocks, st);
+    }
+    // hi + lo parts (the image has the size of the fp32 one)
     if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true, 2>(a, nblocks, st) : launch_wino_bf16_t<0, false, 2>(a, nblocks, st);
     return wide ? launch_wino_bf16_t<1, true, 2>(a, nblocks, st) : launch_wino_bf16_t<1, false, 2>(a, nblocks, st);
   }
@@ -636,10 +643,10 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
     const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
     const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
     ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes);
-    if (wino && g_conv_algo == 3) {
+    if (wino && bf16_algo() && bf16_parts(true) == 1) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_bf16_t<1, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false>(a, nblocks, st)));
-    } else if (wino && g_conv_algo == 7) {
+    } else if (wino && bf16_algo()) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true, 2>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false, 2>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_bf16_t<1, true, 2>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false, 2>(a, nblocks, st)));
     } else if (wino) {
@@ -674,10 +681,10 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   const int nchunks = cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
   if (wino) {
     const int total = ncob * nchunks * WB_FLOATS;
-    if (g_conv_algo == 3 || g_conv_algo == 7)
+    if (bf16_algo())
       hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w,
                          reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks,
-                         g_conv_algo == 7 ? 2 : 1);
+                         bf16_parts(tf != 0));
     else if (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6)  // 8-channel stages of the pipelined kernels: twice as many chunks of half the size
       hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
                          2 * nchunks, 0, 0, ncob, 2 * nchunks);
@@ -863,10 +870,10 @@ static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
     const bool wino = wino_ok(3, 256 * h->nheads);
     const int total = 2 * 16 * (wino ? WC : 9) * CK * NB;
     for (int k = 0; k < h->nheads; ++k) {
-      if (wino && (g_conv_algo == 3 || g_conv_algo == 7))
+      if (wino && bf16_algo())
         hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), reinterpret_cast<__bf16*>(h->wpk_heads_bwd), 256, 128, 1,
-                           32 * h->nheads, 32 * k, 0, 2, 32, g_conv_algo == 7 ? 2 : 1);
+                           32 * h->nheads, 32 * k, 0, 2, 32, bf16_parts(true));
       else if (wino && multi && J.n < PACK_MAX_JOBS)
         add_job(P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
       else if (wino && multi)
@@ -1064,7 +1071,7 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
   c.in = dy[0]; c.in_cs = dy_cs; c.in_co = dy_co; c.cin = (int)align_up(d.cout, 4);
   c.wpk = h->wpk_bwd + d.pk_bwd; c.bias = nullptr; c.wino = wino_ok(d.ks, d.cout);
   c.out = din[0]; c.out_cs = din_cs; c.out_co = din_co; c.cout = d.cin;
-  c.in_scale = nullptr; c.in_shift = nullptr; c.stats = nullptr;
+  c.in_scale = nullptr; c.in_shift = nullptr; c.stats = nullptr; c.backward = true;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 0; c.nchunks = d.nchunks_bwd; c.ncob = d.ncob_bwd;
   if (SS.n == 2) {
     Slot& B = *SS.s[1];
@@ -1160,6 +1167,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     c.in = gQ[0]; c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = h->wpk_heads_bwd; c.bias = nullptr; c.wino = wino_ok(3, hcs);
     c.out = gP[0]; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
     c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = 16 * h->nheads; c.ncob = 2;
+    c.backward = true;
     if (SS.n == 2) { c.nprob = 2; c.in2 = gQ[1]; c.out2 = gP[1]; }
     setup_bnr(h, SS, 7, false, c);
     CHK(launch_conv(h, c, st, SSP_PROF_CONV3X3_DGRAD));
@@ -1428,7 +1436,7 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
-  if (algo < 0 || algo > 7 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3, 5, 6 or 7 (see ssp_set_conv_algo)");
+  if (algo < 0 || algo > 8 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3, 5, 6, 7 or 8 (see ssp_set_conv_algo)");
   h->conv_algo = algo;
   return 0;
 }
@@ -1529,6 +1537,7 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
   c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.wpk = wpk; c.bias = bias_dev; c.out = out_dev; c.out_cs = cout;
   c.out_co = 0; c.cout = cout; c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.stats = stats_dev; c.N = n;
   c.H = hh; c.W = w; c.ks = ksize; c.in_mode = in_mode; c.nchunks = nchunks; c.ncob = ncob; c.wino = wino;
+  c.backward = transpose_flip != 0;
   return launch_conv(nullptr, c, st, 0);
 }
 
@@ -1830,10 +1839,10 @@ int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 7 || algo == 4)
+  if (algo < 0 || algo > 8 || algo == 4)
     return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
                     "operands), 5 (Winograd, pipelined, weights staged through LDS), 6 (Winograd, two 4-wave workgroups per CU) "
-                    "or 7 (Winograd, split-bf16 hi + lo operands)");
+                    ", 7 (Winograd, split-bf16 hi + lo operands) or 8 (forward split-bf16, backward bf16)");
   g_default_conv_algo = algo;
   return 0;
 }
