@@ -347,6 +347,29 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Two-wide fp32 vector arithmetic pinned to the packed instructions (hipcc scalarises most f32x2 expressions whose
+// elements feed MFMA operands): one VALU issue slot for two values.
+__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 x, f32x2 y, f32x2 z) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+
 template <bool WIDE>
 struct WgradWinoGeom {
   static constexpr int TH = WIDE ? 4 : 16, TW = WIDE ? 32 : 8;  // 128 output pixels = 32 tiles per step
@@ -355,6 +378,68 @@ struct WgradWinoGeom {
   static constexpr int X_FLOATS = HT * WT * 64, D_FLOATS = TH * TW * 64;
   static constexpr int LDS_BYTES = (X_FLOATS + D_FLOATS + 256) * 4;
 };
+
+// The 16 K-steps (32 Winograd tiles, lane half lh = tile of the pair) of one block tile, fully unrolled: every LDS offset
+// is base + compile-time constant (the halo rows ra / rb of the wave's component row are folded into the lane bases) and
+// all two-wide arithmetic is written on f32x2 so that it compiles to v_pk_fma_f32 / v_pk_add_f32: 13 VALU instructions per
+// 8 MFMAs instead of ~34.  On this chip every VALU instruction beside a v_mfma_f32_32x32x2_f32 costs matrix-pipe time one
+// for one (the fp32 MFMA executes on the vector ALUs: DESIGN.md section 8, tools/ubench/mfma_overlap.hip).
+//   T[c] = d[ra][c] + sg d[rb][c];   (r0, r1) = c0 dy[0][0..1] + c1 dy[1][0..1]
+template <typename G>
+__device__ __forceinline__ void wgrad_wino_steps(f32x16 (&acc)[4][2], const float* __restrict__ xa0,
+                                                 const float* __restrict__ xb0, const float* __restrict__ db0,
+                                                 const f32x2 sg, const f32x2 c0, const f32x2 c1) {
+  f32x2 U[4], Wv[4], T[4], top, bot, r;
+#define WGS_LOAD(S)                                                                                          \
+  {                                                                                                          \
+    constexpr int t0_ = 2 * (S);  /* even tile of the pair; the odd one (lh = 1) is folded into the lane bases */ \
+    constexpr int ty_ = t0_ / G::TTX, tx_ = t0_ % G::TTX;                                                    \
+    constexpr int xo_ = ((2 * ty_) * G::WT + 2 * tx_) * 64, do_ = ((2 * ty_) * G::TW + 2 * tx_) * 64;        \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+      U[c] = *reinterpret_cast<const f32x2*>(xa0 + xo_ + c * 64);                                            \
+      Wv[c] = *reinterpret_cast<const f32x2*>(xb0 + xo_ + c * 64);                                           \
+    }                                                                                                        \
+    top[0] = db0[do_]; top[1] = db0[do_ + 64];                                                               \
+    bot[0] = db0[do_ + G::TW * 64]; bot[1] = db0[do_ + G::TW * 64 + 64];                                     \
+  }
+  // first half of a step: consumes the raw operands (their registers are free for the next step's LDS reads)
+#define WGS_HEAD()                                                                                           \
+  {                                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) T[c] = pk_fma(sg, Wv[c], U[c]);                   \
+    r = pk_fma(c1, bot, pk_mul(c0, top));                                                                   \
+  }
+#define WGS_TAIL()                                                                                           \
+  {                                                                                                          \
+    const f32x2 V0 = pk_sub(T[0], T[2]), V1 = pk_add(T[1], T[2]), V2 = pk_sub(T[2], T[1]), V3 = pk_sub(T[1], T[3]); \
+    const float D0 = r[0], D1 = r[0] + r[1], D2 = r[0] - r[1], D3 = -r[1];                                   \
+    /* hipcc does not track the VALU-write -> MFMA-read wait states (2) for registers written by inline asm: */ \
+    /* all operands are complete before the fence, the first MFMA reads V0, written >= 3 instructions earlier */ \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[0], D0, acc[0][0], 0, 0, 0);                         \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[1], D0, acc[0][1], 0, 0, 0);                         \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[0], D1, acc[1][0], 0, 0, 0);                         \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[1], D1, acc[1][1], 0, 0, 0);                         \
+    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[0], D2, acc[2][0], 0, 0, 0);                         \
+    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[1], D2, acc[2][1], 0, 0, 0);                         \
+    acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[0], D3, acc[3][0], 0, 0, 0);                         \
+    acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[1], D3, acc[3][1], 0, 0, 0);                         \
+  }
+  // the LDS reads of step s + 1 are issued between the two halves of step s and land under its 8 MFMAs
+#define WGS_STEP(S)                                                                                          \
+  WGS_HEAD()                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                         \
+  if ((S) + 1 < 16) WGS_LOAD(((S) + 1 < 16 ? (S) + 1 : 0))                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                                         \
+  WGS_TAIL()                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+  WGS_LOAD(0)
+  WGS_STEP(0) WGS_STEP(1) WGS_STEP(2) WGS_STEP(3) WGS_STEP(4) WGS_STEP(5) WGS_STEP(6) WGS_STEP(7)
+  WGS_STEP(8) WGS_STEP(9) WGS_STEP(10) WGS_STEP(11) WGS_STEP(12) WGS_STEP(13) WGS_STEP(14) WGS_STEP(15)
+#undef WGS_LOAD
+#undef WGS_HEAD
+#undef WGS_TAIL
+#undef WGS_STEP
+}
 
 template <int IN_MODE, bool WIDE>
 __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
@@ -487,33 +572,12 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
       WGW_ISSUE(nxt)
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(a.ablate & 8))
-#pragma unroll 2
-    for (int s = 0; s < 16; ++s) {
-      const int t = 2 * s + lh;  // K index -> Winograd tile of this block tile
-      const int ty = t / G::TTX, tx = t - ty * G::TTX;
-      const float* xa = sX + ((2 * ty + ra) * G::WT + 2 * tx) * 64 + 2 * li;
-      const float* xb = sX + ((2 * ty + rb) * G::WT + 2 * tx) * 64 + 2 * li;
-      f32x2 T[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x2 u = *reinterpret_cast<const f32x2*>(xa + c * 64), w = *reinterpret_cast<const f32x2*>(xb + c * 64);
-        T[c][0] = fmaf(sg, w[0], u[0]);
-        T[c][1] = fmaf(sg, w[1], u[1]);
-      }
-      const f32x2 V0 = T[0] - T[2], V1 = T[1] + T[2], V2 = T[2] - T[1], V3 = T[1] - T[3];
-      const float* db = sD + ((2 * ty) * G::TW + 2 * tx) * 64 + coh * 32 + li;
-      const float r0 = c0 * db[0] + c1 * db[G::TW * 64];
-      const float r1 = c0 * db[64] + c1 * db[G::TW * 64 + 64];
-      const float D0 = r0, D1 = r0 + r1, D2 = r0 - r1, D3 = -r1;
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[0], D0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[1], D0, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[0], D1, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[1], D1, acc[1][1], 0, 0, 0);
-      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[0], D2, acc[2][0], 0, 0, 0);
-      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[1], D2, acc[2][1], 0, 0, 0);
-      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[0], D3, acc[3][0], 0, 0, 0);
-      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[1], D3, acc[3][1], 0, 0, 0);
+    if (!(a.ablate & 8)) {
+      // lane bases: channel pair 2 li of the raw rows ra / rb, tile column offset of the lane half; dY column of this lane
+      const float* xa0 = sX + (ra * G::WT + 2 * lh) * 64 + 2 * li;
+      const float* xb0 = sX + (rb * G::WT + 2 * lh) * 64 + 2 * li;
+      const float* db0 = sD + (2 * lh) * 64 + coh * 32 + li;
+      wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1});
     }
   }
 #undef WGW_ISSUE
