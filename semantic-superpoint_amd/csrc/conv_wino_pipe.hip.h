@@ -49,11 +49,11 @@ __device__ __forceinline__ void pipe_out_rows(const f32x16 (&acc)[8], int rd, in
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x2 a = {acc[j][r], acc[j][r + 1]}, b = {acc[4 + j][r], acc[4 + j][r + 1]};
-      if (CHALF == 0) { top[j] = a + b; bot[j] = b; }
-      else { top[j] = a; bot[j] = -(a + b); }
+      if (CHALF == 0) { top[j] = pk_add(a, b); bot[j] = b; }
+      else { top[j] = a; bot[j] = pk_nadd(a, b); }
     }
-    const f32x2 y00 = top[0] + top[1] + top[2], y01 = top[1] - top[2] - top[3];
-    const f32x2 y10 = bot[0] + bot[1] + bot[2], y11 = bot[1] - bot[2] - bot[3];
+    const f32x2 y00 = pk_add(pk_add(top[0], top[1]), top[2]), y01 = pk_sub(pk_sub(top[1], top[2]), top[3]);
+    const f32x2 y10 = pk_add(pk_add(bot[0], bot[1]), bot[2]), y11 = pk_sub(pk_sub(bot[1], bot[2]), bot[3]);
     const int csl = ((r8 & 3) + 8 * (r8 >> 2) + 4 * lh) | (mt << 4);  // even r8: tiles csl, csl + 1 are x neighbours
     const int cty = csl / TTX, ctx = csl % TTX;
     float* p = o + ((2 * cty) * TW + 2 * ctx) * NB;
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   const int t_ra = t_row == 0 ? 0 : t_row == 2 ? 2 : 1;   // T[i] = d[ra] + sg d[rb]
   const int t_rb = t_row == 2 ? 1 : t_row == 3 ? 3 : 2;
   const float t_sg = t_row == 1 ? 1.f : -1.f;
+  const f32x2 t_sg2 = {t_sg, t_sg};
   const int t_dst = ((t_row * 4) * WTILES + t_tile) * PK + ((q2 ^ ((t_tile >> 2) & 1)) << 2);
   const int pixb = a.in_cs * 4, rowb = a.W * pixb;
   f32x4 hreg[2], wreg[4];
@@ -209,13 +210,13 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
       const f32x4 u = *reinterpret_cast<const f32x4*>(sR + t_u[j]);                                         \
       const f32x4 w = *reinterpret_cast<const f32x4*>(sR + t_w[j]);                                         \
-      t[j] = u + t_sg * w;                                                                                  \
+      t[j] = pk4_fma_s(t_sg2, w, u);                                                                        \
     }                                                                                                       \
     float* d_ = smem + (B) * (PA_FLOATS + PB_FLOATS) + t_dst;                                               \
-    *reinterpret_cast<f32x4*>(d_ + 0 * WTILES * PK) = t[0] - t[2];                                          \
-    *reinterpret_cast<f32x4*>(d_ + 1 * WTILES * PK) = t[1] + t[2];                                          \
-    *reinterpret_cast<f32x4*>(d_ + 2 * WTILES * PK) = t[2] - t[1];                                          \
-    *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = t[1] - t[3];                                          \
+    *reinterpret_cast<f32x4*>(d_ + 0 * WTILES * PK) = pk4_sub(t[0], t[2]);                                  \
+    *reinterpret_cast<f32x4*>(d_ + 1 * WTILES * PK) = pk4_add(t[1], t[2]);                                  \
+    *reinterpret_cast<f32x4*>(d_ + 2 * WTILES * PK) = pk4_sub(t[2], t[1]);                                  \
+    *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = pk4_sub(t[1], t[3]);                                  \
   }
 
   if (IN_MODE != 0) {
@@ -343,20 +344,20 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       PIPE_MFMA_LO(4)
       PIPE_FENCE();
       f32x4 t[4];
-      t[0] = u0 + t_sg * w0;
-      t[1] = u1 + t_sg * w1;
-      t[2] = u2 + t_sg * w2;
-      t[3] = u3 + t_sg * w3;
+      t[0] = pk4_fma_s(t_sg2, w0, u0);
+      t[1] = pk4_fma_s(t_sg2, w1, u1);
+      t[2] = pk4_fma_s(t_sg2, w2, u2);
+      t[3] = pk4_fma_s(t_sg2, w3, u3);
       float* d_ = nB + t_dst;
-      *reinterpret_cast<f32x4*>(d_ + 0 * WTILES * PK) = t[0] - t[2];
-      *reinterpret_cast<f32x4*>(d_ + 1 * WTILES * PK) = t[1] + t[2];
+      *reinterpret_cast<f32x4*>(d_ + 0 * WTILES * PK) = pk4_sub(t[0], t[2]);
+      *reinterpret_cast<f32x4*>(d_ + 1 * WTILES * PK) = pk4_add(t[1], t[2]);
       PIPE_FENCE();
       PIPE_MFMA_HI(4)
       PIPE_FENCE();
       PIPE_FRAG(6, bB0, bB1)
       PIPE_BLOAD(bA0, bA1, 0, (chunk + 1 == nst ? 0 : chunk + 1))  // first pair of the next stage
-      *reinterpret_cast<f32x4*>(d_ + 2 * WTILES * PK) = t[2] - t[1];
-      *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = t[1] - t[3];
+      *reinterpret_cast<f32x4*>(d_ + 2 * WTILES * PK) = pk4_sub(t[2], t[1]);
+      *reinterpret_cast<f32x4*>(d_ + 3 * WTILES * PK) = pk4_sub(t[1], t[3]);
       PIPE_FENCE();
       PIPE_MFMA_LO(6)
       PIPE_FENCE();
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       const int q16 = tid & 15;
       const int co4 = cob * NB + q16 * 4;
       const int nvalid = min(4, a.Cout - co4);
+      mfma_results_guard();  // the output transform reads the accumulators from inline asm
 #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
         // accumulator registers in pairs (r, r + 1) = Winograd tiles (ctx, ctx + 1): packed adds.  The conv bias is
@@ -411,8 +413,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
           const int sl = (csl & 15) | (rd << 4) | ((csl >> 4) << 5);
           const int oy = ty0 + 2 * (sl / TTX) + (crow & 1), ox = tx0 + ccol;
           if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4) +
-                            *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4);
+            const f32x4 v = pk4_add(*reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4),
+                                    *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4));
             if (IN_MODE == 0 && a.bnr_mode != 0) {
               // BatchNorm-backward sums of the layer below (see ConvArgs::bnr_mode): v is its activation gradient
               const f32x4 t = *reinterpret_cast<const f32x4*>(p_bnr + ((size_t)(n * a.H + oy) * a.W + ox) * a.bnr_cs + a.bnr_co + co4);
@@ -420,8 +422,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
               f32x4 dz, xh;
               if (a.bnr_mode == 1) {
                 const f32x4 q2 = *reinterpret_cast<const f32x4*>(sS + 2 * NB + q16 * 4), q3 = *reinterpret_cast<const f32x4*>(sS + 3 * NB + q16 * 4);
-                const f32x4 z = __builtin_elementwise_fma(t, q0, q1);
-                xh = __builtin_elementwise_fma(t, q2, q3);
+                const f32x4 z = pk4_fma(t, q0, q1);
+                xh = pk4_fma(t, q2, q3);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? v[e] : 0.f;
               } else {
@@ -429,11 +431,11 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dz[e] = t[e] > 0.f ? v[e] : 0.f;
               }
-              ssum += dz;
-              ssq = __builtin_elementwise_fma(dz, xh, ssq);
+              ssum = pk4_add(ssum, dz);
+              ssq = pk4_fma(dz, xh, ssq);
             } else {
-              ssum += v;
-              ssq += v * v;
+              ssum = pk4_add(ssum, v);
+              ssq = pk4_fma(v, v, ssq);
             }
             if (PIPE_ABL & 16) continue;
             float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
