@@ -285,6 +285,11 @@ int ssp_op_heatmap_nms(const float* heat_dev, const ssp_export_params* p, int n_
 int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_dev, const float* stats4_dev,
                   float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int h,
                   int w, int c, int relu, int pool, void* stream);
+/* The same on channel-padded NHWC tensors (pixel stride cs >= c, cs % 4 == 0: the 65-channel detector head lives in
+ * 68-float pixels); the per-channel vectors stay [c]. */
+int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float* gamma_dev, const float* stats4_dev,
+                          float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n,
+                          int h, int w, int c, int cs, int relu, int pool, void* stream);
 
 /* Algorithm of the 3x3 forward / data-gradient convolutions whose input channels are a multiple of 16 (process-wide
  * DEFAULT, copied into a handle at ssp_create; takes effect at the next forward, which re-packs the weights): 1 (default) = Winograd F(2x2,3x3) on the fp32 matrix

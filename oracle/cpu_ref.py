@@ -8,9 +8,11 @@ Parity pin: every function below is checked against the REAL reference (imported
 container through oracle/ref_harness.py) by oracle/make_goldens.py, which also writes the
 fixtures in tests/golden/ that tests/test_oracle_golden.py re-checks on every run (the reference
 itself ships no tests or golden vectors for this path: SURVEY.md section 4).
-Third-party arithmetic (torch ops) is torch 2.10 semantics; cv2.erode / cv2.getPerspectiveTransform
-are absent from the image, so `erode_ellipse` and `sample_homography` are "parity unpinned"
- and masks / homographies are *inputs* in every parity test.
+Third-party arithmetic (torch ops) is torch 2.10 semantics; cv2 (erode / getStructuringElement /
+getPerspectiveTransform) and torchgeometry (SpatialSoftArgmax2d) are absent from the image: they are restated
+from their published sources and pinned against published / hand-evaluated vectors
+(test_third_party_definitions_hand_vectors), not against the binaries - "parity unpinned" for those
+sub-steps; masks / homographies are *inputs* in every parity test.
 
 All file:line citations are relative to the reference repository root.
 """
@@ -449,21 +451,26 @@ def inv_warp_image_batch(img, mat_homo_inv, mode="bilinear"):
     return F.grid_sample(img, src, mode=mode, align_corners=True)
 
 
-def ellipse_kernel(r):
-    """cv2.getStructuringElement(MORPH_ELLIPSE,(2r,2r)) as documented by OpenCV (parity unpinned:
-    cv2 is not in the image).  Returns a (2r x 2r) uint8 array, anchor at (r, r)."""
-    n = 2 * r
-    k = np.zeros((n, n), np.uint8)
-    c = n // 2
-    rr = n // 2
-    inv_r2 = 1.0 / (rr * rr) if rr else 0.0
-    for i in range(n):
-        dy = i - c
-        if abs(dy) <= rr:
-            dx = int(round(rr * math.sqrt(max((rr * rr - dy * dy) * inv_r2, 0.0))))
-            j1, j2 = max(c - dx, 0), min(c + dx + 1, n)
-            k[i, j1:j2] = 1
+def structuring_element_ellipse(height, width):
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (width, height)) restated from OpenCV's published source
+    (modules/imgproc/src/morph.dispatch.cpp, 4.x): row i spans columns c - dx .. c + dx with r = height // 2,
+    c = width // 2, dx = round(c * sqrt((r^2 - dy^2) / r^2)).  cv2 is absent from the image; the restatement is pinned
+    against the 5x5 element printed in OpenCV's "Morphological Transformations" tutorial and hand-evaluated 3x3 / 6x6
+    elements (tests/test_oracle_golden.py::test_third_party_definitions_hand_vectors)."""
+    k = np.zeros((height, width), np.uint8)
+    r, c = height // 2, width // 2
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    for i in range(height):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(round(c * math.sqrt(max((r * r - dy * dy) * inv_r2, 0.0))))  # saturate_cast<int> rounds to nearest
+            k[i, max(c - dx, 0):min(c + dx + 1, width)] = 1
     return k
+
+
+def ellipse_kernel(r):
+    """The element of compute_valid_mask (utils/utils.py:736-740): MORPH_ELLIPSE of size (2r, 2r), anchor at (r, r)."""
+    return structuring_element_ellipse(2 * r, 2 * r)
 
 
 def erode_ellipse(mask, r):
@@ -557,12 +564,21 @@ def sample_homography(rs, shape=(2, 2), shift=-1, perspective=True, scaling=True
     sh = np.array(shape[::-1], dtype=np.float64)
     p1 = pts1 * sh[None] + shift
     p2 = pts2 * sh[None] + shift
+    return get_perspective_transform(p1, p2).astype(np.float32)
+
+
+def get_perspective_transform(src, dst):
+    """cv2.getPerspectiveTransform(src, dst) restated from its published definition (imgproc/src/imgwarp.cpp): the
+    3x3 H with h33 = 1 and dst_i ~ H src_i for four point pairs, i.e. the solution of the 8x8 system
+    [x y 1 0 0 0 -ux -uy; 0 0 0 x y 1 -vx -vy] h = [u; v] in float64.  Pinned against homographies with a known closed
+    form (tests/test_oracle_golden.py::test_third_party_definitions_hand_vectors); cv2's LU pivoting order is not
+    reproduced, the results agree to float64 round-off."""
     A, b = [], []
-    for (x, y), (u, v) in zip(p1, p2):  # maps p1 -> p2
+    for (x, y), (u, v) in zip(np.asarray(src, np.float64), np.asarray(dst, np.float64)):
         A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)
         A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
     h = np.linalg.solve(np.array(A), np.array(b))
-    return np.append(h, 1.0).reshape(3, 3).astype(np.float32)
+    return np.append(h, 1.0).reshape(3, 3)
 
 
 def make_synthetic_pair(B, H, W, seed=0, semantic=False, kp_prob=0.003, erosion=3, n_classes=133):

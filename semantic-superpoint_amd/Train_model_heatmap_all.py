@@ -9,8 +9,8 @@ Deliberate behaviours kept from the reference (SURVEY.md section 8a row a14 / se
   * scalar_dict["eta_*"] are read AFTER the optimizer step (the reference logs the live parameter);
   * validation (train=False) runs BatchNorm in train mode under no_grad, i.e. it updates running statistics.
 Logging branch (every `tensorboard_interval` steps and in validation, Train_model_heatmap_all.py:447-568): the
-precision / recall scalars and the NMS map are produced on the device (`log_precision_recall`); the tensorboard image
-overlays of that branch are not drawn.
+precision / recall scalars, the NMS maps of both views and the image overlays of `images_dict` are produced on the
+device (`log_precision_recall`).
 Data parallel (one process per GPU, torch.distributed initialised by the launcher): the gradient all-reduce of the
 optimizer step is split in two buckets and overlapped with the tail of the backward pass (parallel.pair_step_overlapped).
 """
@@ -250,14 +250,35 @@ class Train_model_heatmap_all(object):
         return float(s["loss"])
 
     def log_precision_recall(self, eng, dev, B, H, W):
-        """Logging branch (Train_model_heatmap_all.py:447-568): flattenDetection of the un-warped view's logits,
-        heatmap_nms with its hard-wired defaults (nms_dist=4, conf_thresh=0.015: :693 ignores the config),
-        batch_precision_recall against labels_2D (:614-622).  The tensorboard image overlays are not produced."""
+        """Logging branch (Train_model_heatmap_all.py:447-568): flattenDetection of both views' logits, heatmap_nms
+        with its hard-wired defaults (nms_dist=4, conf_thresh=0.015: :693 ignores the config), batch_precision_recall
+        of the un-warped view against labels_2D (:555-559, :614-622) and the image overlays of :460-507 in
+        `images_dict` (the reference fills the dict and leaves `tb_images_dict` commented out at :565; so does this)."""
         heat = eng.detector_heatmap(0, B, H, W)
         nms, pr = L.op_heatmap_nms(heat, dev["labels_2D"].float().contiguous(), conf_thresh=0.015, nms_dist=4)
         prm = pr.cpu().numpy().mean(axis=0)
         self.scalar_dict.update({"precision": float(prm[0]), "recall": float(prm[1])})
-        self.images_dict = {"heatmap_org_nms_batch": nms.unsqueeze(1)}
+        self.images_dict = {"heatmap_org_nms_batch": nms.unsqueeze(1).cpu().numpy()}
+        views = [("original", dev["labels_2D"], heat, nms, dev["image"])]
+        if "warped_img" in dev:
+            heat_w = eng.detector_heatmap(1, B, H, W)
+            nms_w, _ = L.op_heatmap_nms(heat_w, dev["warped_labels"].float().contiguous(), conf_thresh=0.015, nms_dist=4)
+            self.images_dict["heatmap_warp_nms_batch"] = nms_w.unsqueeze(1).cpu().numpy()
+            views.append(("warped", dev["warped_labels"], heat_w, nms_w, dev["warped_img"]))
+        for name, lab, hm, nm, img in views:
+            # :473-479 passes heatmap_nms_batch[np.newaxis]: ONE overlay, labels / image of sample 0 over the NMS map of
+            # sample 0; the heat-map overlays (:481-487) cover the whole batch
+            self.images_dict[name + "_nms_overlap"] = self.img_overlap(lab[:1], nm[:1].unsqueeze(1), img[:1]).cpu().numpy()
+            self.images_dict[name + "_heatmap_nms_overlap"] = self.img_overlap(lab, hm.view(B, 1, H, W), img).cpu().numpy()
+
+    @staticmethod
+    def img_overlap(img_r, img_g, img_gray):
+        """utils/draw.py:50-56 for a batch on any device: [B,1,H,W] x 3 -> [B,3,H,W], gray image in all three channels
+        plus img_r on red and img_g on green, clamped to [0, 1]."""
+        out = img_gray.float().repeat(1, 3, 1, 1)
+        out[:, 0:1] += img_r.float()
+        out[:, 1:2] += img_g.float()
+        return out.clamp_(0.0, 1.0)
 
     def tb_scalar_dict(self, losses, task="training"):
         if self._writer is None:

@@ -1821,12 +1821,20 @@ int ssp_op_sem_finalize(const float* sem_warped_dev, const float* valid_dev, int
 int ssp_op_bn_bwd(const float* y_dev, const float* dout_dev, const float* gamma_dev, const float* stats4_dev,
                   float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int hh,
                   int w, int c, int relu, int pool, void* stream) {
+  return ssp_op_bn_bwd_strided(y_dev, dout_dev, gamma_dev, stats4_dev, dy_dev, dgamma_dev, dbeta_dev, dbias_dev, sums_dev, n,
+                               hh, w, c, c, relu, pool, stream);
+}
+
+int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float* gamma_dev, const float* stats4_dev,
+                          float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n,
+                          int hh, int w, int c, int cs, int relu, int pool, void* stream) {
+  if (cs < c || (cs & 3)) return fail(-1, "ssp_op_bn_bwd_strided: the channel stride must be a multiple of 4 and >= C");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(sums_dev, 0, 2 * (size_t)c * NREP * sizeof(double), st));
   BnBwdArgs a;
   a.y = y_dev; a.dout = dout_dev; a.dy = dy_dev; a.scale = stats4_dev; a.shift = stats4_dev + c; a.mean = stats4_dev + 2 * c;
   a.invstd = stats4_dev + 3 * c; a.gamma = gamma_dev; a.sums = sums_dev; a.dbias = dbias_dev; a.N = n; a.H = hh; a.W = w;
-  a.C = c; a.y_cs = c; a.y_co = 0; a.d_cs = c; a.d_co = 0; a.dy_cs = c; a.dy_co = 0; a.count = (double)n * hh * w;
+  a.C = c; a.y_cs = cs; a.y_co = 0; a.d_cs = cs; a.d_co = 0; a.dy_cs = cs; a.dy_co = 0; a.count = (double)n * hh * w;
   float* k12 = nullptr;
   HIPCHK(hipMallocAsync((void**)&k12, 2 * c * sizeof(float), st));
   a.k12 = k12; a.x = nullptr; a.apool = nullptr; a.beta = nullptr; a.pool_fix = 0;

@@ -61,7 +61,7 @@ _lib = None
 EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ssp_bn_channel_count",
            "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
            "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
-           "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd",
+           "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd", "ssp_op_bn_bwd_strided",
            "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_set_conv_algo", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
            "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
            "ssp_op_flatten_detection", "ssp_op_combine_heatmap", "ssp_op_heatmap_points", "ssp_op_soft_argmax_points", "ssp_detector_heatmap", "ssp_op_heatmap_nms", "ssp_op_dense_loss",
@@ -123,6 +123,7 @@ def load_library(path=None):
     lib.ssp_op_erode.argtypes = [vp, vp, i, i, i, i, vp]
     lib.ssp_op_warp_labels.argtypes = [vp, vp, vp, i, i, i, vp]
     lib.ssp_op_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+    lib.ssp_op_bn_bwd_strided.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
     ep = C.POINTER(SspExportParams)
@@ -691,18 +692,20 @@ def op_dense_loss(desc_a_nchw, desc_b_nchw, homographies, mask_valid, lamda_d=25
 
 
 def op_bn_bwd(y_nhwc, dout_nhwc, gamma, scale, shift, mean, invstd, relu=True, pool=False):
-    """Backward of BatchNorm2d(train)+ReLU(+MaxPool2d(2)); returns (dy, dgamma, dbeta, dbias)."""
+    """Backward of BatchNorm2d(train)+ReLU(+MaxPool2d(2)); returns (dy, dgamma, dbeta, dbias).  The channel count is
+    len(gamma); the NHWC tensors may be channel-padded (pixel stride = their last dimension, a multiple of 4)."""
     lib = load_library()
     _need_gpu(y_nhwc, "y")
-    N, H, W, Cc = y_nhwc.shape
+    N, H, W, cs = y_nhwc.shape
+    Cc = gamma.numel()
     dev = y_nhwc.device
     stats4 = torch.cat([scale, shift, mean, invstd]).contiguous()
-    dy = torch.empty_like(y_nhwc)
+    dy = torch.zeros_like(y_nhwc) if cs != Cc else torch.empty_like(y_nhwc)
     dg, db, dbias = (torch.zeros(Cc, dtype=torch.float32, device=dev) for _ in range(3))
     sums = torch.zeros(NREP * 2 * Cc, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        _check(lib.ssp_op_bn_bwd(_ptr(y_nhwc), _ptr(dout_nhwc), _ptr(gamma), _ptr(stats4), _ptr(dy), _ptr(dg), _ptr(db),
-                                 _ptr(dbias), _ptr(sums), N, H, W, Cc, int(relu), int(pool), _stream()))
+        _check(lib.ssp_op_bn_bwd_strided(_ptr(y_nhwc), _ptr(dout_nhwc), _ptr(gamma), _ptr(stats4), _ptr(dy), _ptr(dg),
+                                         _ptr(db), _ptr(dbias), _ptr(sums), N, H, W, Cc, cs, int(relu), int(pool), _stream()))
     return dy, dg, db, dbias
 
 

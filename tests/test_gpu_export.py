@@ -283,11 +283,27 @@ def test_trainer_logs_precision_recall():
         semi = C.forward(C.to_torch(state), sample["image"], "SuperPointNet_gauss2", train=True)["semi"]
     heat = C.flatten_detection(semi).numpy()
     nms = np.stack([C.heatmap_nms(h) for h in heat])
-    mine = agent.images_dict["heatmap_org_nms_batch"].cpu().numpy()[:, 0]
+    mine = agent.images_dict["heatmap_org_nms_batch"][:, 0]
     assert float((mine != nms).mean()) < 2e-3  # fp32 noise at the 0.015 threshold / near-ties may flip a few points
     pr = C.batch_precision_recall(t(nms[:, None]), sample["labels_2D"])
     assert abs(agent.scalar_dict["precision"] - pr["precision"]) < 0.02
     assert abs(agent.scalar_dict["recall"] - pr["recall"]) < 0.02
+    # image overlays of the branch (utils/draw.py:50-56 restated): gray x 3, labels on red, NMS / heat map on green.
+    # The NMS overlay is ONE image (sample 0: the reference passes heatmap_nms_batch[np.newaxis]), the heat-map overlay
+    # covers the batch.
+    def overlap(r, g, gray):
+        img = np.concatenate((gray, gray, gray), axis=0)
+        img[0] += r[0]
+        img[1] += g[0]
+        return np.clip(img, 0.0, 1.0)
+    im = agent.images_dict
+    assert im["original_nms_overlap"].shape == (1, 3, H, W) and im["original_heatmap_nms_overlap"].shape == (B, 3, H, W)
+    assert {"warped_nms_overlap", "warped_heatmap_nms_overlap", "heatmap_warp_nms_batch"} <= set(im)
+    want = overlap(sample["labels_2D"][0].numpy(), mine[0:1], sample["image"][0].numpy())
+    assert np.abs(im["original_nms_overlap"][0] - want).max() < 1e-6
+    for i in range(B):
+        want = overlap(sample["labels_2D"][i].numpy(), heat[i].reshape(1, H, W), sample["image"][i].numpy())
+        assert np.abs(im["original_heatmap_nms_overlap"][i] - want).max() < 1e-4
     agent.train_val_sample(sample, n_iter=3, train=False)  # validation always logs
     assert {"precision", "recall"} <= set(agent.scalar_dict)
 

@@ -170,13 +170,11 @@ def test_bn_relu_pool_backward(N, H, W, C, relu, pool):
         o = torch.zeros(t.shape[0], t.shape[2], t.shape[3], c_pad)
         o[..., :t.shape[1]] = t.detach().permute(0, 2, 3, 1)
         return o.contiguous().to(dev)
-    if Cp != C:
-        pytest.skip("padded-stride BN backward is covered by the model-level test")
     dy, dg, db, dbias = L.op_bn_bwd(nhwc(y), nhwc(g), gamma.detach().to(dev), scale.to(dev), shift.to(dev), mean.to(dev),
                                     invstd.to(dev), relu, pool)
     torch.cuda.synchronize()
     ref = y.grad.permute(0, 2, 3, 1)
-    assert _rel(dy.cpu(), ref) < 1e-4
+    assert _rel(dy.cpu()[..., :C], ref) < 1e-4  # C = 65 rides in 68-float pixels like the detector head
     assert _rel(dg.cpu(), gamma.grad) < 1e-4 and _rel(db.cpu(), beta.grad) < 1e-4
 
 

@@ -1,5 +1,6 @@
 """CPU: the oracle (oracle/cpu_ref.py) against the fixtures generated from the REAL reference
 (oracle/make_goldens.py).  No GPU, no HIP."""
+import math
 import numpy as np
 import pytest
 import torch
@@ -157,6 +158,56 @@ def test_erode_ellipse_shape():
     m[10, 10] = 0
     e = C.erode_ellipse(m, 3)
     assert e.sum() == 400 - k.sum()
+
+
+def test_third_party_definitions_hand_vectors():
+    """cv2 / torchgeometry are absent from the image: their restatements are pinned against vectors that do not come
+    from this repository - OpenCV's documented 5x5 ellipse, hand-evaluated elements, homographies with a closed form,
+    a two-point soft-argmax."""
+    # cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (5, 5)) as printed in OpenCV's morphology tutorial
+    assert C.structuring_element_ellipse(5, 5).tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1],
+                                                            [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+    assert C.structuring_element_ellipse(3, 3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    # (6, 6) = erosion_radius 3 (configs: erosion_radius 3), evaluated by hand from the source: r = c = 3,
+    # dx(dy) = round(3 sqrt(1 - dy^2 / 9)) = 0, 2, 3, 3, 3, 2 for dy = -3 .. 2 -> columns 3 - dx .. 3 + dx (clipped)
+    assert C.ellipse_kernel(3).tolist() == [[0, 0, 0, 1, 0, 0], [0, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1],
+                                            [1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1]]
+    # erosion with that element: a single zero at (10, 10) spreads to the REFLECTED support (anchor (3, 3))
+    m = torch.ones(20, 20)
+    m[10, 10] = 0
+    e = C.erode_ellipse(m, 3)
+    k = torch.tensor(C.ellipse_kernel(3))
+    for y in range(20):
+        for x in range(20):
+            i, j = 10 - y + 3, 10 - x + 3  # out[y, x] = min_k mask[y + i - 3, x + j - 3]
+            hit = 0 <= i < 6 and 0 <= j < 6 and bool(k[i, j])
+            assert e[y, x] == (0.0 if hit else 1.0), (y, x)
+    # getPerspectiveTransform: closed-form homographies are recovered from four correspondences
+    sq = np.array([[0.0, 0.0], [0.0, 1.0], [1.0, 1.0], [1.0, 0.0]])  # the reference's pts1 (homographies.py:59)
+    for Hm in (np.eye(3), np.array([[2.0, 0, 3.0], [0, 0.5, -1.0], [0, 0, 1]]),
+               np.array([[np.cos(0.3), -np.sin(0.3), 0.2], [np.sin(0.3), np.cos(0.3), -0.1], [0, 0, 1]]),
+               np.array([[1.1, 0.05, 0.3], [-0.02, 0.9, 0.1], [0.15, -0.25, 1.0]])):
+        q = np.c_[sq, np.ones(4)] @ Hm.T
+        got = C.get_perspective_transform(sq, q[:, :2] / q[:, 2:])
+        assert np.abs(got - Hm).max() < 1e-12
+    # the textbook unit-square -> quadrilateral map (Heckbert 1989, eq. for the projective mapping of a square):
+    # square (0,0),(1,0),(1,1),(0,1) -> (0,0),(2,0),(3,2),(0,1): g = 1/3... evaluated by hand below
+    src = np.array([[0.0, 0], [1, 0], [1, 1], [0, 1]])
+    dst = np.array([[0.0, 0], [2, 0], [3, 2], [0, 1]])
+    # sx = x0-x1+x2-x3 = 1, sy = y0-y1+y2-y3 = 1; dx1 = x1-x2 = -1, dx2 = x3-x2 = -3, dy1 = y1-y2 = -2, dy2 = y3-y2 = -1
+    # det = dx1 dy2 - dx2 dy1 = 1 - 6 = -5;  g = (sx dy2 - dx2 sy) / det = (-1 + 3) / -5 = -0.4
+    # h = (dx1 sy - sx dy1) / det = (-1 + 2) / -5 = -0.2;  a = x1 - x0 + g x1 = 2 - 0.8 = 1.2;  b = x3 - x0 + h x3 = 0
+    # d = y1 - y0 + g y1 = 0;  e = y3 - y0 + h y3 = 1 - 0.2 = 0.8
+    want = np.array([[1.2, 0.0, 0.0], [0.0, 0.8, 0.0], [-0.4, -0.2, 1.0]])
+    assert np.abs(C.get_perspective_transform(src, dst) - want).max() < 1e-12
+    # SpatialSoftArgmax2d (torchgeometry 0.1.2, normalized_coordinates=False): two cells carry all the mass
+    x = torch.full((1, 1, 5, 5), -1e30)
+    x[0, 0, 2, 1] = math.log(0.25)
+    x[0, 0, 2, 3] = math.log(0.75)
+    ex, ey = C.spatial_soft_argmax2d(x)[0, 0].tolist()
+    inv = 1.0 / (1.0 / 3.0 + 1.0 + 1e-6)  # exp(x - max) = {1/3, 1}; the eps enters the normaliser
+    assert abs(ex - (1.0 / 3.0 + 3.0) * inv) < 1e-6 and abs(ey - 2.0 * (4.0 / 3.0) * inv) < 1e-6
+    assert abs(ex - 2.5) < 1e-5 and abs(ey - 2.0) < 1e-5
 
 
 G8 = ("sp_64x96_v6", "ssp_48x64_v5", "sp_120x160_v4")
