@@ -521,21 +521,28 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
   f32x4 xreg[NX], dreg[ND];
   unsigned xmask = 0;
 
-  // halo / dY raster positions of this thread's staging slots (slot i = pixel (tid >> 4) + 32 i), packed r | c << 8
-  int xrc[NX], drc[ND];
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int pp = (tid >> 4) + 32 * i, r = pp / G::WT;
-    xrc[i] = pp < G::HT * G::WT ? (r | ((pp - r * G::WT) << 8)) : 0xFFFF;  // 0xFFFF: r = 255 is never inside the image
-  }
-#pragma unroll
-  for (int i = 0; i < ND; ++i) {
-    const int pp = (tid >> 4) + 32 * i, r = pp / G::TW;
-    drc[i] = r | ((pp - r * G::TW) << 8);
-  }
   const int xpix = a.in_cs * 4, xrow = a.W * xpix, dpix = a.dout_cs * 4, drow = a.W * dpix;
   const int xq = civalid ? (a.in_co + ci0) * 4 : -1, dq = covalid ? (a.dout_co + co0) * 4 : -1;
   constexpr unsigned OOB = 0x80000000u;
+  // byte offsets of this thread's staging slots (slot i = pixel (tid >> 4) + 32 i of the halo / dY raster) relative to
+  // the first halo / dY pixel of a tile; OOB for slots past the raster and for channel quads outside the tensor.
+  // Tiles whose halo lies inside the image (3/4 of them at 240x320) add the tile origin as the SCALAR offset of the
+  // buffer load: no per-slot address arithmetic in the MFMA phase (it cost ~90 VALU instructions per tile and thread).
+  unsigned xoffv[NX], doffv[ND];
+  unsigned xmask_in = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int pp = (tid >> 4) + 32 * i, r = pp / G::WT, c = pp - r * G::WT;
+    const bool ok = xq >= 0 && pp < G::HT * G::WT;
+    xoffv[i] = ok ? (unsigned)(r * xrow + c * xpix + xq) : OOB;
+    xmask_in |= (ok ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int pp = (tid >> 4) + 32 * i, r = pp / G::TW, c = pp - r * G::TW;
+    doffv[i] = dq >= 0 ? (unsigned)(r * drow + c * dpix + dq) : OOB;
+  }
+  bool cur_inside = false, nxt_inside = false;  // wave-uniform: the staged / the prefetched tile is an interior tile
   // one buffer descriptor per image (32-bit offsets inside it); an offset beyond num_records returns 0
 #define WGW_ISSUE(TILE)                                                                                       \
   if (!(a.ablate & 1)) {                                                                                      \
@@ -547,19 +554,31 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
         const_cast<float*>(pr_ ? a.in2 : a.in) + (size_t)n_ * a.H * a.W * a.in_cs, 0, a.H * xrow, 0x00020000); \
     const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
         const_cast<float*>(pr_ ? a.dout2 : a.dout) + (size_t)n_ * a.H * a.W * a.dout_cs, 0, a.H * drow, 0x00020000); \
-    xmask = 0;                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                          \
-      const int gy = ty0_ - 1 + (xrc[i] & 255), gx = tx0_ - 1 + (xrc[i] >> 8);                                \
-      const bool ok = xq >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;                \
-      xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
-          rx_, ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB, 0, 0));                                     \
-      xmask |= (ok ? 1u : 0u) << i;                                                                           \
-    }                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                          \
-      const int gy = ty0_ + (drc[i] & 255), gx = tx0_ + (drc[i] >> 8);                                        \
-      const bool ok = dq >= 0 && gy < a.H && gx < a.W;                                                        \
-      dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
-          rd_, ok ? (unsigned)(gy * drow + gx * dpix + dq) : OOB, 0, 0));                                     \
+    nxt_inside = ty0_ >= 1 && ty0_ + G::TH + 1 <= a.H && tx0_ >= 1 && tx0_ + G::TW + 1 <= a.W;               \
+    if (nxt_inside) {                                                                                         \
+      const int xb_ = (ty0_ - 1) * xrow + (tx0_ - 1) * xpix, db_ = ty0_ * drow + tx0_ * dpix;                 \
+      _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                          \
+        xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, xoffv[i], xb_, 0));    \
+      _Pragma("unroll") for (int i = 0; i < ND; ++i)                                                          \
+        dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, doffv[i], db_, 0));    \
+      xmask = xmask_in;                                                                                       \
+    } else {                                                                                                  \
+      xmask = 0;                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                        \
+        const int pp_ = (tid >> 4) + 32 * i, r_ = pp_ / G::WT, c_ = pp_ - r_ * G::WT;                         \
+        const int gy = ty0_ - 1 + r_, gx = tx0_ - 1 + c_;                                                     \
+        const bool ok = xq >= 0 && pp_ < G::HT * G::WT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
+        xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                            \
+            rx_, ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB, 0, 0));                                   \
+        xmask |= (ok ? 1u : 0u) << i;                                                                         \
+      }                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                        \
+        const int pp_ = (tid >> 4) + 32 * i, r_ = pp_ / G::TW, c_ = pp_ - r_ * G::TW;                         \
+        const int gy = ty0_ + r_, gx = tx0_ + c_;                                                             \
+        const bool ok = dq >= 0 && gy < a.H && gx < a.W;                                                      \
+        dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                            \
+            rd_, ok ? (unsigned)(gy * drow + gx * dpix + dq) : OOB, 0, 0));                                   \
+      }                                                                                                       \
     }                                                                                                         \
   }
 
@@ -573,6 +592,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
   if (t_begin < t_end) WGW_ISSUE(t_begin)
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // all waves finished reading the previous tile's LDS image
+    cur_inside = nxt_inside;
     if (!(a.ablate & 2)) {
       const int cur_prob = tile >= a.ntiles ? 1 : 0;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -580,6 +600,19 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
         sc = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + q16 * 4);
         sh = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + 64 + q16 * 4);
       }
+      if (IN_MODE != 0 && cur_inside) {
+        // interior tile: no zero padding anywhere (channel quads outside the tensor carry scale 1 / shift 0 and load 0)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const int pp = (tid >> 4) + 32 * i;
+          if (pp < G::HT * G::WT) {
+            f32x4 v = pk4_fma(xreg[i], sc, sh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            *reinterpret_cast<f32x4*>(sX + pp * 64 + q16 * 4) = v;
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         const int pp = (tid >> 4) + 32 * i;
@@ -588,6 +621,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
           if (IN_MODE != 0) v = bn_relu_quad(v, sc, sh, !((xmask >> i) & 1u));
           *reinterpret_cast<f32x4*>(sX + pp * 64 + q16 * 4) = v;
         }
+      }
       }
 #pragma unroll
       for (int i = 0; i < ND; ++i) {

@@ -108,7 +108,10 @@ def test_conv_dgrad(N, H, W, cin, cout, ks, conv_algo):
                                                       (2, 30, 40, 256, 64, 1, 1), (3, 5, 8, 256, 256, 1, 0),
                                                       (1, 9, 11, 64, 64, 3, 1),     # odd map (direct kernel)
                                                       (2, 10, 12, 48, 70, 3, 0),    # even map, ragged tiles, tails
-                                                      (1, 36, 64, 64, 64, 3, 1)])   # several block tiles per image
+                                                      (1, 36, 64, 64, 64, 3, 1),    # several block tiles per image
+                                                      (2, 24, 128, 64, 64, 3, 1),   # 4x32 tiles with interior ones
+                                                      (1, 24, 128, 128, 64, 3, 0),  # (scalar tile origin, no masks)
+                                                      (1, 56, 40, 64, 128, 3, 1)])  # 16x8 tiles with interior ones
 def test_conv_wgrad(N, H, W, cin, cout, ks, mode, conv_algo):
     from semantic_superpoint_amd import lib as L
     dev = _dev()
