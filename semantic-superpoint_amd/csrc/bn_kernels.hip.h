@@ -59,23 +59,36 @@ __device__ __forceinline__ void l0_taps(const float* __restrict__ xr, int ox, bo
   xv[8] = (down && r) ? t8 : 0.f;
 }
 
-// four output channels of the first layer in registers; y() is THE fma chain of the layer (forward and the
+// four output channels of the first layer in registers (two channel PAIRS: every fma of the layer is one half of a
+// v_pk_fma_f32, the tap value broadcast to both halves); y4() is THE fma chain of the layer (forward and the
 // recomputation in its BatchNorm backward must agree bit for bit, or the ReLU mask would differ)
+struct L0Taps {
+  f32x2 p[5];  // taps 0..8 in pairs (2k, 2k + 1); p[4].y unused
+  __device__ __forceinline__ void set(const float (&xv)[9]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = f32x2{xv[2 * k], xv[2 * k + 1]};
+    p[4] = f32x2{xv[8], 0.f};
+  }
+};
 struct L0Conv {
-  float w[4][9], b[4];
+  f32x2 w[2][9], b[2];  // [channel pair][tap]
   __device__ __forceinline__ void load(const float* __restrict__ wt, const float* __restrict__ bias, int c0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      b[i] = bias[c0 + i];
+    for (int h = 0; h < 2; ++h) {
+      b[h] = f32x2{bias[c0 + 2 * h], bias[c0 + 2 * h + 1]};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) w[i][t] = wt[(c0 + i) * 9 + t];
+      for (int t = 0; t < 9; ++t) w[h][t] = f32x2{wt[(c0 + 2 * h) * 9 + t], wt[(c0 + 2 * h + 1) * 9 + t]};
     }
   }
-  __device__ __forceinline__ float y(int i, const float (&xv)[9]) const {
-    float o = b[i];
+  // y[c0 + 2h], y[c0 + 2h + 1] = bias + sum_t x[t] * w[.][t], taps in ascending order
+  __device__ __forceinline__ f32x2 y2(int h, const L0Taps& x) const {
+    f32x2 o = b[h];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) o = fmaf(xv[t], w[i][t], o);
-    return o;
+    for (int k = 0; k < 4; ++k) {
+      o = pk_fma_bcast<false>(x.p[k], w[h][2 * k], o);
+      o = pk_fma_bcast<true>(x.p[k], w[h][2 * k + 1], o);
+    }
+    return pk_fma_bcast<false>(x.p[4], w[h][8], o);
   }
 };
 
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
   const int pl = tid >> 4;     // pixel lane 0..15
   L0Conv cv;
   cv.load(w, bias, q * 4);
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x2 s01 = {0.f, 0.f}, s23 = s01, q01 = s01, q23 = s01;  // BatchNorm sums / sums of squares of the channel pairs
   const int rows = N * H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int oy = row % H;
@@ -104,17 +117,15 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
     for (int ox = pl; ox < W; ox += 16) {
       float v[9];
       l0_taps(xr, ox, up, down, W, v);
-      float o[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) o[c] = cv.y(c, v);
-      *reinterpret_cast<float4*>(orow + (size_t)ox * 64) = make_float4(o[0], o[1], o[2], o[3]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[c] += o[c];
-        acc[4 + c] += o[c] * o[c];
-      }
+      L0Taps xt;
+      xt.set(v);
+      const f32x2 o01 = cv.y2(0, xt), o23 = cv.y2(1, xt);
+      *reinterpret_cast<f32x4*>(orow + (size_t)ox * 64) = cat2(o01, o23);
+      s01 = pk_add(s01, o01); s23 = pk_add(s23, o23);
+      q01 = pk_fma(o01, o01, q01); q23 = pk_fma(o23, o23, q23);
     }
   }
+  float acc[8] = {s01[0], s01[1], s23[0], s23[1], q01[0], q01[1], q23[0], q23[1]};
   if (stats != nullptr) {
     reduce_by_column<8>(acc, red, 16);
     if (tid < 16) {
@@ -488,12 +499,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
   const int c0 = q * 4;
   L0Conv cv;
   cv.load(w0, b0, c0);
-  float scv[4], shv[4], muv[4], isv[4];
+  // per channel pair: z = y scale + shift; xhat = y invstd - mean invstd
+  f32x2 sc2[2], sh2[2], is2[2], nm2[2], s1[2], s2[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    scv[i] = a.scale[c0 + i]; shv[i] = a.shift[c0 + i]; muv[i] = a.mean[c0 + i]; isv[i] = a.invstd[c0 + i];
+  for (int h = 0; h < 2; ++h) {
+    const int c = c0 + 2 * h;
+    sc2[h] = f32x2{a.scale[c], a.scale[c + 1]}; sh2[h] = f32x2{a.shift[c], a.shift[c + 1]};
+    is2[h] = f32x2{a.invstd[c], a.invstd[c + 1]};
+    nm2[h] = f32x2{-a.mean[c] * a.invstd[c], -a.mean[c + 1] * a.invstd[c + 1]};
+    s1[h] = f32x2{0.f, 0.f}; s2[h] = s1[h];
   }
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int rows = a.N * a.H, W = a.W;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int oy = row % a.H;
@@ -514,17 +529,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
 #pragma unroll
       for (int j = 0; j < L0_UNROLL; ++j) {
         const float dv[4] = {d4[j].x, d4[j].y, d4[j].z, d4[j].w};
+        L0Taps xt;
+        xt.set(xv[j]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float yv = cv.y(i, xv[j]);
-          const float z = fmaf(yv, scv[i], shv[i]);
-          const float dz = z > 0.f ? dv[i] : 0.f;
-          acc[i] += dz;
-          acc[4 + i] += dz * ((yv - muv[i]) * isv[i]);
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 yv = cv.y2(h, xt);
+          const f32x2 z = pk_fma(yv, sc2[h], sh2[h]);
+          const f32x2 dz = {z[0] > 0.f ? dv[2 * h] : 0.f, z[1] > 0.f ? dv[2 * h + 1] : 0.f};
+          s1[h] = pk_add(s1[h], dz);
+          s2[h] = pk_fma(dz, pk_fma(yv, is2[h], nm2[h]), s2[h]);
         }
       }
     }
   }
+  float acc[8] = {s1[0][0], s1[0][1], s1[1][0], s1[1][1], s2[0][0], s2[0][1], s2[1][0], s2[1][1]};
   reduce_by_column<8>(acc, red, 16);
   if (tid < 16) {
     double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 128;
@@ -549,19 +567,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
   const int c0 = q * 4;
   L0Conv cv;
   cv.load(w0, b0, c0);
-  float scv[4], shv[4], muv[4], isv[4], k1v[4], k2v[4], gsv[4];
+  // per channel pair: z = y scale + shift; xhat = y invstd - mean invstd; dY = gs (dZ - k1 - xhat k2)
+  f32x2 sc2[2], sh2[2], is2[2], nm2[2], nk1[2], nk2[2], gs2[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    scv[i] = a.scale[c0 + i]; shv[i] = a.shift[c0 + i]; muv[i] = a.mean[c0 + i]; isv[i] = a.invstd[c0 + i];
-    k1v[i] = a.k12[c0 + i];
-    k2v[i] = a.k12[64 + c0 + i];
-    gsv[i] = a.gamma[c0 + i] * isv[i];
+  for (int h = 0; h < 2; ++h) {
+    const int c = c0 + 2 * h;
+    sc2[h] = f32x2{a.scale[c], a.scale[c + 1]}; sh2[h] = f32x2{a.shift[c], a.shift[c + 1]};
+    is2[h] = f32x2{a.invstd[c], a.invstd[c + 1]};
+    nm2[h] = f32x2{-a.mean[c] * a.invstd[c], -a.mean[c + 1] * a.invstd[c + 1]};
+    nk1[h] = f32x2{-a.k12[c], -a.k12[c + 1]};
+    nk2[h] = f32x2{-a.k12[64 + c], -a.k12[64 + c + 1]};
+    gs2[h] = f32x2{a.gamma[c] * a.invstd[c], a.gamma[c + 1] * a.invstd[c + 1]};
   }
-  float wacc[4][9];
+  f32x2 wacc[2][9];  // dW0 of the two channel pairs
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wacc[i][t] = 0.f;
+    for (int t = 0; t < 9; ++t) wacc[h][t] = f32x2{0.f, 0.f};
   const int rows = a.N * a.H, W = a.W;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int oy = row % a.H;
@@ -582,15 +604,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
 #pragma unroll
       for (int j = 0; j < L0_UNROLL_APPLY; ++j) {
         const float dv[4] = {d4[j].x, d4[j].y, d4[j].z, d4[j].w};
+        const float okf = ok[j] ? 1.f : 0.f;  // a clamped (repeated) pixel past the end of the row contributes nothing
+        L0Taps xt;
+        xt.set(xv[j]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float yv = cv.y(i, xv[j]);
-          const float z = fmaf(yv, scv[i], shv[i]);
-          const float dz = z > 0.f ? dv[i] : 0.f;
-          const float xh = (yv - muv[i]) * isv[i];
-          const float g = ok[j] ? gsv[i] * (dz - k1v[i] - xh * k2v[i]) : 0.f;
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 yv = cv.y2(h, xt);
+          const f32x2 z = pk_fma(yv, sc2[h], sh2[h]);
+          const f32x2 dz = {z[0] > 0.f ? dv[2 * h] : 0.f, z[1] > 0.f ? dv[2 * h + 1] : 0.f};
+          const f32x2 xh = pk_fma(yv, is2[h], nm2[h]);
+          const f32x2 g = pk_mul(pk_mul(gs2[h], f32x2{okf, okf}), pk_fma(xh, nk2[h], pk_add(dz, nk1[h])));
 #pragma unroll
-          for (int t = 0; t < 9; ++t) wacc[i][t] = fmaf(g, xv[j][t], wacc[i][t]);
+          for (int k = 0; k < 4; ++k) {
+            wacc[h][2 * k] = pk_fma_bcast<false>(xt.p[k], g, wacc[h][2 * k]);
+            wacc[h][2 * k + 1] = pk_fma_bcast<true>(xt.p[k], g, wacc[h][2 * k + 1]);
+          }
+          wacc[h][8] = pk_fma_bcast<false>(xt.p[4], g, wacc[h][8]);
         }
       }
     }
@@ -600,7 +629,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
   for (int i = 0; i < 4; ++i) {
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[tid * 10 + t] = wacc[i][t];
+    for (int t = 0; t < 9; ++t) red[tid * 10 + t] = wacc[i >> 1][t][i & 1];
     __syncthreads();
     if (tid < 160) {  // 16 quads x 10 slots
       const int qq = tid / 10, t = tid - qq * 10;

@@ -11,8 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pk_math.hip.h"
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace sspk {
 

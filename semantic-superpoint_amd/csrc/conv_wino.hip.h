@@ -41,58 +41,6 @@ __device__ __forceinline__ int wino_raw_off(int r, int c, int q, int HC) {
   return ((r * (HC >> 1) + (c >> 1)) * 2 + ((c ^ (c >> 1)) & 1)) * CK + q * 4;
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Two-wide fp32 vector arithmetic pinned to the packed instructions (hipcc scalarises most f32x2 expressions, in
-// particular every subtraction): one VALU issue slot for two values.  The fp32 MFMA executes on the vector ALUs of
-// this chip, so every VALU instruction saved in a Winograd kernel is matrix-pipe time.
-// HAZARDS: hipcc does not insert wait states for registers read or written by inline asm.  (a) A register written
-// here must not be read by an MFMA within the next 2 instructions (complete all operands, fence, then issue the
-// MFMAs); (b) accumulators of in-flight MFMAs must not be read here (mfma_results_guard() before the first use).
-// `volatile` keeps the program order of these statements among themselves.
-__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
-  f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
-  return d;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
-  f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
-  return d;
-}
-__device__ __forceinline__ f32x2 pk_nadd(f32x2 x, f32x2 y) {  // -(x + y)
-  f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(d) : "v"(x), "v"(y));
-  return d;
-}
-__device__ __forceinline__ f32x2 pk_fma(f32x2 x, f32x2 y, f32x2 z) {
-  f32x2 d;
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
-  return d;
-}
-__device__ __forceinline__ f32x2 pk_mul(f32x2 x, f32x2 y) {
-  f32x2 d;
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
-  return d;
-}
-__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
-__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
-__device__ __forceinline__ f32x4 cat2(f32x2 l, f32x2 h) { return __builtin_shufflevector(l, h, 0, 1, 2, 3); }
-__device__ __forceinline__ f32x4 pk4_add(f32x4 x, f32x4 y) { return cat2(pk_add(lo2(x), lo2(y)), pk_add(hi2(x), hi2(y))); }
-__device__ __forceinline__ f32x4 pk4_sub(f32x4 x, f32x4 y) { return cat2(pk_sub(lo2(x), lo2(y)), pk_sub(hi2(x), hi2(y))); }
-__device__ __forceinline__ f32x4 pk4_fma(f32x4 x, f32x4 y, f32x4 z) {
-  return cat2(pk_fma(lo2(x), lo2(y), lo2(z)), pk_fma(hi2(x), hi2(y), hi2(z)));
-}
-__device__ __forceinline__ f32x4 pk4_fma_s(f32x2 s, f32x4 y, f32x4 z) {  // s (both halves) * y + z
-  return cat2(pk_fma(s, lo2(y), lo2(z)), pk_fma(s, hi2(y), hi2(z)));
-}
-// All MFMAs issued so far have written their accumulators (16-pass MFMA: 18 wait states) - before inline asm reads them.
-__device__ __forceinline__ void mfma_results_guard() {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 15\n\ts_nop 3");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 // relu(v * scale + shift) of a loaded quad, 0 for zero-padding pixels: two packed fmas + one v_med3 per element
 // (clamp to [0, +inf] or, for padding, to [0, 0]) instead of fma + max + select, on the staging path of the MFMA loop
 __device__ __forceinline__ f32x4 bn_relu_quad(f32x4 v, f32x4 sc, f32x4 sh, bool padding) {

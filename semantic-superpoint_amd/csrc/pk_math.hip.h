@@ -1,0 +1,72 @@
+// Packed (two-wide) fp32 vector arithmetic pinned to the v_pk_* instructions through inline asm, shared by the Winograd
+// kernels and the first-layer kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace sspk {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two-wide fp32 vector arithmetic pinned to the packed instructions (hipcc scalarises most f32x2 expressions, in
+// particular every subtraction): one VALU issue slot for two values.  The fp32 MFMA executes on the vector ALUs of
+// this chip, so every VALU instruction saved in a Winograd kernel is matrix-pipe time.
+// HAZARDS: hipcc does not insert wait states for registers read or written by inline asm.  (a) A register written
+// here must not be read by an MFMA within the next 2 instructions (complete all operands, fence, then issue the
+// MFMAs); (b) accumulators of in-flight MFMAs must not be read here (mfma_results_guard() before the first use).
+// `volatile` keeps the program order of these statements among themselves.
+__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_nadd(f32x2 x, f32x2 y) {  // -(x + y)
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 x, f32x2 y, f32x2 z) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x4 cat2(f32x2 l, f32x2 h) { return __builtin_shufflevector(l, h, 0, 1, 2, 3); }
+__device__ __forceinline__ f32x4 pk4_add(f32x4 x, f32x4 y) { return cat2(pk_add(lo2(x), lo2(y)), pk_add(hi2(x), hi2(y))); }
+__device__ __forceinline__ f32x4 pk4_sub(f32x4 x, f32x4 y) { return cat2(pk_sub(lo2(x), lo2(y)), pk_sub(hi2(x), hi2(y))); }
+__device__ __forceinline__ f32x4 pk4_fma(f32x4 x, f32x4 y, f32x4 z) {
+  return cat2(pk_fma(lo2(x), lo2(y), lo2(z)), pk_fma(hi2(x), hi2(y), hi2(z)));
+}
+__device__ __forceinline__ f32x4 pk4_fma_s(f32x2 s, f32x4 y, f32x4 z) {  // s (both halves) * y + z
+  return cat2(pk_fma(s, lo2(y), lo2(z)), pk_fma(s, hi2(y), hi2(z)));
+}
+// All MFMAs issued so far have written their accumulators (16-pass MFMA: 18 wait states) - before inline asm reads them.
+__device__ __forceinline__ void mfma_results_guard() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 3");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// x.lo (BCAST_HI = false) or x.hi (true) broadcast to both halves, times y, plus z: a scalar operand that lives in one
+// half of a register pair feeds two channels (the 1 -> 64 first-layer kernels: taps x channel pairs).
+template <bool BCAST_HI>
+__device__ __forceinline__ f32x2 pk_fma_bcast(f32x2 x, f32x2 y, f32x2 z) {
+  f32x2 d;
+  if (BCAST_HI) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+
+}  // namespace sspk
