@@ -86,6 +86,9 @@ def parse_args(argv=None):
                          "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
                          "workgroups per CU, 7 = Winograd with split-bf16 (hi + lo, 16 significant bits) operands: reported "
                          "as dtype bf16x2")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="f32 = --conv-algo 1 (the headline); bf16 = --conv-algo 8, the validated mixed bf16 mode of BASELINE "
+                         "configs[3] (forward convs split-bf16, backward convs bf16, everything else fp32)")
     ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
                     help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
     ap.add_argument("--graph", action="store_true", help="replay the pair step as a hipGraph (ssp_pair_step_graph)")
@@ -95,7 +98,10 @@ def parse_args(argv=None):
                     help="roofline.traffic: live = two rocprofv3 --pmc child runs of this command (FETCH_SIZE, WRITE_SIZE) "
                          "before the timed run; auto = live when N = 1, rocprofv3 is on PATH and the roofline leg is on")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of --traffic live
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.dtype is not None:
+        args.conv_algo = {"f32": 1, "bf16": 8}[args.dtype]
+    return args
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,44 @@
+"""Soak of the mixed bf16 mode (conv algo 8, BASELINE configs[3]) against fp32: two engines, identical initial weights,
+identical batches and sampler seeds, N optimizer steps each; prints both loss curves (mean over 10-step windows) and
+their relative deviation.  usage: soak_bf16.py [ssp|sp] [steps] [batch]"""
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from semantic_superpoint_amd import synth, lib as L
+from semantic_superpoint_amd.lib import Engine, layer_table, SCALAR_NAMES
+arch = "SuperPointNet_gauss2" if (len(sys.argv) > 1 and sys.argv[1] == "sp") else "SuperPointNet_gauss2_ssmall"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+dev = torch.device("cuda:0")
+H, W = 240, 320
+sd = synth.default_init_state_dict(layer_table(arch), seed=0)
+engs = {}
+for name, algo in (("fp32", 1), ("bf16", 8)):
+    L.set_conv_algo(algo)  # copied into the handle at creation
+    engs[name] = Engine(arch, B, H, W, dev)
+    engs[name].load_state_dict(sd)
+L.set_conv_algo(1)
+pool = [synth.make_pair(B, H, W, dev, seed=100 + k, semantic=arch.endswith("ssmall")) for k in range(4)]
+li = SCALAR_NAMES.index("loss")
+hist = {k: [] for k in engs}
+for it in range(steps):
+    for name, eng in engs.items():
+        eng.zero_grad()
+        eng.pair_step(pool[it % len(pool)], indices=None, seed=it + 1, train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True)
+        eng.adam_step(1e-3)
+        hist[name].append(eng.scalars[li].clone())
+torch.cuda.synchronize()
+f = torch.stack(hist["fp32"]).cpu().double(); b = torch.stack(hist["bf16"]).cpu().double()
+assert torch.isfinite(f).all() and torch.isfinite(b).all()
+print("%s B=%d %dx%d, %d steps, 4 synthetic batches cycled, lr 1e-3; window means of the total loss" % (arch, B, H, W, steps))
+print("%8s %12s %12s %10s" % ("steps", "fp32", "mixed bf16", "rel dev"))
+worst = 0.0
+for s0 in range(0, steps, 10):
+    mf, mb = f[s0:s0 + 10].mean().item(), b[s0:s0 + 10].mean().item()
+    dev_ = abs(mb - mf) / abs(mf)
+    worst = max(worst, dev_)
+    if s0 % 50 == 0 or s0 + 10 >= steps:
+        print("%3d-%-4d %12.5f %12.5f %10.2e" % (s0, min(steps, s0 + 10) - 1, mf, mb, dev_))
+print("per-step |bf16 - fp32| / fp32: mean %.2e  max %.2e;   worst 10-step window %.2e" %
+      (((b - f).abs() / f.abs()).mean().item(), ((b - f).abs() / f.abs()).max().item(), worst))
+print("loss fell: fp32 %.4f -> %.4f, mixed bf16 %.4f -> %.4f" % (f[0], f[-10:].mean(), b[0], b[-10:].mean()))
