@@ -14,7 +14,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // this chip, so every VALU instruction saved in a Winograd kernel is matrix-pipe time.
 // HAZARDS: hipcc does not insert wait states for registers read or written by inline asm.  (a) A register written
 // here must not be read by an MFMA within the next 2 instructions (complete all operands, fence, then issue the
-// MFMAs); (b) accumulators of in-flight MFMAs must not be read here (mfma_results_guard() before the first use).
+// MFMAs); (b) accumulators of in-flight MFMAs must not be read here (mfma_results_guard() before the first use);
+// (c) the result of a transcendental instruction (v_exp_f32 ...) must not be read here by the very next instruction
+// (sem_kernels.hip.h: pk_exp2 carries the wait state).
 // `volatile` keeps the program order of these statements among themselves.
 __device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
   f32x2 d;

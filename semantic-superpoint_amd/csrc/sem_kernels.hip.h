@@ -35,30 +35,78 @@ __global__ __launch_bounds__(256) void sem_count_kernel(const int64_t* __restric
 }
 
 // Fused bilinear upsample (align_corners=False) + log-softmax + NLL (+ gradient), one wave per 8x8 pixel tile
-// shifted by (4,4): all 64 pixels of such a tile interpolate between the same 4 source cells.
-//   pass A (lanes = PIXELS): the wave walks the C classes; the 4 corner logits of a class are wave-uniform (scalar
-//     loads), every lane interpolates its own pixel and accumulates sum_c exp(l_c - m) and l_label.  The shift m is
-//     not the exact maximum but the bound sum_k w_k max_c corner_k[c] >= max_c l_c (the weights are >= 0 and sum to
-//     1), which costs 4 wave reductions per TILE instead of 2 per pixel; log-sum-exp is shift invariant.
-//   pass B (lanes = CLASSES, c = lane + 64 j, j < 3; gradient only): the wave walks the counted pixels (weights,
-//     label, m and g / sum broadcast with v_readlane), d(convSout) of the 4 corners accumulates in 12 registers per
-//     lane that are flushed with 12 atomics per lane and tile.  sem_cnt[view] must be final before a BWD launch.
+// shifted by (4,4): all 64 pixels of such a tile interpolate between the same 4 source cells.  The kernel is bound by
+// vector instructions (C = 134 classes x 64 pixels x ~10 operations per tile), so both passes run on the packed fp32
+// instructions, in the base-2 domain (weights and shift pre-multiplied by log2 e: exp(l - m) = exp2(l' - m')):
+//   pass A (lanes = PIXELS): the wave walks the classes TWO at a time; the 4 corner logits of a class pair are
+//     wave-uniform (scalar 8-byte loads), every lane interpolates its own pixel and accumulates sum_c exp(l_c - m); the
+//     label logit is gathered afterwards.  The shift m is not the exact maximum but the bound
+//     sum_k w_k max_c corner_k[c] >= max_c l_c (the weights are >= 0 and sum to 1), which costs 4 wave reductions
+//     per TILE instead of 2 per pixel; log-sum-exp is shift invariant.
+//   pass B (lanes = CLASSES, c = lane + 64 j, j < 3; gradient only): the wave walks the pixels TWO at a time (pixel
+//     pair = the halves of the packed registers; weights, shift and g / sum come back from LDS as broadcast reads);
+//     d(convSout) of the 4 corners accumulates in 2 x 12 registers per lane.  The -g [c == label] term does not go
+//     through the class lanes at all: every pixel adds -g w_k to an LDS histogram over (corner, class), which joins the
+//     accumulators in the flush (12 atomics per lane and tile).  sem_cnt[view] must be final before a BWD launch.
 // MODE bit 0: accumulate the loss sum, bit 1: accumulate d(convSout); the training step does both in ONE pass (3).
 __device__ __forceinline__ float lane_bcast(float v, int src_lane) {  // src_lane wave-uniform
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
+// x.lo / x.hi broadcast * y (both halves) [+ z], y wave-uniform in a scalar register pair
+template <bool BCAST_HI>
+__device__ __forceinline__ f32x2 pk_fma_bcast_sy(f32x2 x, f32x2 y, f32x2 z) {
+  f32x2 d;
+  if (BCAST_HI) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "s"(y), "v"(z));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "s"(y), "v"(z));
+  return d;
+}
+template <bool BCAST_HI>
+__device__ __forceinline__ f32x2 pk_mul_bcast_sy(f32x2 x, f32x2 y) {
+  f32x2 d;
+  if (BCAST_HI) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "s"(y));
+  else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "s"(y));
+  return d;
+}
+template <bool BCAST_HI>
+__device__ __forceinline__ f32x2 pk_mul_bcast(f32x2 x, f32x2 y) {
+  f32x2 d;
+  if (BCAST_HI) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(y));
+  else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+// exp2 of both halves.  gfx950 needs one wait state between a transcendental instruction and a non-transcendental
+// VALU instruction that reads its result; hipcc does not insert it in front of inline asm, so it is part of the value.
+__device__ __forceinline__ f32x2 pk_exp2(f32x2 x) {
+  f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+  asm volatile("s_nop 0" : "+v"(e));
+  return e;
+}
+
+constexpr int SEM_MAX_C = 192;  // 3 class slots per lane
+constexpr int SEM_PAR = 12;     // floats per pixel pair in LDS: w0e p,q | w1e | w2e | w3e | -m e | g / sum
+
 template <int MODE>
 __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ sout, const int64_t* __restrict__ labels,
                                                      float* __restrict__ dsout, StepAccum* __restrict__ acc, int view,
                                                      int B, int Hc, int Wc, int H, int W, int C, int cs) {
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float s_par[4][32 * SEM_PAR];
+  __shared__ __attribute__((aligned(16))) float s_hist[4][4 * SEM_MAX_C];
   const int wave_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* const par = s_par[wave_in_blk];
+  float* const hist = s_hist[wave_in_blk];
   const int TX = Wc + 1, TY = Hc + 1;
   const int ntile = B * TX * TY;
   constexpr bool FWD = (MODE & 1) != 0, BWD = (MODE & 2) != 0;
   float nll_acc = 0.f;  // per lane (= per pixel slot of the tiles this wave visits)
   const float g = BWD ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < 4 * SEM_MAX_C / 256; ++i) *reinterpret_cast<f32x4*>(hist + (i * 64 + lane) * 4) = zero4;
+  }
   for (int tile = blockIdx.x * 4 + wave_in_blk; tile < ntile; tile += gridDim.x * 4) {
     const int tx = tile % TX - 1, ty = (tile / TX) % TY - 1, n = tile / (TX * TY);
     const int cy0 = max(ty, 0), cy1 = min(ty + 1, Hc - 1), cx0 = max(tx, 0), cx1 = min(tx + 1, Wc - 1);
@@ -98,44 +146,109 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
       }
       m_l = fmaf(w4_l[k], wave_max(mx), m_l);
     }
-    // ---- pass A: lanes = pixels ----
-    float se = 0.f, ll = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < C; ++c) {
-      const float l = fmaf(w4_l[0], cp[0][c], fmaf(w4_l[1], cp[1][c], fmaf(w4_l[2], cp[2][c], w4_l[3] * cp[3][c])));
-      se += __expf(l - m_l);
-      ll = c == label_l ? l : ll;
+    // base-2 domain: l' = l log2 e, m' = m log2 e
+    const f32x2 wp01 = {w4_l[0] * LOG2E, w4_l[1] * LOG2E}, wp23 = {w4_l[2] * LOG2E, w4_l[3] * LOG2E};
+    const float nme_l = -m_l * LOG2E;
+    // ---- pass A: lanes = pixels, two classes per instruction ----
+    float se;
+    {
+      const f32x2 nme2 = {nme_l, nme_l};
+      f32x2 se2 = {0.f, 0.f};
+      int c = 0;
+#define SEM_CLASS_PAIR(S0, S1, S2, S3)                                                         \
+      {                                                                                        \
+        f32x2 l2 = pk_mul_bcast_sy<true>(wp23, S3);                                            \
+        l2 = pk_fma_bcast_sy<false>(wp23, S2, l2);                                             \
+        l2 = pk_fma_bcast_sy<true>(wp01, S1, l2);                                              \
+        l2 = pk_fma_bcast_sy<false>(wp01, S0, l2);                                             \
+        se2 = pk_add(se2, pk_exp2(pk_add(l2, nme2)));                                          \
+      }
+      for (; c + 7 < C; c += 8) {  // 16 scalar 8-byte loads in flight, then 4 class pairs
+        f32x2 sv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sv[u][k] = *reinterpret_cast<const f32x2*>(cp[k] + c + 2 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) SEM_CLASS_PAIR(sv[u][0], sv[u][1], sv[u][2], sv[u][3])
+      }
+      for (; c + 1 < C; c += 2) {
+        const f32x2 s0 = *reinterpret_cast<const f32x2*>(cp[0] + c), s1 = *reinterpret_cast<const f32x2*>(cp[1] + c);
+        const f32x2 s2 = *reinterpret_cast<const f32x2*>(cp[2] + c), s3 = *reinterpret_cast<const f32x2*>(cp[3] + c);
+        SEM_CLASS_PAIR(s0, s1, s2, s3)
+      }
+#undef SEM_CLASS_PAIR
+      se = se2[0] + se2[1];
+      if (c < C) {  // odd class count
+        const float l = fmaf(wp01[0], cp[0][c], fmaf(wp01[1], cp[1][c], fmaf(wp23[0], cp[2][c], wp23[1] * cp[3][c])));
+        se += __builtin_amdgcn_exp2f(l + nme_l);
+      }
     }
-    if (FWD && counted) nll_acc += (m_l + logf(se)) - ll;
+    if (FWD && counted) {  // the label logit, gathered: sum_k w_k corner_k[label]
+      const float ll = fmaf(w4_l[0], cp[0][label_l], fmaf(w4_l[1], cp[1][label_l], fmaf(w4_l[2], cp[2][label_l], w4_l[3] * cp[3][label_l])));
+      nll_acc += (m_l + logf(se)) - ll;
+    }
     if (BWD) {
-      // ---- pass B: lanes = classes ----
-      const float gi_l = g / se;
-      float dacc[4][3];
+      // ---- pass B: lanes = classes, two pixels per instruction ----
+      const float gi_l = counted ? g / se : 0.f;  // uncounted pixels: e is finite (<= 1), d = 0
+      {
+        float* pr = par + (lane >> 1) * SEM_PAR + (lane & 1);
+        pr[0] = wp01[0]; pr[2] = wp01[1]; pr[4] = wp23[0]; pr[6] = wp23[1]; pr[8] = nme_l; pr[10] = gi_l;
+        if (counted) {  // -g [c == label] w_k, in the base-2 domain like the accumulators
+          atomicAdd(hist + 0 * SEM_MAX_C + label_l, -g * wp01[0]);
+          atomicAdd(hist + 1 * SEM_MAX_C + label_l, -g * wp01[1]);
+          atomicAdd(hist + 2 * SEM_MAX_C + label_l, -g * wp23[0]);
+          atomicAdd(hist + 3 * SEM_MAX_C + label_l, -g * wp23[1]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // LDS executes one wave's instructions in order; this only pins the compiler
+      f32x2 cva[4], cvb[4];  // classes (lane, lane + 64) and (lane + 128, -) of the four corners
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cva[k] = f32x2{cv[k][0], cv[k][1]};
+        cvb[k] = f32x2{cv[k][2], 0.f};
+      }
+      f32x2 dacc[4][3];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dacc[k][j] = 0.f;
-      for (unsigned long long rest = counted_mask; rest != 0ull; rest &= rest - 1ull) {
-        const int p = __builtin_ctzll(rest);
-        const float w4[4] = {lane_bcast(w4_l[0], p), lane_bcast(w4_l[1], p), lane_bcast(w4_l[2], p), lane_bcast(w4_l[3], p)};
-        const float m = lane_bcast(m_l, p), gi = lane_bcast(gi_l, p);
-        const int label = __builtin_amdgcn_readlane(label_l, p);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float l = fmaf(w4[0], cv[0][j], fmaf(w4[1], cv[1][j], fmaf(w4[2], cv[2][j], w4[3] * cv[3][j])));
-          const float e = cok[j] ? __expf(l - m) : 0.f;
-          const float d = fmaf(e, gi, (lane + 64 * j == label) ? -g : 0.f);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) dacc[k][j] = fmaf(w4[k], d, dacc[k][j]);
+        for (int j = 0; j < 3; ++j) dacc[k][j] = f32x2{0.f, 0.f};
+      for (int i = 0; i < 32; ++i) {
+        if (((counted_mask >> (2 * i)) & 3ull) == 0ull) continue;  // wave-uniform
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(par + i * SEM_PAR);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(par + i * SEM_PAR + 4);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(par + i * SEM_PAR + 8);
+        const f32x2 W0 = lo2(q0), W1 = hi2(q0), W2 = lo2(q1), W3 = hi2(q1), NM = lo2(q2), GI = hi2(q2);
+#define SEM_CLASS_SLOT(J, CV, HI)                                                              \
+        {                                                                                      \
+          f32x2 l2 = pk_mul_bcast<HI>(CV[3], W3);                                              \
+          l2 = pk_fma_bcast<HI>(CV[2], W2, l2);                                                \
+          l2 = pk_fma_bcast<HI>(CV[1], W1, l2);                                                \
+          l2 = pk_fma_bcast<HI>(CV[0], W0, l2);                                                \
+          const f32x2 d2 = pk_mul(pk_exp2(pk_add(l2, NM)), GI);                                \
+          dacc[0][J] = pk_fma(W0, d2, dacc[0][J]);                                             \
+          dacc[1][J] = pk_fma(W1, d2, dacc[1][J]);                                             \
+          dacc[2][J] = pk_fma(W2, d2, dacc[2][J]);                                             \
+          dacc[3][J] = pk_fma(W3, d2, dacc[3][J]);                                             \
         }
+        SEM_CLASS_SLOT(0, cva, false)
+        if (C > 64) SEM_CLASS_SLOT(1, cva, true)
+        if (C > 128) SEM_CLASS_SLOT(2, cvb, false)
+#undef SEM_CLASS_SLOT
       }
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if (cok[j]) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (dacc[k][j] != 0.f) atomicAdd(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + lane + 64 * j, dacc[k][j]);
+          for (int k = 0; k < 4; ++k) {
+            const float v = ((dacc[k][j][0] + dacc[k][j][1]) + hist[k * SEM_MAX_C + lane + 64 * j]) * LN2;
+            if (v != 0.f) atomicAdd(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + lane + 64 * j, v);
+          }
         }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4 * SEM_MAX_C / 256; ++i) *reinterpret_cast<f32x4*>(hist + (i * 64 + lane) * 4) = zero4;
     }
   }
   if (FWD) {
