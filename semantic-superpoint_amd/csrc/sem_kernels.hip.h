@@ -313,7 +313,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m
   const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(r0 + COLSUM_ROWS, rows);
   for (int q = threadIdx.x & 63; q * 4 < cs; q += 64) {  // one pass per 256 columns (one for every shipped model)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = r0 + rl; r < r1; r += 4) {
+    int r = r0 + rl;
+    for (; r + 28 < r1; r += 32) {  // latency-bound: eight row loads in flight per thread
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(m + (size_t)(r + 4 * u) * cs + q * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; r < r1; r += 4) {
       const float4 v = *reinterpret_cast<const float4*>(m + (size_t)r * cs + q * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
