@@ -199,6 +199,21 @@ __device__ __forceinline__ void atomic_add4(float* p, float4 v) {
   atomicAdd(p + 3, v.w);
 }
 
+
+// Work split of the sparse descriptor-loss kernels: one wave per match, 4 per block, and the blocks of ONE image stay on
+// ONE XCD (hardware dispatches block b to XCD b % 8): image = 8 * round + xcd.  The kernels gather 1 KB descriptor rows of
+// the image's 1.2 MB descriptor map; with the images spread over all XCDs every 4 MB L2 saw eight maps at once and the
+// gathers fell through to the Infinity Cache / HBM (1.9 GB fetched per launch for 39 MB of descriptors).
+// grid: desc_grid(B, n_match).  Returns the global match index (image * n_match + k) or -1.
+static inline int desc_grid(int B, int n_match) { return ((B + 7) / 8) * 8 * ((n_match + 3) / 4); }
+__device__ __forceinline__ int desc_wave_of_block(int B, int n_match, int& img) {
+  const int bpi = (n_match + 3) >> 2;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int round = slot / bpi;
+  img = round * 8 + xcd;
+  const int k = (slot - round * bpi) * 4 + (threadIdx.x >> 6);
+  return (img < B && k < n_match) ? img * n_match + k : -1;
+}
 // Channel mapping: lane l holds channels l, l+64, l+128, l+192, so every load AND every atomic instruction of a wave
 // covers 256 contiguous bytes (with 4 consecutive channels per lane the scatter hit each cache line 4 times).
 template <bool BWD>
@@ -207,10 +222,10 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
                                                          const int32_t* __restrict__ match_b, float* __restrict__ dd_a,
                                                          float* __restrict__ dd_b, StepAccum* __restrict__ acc, int B,
                                                          int Hc, int Wc, int n_match) {
-  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int img;
+  const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
-  if (w >= B * n_match) return;
-  const int img = w / n_match;
+  if (w < 0) return;
   const size_t base = (size_t)img * Hc * Wc * 256 + lane;
   const Bilin ba = bilin_setup(match_a[w], Hc, Wc), bb = bilin_setup(match_b[w], Hc, Wc);
   float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -253,10 +268,10 @@ __global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __r
                                                                 const int32_t* __restrict__ nonmatch_b,
                                                                 float* __restrict__ dots, StepAccum* __restrict__ acc,
                                                                 int B, int Hc, int Wc, int n_match, int n_non) {
-  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int img;
+  const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
-  if (w >= B * n_match) return;
-  const int img = w / n_match;
+  if (w < 0) return;
   const int grp = lane >> 4, l16 = lane & 15;
   const size_t ibase = (size_t)img * Hc * Wc * 256;
   const float* ap = desc_a + ibase + (size_t)match_a[w] * 256 + l16 * 4;
@@ -304,10 +319,10 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
                                                                 const float* __restrict__ dots, float* __restrict__ dd_a,
                                                                 float* __restrict__ dd_b, const StepAccum* __restrict__ acc,
                                                                 int B, int Hc, int Wc, int n_match, int n_non) {
-  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int img;
+  const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
-  if (w >= B * n_match) return;
-  const int img = w / n_match;
+  if (w < 0) return;
   const size_t ibase = (size_t)img * Hc * Wc * 256 + lane;
   const float wgt = acc->coef_neg / (((float)acc->nnz_img[img] + 1.f) * (float)B);
   const int32_t* nm = nonmatch_b + (size_t)w * n_non;

@@ -1371,20 +1371,19 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     }
     HIPCHK(hipGetLastError());
   } else if (use_desc) {
-    const int nw = B * h->cfg.n_match;
     Slot &A = h->slot[0], &Bs = h->slot[1];
-    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
                        in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
-    hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+    hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
                        in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match,
                        h->cfg.n_non);
     hipLaunchKernelGGL(desc_counts_kernel, dim3(1), dim3(64), 0, st, h->accum, B);
     if (in->train) {
       CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), st));
       CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), st));
-      hipLaunchKernelGGL((desc_match_kernel<true>), dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+      hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
                          in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
-      hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(cdiv(nw, 4)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
+      hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
                          in->nonmatch_b_dev, h->dots, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
                          h->cfg.n_non);
       for (int v = 0; v < 2; ++v) {
@@ -1954,10 +1953,9 @@ int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_de
   StepAccum* acc = nullptr;
   HIPCHK(hipMallocAsync((void**)&acc, sizeof(StepAccum), st));
   HIPCHK(hipMemsetAsync(acc, 0, sizeof(StepAccum), st));
-  const int nw = b * n_match;
-  hipLaunchKernelGGL((desc_match_kernel<false>), dim3(cdiv(nw, 4)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
+  hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
                      match_a_dev, match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match);
-  hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(cdiv(nw, 4)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
+  hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
                      match_a_dev, nonmatch_b_dev, (float*)nullptr, acc, b, hc, wc, n_match, n_non);
   hipLaunchKernelGGL(sparse_loss_means_kernel, dim3(1), dim3(1), 0, st, acc, out2_dev, b, n_match);
   HIPCHK(hipGetLastError());
