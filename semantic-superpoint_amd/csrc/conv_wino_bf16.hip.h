@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
   for (int k = 0; k < 2; ++k) {
     const int p = (tid + WINO_THREADS * k) >> 1, r = p / HC, c = p - r * HC;
     rrc[k] = r | (c << 8);
-    r_lds[k] = pipe_raw_off(p, q2);
+    r_lds[k] = pipe_raw_off<WIDE>(p, q2);
   }
   const bool r1 = tid + WINO_THREADS < WHALO * 2;  // the second item exists
   // transform: (quad, tile, V row)
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
   int t_u[4], t_w[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    t_u[j] = pipe_raw_off((2 * t_ty + t_ra) * HC + 2 * t_tx + j, q2);
-    t_w[j] = pipe_raw_off((2 * t_ty + t_rb) * HC + 2 * t_tx + j, q2);
+    t_u[j] = pipe_raw_off<WIDE>((2 * t_ty + t_ra) * HC + 2 * t_tx + j, q2);
+    t_w[j] = pipe_raw_off<WIDE>((2 * t_ty + t_rb) * HC + 2 * t_tx + j, q2);
   }
   // four transformed values -> the bf16 image(s) of the buffer: hi part, and the lo part QA_FLOATS further (NT == 2)
 #define PIPE_STORE_V(DST, VAL)                                                                              \
