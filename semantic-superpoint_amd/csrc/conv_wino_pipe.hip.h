@@ -20,8 +20,11 @@
 #include "conv_wino.hip.h"
 
 #ifndef PIPE_ABL
-#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 2 no staging, 4 no barriers, 8 no MFMA, 1024 cycle-stamp trace,
-                    // 16 no global stores, 32 no output transform, 64 no input transform, 128 no weight LDS write, 256 no halo LDS write, 512 no global loads
+#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 4 no end-of-stage barrier, 8 no MFMA,
+                    // 16 no global stores, 512 no halo loads, 1024 cycle-stamp trace, 2048 no weight-fragment loads (B operands
+                    // constant), 4096 no LDS fragment reads (A operands constant), 8192 halo loads confined to 64 KB (cache
+                    // hits).  CAUTION: variants that make operands constant / zero also lower the power draw - the same
+                    // kernel is 2.6 % (sustained) to 13 % (short bursts) faster on zero data (profiles/r02_conv_power_probe.txt)
 #endif
 
 namespace sspk {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   // the bank row (the former (tile >> 2) & 1 swizzle assumed contiguous lane groups and was 2-way conflicted)
   const int t_dst = ((t_row * 4) * WTILES + t_tile) * PK + ((q2 ^ ((t_tile >> 4) & 1)) << 2);
   const int pixb = a.in_cs * 4, rowb = a.W * pixb;
-  f32x4 hreg[2], wreg[4];
+  f32x4 hreg[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, wreg[4];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   constexpr unsigned OOB = 0x80000000u;
   unsigned hoff[2] = {OOB, OOB};
@@ -164,8 +167,10 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
       psc = *reinterpret_cast<const f32x4*>(sS + ld_chunk * PK + q2 * 4);                                   \
       psh = *reinterpret_cast<const f32x4*>(sS + 1024 + ld_chunk * PK + q2 * 4);                            \
     }                                                                                                       \
+    if (!(PIPE_ABL & 512))                                                                                  \
     _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                           \
-      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], ld_chunk * PK * 4, 0)); \
+      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                            \
+          rsrc_in, (PIPE_ABL & 8192) ? (hoff[k] & 0xFFFFu) : hoff[k], ld_chunk * PK * 4, 0));               \
   }
   // weights of the same (tile, chunk); advances the load cursor
 #define PIPE_ISSUE_W()                                                                                      \
@@ -198,8 +203,9 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   // GB: byte offset of this lane's quad inside a component's [h][64][4] weight block, two register sets of B fragments
   const int b_voff = (lh * NB + nt * 32 + li) * 16;
   f32x4 bA0 = {0.f, 0.f, 0.f, 0.f}, bA1 = bA0, bB0 = bA0, bB1 = bA0;
+  const float4 abl_a = make_float4(1.f + tid * 1e-3f, 0.5f, 0.25f, 2.f);  // PIPE_ABL & 4096: constant A fragments
 #define PIPE_BLOAD(S0, S1, C, CHUNK)                                                                        \
-  if (GB) {                                                                                                 \
+  if (GB && !(PIPE_ABL & 2048)) {                                                                                                 \
     const int so_ = ((cob * nst + (CHUNK)) * PB_FLOATS + (chalf * 8 + (C)) * 2 * NB * 4) * 4;               \
     S0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff, so_, 0));          \
     S1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff, so_ + 2 * NB * 16, 0)); \
@@ -281,8 +287,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   // compiler keeps the order): a wave that has just issued an MFMA group owns the issue slots of the ~250 cycles the
   // matrix pipe needs for it and for the group of the other wave of its SIMD.
 #define PIPE_FRAG(C, S0, S1)                                                                                \
-  const float4 a0_##C = *reinterpret_cast<const float4*>(cA + a_off + (C) * WTILES * PK);                   \
-  const float4 a1_##C = *reinterpret_cast<const float4*>(cA + a_off + ((C) + 1) * WTILES * PK);             \
+  const float4 a0_##C = (PIPE_ABL & 4096) ? abl_a : *reinterpret_cast<const float4*>(cA + a_off + (C) * WTILES * PK);       \
+  const float4 a1_##C = (PIPE_ABL & 4096) ? abl_a : *reinterpret_cast<const float4*>(cA + a_off + ((C) + 1) * WTILES * PK); \
   const f32x4 b0_##C = GB ? S0 : *reinterpret_cast<const f32x4*>(cA + b_off + (C) * 2 * NB * 4);            \
   const f32x4 b1_##C = GB ? S1 : *reinterpret_cast<const f32x4*>(cA + b_off + ((C) + 1) * 2 * NB * 4);
 #define PIPE_MFMA_LO(C)                                                                                     \
