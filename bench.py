@@ -323,6 +323,23 @@ def main():
                                    "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                    "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4),
                                    "flops_per_launch_avg": round(pr["flops"] / pr["launches"] / 1e9, 3)}
+            if world == 1 and args.conv_algo in (0, 1, 2, 5, 6):
+                # second family, outside the timed region: the 3x3 weight-gradient launches (3 extra steps)
+                eng.profile_enable("conv3x3_wgrad")
+                run(3, args.warmup + args.steps)
+                torch.cuda.synchronize()
+                pw = eng.profile_read()
+                if pw["launches"] > 0 and pw["ms"] > 0:
+                    achw = pw["flops"] / (pw["ms"] * 1e-3) / 1e12
+                    rw = 1.0 if args.conv_algo == 0 else 16.0 / 36.0
+                    out["roofline_wgrad"] = {"bound": "mfma", "kernel": "wgrad_mfma_kernel" if args.conv_algo == 0 else
+                                             "wgrad_wino_kernel (3x3 weight gradient, Winograd F(3x3,2x2))",
+                                             "achieved": round(achw, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                                             "frac": round(achw / PEAK_FP32_MFMA_TF, 4),
+                                             "executed_tflops": round(achw * rw, 2),
+                                             "executed_frac": round(achw * rw / PEAK_FP32_MFMA_TF, 4),
+                                             "launches": pw["launches"], "avg_launch_ms": round(pw["ms"] / pw["launches"], 4),
+                                             "note": "measured over 3 extra steps after the timed region"}
             eng.profile_enable("none")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch, H, W, batch=B)

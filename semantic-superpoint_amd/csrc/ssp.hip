@@ -725,11 +725,12 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
 // rounds of resident blocks: the partly filled last round cost conv0_direct_kernel a quarter of its time.
 template <typename K>
 static int l0_resident_grid(K kern, const ssp_handle* h, int nviews, long rows) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) {
+  static int per_cu = 0;  // per kernel (template instance): the occupancy query is not free and never changes
+  if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1)) {
     (void)hipGetLastError();
-    return l0_grid(rows);
+    per_cu = -1;
   }
+  if (per_cu < 1) return l0_grid(rows);
   const long g = std::max(1L, (long)per_cu * (h ? h->n_cu : 256) / std::max(1, nviews));
   return (int)std::min(rows, g);
 }
