@@ -59,6 +59,33 @@ __device__ __forceinline__ void l0_taps(const float* __restrict__ xr, int ox, bo
   xv[8] = (down && r) ? t8 : 0.f;
 }
 
+// The same neighbourhood from an LDS image of the three image rows around `row` ([3][W + 2] floats, zero borders and
+// zero rows outside the image): 9 LDS reads at base + constant offsets instead of 9 clamped global loads and 9 selects.
+// l0_stage_rows fills the image of one row (all 256 threads); the caller alternates two images, so ONE barrier per row
+// (after the fill) is enough: a wave that fills image b again has passed the barrier of image b ^ 1, i.e. every wave has
+// finished reading b.
+constexpr int L0_MAX_W = 2046;  // 2 x 3 x (W + 2) floats of dynamic LDS <= 48 KB
+static inline size_t l0_lds_bytes(int W) { return (size_t)2 * 3 * (W + 2) * sizeof(float); }
+__device__ __forceinline__ void l0_stage_rows(float* __restrict__ img, const float* __restrict__ xr, bool up, bool down, int W) {
+  const int Wp = W + 2;
+  for (int c = threadIdx.x; c < Wp; c += 256) {
+    const bool in = c >= 1 && c <= W;
+    const int cc = in ? c - 1 : 0;
+    const float t0 = xr[(up ? -W : 0) + cc], t1 = xr[cc], t2 = xr[(down ? W : 0) + cc];
+    img[c] = (in && up) ? t0 : 0.f;
+    img[Wp + c] = in ? t1 : 0.f;
+    img[2 * Wp + c] = (in && down) ? t2 : 0.f;
+  }
+}
+__device__ __forceinline__ void l0_taps_lds(const float* __restrict__ img, int ox, int W, float (&xv)[9]) {
+  const int Wp = W + 2;
+  const float* p = img + ox;  // column ox - 1 of the image = LDS column ox
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xv[r * 3 + c] = p[r * Wp + c];
+}
+
 // four output channels of the first layer in registers (two channel PAIRS: every fma of the layer is one half of a
 // v_pk_fma_f32, the tap value broadcast to both halves); y4() is THE fma chain of the layer (forward and the
 // recomputation in its BatchNorm backward must agree bit for bit, or the ReLU mask would differ)
@@ -109,14 +136,19 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
   cv.load(w, bias, q * 4);
   f32x2 s01 = {0.f, 0.f}, s23 = s01, q01 = s01, q23 = s01;  // BatchNorm sums / sums of squares of the channel pairs
   const int rows = N * H;
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+  extern __shared__ float l0_rows[];
+  int par = 0;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
     const int oy = row % H;
     const bool up = oy > 0, down = oy < H - 1;
     const float* xr = x + (size_t)row * W;
+    float* const img = l0_rows + par * 3 * (W + 2);
+    l0_stage_rows(img, xr, up, down, W);
+    __syncthreads();
     float* orow = out + (size_t)row * W * 64 + q * 4;
     for (int ox = pl; ox < W; ox += 16) {
       float v[9];
-      l0_taps(xr, ox, up, down, W, v);
+      l0_taps_lds(img, ox, W, v);
       L0Taps xt;
       xt.set(v);
       const f32x2 o01 = cv.y2(0, xt), o23 = cv.y2(1, xt);
@@ -510,10 +542,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
     s1[h] = f32x2{0.f, 0.f}; s2[h] = s1[h];
   }
   const int rows = a.N * a.H, W = a.W;
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+  extern __shared__ float l0_rows[];
+  int par = 0;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
     const int oy = row % a.H;
     const bool up = oy > 0, down = oy < a.H - 1;
     const float* xr = x + (size_t)row * W;
+    float* const img = l0_rows + par * 3 * (W + 2);
+    l0_stage_rows(img, xr, up, down, W);
+    __syncthreads();
     const float* drow = a.dout + (size_t)row * W * 64 + c0;
     for (int ox0 = pl; ox0 < W; ox0 += 16 * L0_UNROLL) {
       float4 d4[L0_UNROLL];
@@ -524,7 +561,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
         const int ox = ok ? ox0 + 16 * j : W - 1;  // clamped: the loads stay branch-free
         const float4 d = *reinterpret_cast<const float4*>(drow + (size_t)ox * 64);
         d4[j] = ok ? d : make_float4(0.f, 0.f, 0.f, 0.f);  // dZ == 0 past the end of the row
-        l0_taps(xr, ox, up, down, W, xv[j]);
+        l0_taps_lds(img, ox, W, xv[j]);
       }
 #pragma unroll
       for (int j = 0; j < L0_UNROLL; ++j) {
@@ -585,10 +622,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
 #pragma unroll
     for (int t = 0; t < 9; ++t) wacc[h][t] = f32x2{0.f, 0.f};
   const int rows = a.N * a.H, W = a.W;
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+  extern __shared__ float l0_rows[];
+  int par = 0;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
     const int oy = row % a.H;
     const bool up = oy > 0, down = oy < a.H - 1;
     const float* xr = x + (size_t)row * W;
+    float* const img = l0_rows + par * 3 * (W + 2);
+    l0_stage_rows(img, xr, up, down, W);
+    __syncthreads();
     const float* drow = a.dout + (size_t)row * W * 64 + c0;
     for (int ox0 = pl; ox0 < W; ox0 += 16 * L0_UNROLL_APPLY) {
       float4 d4[L0_UNROLL_APPLY];
@@ -599,7 +641,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
         ok[j] = ox0 + 16 * j < W;
         const int ox = ok[j] ? ox0 + 16 * j : W - 1;  // clamped: the loads stay branch-free
         d4[j] = *reinterpret_cast<const float4*>(drow + (size_t)ox * 64);
-        l0_taps(xr, ox, up, down, W, xv[j]);
+        l0_taps_lds(img, ox, W, xv[j]);
       }
 #pragma unroll
       for (int j = 0; j < L0_UNROLL_APPLY; ++j) {

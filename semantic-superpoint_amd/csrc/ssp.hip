@@ -724,9 +724,10 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
 // the views riding blockIdx.y), the rows dealt round-robin.  The former fixed ~1000-block grid ran 1.25 / 2.5 / 3.75
 // rounds of resident blocks: the partly filled last round cost conv0_direct_kernel a quarter of its time.
 template <typename K>
-static int l0_resident_grid(K kern, const ssp_handle* h, int nviews, long rows) {
-  static int per_cu = 0;  // per kernel (template instance): the occupancy query is not free and never changes
-  if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1)) {
+static int l0_resident_grid(K kern, const ssp_handle* h, int nviews, long rows, int W) {
+  static int per_cu = 0, per_cu_w = 0;  // per kernel (template instance) and image width: the query is not free
+  if (per_cu_w != W) { per_cu = 0; per_cu_w = W; }
+  if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, l0_lds_bytes(W)) != hipSuccess || per_cu < 1)) {
     (void)hipGetLastError();
     per_cu = -1;
   }
@@ -747,6 +748,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   if (cfg->arch != SSP_ARCH_GAUSS2 && cfg->arch != SSP_ARCH_GAUSS2_SSMALL) return fail(-1, "unknown arch %d", cfg->arch);
   if (cfg->height % 8 || cfg->width % 8 || cfg->height <= 0 || cfg->width <= 0)
     return fail(-1, "height/width must be positive multiples of 8 (got %dx%d)", cfg->height, cfg->width);
+  if (cfg->width > L0_MAX_W) return fail(-1, "width must be <= %d (row images of the first-layer kernels)", L0_MAX_W);
   if (cfg->max_batch < 1 || cfg->max_batch > 1024) return fail(-1, "max_batch must be in 1..1024");
   if (cfg->arch == SSP_ARCH_GAUSS2_SSMALL && cfg->n_classes > 192) return fail(-1, "n_classes must be <= 192");
   ssp_handle* h = new ssp_handle();
@@ -965,7 +967,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   {
     const LayerDesc& d = h->L[0];
     Slot &S0 = *SS.s[0], &S1 = *SS.s[SS.n - 1];
-    hipLaunchKernelGGL(conv0_direct_kernel, dim3(l0_resident_grid(conv0_direct_kernel, h, SS.n, (long)N * H), SS.n), dim3(256), 0, st, S0.x, S1.x, P(h, d.w_off),
+    hipLaunchKernelGGL(conv0_direct_kernel, dim3(l0_resident_grid(conv0_direct_kernel, h, SS.n, (long)N * H, W), SS.n), dim3(256), l0_lds_bytes(W), st, S0.x, S1.x, P(h, d.w_off),
                        P(h, d.b_off), S0.Y[0], S1.Y[0], train ? S0.bn[0].stats : nullptr, train ? S1.bn[0].stats : nullptr,
                        N, H, W);
     HIPCHK(hipGetLastError());
@@ -1022,11 +1024,11 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
   if (l == 0) {
     // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised);
     // both passes recompute Y0 from the image instead of reading S.Y[0]
-    const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel, h, SS.n, (long)N * H);
-    const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel, h, SS.n, (long)N * H);
-    hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb1, SS.n), dim3(256), 0, st, a0, a1, P(h, d.w_off), P(h, d.b_off));
+    const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel, h, SS.n, (long)N * H, W);
+    const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel, h, SS.n, (long)N * H, W);
+    hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
-    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb2, SS.n), dim3(256), 0, st, a0, a1, P(h, d.w_off), P(h, d.b_off),
+    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                        Gd(h, d.w_off));
   } else if (relu && pool_after && have_pool && d.cout % 4 == 0 && d_cs == d.cout && d_co == 0) {
     // pass 1 from the pooled activation (1/4 of Y's bytes), pass 2 over Y
