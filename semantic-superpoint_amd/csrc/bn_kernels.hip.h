@@ -32,7 +32,7 @@ __device__ __forceinline__ void reduce_by_column(float (&v)[NV], float* smem, in
 // Row-based work split (a block owns image rows, its 16 pixel lanes walk along x): no per-pixel integer division,
 // the row tests are wave-uniform.  grid: l0_grid(N * H), block 256.
 constexpr int L0_UNROLL = 4;        // pixels in flight per thread, pass 1
-constexpr int L0_UNROLL_APPLY = 4;  // pass 2 (2 was slower: 281 vs 236 us per view)
+constexpr int L0_UNROLL_APPLY = 2;  // pass 2
 static inline int l0_grid(long rows) {
   const long per = (rows + 1023) / 1024;
   return (int)((rows + per - 1) / per);
