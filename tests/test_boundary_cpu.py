@@ -144,6 +144,17 @@ def test_bench_gpus_flag_is_checked_and_spawns_ranks():
         assert "ranks failed" in r.stderr and "needs an MI355X" in r.stderr
 
 
+def test_bench_dtype_flag_selects_the_conv_algorithm():
+    """bench.py --dtype: f32 = the headline Winograd fp32 path, bf16 = the validated mixed mode (BASELINE configs[3])."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.parse_args([]).conv_algo == 1 and b.parse_args(["--dtype", "f32", "--conv-algo", "0"]).conv_algo == 1
+    assert b.parse_args(["--dtype", "bf16"]).conv_algo == 8
+    assert b.parse_args([]).arch == "ssp" and b.parse_args([]).batch == 32  # the north-star workload is the default
+
+
 def test_optimizer_state_dict_has_torch_adam_layout():
     """saveModel's optimizer_state_dict loads into the reference's optimizer: torch.optim.Adam(net.parameters() + [eta])."""
     from semantic_superpoint_amd import lib as L

@@ -63,11 +63,14 @@ else:
     b = torch.zeros(C, device=dev); sc = torch.ones(C, device=dev); sh = torch.zeros(C, device=dev)
     st = torch.zeros(L.NREP, 2 * C, dtype=torch.float64, device=dev)
     res = []
+    # sustained regime: 150 back-to-back launches per figure after 50 warm-up launches (short bursts after an idle period run
+    # up to 13 % faster or slower depending on the operand data: profiles/r02_conv_data_probe.txt)
     for mode in (0, 1):
-        for _ in range(4): L.op_conv(x, w, b, 3, mode, sc, sh, st)
+        for _ in range(50): L.op_conv(x, w, b, 3, mode, sc, sh, st)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); t = []
-        for _ in range(9):
-            e0.record(); L.op_conv(x, w, b, 3, mode, sc, sh, st); e1.record(); torch.cuda.synchronize(); t.append(e0.elapsed_time(e1))
-        res.append(sorted(t)[4])
-    print("PIPE_ABL=%2d  mode0 %.3f ms  mode1 %.3f ms" % (v, res[0], res[1]), flush=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(150): L.op_conv(x, w, b, 3, mode, sc, sh, st)
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 150)
+    print("PIPE_ABL=%4d  mode0 %.3f ms  mode1 %.3f ms  (sustained)" % (v, res[0], res[1]), flush=True)
