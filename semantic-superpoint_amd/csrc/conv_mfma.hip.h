@@ -60,6 +60,13 @@ struct ConvArgs {
   const float* bnr_p1[2] = {nullptr, nullptr};
   const float* bnr_p2[2] = {nullptr, nullptr};
   const float* bnr_p3[2] = {nullptr, nullptr};
+  // Forward launches of conv_wino_pipe_kernel whose output feeds BatchNorm + ReLU + MaxPool2d(2): the epilogue also
+  // writes pool_out[k] = [N, H/2, W/2, Cout] = the per-channel max (gamma >= 0) or min (gamma < 0) of every 2x2 window
+  // of the RAW conv output.  maxpool(relu(scale y + shift)) = relu(scale pool(y) + shift) with that choice (scale =
+  // gamma * invstd, invstd > 0; fma and relu are monotonic, so the values are bit-identical): the consumers apply
+  // BatchNorm + ReLU on load to a quarter-size tensor and the separate pooled-activation pass disappears.
+  float* pool_out[2] = {nullptr, nullptr};
+  const float* pool_gamma = nullptr;
 };
 
 // lane/row index m (0..31) of an MFMA M-tile -> pixel (r,c) inside the SH x SW sub-rectangle.

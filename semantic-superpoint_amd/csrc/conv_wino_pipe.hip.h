@@ -34,7 +34,8 @@ constexpr int PA_FLOATS = WC * WTILES * PK;        // 8192 floats = 32 KB
 constexpr int PB_FLOATS = WC * PK * NB;            // 8192 floats = 32 KB
 constexpr int PR_FLOATS = (WHALO + 7) / 8 * 8 * PK;  // 2752 floats: whole 8-pixel rotation groups
 constexpr int PS_FLOATS = 2 * 1024;                // BatchNorm scale | shift of up to 1024 input channels
-constexpr int PIPE_LDS_BYTES = (2 * (PA_FLOATS + PB_FLOATS) + PR_FLOATS + PS_FLOATS) * 4;
+constexpr int PG_FLOATS = NB;                       // +-1 per output channel of the block: sign of gamma (pooled output)
+constexpr int PIPE_LDS_BYTES = (2 * (PA_FLOATS + PB_FLOATS) + PR_FLOATS + PS_FLOATS + PG_FLOATS) * 4;
 
 // raw halo pixel p (raster index), quad q (0/1) -> float offset in sR.  ds_read_b128 is serviced in four groups of 16
 // NON-contiguous lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) on 64 banks (256 B): the stride-2 pixel reads
@@ -264,6 +265,17 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
     __syncthreads();
   }
   const float* const p_bnr = prob ? a.bnr_t2 : a.bnr_t;
+  // (only instantiated for IN_MODE 1: the producers of pooled layers read a BatchNorm + ReLU input themselves, and the
+  // data-gradient variants, already at the register limit, stay free of the code)
+  float* const p_pool = IN_MODE == 0 ? nullptr : (prob ? a.pool_out[1] : a.pool_out[0]);
+  float* const sG = sS + PS_FLOATS;
+  if (IN_MODE != 0 && p_pool != nullptr) {
+    if (tid < NB) {
+      const int co_ = cob * NB + tid;
+      sG[tid] = (co_ < a.Cout && a.pool_gamma[co_] < 0.f) ? -1.f : 1.f;
+    }
+    __syncthreads();
+  }
   // ---- prologue: stage 0 into buffer 0, loads of stage 1 in flight ----
   PIPE_ISSUE_LOADS()
   PIPE_WRITE_STAGE(0)
@@ -483,6 +495,32 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
               if (nvalid > 1) p[1] = v[1];
               if (nvalid > 2) p[2] = v[2];
             }
+          }
+        }
+        if (IN_MODE != 0 && p_pool != nullptr) {
+          // pooled raw output (ConvArgs::pool_out): a Winograd tile IS a pooling window; thread = (window of this round,
+          // channel quad) reads the four summed pixels back from the staging tile
+          const int w_ = tid >> 4, wr = w_ / TTX, wc = w_ - wr * TTX;
+          const int sl = (w_ & 15) | (rd << 4) | ((w_ >> 4) << 5);
+          const int py = (ty0 >> 1) + sl / TTX, px = (tx0 >> 1) + sl % TTX;
+          if (nvalid > 0 && 2 * py < a.H && 2 * px < a.W) {
+            const f32x4 sg = *reinterpret_cast<const f32x4*>(sG + q16 * 4);
+            f32x4 m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int lp = (2 * wr + (i >> 1)) * TW + 2 * wc + (i & 1);
+              const f32x4 v = pk4_add(*reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4),
+                                      *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4)) * sg;
+              if (i == 0) m = v;
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+              }
+            }
+            m *= sg;
+            float* pp = p_pool + ((size_t)(n * (a.H >> 1) + py) * (a.W >> 1) + px) * a.Cout + co4;
+            if (nvalid == 4) *reinterpret_cast<f32x4*>(pp) = m;
+            else { pp[0] = m[0]; if (nvalid > 1) pp[1] = m[1]; if (nvalid > 2) pp[2] = m[2]; }
           }
         }
         PIPE_ETS(rd * 4 + 3)

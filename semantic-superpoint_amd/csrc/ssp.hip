@@ -130,6 +130,7 @@ struct ssp_handle {
   size_t partial_floats;
   size_t partial_used = 0;  // ... and the slices are reduced into the gradients by ONE launch (flush_wgrad_reduce)
   WredJobs rjobs{};
+  bool pool_raw[8] = {};      // Apool[l] holds the RAW pooled conv output written by layer l's conv (else the activated one)
   bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
   StepAccum* accum;
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
@@ -391,6 +392,10 @@ struct ConvCall {
   const float* bnr_t[2] = {nullptr, nullptr};
   int bnr_cs = 0, bnr_co = 0;
   const float* bnr_p[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  // forward launches: raw 2x2-pooled copy of the output for a BatchNorm + ReLU + MaxPool consumer (ConvArgs::pool_out);
+  // honoured by the pipelined Winograd kernel only - conv_writes_pool() tells the caller
+  float* pool_out[2] = {nullptr, nullptr};
+  const float* pool_gamma = nullptr;
 };
 static bool can_fuse_bnr(const ConvCall& c) {
   return c.wino && (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
@@ -446,6 +451,23 @@ static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
+// default algorithm (1): maps with few first-generation work items per CU (the 30x40 layers: 640 items on 256 CUs =
+// 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
+// large maps: tools/conv_probe.py)
+static bool conv_uses_p2(const ssp_handle* h, const ConvCall& c) {
+  if (!c.wino) return false;
+  if (g_conv_algo == 6) return true;
+  if (g_conv_algo != 1) return false;
+  const bool w1 = (c.W % 32) == 0;
+  const long items = (long)c.nprob * c.N * cdiv(c.H, w1 ? 8 : 32) * cdiv(c.W, w1 ? 32 : 8) * c.ncob;
+  return items < 4L * (h ? h->n_cu : 256);
+}
+// will this forward launch write ConvCall::pool_out (first-generation pipelined Winograd kernel, contiguous output)?
+static bool conv_writes_pool(const ssp_handle* h, const ConvCall& c) {
+  return c.wino && c.in_mode == 1 && (g_conv_algo == 1 || g_conv_algo == 5) && !bf16_algo() && !conv_uses_p2(h, c) && c.H % 2 == 0 && c.W % 2 == 0 &&
+         c.cout % 4 == 0 && c.out_co == 0 && c.out_cs == c.cout;
+}
+
 static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int prof_family = 0) {
   ConvArgs a;
   a.in = c.in; a.wpk = c.wpk; a.bias = c.bias; a.out = c.out; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
@@ -479,11 +501,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   // default algorithm (1): maps with few first-generation work items per CU (the 30x40 layers: 640 items on 256 CUs =
   // 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
   // large maps: tools/conv_probe.py)
-  bool p2 = c.wino && g_conv_algo == 6;
-  if (c.wino && g_conv_algo == 1) {
-    const bool w1 = (c.W % 32) == 0;
-    const long items = (long)c.nprob * c.N * cdiv(c.H, w1 ? 8 : 32) * cdiv(c.W, w1 ? 32 : 8) * c.ncob;
-    p2 = items < 4L * (h ? h->n_cu : 256);
+  const bool p2 = conv_uses_p2(h, c);
+  if (c.pool_out[0] != nullptr) {
+    if (!conv_writes_pool(h, c)) return fail(-3, "pooled raw output needs the first-generation pipelined Winograd kernel");
+    a.pool_out[0] = c.pool_out[0]; a.pool_out[1] = c.pool_out[1]; a.pool_gamma = c.pool_gamma;
   }
   const bool wide = p2 ? (c.W % 16) == 0 : (c.W % 32) == 0;
   const int TH = p2 ? (wide ? 8 : 16) : (wide ? 8 : 32), TW = p2 ? (wide ? 16 : 8) : (wide ? 32 : 8);
@@ -924,8 +945,11 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
                           hipStream_t st) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
-  const bool pooled = in_mode == 2;  // input = materialised maxpool(relu(bn(Y_src))): raw (mode 0) for the kernel
-  if (pooled) {
+  const bool pooled = in_mode == 2;  // input = pooled output of layer src: raw pooled y (BatchNorm + ReLU on load, mode 1)
+                                     // when its conv wrote it (pool_raw), else materialised maxpool(relu(bn(Y_src))) (mode 0)
+  if (pooled && h->pool_raw[src]) {
+    in_mode = 1;
+  } else if (pooled) {
     {
       Slot &S0 = *SS.s[0], &S1 = *SS.s[SS.n - 1];
       const long total = (long)N * H * W * (d.cin / 4);
@@ -948,6 +972,14 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
     c.nprob = 2; c.in2 = pooled ? B.Apool[src] : B.Y[src]; c.out2 = B.Y[l]; c.in_scale2 = B.bn[src].scale;
     c.in_shift2 = B.bn[src].shift;
     c.stats2 = (d.bn && train) ? B.bn[l].stats : nullptr;
+  }
+  // layers followed by BatchNorm + ReLU + MaxPool (1, 3, 5): the conv itself writes the raw pooled copy its consumers read
+  if (l < 8) {
+    h->pool_raw[l] = false;
+    if (A.Apool[l] != nullptr && d.bn && conv_writes_pool(h, c)) {
+      c.pool_out[0] = A.Apool[l]; c.pool_out[1] = SS.n == 2 ? SS.s[1]->Apool[l] : nullptr; c.pool_gamma = P(h, d.g_off);
+      h->pool_raw[l] = true;
+    }
   }
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
   if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));  // view 0 then 1 inside the kernel
@@ -1035,7 +1067,8 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const long npix = (long)N * (H / 2) * (W / 2);
     const int rows = 256 / (d.cout / 4);
     const int nb = std::max(1, std::min(cdiv(npix, rows), 1024));
-    if (!fused) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
+    if (!fused && !h->pool_raw[l]) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
+    else if (!fused) hipLaunchKernelGGL((bn_bwd_kernel<true, true, false>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);  // scan over Y
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
   } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st, fused)));
@@ -1052,7 +1085,14 @@ static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, Co
   const LayerDesc& ds = h->L[src];
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
-    if (pooled) {
+    if (pooled && h->pool_raw[src]) {
+      // raw pooled y: the window's arg-max of z IS this element (max for gamma >= 0, min for gamma < 0), so the ReLU-layer
+      // formulas apply to the quarter-size tensor (gamma == 0 channels: pool_fix in bn_layer_backward, as before)
+      if (S.Apool[src] == nullptr) return;
+      c.bnr_t[k] = S.Apool[src];
+      c.bnr_p[0][k] = S.bn[src].scale; c.bnr_p[1][k] = S.bn[src].shift; c.bnr_p[2][k] = S.bn[src].mean;
+      c.bnr_p[3][k] = S.bn[src].invstd;
+    } else if (pooled) {
       if (S.Apool[src] == nullptr) return;
       c.bnr_t[k] = S.Apool[src];
       c.bnr_p[0][k] = P(h, ds.be_off); c.bnr_p[1][k] = P(h, ds.g_off);
@@ -1062,7 +1102,7 @@ static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, Co
       c.bnr_p[3][k] = S.bn[src].invstd;
     }
   }
-  c.bnr_mode = pooled ? 2 : 1;
+  c.bnr_mode = (pooled && !h->pool_raw[src]) ? 2 : 1;
   c.bnr_cs = pooled ? ds.cout : SS.s[0]->y_cs[src];
   c.bnr_co = pooled ? 0 : SS.s[0]->y_co[src];
   if (c.bnr_cs % 4 != 0 || c.bnr_co % 4 != 0) { c.bnr_mode = 0; return; }
@@ -1078,8 +1118,9 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
                                hipStream_t st) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
-  const bool pooled = in_mode == 2;  // the forward materialised maxpool(relu(bn(Y_src))) in Apool[src]
-  if (pooled) in_mode = 0;
+  const bool pooled = in_mode == 2;  // Apool[src] holds the pooled input: raw pooled y (pool_raw: BatchNorm + ReLU on load)
+                                     // or the materialised maxpool(relu(bn(Y_src)))
+  if (pooled) in_mode = h->pool_raw[src] ? 1 : 0;
   WgradCall w;
   w.in = pooled ? A.Apool[src] : A.Y[src]; w.in_cs = A.y_cs[src]; w.in_co = A.y_co[src]; w.cin = d.cin;
   w.dout = dy[0]; w.dout_cs = dy_cs; w.dout_co = dy_co; w.cout = d.cout;
