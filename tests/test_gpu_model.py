@@ -128,6 +128,37 @@ def test_backward_with_zero_gamma_in_pooled_layers(algo):
         L.set_conv_algo(1)
 
 
+def test_negative_gamma_in_pooled_layers():
+    """Pooled layers: the producing conv writes the per-channel MAX of every 2x2 window of its raw output for gamma >= 0
+    and the MIN for gamma < 0 (maxpool(relu(bn(y))) = relu(bn(pool(y))) with that choice); consumers apply BatchNorm + ReLU
+    on load.  Half of the pooled layers' gammas negative: forward outputs and every gradient against the oracle."""
+    arch, B, H, W = ARCHS[0], 2, 32, 64
+    sd = C.init_state_dict(arch, seed=11)
+    rs = np.random.RandomState(6)
+    for k in ("inc.conv.conv.4", "down1.mpconv.1.conv.4", "down2.mpconv.1.conv.4"):
+        g = np.array(sd[k + ".weight"], dtype=np.float32, copy=True)
+        g[::2] *= -1.0
+        sd[k + ".weight"] = g
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32))
+    tsd = C.to_torch(sd, requires_grad=True)
+    ref = C.forward(tsd, x, arch)
+    gs = {k: torch.from_numpy(rs.randn(*ref[k].shape).astype(np.float32)) for k in ref}
+    sum((ref[k] * gs[k]).sum() for k in ref).backward()
+    e = _engine(arch, B, H, W, sd)
+    dev = _dev()
+    out = e.forward(x.to(dev), slot=0, train=True, want=("semi", "desc"))
+    for k in ("semi", "desc"):
+        assert (out[k].cpu() - ref[k].detach()).abs().max() < 1e-3, k
+    e.zero_grad()
+    e.backward(0, gs["semi"].to(dev), gs["desc"].to(dev), None)
+    torch.cuda.synchronize()
+    gd = e.grad_dict()
+    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}  # exact gradient 0 (bias before BN)
+    for k in C.param_keys(arch):
+        if k not in noisy:
+            _grad_close(gd[k].cpu(), tsd[k].grad, k, l2=5e-2, mx=0.1)
+
+
 def _zero_gamma_case():
     arch, B, H, W = ARCHS[0], 2, 32, 48
     sd = C.init_state_dict(arch, seed=9)
