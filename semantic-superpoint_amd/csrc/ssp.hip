@@ -107,7 +107,9 @@ struct Slot {
   float* ddesc;     // [B*cells*256]
   float* dsout;     // [B*cells*SOUT_CS] gradient wrt convSout output (ssmall)
   float *gP, *gQ;   // backward ping-pong buffers of this slot (dOut / dY)
-  float* Apool[8];  // maxpool(relu(bn(Y_l))) for l = 1, 3, 5 (inputs of layers 2, 4, 6), else nullptr
+  float* Apool[8];  // pooled output of layers l = 1, 3, 5 (inputs of layers 2, 4, 6), else nullptr: the RAW pooled conv output
+                    // written by layer l's conv (pool_raw[l], BatchNorm + ReLU applied on load) or maxpool(relu(bn(Y_l)))
+  bool pool_raw[8] = {false, false, false, false, false, false, false, false};  // set by this slot's last forward
   const float* x;   // input image of the last forward (caller-owned)
   void* stats_region;
   size_t stats_bytes;
@@ -130,7 +132,6 @@ struct ssp_handle {
   size_t partial_floats;
   size_t partial_used = 0;  // ... and the slices are reduced into the gradients by ONE launch (flush_wgrad_reduce)
   WredJobs rjobs{};
-  bool pool_raw[8] = {};      // Apool[l] holds the RAW pooled conv output written by layer l's conv (else the activated one)
   bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
   StepAccum* accum;
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
@@ -947,7 +948,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
   Slot& A = *SS.s[0];
   const bool pooled = in_mode == 2;  // input = pooled output of layer src: raw pooled y (BatchNorm + ReLU on load, mode 1)
                                      // when its conv wrote it (pool_raw), else materialised maxpool(relu(bn(Y_src))) (mode 0)
-  if (pooled && h->pool_raw[src]) {
+  if (pooled && A.pool_raw[src]) {
     in_mode = 1;
   } else if (pooled) {
     {
@@ -975,11 +976,11 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
   }
   // layers followed by BatchNorm + ReLU + MaxPool (1, 3, 5): the conv itself writes the raw pooled copy its consumers read
   if (l < 8) {
-    h->pool_raw[l] = false;
-    if (A.Apool[l] != nullptr && d.bn && conv_writes_pool(h, c)) {
+    const bool raw = A.Apool[l] != nullptr && d.bn && conv_writes_pool(h, c);
+    if (raw) {
       c.pool_out[0] = A.Apool[l]; c.pool_out[1] = SS.n == 2 ? SS.s[1]->Apool[l] : nullptr; c.pool_gamma = P(h, d.g_off);
-      h->pool_raw[l] = true;
     }
+    for (int k = 0; k < SS.n; ++k) SS.s[k]->pool_raw[l] = raw;
   }
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
   if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));  // view 0 then 1 inside the kernel
@@ -1067,7 +1068,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const long npix = (long)N * (H / 2) * (W / 2);
     const int rows = 256 / (d.cout / 4);
     const int nb = std::max(1, std::min(cdiv(npix, rows), 1024));
-    if (!fused && !h->pool_raw[l]) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
+    if (!fused && !SS.s[0]->pool_raw[l]) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
     else if (!fused) hipLaunchKernelGGL((bn_bwd_kernel<true, true, false>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);  // scan over Y
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
@@ -1085,7 +1086,7 @@ static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, Co
   const LayerDesc& ds = h->L[src];
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
-    if (pooled && h->pool_raw[src]) {
+    if (pooled && S.pool_raw[src]) {
       // raw pooled y: the window's arg-max of z IS this element (max for gamma >= 0, min for gamma < 0), so the ReLU-layer
       // formulas apply to the quarter-size tensor (gamma == 0 channels: pool_fix in bn_layer_backward, as before)
       if (S.Apool[src] == nullptr) return;
@@ -1102,7 +1103,7 @@ static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, Co
       c.bnr_p[3][k] = S.bn[src].invstd;
     }
   }
-  c.bnr_mode = (pooled && !h->pool_raw[src]) ? 2 : 1;
+  c.bnr_mode = (pooled && !SS.s[0]->pool_raw[src]) ? 2 : 1;
   c.bnr_cs = pooled ? ds.cout : SS.s[0]->y_cs[src];
   c.bnr_co = pooled ? 0 : SS.s[0]->y_co[src];
   if (c.bnr_cs % 4 != 0 || c.bnr_co % 4 != 0) { c.bnr_mode = 0; return; }
@@ -1120,7 +1121,7 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
   Slot& A = *SS.s[0];
   const bool pooled = in_mode == 2;  // Apool[src] holds the pooled input: raw pooled y (pool_raw: BatchNorm + ReLU on load)
                                      // or the materialised maxpool(relu(bn(Y_src)))
-  if (pooled) in_mode = h->pool_raw[src] ? 1 : 0;
+  if (pooled) in_mode = A.pool_raw[src] ? 1 : 0;
   WgradCall w;
   w.in = pooled ? A.Apool[src] : A.Y[src]; w.in_cs = A.y_cs[src]; w.in_co = A.y_co[src]; w.cin = d.cin;
   w.dout = dy[0]; w.dout_cs = dy_cs; w.dout_co = dy_co; w.cout = d.cout;
