@@ -454,6 +454,52 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
         __syncthreads();
         PIPE_ETS(rd * 4 + 2)
         const float* const s0p = smem + buf * (PA_FLOATS + PB_FLOATS);
+        if (full && (cob + 1) * NB <= a.Cout) {
+          // whole tile inside the image, whole channel block inside the tensor (block-uniform: the common case): straight-
+          // line code - all eight LDS reads of the round first, then sums / statistics / four 16-byte stores.  The general
+          // loop below compiles to four branchy blocks that each wait for their own LDS round trip (2700 of the ~9500
+          // cycles of a tile epilogue were spent there: profiles/r02_conv_cycle_trace.txt).
+          f32x4 va[NSTORE], vb[NSTORE];
+#pragma unroll
+          for (int k = 0; k < NSTORE; ++k) {
+            const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
+            va[k] = *reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4);
+            vb[k] = *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < NSTORE; ++k) {
+            const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
+            const int crow = lp / TW, ccol = lp - crow * TW;
+            const int csl = (crow >> 1) * TTX + (ccol >> 1);
+            const int sl = (csl & 15) | (rd << 4) | ((csl >> 4) << 5);
+            const int oy = ty0 + 2 * (sl / TTX) + (crow & 1), ox = tx0 + ccol;
+            const f32x4 v = pk4_add(va[k], vb[k]);
+            if (IN_MODE == 0 && a.bnr_mode != 0) {
+              const f32x4 t = tpre[k];
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(sS + q16 * 4), q1 = *reinterpret_cast<const f32x4*>(sS + NB + q16 * 4);
+              f32x4 dz, xh;
+              if (a.bnr_mode == 1) {
+                const f32x4 q2 = *reinterpret_cast<const f32x4*>(sS + 2 * NB + q16 * 4), q3 = *reinterpret_cast<const f32x4*>(sS + 3 * NB + q16 * 4);
+                const f32x4 z = pk4_fma(t, q0, q1);
+                xh = pk4_fma(t, q2, q3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? v[e] : 0.f;
+              } else {
+                xh = (t - q0) * q1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = t[e] > 0.f ? v[e] : 0.f;
+              }
+              ssum = pk4_add(ssum, dz);
+              ssq = pk4_fma(dz, xh, ssq);
+            } else {
+              ssum = pk4_add(ssum, v);
+              ssq = pk4_fma(v, v, ssq);
+            }
+            if (!(PIPE_ABL & 16))
+              *reinterpret_cast<f32x4*>(p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4) = v;
+          }
+        } else
 #pragma unroll
         for (int k = 0; k < (TH * TW * 8) / WINO_THREADS; ++k) {
           const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;  // compact pixel of the half tile
