@@ -66,8 +66,12 @@ __device__ __forceinline__ void pipe_out_rows(const f32x16 (&acc)[8], int rd, in
       if (CHALF == 0) { top[j] = pk_add(a, b); bot[j] = b; }
       else { top[j] = a; bot[j] = pk_nadd(a, b); }
     }
-    const f32x2 y00 = pk_add(pk_add(top[0], top[1]), top[2]), y01 = pk_sub(pk_sub(top[1], top[2]), top[3]);
-    const f32x2 y10 = pk_add(pk_add(bot[0], bot[1]), bot[2]), y11 = pk_sub(pk_sub(bot[1], bot[2]), bot[3]);
+    // three groups of four independent packed instructions (the asm statements keep their program order: a nested
+    // pk_add(pk_add(..)) would issue every dependent pair back to back and stall on the result)
+    const f32x2 s00 = pk_add(top[0], top[1]), s01 = pk_sub(top[1], top[2]);
+    const f32x2 s10 = pk_add(bot[0], bot[1]), s11 = pk_sub(bot[1], bot[2]);
+    const f32x2 y00 = pk_add(s00, top[2]), y01 = pk_sub(s01, top[3]);
+    const f32x2 y10 = pk_add(s10, bot[2]), y11 = pk_sub(s11, bot[3]);
     const int csl = ((r8 & 3) + 8 * (r8 >> 2) + 4 * lh) | (mt << 4);  // even r8: tiles csl, csl + 1 are x neighbours
     const int cty = csl / TTX, ctx = csl % TTX;
     float* p = o + ((2 * cty) * TW + 2 * ctx) * NB;
