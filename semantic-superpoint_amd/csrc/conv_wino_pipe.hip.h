@@ -458,11 +458,12 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
         __syncthreads();
         PIPE_ETS(rd * 4 + 2)
         const float* const s0p = smem + buf * (PA_FLOATS + PB_FLOATS);
-        if (full && (cob + 1) * NB <= a.Cout) {
-          // whole tile inside the image, whole channel block inside the tensor (block-uniform: the common case): straight-
-          // line code - all eight LDS reads of the round first, then sums / statistics / four 16-byte stores.  The general
-          // loop below compiles to four branchy blocks that each wait for their own LDS round trip (2700 of the ~9500
-          // cycles of a tile epilogue were spent there: profiles/r02_conv_cycle_trace.txt).
+        if ((WIDE ? full : true) && (cob + 1) * NB <= a.Cout) {
+          // whole channel block inside the tensor (block-uniform: every shipped layer; 8x32 tiles: full tiles only, their
+          // partial tiles are rare and the predication costs the full ones 1 %): all eight LDS reads of the round
+          // first, then sums / statistics / four (predicated) 16-byte stores.  The general loop below compiles to four
+          // branchy blocks that each wait for their own LDS round trip (2700 of the ~9500 cycles of a tile epilogue were
+          // spent there, ~850 now: profiles/r02_conv_cycle_trace.txt).
           f32x4 va[NSTORE], vb[NSTORE];
 #pragma unroll
           for (int k = 0; k < NSTORE; ++k) {
@@ -478,7 +479,13 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
             const int csl = (crow >> 1) * TTX + (ccol >> 1);
             const int sl = (csl & 15) | (rd << 4) | ((csl >> 4) << 5);
             const int oy = ty0 + 2 * (sl / TTX) + (crow & 1), ox = tx0 + ccol;
-            const f32x4 v = pk4_add(va[k], vb[k]);
+            const bool fullk = WIDE ? true : full;
+            const bool ok = fullk || (oy < a.H && ox < a.W);
+            f32x4 v = pk4_add(va[k], vb[k]);
+            if (!fullk) {  // block-uniform; pixels of a partial tile beyond the image: no statistics, no store
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            }
             if (IN_MODE == 0 && a.bnr_mode != 0) {
               const f32x4 t = tpre[k];
               const f32x4 q0 = *reinterpret_cast<const f32x4*>(sS + q16 * 4), q1 = *reinterpret_cast<const f32x4*>(sS + NB + q16 * 4);
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
               ssum = pk4_add(ssum, v);
               ssq = pk4_fma(v, v, ssq);
             }
-            if (!(PIPE_ABL & 16))
+            if (!(PIPE_ABL & 16) && ok)
               *reinterpret_cast<f32x4*>(p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4) = v;
           }
         } else
