@@ -70,8 +70,8 @@ def cpu_baseline(arch, H, W, batch=32, steps=3):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--arch", default="ssp", choices=["sp", "ssp"],
                     help="ssp = SuperPointNet_gauss2_ssmall (north star, configs[2]); sp = SuperPointNet_gauss2 (configs[1])")
     ap.add_argument("--batch", type=int, default=32)
