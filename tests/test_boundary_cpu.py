@@ -155,6 +155,25 @@ def test_bench_dtype_flag_selects_the_conv_algorithm():
     assert b.parse_args([]).arch == "ssp" and b.parse_args([]).batch == 32  # the north-star workload is the default
 
 
+def test_lds_layouts_are_conflict_free_under_the_lane_group_model():
+    """The LDS layouts of the pipelined Winograd conv against the ds_read_b128 lane-group model of MI355X_MICROARCH.md
+    (tools/lds_conflicts.py restates the kernel's offset formulas): fragment reads and the 8x32-tile transform reads take
+    the conflict-free 4 LDS cycles, the round-1 swizzle took 8 (the hardware counter agrees: profiles/r02_pmc_before_after.txt)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_conflicts as M
+    assert [M.cycles(M.a_frag(4, mt)) for mt in (0, 1)] == [4, 4]
+    assert [M.cycles(M.a_frag(2, mt)) for mt in (0, 1)] == [8, 8]
+    def rot(wide):
+        def f(p, q):
+            b = p >> 3
+            g = (b + 6 * (b >> 1)) if wide else ((b >> 1) + 6 * (b >> 2))
+            return ((p & ~7) + ((p + g) & 7)) * M.PK + q * 4
+        return f
+    wide = [M.cycles(M.transform(True, w, j, ra, rot(True))) for w in range(2) for j in range(4) for ra in range(4)]
+    narrow = [M.cycles(M.transform(False, w, j, ra, rot(False))) for w in range(2) for j in range(4) for ra in range(4)]
+    assert max(wide) == 4 and sum(narrow) / len(narrow) <= 6.5
+
+
 def test_optimizer_state_dict_has_torch_adam_layout():
     """saveModel's optimizer_state_dict loads into the reference's optimizer: torch.optim.Adam(net.parameters() + [eta])."""
     from semantic_superpoint_amd import lib as L
