@@ -342,6 +342,30 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
         }
         __syncthreads();
         const float* const s0p = sStage;
+        if (full && (cob + 1) * NB <= a.Cout) {
+          // straight-line fast path (as in conv_wino_pipe_kernel): all eight LDS reads of the round first
+          constexpr int NSTORE = (TH * TW * 8) / WINO_THREADS;
+          f32x4 va[NSTORE], vb[NSTORE];
+#pragma unroll
+          for (int k = 0; k < NSTORE; ++k) {
+            const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
+            va[k] = *reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4);
+            vb[k] = *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < NSTORE; ++k) {
+            const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
+            const int crow = lp / TW, ccol = lp - crow * TW;
+            const int csl = (crow >> 1) * TTX + (ccol >> 1);
+            const int sl = (csl & 15) | (rd << 4) | ((csl >> 4) << 5);
+            const int oy = ty0 + 2 * (sl / TTX) + (crow & 1), ox = tx0 + ccol;
+            const f32x4 v = pk4_add(va[k], vb[k]);
+            ssum = pk4_add(ssum, v);
+            ssq = pk4_fma(v, v, ssq);
+            *reinterpret_cast<f32x4*>(p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4) = v;
+          }
+        } else
 #pragma unroll
         for (int k = 0; k < (TH * TW * 8) / WINO_THREADS; ++k) {
           const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;  // compact pixel of the half tile
