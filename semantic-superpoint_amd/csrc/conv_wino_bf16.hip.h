@@ -21,8 +21,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int QA_FLOATS = WC * WTILES * PK / 2;   // 16 KB of bf16
 constexpr int QB_FLOATS = WC * PK * NB / 2;       // 16 KB of bf16
-constexpr int BF16_LDS_BYTES = (2 * (QA_FLOATS + QB_FLOATS) + PR_FLOATS + PS_FLOATS + 8 * 32 * NB) * 4;
-constexpr int BF16X2_LDS_BYTES = (2 * 2 * (QA_FLOATS + QB_FLOATS) + PR_FLOATS + PS_FLOATS) * 4;
+constexpr int BF16_LDS_BYTES = (2 * (QA_FLOATS + QB_FLOATS) + PR_FLOATS + PS_FLOATS + 8 * 32 * NB + NB) * 4;  // + sign of gamma (pooled output)
+constexpr int BF16X2_LDS_BYTES = (2 * 2 * (QA_FLOATS + QB_FLOATS) + PR_FLOATS + PS_FLOATS + NB) * 4;
 
 // hi / lo split of four fp32 values into bf16 (round to nearest even both times)
 __device__ __forceinline__ void bf16_split(const f32x4 v, bf16x4& hi, bf16x4& lo) {
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
   float* const sR = smem + 2 * BUF_FLOATS;
   float* const sS = sR + PR_FLOATS;  // scale[Cin] | shift[Cin] of the producer's BatchNorm (IN_MODE 1)
   float* const sStageDedicated = sS + PS_FLOATS;  // NT == 1 only
+  float* const sG = NT == 1 ? sStageDedicated + 8 * 32 * NB : sS + PS_FLOATS;  // +-1 per output channel: sign of gamma
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -66,6 +67,8 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
   const float* const p_scale = prob ? a.in_scale2 : a.in_scale;
   const float* const p_shift = prob ? a.in_shift2 : a.in_shift;
   double* const p_stats = prob ? a.stats2 : a.stats;
+  // raw 2x2-pooled copy of the output for a BatchNorm + ReLU + MaxPool consumer (ConvArgs::pool_out, see conv_wino_pipe_kernel)
+  float* const p_pool = IN_MODE == 0 ? nullptr : (prob ? a.pool_out[1] : a.pool_out[0]);
   const int nst = a.Cin / PK;                                  // stages per tile
   const int my_tiles = (t_end - tile0 + per_cob - 1) / per_cob;
   const int nstages = my_tiles * nst;
@@ -189,6 +192,10 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
     for (int c = tid; c < a.Cin; c += WINO_THREADS) {
       sS[c] = p_scale[c];
       sS[1024 + c] = p_shift[c];
+    }
+    if (p_pool != nullptr && tid < NB) {
+      const int co_ = cob * NB + tid;
+      sG[tid] = (co_ < a.Cout && a.pool_gamma[co_] < 0.f) ? -1.f : 1.f;
     }
     __syncthreads();
   }
@@ -386,6 +393,30 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
               if (nvalid > 1) p[1] = v[1];
               if (nvalid > 2) p[2] = v[2];
             }
+          }
+        }
+        if (IN_MODE != 0 && p_pool != nullptr) {
+          const int w_ = tid >> 4, wr = w_ / TTX, wc = w_ - wr * TTX;
+          const int sl = (w_ & 15) | (rd << 4) | ((w_ >> 4) << 5);
+          const int py = (ty0 >> 1) + sl / TTX, px = (tx0 >> 1) + sl % TTX;
+          if (nvalid > 0 && 2 * py < a.H && 2 * px < a.W) {
+            const f32x4 sg = *reinterpret_cast<const f32x4*>(sG + q16 * 4);
+            f32x4 m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int lp = (2 * wr + (i >> 1)) * TW + 2 * wc + (i & 1);
+              const f32x4 v = pk4_add(*reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4),
+                                      *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4)) * sg;
+              if (i == 0) m = v;
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+              }
+            }
+            m *= sg;
+            float* pp = p_pool + ((size_t)(n * (a.H >> 1) + py) * (a.W >> 1) + px) * a.Cout + co4;
+            if (nvalid == 4) *reinterpret_cast<f32x4*>(pp) = m;
+            else { pp[0] = m[0]; if (nvalid > 1) pp[1] = m[1]; if (nvalid > 2) pp[2] = m[2]; }
           }
         }
         __syncthreads();  // round 1 / the next-but-one stage overwrite the staging half-tiles

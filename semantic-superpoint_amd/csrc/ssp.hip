@@ -465,7 +465,8 @@ static bool conv_uses_p2(const ssp_handle* h, const ConvCall& c) {
 }
 // will this forward launch write ConvCall::pool_out (first-generation pipelined Winograd kernel, contiguous output)?
 static bool conv_writes_pool(const ssp_handle* h, const ConvCall& c) {
-  return c.wino && c.in_mode == 1 && (g_conv_algo == 1 || g_conv_algo == 5) && !bf16_algo() && !conv_uses_p2(h, c) && c.H % 2 == 0 && c.W % 2 == 0 &&
+  // (first-generation pipelined kernels: fp32 algorithms 1 / 5 and the bf16-operand kernels 3 / 7 / 8, which share the tile geometry)
+  return c.wino && c.in_mode == 1 && (g_conv_algo == 1 || g_conv_algo == 5 || bf16_algo()) && !conv_uses_p2(h, c) && c.H % 2 == 0 && c.W % 2 == 0 &&
          c.cout % 4 == 0 && c.out_co == 0 && c.out_cs == c.cout;
 }
 
@@ -1050,7 +1051,8 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
   }
   const bool fused = h->bsums_fused[l];  // pass 1 already sits in bsums (conv_layer_backward of the layer above)
   h->bsums_fused[l] = false;
-  if (fused && pool_after)
+  const bool raw_pool = pool_after && l < 8 && SS.s[0]->pool_raw[l];
+  if ((fused || raw_pool) && pool_after)  // S2 of gamma == 0 channels comes from a scan over Y (bn_bwd_sums_kernel)
     for (int k = 0; k < SS.n; ++k) a[k].pool_fix = 1;
   const BnBwdArgs &a0 = a[0], &a1 = a[SS.n - 1];
   float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
@@ -1069,7 +1071,15 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const int rows = 256 / (d.cout / 4);
     const int nb = std::max(1, std::min(cdiv(npix, rows), 1024));
     if (!fused && !SS.s[0]->pool_raw[l]) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(nb, SS.n), dim3(256), 0, st, a0, a1, P(h, d.be_off));
-    else if (!fused) hipLaunchKernelGGL((bn_bwd_kernel<true, true, false>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);  // scan over Y
+    else if (!fused) {
+      // raw pooled y in Apool: the window's arg-max of z is that element, so pass 1 is the plain ReLU-layer reduction over the
+      // quarter-size tensors (y = Apool, dOut)
+      BnBwdArgs r[2] = {a[0], a[SS.n - 1]};
+      for (int k = 0; k < 2; ++k) {
+        r[k].y = r[k].apool; r[k].y_cs = d.cout; r[k].y_co = 0; r[k].H = H / 2; r[k].W = W / 2;
+      }
+      hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[1]);
+    }
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
   } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st, fused)));
