@@ -198,7 +198,25 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
       sG[tid] = (co_ < a.Cout && a.pool_gamma[co_] < 0.f) ? -1.f : 1.f;
     }
     __syncthreads();
+  } else if (a.bnr_mode != 0) {
+    // fused BatchNorm-backward sums of the layer below (ConvArgs::bnr_*, as in conv_wino_pipe_kernel)
+    if (tid < NB) {
+      const int co_ = cob * NB + tid;
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+      if (co_ < a.Cout) {
+        if (a.bnr_mode == 1) {
+          const float is_ = a.bnr_p3[prob][co_];
+          q0 = a.bnr_p0[prob][co_]; q1 = a.bnr_p1[prob][co_]; q2 = is_; q3 = -a.bnr_p2[prob][co_] * is_;
+        } else {
+          const float g_ = a.bnr_p1[prob][co_];
+          q0 = a.bnr_p0[prob][co_]; q1 = g_ != 0.f ? 1.f / g_ : 0.f;
+        }
+      }
+      sS[tid] = q0; sS[NB + tid] = q1; sS[2 * NB + tid] = q2; sS[3 * NB + tid] = q3;
+    }
+    __syncthreads();
   }
+  const float* const p_bnr = prob ? a.bnr_t2 : a.bnr_t;
   // ---- prologue: stage 0 into buffer 0, loads of stage 1 in flight ----
   PIPE_ISSUE_LOADS()
   PIPE_WRITE_STAGE(0)
@@ -347,11 +365,24 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
           o[TW * NB] = s1[0] + s1[1] + s1[2] + bz;
           o[TW * NB + NB] = s1[1] - s1[2] - s1[3] + bz;
         }
+        constexpr int NSTORE = (TH * TW * 8) / WINO_THREADS;
+        const bool fast = full && (cob + 1) * NB <= a.Cout;  // block-uniform
+        f32x4 tpre[NSTORE];
+        if (IN_MODE == 0 && a.bnr_mode != 0 && fast) {  // requested before the barrier (see conv_wino_pipe_kernel)
+#pragma unroll
+          for (int k = 0; k < NSTORE; ++k) {
+            const int lp = (tid >> 4) + (WINO_THREADS / 16) * k;
+            const int crow = lp / TW, ccol = lp - crow * TW;
+            const int csl = (crow >> 1) * TTX + (ccol >> 1);
+            const int sl = (csl & 15) | (rd << 4) | ((csl >> 4) << 5);
+            const int oy = ty0 + 2 * (sl / TTX) + (crow & 1), ox = tx0 + ccol;
+            tpre[k] = *reinterpret_cast<const f32x4*>(p_bnr + ((size_t)(n * a.H + oy) * a.W + ox) * a.bnr_cs + a.bnr_co + co4);
+          }
+        }
         __syncthreads();
         const float* const s0p = sStage;
-        if (full && (cob + 1) * NB <= a.Cout) {
+        if (fast) {
           // straight-line fast path (as in conv_wino_pipe_kernel): all eight LDS reads of the round first
-          constexpr int NSTORE = (TH * TW * 8) / WINO_THREADS;
           f32x4 va[NSTORE], vb[NSTORE];
 #pragma unroll
           for (int k = 0; k < NSTORE; ++k) {
@@ -368,8 +399,27 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
             const int sl = (csl & 15) | (rd << 4) | ((csl >> 4) << 5);
             const int oy = ty0 + 2 * (sl / TTX) + (crow & 1), ox = tx0 + ccol;
             const f32x4 v = pk4_add(va[k], vb[k]);
-            ssum = pk4_add(ssum, v);
-            ssq = pk4_fma(v, v, ssq);
+            if (IN_MODE == 0 && a.bnr_mode != 0) {
+              const f32x4 t = tpre[k];
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(sS + q16 * 4), q1 = *reinterpret_cast<const f32x4*>(sS + NB + q16 * 4);
+              f32x4 dz, xh;
+              if (a.bnr_mode == 1) {
+                const f32x4 q2 = *reinterpret_cast<const f32x4*>(sS + 2 * NB + q16 * 4), q3 = *reinterpret_cast<const f32x4*>(sS + 3 * NB + q16 * 4);
+                const f32x4 z = pk4_fma(t, q0, q1);
+                xh = pk4_fma(t, q2, q3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? v[e] : 0.f;
+              } else {
+                xh = (t - q0) * q1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = t[e] > 0.f ? v[e] : 0.f;
+              }
+              ssum = pk4_add(ssum, dz);
+              ssq = pk4_fma(dz, xh, ssq);
+            } else {
+              ssum = pk4_add(ssum, v);
+              ssq = pk4_fma(v, v, ssq);
+            }
             *reinterpret_cast<f32x4*>(p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4) = v;
           }
         } else
@@ -383,8 +433,27 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_bf16_kernel(const Conv
           if (nvalid > 0 && (full || (oy < a.H && ox < a.W))) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(s0p + lp * NB + q16 * 4) +
                             *reinterpret_cast<const f32x4*>(s0p + TH * TW * NB / 2 + lp * NB + q16 * 4);
-            ssum += v;
-            ssq += v * v;
+            if (IN_MODE == 0 && a.bnr_mode != 0) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(p_bnr + ((size_t)(n * a.H + oy) * a.W + ox) * a.bnr_cs + a.bnr_co + co4);
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(sS + q16 * 4), q1 = *reinterpret_cast<const f32x4*>(sS + NB + q16 * 4);
+              f32x4 dz, xh;
+              if (a.bnr_mode == 1) {
+                const f32x4 q2 = *reinterpret_cast<const f32x4*>(sS + 2 * NB + q16 * 4), q3 = *reinterpret_cast<const f32x4*>(sS + 3 * NB + q16 * 4);
+                const f32x4 z = pk4_fma(t, q0, q1);
+                xh = pk4_fma(t, q2, q3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? v[e] : 0.f;
+              } else {
+                xh = (t - q0) * q1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = t[e] > 0.f ? v[e] : 0.f;
+              }
+              ssum += dz;
+              ssq += dz * xh;
+            } else {
+              ssum += v;
+              ssq += v * v;
+            }
             float* p = p_out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co4;
             if (nvalid == 4) {
               *reinterpret_cast<f32x4*>(p) = v;

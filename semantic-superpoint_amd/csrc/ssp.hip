@@ -399,7 +399,7 @@ struct ConvCall {
   const float* pool_gamma = nullptr;
 };
 static bool can_fuse_bnr(const ConvCall& c) {
-  return c.wino && (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
+  return c.wino && (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6 || bf16_algo()) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
          c.out_cs % 4 == 0;
 }
 
