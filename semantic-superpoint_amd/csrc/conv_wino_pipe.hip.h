@@ -669,6 +669,63 @@ __device__ __forceinline__ void pack_wino8_element(const float* __restrict__ w, 
   dst[((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * per_chunk + ((comp * 2 + h) * NB + nn) * 4 + e] = u;
 }
 
+// OIHW 3x3 weights -> U = G g G^T of Winograd F(4x4,3x3) (G: 6x3) in the fragment image of conv_wino4_kernel:
+// [cob][chunk8][component 36][h][64][4]
+constexpr int W4_PACK_FLOATS = 36 * PK * NB;
+__device__ __forceinline__ void pack_wino4_element(const float* __restrict__ w, float* __restrict__ dst, int Cout_w,
+                                                   int Cin_w, int transpose_flip, int nchunks_total, int chunk_off,
+                                                   int cob_off, int ncob, int nchunks, int idx) {
+  const int per_chunk = W4_PACK_FLOATS;
+  const int total = ncob * nchunks * per_chunk;
+  if (idx >= total) return;
+  int t = idx;
+  const int e = t & 3;
+  t >>= 2;
+  const int nn = t & 63;
+  t >>= 6;
+  const int h = t & 1;
+  t >>= 1;
+  const int comp = t % 36;
+  t /= 36;
+  const int chunk = t % nchunks;
+  const int cob = t / nchunks;
+  const int co = cob * NB + nn;
+  const int ci = chunk * PK + h * 4 + e;
+  float k[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float v = 0.f;
+      if (!transpose_flip) {
+        if (co < Cout_w && ci < Cin_w) v = w[(((size_t)co * Cin_w + ci) * 3 + ky) * 3 + kx];
+      } else {
+        if (co < Cin_w && ci < Cout_w) v = w[(((size_t)ci * Cin_w + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+      }
+      k[ky][kx] = v;
+    }
+  const int i = comp / 6, j = comp % 6;
+  // rows of G: {1/4, 0, 0}, {-1/6, -1/6, -1/6}, {-1/6, 1/6, -1/6}, {1/24, 1/12, 1/6}, {1/24, -1/12, 1/6}, {0, 0, 1}
+  const float g0i = i == 0 ? 0.25f : i == 1 || i == 2 ? -1.f / 6.f : i == 5 ? 0.f : 1.f / 24.f;
+  const float g1i = i == 0 || i == 5 ? 0.f : i == 1 ? -1.f / 6.f : i == 2 ? 1.f / 6.f : i == 3 ? 1.f / 12.f : -1.f / 12.f;
+  const float g2i = i == 0 ? 0.f : i == 1 || i == 2 ? -1.f / 6.f : i == 5 ? 1.f : 1.f / 6.f;
+  const float g0j = j == 0 ? 0.25f : j == 1 || j == 2 ? -1.f / 6.f : j == 5 ? 0.f : 1.f / 24.f;
+  const float g1j = j == 0 || j == 5 ? 0.f : j == 1 ? -1.f / 6.f : j == 2 ? 1.f / 6.f : j == 3 ? 1.f / 12.f : -1.f / 12.f;
+  const float g2j = j == 0 ? 0.f : j == 1 || j == 2 ? -1.f / 6.f : j == 5 ? 1.f : 1.f / 6.f;
+  float r[3];
+#pragma unroll
+  for (int x = 0; x < 3; ++x) r[x] = g0i * k[0][x] + g1i * k[1][x] + g2i * k[2][x];
+  const float u = g0j * r[0] + g1j * r[1] + g2j * r[2];
+  dst[((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * per_chunk + ((comp * 2 + h) * NB + nn) * 4 + e] = u;
+}
+
+__global__ void pack_weights_wino4_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout_w, int Cin_w,
+                                          int transpose_flip, int nchunks_total, int chunk_off, int cob_off, int ncob,
+                                          int nchunks) {
+  pack_wino4_element(w, dst, Cout_w, Cin_w, transpose_flip, nchunks_total, chunk_off, cob_off, ncob, nchunks,
+                     blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 __global__ void pack_weights_wino8_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout_w, int Cin_w,
                                           int transpose_flip, int nchunks_total, int chunk_off, int cob_off, int ncob,
                                           int nchunks) {
@@ -683,6 +740,7 @@ struct PackJob {
   float* dst;
   int cout_w, cin_w, tf, nchunks_total, chunk_off, cob_off, ncob, nchunks;
   int block0;  // first block of this job (256 elements per block)
+  int w4;      // F(4x4,3x3) image (pack_wino4_element) instead of the F(2x2,3x3) one
 };
 constexpr int PACK_MAX_JOBS = 32;
 struct PackJobs {
@@ -693,6 +751,10 @@ __global__ void pack_weights_wino8_multi_kernel(const PackJobs J) {
   int k = 0;
   while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;  // wave-uniform linear search, <= 32 jobs
   const PackJob& q = J.j[k];
+  if (q.w4)
+    pack_wino4_element(q.w, q.dst, q.cout_w, q.cin_w, q.tf, q.nchunks_total, q.chunk_off, q.cob_off, q.ncob, q.nchunks,
+                       ((int)blockIdx.x - q.block0) * blockDim.x + threadIdx.x);
+  else
   pack_wino8_element(q.w, q.dst, q.cout_w, q.cin_w, q.tf, q.nchunks_total, q.chunk_off, q.cob_off, q.ncob, q.nchunks,
                      ((int)blockIdx.x - q.block0) * blockDim.x + threadIdx.x);
 }

@@ -18,6 +18,7 @@
 #include "conv_wino.hip.h"
 #include "conv_wino_pipe.hip.h"
 #include "conv_wino_p2.hip.h"
+#include "conv_wino4.hip.h"
 #include "conv_wino_bf16.hip.h"
 #include "loss_kernels.hip.h"
 #include "dense_loss.hip.h"
@@ -39,9 +40,11 @@ static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks
 // bf16 Winograd modes: number of bf16 parts per operand element.  3: one part everywhere; 7: hi + lo everywhere;
 // 8 (mixed): hi + lo in the FORWARD convolutions (the activations every later layer and the ReLU gates depend on), one
 // part in the data-gradient and weight-gradient kernels (unbiased 2^-9 noise on the gradients, like any bf16 training)
+// fp32 pipelined Winograd family: 1 (default), 9 = 1 + F(4x4,3x3) on the large maps (conv_uses_w4), 10 = F(4x4,3x3) wherever legal
+static inline bool pipe_algo() { return g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10; }
 static inline bool bf16_algo() { return g_conv_algo == 3 || g_conv_algo == 7 || g_conv_algo == 8; }
 static inline int bf16_parts(bool backward) { return g_conv_algo == 7 || (g_conv_algo == 8 && !backward) ? 2 : 1; }
-static inline int pk_taps(int ks) { return ks == 3 ? WC : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
+static inline int pk_taps(int ks) { return ks == 3 ? W4C : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
 static int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -399,7 +402,7 @@ struct ConvCall {
   const float* pool_gamma = nullptr;
 };
 static bool can_fuse_bnr(const ConvCall& c) {
-  return c.wino && (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6 || bf16_algo()) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
+  return c.wino && (pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6 || bf16_algo()) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
          c.out_cs % 4 == 0;
 }
 
@@ -423,6 +426,18 @@ static int launch_wino_p2_t(const ConvArgs& a, int nblocks, hipStream_t st) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES));
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(P2_THREADS), P2_LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int IN_MODE, bool WIDE>
+static int launch_wino4_t(const ConvArgs& a, int nblocks, hipStream_t st) {
+  static AttrOnce attr_once;
+  auto kern = conv_wino4_kernel<IN_MODE, WIDE>;
+  if (attr_once.need()) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(W4_THREADS), W4_LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -455,10 +470,30 @@ static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
 // default algorithm (1): maps with few first-generation work items per CU (the 30x40 layers: 640 items on 256 CUs =
 // 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
 // large maps: tools/conv_probe.py)
+// Winograd F(4x4,3x3) (conv_wino4_kernel): tile blocks of 32x16 / 16x32 pixels, whichever wastes less of the map
+static void w4_geometry(int H, int W, bool& wide, int& tiles_y, int& tiles_x) {
+  const long a_w = (long)cdiv(H, 16) * 16 * cdiv(W, 32) * 32, a_t = (long)cdiv(H, 32) * 32 * cdiv(W, 16) * 16;
+  wide = a_w <= a_t;
+  tiles_y = cdiv(H, wide ? 16 : 32); tiles_x = cdiv(W, wide ? 32 : 16);
+}
+// does a 3x3 launch of this shape run F(4x4,3x3)?  Decided from the shape alone: the weight images are packed with the
+// same predicate (launch_pack / pack_all).  Algorithm 9: maps of >= 120x160 pixels with >= 4 tile blocks per CU.
+static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int cin, int cout) {
+  if (g_conv_algo != 9 && g_conv_algo != 10) return false;
+  if (cin % 8 != 0) return false;
+  if (g_conv_algo == 10) return true;
+  bool wide; int ty, tx;
+  w4_geometry(H, W, wide, ty, tx);
+  const long items = (long)nprob * N * ty * tx * cdiv(cout, NB);
+  return (long)H * W >= 120L * 160L && items >= 4L * (h ? h->n_cu : 256);
+}
+static bool conv_uses_w4(const ssp_handle* h, const ConvCall& c) {
+  return c.wino && c.ks == 3 && c.in_mode != 2 && w4_eligible(h, c.nprob, c.N, c.H, c.W, c.cin, c.cout);
+}
 static bool conv_uses_p2(const ssp_handle* h, const ConvCall& c) {
   if (!c.wino) return false;
   if (g_conv_algo == 6) return true;
-  if (g_conv_algo != 1) return false;
+  if (!pipe_algo() || conv_uses_w4(h, c)) return false;
   const bool w1 = (c.W % 32) == 0;
   const long items = (long)c.nprob * c.N * cdiv(c.H, w1 ? 8 : 32) * cdiv(c.W, w1 ? 32 : 8) * c.ncob;
   return items < 4L * (h ? h->n_cu : 256);
@@ -466,8 +501,8 @@ static bool conv_uses_p2(const ssp_handle* h, const ConvCall& c) {
 // will this forward launch write ConvCall::pool_out (first-generation pipelined Winograd kernel, contiguous output)?
 static bool conv_writes_pool(const ssp_handle* h, const ConvCall& c) {
   // (first-generation pipelined kernels: fp32 algorithms 1 / 5 and the bf16-operand kernels 3 / 7 / 8, which share the tile geometry)
-  return c.wino && c.in_mode == 1 && (g_conv_algo == 1 || g_conv_algo == 5 || bf16_algo()) && !conv_uses_p2(h, c) && c.H % 2 == 0 && c.W % 2 == 0 &&
-         c.cout % 4 == 0 && c.out_co == 0 && c.out_cs == c.cout;
+  return c.wino && c.in_mode == 1 && (pipe_algo() || g_conv_algo == 5 || bf16_algo()) && !conv_uses_p2(h, c) && c.H % 2 == 0 && c.W % 2 == 0 &&
+         c.cout % 4 == 0 && c.out_co == 0 && c.out_cs == c.cout && (!conv_uses_w4(h, c) || c.cout % NB == 0);
 }
 
 static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int prof_family = 0) {
@@ -504,6 +539,7 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   // 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
   // large maps: tools/conv_probe.py)
   const bool p2 = conv_uses_p2(h, c);
+  const bool w4 = conv_uses_w4(h, c);
   if (c.pool_out[0] != nullptr) {
     if (!conv_writes_pool(h, c)) return fail(-3, "pooled raw output needs the first-generation pipelined Winograd kernel");
     a.pool_out[0] = c.pool_out[0]; a.pool_out[1] = c.pool_out[1]; a.pool_gamma = c.pool_gamma;
@@ -511,6 +547,11 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   const bool wide = p2 ? (c.W % 16) == 0 : (c.W % 32) == 0;
   const int TH = p2 ? (wide ? 8 : 16) : (wide ? 8 : 32), TW = p2 ? (wide ? 16 : 8) : (wide ? 32 : 8);
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
+  bool wide4 = false;
+  if (w4) {
+    w4_geometry(c.H, c.W, wide4, a.tiles_y, a.tiles_x);
+    a.wpk_bytes = (unsigned)((double)c.ncob * (c.cin / 8) * W4_B_FLOATS * 4.0);
+  }
   // persistent grid: 2 blocks per CU (LDS-limited residency; first-generation Winograd: 1), a multiple of 8 (one slot
   // set per XCD)
   const int n_cu = h ? h->n_cu : 256;
@@ -525,6 +566,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
       c.cin == 64)
     fam = SSP_PROF_CONV_BIG_FWD;
   ProfScope ps(h, fam, st, flops, bytes);
+  if (w4) {  // Winograd F(4x4,3x3), one 8-wave workgroup per CU
+    if (c.in_mode == 0) return wide4 ? launch_wino4_t<0, true>(a, nblocks, st) : launch_wino4_t<0, false>(a, nblocks, st);
+    return wide4 ? launch_wino4_t<1, true>(a, nblocks, st) : launch_wino4_t<1, false>(a, nblocks, st);
+  }
   if (c.wino && bf16_algo()) {
     if (bf16_parts(c.backward) == 1) {
       a.wpk_bytes /= 2;  // one bf16 part: half the bytes of the fp32 image
@@ -539,7 +584,7 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     if (c.in_mode == 0) return wide ? launch_wino_p2_t<0, true>(a, nblocks, st) : launch_wino_p2_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_p2_t<1, true>(a, nblocks, st) : launch_wino_p2_t<1, false>(a, nblocks, st);
   }
-  if (c.wino && g_conv_algo == 1) {  // pipelined Winograd, weight fragments straight from L2 (default)
+  if (c.wino && pipe_algo()) {  // pipelined Winograd, weight fragments straight from L2 (default)
     if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true, true>(a, nblocks, st) : launch_wino_pipe_t<0, false, true>(a, nblocks, st);
     return wide ? launch_wino_pipe_t<1, true, true>(a, nblocks, st) : launch_wino_pipe_t<1, false, true>(a, nblocks, st);
   }
@@ -698,17 +743,20 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   return 0;
 }
 
-static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino, hipStream_t st) {
+static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino, hipStream_t st, bool w4 = false) {
   const int taps = ks * ks;
   const int conv_cin = tf ? cout_w : cin_w, conv_cout = tf ? cin_w : cout_w;
   const int nchunks = cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
   if (wino) {
     const int total = ncob * nchunks * WB_FLOATS;
-    if (bf16_algo())
+    if (w4)  // F(4x4,3x3) image of conv_wino4_kernel: 8-channel chunks of 36 components
+      hipLaunchKernelGGL(pack_weights_wino4_kernel, dim3(cdiv(ncob * 2 * nchunks * W4_B_FLOATS, 256)), dim3(256), 0, st, w, dst,
+                         cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks);
+    else if (bf16_algo())
       hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w,
                          reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks,
                          bf16_parts(tf != 0));
-    else if (g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6)  // 8-channel stages of the pipelined kernels: twice as many chunks of half the size
+    else if (pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6)  // 8-channel stages of the pipelined kernels: twice as many chunks of half the size
       hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
                          2 * nchunks, 0, 0, ncob, 2 * nchunks);
     else
@@ -878,32 +926,39 @@ static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, dou
   return 0;
 }
 
-static int pack_all(ssp_handle* h, bool with_bwd, hipStream_t st) {
+static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W, hipStream_t st) {
   // default algorithm: every Winograd image (3x3 layers forward + data gradient, concatenated heads) in one launch
-  const bool multi = g_conv_algo == 1 || g_conv_algo == 5 || g_conv_algo == 6;
+  const bool multi = pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6;
   PackJobs J;
   J.n = 0;
   int nblocks = 0;
   auto add_job = [&](const float* w, float* dst, int cout_w, int cin_w, int tf, int nchunks_total, int chunk_off, int cob_off,
-                     int ncob, int nchunks) {
+                     int ncob, int nchunks, bool w4 = false) {
     PackJob& q = J.j[J.n++];
     q.w = w; q.dst = dst; q.cout_w = cout_w; q.cin_w = cin_w; q.tf = tf; q.nchunks_total = nchunks_total;
-    q.chunk_off = chunk_off; q.cob_off = cob_off; q.ncob = ncob; q.nchunks = nchunks; q.block0 = nblocks;
-    nblocks += cdiv((long)ncob * nchunks * PB_FLOATS, 256);
+    q.chunk_off = chunk_off; q.cob_off = cob_off; q.ncob = ncob; q.nchunks = nchunks; q.block0 = nblocks; q.w4 = w4 ? 1 : 0;
+    nblocks += cdiv((long)ncob * nchunks * (w4 ? W4_B_FLOATS : PB_FLOATS), 256);
   };
-  auto pack = [&](const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino) -> int {
+  auto pack = [&](const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino, bool w4) -> int {
     if (multi && wino && J.n < PACK_MAX_JOBS) {
       const int conv_cin = tf ? cout_w : cin_w, conv_cout = tf ? cin_w : cout_w;
       const int nchunks = 2 * cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
-      add_job(w, dst, cout_w, cin_w, tf, nchunks, 0, 0, ncob, nchunks);
+      add_job(w, dst, cout_w, cin_w, tf, nchunks, 0, 0, ncob, nchunks, w4);
       return 0;
     }
-    return launch_pack(w, dst, cout_w, cin_w, ks, tf, wino, st);
+    return launch_pack(w, dst, cout_w, cin_w, ks, tf, wino, st, w4);
   };
   for (int l = 1; l < h->nlayers; ++l) {
     const LayerDesc& d = h->L[l];
-    CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wino_ok(d.ks, d.cin)));
-    if (with_bwd) CHK(pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wino_ok(d.ks, d.cout)));
+    // the encoder's 3x3 layers at their resolution: the same F(4x4,3x3) predicate as the launches (conv_uses_w4)
+    int lh = H / 8, lw = W / 8;
+    if (l < 8) layer_res(l, H, W, lh, lw);
+    const bool wf = wino_ok(d.ks, d.cin), wb = wino_ok(d.ks, d.cout);
+    CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wf,
+             wf && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, d.cin, d.cout)));
+    if (with_bwd)
+      CHK(pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wb,
+               wb && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, (int)align_up(d.cout, 4), d.cin)));
   }
   if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
     const int heads[3] = {L_PA, L_DA, L_DS};
@@ -996,7 +1051,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     CHK(dev_zero(S.stats_region, S.stats_bytes, st));
     S.bsums_dirty = false;
   }
-  CHK(pack_all(h, for_backward, st));
+  CHK(pack_all(h, for_backward, SS.n, N, H, W, st));
   // layer 0: direct 1->64 conv (HBM-bound; the views ride one launch, blockIdx.y)
   {
     const LayerDesc& d = h->L[0];
@@ -1505,7 +1560,7 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
-  if (algo < 0 || algo > 8 || algo == 4) return fail(-1, "conv algo must be 0, 1, 2, 3, 5, 6, 7 or 8 (see ssp_set_conv_algo)");
+  if (algo < 0 || algo > 10 || algo == 4) return fail(-1, "conv algo must be 0..3 or 5..10 (see ssp_set_conv_algo)");
   h->conv_algo = algo;
   return 0;
 }
@@ -1600,8 +1655,9 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
   if (workspace_bytes < need) return fail(-4, "ssp_op_conv workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   float* wpk = reinterpret_cast<float*>(workspace_dev);
-  if (!transpose_flip) CHK(launch_pack(w_oihw_dev, wpk, cout, cin, ksize, 0, wino, st));
-  else CHK(launch_pack(w_oihw_dev, wpk, cin, cout, ksize, 1, wino, st));
+  const bool w4 = wino && ksize == 3 && w4_eligible(nullptr, 1, n, hh, w, cin, cout);
+  if (!transpose_flip) CHK(launch_pack(w_oihw_dev, wpk, cout, cin, ksize, 0, wino, st, w4));
+  else CHK(launch_pack(w_oihw_dev, wpk, cin, cout, ksize, 1, wino, st, w4));
   ConvCall c;
   c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.wpk = wpk; c.bias = bias_dev; c.out = out_dev; c.out_cs = cout;
   c.out_co = 0; c.cout = cout; c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.stats = stats_dev; c.N = n;
@@ -1916,10 +1972,11 @@ int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 8 || algo == 4)
+  if (algo < 0 || algo > 10 || algo == 4)
     return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
                     "operands), 5 (Winograd, pipelined, weights staged through LDS), 6 (Winograd, two 4-wave workgroups per CU) "
-                    ", 7 (Winograd, split-bf16 hi + lo operands) or 8 (forward split-bf16, backward bf16)");
+                    ", 7 (Winograd, split-bf16 hi + lo operands), 8 (forward split-bf16, backward bf16), 9 (1 + Winograd "
+                    "F(4x4,3x3) on the large maps) or 10 (F(4x4,3x3) wherever legal)");
   g_default_conv_algo = algo;
   return 0;
 }

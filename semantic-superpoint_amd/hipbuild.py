@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libssp_hip.so")
-SOURCES = ["ssp.hip", "pk_math.hip.h", "conv_mfma.hip.h", "conv_wino.hip.h", "conv_wino_pipe.hip.h", "conv_wino_p2.hip.h", "conv_wino_bf16.hip.h", "dense_loss.hip.h", "bn_kernels.hip.h", "loss_kernels.hip.h", "sem_kernels.hip.h", "pair_kernels.hip.h", "export_kernels.hip.h",
+SOURCES = ["ssp.hip", "pk_math.hip.h", "conv_mfma.hip.h", "conv_wino.hip.h", "conv_wino_pipe.hip.h", "conv_wino_p2.hip.h", "conv_wino4.hip.h", "conv_wino_bf16.hip.h", "dense_loss.hip.h", "bn_kernels.hip.h", "loss_kernels.hip.h", "sem_kernels.hip.h", "pair_kernels.hip.h", "export_kernels.hip.h",
            os.path.join("..", "..", "include", "ssp_hip.h")]
 
 

@@ -27,15 +27,16 @@ def _ref_input(x_nhwc, in_mode, sc, sh):
     return x
 
 
-@pytest.fixture(params=[1, 0, 2, 5, 6, 7], ids=["winograd_pipelined", "direct", "winograd_unpipelined", "winograd_lds_weights",
-                                                 "winograd_two_workgroups", "winograd_bf16x2"])
+@pytest.fixture(params=[1, 0, 2, 5, 6, 7, 10], ids=["winograd_pipelined", "direct", "winograd_unpipelined", "winograd_lds_weights",
+                                                     "winograd_two_workgroups", "winograd_bf16x2", "winograd_f4x4"])
 def conv_algo(request):
     """ssp_set_conv_algo: every convolution / weight-gradient operator test runs under the fp32 implementations
     (1 = default: software-pipelined Winograd; 0 = direct implicit GEMM; 2 = Winograd without the software pipeline;
     5 = the pipelined kernel with the weights staged through LDS instead of loaded from L2 into the operand registers;
     6 = the second-generation pipelined Winograd kernel: two independent 4-wave workgroups per CU;
     7 = split-bf16 operands (hi + lo, 16 significant bits, three bf16 MFMAs per product block, fp32 accumulation):
-    product rounding ~2^-16, i.e. ~1e-5 of the output scale - inside this file's 2e-4 tolerance)."""
+    product rounding ~2^-16, i.e. ~1e-5 of the output scale - inside this file's 2e-4 tolerance;
+    10 = Winograd F(4x4,3x3) (conv_wino4_kernel) on every 3x3 convolution it can run, F(2x2,3x3) elsewhere)."""
     from semantic_superpoint_amd import lib as L
     L.set_conv_algo(request.param)
     yield request.param
