@@ -3,67 +3,68 @@
 // about the same transform work per output.  fp32 error against fp64 on a 64 -> 64 layer's data: rel-L2 1.5e-6 (F(2x2):
 // 2.4e-7; tools/wino_error_probe.py).
 //
-//   workgroup = 8 waves = 32 tiles (32x16 or 16x32 output pixels) x 64 output channels, one workgroup per CU;
-//   wave = (I, J, nt): the 3x3 quadrant (rows 3I.., columns 3J..) of the 6x6 component matrix M, output-channel half nt:
-//          9 accumulators of 32 channels x 32 tiles = 144 registers.
+//   workgroup = 4 waves (ONE per SIMD) = 32 tiles (32x16 or 16x32 output pixels) x 64 output channels, one per CU;
+//   wave = (I, nt): rows 3I .. 3I+2 of the 6x6 component matrix M (18 components), output-channel half nt:
+//          18 accumulators of 32 channels x 32 tiles = 288 registers of the wave's 512 (256 of them accumulation registers).
+// The accumulators alone are 295 KB of the CU's 512 KB register file: with eight waves (the first version of this
+// kernel, 144 + 112 registers per wave) every per-thread cost - operand sets, halo registers, LDS addresses - is paid
+// twice and the kernel spilled 60-80 registers; four waves of 512 registers hold everything, and the output transform
+// along the columns of M stays inside a wave.  One wave per SIMD hides no latency by itself: every operand is fetched
+// two component pairs (16 MFMAs) ahead and the transform reads its raw pixels two MFMA slots ahead.
 //
 // Operand roles as in conv_wino_p2_kernel: A = weight fragment (32 output channels x 2 k), B = transformed input fragment
 // (2 k x 32 tiles); an accumulator lane holds ONE tile (column = lane & 31) and 16 output channels (row = (reg & 3) + 8 (reg
 // >> 2) + 4 (lane >> 5)), so four consecutive channels sit in four consecutive registers (16-byte LDS / global accesses).
 //
-// Stage pipeline (8 input channels per stage = 36 MFMAs per wave; transformed input double-buffered, ONE raw-halo buffer):
+// Stage pipeline (8 input channels per stage = 72 MFMAs per wave in 9 component pairs, the two accumulators of a pair
+// alternating; transformed input double-buffered, ONE raw-halo buffer):
 //
-//   first half : components 0..4  ||  transform raw(g+1): sR -> sA[~g&1]   (waves 0..5 = rows 0..5 of V = B^T d B)
+//   first half : pairs 0..4  ||  transform raw(g+1): sR -> sA[~g&1]  (wave w: row w of V = B^T d B, waves 0, 1 also row w + 4)
 //   barrier A
-//   second half: components 5..8  ||  halo (g+2): registers -> sR (BatchNorm + ReLU of the producer), halo loads (g+3)
+//   second half: pairs 5..8  ||  halo (g+2): registers -> sR (BatchNorm + ReLU of the producer), halo loads (g+3)
 //   barrier B
 //
-// Every MFMA operand is fetched two components (8 MFMAs) ahead into one of three rotating register sets (9 = 3 x 3
-// components per stage, so the rotation is the same in every stage): weights from L2 (the packed image
-// [cob][chunk8][component][h][64][4] IS the fragment layout), inputs from LDS.
+// Three rotating operand sets (9 = 3 x 3 pairs per stage: the same rotation in every stage): weights from L2 (the packed
+// image [cob][chunk8][component][h][64][4] IS the fragment layout), inputs from LDS.
 //
-// Epilogue Y = A^T M A (4x6 . 6x6 . 6x4) over four waves per channel half, two exchange steps per register quad:
-//   step 1: Q = M[I,J] A[J,:]  (3 x 4);  the waves (I,0) and (I,1) swap the two output columns they do not keep -> R (3 x 2)
-//   step 2: P = A^T[:,I] R      (4 x 2);  the waves (0,J) and (1,J) swap the two output rows they do not keep   -> Y (2 x 2)
-// so every wave ends up with the 2x2 pixel block (2I, 2J) of its lane's tile - one pooling window - for 16 channels in
-// registers: 16-byte global stores straight from registers, BatchNorm sums by shuffles, pooled raw output in registers.
-// 10 instead of 16 exchanged values per (tile, channel) and wave; the step-1 buffer is the just-consumed sA image.
+// Epilogue Y = A^T M A (4x6 . 6x6 . 6x4) per register quad: R = M[I,:] A (3 x 4) inside the wave, P = A^T[:,I] R (4 x 4
+// partial sums); the waves (0, nt) and (1, nt) swap the two output rows they do not keep (8 values per tile and channel
+// through LDS, one barrier, double-buffered in the just-consumed sA image and sX) and each finishes a 2x4 pixel block =
+// two pooling windows of its lane's tile for 16 channels in registers: 16-byte global stores straight from registers,
+// BatchNorm sums by shuffles, pooled raw output in registers.
 //
-// Raw halo in LDS: [row][pixel][8 channels], row pitch 40 / 24 pixels (a multiple of the 256-byte bank row); the pixels
-// of halo row R are rotated by (R >> 2) & 3 inside aligned groups of 8: the transform's ds_read_b128 (lane = (quad, tile),
-// a 16-lane group = 8 tiles with distinct (tx & 1, ty & 3)) then hits 8 distinct 32-byte slots.
+// Raw halo in LDS: [row][pixel][8 channels] at LDS offset 0, row pitch 40 / 24 pixels (a multiple of the 256-byte bank
+// row); the pixels of halo row R are rotated by (R >> 2) & 3 inside aligned groups of 8: the transform's ds_read_b128
+// (lane = (quad, tile), a 16-lane group = 8 tiles with distinct (tx & 1, ty & 3)) then hits 8 distinct 32-byte slots.
 #pragma once
 #include "conv_wino_p2.hip.h"
+#include <type_traits>
 
 #ifndef W4_ABL
-#define W4_ABL 0  // compile-time perf ablation: 1 no tile epilogue
+#define W4_ABL 0  // compile-time perf ablation: 1 no tile epilogue, 2 no transform, 4 no halo staging, 16 no output stores,
+                  // 32 no barrier in the epilogue rounds, 64 accumulators not cleared
 #endif
 
 namespace sspk {
 
 constexpr int W4C = 36;                                // Winograd components
-constexpr int W4_THREADS = 512;
+constexpr int W4_THREADS = 256;
 constexpr int W4_TILES = 32;                           // 4x4-pixel tiles per workgroup
 constexpr int W4_A_FLOATS = W4C * W4_TILES * PK;       // 9216 floats = 36 KB transformed input per buffer
 constexpr int W4_B_FLOATS = W4C * PK * NB;             // 18432 floats: packed weights per (cob, 8-channel chunk)
 constexpr int W4_R_FLOATS = 34 * 24 * PK;              // raw halo: 34 rows x 24 pixels (16x32 tiles) >= 18 x 40 (32x16)
-constexpr int W4_XA_FLOATS = 2 * 6 * 256;              // step-1 exchange of waves 6, 7 (waves 0..5: the consumed sA image)
-constexpr int W4_X2_FLOATS = 8 * 4 * 256;              // step-2 exchange: [wave][value][lane][4]
+constexpr int W4_X_FLOATS = 4 * 8 * 256;               // row exchange: [wave][8 values][lane][4] = 32 KB
 constexpr int W4_S_FLOATS = 2048 + 2 * NB;             // BatchNorm scale | shift (or 4 x 64 bnr parameters), bias, pool sign
-constexpr int W4_LDS_BYTES = (2 * W4_A_FLOATS + W4_R_FLOATS + W4_XA_FLOATS + W4_X2_FLOATS + W4_S_FLOATS) * 4;  // 153600
-static_assert(6 * 6 * 256 == W4_A_FLOATS, "six waves' step-1 slots fill one transformed-input buffer");
+constexpr int W4_LDS_BYTES = (2 * W4_A_FLOATS + W4_R_FLOATS + W4_X_FLOATS + W4_S_FLOATS) * 4;  // 141312
+static_assert(W4_X_FLOATS <= W4_A_FLOATS, "the consumed transformed-input buffer is the second exchange buffer");
 static_assert(W4_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 static_assert(W4_R_FLOATS * 4 < 65536, "16-bit raw-halo byte addresses");
+static_assert(W4_B_FLOATS == W4_PACK_FLOATS, "pack_wino4_element");
 
 // k (wave-uniform, in a scalar register pair) * y + z
 __device__ __forceinline__ f32x2 pk_fma_k(f32x2 k, f32x2 y, f32x2 z) {
   f32x2 d;
   asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(k), "v"(y), "v"(z));
-  return d;
-}
-__device__ __forceinline__ f32x2 pk_mul_k(f32x2 k, f32x2 y) {
-  f32x2 d;
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "s"(k), "v"(y));
   return d;
 }
 // inline-constant multiplier (4.0, -4.0, 2.0, -2.0), broadcast to both halves: no register for the constant
@@ -80,7 +81,32 @@ W4_PK_IMM(pk_fma_p2, "2.0")
 W4_PK_IMM(pk_fma_m2, "-2.0")
 #undef W4_PK_IMM
 __device__ __forceinline__ f32x4 pk4_fma_k(f32x2 k, f32x4 y, f32x4 z) { return cat2(pk_fma_k(k, lo2(y), lo2(z)), pk_fma_k(k, hi2(y), hi2(z))); }
-__device__ __forceinline__ f32x4 pk4_mul_k(f32x2 k, f32x4 y) { return cat2(pk_mul_k(k, lo2(y)), pk_mul_k(k, hi2(y))); }
+
+// Accumulators 0..15 live in FIXED accumulation registers a[16 A : 16 A + 15], touched by inline asm only (MFMA, clear,
+// read).  hipcc keeps every accumulator of a builtin MFMA in accumulation registers once a kernel may use more than 256
+// registers, and with 18 of them (288 registers) it spilled whole accumulators at the head of the stage loop; as
+// compiler-managed values in vector registers they would not fit either.  The compiler sees none of these registers
+// (w4_claim_agprs() makes it reserve all 256 in the kernel descriptor), so the hazards are handled here: consecutive
+// MFMAs of one accumulator chain need no wait states, MFMA operands come from loads (s_waitcnt is inserted for asm
+// operands), mfma_results_guard() precedes the reads, and a cleared accumulator is next used dozens of instructions later.
+template <int A>
+__device__ __forceinline__ void w4_mfma_a(float w, float f) {
+  asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(w), "v"(f), "n"(A * 16), "n"(A * 16 + 15));
+}
+template <int R>
+__device__ __forceinline__ float w4_acc_rd() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(R));
+  return x;
+}
+template <int R>
+__device__ __forceinline__ f32x4 w4_acc_quad() { return f32x4{w4_acc_rd<R>(), w4_acc_rd<R + 1>(), w4_acc_rd<R + 2>(), w4_acc_rd<R + 3>()}; }
+template <int R = 0>
+__device__ __forceinline__ void w4_acc_clear() {
+  asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(R));
+  if constexpr (R + 1 < 256) w4_acc_clear<R + 1>();
+}
+__device__ __forceinline__ void w4_claim_agprs() { asm volatile("" : : : "a0", "a255"); }
 
 // tile index (= MFMA column = lane & 31) -> tile coordinates inside the workgroup's 8x4 / 4x8 tile block; tiles with the
 // same index mod 8 differ in (tx & 1, ty & 3)
@@ -98,14 +124,14 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   constexpr int PITCH = (HC + 7) / 8 * 8;              // pixels per LDS halo row: whole rotation groups
   constexpr int NHALO = HR * HC;                       // 612
   constexpr int ROWF = PITCH * PK;                     // floats per LDS halo row
+  constexpr int NH = 5;                                // halo items (pixel, channel quad) per thread: 1224 / 256
   static_assert(HR * PITCH * PK <= W4_R_FLOATS, "raw halo buffer");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // [sR][sA0][sA1][sXa][sX2][sS]: the raw halo sits at LDS offset 0, so that two of its byte addresses fit one register
+  // [sR][sA0][sA1][sX][sS]: the raw halo sits at LDS offset 0, so that two of its byte addresses fit one register
   float* const sR = smem;
   float* const sA = smem + W4_R_FLOATS;
-  float* const sXa = sA + 2 * W4_A_FLOATS;
-  float* const sX2 = sXa + W4_XA_FLOATS;
-  float* const sS = sX2 + W4_X2_FLOATS;                // IN_MODE 1: scale[Cin] | shift[Cin]; bnr: 4 x 64 parameters
+  float* const sX = sA + 2 * W4_A_FLOATS;
+  float* const sS = sX + W4_X_FLOATS;                  // IN_MODE 1: scale[Cin] | shift[Cin]; bnr: 4 x 64 parameters
   float* const sBias = sS + 2048;
   float* const sG = sBias + NB;                        // +-1: sign of gamma (pooled raw output)
 
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int nt = wave & 1, qJ = (wave >> 1) & 1, qI = wave >> 2;
+  const int nt = wave & 1, qI = wave >> 1;
 
   // ---- work assignment (as conv_wino_pipe_kernel): XCD-aware persistent tile list ----
   const int nslot = gridDim.x >> 3;
@@ -138,18 +164,22 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   const int my_tiles = (t_end - tile0 + per_cob - 1) / per_cob;
   const int nstages = my_tiles * nst;
 
-  // ---- staging roles: raw halo items tid + 512 k (k < 3), item = pixel * 2 + quad ----
-  // (LDS addresses of the staging and transform roles are recomputed from t_key after every tile epilogue, W4_ADDR_SETUP:
-  // the epilogue needs their registers)
+  // ---- staging roles: raw halo items tid + 256 k (k < 5), item = pixel * 2 + quad ----
   const int q2 = tid & 1;
-  int t_key = tid;
-  int r_lds[3];
-  const bool r2 = tid + 2 * W4_THREADS < NHALO * 2;  // the third item exists
+  int r_lds[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int p = (tid + W4_THREADS * k) >> 1, r = p / HC, c = p - r * HC;
+    r_lds[k] = (r * PITCH + (c & ~7) + ((c + ((r >> 2) & 3)) & 7)) * PK + q2 * 4;
+  }
+  const bool r4 = tid + 4 * W4_THREADS < NHALO * 2;  // the fifth item exists
   const int pixb = a.in_cs * 4, rowb = a.W * pixb;
-  f32x4 hreg[3];
+  f32x4 hreg[NH];
   int h_chunk = 0;  // 8-channel chunk of the halo loads in hreg (BatchNorm parameters of the producer at W4_HALO_BN)
   constexpr unsigned OOB = 0x80000000u;
-  unsigned hoff[3] = {OOB, OOB, OOB};
+  unsigned hoff[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) hoff[k] = OOB;
   const size_t img_floats = (size_t)a.H * a.W * a.in_cs;
   __amdgpu_buffer_rsrc_t rsrc_in;
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
@@ -161,17 +191,17 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
       const int tt_ = min(ld_tile, t_end - 1);  /* past the end: harmless redundant loads of the last tile */ \
       const int tx_ = tt_ % a.tiles_x, t2_ = tt_ / a.tiles_x;                                               \
       const int ty0_ = (t2_ % a.tiles_y) * TH, tx0_ = tx_ * TW, n_ = t2_ / a.tiles_y;                       \
-      _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                       \
+      _Pragma("unroll") for (int k = 0; k < NH; ++k) {                                                      \
         const int p_ = (tid + W4_THREADS * k) >> 1, r_ = p_ / HC, c_ = p_ - r_ * HC;                        \
         const int gy = ty0_ - 1 + r_, gx = tx0_ - 1 + c_;                                                   \
-        const bool ok = (k < 2 || r2) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;      \
+        const bool ok = (k < NH - 1 || r4) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W; \
         hoff[k] = ok ? (unsigned)(gy * rowb + gx * pixb + (a.in_co + q2 * 4) * 4) : OOB;                    \
       }                                                                                                     \
       rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in) + (size_t)n_ * img_floats, 0,    \
                                                   a.in_bytes, 0x00020000);                                  \
     }                                                                                                       \
     h_chunk = ld_chunk;                                                                                     \
-    _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                           \
+    _Pragma("unroll") for (int k = 0; k < NH; ++k)                                                          \
       hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], ld_chunk * PK * 4, 0)); \
     if (++ld_chunk == nst) { ld_chunk = 0; ld_tile += per_cob; }                                            \
   }
@@ -182,58 +212,57 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     psh = *reinterpret_cast<const f32x4*>(sS + 1024 + h_chunk * PK + q2 * 4);                               \
   }
 #define W4_HALO_BN(K) if (IN_MODE != 0 && !(W4_ABL & 4)) hreg[K] = bn_relu_quad(hreg[K], psc, psh, hoff[K] == OOB);
-#define W4_HALO_WR(K) if (!(W4_ABL & 4) && ((K) < 2 || r2)) *reinterpret_cast<f32x4*>(sR + r_lds[K]) = hreg[K];
+#define W4_HALO_WR(K) if (!(W4_ABL & 4) && ((K) < NH - 1 || r4)) *reinterpret_cast<f32x4*>(sR + r_lds[K]) = hreg[K];
 
-  // ---- transform roles: wave i < 6 computes row i of V = B^T d B for (tile, channel quad) = (tid >> 1) & 31, tid & 1 ----
-  //   T[c] = k0 d[r0][c] + k1 d[r0+1][c] + k2 d[r0+2][c] + d[rl][c]   (rows of B^T; rows 0 and 5 have k1 = 0)
-  const bool tw = (W4_ABL & 2) ? false : wave < 6;
-  const int t_r0 = wave == 0 ? 0 : 1, t_rl = wave == 5 ? 5 : 4;
-  const float k0f = (wave == 1) ? -4.f : (wave == 3) ? -2.f : (wave == 4) ? 2.f : 4.f;
-  const float k1f = (wave == 0 || wave == 5) ? 0.f : (wave == 1 || wave == 2) ? -4.f : -1.f;
-  const float k2f = (wave == 0 || wave == 5) ? -5.f : (wave == 1) ? 1.f : (wave == 2) ? -1.f : (wave == 3) ? 2.f : -2.f;
+  // ---- transform roles: wave w computes row w (and, waves 0 / 1, row w + 4) of V = B^T d B for (tile, channel quad) =
+  // (tid >> 1) & 31, tid & 1:   T[c] = k0 d[r0][c] + k1 d[r0+1][c] + k2 d[r0+2][c] + d[rl][c]
+  //   row 0: r0 0, rl 4, k ( 4,  0, -5)   row 1: r0 1, rl 4, k (-4, -4,  1)   row 2: r0 1, rl 4, k ( 4, -4, -1)
+  //   row 3: r0 1, rl 4, k (-2, -1,  2)   row 4: r0 1, rl 4, k ( 2, -1, -2)   row 5: r0 1, rl 5, k ( 4,  0, -5)
+  const bool twB = (W4_ABL & 2) ? false : wave < 2;  // second row
+  const int t_tile = (tid >> 1) & 31;
+  int t_ty, t_tx;
+  w4_tile_xy<WIDE>(t_tile, t_ty, t_tx);
+  const int t_r0 = wave == 0 ? 0 : 1;
   // (readfirstlane: the coefficients must reach the packed fmas in scalar register pairs, not in per-lane selects)
 #define W4_UNI(X) __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (X))))
-  const float k0u = W4_UNI(k0f), k1u = W4_UNI(k1f), k2u = W4_UNI(k2f);
+  const float ka0 = W4_UNI(wave == 1 ? -4.f : wave == 3 ? -2.f : 4.f);
+  const float ka1 = W4_UNI(wave == 0 ? 0.f : wave == 3 ? -1.f : -4.f);
+  const float ka2 = W4_UNI(wave == 0 ? -5.f : wave == 1 ? 1.f : wave == 2 ? -1.f : 2.f);
+  const float kb0 = W4_UNI(wave == 0 ? 2.f : 4.f);
+  const float kb1 = W4_UNI(wave == 0 ? -1.f : 0.f);
+  const float kb2 = W4_UNI(wave == 0 ? -2.f : -5.f);
 #undef W4_UNI
-  const f32x2 tk0 = {k0u, k0u}, tk1 = {k1u, k1u}, tk2 = {k2u, k2u};
-  int t_ab[6], t_dst;  // byte addresses of the first row read | of the last row read << 16
-#define W4_ADDR_SETUP()                                                                                     \
-  {                                                                                                         \
-    asm volatile("" : "+v"(t_key));  /* opaque: the addresses below are recomputed, not kept live */        \
-    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                         \
-      const int p_ = (t_key + W4_THREADS * k) >> 1, r_ = p_ / HC, c_ = p_ - r_ * HC;                        \
-      r_lds[k] = (r_ * PITCH + (c_ & ~7) + ((c_ + ((r_ >> 2) & 3)) & 7)) * PK + (t_key & 1) * 4;            \
-    }                                                                                                       \
-    const int tt_ = (t_key >> 1) & 31;                                                                      \
-    int ty_, tx_;                                                                                           \
-    w4_tile_xy<WIDE>(tt_, ty_, tx_);                                                                        \
-    _Pragma("unroll") for (int c = 0; c < 6; ++c) {                                                         \
-      const int C = 4 * tx_ + c, Ra = 4 * ty_ + t_r0, Rb = 4 * ty_ + t_rl;                                  \
-      const int ta_ = (Ra * PITCH + (C & ~7) + ((C + ((Ra >> 2) & 3)) & 7)) * PK + (t_key & 1) * 4;         \
-      const int tb_ = (Rb * PITCH + (C & ~7) + ((C + ((Rb >> 2) & 3)) & 7)) * PK + (t_key & 1) * 4;         \
-      t_ab[c] = (ta_ * 4) | ((tb_ * 4) << 16);                                                              \
-    }                                                                                                       \
-    t_dst = (wave * 6 * W4_TILES + tt_) * PK + (((t_key & 1) ^ ((tt_ >> 3) & 1)) << 2);                     \
+  const f32x2 tka0 = {ka0, ka0}, tka1 = {ka1, ka1}, tka2 = {ka2, ka2}, tkb0 = {kb0, kb0}, tkb1 = {kb1, kb1}, tkb2 = {kb2, kb2};
+  // second row: byte offsets of its first / last raw row against the first row's (wave 0: rows 1.. / 4; wave 1: rows 1.. / 5)
+  const int dAb = wave == 0 ? ROWF * 4 : 0, dLb = wave == 1 ? ROWF * 4 : 0;
+  int t_ab[6];  // byte addresses of the first raw row read | of the last raw row read << 16
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const int C = 4 * t_tx + c, Ra = 4 * t_ty + t_r0, Rb = 4 * t_ty + 4;
+    const int ta_ = (Ra * PITCH + (C & ~7) + ((C + ((Ra >> 2) & 3)) & 7)) * PK + q2 * 4;
+    const int tb_ = (Rb * PITCH + (C & ~7) + ((C + ((Rb >> 2) & 3)) & 7)) * PK + q2 * 4;
+    t_ab[c] = (ta_ * 4) | ((tb_ * 4) << 16);
   }
-  W4_ADDR_SETUP()
+  const int t_dst = (wave * 6 * W4_TILES + t_tile) * PK + ((q2 ^ ((t_tile >> 3) & 1)) << 2);
+  constexpr int DST_B = 4 * 6 * W4_TILES * PK;  // row w + 4
 #define W4_LD(P) (*reinterpret_cast<const f32x4*>(P))
-#define W4_TR_RD(C)                                                                                         \
-  if (tw) {                                                                                                 \
-    const char* pa_ = reinterpret_cast<const char*>(smem) + (t_ab[C] & 0xffff);                            \
-    raw0 = W4_LD(pa_); raw1 = W4_LD(pa_ + ROWF * 4); raw2 = W4_LD(pa_ + 2 * ROWF * 4);                      \
-    raw3 = W4_LD(reinterpret_cast<const char*>(smem) + ((unsigned)t_ab[C] >> 16));                          \
+  // raw pixels of column C into register set X (two sets alternate: the reads are issued two MFMA slots ahead of their use)
+#define W4_TR_RD(X, C, DA, DL)                                                                              \
+  {                                                                                                         \
+    const char* pa_ = reinterpret_cast<const char*>(smem) + ((t_ab[C] & 0xffff) + (DA));                    \
+    X##0 = W4_LD(pa_); X##1 = W4_LD(pa_ + ROWF * 4); X##2 = W4_LD(pa_ + 2 * ROWF * 4);                      \
+    X##3 = W4_LD(reinterpret_cast<const char*>(smem) + (((unsigned)t_ab[C] >> 16) + (DL)));                 \
   }
-#define W4_TR_T(DST) if (tw) DST = pk4_fma_k(tk2, raw2, pk4_fma_k(tk1, raw1, pk4_fma_k(tk0, raw0, raw3)));
+#define W4_TR_T(DST, X, K0, K1, K2) DST = pk4_fma_k(K2, X##2, pk4_fma_k(K1, X##1, pk4_fma_k(K0, X##0, X##3)));
 #define W4_TR_WR(DSTBUF, J, V) *reinterpret_cast<f32x4*>((DSTBUF) + t_dst + (J) * W4_TILES * PK) = (V);
-  // whole transform of one stage, unsliced (prologue)
-#define W4_TRANSFORM(DSTBUF)                                                                                \
-  if (tw) {                                                                                                 \
+  // one V row, unsliced (prologue)
+#define W4_TRANSFORM_ROW(DSTBUF, DA, DL, K0, K1, K2)                                                        \
+  {                                                                                                         \
     f32x4 T_[6];                                                                                            \
     _Pragma("unroll") for (int c = 0; c < 6; ++c) {                                                         \
-      const char* pa_ = reinterpret_cast<const char*>(smem) + (t_ab[c] & 0xffff);                          \
-      const f32x4 d0 = W4_LD(pa_), d1 = W4_LD(pa_ + ROWF * 4), d2 = W4_LD(pa_ + 2 * ROWF * 4);              \
-      const f32x4 d3 = W4_LD(reinterpret_cast<const char*>(smem) + ((unsigned)t_ab[c] >> 16));              \
-      T_[c] = pk4_fma_k(tk2, d2, pk4_fma_k(tk1, d1, pk4_fma_k(tk0, d0, d3)));                               \
+      f32x4 x_0, x_1, x_2, x_3;                                                                             \
+      W4_TR_RD(x_, c, DA, DL)                                                                               \
+      W4_TR_T(T_[c], x_, K0, K1, K2)                                                                        \
     }                                                                                                       \
     const f32x4 ta_ = pk_fma_m44(T_[2], T_[4]), tb_ = pk_fma_m44(T_[1], T_[3]);                             \
     const f32x4 tc_ = pk4_sub(T_[4], T_[2]), te_ = pk4_sub(T_[3], T_[1]);                                   \
@@ -277,44 +306,70 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   __syncthreads();
 
   // ---- prologue: sA[0] = transformed stage 0, sR = raw halo of stage 1, halo loads of stage 2 in flight ----
+#define W4_HALO_ALL()                                                                                       \
+  W4_HALO_PAR() W4_HALO_BN(0) W4_HALO_BN(1) W4_HALO_BN(2) W4_HALO_BN(3) W4_HALO_BN(4)                       \
+  W4_HALO_WR(0) W4_HALO_WR(1) W4_HALO_WR(2) W4_HALO_WR(3) W4_HALO_WR(4)
   W4_ISSUE_HALO()
-  W4_HALO_PAR() W4_HALO_BN(0) W4_HALO_BN(1) W4_HALO_BN(2)
-  W4_HALO_WR(0) W4_HALO_WR(1) W4_HALO_WR(2)
+  W4_HALO_ALL()
   __syncthreads();
-  W4_TRANSFORM(sA)
+  W4_TRANSFORM_ROW(sA, 0, 0, tka0, tka1, tka2)
+  if (wave < 2) W4_TRANSFORM_ROW(sA + DST_B, dAb, dLb, tkb0, tkb1, tkb2)
   W4_ISSUE_HALO()
   __syncthreads();
-  W4_HALO_PAR() W4_HALO_BN(0) W4_HALO_BN(1) W4_HALO_BN(2)
-  W4_HALO_WR(0) W4_HALO_WR(1) W4_HALO_WR(2)
+  W4_HALO_ALL()
   W4_ISSUE_HALO()
   __syncthreads();
+#undef W4_HALO_ALL
 
-  f32x16 acc[9];
+  // accumulators 0..15: a[0:255] (w4_mfma_a / w4_acc_quad / w4_acc_clear); 16, 17: ordinary vector registers
+  w4_claim_agprs();
+  w4_acc_clear();
+  f32x16 acc16, acc17;
 #pragma unroll
-  for (int c = 0; c < 9; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  float stat_acc[4] = {0.f, 0.f, 0.f, 0.f};  // per register quad: lane li holds value (li >> 2) & 7 (sums 0..3, weighted sums 4..7)
+  for (int r = 0; r < 16; ++r) { acc16[r] = 0.f; acc17[r] = 0.f; }
+  float stat_s1 = 0.f, stat_s2 = 0.f;  // BatchNorm sums of this lane's output channel (over this lane half's tiles)
 
-  // ---- operand fetch: component CI (0..8) of this wave's quadrant = global component cbase + (CI / 3) * 6 + CI % 3 ----
-  const int cbase = 18 * qI + 3 * qJ;
+  // ---- operand fetch: component pair P (components 2P, 2P + 1 of this wave's 18 = global components 18 I + ..) ----
+  const int cbase = 18 * qI;
   const int in_off = (cbase * W4_TILES + li) * PK + ((lh ^ ((li >> 3) & 1)) << 2);
   const int w_voff = (lh * NB + nt * 32 + li) * 16;
-  f32x4 F0, F1, F2, Wt0, Wt1, Wt2;
-#define W4_CO(CI) (((CI) / 3) * 6 + (CI) % 3)
-#define W4_FETCH(S, BUF, CI, CHUNK)                                                                         \
+  f32x4 Fa0, Fb0, Wa0, Wb0, Fa1, Fb1, Wa1, Wb1, Fa2, Fb2, Wa2, Wb2;
+#define W4_FETCH(S, BUF, P, CHUNK)                                                                          \
   {                                                                                                         \
-    F##S = W4_LD((BUF) + in_off + W4_CO(CI) * W4_TILES * PK);                                               \
-    const int so_ = (((cob * nst + (CHUNK)) * W4_B_FLOATS) + (cbase + W4_CO(CI)) * 2 * NB * 4) * 4;         \
-    Wt##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_, 0));       \
+    Fa##S = W4_LD((BUF) + in_off + (2 * (P)) * W4_TILES * PK);                                              \
+    Fb##S = W4_LD((BUF) + in_off + (2 * (P) + 1) * W4_TILES * PK);                                          \
+    const int so_ = (((cob * nst + (CHUNK)) * W4_B_FLOATS) + (cbase + 2 * (P)) * 2 * NB * 4) * 4;           \
+    Wa##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_, 0));       \
+    Wb##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_ + 2 * NB * 16, 0)); \
   }
-#define W4_MM(CI, E, S)                                                                                     \
-  acc[CI] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wt##S[E], F##S[E], acc[CI], 0, 0, 0);                      \
+  // MFMA number I (0..7) of pair P: component 2P + (I & 1), k pair I >> 1
+#define W4_MM(P, I, S)                                                                                      \
+  if ((P) == 8) {                                                                                           \
+    if (((I) & 1) == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc16) : "v"(Fa##S[(I) >> 1]), "v"(Wa##S[(I) >> 1])); \
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc17) : "v"(Fb##S[(I) >> 1]), "v"(Wb##S[(I) >> 1]));            \
+  } else if (((I) & 1) == 0) w4_mfma_a<((P) < 8 ? 2 * (P) : 0)>(Fa##S[(I) >> 1], Wa##S[(I) >> 1]);           \
+  else w4_mfma_a<((P) < 8 ? 2 * (P) + 1 : 0)>(Fb##S[(I) >> 1], Wb##S[(I) >> 1]);                             \
   __builtin_amdgcn_sched_barrier(0);
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define W4_MM8(P, S) W4_MM(P, 0, S) W4_MM(P, 1, S) W4_MM(P, 2, S) W4_MM(P, 3, S) W4_MM(P, 4, S) W4_MM(P, 5, S) W4_MM(P, 6, S) W4_MM(P, 7, S)
 
   W4_FETCH(0, sA, 0, 0)
   W4_FETCH(1, sA, 1, 0)
+
+  // eleven transform slices of one V row behind MFMAs N .. N + 10 of pairs P0, P0 + 1 (column order 0, 2, 4, 1, 3, 5)
+#define W4_ROW_SLICES(COND, DSTBUF, DA, DL, K0, K1, K2, M0, M1, M2, M3, M4, M5, M6, M7, M8, M9, M10, M11)   \
+  M0  if (COND) W4_TR_RD(rx, 0, DA, DL) W4_FENCE();                                                         \
+  M1  if (COND) W4_TR_RD(ry, 2, DA, DL) W4_FENCE();                                                         \
+  M2  if (COND) { W4_TR_T(T0, rx, K0, K1, K2) W4_TR_RD(rx, 4, DA, DL) } W4_FENCE();                         \
+  M3  if (COND) { W4_TR_T(T2, ry, K0, K1, K2) W4_TR_RD(ry, 1, DA, DL) } W4_FENCE();                         \
+  M4  if (COND) { W4_TR_T(T4, rx, K0, K1, K2) W4_TR_RD(rx, 3, DA, DL) } W4_FENCE();                         \
+  M5  if (COND) { tc = pk4_sub(T4, T2); ta = pk_fma_m44(T2, T4); W4_TR_WR(DSTBUF, 0, pk_fma_p44(pk4_sub(T0, T2), tc)) } W4_FENCE(); \
+  M6  if (COND) { W4_TR_T(T1, ry, K0, K1, K2) W4_TR_RD(ry, 5, DA, DL) } W4_FENCE();                         \
+  M7  if (COND) { W4_TR_T(T3, rx, K0, K1, K2) } W4_FENCE();                                                 \
+  M8  if (COND) { W4_TR_T(T5, ry, K0, K1, K2) } W4_FENCE();                                                 \
+  M9  if (COND) { te = pk4_sub(T3, T1); tb = pk_fma_m44(T1, T3); W4_TR_WR(DSTBUF, 5, pk_fma_m44(te, pk4_sub(T5, T3))) } W4_FENCE(); \
+  M10 if (COND) { W4_TR_WR(DSTBUF, 1, pk4_add(ta, tb)) W4_TR_WR(DSTBUF, 2, pk4_sub(ta, tb)) } W4_FENCE();   \
+  M11 if (COND) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(te, tc)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(te, tc)) } W4_FENCE();
 
   int tile = tile0, chunk = 0;
   for (int g = 0; g < nstages; ++g) {
@@ -322,277 +377,269 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     const float* const cA = sA + buf * W4_A_FLOATS;
     float* const nA = sA + (buf ^ 1) * W4_A_FLOATS;
     const int nchunk = chunk + 1 == nst ? 0 : chunk + 1;
-    f32x4 raw0, raw1, raw2, raw3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;
-    // ---- first half: components 0..4 || transform of stage g+1 (column order 0, 2, 4, 1, 3, 5) ----
+    f32x4 rx0, rx1, rx2, rx3, ry0, ry1, ry2, ry3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;
+    // ---- first half: pairs 0..4 || transform of stage g+1 ----
     W4_FETCH(2, cA, 2, chunk)
     W4_FENCE();
-    W4_MM(0, 0, 0) W4_TR_RD(0) W4_FENCE();
-    W4_MM(0, 1, 0) W4_TR_T(T0) W4_TR_RD(2) W4_FENCE();
-    W4_MM(0, 2, 0) W4_TR_T(T2) W4_TR_RD(4) W4_FENCE();
-    W4_MM(0, 3, 0) W4_TR_T(T4) W4_TR_RD(1) W4_FENCE();
-    W4_FETCH(0, cA, 3, chunk)
-    W4_FENCE();
-    W4_MM(1, 0, 1)
-    if (tw) {
-      tc = pk4_sub(T4, T2);
-      ta = pk_fma_m44(T2, T4);
-      W4_TR_WR(nA, 0, pk_fma_p44(pk4_sub(T0, T2), tc))
-    }
-    W4_FENCE();
-    W4_MM(1, 1, 1) W4_TR_T(T1) W4_TR_RD(3) W4_FENCE();
-    W4_MM(1, 2, 1) W4_TR_T(T3) W4_TR_RD(5) W4_FENCE();
-    W4_MM(1, 3, 1) W4_TR_T(T5) W4_FENCE();
+    W4_ROW_SLICES(!(W4_ABL & 2), nA, 0, 0, tka0, tka1, tka2,
+                  W4_MM(0, 0, 0), W4_MM(0, 1, 0), W4_MM(0, 2, 0), W4_MM(0, 3, 0), W4_MM(0, 4, 0), W4_MM(0, 5, 0), W4_MM(0, 6, 0),
+                  W4_MM(0, 7, 0) W4_FETCH(0, cA, 3, chunk) W4_FENCE();, W4_MM(1, 0, 1), W4_MM(1, 1, 1), W4_MM(1, 2, 1), W4_MM(1, 3, 1))
+    W4_MM(1, 4, 1) W4_MM(1, 5, 1) W4_MM(1, 6, 1) W4_MM(1, 7, 1)
     W4_FETCH(1, cA, 4, chunk)
     W4_FENCE();
-    W4_MM(2, 0, 2)
-    if (tw) {
-      te = pk4_sub(T3, T1);
-      tb = pk_fma_m44(T1, T3);
-      W4_TR_WR(nA, 5, pk_fma_m44(te, pk4_sub(T5, T3)))
-    }
-    W4_FENCE();
-    W4_MM(2, 1, 2)
-    if (tw) { W4_TR_WR(nA, 1, pk4_add(ta, tb)) W4_TR_WR(nA, 2, pk4_sub(ta, tb)) }
-    W4_FENCE();
-    W4_MM(2, 2, 2)
-    if (tw) { W4_TR_WR(nA, 3, pk_fma_p24(te, tc)) W4_TR_WR(nA, 4, pk_fma_m24(te, tc)) }
-    W4_FENCE();
-    W4_MM(2, 3, 2)
-    W4_FETCH(2, cA, 5, chunk)
-    W4_FENCE();
-    W4_MM(3, 0, 0) W4_MM(3, 1, 0) W4_MM(3, 2, 0) W4_MM(3, 3, 0)
+    W4_ROW_SLICES(twB, nA + DST_B, dAb, dLb, tkb0, tkb1, tkb2,
+                  W4_MM(2, 0, 2), W4_MM(2, 1, 2), W4_MM(2, 2, 2), W4_MM(2, 3, 2), W4_MM(2, 4, 2), W4_MM(2, 5, 2), W4_MM(2, 6, 2),
+                  W4_MM(2, 7, 2) W4_FETCH(2, cA, 5, chunk) W4_FENCE();, W4_MM(3, 0, 0), W4_MM(3, 1, 0), W4_MM(3, 2, 0), W4_MM(3, 3, 0))
+    W4_MM(3, 4, 0) W4_MM(3, 5, 0) W4_MM(3, 6, 0) W4_MM(3, 7, 0)
     W4_FETCH(0, cA, 6, chunk)
     W4_FENCE();
-    W4_MM(4, 0, 1) W4_MM(4, 1, 1) W4_MM(4, 2, 1) W4_MM(4, 3, 1)
+    W4_MM8(4, 1)
     __syncthreads();  // barrier A: sA[~g&1] complete, sR free
-    // ---- second half: components 5..8 || halo (g+2): registers -> sR, halo loads (g+3) ----
+    // ---- second half: pairs 5..8 || halo (g+2): registers -> sR, halo loads (g+3) ----
     W4_FETCH(1, cA, 7, chunk)
     W4_FENCE();
     W4_MM(5, 0, 2) W4_HALO_PAR() W4_HALO_BN(0) W4_FENCE();
     W4_MM(5, 1, 2) W4_HALO_WR(0) W4_FENCE();
     W4_MM(5, 2, 2) W4_HALO_BN(1) W4_FENCE();
     W4_MM(5, 3, 2) W4_HALO_WR(1) W4_FENCE();
+    W4_MM(5, 4, 2) W4_HALO_BN(2) W4_FENCE();
+    W4_MM(5, 5, 2) W4_HALO_WR(2) W4_FENCE();
+    W4_MM(5, 6, 2) W4_HALO_BN(3) W4_FENCE();
+    W4_MM(5, 7, 2) W4_HALO_WR(3) W4_FENCE();
     W4_FETCH(2, cA, 8, chunk)
     W4_FENCE();
-    W4_MM(6, 0, 0) W4_HALO_BN(2) W4_FENCE();
-    W4_MM(6, 1, 0) W4_HALO_WR(2) W4_FENCE();
+    W4_MM(6, 0, 0) W4_HALO_BN(4) W4_FENCE();
+    W4_MM(6, 1, 0) W4_HALO_WR(4) W4_FENCE();
     W4_MM(6, 2, 0)
     W4_ISSUE_HALO()  // a full stage ahead of their use
     W4_FENCE();
-    W4_MM(6, 3, 0)
-    // first components of the next stage (after a tile epilogue they are fetched behind it: the epilogue needs the registers)
+    W4_MM(6, 3, 0) W4_MM(6, 4, 0) W4_MM(6, 5, 0) W4_MM(6, 6, 0) W4_MM(6, 7, 0)
+    // first pairs of the next stage (after a tile epilogue they are fetched behind it)
     if (nchunk != 0) W4_FETCH(0, nA, 0, nchunk)
     W4_FENCE();
-    W4_MM(7, 0, 1) W4_MM(7, 1, 1) W4_MM(7, 2, 1) W4_MM(7, 3, 1)
+    W4_MM8(7, 1)
     if (nchunk != 0) W4_FETCH(1, nA, 1, nchunk)
     W4_FENCE();
-    W4_MM(8, 0, 2) W4_MM(8, 1, 2) W4_MM(8, 2, 2) W4_MM(8, 3, 2)
+    W4_MM8(8, 2)
     __syncthreads();  // barrier B: sR = raw(g+2) complete, sA[g&1] consumed
 
     if (++chunk == nst) {
 #if W4_ABL & 1
-      if (tid == 1023) p_out[0] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][0] + acc[5][0] + acc[6][0] + acc[7][0] + acc[8][0];
+      if (tid == 1023) {
+        p_out[0] = w4_acc_rd<0>() + w4_acc_rd<17>() + w4_acc_rd<250>() + acc16[0] + acc17[1];
+      }
 #else
       // ---- tile epilogue ----
+      // accumulator element (lane (li, lh), register 4 gq + e) = output channel nt * 32 + li of tile e + 4 lh + 8 gq, i.e.
+      // (w4_tile_xy) tile row e (+ 4 (gq >> 1) for the 16x32 blocks), tile column 2 gq + lh (2 (gq & 1) + lh): everything
+      // but the lh part of a pixel address is wave-uniform (scalar offsets), and the 32 lanes of a half wave store 128
+      // contiguous bytes of one pixel
       const int tx_i = tile % a.tiles_x, t2 = tile / a.tiles_x;
       const int ty0 = (t2 % a.tiles_y) * TH, tx0 = tx_i * TW, n = t2 / a.tiles_y;
-      int e_ty, e_tx;
-      w4_tile_xy<WIDE>(li, e_ty, e_tx);
-      const int oy = ty0 + 4 * e_ty + 2 * qI, ox = tx0 + 4 * e_tx + 2 * qJ;  // this lane's 2x2 pixel block
-      const int co_l = nt * 32 + 4 * lh;                                     // + 8 gq + e: local channel of register 4 gq + e
+      const bool full = (ty0 + TH <= a.H) && (tx0 + TW <= a.W);
+      const int co = cob * NB + nt * 32 + li;
+      const bool co_ok = co < a.Cout;
+      const float bias_v = sBias[nt * 32 + li];
       const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
           p_out + (size_t)n * a.H * a.W * a.out_cs, 0, (unsigned)(a.H * a.W * a.out_cs) * 4u, 0x00020000);
-      const unsigned obase = (unsigned)(((oy * a.W + ox) * a.out_cs + a.out_co + cob * NB + co_l) * 4);
-      unsigned ooff[4];
+      // lane part of an output address (bytes): channel + the lh tile column (4 pixels); OOB for channels beyond Cout
+      unsigned lane_o[4], lane_t[4] = {OOB, OOB, OOB, OOB};  // + pixel column x
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const bool in_ = (oy + (p >> 1) < a.H) && (ox + (p & 1) < a.W);
-        ooff[p] = in_ ? obase + (unsigned)(((p >> 1) * a.W + (p & 1)) * a.out_cs) * 4u : OOB;
-      }
-      unsigned toff[4] = {OOB, OOB, OOB, OOB};
+      for (int x = 0; x < 4; ++x) lane_o[x] = co_ok ? (unsigned)(((4 * lh + x) * a.out_cs + a.out_co + co) * 4) : OOB;
+      const int row_u = ty0 + 2 * qI, col_u = tx0;  // + compile-time offsets of (gq, e, pixel)
       __amdgpu_buffer_rsrc_t rsrc_t = rsrc_out;
+      float bq0 = 0.f, bq1 = 0.f, bq2 = 0.f, bq3 = 0.f;
       if (IN_MODE == 0 && a.bnr_mode != 0) {
         rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_bnr) + (size_t)n * a.H * a.W * a.bnr_cs, 0,
                                                    (unsigned)(a.H * a.W * a.bnr_cs) * 4u, 0x00020000);
-        const unsigned tbase = (unsigned)(((oy * a.W + ox) * a.bnr_cs + a.bnr_co + cob * NB + co_l) * 4);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-          toff[p] = ooff[p] != OOB ? tbase + (unsigned)(((p >> 1) * a.W + (p & 1)) * a.bnr_cs) * 4u : OOB;
+        for (int x = 0; x < 4; ++x) lane_t[x] = co_ok ? (unsigned)(((4 * lh + x) * a.bnr_cs + a.bnr_co + co) * 4) : OOB;
+        bq0 = sS[nt * 32 + li]; bq1 = sS[NB + nt * 32 + li]; bq2 = sS[2 * NB + nt * 32 + li]; bq3 = sS[3 * NB + nt * 32 + li];
       }
-      // exchange slots: step 1 [wave][6 values][lane][4] in the consumed sA image (waves 0..5) / sXa (waves 6, 7),
-      // partner = the other column half (wave ^ 2); step 2 [wave][4 values][lane][4] in sX2, partner = the other row half
+      const float sg = (IN_MODE != 0 && p_pool != nullptr) ? sG[nt * 32 + li] : 1.f;
+      // row exchange [wave][8 values][lane][4], partner = the other row half (wave ^ 2); even register quads through the
+      // consumed sA image, odd ones through sX: one barrier per quad
       float* const sAc = sA + buf * W4_A_FLOATS;
-      float* const x1w = (wave < 6 ? sAc + wave * 1536 : sXa + (wave - 6) * 1536) + lane * 4;
-      const int pw = wave ^ 2;
-      const float* const x1r = (pw < 6 ? sAc + pw * 1536 : sXa + (pw - 6) * 1536) + lane * 4;
-      float* const x2w = sX2 + wave * 1024 + lane * 4;
-      const float* const x2r = sX2 + (wave ^ 4) * 1024 + lane * 4;
-      const bool tail = (cob + 1) * NB > a.Cout;  // block-uniform: channel quads that straddle Cout (operator tests only)
       mfma_results_guard();  // the output transform reads the accumulators from inline asm
+      auto round = [&](auto GQ) {
+        constexpr int gq = decltype(GQ)::value;
+        constexpr int g_row = WIDE ? 0 : 16 * (gq >> 1), g_col = WIDE ? 8 * gq : 8 * (gq & 1);  // pixel offsets of the quad's tiles
+        float* const xb = (gq & 1) ? sX : sAc;
+        float* const xw = xb + wave * 2048 + lane * 4;
+        const float* const xr = xb + (wave ^ 2) * 2048 + lane * 4;
+#define W4_Q(C) ((C) < 16 ? w4_acc_quad<((C) < 16 ? (C) : 0) * 16 + 4 * gq>()                                    \
+                  : (C) == 16 ? f32x4{acc16[4 * gq], acc16[4 * gq + 1], acc16[4 * gq + 2], acc16[4 * gq + 3]}  \
+                              : f32x4{acc17[4 * gq], acc17[4 * gq + 1], acc17[4 * gq + 2], acc17[4 * gq + 3]})
+        // R = M[I,:] A, one row of M at a time: R[.][0] = m0 + m1 + m2 + m3 + m4, [1] = m1 - m2 + 2 (m3 - m4), [2] = m1 + m2 +
+        // 4 (m3 + m4), [3] = m1 - m2 + 8 (m3 - m4) + m5
+#define W4_RR(R, O)                                                                                         \
+        f32x4 O[4];                                                                                         \
+        {                                                                                                   \
+          const f32x4 m1 = W4_Q(6 * (R) + 1), m2 = W4_Q(6 * (R) + 2), m3 = W4_Q(6 * (R) + 3), m4 = W4_Q(6 * (R) + 4);  \
+          const f32x4 s1 = pk4_add(m1, m2), d1 = pk4_sub(m1, m2), s2 = pk4_add(m3, m4), d2 = pk4_sub(m3, m4); \
+          O[0] = pk4_add(pk4_add(W4_Q(6 * (R)), s1), s2);                                                   \
+          O[1] = pk_fma_p24(d2, d1);                                                                        \
+          O[2] = pk_fma_p44(s2, s1);                                                                        \
+          O[3] = pk_fma_p44(pk4_add(d2, d2), pk4_add(d1, W4_Q(6 * (R) + 5)));                               \
+        }
+        // P = A^T[:,I] R, the same coefficient pattern along the rows, folded row by row (fewer live registers): I = 0 keeps
+        // {r0 + r1 + r2, r1 - r2}, sends {r1 + r2, r1 - r2}; I = 1 sends {r0 + r1, 2 (r0 - r1)}, keeps {4 (r0 + r1), 8 (r0 -
+        // r1) + r2}
+        f32x4 kp[2][4];
+        if (qI == 0) {
+          W4_RR(1, o1)
+          W4_RR(2, o2)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-#define W4_Q(C) (f32x4{acc[C][4 * gq], acc[C][4 * gq + 1], acc[C][4 * gq + 2], acc[C][4 * gq + 3]})
-        // step 1: Q = M[I,J] A[J,:]; J = 0: Q = {m0 + m1 + m2, m1 - m2 | m1 + m2, m1 - m2}, J = 1: {m0 + m1, 2 (m0 - m1) |
-        // 4 (m0 + m1), 8 (m0 - m1) + m2} (own quadrant columns m0..m2); kept half | sent half swap roles with J
-        f32x4 kq[3][2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const f32x4 m0 = W4_Q(3 * r), m1 = W4_Q(3 * r + 1), m2 = W4_Q(3 * r + 2);
-          if (qJ == 0) {
-            const f32x4 s = pk4_add(m1, m2), d = pk4_sub(m1, m2);
-            kq[r][0] = pk4_add(m0, s); kq[r][1] = d;
-            *reinterpret_cast<f32x4*>(x1w + (2 * r) * 256) = s;
-            *reinterpret_cast<f32x4*>(x1w + (2 * r + 1) * 256) = d;
-          } else {
-            const f32x4 s = pk4_add(m0, m1), d = pk4_sub(m0, m1);
-            *reinterpret_cast<f32x4*>(x1w + (2 * r) * 256) = s;
-            const f32x4 d2 = pk4_add(d, d);
-            *reinterpret_cast<f32x4*>(x1w + (2 * r + 1) * 256) = d2;
-            const f32x4 s2 = pk4_add(s, s);
-            kq[r][0] = pk4_add(s2, s2); kq[r][1] = pk_fma_p44(d2, m2);
+          for (int x = 0; x < 4; ++x) {
+            const f32x4 s = pk4_add(o1[x], o2[x]), d = pk4_sub(o1[x], o2[x]);
+            kp[0][x] = s; kp[1][x] = d;
+            *reinterpret_cast<f32x4*>(xw + x * 256) = s;
+            *reinterpret_cast<f32x4*>(xw + (4 + x) * 256) = d;
           }
-        }
-#undef W4_Q
+          W4_RR(0, o0)
 #pragma unroll
-        for (int c = 0; c < 9; ++c)
+          for (int x = 0; x < 4; ++x) kp[0][x] = pk4_add(kp[0][x], o0[x]);
+        } else {
+          W4_RR(0, o0)
+          W4_RR(1, o1)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[c][4 * gq + e] = 0.f;
-        // fused BatchNorm-backward sums: the layer-below tensor at this lane's four pixels (latency under the barriers)
-        f32x4 tq[4];
-        if (IN_MODE == 0 && a.bnr_mode != 0) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-            tq[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, toff[p], gq * 32, 0));
-        }
-        __syncthreads();
-        f32x4 rr[3][2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int x = 0; x < 2; ++x) rr[r][x] = pk4_add(kq[r][x], W4_LD(x1r + (2 * r + x) * 256));
-        // step 2: P = A^T[:,I] R, same coefficient pattern along the rows
-        f32x4 kp[2][2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          if (qI == 0) {
-            const f32x4 s = pk4_add(rr[1][x], rr[2][x]), d = pk4_sub(rr[1][x], rr[2][x]);
-            kp[0][x] = pk4_add(rr[0][x], s); kp[1][x] = d;
-            *reinterpret_cast<f32x4*>(x2w + x * 256) = s;
-            *reinterpret_cast<f32x4*>(x2w + (2 + x) * 256) = d;
-          } else {
-            const f32x4 s = pk4_add(rr[0][x], rr[1][x]), d = pk4_sub(rr[0][x], rr[1][x]);
-            *reinterpret_cast<f32x4*>(x2w + x * 256) = s;
+          for (int x = 0; x < 4; ++x) {
+            const f32x4 s = pk4_add(o0[x], o1[x]), d = pk4_sub(o0[x], o1[x]);
             const f32x4 d2 = pk4_add(d, d), s2 = pk4_add(s, s);
-            *reinterpret_cast<f32x4*>(x2w + (2 + x) * 256) = d2;
-            kp[0][x] = pk4_add(s2, s2); kp[1][x] = pk_fma_p44(d2, rr[2][x]);
+            *reinterpret_cast<f32x4*>(xw + x * 256) = s;
+            *reinterpret_cast<f32x4*>(xw + (4 + x) * 256) = d2;
+            kp[0][x] = pk4_add(s2, s2); kp[1][x] = d2;
           }
+          W4_RR(2, o2)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) kp[1][x] = pk_fma_p44(kp[1][x], o2[x]);
         }
-        __syncthreads();
-        const f32x4 bq = W4_LD(sBias + co_l + 8 * gq);
-        f32x4 s1a = {0.f, 0.f, 0.f, 0.f}, s2a = s1a, pm;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const f32x4 v = pk4_add(pk4_add(kp[p >> 1][p & 1], W4_LD(x2r + p * 256)), bq);
-          f32x4 s1v, xw;
-          if (IN_MODE == 0 && a.bnr_mode != 0) {
-            const f32x4 q0 = W4_LD(sS + co_l + 8 * gq), q1 = W4_LD(sS + NB + co_l + 8 * gq);
-            const f32x4 t = tq[p];
-            f32x4 dz, xh;
-            if (a.bnr_mode == 1) {
-              const f32x4 q2v = W4_LD(sS + 2 * NB + co_l + 8 * gq), q3 = W4_LD(sS + 3 * NB + co_l + 8 * gq);
-              const f32x4 z = pk4_fma(t, q0, q1);
-              xh = pk4_fma(t, q2v, q3);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? v[e] : 0.f;
-            } else {
-              xh = (t - q0) * q1;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) dz[e] = t[e] > 0.f ? v[e] : 0.f;
-            }
-            s1v = dz * (ooff[p] != OOB ? 1.f : 0.f); xw = xh;
-          } else {
-            s1v = v * (ooff[p] != OOB ? 1.f : 0.f); xw = v;
+#undef W4_RR
+#undef W4_Q
+        // scalar (wave-uniform) byte offset of pixel P = yy * 4 + x of tile row E of this quad, for a tensor of CS channels
+        // (the pixel column rides in the lane offset, the pixel row in the scalar offset: two scalar registers per tensor
+        // instead of 32 hoisted offsets per round)
+        const unsigned so_o = (unsigned)(((row_u + g_row) * a.W + col_u + g_col) * a.out_cs) * 4u, sr_o = (unsigned)(a.W * a.out_cs) * 4u;
+        const unsigned so_t = (unsigned)(((row_u + g_row) * a.W + col_u + g_col) * a.bnr_cs) * 4u, sr_t = (unsigned)(a.W * a.bnr_cs) * 4u;
+#define W4_SOFF(E, P, T) (so_##T + (unsigned)(4 * (E) + ((P) >> 2)) * sr_##T)
+        // lane offset of pixel column x, OOB where the pixel is outside the map (partial tile blocks only)
+#define W4_VOFF(T, E, P) ((FULL || (4 * (E) + ((P) >> 2) < lim_y && ((P) & 3) < lim_x)) ? lane_##T[(P) & 3] : OOB)
+        const int lim_y = a.H - row_u - g_row, lim_x = a.W - col_u - g_col - 4 * lh;
+        // the second half of the round, straight-line per (bnr mode, full tile block): both are block-uniform
+        auto fin = [&](auto MODE_, auto FULL_) {
+          constexpr int MODE = decltype(MODE_)::value;
+          constexpr bool FULL = decltype(FULL_)::value;
+          // fused BatchNorm-backward sums: the layer-below tensor at this lane's 8 x 4 (pixel, tile) positions (first pixel
+          // row before the barrier, second row while the first is finished)
+          f32x4 tq[8];
+#define W4_TQ(P0)                                                                                           \
+          if (MODE != 0) {                                                                                  \
+            _Pragma("unroll") for (int p = (P0); p < (P0) + 4; ++p)                                         \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                   \
+              tq[p][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, W4_VOFF(t, e, p), W4_SOFF(e, p, t), 0)); \
           }
-          s1a = pk4_add(s1a, s1v);
-          s2a = pk4_fma(s1v, xw, s2a);
+          W4_TQ(0)
+          if (!(W4_ABL & 32)) __syncthreads();
+          W4_TQ(4)
+#undef W4_TQ
+          f32x4 pm[2];
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            f32x4 v = pk4_add(kp[p >> 2][p & 3], W4_LD(xr + p * 256));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned vo = W4_VOFF(o, e, p);
+              const float ve = v[e] + bias_v;
+              v[e] = ve;
+              float s1e, xe;
+              if (MODE == 1) {
+                const float t = tq[p][e];
+                s1e = fmaf(t, bq0, bq1) > 0.f ? ve : 0.f; xe = fmaf(t, bq2, bq3);
+              } else if (MODE == 2) {
+                const float t = tq[p][e];
+                s1e = t > 0.f ? ve : 0.f; xe = (t - bq0) * bq1;
+              } else {
+                s1e = ve; xe = ve;
+              }
+              if (!FULL) s1e = vo != OOB ? s1e : 0.f;
+              stat_s1 += s1e;
+              stat_s2 = fmaf(s1e, xe, stat_s2);
+              if (!(W4_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ve), rsrc_out, vo, W4_SOFF(e, p, o), 0);
+            }
+            if (IN_MODE != 0 && p_pool != nullptr) {
+              // pixels (row, 0..1) and (row, 2..3) of the 2x4 block are two pooling windows (ConvArgs::pool_out)
+              const f32x4 sv = v * sg;
+              const int wnd = (p >> 1) & 1;
+              if (p < 4 && (p & 1) == 0) pm[wnd] = sv;
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pm[wnd][e] = fmaxf(pm[wnd][e], sv[e]);
+              }
+            }
+          }
           if (IN_MODE != 0 && p_pool != nullptr) {
-            const f32x4 sv = v * W4_LD(sG + co_l + 8 * gq);
-            if (p == 0) pm = sv;
-            else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) pm[e] = fmaxf(pm[e], sv[e]);
-            }
-          }
-          if (!tail) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc_out,
-                                                   ooff[p], gq * 32, 0);
-          } else {
-            const int nvalid = a.Cout - (cob * NB + co_l + 8 * gq);
-            if (ooff[p] != OOB && nvalid > 0) {
-              float* q = p_out + (size_t)n * a.H * a.W * a.out_cs + (ooff[p] >> 2) + 8 * gq;
-              q[0] = v[0];
-              if (nvalid > 1) q[1] = v[1];
-              if (nvalid > 2) q[2] = v[2];
-              if (nvalid > 3) q[3] = v[3];
-            }
-          }
-        }
-        if (IN_MODE != 0 && p_pool != nullptr) {
-          // the 2x2 block IS a pooling window (ConvArgs::pool_out: max for gamma >= 0, min for gamma < 0)
-          if (oy < a.H && ox < a.W) {
-            const f32x4 m = pm * W4_LD(sG + co_l + 8 * gq);
-            *reinterpret_cast<f32x4*>(p_pool + ((size_t)(n * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * a.Cout + cob * NB +
-                                      co_l + 8 * gq) = m;
-          }
-        }
-        if (p_stats != nullptr) {
-          // reduce-scatter of the 8 values over the 32 tile lanes (never across lh): 4 + 2 + 1 exchanges, then two plain
-          // butterfly steps; lane li ends with value ((li >> 4) & 1) * 4 + ((li >> 3) & 1) * 2 + ((li >> 2) & 1)
-          float st[8] = {s1a[0], s1a[1], s1a[2], s1a[3], s2a[0], s2a[1], s2a[2], s2a[3]};
+            for (int wnd = 0; wnd < 2; ++wnd)
 #pragma unroll
-          for (int w = 16, nv = 4; w >= 4; w >>= 1, nv >>= 1) {
-            const bool up = (li & w) != 0;
-#pragma unroll
-            for (int i = 0; i < nv; ++i) {
-              const float snd = up ? st[i] : st[i + nv];
-              const float kp_ = up ? st[i + nv] : st[i];
-              st[i] = kp_ + __shfl_xor(snd, w);
-            }
+              for (int e = 0; e < 4; ++e) {
+                const int py = (row_u + g_row + 4 * e) >> 1, px = ((col_u + g_col + 4 * lh) >> 1) + wnd;
+                if (co_ok && 2 * py < a.H && 2 * px < a.W)
+                  p_pool[((size_t)(n * (a.H >> 1) + py) * (a.W >> 1) + px) * a.Cout + co] = pm[wnd][e] * sg;
+              }
           }
-          st[0] += __shfl_xor(st[0], 2);
-          st[0] += __shfl_xor(st[0], 1);
-          stat_acc[gq] += st[0];
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        const int mode = IN_MODE == 0 ? a.bnr_mode : 0;
+        if (full) {
+          if (mode == 0) fin(std::integral_constant<int, 0>{}, T_{});
+          else if (mode == 1) fin(std::integral_constant<int, 1>{}, T_{});
+          else fin(std::integral_constant<int, 2>{}, T_{});
+        } else {
+          if (mode == 0) fin(std::integral_constant<int, 0>{}, F_{});
+          else if (mode == 1) fin(std::integral_constant<int, 1>{}, F_{});
+          else fin(std::integral_constant<int, 2>{}, F_{});
         }
-      }
+#undef W4_SOFF
+#undef W4_VOFF
+      };
+      round(std::integral_constant<int, 0>{});
+      round(std::integral_constant<int, 1>{});
+      round(std::integral_constant<int, 2>{});
+      round(std::integral_constant<int, 3>{});
+      if (!(W4_ABL & 64)) w4_acc_clear();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc16[r] = 0.f; acc17[r] = 0.f; }
 #endif
       chunk = 0;
       tile += per_cob;
-      W4_ADDR_SETUP()
       W4_FETCH(0, nA, 0, 0)
       W4_FETCH(1, nA, 1, 0)
     }
   }
 #undef W4_ISSUE_HALO
-#undef W4_ADDR_SETUP
 #undef W4_HALO_PAR
 #undef W4_HALO_BN
 #undef W4_HALO_WR
 #undef W4_TR_RD
 #undef W4_TR_T
 #undef W4_TR_WR
-#undef W4_TRANSFORM
+#undef W4_TRANSFORM_ROW
+#undef W4_ROW_SLICES
 #undef W4_FETCH
 #undef W4_MM
+#undef W4_MM8
 #undef W4_FENCE
-#undef W4_CO
 
-  if (p_stats != nullptr && (li & 3) == 0) {
-    const int which = (li >> 4) & 1, e = 2 * ((li >> 3) & 1) + ((li >> 2) & 1);
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int co = cob * NB + nt * 32 + 4 * lh + 8 * gq + e;
-      if (co < a.Cout)
-        unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)stat_acc[gq]);
+  if (p_stats != nullptr) {
+    // the two lane halves hold the same channel (different tiles)
+    stat_s1 += __shfl_xor(stat_s1, 32);
+    stat_s2 += __shfl_xor(stat_s2, 32);
+    const int co = cob * NB + nt * 32 + li;
+    if (lh == 0 && co < a.Cout) {
+      double* q = p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + co;
+      unsafeAtomicAdd(q, (double)stat_s1);
+      unsafeAtomicAdd(q + a.Cout, (double)stat_s2);
     }
   }
 }
