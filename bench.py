@@ -41,9 +41,10 @@ GFLOP_PER_PAIR = {"SuperPointNet_gauss2": 77.98, "SuperPointNet_gauss2_ssmall": 
 PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3 line)
 # kernels of the 3x3 forward + data-gradient launches per --conv-algo (algo 1 runs the small 30x40 maps on the p2 kernel)
-DOMINANT_KERNEL = {0: ("conv_mfma_kernel<3",), 1: ("conv_wino_pipe_kernel", "conv_wino_p2_kernel"), 2: ("conv_wino_kernel",),
+DOMINANT_KERNEL = {0: ("conv_mfma_kernel<3",), 1: ("conv_wino4_kernel", "conv_wino_pipe_kernel", "conv_wino_p2_kernel"), 2: ("conv_wino_kernel",),
                    3: ("conv_wino_bf16_kernel",), 5: ("conv_wino_pipe_kernel",), 6: ("conv_wino_p2_kernel",),
-                   7: ("conv_wino_bf16_kernel",), 8: ("conv_wino_bf16_kernel",)}
+                   7: ("conv_wino_bf16_kernel",), 8: ("conv_wino_bf16_kernel",),
+                   9: ("conv_wino_pipe_kernel", "conv_wino_p2_kernel"), 10: ("conv_wino4_kernel", "conv_wino_p2_kernel")}
 
 
 def cpu_baseline(arch, H, W, batch=32, steps=3):
@@ -80,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8],
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8, 9, 10],
                     help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
                          "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
                          "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
@@ -308,22 +309,27 @@ def main():
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
                 peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
                 # Winograd executes 16 of 36 multiplies; the split-bf16 mode three bf16 MFMAs per product block
-                exec_ratio = 1.0 if args.conv_algo == 0 else {7: 3.0, 8: 2.0}.get(args.conv_algo, 1.0) * 16.0 / 36.0
+                # (the library counts the multiplies each launch executes: 1/4 of the algorithmic ones for F(4x4,3x3), 16/36 for
+                # F(2x2,3x3))
+                exec_ratio = {7: 3.0, 8: 2.0}.get(args.conv_algo, 1.0) * pr["exec_flops"] / pr["flops"]
                 out["roofline"] = {"bound": "mfma", "kernel": "%s (3x3 forward + data-gradient, %s on v_mfma_f32_32x32x2_f32)"
                                                               % (" + ".join(DOMINANT_KERNEL[args.conv_algo]), "direct implicit GEMM"
-                                                                 if args.conv_algo == 0 else "Winograd F(2x2,3x3)"),
+                                                                 if args.conv_algo == 0 else "Winograd F(4x4,3x3) on the "
+                                                                 "240x320 / 120x160 maps, F(2x2,3x3) below" if args.conv_algo == 1
+                                                                 else "Winograd F(4x4,3x3)" if args.conv_algo == 10
+                                                                 else "Winograd F(2x2,3x3)"),
                                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4),
                                    "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / time; Winograd executes "
-                                           "16/36 of them on the matrix cores, so frac may exceed 1: executed_frac is the "
-                                           "hardware fraction of the matrix-core peak",
+                                           "16/36 (F(2x2,3x3)) or 1/4 (F(4x4,3x3)) of them on the matrix cores, so frac may "
+                                           "exceed 1: executed_frac is the hardware fraction of the matrix-core peak",
                                    "executed_tflops": round(ach * exec_ratio, 2),
                                    "executed_frac": round(ach * exec_ratio / peak, 4),
                                    "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_note,
                                    "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                    "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4),
                                    "flops_per_launch_avg": round(pr["flops"] / pr["launches"] / 1e9, 3)}
-            if world == 1 and args.conv_algo in (0, 1, 2, 5, 6):
+            if world == 1 and args.conv_algo in (0, 1, 2, 5, 6, 9, 10):
                 # second family, outside the timed region: the 3x3 weight-gradient launches (3 extra steps)
                 eng.profile_enable("conv3x3_wgrad")
                 run(3, args.warmup + args.steps)

@@ -162,6 +162,9 @@ enum { SSP_PROF_NONE = 0, SSP_PROF_CONV3X3_FWD = 1, SSP_PROF_CONV3X3_DGRAD = 2, 
        SSP_PROF_CONV_BIG_FWD = 4, SSP_PROF_CONV3X3_ALL = 5 /* fwd + dgrad launches of conv_mfma_kernel */ };
 int ssp_profile_enable(ssp_handle* h, int family);
 int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops, double* bytes);
+/* FLOPs the tagged launches since ssp_profile_enable EXECUTED on the matrix cores (ssp_profile_read's `flops` are the
+ * algorithmic, direct-convolution FLOPs): x 1/4 for a Winograd F(4x4,3x3) launch, x 16/36 for F(2x2,3x3), x 1 otherwise. */
+int ssp_profile_read_executed(ssp_handle* h, double* executed_flops);
 
 /* ---- operator-level entry points (used by the unit parity tests; same kernels as above) ---- */
 /* 3x3 / 1x1 convolution, NHWC fp32, stride 1, "same" padding, weights OIHW (reference layout).
@@ -292,9 +295,12 @@ int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float
                           int h, int w, int c, int cs, int relu, int pool, void* stream);
 
 /* Algorithm of the 3x3 forward / data-gradient convolutions whose input channels are a multiple of 16 (process-wide
- * DEFAULT, copied into a handle at ssp_create; takes effect at the next forward, which re-packs the weights): 1 (default) = Winograd F(2x2,3x3) on the fp32 matrix
- * cores (2.25x fewer multiplies, fp32 throughout, results within ~1e-6 relative of the direct form; software-pipelined
- * kernel whose weight fragments come straight from L2), 5 = the same pipeline with the weights staged through LDS,
+ * DEFAULT, copied into a handle at ssp_create; takes effect at the next forward, which re-packs the weights): 1 (default) = Winograd on the fp32 matrix
+ * cores, fp32 throughout: F(4x4,3x3) (4x fewer multiplies, conv_wino4_kernel) on maps of >= 120x160 pixels with >= 4 tile
+ * blocks per CU, F(2x2,3x3) (2.25x fewer, software-pipelined kernel whose weight fragments come straight from L2)
+ * elsewhere; results within ~2e-6 / ~3e-7 relative of the direct form, 9 = F(2x2,3x3) only (the default of rounds 1-2),
+ * 10 = F(4x4,3x3) wherever legal (tests), 5 = the F(2x2,3x3) pipeline with the weights staged through LDS, 6 = its
+ * two-workgroups-per-CU variant everywhere,
  * 2 = Winograd without the software pipeline (both for A/B measurements), 0 = direct implicit GEMM,
  * 3 = EXPERIMENTAL reduced precision: the Winograd kernels with bf16 matrix-core operands (fp32 storage, transforms,
  * accumulation and master weights); outputs within ~4e-3 relative RMS of fp32, gradients of the first layers up to

@@ -40,7 +40,8 @@ static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks
 // bf16 Winograd modes: number of bf16 parts per operand element.  3: one part everywhere; 7: hi + lo everywhere;
 // 8 (mixed): hi + lo in the FORWARD convolutions (the activations every later layer and the ReLU gates depend on), one
 // part in the data-gradient and weight-gradient kernels (unbiased 2^-9 noise on the gradients, like any bf16 training)
-// fp32 pipelined Winograd family: 1 (default), 9 = 1 + F(4x4,3x3) on the large maps (conv_uses_w4), 10 = F(4x4,3x3) wherever legal
+// fp32 pipelined Winograd family: 1 (default: F(4x4,3x3) on the large maps - conv_uses_w4 -, F(2x2,3x3) elsewhere), 9 = F(2x2,3x3)
+// only (the default of rounds 1-2), 10 = F(4x4,3x3) wherever legal
 static inline bool pipe_algo() { return g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10; }
 static inline bool bf16_algo() { return g_conv_algo == 3 || g_conv_algo == 7 || g_conv_algo == 8; }
 static inline int bf16_parts(bool backward) { return g_conv_algo == 7 || (g_conv_algo == 8 && !backward) ? 2 : 1; }
@@ -149,7 +150,7 @@ struct ssp_handle {
   int prof_family;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used;
-  double prof_flops, prof_bytes;
+  double prof_flops, prof_bytes, prof_exec_flops;
   int64_t prof_launches;
   int n_cu;
 };
@@ -320,13 +321,14 @@ static size_t carve(ssp_handle* h, void* base) {
 // ------------------------------------------------------------------------------------------------
 struct ProfScope {
   ssp_handle* h; hipStream_t st; bool on;
-  ProfScope(ssp_handle* h_, int family, hipStream_t s, double flops, double bytes) : h(h_), st(s), on(false) {
+  ProfScope(ssp_handle* h_, int family, hipStream_t s, double flops, double bytes, double exec_flops = -1.0) : h(h_), st(s), on(false) {
     const bool match = h && family > 0 && (h->prof_family == family ||
         (h->prof_family == SSP_PROF_CONV3X3_ALL && (family == SSP_PROF_CONV3X3_FWD || family == SSP_PROF_CONV3X3_DGRAD)));
     if (match && h->ev_used + 2 <= h->ev_pool.size()) {
       on = true;
       (void)hipEventRecord(h->ev_pool[h->ev_used], st);
       h->prof_flops += flops; h->prof_bytes += bytes; h->prof_launches += 1;
+      h->prof_exec_flops += exec_flops >= 0.0 ? exec_flops : flops;
     }
   }
   ~ProfScope() {
@@ -400,6 +402,7 @@ struct ConvCall {
   // honoured by the pipelined Winograd kernel only - conv_writes_pool() tells the caller
   float* pool_out[2] = {nullptr, nullptr};
   const float* pool_gamma = nullptr;
+  bool allow_w4 = true;  // false: wpk is an F(2x2,3x3) image whatever the shape (the concatenated data-gradient weights of the heads)
 };
 static bool can_fuse_bnr(const ConvCall& c) {
   return c.wino && (pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6 || bf16_algo()) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
@@ -477,9 +480,10 @@ static void w4_geometry(int H, int W, bool& wide, int& tiles_y, int& tiles_x) {
   tiles_y = cdiv(H, wide ? 16 : 32); tiles_x = cdiv(W, wide ? 32 : 16);
 }
 // does a 3x3 launch of this shape run F(4x4,3x3)?  Decided from the shape alone: the weight images are packed with the
-// same predicate (launch_pack / pack_all).  Algorithm 9: maps of >= 120x160 pixels with >= 4 tile blocks per CU.
+// same predicate (launch_pack / pack_all).  Default algorithm: maps of >= 120x160 pixels with >= 4 tile blocks per CU
+// (measured 1.2x / 1.12x faster than F(2x2,3x3) on the 64 -> 64 layers at 240x320 / 120x160, slower at 60x80).
 static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int cin, int cout) {
-  if (g_conv_algo != 9 && g_conv_algo != 10) return false;
+  if (g_conv_algo != 1 && g_conv_algo != 10) return false;
   if (cin % 8 != 0) return false;
   if (g_conv_algo == 10) return true;
   bool wide; int ty, tx;
@@ -488,7 +492,7 @@ static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int
   return (long)H * W >= 120L * 160L && items >= 4L * (h ? h->n_cu : 256);
 }
 static bool conv_uses_w4(const ssp_handle* h, const ConvCall& c) {
-  return c.wino && c.ks == 3 && c.in_mode != 2 && w4_eligible(h, c.nprob, c.N, c.H, c.W, c.cin, c.cout);
+  return c.wino && c.allow_w4 && c.ks == 3 && c.in_mode != 2 && w4_eligible(h, c.nprob, c.N, c.H, c.W, c.cin, c.cout);
 }
 static bool conv_uses_p2(const ssp_handle* h, const ConvCall& c) {
   if (!c.wino) return false;
@@ -565,7 +569,8 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   if (prof_family == SSP_PROF_CONV3X3_FWD && h && h->prof_family == SSP_PROF_CONV_BIG_FWD && c.H * c.W >= 240 * 320 &&
       c.cin == 64)
     fam = SSP_PROF_CONV_BIG_FWD;
-  ProfScope ps(h, fam, st, flops, bytes);
+  // multiplies executed on the matrix cores: 36 per 16 outputs x 9 taps (F(4x4,3x3)), 16 per 4 x 9 (F(2x2,3x3))
+  ProfScope ps(h, fam, st, flops, bytes, flops * (w4 ? 0.25 : c.wino ? 16.0 / 36.0 : 1.0));
   if (w4) {  // Winograd F(4x4,3x3), one 8-wave workgroup per CU
     if (c.in_mode == 0) return wide4 ? launch_wino4_t<0, true>(a, nblocks, st) : launch_wino4_t<0, false>(a, nblocks, st);
     return wide4 ? launch_wino4_t<1, true>(a, nblocks, st) : launch_wino4_t<1, false>(a, nblocks, st);
@@ -832,7 +837,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   build_layers(h);
   h->bound = false;
   h->ws_bytes = carve(h, nullptr);
-  h->prof_family = 0; h->ev_used = 0; h->prof_flops = h->prof_bytes = 0; h->prof_launches = 0;
+  h->prof_family = 0; h->ev_used = 0; h->prof_flops = h->prof_bytes = h->prof_exec_flops = 0; h->prof_launches = 0;
   h->n_cu = 256;
   int dev = 0;
   hipDeviceProp_t prop;
@@ -876,7 +881,7 @@ int ssp_zero_grad(ssp_handle* h, void* stream) {
 
 int ssp_profile_enable(ssp_handle* h, int family) {
   if (!h) return fail(-1, "null handle");
-  h->prof_family = family; h->ev_used = 0; h->prof_flops = h->prof_bytes = 0; h->prof_launches = 0;
+  h->prof_family = family; h->ev_used = 0; h->prof_flops = h->prof_bytes = h->prof_exec_flops = 0; h->prof_launches = 0;
   if (family != 0 && h->ev_pool.empty()) {
     h->ev_pool.resize(8192);
     for (auto& e : h->ev_pool) HIPCHK(hipEventCreate(&e));
@@ -897,6 +902,12 @@ int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops
   if (launches) *launches = h->prof_launches;
   if (flops) *flops = h->prof_flops;
   if (bytes) *bytes = h->prof_bytes;
+  return 0;
+}
+
+int ssp_profile_read_executed(ssp_handle* h, double* executed_flops) {
+  if (!h || !executed_flops) return fail(-1, "null handle / pointer");
+  *executed_flops = h->prof_exec_flops;
   return 0;
 }
 
@@ -1290,6 +1301,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     }
     ConvCall c;
     c.in = gQ[0]; c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = h->wpk_heads_bwd; c.bias = nullptr; c.wino = wino_ok(3, hcs);
+    c.allow_w4 = false;
     c.out = gP[0]; c.out_cs = 128; c.out_co = 0; c.cout = 128; c.in_scale = nullptr; c.in_shift = nullptr;
     c.stats = nullptr; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.nchunks = 16 * h->nheads; c.ncob = 2;
     c.backward = true;
@@ -1975,8 +1987,8 @@ int ssp_set_conv_algo(int algo) {
   if (algo < 0 || algo > 10 || algo == 4)
     return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
                     "operands), 5 (Winograd, pipelined, weights staged through LDS), 6 (Winograd, two 4-wave workgroups per CU) "
-                    ", 7 (Winograd, split-bf16 hi + lo operands), 8 (forward split-bf16, backward bf16), 9 (1 + Winograd "
-                    "F(4x4,3x3) on the large maps) or 10 (F(4x4,3x3) wherever legal)");
+                    ", 7 (Winograd, split-bf16 hi + lo operands), 8 (forward split-bf16, backward bf16), 9 (Winograd "
+                    "F(2x2,3x3) only: algorithm 1 without F(4x4,3x3) on the large maps) or 10 (F(4x4,3x3) wherever legal)");
   g_default_conv_algo = algo;
   return 0;
 }

@@ -60,7 +60,7 @@ _lib = None
 
 EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ssp_bn_channel_count",
            "ssp_bn_layer_count", "ssp_workspace_bytes", "ssp_bind", "ssp_forward", "ssp_backward", "ssp_zero_grad",
-           "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read",
+           "ssp_pair_step", "ssp_adam_step", "ssp_sample_indices", "ssp_profile_enable", "ssp_profile_read", "ssp_profile_read_executed",
            "ssp_op_conv", "ssp_op_conv_wgrad", "ssp_op_labels", "ssp_op_sparse_loss", "ssp_op_bn_bwd", "ssp_op_bn_bwd_strided",
            "ssp_debug_buffer", "ssp_debug_conv_knobs", "ssp_set_conv_algo", "ssp_op_warp_image", "ssp_op_erode", "ssp_op_warp_labels",
            "ssp_export_workspace_bytes", "ssp_export_max_points", "ssp_export_points", "ssp_op_homoadapt_views",
@@ -113,6 +113,7 @@ def load_library(path=None):
     lib.ssp_profile_enable.argtypes = [vp, i]
     lib.ssp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
+    lib.ssp_profile_read_executed.argtypes = [vp, C.POINTER(C.c_double)]
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -541,7 +542,9 @@ class Engine:
     def profile_read(self):
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         _check(self.lib.ssp_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
-        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        ex = C.c_double()
+        _check(self.lib.ssp_profile_read_executed(self.h, C.byref(ex)))
+        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value, "exec_flops": ex.value}
 
 
 # ---- optimizer state in torch.optim.Adam's wire format ----

@@ -232,3 +232,35 @@ def test_scaled_homographies_and_device_warp_order_match_the_reference_ops():
                 rows.append(f32(t + a[r, 2]))     # fma(p2, 1, t) == t + p2 rounded once
             wx, wy = (rows[0] / rows[2]).float(), (rows[1] / rows[2]).float()
             assert torch.equal(wx, ref_xy[:, 0]) and torch.equal(wy, ref_xy[:, 1]), n
+
+
+def test_f4x4_kernel_accumulators_are_private_to_its_inline_asm(tmp_path):
+    """conv_wino4_kernel keeps 16 accumulators in FIXED accumulation registers a[0:255] that only its inline asm touches
+    (conv_wino4.hip.h).  The compiler does not know they are occupied: if register pressure ever made it park a value in
+    an accumulation register (or spill), the convolution would be silently wrong.  Compile the kernel to ISA and check:
+    every accumulation-register access is one of the asm forms (bracket syntax a[N]), nothing goes to scratch, and the
+    kernel descriptor reserves all 256 accumulation registers behind the vector registers."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semantic-superpoint_amd", "csrc")
+    tu = tmp_path / "tu.hip"
+    tu.write_text('#include <hip/hip_runtime.h>\n#include "conv_wino4.hip.h"\n' + "".join(
+        "template __global__ void sspk::conv_wino4_kernel<%d, %s>(const sspk::ConvArgs);\n" % (m, w)
+        for m in (0, 1) for w in ("true", "false")))
+    out = tmp_path / "tu.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-munsafe-fp-atomics",
+                    "-I", csrc, str(tu), "-o", str(out)], check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN4sspk17conv_wino4_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M)
+    assert len(kernels) == 4
+    for name, body in kernels:
+        assert not re.search(r"v_accvgpr_(write|read)_b32 [^\n]*\ba\d+\b", body), name   # compiler-allocated aN
+        assert "v_accvgpr_mov" not in body and "scratch_" not in body, name
+        assert len(re.findall(r"v_mfma_f32_32x32x2_f32 a\[", body)) == 64, name          # 16 accumulators x 4 k pairs
+        assert len(re.findall(r"v_mfma_f32_32x32x2_f32 v\[", body)) == 8, name           # the pair in vector registers
+    for accum, nxt in zip(re.findall(r"\.amdhsa_accum_offset (\d+)", text), re.findall(r"\.amdhsa_next_free_vgpr (\d+)", text)):
+        if int(nxt) > 256:  # the four conv_wino4_kernel instances
+            assert int(nxt) == int(accum) + 256

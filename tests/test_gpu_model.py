@@ -115,7 +115,7 @@ def test_backward_vs_oracle(arch):
         _grad_close(mine, r, k)
 
 
-@pytest.mark.parametrize("algo", [1, 0])
+@pytest.mark.parametrize("algo", [1, 0, 10])
 def test_backward_with_zero_gamma_in_pooled_layers(algo):
     """The pooled layers' BatchNorm-backward sums are taken from the pooled activation (xhat = (z - beta)/gamma) - inside
     the data-gradient conv's epilogue (default algorithm) or by bn_bwd_reduce_pool_kernel (algo 0); channels with
@@ -128,10 +128,20 @@ def test_backward_with_zero_gamma_in_pooled_layers(algo):
         L.set_conv_algo(1)
 
 
-def test_negative_gamma_in_pooled_layers():
-    """Pooled layers: the producing conv writes the per-channel MAX of every 2x2 window of its raw output for gamma >= 0
+@pytest.mark.parametrize("algo", [1, 10])
+def test_negative_gamma_in_pooled_layers(algo):
+    """(conv algorithm 1: conv_wino_pipe_kernel writes the pooled raw copy; 10: conv_wino4_kernel.)  Pooled layers: the producing conv writes the per-channel MAX of every 2x2 window of its raw output for gamma >= 0
     and the MIN for gamma < 0 (maxpool(relu(bn(y))) = relu(bn(pool(y))) with that choice); consumers apply BatchNorm + ReLU
     on load.  Half of the pooled layers' gammas negative: forward outputs and every gradient against the oracle."""
+    from semantic_superpoint_amd import lib as L
+    L.set_conv_algo(algo)
+    try:
+        _negative_gamma_case()
+    finally:
+        L.set_conv_algo(1)
+
+
+def _negative_gamma_case():
     arch, B, H, W = ARCHS[0], 2, 32, 64
     sd = C.init_state_dict(arch, seed=11)
     rs = np.random.RandomState(6)
@@ -401,10 +411,11 @@ def test_odd_shapes_forward_and_step(B, H, W):
         _grad_close(gd[k].cpu(), tr.last_grads[k], k, l2=3e-2, mx=0.2)
 
 
-@pytest.mark.parametrize("algo", [0, 2, 5, 6])
+@pytest.mark.parametrize("algo", [0, 2, 5, 6, 10])
 def test_conv_algorithms_agree_on_a_training_step(algo):
-    """ssp_set_conv_algo: the direct implicit-GEMM kernels (0), the un-pipelined Winograd kernels (2) and the pipelined
-    kernel with LDS-staged weights (5) give the
+    """ssp_set_conv_algo: the direct implicit-GEMM kernels (0), the un-pipelined Winograd kernels (2), the pipelined
+    kernel with LDS-staged weights (5) and Winograd F(4x4,3x3) on every 3x3 layer (10: pooled raw outputs, fused
+    BatchNorm-backward sums and partial tile blocks of conv_wino4_kernel) give the
     losses and gradients of the default (pipelined Winograd, 1) on the same step (fp32 everywhere; only the summation
     order / the Winograd transforms differ)."""
     from semantic_superpoint_amd import lib as L
