@@ -101,10 +101,13 @@ __device__ __forceinline__ float w4_acc_rd() {
 }
 template <int R>
 __device__ __forceinline__ f32x4 w4_acc_quad() { return f32x4{w4_acc_rd<R>(), w4_acc_rd<R + 1>(), w4_acc_rd<R + 2>(), w4_acc_rd<R + 3>()}; }
+// all 16 accumulators = 0, except accumulator 7 = component (1,1) of the I = 0 waves, which starts at `c11` (the conv bias:
+// (1,1) enters all sixteen outputs of a tile with coefficient +1, which saves the bias adds of the epilogue)
 template <int R = 0>
-__device__ __forceinline__ void w4_acc_clear() {
-  asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(R));
-  if constexpr (R + 1 < 256) w4_acc_clear<R + 1>();
+__device__ __forceinline__ void w4_acc_clear(float c11) {
+  if constexpr (R / 16 == 7) asm volatile("v_accvgpr_write_b32 a[%0], %1" : : "n"(R), "v"(c11));
+  else asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(R));
+  if constexpr (R + 1 < 256) w4_acc_clear<R + 1>(c11);
 }
 __device__ __forceinline__ void w4_claim_agprs() { asm volatile("" : : : "a0", "a255"); }
 
@@ -323,11 +326,12 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 
   // accumulators 0..15: a[0:255] (w4_mfma_a / w4_acc_quad / w4_acc_clear); 16, 17: ordinary vector registers
   w4_claim_agprs();
-  w4_acc_clear();
+  const float c11 = qI == 0 ? sBias[nt * 32 + li] : 0.f;  // (after the parameter barrier above)
+  w4_acc_clear(c11);
   f32x16 acc16, acc17;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc16[r] = 0.f; acc17[r] = 0.f; }
-  float stat_s1 = 0.f, stat_s2 = 0.f;  // BatchNorm sums of this lane's output channel (over this lane half's tiles)
+  f32x2 stat_s1 = {0.f, 0.f}, stat_s2 = {0.f, 0.f};  // BatchNorm sums of this lane's output channel (two partial sums each)
 
   // ---- operand fetch: component pair P (components 2P, 2P + 1 of this wave's 18 = global components 18 I + ..) ----
   const int cbase = 18 * qI;
@@ -439,7 +443,6 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
       const bool full = (ty0 + TH <= a.H) && (tx0 + TW <= a.W);
       const int co = cob * NB + nt * 32 + li;
       const bool co_ok = co < a.Cout;
-      const float bias_v = sBias[nt * 32 + li];
       const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
           p_out + (size_t)n * a.H * a.W * a.out_cs, 0, (unsigned)(a.H * a.W * a.out_cs) * 4u, 0x00020000);
       // lane part of an output address (bytes): channel + the lh tile column (4 pixels); OOB for channels beyond Cout
@@ -545,27 +548,24 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
           f32x4 pm[2];
 #pragma unroll
           for (int p = 0; p < 8; ++p) {
-            f32x4 v = pk4_add(kp[p >> 2][p & 3], W4_LD(xr + p * 256));
+            const f32x4 v = pk4_add(kp[p >> 2][p & 3], W4_LD(xr + p * 256));  // (the bias rides in component (1,1))
+            f32x4 s1v = v, xv = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const unsigned vo = W4_VOFF(o, e, p);
-              const float ve = v[e] + bias_v;
-              v[e] = ve;
-              float s1e, xe;
               if (MODE == 1) {
                 const float t = tq[p][e];
-                s1e = fmaf(t, bq0, bq1) > 0.f ? ve : 0.f; xe = fmaf(t, bq2, bq3);
+                s1v[e] = fmaf(t, bq0, bq1) > 0.f ? v[e] : 0.f; xv[e] = fmaf(t, bq2, bq3);
               } else if (MODE == 2) {
                 const float t = tq[p][e];
-                s1e = t > 0.f ? ve : 0.f; xe = (t - bq0) * bq1;
-              } else {
-                s1e = ve; xe = ve;
+                s1v[e] = t > 0.f ? v[e] : 0.f; xv[e] = (t - bq0) * bq1;
               }
-              if (!FULL) s1e = vo != OOB ? s1e : 0.f;
-              stat_s1 += s1e;
-              stat_s2 = fmaf(s1e, xe, stat_s2);
+              if (!FULL) s1v[e] = vo != OOB ? s1v[e] : 0.f;
+              const float ve = v[e];  // (__builtin_bit_cast of the element expression v[e] itself reads element 0)
               if (!(W4_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ve), rsrc_out, vo, W4_SOFF(e, p, o), 0);
             }
+            stat_s1 = pk_add(pk_add(stat_s1, lo2(s1v)), hi2(s1v));
+            stat_s2 = pk_fma(hi2(s1v), hi2(xv), pk_fma(lo2(s1v), lo2(xv), stat_s2));
             if (IN_MODE != 0 && p_pool != nullptr) {
               // pixels (row, 0..1) and (row, 2..3) of the 2x4 block are two pooling windows (ConvArgs::pool_out)
               const f32x4 sv = v * sg;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
       round(std::integral_constant<int, 1>{});
       round(std::integral_constant<int, 2>{});
       round(std::integral_constant<int, 3>{});
-      if (!(W4_ABL & 64)) w4_acc_clear();
+      if (!(W4_ABL & 64)) w4_acc_clear(c11);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc16[r] = 0.f; acc17[r] = 0.f; }
 #endif
@@ -633,13 +633,14 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 
   if (p_stats != nullptr) {
     // the two lane halves hold the same channel (different tiles)
-    stat_s1 += __shfl_xor(stat_s1, 32);
-    stat_s2 += __shfl_xor(stat_s2, 32);
+    float t1 = stat_s1[0] + stat_s1[1], t2 = stat_s2[0] + stat_s2[1];
+    t1 += __shfl_xor(t1, 32);
+    t2 += __shfl_xor(t2, 32);
     const int co = cob * NB + nt * 32 + li;
     if (lh == 0 && co < a.Cout) {
       double* q = p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + co;
-      unsafeAtomicAdd(q, (double)stat_s1);
-      unsafeAtomicAdd(q + a.Cout, (double)stat_s2);
+      unsafeAtomicAdd(q, (double)t1);
+      unsafeAtomicAdd(q + a.Cout, (double)t2);
     }
   }
 }

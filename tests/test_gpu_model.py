@@ -123,7 +123,9 @@ def test_backward_with_zero_gamma_in_pooled_layers(algo):
     from semantic_superpoint_amd import lib as L
     L.set_conv_algo(algo)
     try:
-        _zero_gamma_case()
+        # (F(4x4,3x3) on every layer: six times the rounding noise of F(2x2,3x3), so a few more ReLU gates of the deeper
+        # layers flip against the oracle and move the gradient that ARRIVES at the zeroed channels - 2e-4 observed)
+        _zero_gamma_case(exact_tol=1e-3 if algo == 10 else 1e-4)
     finally:
         L.set_conv_algo(1)
 
@@ -169,7 +171,7 @@ def _negative_gamma_case():
             _grad_close(gd[k].cpu(), tsd[k].grad, k, l2=5e-2, mx=0.1)
 
 
-def _zero_gamma_case():
+def _zero_gamma_case(exact_tol=1e-4):
     arch, B, H, W = ARCHS[0], 2, 32, 48
     sd = C.init_state_dict(arch, seed=9)
     rs = np.random.RandomState(5)
@@ -197,7 +199,7 @@ def _zero_gamma_case():
         for k in (layer + ".weight", layer + ".bias"):
             r, mine = tsd[k].grad, gd[k].cpu()
             # the zeroed channels exactly (no ReLU flips possible there: z == beta), the rest statistically
-            assert (mine[zeroed] - r[zeroed]).abs().max() <= 1e-4 * float(r.abs().max()), k
+            assert (mine[zeroed] - r[zeroed]).abs().max() <= exact_tol * float(r.abs().max()), k
             _grad_close(mine, r, k, l2=5e-2, mx=0.1)
     for k in ("inc.conv.conv.3.weight", "inc.conv.conv.0.weight", "down1.mpconv.1.conv.0.weight"):
         _grad_close(gd[k].cpu(), tsd[k].grad, k, l2=5e-2, mx=0.1)
