@@ -296,7 +296,7 @@ int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float
 
 /* Algorithm of the 3x3 forward / data-gradient convolutions whose input channels are a multiple of 16 (process-wide
  * DEFAULT, copied into a handle at ssp_create; takes effect at the next forward, which re-packs the weights): 1 (default) = Winograd on the fp32 matrix
- * cores, fp32 throughout: F(4x4,3x3) (4x fewer multiplies, conv_wino4_kernel) on maps of >= 120x160 pixels with >= 4 tile
+ * cores, fp32 throughout: F(4x4,3x3) (4x fewer multiplies, conv_wino4_kernel) on maps of >= 60x80 pixels with >= 4 tile
  * blocks per CU, F(2x2,3x3) (2.25x fewer, software-pipelined kernel whose weight fragments come straight from L2)
  * elsewhere; results within ~2e-6 / ~3e-7 relative of the direct form, 9 = F(2x2,3x3) only (the default of rounds 1-2),
  * 10 = F(4x4,3x3) wherever legal (tests), 5 = the F(2x2,3x3) pipeline with the weights staged through LDS, 6 = its

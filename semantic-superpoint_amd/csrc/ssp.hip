@@ -480,8 +480,9 @@ static void w4_geometry(int H, int W, bool& wide, int& tiles_y, int& tiles_x) {
   tiles_y = cdiv(H, wide ? 16 : 32); tiles_x = cdiv(W, wide ? 32 : 16);
 }
 // does a 3x3 launch of this shape run F(4x4,3x3)?  Decided from the shape alone: the weight images are packed with the
-// same predicate (launch_pack / pack_all).  Default algorithm: maps of >= 120x160 pixels with >= 4 tile blocks per CU
-// (measured 1.2x / 1.12x faster than F(2x2,3x3) on the 64 -> 64 layers at 240x320 / 120x160, slower at 60x80).
+// same predicate (launch_pack / pack_all).  Default algorithm: maps of >= 60x80 pixels with >= 4 tile blocks per CU
+// (measured 1.2x / 1.15x faster than F(2x2,3x3) on the 64 -> 64 layers at 240x320 / 120x160; the 60x80 layers of a
+// 32-pair step gain 0.7 % of the step, the 30x40 ones nothing).
 static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int cin, int cout) {
   if (g_conv_algo != 1 && g_conv_algo != 10) return false;
   if (cin % 8 != 0) return false;
@@ -489,7 +490,8 @@ static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int
   bool wide; int ty, tx;
   w4_geometry(H, W, wide, ty, tx);
   const long items = (long)nprob * N * ty * tx * cdiv(cout, NB);
-  return (long)H * W >= 120L * 160L && items >= 4L * (h ? h->n_cu : 256);
+  static const long min_px = getenv("SSP_W4_MIN_PIXELS") ? atol(getenv("SSP_W4_MIN_PIXELS")) : 60L * 80L;  // (perf-debug override)
+  return (long)H * W >= min_px && items >= 4L * (h ? h->n_cu : 256);
 }
 static bool conv_uses_w4(const ssp_handle* h, const ConvCall& c) {
   return c.wino && c.allow_w4 && c.ks == 3 && c.in_mode != 2 && w4_eligible(h, c.nprob, c.N, c.H, c.W, c.cin, c.cout);
