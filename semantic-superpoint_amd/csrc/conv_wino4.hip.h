@@ -42,7 +42,9 @@
 
 #ifndef W4_ABL
 #define W4_ABL 0  // compile-time perf ablation: 1 no tile epilogue, 2 no transform, 4 no halo staging, 16 no output stores,
-                  // 32 no barrier in the epilogue rounds, 64 accumulators not cleared
+                  // 32 no barrier in the epilogue rounds, 64 accumulators not cleared, 128 no barriers in the stage loop, 256 no
+                  // weight loads, 512 no fragment reads from LDS in the stage loop, 1024 halo loads confined to 64 KB (cache
+                  // hits); results: profiles/r02_w4_ablation.txt
 #endif
 
 namespace sspk {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     }                                                                                                       \
     h_chunk = ld_chunk;                                                                                     \
     _Pragma("unroll") for (int k = 0; k < NH; ++k)                                                          \
-      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, hoff[k], ld_chunk * PK * 4, 0)); \
+      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (W4_ABL & 1024) ? (hoff[k] & 0xFFFFu) : hoff[k], ld_chunk * PK * 4, 0)); \
     if (++ld_chunk == nst) { ld_chunk = 0; ld_tile += per_cob; }                                            \
   }
   f32x4 psc, psh;
@@ -340,11 +342,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   f32x4 Fa0, Fb0, Wa0, Wb0, Fa1, Fb1, Wa1, Wb1, Fa2, Fb2, Wa2, Wb2;
 #define W4_FETCH(S, BUF, P, CHUNK)                                                                          \
   {                                                                                                         \
+    if (!(W4_ABL & 512) || g < 0) {                                                                         \
     Fa##S = W4_LD((BUF) + in_off + (2 * (P)) * W4_TILES * PK);                                              \
-    Fb##S = W4_LD((BUF) + in_off + (2 * (P) + 1) * W4_TILES * PK);                                          \
+    Fb##S = W4_LD((BUF) + in_off + (2 * (P) + 1) * W4_TILES * PK); }                                        \
     const int so_ = (((cob * nst + (CHUNK)) * W4_B_FLOATS) + (cbase + 2 * (P)) * 2 * NB * 4) * 4;           \
+    if (!(W4_ABL & 256) || g < 0) {                                                                         \
     Wa##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_, 0));       \
-    Wb##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_ + 2 * NB * 16, 0)); \
+    Wb##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_ + 2 * NB * 16, 0)); } \
   }
   // MFMA number I (0..7) of pair P: component 2P + (I & 1), k pair I >> 1
 #define W4_MM(P, I, S)                                                                                      \
@@ -357,8 +361,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define W4_MM8(P, S) W4_MM(P, 0, S) W4_MM(P, 1, S) W4_MM(P, 2, S) W4_MM(P, 3, S) W4_MM(P, 4, S) W4_MM(P, 5, S) W4_MM(P, 6, S) W4_MM(P, 7, S)
 
+  int g = -1;  // (the ablation macros test g < 0 = prologue)
   W4_FETCH(0, sA, 0, 0)
   W4_FETCH(1, sA, 1, 0)
+  if (W4_ABL & (256 | 512)) { W4_FETCH(2, sA, 2, 0) }
 
   // eleven transform slices of one V row behind MFMAs N .. N + 10 of pairs P0, P0 + 1 (column order 0, 2, 4, 1, 3, 5)
 #define W4_ROW_SLICES(COND, DSTBUF, DA, DL, K0, K1, K2, M0, M1, M2, M3, M4, M5, M6, M7, M8, M9, M10, M11)   \
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   M11 if (COND) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(te, tc)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(te, tc)) } W4_FENCE();
 
   int tile = tile0, chunk = 0;
-  for (int g = 0; g < nstages; ++g) {
+  for (g = 0; g < nstages; ++g) {
     const int buf = g & 1;
     const float* const cA = sA + buf * W4_A_FLOATS;
     float* const nA = sA + (buf ^ 1) * W4_A_FLOATS;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_FETCH(0, cA, 6, chunk)
     W4_FENCE();
     W4_MM8(4, 1)
-    __syncthreads();  // barrier A: sA[~g&1] complete, sR free
+    if (!(W4_ABL & 128)) __syncthreads();  // barrier A: sA[~g&1] complete, sR free
     // ---- second half: pairs 5..8 || halo (g+2): registers -> sR, halo loads (g+3) ----
     W4_FETCH(1, cA, 7, chunk)
     W4_FENCE();
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     if (nchunk != 0) W4_FETCH(1, nA, 1, nchunk)
     W4_FENCE();
     W4_MM8(8, 2)
-    __syncthreads();  // barrier B: sR = raw(g+2) complete, sA[g&1] consumed
+    if (!(W4_ABL & 128)) __syncthreads();  // barrier B: sR = raw(g+2) complete, sA[g&1] consumed
 
     if (++chunk == nst) {
 #if W4_ABL & 1

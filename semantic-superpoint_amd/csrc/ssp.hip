@@ -491,7 +491,8 @@ static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int
   w4_geometry(H, W, wide, ty, tx);
   const long items = (long)nprob * N * ty * tx * cdiv(cout, NB);
   static const long min_px = getenv("SSP_W4_MIN_PIXELS") ? atol(getenv("SSP_W4_MIN_PIXELS")) : 60L * 80L;  // (perf-debug override)
-  return (long)H * W >= min_px && items >= 4L * (h ? h->n_cu : 256);
+  static const long min_items_x4 = getenv("SSP_W4_MIN_ITEMS_X4") ? atol(getenv("SSP_W4_MIN_ITEMS_X4")) : 16L;  // (quarter blocks per CU)
+  return (long)H * W >= min_px && 4L * items >= min_items_x4 * (h ? h->n_cu : 256);
 }
 static bool conv_uses_w4(const ssp_handle* h, const ConvCall& c) {
   return c.wino && c.allow_w4 && c.ks == 3 && c.in_mode != 2 && w4_eligible(h, c.nprob, c.N, c.H, c.W, c.cin, c.cout);
