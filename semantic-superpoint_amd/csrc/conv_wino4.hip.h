@@ -10,7 +10,7 @@
 // kernel, 144 + 112 registers per wave) every per-thread cost - operand sets, halo registers, LDS addresses - is paid
 // twice and the kernel spilled 60-80 registers; four waves of 512 registers hold everything, and the output transform
 // along the columns of M stays inside a wave.  One wave per SIMD hides no latency by itself: every operand is fetched
-// two component pairs (16 MFMAs) ahead and the transform reads its raw pixels two MFMA slots ahead.
+// one component pair (8 MFMAs) ahead and the transform reads its raw pixels one MFMA slot ahead.
 //
 // Operand roles as in conv_wino_p2_kernel: A = weight fragment (32 output channels x 2 k), B = transformed input fragment
 // (2 k x 32 tiles); an accumulator lane holds ONE tile (column = lane & 31) and 16 output channels (row = (reg & 3) + 8 (reg
@@ -24,7 +24,8 @@
 //   second half: pairs 5..8  ||  halo (g+2): registers -> sR (BatchNorm + ReLU of the producer), halo loads (g+3)
 //   barrier B
 //
-// Three rotating operand sets (9 = 3 x 3 pairs per stage: the same rotation in every stage): weights from L2 (the packed
+// Three rotating operand sets (9 = 3 x 3 pairs per stage: the same rotation in every stage; two of them live at a time):
+// weights from L2 (the packed
 // image [cob][chunk8][component][h][64][4] IS the fragment layout), inputs from LDS.
 //
 // Epilogue Y = A^T M A (4x6 . 6x6 . 6x4) per register quad: R = M[I,:] A (3 x 4) inside the wave, P = A^T[:,I] R (4 x 4
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   const int t_dst = (wave * 6 * W4_TILES + t_tile) * PK + ((q2 ^ ((t_tile >> 3) & 1)) << 2);
   constexpr int DST_B = 4 * 6 * W4_TILES * PK;  // row w + 4
 #define W4_LD(P) (*reinterpret_cast<const f32x4*>(P))
-  // raw pixels of column C into register set X (two sets alternate: the reads are issued two MFMA slots ahead of their use)
+  // raw pixels of column C into register set X, one MFMA slot ahead of their use (a second set, two slots ahead, and operands
+  // fetched two component pairs ahead instead of one measured the same: 0.745 vs 0.745 ms on one box)
 #define W4_TR_RD(X, C, DA, DL)                                                                              \
   {                                                                                                         \
     const char* pa_ = reinterpret_cast<const char*>(smem) + ((t_ab[C] & 0xffff) + (DA));                    \
@@ -330,9 +332,16 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   w4_claim_agprs();
   const float c11 = qI == 0 ? sBias[nt * 32 + li] : 0.f;  // (after the parameter barrier above)
   w4_acc_clear(c11);
+  // (cleared from an opaque zero: under register pressure hipcc materialised the constant in an accumulation register - a0 -
+  // and copied it around, i.e. into accumulators it does not know about)
   f32x16 acc16, acc17;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc16[r] = 0.f; acc17[r] = 0.f; }
+#define W4_CLEAR_V()                                                                                        \
+  {                                                                                                         \
+    float z_;                                                                                               \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z_));                                                             \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc16[r] = z_; acc17[r] = z_; }                        \
+  }
+  W4_CLEAR_V()
   f32x2 stat_s1 = {0.f, 0.f}, stat_s2 = {0.f, 0.f};  // BatchNorm sums of this lane's output channel (two partial sums each)
 
   // ---- operand fetch: component pair P (components 2P, 2P + 1 of this wave's 18 = global components 18 I + ..) ----
@@ -363,23 +372,22 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 
   int g = -1;  // (the ablation macros test g < 0 = prologue)
   W4_FETCH(0, sA, 0, 0)
-  W4_FETCH(1, sA, 1, 0)
-  if (W4_ABL & (256 | 512)) { W4_FETCH(2, sA, 2, 0) }
+  if (W4_ABL & (256 | 512)) { W4_FETCH(1, sA, 1, 0) W4_FETCH(2, sA, 2, 0) }
 
   // eleven transform slices of one V row behind MFMAs N .. N + 10 of pairs P0, P0 + 1 (column order 0, 2, 4, 1, 3, 5)
 #define W4_ROW_SLICES(COND, DSTBUF, DA, DL, K0, K1, K2, M0, M1, M2, M3, M4, M5, M6, M7, M8, M9, M10, M11)   \
   M0  if (COND) W4_TR_RD(rx, 0, DA, DL) W4_FENCE();                                                         \
-  M1  if (COND) W4_TR_RD(ry, 2, DA, DL) W4_FENCE();                                                         \
-  M2  if (COND) { W4_TR_T(T0, rx, K0, K1, K2) W4_TR_RD(rx, 4, DA, DL) } W4_FENCE();                         \
-  M3  if (COND) { W4_TR_T(T2, ry, K0, K1, K2) W4_TR_RD(ry, 1, DA, DL) } W4_FENCE();                         \
-  M4  if (COND) { W4_TR_T(T4, rx, K0, K1, K2) W4_TR_RD(rx, 3, DA, DL) } W4_FENCE();                         \
-  M5  if (COND) { tc = pk4_sub(T4, T2); ta = pk_fma_m44(T2, T4); W4_TR_WR(DSTBUF, 0, pk_fma_p44(pk4_sub(T0, T2), tc)) } W4_FENCE(); \
-  M6  if (COND) { W4_TR_T(T1, ry, K0, K1, K2) W4_TR_RD(ry, 5, DA, DL) } W4_FENCE();                         \
-  M7  if (COND) { W4_TR_T(T3, rx, K0, K1, K2) } W4_FENCE();                                                 \
-  M8  if (COND) { W4_TR_T(T5, ry, K0, K1, K2) } W4_FENCE();                                                 \
-  M9  if (COND) { te = pk4_sub(T3, T1); tb = pk_fma_m44(T1, T3); W4_TR_WR(DSTBUF, 5, pk_fma_m44(te, pk4_sub(T5, T3))) } W4_FENCE(); \
-  M10 if (COND) { W4_TR_WR(DSTBUF, 1, pk4_add(ta, tb)) W4_TR_WR(DSTBUF, 2, pk4_sub(ta, tb)) } W4_FENCE();   \
-  M11 if (COND) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(te, tc)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(te, tc)) } W4_FENCE();
+  M1  if (COND) { W4_TR_T(T0, rx, K0, K1, K2) W4_TR_RD(rx, 2, DA, DL) } W4_FENCE();                         \
+  M2  if (COND) { W4_TR_T(T2, rx, K0, K1, K2) W4_TR_RD(rx, 4, DA, DL) } W4_FENCE();                         \
+  M3  if (COND) { W4_TR_T(T4, rx, K0, K1, K2) W4_TR_RD(rx, 1, DA, DL) } W4_FENCE();                         \
+  M4  if (COND) { tc = pk4_sub(T4, T2); ta = pk_fma_m44(T2, T4); W4_TR_WR(DSTBUF, 0, pk_fma_p44(pk4_sub(T0, T2), tc)) } W4_FENCE(); \
+  M5  if (COND) { W4_TR_T(T1, rx, K0, K1, K2) W4_TR_RD(rx, 3, DA, DL) } W4_FENCE();                         \
+  M6  if (COND) { W4_TR_T(T3, rx, K0, K1, K2) W4_TR_RD(rx, 5, DA, DL) } W4_FENCE();                         \
+  M7  if (COND) { W4_TR_T(T5, rx, K0, K1, K2) } W4_FENCE();                                                 \
+  M8  if (COND) { te = pk4_sub(T3, T1); tb = pk_fma_m44(T1, T3); W4_TR_WR(DSTBUF, 5, pk_fma_m44(te, pk4_sub(T5, T3))) } W4_FENCE(); \
+  M9  if (COND) { W4_TR_WR(DSTBUF, 1, pk4_add(ta, tb)) W4_TR_WR(DSTBUF, 2, pk4_sub(ta, tb)) } W4_FENCE();   \
+  M10 if (COND) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(te, tc)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(te, tc)) } W4_FENCE(); \
+  M11 W4_FENCE();
 
   int tile = tile0, chunk = 0;
   for (g = 0; g < nstages; ++g) {
@@ -387,26 +395,26 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     const float* const cA = sA + buf * W4_A_FLOATS;
     float* const nA = sA + (buf ^ 1) * W4_A_FLOATS;
     const int nchunk = chunk + 1 == nst ? 0 : chunk + 1;
-    f32x4 rx0, rx1, rx2, rx3, ry0, ry1, ry2, ry3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;
+    f32x4 rx0, rx1, rx2, rx3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;
     // ---- first half: pairs 0..4 || transform of stage g+1 ----
-    W4_FETCH(2, cA, 2, chunk)
+    W4_FETCH(1, cA, 1, chunk)
     W4_FENCE();
     W4_ROW_SLICES(!(W4_ABL & 2), nA, 0, 0, tka0, tka1, tka2,
                   W4_MM(0, 0, 0), W4_MM(0, 1, 0), W4_MM(0, 2, 0), W4_MM(0, 3, 0), W4_MM(0, 4, 0), W4_MM(0, 5, 0), W4_MM(0, 6, 0),
-                  W4_MM(0, 7, 0) W4_FETCH(0, cA, 3, chunk) W4_FENCE();, W4_MM(1, 0, 1), W4_MM(1, 1, 1), W4_MM(1, 2, 1), W4_MM(1, 3, 1))
+                  W4_MM(0, 7, 0) W4_FETCH(2, cA, 2, chunk) W4_FENCE();, W4_MM(1, 0, 1), W4_MM(1, 1, 1), W4_MM(1, 2, 1), W4_MM(1, 3, 1))
     W4_MM(1, 4, 1) W4_MM(1, 5, 1) W4_MM(1, 6, 1) W4_MM(1, 7, 1)
-    W4_FETCH(1, cA, 4, chunk)
+    W4_FETCH(0, cA, 3, chunk)
     W4_FENCE();
     W4_ROW_SLICES(twB, nA + DST_B, dAb, dLb, tkb0, tkb1, tkb2,
                   W4_MM(2, 0, 2), W4_MM(2, 1, 2), W4_MM(2, 2, 2), W4_MM(2, 3, 2), W4_MM(2, 4, 2), W4_MM(2, 5, 2), W4_MM(2, 6, 2),
-                  W4_MM(2, 7, 2) W4_FETCH(2, cA, 5, chunk) W4_FENCE();, W4_MM(3, 0, 0), W4_MM(3, 1, 0), W4_MM(3, 2, 0), W4_MM(3, 3, 0))
+                  W4_MM(2, 7, 2) W4_FETCH(1, cA, 4, chunk) W4_FENCE();, W4_MM(3, 0, 0), W4_MM(3, 1, 0), W4_MM(3, 2, 0), W4_MM(3, 3, 0))
     W4_MM(3, 4, 0) W4_MM(3, 5, 0) W4_MM(3, 6, 0) W4_MM(3, 7, 0)
-    W4_FETCH(0, cA, 6, chunk)
+    W4_FETCH(2, cA, 5, chunk)
     W4_FENCE();
     W4_MM8(4, 1)
     if (!(W4_ABL & 128)) __syncthreads();  // barrier A: sA[~g&1] complete, sR free
     // ---- second half: pairs 5..8 || halo (g+2): registers -> sR, halo loads (g+3) ----
-    W4_FETCH(1, cA, 7, chunk)
+    W4_FETCH(0, cA, 6, chunk)
     W4_FENCE();
     W4_MM(5, 0, 2) W4_HALO_PAR() W4_HALO_BN(0) W4_FENCE();
     W4_MM(5, 1, 2) W4_HALO_WR(0) W4_FENCE();
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_MM(5, 5, 2) W4_HALO_WR(2) W4_FENCE();
     W4_MM(5, 6, 2) W4_HALO_BN(3) W4_FENCE();
     W4_MM(5, 7, 2) W4_HALO_WR(3) W4_FENCE();
-    W4_FETCH(2, cA, 8, chunk)
+    W4_FETCH(1, cA, 7, chunk)
     W4_FENCE();
     W4_MM(6, 0, 0) W4_HALO_BN(4) W4_FENCE();
     W4_MM(6, 1, 0) W4_HALO_WR(4) W4_FENCE();
@@ -425,10 +433,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_FENCE();
     W4_MM(6, 3, 0) W4_MM(6, 4, 0) W4_MM(6, 5, 0) W4_MM(6, 6, 0) W4_MM(6, 7, 0)
     // first pairs of the next stage (after a tile epilogue they are fetched behind it)
-    if (nchunk != 0) W4_FETCH(0, nA, 0, nchunk)
+    W4_FETCH(2, cA, 8, chunk)
     W4_FENCE();
     W4_MM8(7, 1)
-    if (nchunk != 0) W4_FETCH(1, nA, 1, nchunk)
+    if (nchunk != 0) W4_FETCH(0, nA, 0, nchunk)
     W4_FENCE();
     W4_MM8(8, 2)
     if (!(W4_ABL & 128)) __syncthreads();  // barrier B: sR = raw(g+2) complete, sA[g&1] consumed
@@ -614,16 +622,15 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
       round(std::integral_constant<int, 2>{});
       round(std::integral_constant<int, 3>{});
       if (!(W4_ABL & 64)) w4_acc_clear(c11);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc16[r] = 0.f; acc17[r] = 0.f; }
+      W4_CLEAR_V()
 #endif
       chunk = 0;
       tile += per_cob;
       W4_FETCH(0, nA, 0, 0)
-      W4_FETCH(1, nA, 1, 0)
     }
   }
 #undef W4_ISSUE_HALO
+#undef W4_CLEAR_V
 #undef W4_HALO_PAR
 #undef W4_HALO_BN
 #undef W4_HALO_WR
