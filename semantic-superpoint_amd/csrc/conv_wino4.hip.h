@@ -348,31 +348,41 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   const int cbase = 18 * qI;
   const int in_off = (cbase * W4_TILES + li) * PK + ((lh ^ ((li >> 3) & 1)) << 2);
   const int w_voff = (lh * NB + nt * 32 + li) * 16;
-  f32x4 Fa0, Fb0, Wa0, Wb0, Fa1, Fb1, Wa1, Wb1, Fa2, Fb2, Wa2, Wb2;
-#define W4_FETCH(S, BUF, P, CHUNK)                                                                          \
-  {                                                                                                         \
-    if (!(W4_ABL & 512) || g < 0) {                                                                         \
+  // Weight sets 3, 4 hold pairs 0, 1 of the NEXT stage: together with the weights of pairs 7, 8 they are fetched right
+  // before the halo loads of a stage are issued.  The memory counter (vmcnt) retires loads in order: the first weight fetch
+  // issued AFTER the halo loads cannot be consumed before they have come back from HBM, so that fetch is pushed 4.5 pairs
+  // (~1 us) behind the halo issue instead of one pair (the coupling cost 0.05 ms of a 0.75 ms launch: halo staging +0.12 ms
+  // with the weight loads in the loop, +0.07 without, profiles/r02_w4_ablation.txt).
+  f32x4 Fa0, Fb0, Wa0, Wb0, Fa1, Fb1, Wa1, Wb1, Fa2, Fb2, Wa2, Wb2, Wa3, Wb3, Wa4, Wb4;
+#define W4_FETCH_F(S, BUF, P)                                                                               \
+  if (!(W4_ABL & 512) || g < 0) {                                                                           \
     Fa##S = W4_LD((BUF) + in_off + (2 * (P)) * W4_TILES * PK);                                              \
-    Fb##S = W4_LD((BUF) + in_off + (2 * (P) + 1) * W4_TILES * PK); }                                        \
-    const int so_ = (((cob * nst + (CHUNK)) * W4_B_FLOATS) + (cbase + 2 * (P)) * 2 * NB * 4) * 4;           \
-    if (!(W4_ABL & 256) || g < 0) {                                                                         \
-    Wa##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_, 0));       \
-    Wb##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_ + 2 * NB * 16, 0)); } \
+    Fb##S = W4_LD((BUF) + in_off + (2 * (P) + 1) * W4_TILES * PK);                                          \
   }
+#define W4_FETCH_W(S, P, CHUNK)                                                                             \
+  if (!(W4_ABL & 256) || g < 0) {                                                                           \
+    const int so_ = (((cob * nst + (CHUNK)) * W4_B_FLOATS) + (cbase + 2 * (P)) * 2 * NB * 4) * 4;           \
+    Wa##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_, 0));       \
+    Wb##S = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff, so_ + 2 * NB * 16, 0)); \
+  }
+#define W4_FETCH(S, BUF, P, CHUNK) { W4_FETCH_F(S, BUF, P) W4_FETCH_W(S, P, CHUNK) }
   // MFMA number I (0..7) of pair P: component 2P + (I & 1), k pair I >> 1
-#define W4_MM(P, I, S)                                                                                      \
+#define W4_MMX(P, I, S, SW)                                                                                 \
   if ((P) == 8) {                                                                                           \
-    if (((I) & 1) == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc16) : "v"(Fa##S[(I) >> 1]), "v"(Wa##S[(I) >> 1])); \
-    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc17) : "v"(Fb##S[(I) >> 1]), "v"(Wb##S[(I) >> 1]));            \
-  } else if (((I) & 1) == 0) w4_mfma_a<((P) < 8 ? 2 * (P) : 0)>(Fa##S[(I) >> 1], Wa##S[(I) >> 1]);           \
-  else w4_mfma_a<((P) < 8 ? 2 * (P) + 1 : 0)>(Fb##S[(I) >> 1], Wb##S[(I) >> 1]);                             \
+    if (((I) & 1) == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc16) : "v"(Fa##S[(I) >> 1]), "v"(Wa##SW[(I) >> 1])); \
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc17) : "v"(Fb##S[(I) >> 1]), "v"(Wb##SW[(I) >> 1]));           \
+  } else if (((I) & 1) == 0) w4_mfma_a<((P) < 8 ? 2 * (P) : 0)>(Fa##S[(I) >> 1], Wa##SW[(I) >> 1]);          \
+  else w4_mfma_a<((P) < 8 ? 2 * (P) + 1 : 0)>(Fb##S[(I) >> 1], Wb##SW[(I) >> 1]);                            \
   __builtin_amdgcn_sched_barrier(0);
+#define W4_MM(P, I, S) W4_MMX(P, I, S, S)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define W4_MM8(P, S) W4_MM(P, 0, S) W4_MM(P, 1, S) W4_MM(P, 2, S) W4_MM(P, 3, S) W4_MM(P, 4, S) W4_MM(P, 5, S) W4_MM(P, 6, S) W4_MM(P, 7, S)
 
   int g = -1;  // (the ablation macros test g < 0 = prologue)
-  W4_FETCH(0, sA, 0, 0)
-  if (W4_ABL & (256 | 512)) { W4_FETCH(1, sA, 1, 0) W4_FETCH(2, sA, 2, 0) }
+  W4_FETCH_F(0, sA, 0)
+  W4_FETCH_W(3, 0, 0)
+  W4_FETCH_W(4, 1, 0)
+  if (W4_ABL & (256 | 512)) { W4_FETCH(0, sA, 0, 0) W4_FETCH(1, sA, 1, 0) W4_FETCH(2, sA, 2, 0) }
 
   // eleven transform slices of one V row behind MFMAs N .. N + 10 of pairs P0, P0 + 1 (column order 0, 2, 4, 1, 3, 5)
 #define W4_ROW_SLICES(COND, DSTBUF, DA, DL, K0, K1, K2, M0, M1, M2, M3, M4, M5, M6, M7, M8, M9, M10, M11)   \
@@ -397,12 +407,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     const int nchunk = chunk + 1 == nst ? 0 : chunk + 1;
     f32x4 rx0, rx1, rx2, rx3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;
     // ---- first half: pairs 0..4 || transform of stage g+1 ----
-    W4_FETCH(1, cA, 1, chunk)
+    W4_FETCH_F(1, cA, 1)
     W4_FENCE();
     W4_ROW_SLICES(!(W4_ABL & 2), nA, 0, 0, tka0, tka1, tka2,
-                  W4_MM(0, 0, 0), W4_MM(0, 1, 0), W4_MM(0, 2, 0), W4_MM(0, 3, 0), W4_MM(0, 4, 0), W4_MM(0, 5, 0), W4_MM(0, 6, 0),
-                  W4_MM(0, 7, 0) W4_FETCH(2, cA, 2, chunk) W4_FENCE();, W4_MM(1, 0, 1), W4_MM(1, 1, 1), W4_MM(1, 2, 1), W4_MM(1, 3, 1))
-    W4_MM(1, 4, 1) W4_MM(1, 5, 1) W4_MM(1, 6, 1) W4_MM(1, 7, 1)
+                  W4_MMX(0, 0, 0, 3), W4_MMX(0, 1, 0, 3), W4_MMX(0, 2, 0, 3), W4_MMX(0, 3, 0, 3), W4_MMX(0, 4, 0, 3), W4_MMX(0, 5, 0, 3),
+                  W4_MMX(0, 6, 0, 3), W4_MMX(0, 7, 0, 3) W4_FETCH(2, cA, 2, chunk) W4_FENCE();, W4_MMX(1, 0, 1, 4), W4_MMX(1, 1, 1, 4),
+                  W4_MMX(1, 2, 1, 4), W4_MMX(1, 3, 1, 4))
+    W4_MMX(1, 4, 1, 4) W4_MMX(1, 5, 1, 4) W4_MMX(1, 6, 1, 4) W4_MMX(1, 7, 1, 4)
     W4_FETCH(0, cA, 3, chunk)
     W4_FENCE();
     W4_ROW_SLICES(twB, nA + DST_B, dAb, dLb, tkb0, tkb1, tkb2,
@@ -425,6 +436,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_MM(5, 6, 2) W4_HALO_BN(3) W4_FENCE();
     W4_MM(5, 7, 2) W4_HALO_WR(3) W4_FENCE();
     W4_FETCH(1, cA, 7, chunk)
+    W4_FETCH_W(2, 8, chunk)   // every weight needed before the halo loads come back ..
+    W4_FETCH_W(3, 0, nchunk)  // .. incl. pairs 0, 1 of the next stage
+    W4_FETCH_W(4, 1, nchunk)
     W4_FENCE();
     W4_MM(6, 0, 0) W4_HALO_BN(4) W4_FENCE();
     W4_MM(6, 1, 0) W4_HALO_WR(4) W4_FENCE();
@@ -433,10 +447,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_FENCE();
     W4_MM(6, 3, 0) W4_MM(6, 4, 0) W4_MM(6, 5, 0) W4_MM(6, 6, 0) W4_MM(6, 7, 0)
     // first pairs of the next stage (after a tile epilogue they are fetched behind it)
-    W4_FETCH(2, cA, 8, chunk)
+    W4_FETCH_F(2, cA, 8)
     W4_FENCE();
     W4_MM8(7, 1)
-    if (nchunk != 0) W4_FETCH(0, nA, 0, nchunk)
+    if (nchunk != 0) W4_FETCH_F(0, nA, 0)
     W4_FENCE();
     W4_MM8(8, 2)
     if (!(W4_ABL & 128)) __syncthreads();  // barrier B: sR = raw(g+2) complete, sA[g&1] consumed
@@ -626,7 +640,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #endif
       chunk = 0;
       tile += per_cob;
-      W4_FETCH(0, nA, 0, 0)
+      W4_FETCH_F(0, nA, 0)
     }
   }
 #undef W4_ISSUE_HALO
@@ -640,6 +654,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #undef W4_TRANSFORM_ROW
 #undef W4_ROW_SLICES
 #undef W4_FETCH
+#undef W4_FETCH_F
+#undef W4_FETCH_W
+#undef W4_MMX
 #undef W4_MM
 #undef W4_MM8
 #undef W4_FENCE
