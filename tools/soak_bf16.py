@@ -1,6 +1,7 @@
 """Soak of the mixed bf16 mode (conv algo 8, BASELINE configs[3]) against fp32: two engines, identical initial weights,
 identical batches and sampler seeds, N optimizer steps each; prints both loss curves (mean over 10-step windows) and
-their relative deviation.  usage: soak_bf16.py [ssp|sp] [steps] [batch]"""
+their relative deviation.  usage: soak_bf16.py [ssp|sp] [steps] [batch] [algo_a,algo_b]   (default 1,8; "9,1" soaks the default
+algorithm - Winograd F(4x4,3x3) on the large maps - against F(2x2,3x3) only)"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -13,7 +14,9 @@ dev = torch.device("cuda:0")
 H, W = 240, 320
 sd = synth.default_init_state_dict(layer_table(arch), seed=0)
 engs = {}
-for name, algo in (("fp32", 1), ("bf16", 8)):
+pair = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "1,8").split(",")]
+NAMES = {1: "fp32", 8: "bf16", 9: "fp32 F(2x2,3x3) only", 10: "fp32 F(4x4,3x3) forced"}
+for name, algo in ((NAMES.get(pair[0], "algo %d" % pair[0]), pair[0]), (NAMES.get(pair[1], "algo %d" % pair[1]), pair[1])):
     L.set_conv_algo(algo)  # copied into the handle at creation
     engs[name] = Engine(arch, B, H, W, dev)
     engs[name].load_state_dict(sd)
@@ -28,17 +31,18 @@ for it in range(steps):
         eng.adam_step(1e-3)
         hist[name].append(eng.scalars[li].clone())
 torch.cuda.synchronize()
-f = torch.stack(hist["fp32"]).cpu().double(); b = torch.stack(hist["bf16"]).cpu().double()
+na, nb = list(engs.keys())
+f = torch.stack(hist[na]).cpu().double(); b = torch.stack(hist[nb]).cpu().double()
 assert torch.isfinite(f).all() and torch.isfinite(b).all()
 print("%s B=%d %dx%d, %d steps, 4 synthetic batches cycled, lr 1e-3; window means of the total loss" % (arch, B, H, W, steps))
-print("%8s %12s %12s %10s" % ("steps", "fp32", "mixed bf16", "rel dev"))
+print("%8s %24s %24s %10s" % ("steps", na, nb, "rel dev"))
 worst = 0.0
 for s0 in range(0, steps, 10):
     mf, mb = f[s0:s0 + 10].mean().item(), b[s0:s0 + 10].mean().item()
     dev_ = abs(mb - mf) / abs(mf)
     worst = max(worst, dev_)
     if s0 % 50 == 0 or s0 + 10 >= steps:
-        print("%3d-%-4d %12.5f %12.5f %10.2e" % (s0, min(steps, s0 + 10) - 1, mf, mb, dev_))
-print("per-step |bf16 - fp32| / fp32: mean %.2e  max %.2e;   worst 10-step window %.2e" %
+        print("%3d-%-4d %24.5f %24.5f %10.2e" % (s0, min(steps, s0 + 10) - 1, mf, mb, dev_))
+print("per-step |b - a| / a: mean %.2e  max %.2e;   worst 10-step window %.2e" %
       (((b - f).abs() / f.abs()).mean().item(), ((b - f).abs() / f.abs()).max().item(), worst))
-print("loss fell: fp32 %.4f -> %.4f, mixed bf16 %.4f -> %.4f" % (f[0], f[-10:].mean(), b[0], b[-10:].mean()))
+print("loss fell: %s %.4f -> %.4f, %s %.4f -> %.4f" % (na, f[0], f[-10:].mean(), nb, b[0], b[-10:].mean()))
