@@ -58,6 +58,8 @@ CONV_CASES = [
     (2, 14, 20, 32, 64, 3, 0),    # 32 input channels (four 8-channel stages), narrow partial tiles
     (1, 8, 32, 48, 70, 3, 1),     # Cin = 48, cout tail (70 = 64 + 6)
     (3, 10, 64, 16, 64, 3, 0),    # Cin = 16: two stages per tile, many tiles per block
+    (2, 50, 70, 64, 128, 3, 1),   # several F(4x4,3x3) tile blocks per image, partial at both edges (32x16 blocks: 50 = 3 x 16 + 2)
+    (1, 70, 50, 32, 64, 3, 0),    # the 16x32 block shape of F(4x4,3x3) (70 = 2 x 32 + 6, 50 = 3 x 16 + 2)
 ]
 
 
