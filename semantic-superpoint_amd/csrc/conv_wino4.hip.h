@@ -228,7 +228,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   // (tid >> 1) & 31, tid & 1:   T[c] = k0 d[r0][c] + k1 d[r0+1][c] + k2 d[r0+2][c] + d[rl][c]
   //   row 0: r0 0, rl 4, k ( 4,  0, -5)   row 1: r0 1, rl 4, k (-4, -4,  1)   row 2: r0 1, rl 4, k ( 4, -4, -1)
   //   row 3: r0 1, rl 4, k (-2, -1,  2)   row 4: r0 1, rl 4, k ( 2, -1, -2)   row 5: r0 1, rl 5, k ( 4,  0, -5)
-  const bool twB = (W4_ABL & 2) ? false : wave < 2;  // second row
+  // second row: waves 2 and 3 recompute rows 4 and 5 as well (identical values, benign double writes): they would wait at
+  // the stage barrier anyway, and twelve wave-uniform branches per stage around the slices cost the waves that do need
+  // the row more (~16 cycles each) than the duplicated LDS traffic costs anybody
+  constexpr bool twB = !(W4_ABL & 2);
   const int t_tile = (tid >> 1) & 31;
   int t_ty, t_tx;
   w4_tile_xy<WIDE>(t_tile, t_ty, t_tx);
@@ -238,13 +241,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   const float ka0 = W4_UNI(wave == 1 ? -4.f : wave == 3 ? -2.f : 4.f);
   const float ka1 = W4_UNI(wave == 0 ? 0.f : wave == 3 ? -1.f : -4.f);
   const float ka2 = W4_UNI(wave == 0 ? -5.f : wave == 1 ? 1.f : wave == 2 ? -1.f : 2.f);
-  const float kb0 = W4_UNI(wave == 0 ? 2.f : 4.f);
-  const float kb1 = W4_UNI(wave == 0 ? -1.f : 0.f);
-  const float kb2 = W4_UNI(wave == 0 ? -2.f : -5.f);
+  const float kb0 = W4_UNI((wave & 1) == 0 ? 2.f : 4.f);   // row 4 (even waves) / row 5 (odd waves)
+  const float kb1 = W4_UNI((wave & 1) == 0 ? -1.f : 0.f);
+  const float kb2 = W4_UNI((wave & 1) == 0 ? -2.f : -5.f);
 #undef W4_UNI
   const f32x2 tka0 = {ka0, ka0}, tka1 = {ka1, ka1}, tka2 = {ka2, ka2}, tkb0 = {kb0, kb0}, tkb1 = {kb1, kb1}, tkb2 = {kb2, kb2};
   // second row: byte offsets of its first / last raw row against the first row's (wave 0: rows 1.. / 4; wave 1: rows 1.. / 5)
-  const int dAb = wave == 0 ? ROWF * 4 : 0, dLb = wave == 1 ? ROWF * 4 : 0;
+  const int dAb = wave == 0 ? ROWF * 4 : 0, dLb = (wave & 1) ? ROWF * 4 : 0;
   int t_ab[6];  // byte addresses of the first raw row read | of the last raw row read << 16
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     t_ab[c] = (ta_ * 4) | ((tb_ * 4) << 16);
   }
   const int t_dst = (wave * 6 * W4_TILES + t_tile) * PK + ((q2 ^ ((t_tile >> 3) & 1)) << 2);
-  constexpr int DST_B = 4 * 6 * W4_TILES * PK;  // row w + 4
+  const int DST_B = (4 + (wave & 1) - wave) * 6 * W4_TILES * PK;  // row 4 + (w & 1) against row w
 #define W4_LD(P) (*reinterpret_cast<const f32x4*>(P))
   // raw pixels of column C into register set X, one MFMA slot ahead of their use (a second set, two slots ahead, and operands
   // fetched two component pairs ahead instead of one measured the same: 0.745 vs 0.745 ms on one box)
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   W4_HALO_ALL()
   __syncthreads();
   W4_TRANSFORM_ROW(sA, 0, 0, tka0, tka1, tka2)
-  if (wave < 2) W4_TRANSFORM_ROW(sA + DST_B, dAb, dLb, tkb0, tkb1, tkb2)
+  W4_TRANSFORM_ROW(sA + DST_B, dAb, dLb, tkb0, tkb1, tkb2)
   W4_ISSUE_HALO()
   __syncthreads();
   W4_HALO_ALL()
