@@ -43,7 +43,7 @@ def cpu_baseline(arch, H, W, views, thr):
                       "linearly (%.1f s/image)" % (arch, H, W, v, views, dt)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -55,37 +55,18 @@ def main():
     ap.add_argument("--thresh", type=float, default=0.0155)  # random-init logits: softmax ~ 1/65 = 0.01538
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also time the stages separately (extra, untimed pass)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    # same launch contract as bench.py: bare `--gpus N` spawns N ranks before anything touches the GPU; under a launcher
-    # WORLD_SIZE must equal --gpus.  Images are sharded over the ranks with no collective on the data path.
-    world_env = os.environ.get("WORLD_SIZE")
-    if world_env is None and args.gpus > 1:
-        from bench import spawn_ranks
-        sys.exit(spawn_ranks(args))
-    if int(world_env or "1") != args.gpus:
-        raise SystemExit("bench_export.py: --gpus %d does not match WORLD_SIZE=%s of the launcher" % (args.gpus, world_env))
 
+def measure_export(dev, arch, n, H, W, thresh, steps, warmup, rank=0, world=1, dist=None, stages=False):
+    """`steps` timed ssp_export_points calls (two images each) on `dev` after `warmup` untimed ones; barriers and the
+    max over ranks when world > 1.  Returns the result fields (rank 0: incl. the roofline of the 3x3 forward launches).
+    Used by main() below and by bench.py's `export` block (BASELINE configs[4] beside the headline line)."""
     import numpy as np
     import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench_export.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     from semantic_superpoint_amd import lib as L
     from semantic_superpoint_amd import synth
 
-    arch = "SuperPointNet_gauss2" if args.arch == "sp" else "SuperPointNet_gauss2_ssmall"
-    n, H, W = args.views, args.height, args.width
     eng = L.Engine(arch, n, H, W, dev, with_grad=False)
     eng.load_state_dict(synth.default_init_state_dict(L.layer_table(arch), seed=0))
     rs = np.random.RandomState(1000 + rank)
@@ -104,10 +85,11 @@ def main():
     def step():
         vm = [L.op_homoadapt_views(imgs[k], hom[k][1]) for k in range(2)]
         outs = eng.export_points([v for v, _ in vm], [m for _, m in vm], [hom[k][0] for k in range(2)],
-                                 conf_thresh=args.thresh, nms_dist=4, top_k=600, subpixel=True)
+                                 conf_thresh=thresh, nms_dist=4, top_k=600, subpixel=True)
         return [int(o["count"].item()) for o in outs]  # the host needs the counts to slice the point lists
 
-    for _ in range(args.warmup):
+    counts = None
+    for _ in range(warmup):
         counts = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -116,7 +98,7 @@ def main():
         eng.profile_enable("conv3x3_all")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         counts = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -126,46 +108,86 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
+    res = {"images_per_s": world * 2 * steps / dt, "ms_per_step": 1e3 * dt / steps, "points_last_step": counts}
     if rank == 0:
-        ips = world * 2 * args.steps / dt
-        gf = GFLOP_FWD_DET_240x320 * (H * W) / (240.0 * 320.0) * n
-        out = {"metric": "images/sec, homography-adaptation export (%d views/image, %dx%d)" % (n, H, W),
-               "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s homography-adaptation export, %d views of %dx%d per image, 2 images per step, "
-                                      "threshold %.4f, nms 4, top-k 600, soft-argmax" % (arch, n, H, W, args.thresh),
-                          "parallelism": "images sharded over %d rank(s), no collective" % world},
-               "views_per_s": round(ips * n, 1), "forward_tflops": round(ips * gf / 1e3, 2),
-               "points_last_step": counts}
         pr = eng.profile_read()
         if pr["launches"] > 0 and pr["ms"] > 0:
-            ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
-            er = pr["exec_flops"] / pr["flops"]  # multiplies executed on the matrix cores / algorithmic ones (per launch, library)
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_wino4_kernel + conv_wino_pipe_kernel + conv_wino_p2_kernel (3x3 forward of "
-                                                          "the encoder and the detector head, Winograd F(4x4,3x3) on the large maps / "
-                                                          "F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
-                               "achieved": round(ach, 2),
-                               "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TF, 4),
-                               "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / time; Winograd executes 16/36 (F(2x2,3x3)) or 1/4 "
-                                       "(F(4x4,3x3)) of them",
-                               "executed_tflops": round(ach * er, 2),
-                               "executed_frac": round(ach * er / PEAK_FP32_MFMA_TF, 4),
+            alg = pr["flops"] / (pr["ms"] * 1e-3) / 1e12
+            ex = pr["exec_flops"] / (pr["ms"] * 1e-3) / 1e12  # multiplies executed on the matrix cores (per launch, library)
+            kern = eng.profile_read_kernels()
+            res["roofline"] = {"bound": "mfma",
+                               "kernel": " + ".join(kern) + " (3x3 forward of the encoder and the detector head; Winograd F(4x4,3x3) "
+                                         "on the large maps / F(2x2,3x3) below, v_mfma_f32_32x32x2_f32)",
+                               "achieved": round(ex, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                               "frac": round(ex / PEAK_FP32_MFMA_TF, 4),
+                               "note": "achieved / frac = multiplies EXECUTED on the matrix cores (1/4 of the direct-convolution ones "
+                                       "for F(4x4,3x3), 16/36 for F(2x2,3x3)); algorithmic_* = direct-convolution FLOPs / time",
+                               "algorithmic_tflops": round(alg, 2), "algorithmic_frac": round(alg / PEAK_FP32_MFMA_TF, 4),
+                               "executed_tflops": round(ex, 2), "executed_frac": round(ex / PEAK_FP32_MFMA_TF, 4),
                                "traffic": None, "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4)}
         eng.profile_enable("none")
-        if args.stages:
+        if stages:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
             vm = [L.op_homoadapt_views(imgs[k], hom[k][1]) for k in range(2)]
             ev[1].record()
             eng.export_points([v for v, _ in vm], [m for _, m in vm], [hom[k][0] for k in range(2)],
-                              conf_thresh=args.thresh, nms_dist=4, top_k=600, subpixel=True)
+                              conf_thresh=thresh, nms_dist=4, top_k=600, subpixel=True)
             ev[2].record()
             torch.cuda.synchronize()
-            out["stage_ms"] = {"views": round(ev[0].elapsed_time(ev[1]), 3),
+            res["stage_ms"] = {"views": round(ev[0].elapsed_time(ev[1]), 3),
                                "export_points": round(ev[1].elapsed_time(ev[2]), 3)}
+    del eng
+    return res
+
+
+def main():
+    args = parse_args()
+    # same launch contract as bench.py: bare `--gpus N` spawns N ranks of THIS script before anything touches the GPU;
+    # under a launcher WORLD_SIZE must equal --gpus.  Images are sharded over the ranks with no collective on the data path.
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world_env is None and args.gpus > 1:
+        from bench import spawn_ranks
+        sys.exit(spawn_ranks(args, script=os.path.abspath(__file__)))
+    if int(world_env or "1") != args.gpus:
+        raise SystemExit("bench_export.py: --gpus %d does not match WORLD_SIZE=%s of the launcher" % (args.gpus, world_env))
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_export.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    arch = "SuperPointNet_gauss2" if args.arch == "sp" else "SuperPointNet_gauss2_ssmall"
+    n, H, W = args.views, args.height, args.width
+    res = measure_export(dev, arch, n, H, W, args.thresh, args.steps, args.warmup, rank, world, dist, stages=args.stages)
+
+    if rank == 0:
+        ips = res["images_per_s"]
+        gf = GFLOP_FWD_DET_240x320 * (H * W) / (240.0 * 320.0) * n
+        out = {"metric": "images/sec, homography-adaptation export (%d views/image, %dx%d)" % (n, H, W),
+               "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(res["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s homography-adaptation export, %d views of %dx%d per image, 2 images per step, "
+                                      "threshold %.4f, nms 4, top-k 600, soft-argmax" % (arch, n, H, W, args.thresh),
+                          "parallelism": "images sharded over %d rank(s), no collective" % world},
+               "views_per_s": round(ips * n, 1), "forward_tflops": round(ips * gf / 1e3, 2),
+               "points_last_step": res["points_last_step"]}
+        for k in ("roofline", "stage_ms"):
+            if k in res:
+                out[k] = res[k]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch, H, W, n, args.thresh)
         print(json.dumps(out), flush=True)

@@ -159,9 +159,16 @@ int ssp_sample_indices_cell(ssp_handle* h, const float* cell_homographies_dev, i
 /* timing hook for bench.py: when enabled, every launch of the tagged kernel family is bracketed by
  * hipEvents on `stream`; ssp_profile_read returns accumulated milliseconds, launches and FLOPs. */
 enum { SSP_PROF_NONE = 0, SSP_PROF_CONV3X3_FWD = 1, SSP_PROF_CONV3X3_DGRAD = 2, SSP_PROF_CONV3X3_WGRAD = 3,
-       SSP_PROF_CONV_BIG_FWD = 4, SSP_PROF_CONV3X3_ALL = 5 /* fwd + dgrad launches of conv_mfma_kernel */ };
+       SSP_PROF_CONV_BIG_FWD = 4, SSP_PROF_CONV3X3_ALL = 5 /* 3x3 forward + data-gradient launches */,
+       SSP_PROF_CONV3X3_EVERY = 6 /* 3x3 forward + data-gradient + weight-gradient launches */ };
 int ssp_profile_enable(ssp_handle* h, int family);
 int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops, double* bytes);
+/* The same measurement split by the KERNEL that ran each tagged launch (bench.py's per-kernel roofline entries). */
+enum { SSP_PROF_K_CONV_WINO4 = 0 /* conv_wino4_kernel, Winograd F(4x4,3x3) */, SSP_PROF_K_CONV_WINO_PIPE = 1, SSP_PROF_K_CONV_WINO_P2 = 2,
+       SSP_PROF_K_WGRAD_WINO = 3 /* wgrad_wino_kernel, F(3x3,2x2) */, SSP_PROF_K_WGRAD_WINO4 = 4 /* wgrad_wino4_kernel, F(3x3,4x4) */,
+       SSP_PROF_K_OTHER = 5 /* direct implicit GEMM, bf16-operand kernels */, SSP_PROF_K_COUNT = 6 };
+int ssp_profile_read_kernel(ssp_handle* h, int kernel, double* ms, int64_t* launches, double* flops, double* executed_flops,
+                            double* bytes);
 /* FLOPs the tagged launches since ssp_profile_enable EXECUTED on the matrix cores (ssp_profile_read's `flops` are the
  * algorithmic, direct-convolution FLOPs): x 1/4 for a Winograd F(4x4,3x3) launch, x 16/36 for F(2x2,3x3), x 1 otherwise. */
 int ssp_profile_read_executed(ssp_handle* h, double* executed_flops);

@@ -116,7 +116,17 @@ __device__ __forceinline__ void w4_acc_clear(float c11) {
   else asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(R));
   if constexpr (R + 1 < 256) w4_acc_clear<R + 1>(c11);
 }
-__device__ __forceinline__ void w4_claim_agprs() { asm volatile("" : : : "a0", "a255"); }
+// every one of a0..a255 is named: the compiler must treat all of them as clobbered here, and the kernel descriptor reserves
+// the full accumulation-register file (hipbuild.verify_binary checks the BINARY: exactly the asm's own a-register
+// instructions, no scratch, no spills)
+#define W4_A8(B) "a" #B "0", "a" #B "1", "a" #B "2", "a" #B "3", "a" #B "4", "a" #B "5", "a" #B "6", "a" #B "7", "a" #B "8", "a" #B "9"
+__device__ __forceinline__ void w4_claim_agprs() {
+  asm volatile("" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", W4_A8(1), W4_A8(2), W4_A8(3), W4_A8(4), W4_A8(5),
+               W4_A8(6), W4_A8(7), W4_A8(8), W4_A8(9), W4_A8(10), W4_A8(11), W4_A8(12), W4_A8(13), W4_A8(14), W4_A8(15), W4_A8(16),
+               W4_A8(17), W4_A8(18), W4_A8(19), W4_A8(20), W4_A8(21), W4_A8(22), W4_A8(23), W4_A8(24), "a250", "a251", "a252",
+               "a253", "a254", "a255");
+}
+#undef W4_A8
 
 // tile index (= MFMA column = lane & 31) -> tile coordinates inside the workgroup's 8x4 / 4x8 tile block; tiles with the
 // same index mod 8 differ in (tx & 1, ty & 3)

@@ -240,13 +240,15 @@ __global__ void sample_homographies_kernel(uint64_t seed, HomographyParams p, fl
     centre(cx, cy);
     double scales[17];
     const int ns = min(p.n_scales, 16);
-    for (int i = 0; i < ns; ++i) scales[i] = 1.0 + rng.truncnorm(p.scaling_amplitude / 2);
-    scales[ns] = 1.0;
+    // utils/homographies.py:83-95: candidates [1, s_1 .. s_n]; with allow_artifacts the index is drawn from arange(n_scales),
+    // i.e. over [1, s_1 .. s_{n-1}] (the reference's comment says "all but scale = 1"; its code says this)
+    scales[0] = 1.0;
+    for (int i = 1; i <= ns; ++i) scales[i] = 1.0 + rng.truncnorm(p.scaling_amplitude / 2);
     int valid[17], nv = 0;
     for (int i = 0; i <= ns; ++i) {
       double q[4][2];
       for (int k = 0; k < 4; ++k) { q[k][0] = (p2[k][0] - cx) * scales[i] + cx; q[k][1] = (p2[k][1] - cy) * scales[i] + cy; }
-      if (p.allow_artifacts || in_unit(q)) valid[nv++] = i;
+      if (p.allow_artifacts ? i < ns : in_unit(q)) valid[nv++] = i;
     }
     const double s = nv > 0 ? scales[valid[min((int)(rng.uniform() * nv), nv - 1)]] : 1.0;
     for (int k = 0; k < 4; ++k) { p2[k][0] = (p2[k][0] - cx) * s + cx; p2[k][1] = (p2[k][1] - cy) * s + cy; }
@@ -275,7 +277,7 @@ __global__ void sample_homographies_kernel(uint64_t seed, HomographyParams p, fl
         q[k][0] = dx * c + dy * s + cx;
         q[k][1] = -dx * s + dy * c + cy;
       }
-      if (p.allow_artifacts || in_unit(q)) valid[nv++] = i;
+      if (p.allow_artifacts ? i < na : in_unit(q)) valid[nv++] = i;  // :118-119: arange(n_angles), the appended 0 is never drawn
     }
     if (nv > 0) {
       const int i = valid[min((int)(rng.uniform() * nv), nv - 1)];

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void sem_count_kernel(const int64_t* __restric
   __shared__ float red[4];
   float cnt = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    cnt += (labels[i] != (int64_t)C) ? 1.f : 0.f;
+    cnt += ((uint64_t)labels[i] < (uint64_t)C) ? 1.f : 0.f;  // 0 <= label < C; C = ignore_index; anything else is ignored too (sem_ce_kernel)
   cnt = wave_sum(cnt);
   const float tot = block_sum_of_waves(cnt, red);
   if (threadIdx.x == 0) unsafeAtomicAdd(&acc->sem_cnt[view], (double)tot);
@@ -120,9 +120,12 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
       int a0, a1;
       up_src(y, Hc, H, a0, a1, wy1_l);
       up_src(x, Wc, W, a0, a1, wx1_l);
-      label_l = (int)labels[((size_t)n * H + y) * W + x];
+      const int64_t lv = labels[((size_t)n * H + y) * W + x];
+      label_l = (uint64_t)lv < (uint64_t)C ? (int)lv : C;  // (the same test as sem_count_kernel, on all 64 bits)
     }
-    const bool counted = inside && label_l != C;
+    // labels outside [0, C] (torch raises; e.g. 255 / -1 from a dataset) are treated like the ignore index C: they must never
+    // index the corner logits or the LDS histogram below
+    const bool counted = inside && (unsigned)label_l < (unsigned)C;
     const unsigned long long counted_mask = __ballot(counted);
     if (counted_mask == 0ull) continue;  // wave-uniform: ignored / outside pixels contribute nothing
     const float wy0_l = 1.f - wy1_l, wx0_l = 1.f - wx1_l;

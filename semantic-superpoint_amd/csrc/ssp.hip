@@ -142,6 +142,13 @@ struct ssp_handle {
   float* dense_coef; // [B * cells * cells] d total / d dot of the dense descriptor loss (cfg.dense_loss), else nullptr
   int sout_cs;
   int conv_algo;     // ssp_handle_set_conv_algo (initialised from the process default of ssp_set_conv_algo)
+  // layout of the packed weight images wpk_fwd / wpk_bwd as pack_all last wrote them (they are shared by both slots and
+  // re-packed by every forward): the launches of a layer use THIS record, never a re-evaluation of w4_eligible with their own
+  // shape (a forward of another shape / view count on the other slot, or ssp_handle_set_conv_algo, between a forward and its
+  // backward would otherwise run an F(2x2,3x3) kernel on an F(4x4,3x3) image or the reverse)
+  bool pk_w4_fwd[16] = {}, pk_w4_bwd[16] = {};
+  int packed_algo = -1;      // conv algorithm the images were packed for
+  bool packed_bwd = false;   // the data-gradient images were packed too
   // captured pair steps (ssp_pair_step_graph): one executable graph per (phase, input signature)
   struct GraphEntry { std::vector<unsigned char> key; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
@@ -152,6 +159,8 @@ struct ssp_handle {
   size_t ev_used;
   double prof_flops, prof_bytes, prof_exec_flops;
   int64_t prof_launches;
+  struct ProfKernel { double flops = 0, exec_flops = 0, bytes = 0; int64_t launches = 0; } prof_k[SSP_PROF_K_COUNT];
+  std::vector<unsigned char> ev_kernel;  // kernel bucket of event pair i (ev_pool[2 i], ev_pool[2 i + 1])
   int n_cu;
 };
 
@@ -321,14 +330,20 @@ static size_t carve(ssp_handle* h, void* base) {
 // ------------------------------------------------------------------------------------------------
 struct ProfScope {
   ssp_handle* h; hipStream_t st; bool on;
-  ProfScope(ssp_handle* h_, int family, hipStream_t s, double flops, double bytes, double exec_flops = -1.0) : h(h_), st(s), on(false) {
-    const bool match = h && family > 0 && (h->prof_family == family ||
-        (h->prof_family == SSP_PROF_CONV3X3_ALL && (family == SSP_PROF_CONV3X3_FWD || family == SSP_PROF_CONV3X3_DGRAD)));
+  ProfScope(ssp_handle* h_, int family, hipStream_t s, double flops, double bytes, double exec_flops = -1.0,
+            int kernel = SSP_PROF_K_OTHER) : h(h_), st(s), on(false) {
+    const bool conv = family == SSP_PROF_CONV3X3_FWD || family == SSP_PROF_CONV3X3_DGRAD;
+    const bool match = h && family > 0 && (h->prof_family == family || (h->prof_family == SSP_PROF_CONV3X3_ALL && conv) ||
+        (h->prof_family == SSP_PROF_CONV3X3_EVERY && (conv || family == SSP_PROF_CONV3X3_WGRAD)));
     if (match && h->ev_used + 2 <= h->ev_pool.size()) {
       on = true;
       (void)hipEventRecord(h->ev_pool[h->ev_used], st);
+      const double ex = exec_flops >= 0.0 ? exec_flops : flops;
       h->prof_flops += flops; h->prof_bytes += bytes; h->prof_launches += 1;
-      h->prof_exec_flops += exec_flops >= 0.0 ? exec_flops : flops;
+      h->prof_exec_flops += ex;
+      ssp_handle::ProfKernel& k = h->prof_k[kernel];
+      k.flops += flops; k.exec_flops += ex; k.bytes += bytes; k.launches += 1;
+      h->ev_kernel[h->ev_used / 2] = (unsigned char)kernel;
     }
   }
   ~ProfScope() {
@@ -403,6 +418,8 @@ struct ConvCall {
   float* pool_out[2] = {nullptr, nullptr};
   const float* pool_gamma = nullptr;
   bool allow_w4 = true;  // false: wpk is an F(2x2,3x3) image whatever the shape (the concatenated data-gradient weights of the heads)
+  int force_w4 = -1;     // engine launches: 1 / 0 = wpk is / is not an F(4x4,3x3) image (ssp_handle::pk_w4_*); -1 = decide from the
+                         // shape (operator-level calls, which pack with the same predicate right before the launch)
 };
 static bool can_fuse_bnr(const ConvCall& c) {
   return c.wino && (pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6 || bf16_algo()) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
@@ -495,7 +512,9 @@ static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int
   return (long)H * W >= min_px && 4L * items >= min_items_x4 * (h ? h->n_cu : 256);
 }
 static bool conv_uses_w4(const ssp_handle* h, const ConvCall& c) {
-  return c.wino && c.allow_w4 && c.ks == 3 && c.in_mode != 2 && w4_eligible(h, c.nprob, c.N, c.H, c.W, c.cin, c.cout);
+  if (!(c.wino && c.allow_w4 && c.ks == 3 && c.in_mode != 2)) return false;
+  if (c.force_w4 >= 0) return c.force_w4 == 1;  // conv_wino4_kernel is legal on every map size (algorithm 10 runs it everywhere)
+  return w4_eligible(h, c.nprob, c.N, c.H, c.W, c.cin, c.cout);
 }
 static bool conv_uses_p2(const ssp_handle* h, const ConvCall& c) {
   if (!c.wino) return false;
@@ -573,7 +592,9 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
       c.cin == 64)
     fam = SSP_PROF_CONV_BIG_FWD;
   // multiplies executed on the matrix cores: 36 per 16 outputs x 9 taps (F(4x4,3x3)), 16 per 4 x 9 (F(2x2,3x3))
-  ProfScope ps(h, fam, st, flops, bytes, flops * (w4 ? 0.25 : c.wino ? 16.0 / 36.0 : 1.0));
+  const int pkern = w4 ? SSP_PROF_K_CONV_WINO4 : (c.wino && bf16_algo()) ? SSP_PROF_K_OTHER : p2 ? SSP_PROF_K_CONV_WINO_P2
+                    : (c.wino && (pipe_algo() || g_conv_algo == 5)) ? SSP_PROF_K_CONV_WINO_PIPE : SSP_PROF_K_OTHER;
+  ProfScope ps(h, fam, st, flops, bytes, flops * (w4 ? 0.25 : c.wino ? 16.0 / 36.0 : 1.0), pkern);
   if (w4) {  // Winograd F(4x4,3x3), one 8-wave workgroup per CU
     if (c.in_mode == 0) return wide4 ? launch_wino4_t<0, true>(a, nblocks, st) : launch_wino4_t<0, false>(a, nblocks, st);
     return wide4 ? launch_wino4_t<1, true>(a, nblocks, st) : launch_wino4_t<1, false>(a, nblocks, st);
@@ -718,7 +739,8 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   {
     const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
     const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
-    ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes);
+    ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes, flops * (wino ? 16.0 / 36.0 : 1.0),
+                 wino && !bf16_algo() ? SSP_PROF_K_WGRAD_WINO : SSP_PROF_K_OTHER);
     if (wino && bf16_algo() && bf16_parts(true) == 1) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_bf16_t<1, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false>(a, nblocks, st)));
@@ -885,10 +907,33 @@ int ssp_zero_grad(ssp_handle* h, void* stream) {
 int ssp_profile_enable(ssp_handle* h, int family) {
   if (!h) return fail(-1, "null handle");
   h->prof_family = family; h->ev_used = 0; h->prof_flops = h->prof_bytes = h->prof_exec_flops = 0; h->prof_launches = 0;
+  for (auto& k : h->prof_k) k = ssp_handle::ProfKernel();
   if (family != 0 && h->ev_pool.empty()) {
     h->ev_pool.resize(8192);
+    h->ev_kernel.assign(4096, (unsigned char)SSP_PROF_K_OTHER);
     for (auto& e : h->ev_pool) HIPCHK(hipEventCreate(&e));
   }
+  return 0;
+}
+
+int ssp_profile_read_kernel(ssp_handle* h, int kernel, double* ms, int64_t* launches, double* flops, double* executed_flops,
+                            double* bytes) {
+  if (!h) return fail(-1, "null handle");
+  if (kernel < 0 || kernel >= SSP_PROF_K_COUNT) return fail(-1, "profile kernel bucket out of range");
+  double tot = 0;
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    if (h->ev_kernel[i / 2] != kernel) continue;
+    float t = 0;
+    HIPCHK(hipEventSynchronize(h->ev_pool[i + 1]));
+    HIPCHK(hipEventElapsedTime(&t, h->ev_pool[i], h->ev_pool[i + 1]));
+    tot += t;
+  }
+  const ssp_handle::ProfKernel& k = h->prof_k[kernel];
+  if (ms) *ms = tot;
+  if (launches) *launches = k.launches;
+  if (flops) *flops = k.flops;
+  if (executed_flops) *executed_flops = k.exec_flops;
+  if (bytes) *bytes = k.bytes;
   return 0;
 }
 
@@ -968,12 +1013,15 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     int lh = H / 8, lw = W / 8;
     if (l < 8) layer_res(l, H, W, lh, lw);
     const bool wf = wino_ok(d.ks, d.cin), wb = wino_ok(d.ks, d.cout);
-    CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wf,
-             wf && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, d.cin, d.cout)));
-    if (with_bwd)
-      CHK(pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wb,
-               wb && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, (int)align_up(d.cout, 4), d.cin)));
+    h->pk_w4_fwd[l] = wf && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, d.cin, d.cout);
+    CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wf, h->pk_w4_fwd[l]));
+    if (with_bwd) {
+      h->pk_w4_bwd[l] = wb && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, (int)align_up(d.cout, 4), d.cin);
+      CHK(pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wb, h->pk_w4_bwd[l]));
+    }
   }
+  h->packed_algo = g_conv_algo;
+  h->packed_bwd = with_bwd;
   if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
     const int heads[3] = {L_PA, L_DA, L_DS};
     const bool wino = wino_ok(3, 256 * h->nheads);
@@ -1038,6 +1086,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
   c.in_scale = A.bn[src].scale; c.in_shift = A.bn[src].shift;
   c.stats = (d.bn && train) ? A.bn[l].stats : nullptr;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = in_mode; c.nchunks = d.nchunks_fwd; c.ncob = d.ncob_fwd;
+  c.force_w4 = h->pk_w4_fwd[l] ? 1 : 0;
   if (SS.n == 2) {
     Slot& B = *SS.s[1];
     c.nprob = 2; c.in2 = pooled ? B.Apool[src] : B.Y[src]; c.out2 = B.Y[l]; c.in_scale2 = B.bn[src].scale;
@@ -1212,6 +1261,7 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
   c.out = din[0]; c.out_cs = din_cs; c.out_co = din_co; c.cout = d.cin;
   c.in_scale = nullptr; c.in_shift = nullptr; c.stats = nullptr; c.backward = true;
   c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 0; c.nchunks = d.nchunks_bwd; c.ncob = d.ncob_bwd;
+  c.force_w4 = h->pk_w4_bwd[l] ? 1 : 0;
   if (SS.n == 2) {
     Slot& B = *SS.s[1];
     w.nprob = 2; w.in2 = pooled ? B.Apool[src] : B.Y[src]; w.dout2 = dy[1]; w.in_scale2 = B.bn[src].scale;
@@ -1234,6 +1284,11 @@ enum { EARLY_SPLIT_LAYER = 2 };
 static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
                         float* const* dsout, hipStream_t st, int part = 0) {
   Slot& S0 = *SS.s[0];
+  if (!h->packed_bwd || h->packed_algo != g_conv_algo)
+    return fail(-3, "backward: the packed weight images do not belong to this pass (%s) - run the forward of the step again",
+                !h->packed_bwd ? "the last forward packed no data-gradient weights" : "the conv algorithm changed since the forward");
+  for (int k = 0; k < SS.n; ++k)
+    if (SS.s[k]->N <= 0) return fail(-3, "backward: the slot holds no forward");
   const int N = S0.N, H = S0.H, W = S0.W, Hc = H / 8, Wc = W / 8;
   const int hcs = 256 * h->nheads;
   const bool has_semi = dsemi[0] != nullptr, has_desc = draw_desc[0] != nullptr;

@@ -1,20 +1,44 @@
-"""Builds the HIP library in-tree (semantic-superpoint_amd/csrc/libssp_hip.so) for gfx950.
-hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots."""
+"""Builds the HIP library in-tree (semantic-superpoint_amd/csrc/libssp_hip.so) for gfx950 and verifies the BINARY.
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots.
+
+Binary verification (`verify_binary`): the kernels that keep accumulators in FIXED accumulation registers behind inline
+asm (conv_wino4.hip.h: a[0:255]) are only correct while the compiler never allocates an accumulation register or spills
+in them - it does not know the registers are occupied.  The check disassembles the gfx950 code object embedded in the .so
+that is actually shipped / loaded and requires, per such kernel, EXACTLY the accumulation-register instructions its
+inline asm contains (any compiler-generated v_accvgpr_* / a-register operand changes the counts), no scratch and no
+vector-register spills.  `build()` runs it after every compile and leaves a `<lib>.isa_ok` stamp (sha256 of the .so);
+`lib.load_library()` re-verifies a library whose stamp is missing or stale, so the binary on the GPU box is covered too.
+"""
+import hashlib
 import os
+import re
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libssp_hip.so")
-SOURCES = ["ssp.hip", "pk_math.hip.h", "conv_mfma.hip.h", "conv_wino.hip.h", "conv_wino_pipe.hip.h", "conv_wino_p2.hip.h", "conv_wino4.hip.h", "conv_wino_bf16.hip.h", "dense_loss.hip.h", "bn_kernels.hip.h", "loss_kernels.hip.h", "sem_kernels.hip.h", "pair_kernels.hip.h", "export_kernels.hip.h",
-           os.path.join("..", "..", "include", "ssp_hip.h")]
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+# kernels with inline-asm-private accumulation registers -> the exact count of every instruction that may touch a0..a255:
+# conv_wino4_kernel: 16 accumulators x 4 k-pairs = 64 MFMAs on a[..]; two clear sites x 256 writes; the epilogue reads each
+# of the 256 registers once in either wave role (2 x 256)
+FIXED_AGPR_KERNELS = {
+    "conv_wino4_kernel": {"v_mfma_f32_32x32x2_f32": 64, "v_accvgpr_write_b32": 512, "v_accvgpr_read_b32": 512},
+}
+
+
+def _sources():
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") or f.endswith(".hip.h")]
+    out.append(os.path.join(HERE, "..", "include", "ssp_hip.h"))
+    return out
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+    return any(os.path.getmtime(s) > t for s in _sources())
 
 
 def hipcc_path():
@@ -24,29 +48,128 @@ def hipcc_path():
     return "hipcc"
 
 
+def _sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _tool(name):
+    p = os.path.join(LLVM_BIN, name)
+    if not os.path.exists(p):
+        raise RuntimeError("%s not found: cannot verify the accumulation-register contract of %s" % (p, LIB))
+    return p
+
+
+def disassemble(lib_path, workdir):
+    """gfx950 code object of the fat binary inside `lib_path` -> (disassembly text, llvm-readelf --notes text)."""
+    fat, co = os.path.join(workdir, "fat.bin"), os.path.join(workdir, "dev.co")
+    subprocess.run([_tool("llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path, os.path.join(workdir, "unused.so")],
+                   check=True, capture_output=True)
+    subprocess.run([_tool("clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
+    dis = subprocess.run([_tool("llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+    notes = subprocess.run([_tool("llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    return dis, notes
+
+
+def verify_binary(lib_path=LIB, expected=None):
+    """Raises RuntimeError if a fixed-accumulation-register kernel of `lib_path` contains any accumulation-register
+    instruction beyond its inline asm, touches scratch, or spills vector registers.  Returns {kernel symbol: counts}."""
+    expected = expected if expected is not None else FIXED_AGPR_KERNELS
+    with tempfile.TemporaryDirectory(prefix="ssp_isa_", dir="/tmp") as tmp:
+        dis, notes = disassemble(lib_path, tmp)
+    parts = re.split(r"^[0-9a-f]{16} <([^>]+)>:\n", dis, flags=re.M)
+    found, report = {k: 0 for k in expected}, {}
+    for i in range(1, len(parts), 2):
+        name, body = parts[i], parts[i + 1]
+        fam = next((k for k in expected if k in name), None)
+        if fam is None:
+            continue
+        counts = {}
+        for line in body.splitlines():
+            m = re.match(r"\s+(\S+)\s+(.*?)\s*//", line)
+            if not m:
+                continue
+            op, args = m.group(1), m.group(2)
+            if op.startswith("scratch_"):
+                counts["scratch"] = counts.get("scratch", 0) + 1
+            if re.search(r"\ba(\d+|\[\d+:\d+\])", args):
+                counts[op] = counts.get(op, 0) + 1
+        if counts != expected[fam]:
+            raise RuntimeError("%s: accumulation-register instructions %s differ from the inline-asm contract %s - the compiler "
+                               "allocated an accumulation register or spilled in a kernel whose a[0:255] are private"
+                               % (name, counts, expected[fam]))
+        found[fam] += 1
+        report[name] = counts
+    for fam, n in found.items():
+        if n == 0:
+            raise RuntimeError("no %s instance found in %s" % (fam, lib_path))
+    # kernel descriptors: no private segment, no vector-register spills
+    for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+        m = re.search(r"\.name:\s+(\S+)", blk)
+        if not m or not any(k in m.group(1) for k in expected):
+            continue
+        seg = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+        agpr = int(re.search(r"^\s*(\d+)", blk).group(1))
+        if seg != 0 or spill != 0 or agpr != 256:
+            raise RuntimeError("%s: private segment %d B, %d spilled vector registers, %d accumulation registers reserved "
+                               "(need 0 / 0 / 256)" % (m.group(1), seg, spill, agpr))
+    return report
+
+
+def stamp_path(lib_path=LIB):
+    return lib_path + ".isa_ok"
+
+
+def verified(lib_path=LIB):
+    """True iff `lib_path` carries a stamp written by verify_and_stamp for exactly this binary."""
+    try:
+        return open(stamp_path(lib_path)).read().strip() == _sha256(lib_path)
+    except OSError:
+        return False
+
+
+def verify_and_stamp(lib_path=LIB):
+    verify_binary(lib_path)
+    with open(stamp_path(lib_path), "w") as f:
+        f.write(_sha256(lib_path) + "\n")
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/ssp.hip -> csrc/libssp_hip.so (gfx950). Returns the library path."""
+    """Compile csrc/ssp.hip -> csrc/libssp_hip.so (gfx950), verify the binary.  Returns the library path."""
     if not force and not _stale():
+        if not verified():
+            verify_and_stamp()
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-           "ssp.hip", "-o", "libssp_hip.so"]
+           "ssp.hip", "-o", "libssp_hip.so"] + os.environ.get("SSP_HIPCC_EXTRA", "").split()
     r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0 or verbose:
         print(r.stdout)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed (%d): %s" % (r.returncode, " ".join(cmd)))
+    try:
+        verify_and_stamp()
+    except Exception:
+        # a library that violates the register contract must never be loadable by accident
+        os.replace(LIB, LIB + ".rejected")
+        raise
     return LIB
 
 
 def build_locked():
     """build() when stale, with an exclusive file lock so that the ranks of one node do not compile concurrently."""
-    if not _stale():
+    if not _stale() and verified():
         return LIB
     import fcntl
     with open(os.path.join(CSRC, ".build.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
-            return build()  # re-checks _stale() under the lock
+            return build()  # re-checks _stale() / the stamp under the lock
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
 

@@ -19,7 +19,10 @@ SCALAR_NAMES = ["loss", "loss_det", "loss_det_warp", "loss_desc", "loss_sem", "l
 N_SCALARS = 16
 NREP = 32  # SSP_NREP
 SAMPLER_MAX_MATCHES = 8192  # SAMPLER_MAX_CELLS of csrc/sem_kernels.hip.h (bitonic sort capacity of the device sampler)
-PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4, "conv3x3_all": 5}
+PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4, "conv3x3_all": 5,
+        "conv3x3_every": 6}
+PROF_KERNELS = ["conv_wino4_kernel", "conv_wino_pipe_kernel", "conv_wino_p2_kernel", "wgrad_wino_kernel", "wgrad_wino4_kernel",
+                "other"]  # SSP_PROF_K_*
 
 
 class SspConfig(C.Structure):
@@ -68,7 +71,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
-           "ssp_op_warp_labels_full_px"]
+           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel"]
 
 
 def load_library(path=None):
@@ -83,6 +86,11 @@ def load_library(path=None):
         path = _build.build_locked()
     if not os.path.exists(path):
         raise RuntimeError("libssp_hip.so not found at %s" % path)
+    if not _build.verified(path):  # the binary about to be loaded (e.g. shipped to the GPU box) keeps the register contract
+        try:
+            _build.verify_and_stamp(path)
+        except OSError:  # read-only tree: verified, not stamped
+            _build.verify_binary(path)
     lib = C.CDLL(path)
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     lib.ssp_last_error.restype = C.c_char_p
@@ -114,6 +122,8 @@ def load_library(path=None):
     lib.ssp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
     lib.ssp_profile_read_executed.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.ssp_profile_read_kernel.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -545,6 +555,16 @@ class Engine:
         ex = C.c_double()
         _check(self.lib.ssp_profile_read_executed(self.h, C.byref(ex)))
         return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value, "exec_flops": ex.value}
+
+    def profile_read_kernels(self):
+        """Per-kernel split of profile_read(): {kernel name: {ms, launches, flops, exec_flops, bytes}} (launched kernels only)."""
+        out = {}
+        for k, name in enumerate(PROF_KERNELS):
+            ms, n, fl, ex, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _check(self.lib.ssp_profile_read_kernel(self.h, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(ex), C.byref(by)))
+            if n.value > 0:
+                out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "exec_flops": ex.value, "bytes": by.value}
+        return out
 
 
 # ---- optimizer state in torch.optim.Adam's wire format ----

@@ -45,10 +45,10 @@ def sample_homography(rs, shape=(2, 2), shift=-1, perspective=True, scaling=True
         hr = _truncnorm(rs, perspective_amplitude_x / 2)
         pts2 = pts2 + np.array([[hl, pd], [hl, -pd], [hr, pd], [hr, -pd]])
     if scaling:
-        scales = np.array([1 + _truncnorm(rs, scaling_amplitude / 2) for _ in range(n_scales)] + [1.0])
+        scales = np.array([1.0] + [1 + _truncnorm(rs, scaling_amplitude / 2) for _ in range(n_scales)])  # :83-84: [1, s_1 .. s_n]
         center = pts2.mean(axis=0, keepdims=True)
         scaled = (pts2 - center)[None] * scales[:, None, None] + center
-        valid = np.arange(n_scales + 1) if allow_artifacts else np.where(((scaled >= 0) & (scaled < 1)).all(axis=(1, 2)))[0]
+        valid = np.arange(n_scales) if allow_artifacts else np.where(((scaled >= 0) & (scaled < 1)).all(axis=(1, 2)))[0]
         pts2 = scaled[valid[rs.randint(valid.shape[0])]]
     if translation:
         t_min, t_max = pts2.min(axis=0), (1 - pts2).min(axis=0)
@@ -61,7 +61,7 @@ def sample_homography(rs, shape=(2, 2), shift=-1, perspective=True, scaling=True
         center = pts2.mean(axis=0, keepdims=True)
         rot = np.stack([np.cos(angles), -np.sin(angles), np.sin(angles), np.cos(angles)], axis=1).reshape(-1, 2, 2)
         rotated = np.matmul((pts2 - center)[None], rot) + center
-        valid = np.arange(n_angles + 1) if allow_artifacts else np.where(((rotated >= 0) & (rotated < 1)).all(axis=(1, 2)))[0]
+        valid = np.arange(n_angles) if allow_artifacts else np.where(((rotated >= 0) & (rotated < 1)).all(axis=(1, 2)))[0]
         pts2 = rotated[valid[rs.randint(valid.shape[0])]]
     sh = np.array(shape[::-1], dtype=np.float64)
     p1, p2 = pts1 * sh[None] + shift, pts2 * sh[None] + shift

@@ -144,6 +144,51 @@ def test_bench_gpus_flag_is_checked_and_spawns_ranks():
         assert "ranks failed" in r.stderr and "needs an MI355X" in r.stderr
 
 
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_bench_export_gpus_flag_spawns_the_export_script():
+    """bench_export.py --gpus 2 must start ranks of bench_export.py itself (round 2 relayed bench.py's TRAINING line): without a
+    GPU both ranks die with bench_export's own message, and the parent names bench_export.py."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_export.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--views", "4", "--height", "64", "--width", "96"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "bench_export.py: ranks failed" in r.stderr
+    if not torch.cuda.is_available():
+        assert "bench_export.py needs an MI355X" in r.stderr and "bench.py needs" not in r.stderr
+
+
+def test_spawn_ranks_watchdog_stops_the_survivors(tmp_path):
+    """One rank dies at start-up while the other would block forever (RCCL rendezvous in real life): the parent terminates
+    the survivor and returns non-zero within seconds; a healthy pair relays rank 0's stdout and returns 0."""
+    import time
+    import types
+    b = _load_bench()
+    bad = tmp_path / "ranks_bad.py"
+    bad.write_text("import os, sys, time\n"
+                   "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                   "print('rank0 alive', flush=True)\ntime.sleep(600)\n")
+    t0 = time.monotonic()
+    rc = b.spawn_ranks(types.SimpleNamespace(gpus=2), script=str(bad), argv=[])
+    assert rc == 1 and time.monotonic() - t0 < 60
+    good = tmp_path / "ranks_good.py"
+    good.write_text("import os\nassert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                    "print('rank', os.environ['RANK'])\n")
+    assert b.spawn_ranks(types.SimpleNamespace(gpus=2), script=str(good), argv=[]) == 0
+    hang = tmp_path / "ranks_hang.py"
+    hang.write_text("import time\ntime.sleep(600)\n")
+    t0 = time.monotonic()
+    assert b.spawn_ranks(types.SimpleNamespace(gpus=2), script=str(hang), argv=[], timeout=2.0) == 1
+    assert time.monotonic() - t0 < 60
+
+
 def test_bench_dtype_flag_selects_the_conv_algorithm():
     """bench.py --dtype: f32 = the headline Winograd fp32 path, bf16 = the validated mixed mode (BASELINE configs[3])."""
     import importlib.util
@@ -264,3 +309,20 @@ def test_f4x4_kernel_accumulators_are_private_to_its_inline_asm(tmp_path):
     for accum, nxt in zip(re.findall(r"\.amdhsa_accum_offset (\d+)", text), re.findall(r"\.amdhsa_next_free_vgpr (\d+)", text)):
         if int(nxt) > 256:  # the four conv_wino4_kernel instances
             assert int(nxt) == int(accum) + 256
+
+
+def test_shipped_binary_keeps_the_accumulation_register_contract():
+    """hipbuild.verify_binary on the in-tree .so (the file that ships with the gpurun snapshot): the gfx950 code object is
+    unbundled and disassembled; conv_wino4_kernel must contain exactly its inline asm's accumulation-register instructions
+    (64 MFMAs, 2 x 256 clears, 2 x 256 reads), no scratch, no spilled vector registers, 256 reserved accumulation registers.
+    A tampered contract (one instruction less expected) must be rejected."""
+    from semantic_superpoint_amd import hipbuild
+    if not os.path.exists(os.path.join(hipbuild.LLVM_BIN, "llvm-objdump")):
+        pytest.skip("llvm binutils not available")
+    lib = hipbuild.build()
+    rep = hipbuild.verify_binary(lib)
+    assert len(rep) == 4 and all("conv_wino4_kernel" in k for k in rep)
+    assert hipbuild.verified(lib)
+    wrong = {"conv_wino4_kernel": dict(hipbuild.FIXED_AGPR_KERNELS["conv_wino4_kernel"], v_accvgpr_read_b32=511)}
+    with pytest.raises(RuntimeError, match="differ from the inline-asm contract"):
+        hipbuild.verify_binary(lib, expected=wrong)

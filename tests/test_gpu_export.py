@@ -129,8 +129,16 @@ def test_top_k_and_subpixel_on_random_heatmap():
     assert np.abs(mine[:, :2] - ref[:, :2]).max() < 1e-5
 
 
+# Winograd F(4x4,3x3) carries ~6x the rounding noise of F(2x2,3x3) (1.5e-6 vs 2.4e-7 rel-L2 on a layer's data,
+# profiles/r02_wino_error_probe.txt): forced onto every 3x3 layer (algo 10: the export's real kernel set at 480x640, which
+# the small fixtures would otherwise never reach) the aggregated heat map sits 1.6e-5 from the reference instead of
+# < 1e-5; the north-star tolerance is 1e-3.
+HEAT_TOL = {1: 1e-5, 10: 3e-5}
+
+
+@pytest.mark.parametrize("algo", [1, 10])
 @pytest.mark.parametrize("name", G8)
-def test_fused_export_against_reference(name):
+def test_fused_export_against_reference(name, algo):
     """Engine.export_points (forward + flatten + combine + points in one call) on the fixture's views."""
     from semantic_superpoint_amd.lib import Engine, points_to_numpy
     g = G.load("g8_export_%s.npz" % name)
@@ -138,12 +146,13 @@ def test_fused_export_against_reference(name):
     arch, thr, top_k = str(g["arch"]), float(g["thr"]), int(g["top_k"])
     n, _, H, W = g["views"].shape
     e = Engine(arch, n, H, W, dev, with_grad=False)
+    e.set_conv_algo(algo)
     e.load_state_dict(C.init_state_dict(arch, seed=int(g["seed"])))
     views, masks, hms = (t(g[k]).to(dev).contiguous() for k in ("views", "valid_mask", "homographies"))
     out = e.export_points([views], [masks], [hms], conf_thresh=thr, nms_dist=4, top_k=top_k, subpixel=True,
                           want_heatmap=True)[0]
     agg = out["heatmap"].cpu().numpy()
-    assert np.abs(agg - g["aggregate"]).max() < 1e-5
+    assert np.abs(agg - g["aggregate"]).max() < HEAT_TOL[algo]
     # BatchNorm ran in train mode over the views: running statistics move exactly as in the reference
     assert (e.state_dict()["bnPb.running_var"].cpu() - t(g["bnPb_running_var"])).abs().max() < 1e-4
     # points: exactly what the reference's extraction gives on THIS aggregate ...
@@ -186,8 +195,18 @@ def test_two_images_per_call_match_single_calls():
         assert (o["heatmap"].squeeze() - both[k]["heatmap"].cpu()).abs().max() < 1e-5
 
 
-def test_dropin_frontend_and_combine_heatmap():
-    """The reference's call sequence (export.py:296-309) through the drop-in names."""
+@pytest.mark.parametrize("algo", [1, 10])
+def test_dropin_frontend_and_combine_heatmap(algo):
+    """The reference's call sequence (export.py:296-309) through the drop-in names (algo 10: F(4x4,3x3) on every 3x3 layer)."""
+    from semantic_superpoint_amd import lib as L
+    L.set_conv_algo(algo)  # process default: the nn.Module creates its engine lazily
+    try:
+        _dropin_frontend_case(HEAT_TOL[algo])
+    finally:
+        L.set_conv_algo(1)
+
+
+def _dropin_frontend_case(heat_tol):
     from semantic_superpoint_amd import export as X
     from semantic_superpoint_amd.models.SuperPointNet_gauss2 import SuperPointNet_gauss2
     g = G.load("g8_export_sp_64x96_v6.npz")
@@ -200,10 +219,10 @@ def test_dropin_frontend_and_combine_heatmap():
     fe.net = net.to(dev)
     img, mask = t(g["views"]).to(dev), t(g["valid_mask"]).to(dev)
     heat = fe.run(img, onlyHeatmap=True, train=False)
-    assert (heat.cpu() - t(g["views_heatmap"])).abs().max() < 1e-5
+    assert (heat.cpu() - t(g["views_heatmap"])).abs().max() < heat_tol
     outputs = X.combine_heatmap(heat, t(g["homographies"]).unsqueeze(0).to(dev), mask, device=dev)
     assert outputs.shape == (1, 64, 96)
-    assert (outputs.cpu().squeeze() - t(g["aggregate"])).abs().max() < 1e-5
+    assert (outputs.cpu().squeeze() - t(g["aggregate"])).abs().max() < heat_tol
     # identical heatmap in -> identical points out, through the reference's method names
     fe.heatmap = t(g["aggregate"])
     pts = fe.getPtsFromHeatmap(t(g["aggregate"]))
@@ -223,7 +242,7 @@ def test_dropin_frontend_and_combine_heatmap():
     # the fused exporter on the same sample
     ex = X.HomoAdaptExporter(fe.net, dev, thr, 4, top_k, True)
     pts2, hms = ex([{"image": img, "valid_mask": mask, "homographies": t(g["homographies"])}], want_heatmap=True)
-    assert (hms[0].cpu() - t(g["aggregate"])).abs().max() < 1e-5
+    assert (hms[0].cpu() - t(g["aggregate"])).abs().max() < heat_tol
     assert pts2[0].shape[1] == 3 and len(pts2[0]) <= top_k
 
 

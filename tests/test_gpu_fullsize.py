@@ -51,9 +51,13 @@ def _noisy(arch):  # conv biases feeding a BatchNorm: exact gradient 0, both sid
 # ------------------------------------------------------------------------------------------------
 # (i) the real reference's step at 240x320 (G12)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo", [1, 10])
 @pytest.mark.parametrize("tag", ["sp", "ssp"])
-def test_full_size_step_golden(tag):
-    """G12: forward checksums, two optimizer steps and the first step's gradients of the REAL reference at 240x320, B = 2."""
+def test_full_size_step_golden(tag, algo):
+    """G12: forward checksums, two optimizer steps and the first step's gradients of the REAL reference at 240x320, B = 2.
+    algo 1 = the default predicate (at B = 2 every 3x3 layer runs F(2x2,3x3): 600 tile-block items < 1024); algo 10 = the
+    BENCHMARKED kernel set: conv_wino4_kernel (Winograd F(4x4,3x3)) with its in-step epilogues - pooled raw output, fused
+    BatchNorm-backward sums, two views per launch, XCD split, nt stores - on every 3x3 layer of the reference's own step."""
     from semantic_superpoint_amd.lib import SCALAR_NAMES
     arch = ARCHS[tag]
     g = G.load("g12_step_%s_240x320.npz" % tag)
@@ -64,6 +68,7 @@ def test_full_size_step_golden(tag):
     ds = _to_dev(sample)
     # forward: per-channel checksums (sums over 1200 cells / 76800 pixels) and strided slices
     e = _engine(arch, B, H, W, sd, with_grad=False)
+    e.set_conv_algo(algo)
     want = ("semi", "desc", "sem") if tag == "ssp" else ("semi", "desc")
     o = e.forward(ds["image"], slot=0, train=True, want=want)
     torch.cuda.synchronize()
@@ -81,6 +86,7 @@ def test_full_size_step_golden(tag):
     del e
     # the step
     e = _engine(arch, B, H, W, sd)
+    e.set_conv_algo(algo)
     idx = _idx_to_dev(G.indices_from(g, "idx/", B), W // 8)
     for it in range(2):
         e.zero_grad()
@@ -103,7 +109,7 @@ def test_full_size_step_golden(tag):
                 err = float((mine[:64] - sl).abs().max()) / (float(mine.abs().max()) + 1e-30)
                 worst = max(worst, err)
                 assert err < 2e-2, (k, err)
-            print("G12 %s: worst 64-element slice error %.2e of max|grad|" % (tag, worst))
+            print("G12 %s algo %d: worst 64-element slice error %.2e of max|grad|" % (tag, algo, worst))
             assert (gd["eta"].cpu() - torch.from_numpy(g["grad/eta"])).abs().max() < 2e-4
         e.adam_step(0.001)
     torch.cuda.synchronize()
@@ -266,6 +272,133 @@ def test_bench_size_properties(tag):
             first, last = (v, last) if it == 0 else (first, v)
     assert last["loss"] < first["loss"] - 0.05, (first["loss"], last["loss"])
     assert bool(torch.isfinite(e.params).all())
+
+
+def _oracle_indices(idx, Wc):
+    """Device-sampled (match_a, match_b, nonmatch_b) -> the per-image index dicts of cpu_ref.Trainer."""
+    ma, mb, nm = (t.cpu().long() for t in idx)
+    out = []
+    for i in range(ma.shape[0]):
+        out.append({"uv_a": torch.stack((ma[i] % Wc, ma[i] // Wc), dim=1).float(),
+                    "uv_b": torch.stack((mb[i] % Wc, mb[i] // Wc), dim=1).float(), "nm_b": nm[i]})
+    return out
+
+
+def _np_sd(sd):
+    return {k: (v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+
+
+def _compare_step_with_oracle(tag, e, sd, sample, sc, idx, scal_tol, norm_tol, flat_tol, what):
+    """One oracle step (cpu_ref.Trainer) on the same inputs and the same sparse-loss indices: 8 scalars, per-tensor
+    gradient norms, the flat gradient and the eta gradient."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    arch = ARCHS[tag]
+    W = sample["image"].shape[-1]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    tr = C.Trainer(arch, _np_sd(sd), lr=0.001)
+    tr.real_batch_size = 10 ** 9  # gradients only
+    cpu = {k: v.cpu() for k, v in sample.items() if k != "cell_homographies"}
+    tr.train_val_sample(cpu, n_iter=0, train=True, indices=_oracle_indices(idx, W // 8))
+    sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+    for name in SCALARS:
+        ref = tr.scalar_dict[name]
+        assert abs(sc[name] - ref) < scal_tol * max(1.0, abs(ref)), (what, name, sc[name], ref)
+    gd = e.grad_dict()
+    mine_flat, ref_flat, worst = [], [], (0.0, "")
+    for k in C.param_keys(arch):
+        if k in _noisy(arch):
+            continue
+        mine, ref = gd[k].cpu().reshape(-1).double(), tr.last_grads[k].reshape(-1).double()
+        n_ref = float(ref.norm())
+        assert abs(float(mine.norm()) - n_ref) < norm_tol * n_ref + 1e-7, (what, k, float(mine.norm()), n_ref)
+        worst = max(worst, (float((mine - ref).norm()) / (n_ref + 1e-30), k))
+        mine_flat.append(mine), ref_flat.append(ref)
+    l2, mx = _rel(torch.cat(mine_flat), torch.cat(ref_flat))
+    print("%s: flat gradient rel-L2 %.2e (max %.2e), worst tensor %.2e (%s)" % (what, l2, mx, worst[0], worst[1]))
+    assert l2 < flat_tol, (what, l2)
+    assert (gd["eta"].cpu() - tr.last_grads["eta"]).abs().max() < 1e-5, what
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["sp", "ssp"])
+def test_bench_size_step_vs_oracle(tag):
+    """THE benchmarked configuration against the oracle: B = 32, 240x320 (BASELINE configs[1] / [2]), default algorithm -
+    conv_wino4_kernel on the 240x320 / 120x160 / 60x80 layers with nprob = 2, fused BatchNorm-backward sums, pooled raw
+    outputs, the XCD split and nt stores, F(2x2,3x3) on the 30x40 layers, F(3x3,2x2) / F(3x3,4x4) weight gradients -, inputs
+    of bench.py's generator, DEVICE-sampled indices read back and fed to cpu_ref.Trainer (one oracle step ~ 15 s on the
+    GPU host).  8 scalars <= 2e-4, per-tensor gradient norm <= 2e-3, flat gradient rel-L2 <= 3e-3, eta gradient 1e-5."""
+    from semantic_superpoint_amd import synth
+    from semantic_superpoint_amd.lib import layer_table
+    arch = ARCHS[tag]
+    B, H, W = 32, 240, 320
+    sd = synth.default_init_state_dict(layer_table(arch), seed=0)
+    sample = synth.make_pair(B, H, W, _dev(), seed=100, semantic=(tag == "ssp"))
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    sc = e.pair_step(sample, indices=None, seed=7, train=True).clone()
+    torch.cuda.synchronize()
+    _compare_step_with_oracle(tag, e, sd, sample, sc, e._last_idx, 2e-4, 2e-3, 3e-3, "B=32 240x320 %s" % tag)
+
+
+def test_default_predicate_mixes_kernels_below_max_batch():
+    """Engine sized for 6 pairs, step of 4 at 240x320: the default predicate sends the two 240x320 layers through
+    conv_wino4_kernel (2 x 4 x 150 = 1200 tile-block items >= 1024) and everything below through F(2x2,3x3) (320 / 80 items),
+    i.e. the mixed per-layer weight-image layouts of ONE step (ssp_handle::pk_w4_*) with B < max_batch, against the oracle.
+    A second step of 2 pairs on the same engine (no layer eligible any more) must re-pack and agree as well."""
+    from semantic_superpoint_amd import synth
+    from semantic_superpoint_amd.lib import layer_table
+    tag, arch = "ssp", ARCHS["ssp"]
+    H, W = 240, 320
+    sd = synth.default_init_state_dict(layer_table(arch), seed=2)
+    e = _engine(arch, 6, H, W, sd)
+    for B, seed in ((4, 31), (2, 32)):
+        sample = synth.make_pair(B, H, W, _dev(), seed=seed, semantic=True)
+        e.load_state_dict(sd)
+        e.zero_grad()
+        sc = e.pair_step(sample, indices=None, seed=seed, train=True).clone()
+        torch.cuda.synchronize()
+        _compare_step_with_oracle(tag, e, sd, sample, sc, e._last_idx, 2e-4, 3e-3, 5e-3, "default predicate, B=%d of 6" % B)
+
+
+def test_backward_refuses_stale_weight_images():
+    """The packed weight images belong to the last forward of the handle: changing the conv algorithm between a forward and
+    its backward, or back-propagating after an inference-only pack, must fail loudly instead of running a kernel on an image
+    of another layout."""
+    arch = ARCHS["sp"]
+    B, H, W = 2, 64, 96
+    sd = C.init_state_dict(arch, seed=3)
+    e = _engine(arch, B, H, W, sd)
+    x = torch.rand(B, 1, H, W, device=_dev())
+    out = e.forward(x, slot=0, train=True)
+    e.set_conv_algo(10)
+    with pytest.raises(RuntimeError, match="conv algorithm changed"):
+        e.backward(0, torch.zeros_like(out["semi"]), torch.zeros_like(out["desc"]), None)
+    e.set_conv_algo(1)
+    # forward of ANOTHER shape on the other slot, then the backward of slot 0: the record, not the shape, picks the kernels
+    tsd = C.to_torch(sd, requires_grad=True)
+    ref = C.forward(tsd, x.cpu(), arch)
+    gs = {k: torch.randn_like(ref[k]) for k in ref}
+    sum((ref[k] * gs[k]).sum() for k in ref).backward()
+    e.forward(x, slot=0, train=True)
+    e.forward(torch.rand(1, 1, 32, 48, device=_dev()), slot=1, train=True)
+    e.zero_grad()
+    e.backward(0, gs["semi"].to(_dev()), gs["desc"].to(_dev()), None)
+    torch.cuda.synchronize()
+    gd = e.grad_dict()
+    for k in ("convPa.weight", "down2.mpconv.1.conv.3.weight", "inc.conv.conv.3.weight"):
+        l2, _ = _rel(gd[k].cpu(), tsd[k].grad)
+        assert l2 < 5e-2, (k, l2)  # 8x12-cell maps: single gate flips dominate (see tests/test_gpu_model.py::_grad_close)
+
+
+def test_loaded_binary_keeps_the_accumulation_register_contract():
+    """The .so THIS process loaded (on the GPU box: the one shipped with the snapshot) is disassembled and checked:
+    conv_wino4_kernel's fixed accumulation registers are touched by its inline asm only, no scratch, no spills."""
+    from semantic_superpoint_amd import hipbuild
+    from semantic_superpoint_amd.lib import load_library
+    lib = load_library()
+    rep = hipbuild.verify_binary(lib._name)
+    assert len([k for k in rep if "conv_wino4_kernel" in k]) == 4
+    assert hipbuild.verified(lib._name)
 
 
 # ------------------------------------------------------------------------------------------------

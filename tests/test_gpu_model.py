@@ -18,17 +18,26 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _grad_close(mine, ref, what, l2=1.5e-2, mx=0.1):
-    """Gradients flow through ReLU / max-pool masks: an activation within rounding distance of 0 (about one
-    element per 50k at fp32) may take the other branch than in the oracle.  One such flip in the 8x12 head maps of
-    this test moves dY of that element by O(|dA|) (measured: 5 % of max|dY| at convPa) and the perturbation
-    spreads to every lower layer, so the END-TO-END check is statistical: relative L2 error <= l2 and no element
-    off by more than mx * max|ref|.  Each kernel is checked strictly (1e-4) in tests/test_gpu_ops.py."""
+# End-to-end gradient tolerances.  Every kernel is exact to fp32 rounding (tests/test_gpu_ops.py, 1e-4; the gates-forced
+# comparison of tests/test_gpu_fullsize.py::test_gradient_differences_are_gate_flips_only: 5.6e-6).  What is left end to end
+# are ReLU / max-pool GATE FLIPS: an activation within rounding distance of 0 (about one element per 50 k at fp32) may take
+# the other branch than in the oracle, which moves dY of that element by O(|dA|) and spreads to every lower layer.
+#   * maps of >= 120x160 pixels (>= 15x20 cells): flips average out - measured 2.6e-3 worst per-tensor rel-L2 at 120x160,
+#     B = 2 -> DEFAULT bound l2 <= 5e-3, no element off by more than 5 % of max|ref|;
+#   * the 8x12-cell (64x96) and smaller test shapes: ONE flip in a 96-cell head map is 5 % of max|dY| at convPa (measured),
+#     so those calls pass SMALL explicitly.
+SMALL = dict(l2=1.5e-2, mx=0.1)     # 64x96 inputs (8x12 cells)
+TINY = dict(l2=5e-2, mx=0.1)        # 32x48 / 32x64 / 40x56 inputs (4x6 .. 5x7 cells)
+
+
+def _grad_close(mine, ref, what, l2=5e-3, mx=5e-2):
+    """relative L2 error <= l2 and no element off by more than mx * max|ref| (see the tolerance note above)."""
     mine, ref = mine.double().reshape(-1), ref.double().reshape(-1)
     n = float(ref.norm())
     e2 = float((mine - ref).norm()) / (n + 1e-30)
     em = float((mine - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
     assert e2 <= l2 and em <= mx, (what, "rel-l2 %.3e rel-max %.3e" % (e2, em))
+    return e2
 
 
 def _engine(arch, B, H, W, sd, **kw):
@@ -112,7 +121,7 @@ def test_backward_vs_oracle(arch):
         if k in noisy:  # exact gradient is 0; both sides hold rounding noise of the size of the dY sums
             assert float(mine.abs().max()) < 1e-3 * max(1.0, scale) + 1e-2, k
             continue
-        _grad_close(mine, r, k)
+        _grad_close(mine, r, k, **SMALL)  # 64x96
 
 
 @pytest.mark.parametrize("algo", [1, 0, 10])
@@ -168,7 +177,7 @@ def _negative_gamma_case():
     noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}  # exact gradient 0 (bias before BN)
     for k in C.param_keys(arch):
         if k not in noisy:
-            _grad_close(gd[k].cpu(), tsd[k].grad, k, l2=5e-2, mx=0.1)
+            _grad_close(gd[k].cpu(), tsd[k].grad, k, **TINY)  # 32x64
 
 
 def _zero_gamma_case(exact_tol=1e-4):
@@ -200,9 +209,9 @@ def _zero_gamma_case(exact_tol=1e-4):
             r, mine = tsd[k].grad, gd[k].cpu()
             # the zeroed channels exactly (no ReLU flips possible there: z == beta), the rest statistically
             assert (mine[zeroed] - r[zeroed]).abs().max() <= exact_tol * float(r.abs().max()), k
-            _grad_close(mine, r, k, l2=5e-2, mx=0.1)
+            _grad_close(mine, r, k, **TINY)  # 32x48
     for k in ("inc.conv.conv.3.weight", "inc.conv.conv.0.weight", "down1.mpconv.1.conv.0.weight"):
-        _grad_close(gd[k].cpu(), tsd[k].grad, k, l2=5e-2, mx=0.1)
+        _grad_close(gd[k].cpu(), tsd[k].grad, k, **TINY)
 
 
 def _to_dev(sample):
@@ -218,15 +227,18 @@ def _idx_to_dev(idx, Wc):
 
 @pytest.mark.parametrize("tag,arch,lam", [("sp_64x96", ARCHS[0], 1.0), ("ssp_64x96", ARCHS[1], 1.0),
                                           ("magicpoint_32x48", ARCHS[0], 0.0)])
-def test_pair_step_golden(tag, arch, lam):
+@pytest.mark.parametrize("algo", [1, 10])
+def test_pair_step_golden(tag, arch, lam, algo):
     """G6: the full step (2 forwards + losses + backward + Adam) against the reference's scalars,
-    gradients and post-step eta, with the reference's own sampled indices."""
+    gradients and post-step eta, with the reference's own sampled indices.  algo 10: every 3x3 layer on conv_wino4_kernel
+    (Winograd F(4x4,3x3), the benchmarked kernel of the large maps) with its in-step epilogues."""
     from semantic_superpoint_amd.lib import SCALAR_NAMES
     g = G.load("g6_step_%s.npz" % tag)
     sample = G.sample_from(g)
     B, _, H, W = sample["image"].shape
     sd = C.init_state_dict(arch, seed=23)
     e = _engine(arch, B, H, W, sd)
+    e.set_conv_algo(algo)
     idx = _idx_to_dev(G.indices_from(g, "idx/", B), W // 8) if lam > 0 else None
     e.zero_grad()
     sc = e.pair_step(_to_dev(sample), indices=idx, train=True, lambda_loss=lam, lamda_d=1.0, multi_task=True)
@@ -274,12 +286,18 @@ def test_pair_step_vs_oracle_two_steps(arch):
         idx = _idx_to_dev(tr.aux["indices"], W // 8)
         e.zero_grad()
         sc = e.pair_step(ds, indices=idx, train=True)
+        if it == 0:  # every gradient tensor of the first step at the tight (>= 120x160) bound
+            torch.cuda.synchronize()
+            gd = e.grad_dict()
+            noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+            worst = max(_grad_close(gd[k].cpu(), tr.last_grads[k], k) for k in C.param_keys(arch) if k not in noisy)
+            print("120x160 %s: worst per-tensor gradient rel-L2 %.2e" % (arch, worst))
         e.adam_step(0.001)
         torch.cuda.synchronize()
         sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
         for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
             ref = tr.scalar_dict[name]
-            assert abs(sc[name] - ref) < 2e-3 * max(1.0, abs(ref)), (it, name, sc[name], ref)
+            assert abs(sc[name] - ref) < (2e-4 if it == 0 else 2e-3) * max(1.0, abs(ref)), (it, name, sc[name], ref)
     assert (e.eta.cpu() - tr.eta.detach()).abs().max() < 1e-4
     rv = e.state_dict()
     for k in ("inc.conv.conv.1.running_var", "bnPb.running_mean", "down3.mpconv.1.conv.4.running_var"):
@@ -360,7 +378,7 @@ def test_uniform_sum_loss_and_lamda_d():
     gd = e.grad_dict()
     assert float(gd["eta"].abs().max()) == 0.0  # eta is not in the graph of the uniform sum
     for k in ("convDb.weight", "convPb.weight", "inc.conv.conv.3.weight"):
-        _grad_close(gd[k].cpu(), tr.last_grads[k], k)
+        _grad_close(gd[k].cpu(), tr.last_grads[k], k, **SMALL)  # 64x96
 
 
 def test_gradient_accumulation_over_micro_batches():
@@ -383,7 +401,7 @@ def test_gradient_accumulation_over_micro_batches():
     # the oracle's last_grads holds the ACCUMULATED gradient after micro-batch 2 (cloned before its optimizer step)
     gd = e.grad_dict()
     for k in ("convDb.weight", "convPa.weight", "down1.mpconv.1.conv.0.weight", "bnPb.weight"):
-        _grad_close(gd[k].cpu(), tr.last_grads[k], k)
+        _grad_close(gd[k].cpu(), tr.last_grads[k], k, **SMALL)  # 64x96
     e.adam_step(0.001)
     torch.cuda.synchronize()
     assert (e.eta.cpu() - tr.eta.detach()).abs().max() < 1e-4
@@ -410,7 +428,10 @@ def test_odd_shapes_forward_and_step(B, H, W):
         assert abs(sc[name] - ref) < 2e-3 * max(1.0, abs(ref)), (name, sc[name], ref)
     gd = e.grad_dict()
     for k in ("convDb.weight", "inc.conv.conv.0.weight", "down2.mpconv.1.conv.3.weight"):
-        _grad_close(gd[k].cpu(), tr.last_grads[k], k, l2=3e-2, mx=0.2)
+        if H >= 120:
+            _grad_close(gd[k].cpu(), tr.last_grads[k], k)  # 120x160: the tight default
+        else:  # batch 1 at 64x96 (96 cells in the whole batch) / 40x56 (5x7 cells): single flips dominate
+            _grad_close(gd[k].cpu(), tr.last_grads[k], k, l2=3e-2, mx=0.2)
 
 
 @pytest.mark.parametrize("algo", [0, 2, 5, 6, 10])
@@ -438,7 +459,7 @@ def test_conv_algorithms_agree_on_a_training_step(algo):
         L.set_conv_algo(1)
     for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist"):
         assert abs(out[1][0][name] - out[algo][0][name]) < 1e-4 * max(1.0, abs(out[1][0][name])), name
-    _grad_close(out[algo][1], out[1][1], "flat gradient, algo %d vs 1" % algo)
+    _grad_close(out[algo][1], out[1][1], "flat gradient, algo %d vs 1" % algo, **SMALL)  # 64x96
 
 
 def test_bf16_operand_mode_tracks_the_fp32_step():
@@ -503,3 +524,84 @@ def test_bf16x2_mode_tracks_the_fp32_step(arch):
     g1, g7 = out[1][2], out[7][2]
     assert float((g1 - g7).norm() / g1.norm()) < 1e-2
     print("bf16x2 vs fp32: worst per-tensor gradient rel-L2 %.2e" % worst)
+
+
+@pytest.mark.parametrize("arch", ARCHS)
+def test_mixed_bf16_mode_tracks_the_fp32_step(arch):
+    """ssp_set_conv_algo(8) = `bench.py --dtype bf16`, the BASELINE configs[3] candidate ("bf16 compute / fp32 master"):
+    forward 3x3 convolutions with split-bf16 (hi + lo) operands, data / weight gradients with one bf16 part, fp32 storage,
+    accumulation, BatchNorm, master weights and Adam.  Against the fp32 step at 120x160, B = 2: losses within 1e-3, every
+    gradient tensor within 2e-2 relative L2 (one-part backward operands add unbiased 2^-9 noise on top of the gate flips of
+    the 16-bit forward products), flat gradient within 5e-3, cosine > 0.9999."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    B, H, W = 2, 120, 160
+    sd = C.init_state_dict(arch, seed=21)
+    sample = _to_dev(C.make_synthetic_pair(B, H, W, seed=6, semantic=arch.endswith("ssmall"), kp_prob=0.005))
+    out = {}
+    for a in (1, 8):
+        e = _engine(arch, B, H, W, sd)
+        e.set_conv_algo(a)
+        e.zero_grad()
+        sc = e.pair_step(sample, indices=None, seed=3, train=True)
+        torch.cuda.synchronize()
+        out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), {k: v.clone().cpu().double() for k, v in e.grad_dict().items()},
+                  e.grads.clone().cpu().double())
+    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
+        assert abs(out[1][0][name] - out[8][0][name]) < 1e-3 * max(1.0, abs(out[1][0][name])), name
+    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+    worst = (0.0, "")
+    for k, g1 in out[1][1].items():
+        if k in noisy or k == "eta":
+            continue
+        rel = float((g1 - out[8][1][k]).norm() / (g1.norm() + 1e-30))
+        worst = max(worst, (rel, k))
+        assert rel <= 2e-2, (k, rel)
+    g1, g8 = out[1][2], out[8][2]
+    flat = float((g1 - g8).norm() / g1.norm())
+    print("mixed bf16 vs fp32 (%s, 120x160): worst per-tensor rel-L2 %.2e (%s), flat %.2e" % (arch, worst[0], worst[1], flat))
+    assert flat < 5e-3
+    assert float((g1 * g8).sum() / (g1.norm() * g8.norm())) > 0.9999
+
+
+def test_mixed_bf16_mode_at_the_benchmark_size():
+    """The same comparison at B = 32, 240x320 (SSp, configs[3]'s per-GPU shape; tools/bf16_grad_probe.py measured 1.4e-2
+    worst per tensor, 3.7e-3 flat): per-tensor <= 2e-2, flat <= 5e-3, every scalar within 1e-3; then 10 optimizer steps
+    in mode 8 stay finite and lower the loss."""
+    from semantic_superpoint_amd import synth
+    from semantic_superpoint_amd.lib import SCALAR_NAMES, layer_table
+    arch = ARCHS[1]
+    B, H, W = 32, 240, 320
+    sd = synth.default_init_state_dict(layer_table(arch), seed=0)
+    sample = synth.make_pair(B, H, W, _dev(), seed=100, semantic=True)
+    e = _engine(arch, B, H, W, sd)
+    out = {}
+    for a in (1, 8):
+        e.set_conv_algo(a)
+        e.load_state_dict(sd)
+        e.zero_grad()
+        sc = e.pair_step(sample, indices=None, seed=7, train=True)
+        torch.cuda.synchronize()
+        out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), {k: v.clone().double() for k, v in e.grad_dict().items()},
+                  e.grads.clone().double())
+    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
+        assert abs(out[1][0][name] - out[8][0][name]) < 1e-3 * max(1.0, abs(out[1][0][name])), name
+    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+    worst = (0.0, "")
+    for k, g1 in out[1][1].items():
+        if k in noisy or k == "eta":
+            continue
+        worst = max(worst, (float((g1 - out[8][1][k]).norm() / (g1.norm() + 1e-30)), k))
+    flat = float((out[1][2] - out[8][2]).norm() / out[1][2].norm())
+    print("mixed bf16 vs fp32 (B = 32, 240x320): worst per-tensor rel-L2 %.2e (%s), flat %.2e" % (worst[0], worst[1], flat))
+    assert worst[0] <= 2e-2 and flat <= 5e-3, (worst, flat)
+    e.load_state_dict(sd)
+    first = last = None
+    for it in range(10):
+        e.zero_grad()
+        sc = e.pair_step(sample, indices=None, seed=1000 + it, train=True)
+        e.adam_step(0.001)
+        if it in (0, 9):
+            v = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+            assert all(np.isfinite(x) for x in v.values()), v
+            first, last = (v, last) if it == 0 else (first, v)
+    assert last["loss"] < first["loss"], (first["loss"], last["loss"])
