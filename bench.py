@@ -86,7 +86,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8, 9, 10],
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11],
                     help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
                          "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
                          "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "

@@ -654,7 +654,43 @@ struct WredJob {
   float* dw;
   int cin, cout, ncob, nsplit;
   int block0;
+  int f4;  // 0: 16-component slabs of wgrad_wino_kernel (ncob = 64-channel blocks); 1: 9-tap slabs [9][64][32] of
+           // wgrad_wino4_kernel, already through G^T . G (ncob = 32-channel blocks)
 };
+
+// wgrad_wino4_kernel's partial slabs [pair * nsplit + k][9 taps][64 ci][32 co] summed over the splits and ACCUMULATED into
+// the OIHW gradient.  block = 256 threads = 32 consecutive co x 8 split groups, one input channel per block.
+__device__ __forceinline__ void wgrad_wino4_reduce_block(const float* __restrict__ partial, float* __restrict__ dw, int Cin,
+                                                         int Cout, int ncob, int nsplit, int bid, float* red) {
+  const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int cob = bid % ncob, ci = bid / ncob;
+  const int co = cob * 32 + o, cib = ci >> 6;
+  float m[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) m[t] = 0.f;
+  const float* src = partial + (size_t)((cib * ncob + cob) * nsplit) * (9 * 2048) + (ci & 63) * 32 + o;
+  for (int k = grp; k < nsplit; k += 8)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) m[t] += src[((size_t)k * 9 + t) * 2048];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[(grp * 9 + t) * 32 + o] = m[t];
+  __syncthreads();
+  if (grp != 0 || co >= Cout) return;
+  float* out = dw + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += red[(g * 9 + t) * 32 + o];
+    out[t] += s;
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_wino4_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                 int Cin, int Cout, int ncob, int nsplit) {
+  __shared__ float red[8 * 9 * 32];
+  wgrad_wino4_reduce_block(partial, dw, Cin, Cout, ncob, nsplit, blockIdx.x, red);
+}
+
 constexpr int WRED_MAX_JOBS = 16;
 struct WredJobs {
   int n;
@@ -665,7 +701,8 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_multi_kernel(const Wred
   int k = 0;
   while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;
   const WredJob& q = J.j[k];
-  wgrad_wino_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, red);
+  if (q.f4) wgrad_wino4_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, &red[0][0][0]);
+  else wgrad_wino_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, red);
 }
 
 // OIHW 3x3 weights -> U = G g G^T in the LDS image of conv_wino_kernel: [cob][chunk][component][g][h][64][4].

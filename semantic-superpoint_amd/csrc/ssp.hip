@@ -19,6 +19,7 @@
 #include "conv_wino_pipe.hip.h"
 #include "conv_wino_p2.hip.h"
 #include "conv_wino4.hip.h"
+#include "wgrad_wino4.hip.h"
 #include "conv_wino_bf16.hip.h"
 #include "loss_kernels.hip.h"
 #include "dense_loss.hip.h"
@@ -42,7 +43,8 @@ static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks
 // part in the data-gradient and weight-gradient kernels (unbiased 2^-9 noise on the gradients, like any bf16 training)
 // fp32 pipelined Winograd family: 1 (default: F(4x4,3x3) on the large maps - conv_uses_w4 -, F(2x2,3x3) elsewhere), 9 = F(2x2,3x3)
 // only (the default of rounds 1-2), 10 = F(4x4,3x3) wherever legal
-static inline bool pipe_algo() { return g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10; }
+// 11 = algorithm 1 with the Winograd F(3x3,4x4) weight gradient (wgrad_wino4_kernel: opt-in, measured not faster)
+static inline bool pipe_algo() { return g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10 || g_conv_algo == 11; }
 static inline bool bf16_algo() { return g_conv_algo == 3 || g_conv_algo == 7 || g_conv_algo == 8; }
 static inline int bf16_parts(bool backward) { return g_conv_algo == 7 || (g_conv_algo == 8 && !backward) ? 2 : 1; }
 static inline int pk_taps(int ks) { return ks == 3 ? W4C : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
@@ -501,7 +503,7 @@ static void w4_geometry(int H, int W, bool& wide, int& tiles_y, int& tiles_x) {
 // (measured 1.2x / 1.15x faster than F(2x2,3x3) on the 64 -> 64 layers at 240x320 / 120x160; the 60x80 layers of a
 // 32-pair step gain 0.7 % of the step, the 30x40 ones nothing).
 static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int cin, int cout) {
-  if (g_conv_algo != 1 && g_conv_algo != 10) return false;
+  if (g_conv_algo != 1 && g_conv_algo != 10 && g_conv_algo != 11) return false;
   if (cin % 8 != 0) return false;
   if (g_conv_algo == 10) return true;
   bool wide; int ty, tx;
@@ -660,6 +662,19 @@ static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) 
   return 0;
 }
 
+template <int IN_MODE, bool WIDE>
+static int launch_wgrad_wino4_t(const WgradArgs& a, int nblocks, hipStream_t st) {
+  using G = Wgrad4Geom<WIDE>;
+  static AttrOnce attr_once;
+  auto kern = wgrad_wino4_kernel<IN_MODE, WIDE>;
+  if (attr_once.need()) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WG4_THREADS), G::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <int IN_MODE, bool WIDE, int NT = 1>
 static int launch_wgrad_wino_bf16_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using G = WgradWinoGeom<WIDE>;
@@ -706,30 +721,37 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.ablate = g_dbg_ablate;
   const bool wide = (c.W % 32) == 0;
   // Winograd F(3x3,2x2): 3x3 filters on even-sized maps with a prefetchable (non-pooled) input
-  const bool wino = g_conv_algo != 0 && c.ks == 3 && c.in_mode != 2 && c.H % 2 == 0 && c.W % 2 == 0;
+  // Winograd F(3x3,4x4) (wgrad_wino4_kernel: 1/4 of the direct multiplies), OPT-IN: conv algorithm 11 (= algorithm 1 with this
+  // weight gradient) or SSP_WGRAD_F4=1 under algorithms 1 / 10.  Correct on every 3x3 layer with a prefetchable input and any
+  // map size (dY is zero-filled outside the map); 64 ci x 32 co slabs over the same 128-pixel block tiles as F(3x3,2x2).
+  // Not the default: measured equal at 240x320 and 10-50 % slower below (profiles/r03_wgrad4_ablation.txt, DESIGN.md s. 12).
+  static const int wg4_env = getenv("SSP_WGRAD_F4") ? atoi(getenv("SSP_WGRAD_F4")) : 0;
+  const bool wino4 = (g_conv_algo == 11 || (wg4_env != 0 && (g_conv_algo == 1 || g_conv_algo == 10))) && c.ks == 3 && c.in_mode != 2;
+  const bool wino = wino4 || (g_conv_algo != 0 && c.ks == 3 && c.in_mode != 2 && c.H % 2 == 0 && c.W % 2 == 0);
   if (wino && ((double)c.H * c.W * std::max(c.in_cs, c.dout_cs) * 4.0 > 2147483647.0))
     return fail(-3, "wgrad: one image [%d,%d,%d] exceeds 2 GiB", c.H, c.W, std::max(c.in_cs, c.dout_cs));
   const int TH = wino ? (wide ? 4 : 16) : (wide ? 2 : 8), TW = wide ? 32 : 8;
   a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
   a.ntiles = c.N * a.tiles_x * a.tiles_y;
-  a.ncib = cdiv(c.cin, 64); a.ncob = cdiv(c.cout, 64);
+  a.ncib = cdiv(c.cin, 64); a.ncob = cdiv(c.cout, wino4 ? 32 : 64);
   const int pairs = a.ncib * a.ncob;
-  const int taps = wino ? WC : c.ks * c.ks;  // slabs per partial block
+  const int taps = wino ? WC : c.ks * c.ks;  // 64 x 64 slabs per partial block
+  const size_t slab = wino4 ? (size_t)WG4_SLAB : (size_t)taps * 4096;  // floats per partial block
   int nsplit = ((wino ? 1 : 2) * n_cu) / pairs / 8 * 8;  // blocks per CU; multiple of 8: blocks sharing tiles share an XCD
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.ntiles * a.nprob) nsplit = a.ntiles * a.nprob;
-  while ((size_t)pairs * nsplit * taps * 4096 > partial_floats && nsplit > 1) --nsplit;
-  if ((size_t)pairs * nsplit * taps * 4096 > partial_floats) return fail(-4, "wgrad scratch too small");
+  while ((size_t)pairs * nsplit * slab > partial_floats && nsplit > 1) --nsplit;
+  if ((size_t)pairs * nsplit * slab > partial_floats) return fail(-4, "wgrad scratch too small");
   a.nsplit = nsplit;
   const int nblocks = pairs * nsplit;
   // engine launches (partial == the handle's buffer): Winograd slabs stay in their own slice until flush_wgrad_reduce
   const bool deferred = wino && h != nullptr && partial == h->partial;
   if (deferred) {
-    const size_t need = (size_t)pairs * nsplit * taps * 4096;
+    const size_t need = (size_t)pairs * nsplit * slab;
     if (h->partial_used + need > partial_floats || h->rjobs.n == WRED_MAX_JOBS) CHK(flush_wgrad_reduce(h, st));
     a.partial = partial + h->partial_used;
     WredJob& q = h->rjobs.j[h->rjobs.n];
-    q.partial = a.partial; q.dw = c.dw; q.cin = c.cin; q.cout = c.cout; q.ncob = a.ncob; q.nsplit = nsplit;
+    q.partial = a.partial; q.dw = c.dw; q.cin = c.cin; q.cout = c.cout; q.ncob = a.ncob; q.nsplit = nsplit; q.f4 = wino4 ? 1 : 0;
     q.block0 = h->rjobs.n ? h->rjobs.j[h->rjobs.n - 1].block0 + h->rjobs.j[h->rjobs.n - 1].ncob * h->rjobs.j[h->rjobs.n - 1].cin : 0;
     ++h->rjobs.n;
     h->partial_used += need;
@@ -739,9 +761,12 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   {
     const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
     const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
-    ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes, flops * (wino ? 16.0 / 36.0 : 1.0),
-                 wino && !bf16_algo() ? SSP_PROF_K_WGRAD_WINO : SSP_PROF_K_OTHER);
-    if (wino && bf16_algo() && bf16_parts(true) == 1) {
+    ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes, flops * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0),
+                 wino4 ? SSP_PROF_K_WGRAD_WINO4 : wino && !bf16_algo() ? SSP_PROF_K_WGRAD_WINO : SSP_PROF_K_OTHER);
+    if (wino4) {
+      if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino4_t<0, true>(a, nblocks, st) : launch_wgrad_wino4_t<0, false>(a, nblocks, st)));
+      else CHK((wide ? launch_wgrad_wino4_t<1, true>(a, nblocks, st) : launch_wgrad_wino4_t<1, false>(a, nblocks, st)));
+    } else if (wino && bf16_algo() && bf16_parts(true) == 1) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_bf16_t<1, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false>(a, nblocks, st)));
     } else if (wino && bf16_algo()) {
@@ -752,7 +777,10 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
       else CHK((wide ? launch_wgrad_wino_t<1, true>(a, nblocks, st) : launch_wgrad_wino_t<1, false>(a, nblocks, st)));
     }
     if (wino) {
-      if (!deferred)
+      if (!deferred && wino4)
+        hipLaunchKernelGGL(wgrad_wino4_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
+                           a.ncob, nsplit);
+      else if (!deferred)
         hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
                            a.ncob, nsplit);
       HIPCHK(hipGetLastError());
@@ -1179,7 +1207,8 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     // both passes recompute Y0 from the image instead of reading S.Y[0]
     const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel, h, SS.n, (long)N * H, W);
     const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel, h, SS.n, (long)N * H, W);
-    hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
+    if (!fused)  // else: S1 / S2 were accumulated by the data-gradient conv of layer 1 (setup_bnr)
+      hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                        Gd(h, d.w_off));
@@ -1210,7 +1239,9 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
 // Ask the data-gradient conv `c` (output = gradient wrt the activation of layer src) to accumulate pass 1 of layer src's
 // BatchNorm backward in its epilogue; records the fact for bn_layer_backward(src).
 static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, ConvCall& c) {
-  if (src < 1 || !h->L[src].bn || !can_fuse_bnr(c) || c.out_co != 0 || c.out_cs != c.cout || c.cout != h->L[src].cout) return;
+  // (src == 0 too: the first layer's pass 1 then reads Y0 inside the MFMA-bound data-gradient launch of layer 1 instead of
+  // running bn_bwd_reduce_l0_kernel, an HBM-bound pass over dOut0 of its own)
+  if (src < 0 || !h->L[src].bn || !can_fuse_bnr(c) || c.out_co != 0 || c.out_cs != c.cout || c.cout != h->L[src].cout) return;
   const LayerDesc& ds = h->L[src];
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
@@ -1630,7 +1661,7 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
-  if (algo < 0 || algo > 10 || algo == 4) return fail(-1, "conv algo must be 0..3 or 5..10 (see ssp_set_conv_algo)");
+  if (algo < 0 || algo > 11 || algo == 4) return fail(-1, "conv algo must be 0..3 or 5..11 (see ssp_set_conv_algo)");
   h->conv_algo = algo;
   return 0;
 }
@@ -2042,11 +2073,12 @@ int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 10 || algo == 4)
+  if (algo < 0 || algo > 11 || algo == 4)
     return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
                     "operands), 5 (Winograd, pipelined, weights staged through LDS), 6 (Winograd, two 4-wave workgroups per CU) "
                     ", 7 (Winograd, split-bf16 hi + lo operands), 8 (forward split-bf16, backward bf16), 9 (Winograd "
-                    "F(2x2,3x3) only: algorithm 1 without F(4x4,3x3) on the large maps) or 10 (F(4x4,3x3) wherever legal)");
+                    "F(2x2,3x3) only: algorithm 1 without F(4x4,3x3) on the large maps), 10 (F(4x4,3x3) wherever legal) or 11 (algorithm 1 "
+                    "with the F(3x3,4x4) weight gradient)");
   g_default_conv_algo = algo;
   return 0;
 }

@@ -314,14 +314,14 @@ def test_f4x4_kernel_accumulators_are_private_to_its_inline_asm(tmp_path):
 def test_shipped_binary_keeps_the_accumulation_register_contract():
     """hipbuild.verify_binary on the in-tree .so (the file that ships with the gpurun snapshot): the gfx950 code object is
     unbundled and disassembled; conv_wino4_kernel must contain exactly its inline asm's accumulation-register instructions
-    (64 MFMAs, 2 x 256 clears, 2 x 256 reads), no scratch, no spilled vector registers, 256 reserved accumulation registers.
+    (64 MFMAs, 2 x 256 clears, 2 x 256 reads; wgrad_wino4_kernel: 256 / 256 / 256), no scratch, no spilled vector registers, 256 reserved accumulation registers.
     A tampered contract (one instruction less expected) must be rejected."""
     from semantic_superpoint_amd import hipbuild
     if not os.path.exists(os.path.join(hipbuild.LLVM_BIN, "llvm-objdump")):
         pytest.skip("llvm binutils not available")
     lib = hipbuild.build()
     rep = hipbuild.verify_binary(lib)
-    assert len(rep) == 4 and all("conv_wino4_kernel" in k for k in rep)
+    assert len([k for k in rep if "conv_wino4_kernel" in k]) == 4 and len([k for k in rep if "wgrad_wino4_kernel" in k]) == 4
     assert hipbuild.verified(lib)
     wrong = {"conv_wino4_kernel": dict(hipbuild.FIXED_AGPR_KERNELS["conv_wino4_kernel"], v_accvgpr_read_b32=511)}
     with pytest.raises(RuntimeError, match="differ from the inline-asm contract"):

@@ -27,8 +27,8 @@ def _ref_input(x_nhwc, in_mode, sc, sh):
     return x
 
 
-@pytest.fixture(params=[1, 0, 2, 5, 6, 7, 10], ids=["winograd_pipelined", "direct", "winograd_unpipelined", "winograd_lds_weights",
-                                                     "winograd_two_workgroups", "winograd_bf16x2", "winograd_f4x4"])
+@pytest.fixture(params=[1, 0, 2, 5, 6, 7, 10, 11], ids=["winograd_pipelined", "direct", "winograd_unpipelined", "winograd_lds_weights",
+                                                         "winograd_two_workgroups", "winograd_bf16x2", "winograd_f4x4", "wgrad_f3x3_4x4"])
 def conv_algo(request):
     """ssp_set_conv_algo: every convolution / weight-gradient operator test runs under the fp32 implementations
     (1 = default: software-pipelined Winograd; 0 = direct implicit GEMM; 2 = Winograd without the software pipeline;
@@ -36,7 +36,8 @@ def conv_algo(request):
     6 = the second-generation pipelined Winograd kernel: two independent 4-wave workgroups per CU;
     7 = split-bf16 operands (hi + lo, 16 significant bits, three bf16 MFMAs per product block, fp32 accumulation):
     product rounding ~2^-16, i.e. ~1e-5 of the output scale - inside this file's 2e-4 tolerance;
-    10 = Winograd F(4x4,3x3) (conv_wino4_kernel) on every 3x3 convolution it can run, F(2x2,3x3) elsewhere)."""
+    10 = Winograd F(4x4,3x3) (conv_wino4_kernel) on every 3x3 convolution it can run, F(2x2,3x3) elsewhere;
+    11 = algorithm 1 with the Winograd F(3x3,4x4) weight gradient, wgrad_wino4_kernel (opt-in: correct, not faster))."""
     from semantic_superpoint_amd import lib as L
     L.set_conv_algo(request.param)
     yield request.param

@@ -37,13 +37,14 @@ def test_warp_labels_full_golden():
         assert torch.equal(out.cpu()[0], t(g["labels%d" % k])), k
         # residuals / bilinear weights = fp32 coordinates: the device applies ONE fixed operation order (the fma chain of
         # oneMKL's AVX-512 sgemm, bit-equal to torch in the build container: tests/test_boundary_cpu.py); torch on another
-        # host CPU may take a kernel that differs in the last ulp (4e-6 at x ~ 50), so fixtures and the live oracle are
-        # compared at 1e-5 - the integer label positions above are equal in every case
+        # host CPU may take a kernel that differs in the last ulp (one ulp of a coordinate in [128, 256) is 1.5e-5, in
+        # [256, 512) 3.05e-5; measured 1.1e-5 on the GPU host), so fixtures and the live oracle are compared at 4e-5 - the
+        # integer label positions above are equal in every case
         o_lab, o_res, o_bi = C.warp_labels_full(pts, H, W, t(g["H%d" % k]))
         assert torch.equal(out.cpu()[0], o_lab), k
-        assert (res.cpu()[0] - o_res).abs().max() < 1e-5 and (bi.cpu()[0] - o_bi).abs().max() < 1e-5, k
-        assert (res.cpu()[0] - t(g["res%d" % k])).abs().max() < 1e-5, k
-        assert (bi.cpu()[0] - t(g["bi%d" % k])).abs().max() < 1e-5, k
+        assert (res.cpu()[0] - o_res).abs().max() < 4e-5 and (bi.cpu()[0] - o_bi).abs().max() < 4e-5, k
+        assert (res.cpu()[0] - t(g["res%d" % k])).abs().max() < 4e-5, k
+        assert (bi.cpu()[0] - t(g["bi%d" % k])).abs().max() < 4e-5, k
         out2, res2, bi2 = L.op_warp_labels_full(lab.to(_dev()), t(g["H%d" % k]).view(1, 3, 3), exact=False)
         assert float((out2.cpu()[0] != t(g["labels%d" % k])).float().sum()) <= 2, k  # a rounding tie may move a point
 
