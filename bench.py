@@ -202,7 +202,7 @@ def live_pmc(args):
                 notes.append("no counter_collection.csv for %s" % " ".join(ctrs))
                 continue
             for row in csv.DictReader(open(files[0])):
-                k = next((k for k in PMC_KERNELS if k in row["Kernel_Name"]), None)
+                k = next((k for k in PMC_KERNELS if k in row["Kernel_Name"].replace("wgrad_wino_fused_kernel", "wgrad_wino_kernel")), None)
                 if k is None or row["Counter_Name"] not in ctrs:
                     continue
                 e = tot.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, set()])

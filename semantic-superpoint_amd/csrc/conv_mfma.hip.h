@@ -450,6 +450,19 @@ struct WgradArgs {
   int tiles_x, tiles_y, ntiles;  // per-image tiles and total tiles of ONE problem
   int ncib, ncob, nsplit;
   int ablate;  // perf-debug only (wgrad_wino_kernel): 1 no global loads, 2 no LDS writes, 8 no MFMA loop, 64 no LDS reads
+  // wgrad_wino_fused_kernel: the APPLY pass of this layer's BatchNorm + ReLU + MaxPool backward rides the dY staging.
+  // dout / dout2 then hold the gradient wrt the POOLED activation [N,H/2,W/2,dout_cs]; f_y = the layer's raw conv output
+  // [N,H,W,f_ycs] (channel offset 0), f_dy = dY written for the data-gradient convolution (same geometry as f_y); per
+  // problem k: scale / shift / mean / invstd of the layer and f_k12 = {S1/n, S2/n} (bn_bwd_sums_kernel); f_gamma shared.
+  const float* f_y[2] = {nullptr, nullptr};
+  float* f_dy[2] = {nullptr, nullptr};
+  const float* f_scale[2] = {nullptr, nullptr};
+  const float* f_shift[2] = {nullptr, nullptr};
+  const float* f_mean[2] = {nullptr, nullptr};
+  const float* f_invstd[2] = {nullptr, nullptr};
+  const float* f_k12[2] = {nullptr, nullptr};
+  const float* f_gamma = nullptr;
+  int f_ycs = 0;
 };
 
 template <int KS, int SH, int SW>

@@ -20,6 +20,7 @@
 #include "conv_wino_p2.hip.h"
 #include "conv_wino4.hip.h"
 #include "wgrad_wino4.hip.h"
+#include "wgrad_wino_fused.hip.h"
 #include "conv_wino_bf16.hip.h"
 #include "loss_kernels.hip.h"
 #include "dense_loss.hip.h"
@@ -139,6 +140,7 @@ struct ssp_handle {
   size_t partial_used = 0;  // ... and the slices are reduced into the gradients by ONE launch (flush_wgrad_reduce)
   WredJobs rjobs{};
   bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
+  bool apply_fused[16] = {};  // pass 2 (APPLY) of layer l was left to the layer's weight gradient (wgrad_wino_fused_kernel)
   StepAccum* accum;
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
   float* dense_coef; // [B * cells * cells] d total / d dot of the dense descriptor loss (cfg.dense_loss), else nullptr
@@ -662,6 +664,19 @@ static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) 
   return 0;
 }
 
+template <int IN_MODE, bool WIDE, bool POOL>
+static int launch_wgrad_wino_fused_t(const WgradArgs& a, int nblocks, hipStream_t st) {
+  using GF = WgradFusedGeom<WIDE>;
+  static AttrOnce attr_once;
+  auto kern = wgrad_wino_fused_kernel<IN_MODE, WIDE, POOL>;
+  if (attr_once.need()) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GF::LDS_BYTES));
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), GF::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <int IN_MODE, bool WIDE>
 static int launch_wgrad_wino4_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using G = Wgrad4Geom<WIDE>;
@@ -697,7 +712,25 @@ struct WgradCall {
   int nprob = 1;  // optional second problem accumulated into the same gradient
   const float* in2 = nullptr; const float* dout2 = nullptr;
   const float* in_scale2 = nullptr; const float* in_shift2 = nullptr;
+  // fused BatchNorm + ReLU + MaxPool backward APPLY (wgrad_wino_fused_kernel, WgradArgs::f_*): dout / dout2 = pooled gradient
+  bool fuse_apply = false, fuse_pool = false;  // fuse_pool: the layer is followed by MaxPool2d(2) (dout = pooled gradient)
+  const float* f_y[2] = {nullptr, nullptr};
+  float* f_dy[2] = {nullptr, nullptr};
+  const float* f_scale[2] = {nullptr, nullptr}; const float* f_shift[2] = {nullptr, nullptr};
+  const float* f_mean[2] = {nullptr, nullptr}; const float* f_invstd[2] = {nullptr, nullptr};
+  const float* f_k12[2] = {nullptr, nullptr};
+  const float* f_gamma = nullptr;
+  int f_ycs = 0;
 };
+
+// Can the weight gradient of a layer whose output feeds BatchNorm + ReLU + MaxPool2d(2) take that layer's APPLY pass along
+// (wgrad_wino_fused_kernel)?  fp32 Winograd F(3x3,2x2) weight gradient, even map, whole 4-channel quads, dense y / dY.
+static bool wgrad_can_fuse_apply(int ks, int in_mode, int H, int W, int cout, int y_cs, int y_co) {
+  static const int env = getenv("SSP_FUSE_APPLY") ? atoi(getenv("SSP_FUSE_APPLY")) : 1;  // (perf-debug A/B)
+  static const int f4 = getenv("SSP_WGRAD_F4") ? atoi(getenv("SSP_WGRAD_F4")) : 0;        // (forces wgrad_wino4_kernel)
+  return env != 0 && f4 == 0 && (g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10) && ks == 3 && in_mode != 2 && H % 2 == 0 &&
+         W % 2 == 0 && cout % 4 == 0 && y_cs == cout && y_co == 0;
+}
 
 // sums the pending partial slabs of the deferred Winograd weight-gradient launches into the OIHW gradients
 static int flush_wgrad_reduce(ssp_handle* h, hipStream_t st) {
@@ -719,6 +752,13 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.Cout = c.cout; a.dout_cs = c.dout_cs; a.dout_co = c.dout_co;
   a.nprob = c.nprob; a.in2 = c.in2; a.dout2 = c.dout2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
   a.ablate = g_dbg_ablate;
+  if (c.fuse_apply) {
+    for (int k = 0; k < 2; ++k) {
+      a.f_y[k] = c.f_y[k]; a.f_dy[k] = c.f_dy[k]; a.f_scale[k] = c.f_scale[k]; a.f_shift[k] = c.f_shift[k];
+      a.f_mean[k] = c.f_mean[k]; a.f_invstd[k] = c.f_invstd[k]; a.f_k12[k] = c.f_k12[k];
+    }
+    a.f_gamma = c.f_gamma; a.f_ycs = c.f_ycs;
+  }
   const bool wide = (c.W % 32) == 0;
   // Winograd F(3x3,2x2): 3x3 filters on even-sized maps with a prefetchable (non-pooled) input
   // Winograd F(3x3,4x4) (wgrad_wino4_kernel: 1/4 of the direct multiplies), OPT-IN: conv algorithm 11 (= algorithm 1 with this
@@ -763,7 +803,13 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
     const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
     ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes, flops * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0),
                  wino4 ? SSP_PROF_K_WGRAD_WINO4 : wino && !bf16_algo() ? SSP_PROF_K_WGRAD_WINO : SSP_PROF_K_OTHER);
-    if (wino4) {
+    if (c.fuse_apply) {
+      if (!wino || wino4 || bf16_algo()) return fail(-3, "fused BatchNorm apply needs the fp32 F(3x3,2x2) weight gradient");
+#define WGF_CASE(M_, P_) \
+      if (c.in_mode == M_ && c.fuse_pool == P_) CHK((wide ? launch_wgrad_wino_fused_t<M_, true, P_>(a, nblocks, st) : launch_wgrad_wino_fused_t<M_, false, P_>(a, nblocks, st)));
+      WGF_CASE(0, false) WGF_CASE(0, true) WGF_CASE(1, false) WGF_CASE(1, true)
+#undef WGF_CASE
+    } else if (wino4) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino4_t<0, true>(a, nblocks, st) : launch_wgrad_wino4_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino4_t<1, true>(a, nblocks, st) : launch_wgrad_wino4_t<1, false>(a, nblocks, st)));
     } else if (wino && bf16_algo() && bf16_parts(true) == 1) {
@@ -833,7 +879,7 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
 // pass 1 (sums) -> replica reduction + dgamma/dbeta -> pass 2 (apply); a[0 .. nviews-1] ride the same launches
 template <bool RELU, bool POOL>
 static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* dbeta, hipStream_t st,
-                         bool sums_done = false) {
+                         bool sums_done = false, bool skip_apply = false) {
   // a.dbias (conv bias gradient, may be null) is produced by bn_bwd_sums_kernel
   const BnBwdArgs& a0 = a[0];
   const BnBwdArgs& a1 = a[nviews - 1];
@@ -844,7 +890,8 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
   if (!sums_done)  // else: pass 1 was accumulated by the data-gradient conv that produced dOut
     hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a0.C * 32, 256)), dim3(256), 0, st, a0, a1, nviews, dgamma, dbeta);
-  hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
+  if (!skip_apply)  // else: pass 2 rides the layer's weight gradient (wgrad_wino_fused_kernel)
+    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1228,9 +1275,20 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
       hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[1]);
     }
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
-    hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
+    // pass 2: inside the layer's weight gradient (it stages dY anyway and writes it for the data gradient) where possible
+    // (the pooled layers 1, 3, 5 read the un-pooled activation of layers 0, 2, 4: input mode 1)
+    const bool defer = l >= 1 && l < 8 && layer_in_mode(l) == 1 && dy_cs == d.cout && dy_co == 0 &&
+                       wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout, SS.s[0]->y_cs[l], SS.s[0]->y_co[l]);
+    h->apply_fused[l] = defer;
+    if (!defer) hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
   } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st, fused)));
-  else if (relu) CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused)));
+  else if (relu) {
+    // encoder layers 2, 4, 6, 7 (dense [N,H,W,C] tensors): pass 2 inside the weight gradient as well
+    const bool defer = l >= 1 && l < 8 && d_cs == d.cout && d_co == 0 && dy_cs == d.cout && dy_co == 0 &&
+                       wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout, SS.s[0]->y_cs[l], SS.s[0]->y_co[l]);
+    h->apply_fused[l] = defer;
+    CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused, defer)));
+  }
   else CHK((launch_bn_bwd<false, false>(a, SS.n, dg, db, st)));
   HIPCHK(hipGetLastError());
   return 0;
@@ -1300,6 +1358,20 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
     c.nprob = 2; c.in2 = dy[1]; c.out2 = din[1];
   }
   if (d.ks == 3 && src < 8) setup_bnr(h, SS, src, pooled, c);  // layer src: BatchNorm + ReLU (+ pool) of the encoder
+  if (l < 8 && h->apply_fused[l]) {
+    // bn_layer_backward(l) ran the sums only: dOut of the pooled activation still sits in gP (= din, which the data-gradient
+    // conv overwrites AFTER the weight gradient has consumed it: same stream), dY is produced into dy[] by the weight gradient
+    h->apply_fused[l] = false;
+    w.fuse_apply = true;
+    w.fuse_pool = (l == 1 || l == 3 || l == 5);
+    w.dout_cs = d.cout; w.dout_co = 0; w.f_gamma = P(h, d.g_off); w.f_ycs = A.y_cs[l];
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      (k ? w.dout2 : w.dout) = din[k];
+      w.f_y[k] = S.Y[l]; w.f_dy[k] = dy[k]; w.f_scale[k] = S.bn[l].scale; w.f_shift[k] = S.bn[l].shift;
+      w.f_mean[k] = S.bn[l].mean; w.f_invstd[k] = S.bn[l].invstd; w.f_k12[k] = S.bn[l].k12;
+    }
+  }
   CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_DGRAD : 0));
   return 0;

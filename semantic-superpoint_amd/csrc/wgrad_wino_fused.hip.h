@@ -1,0 +1,312 @@
+// wgrad_wino_kernel (Winograd F(3x3,2x2) weight gradient, conv_wino.hip.h) with the APPLY pass of the layer's own
+// BatchNorm + ReLU + MaxPool2d(2) backward fused into its dY staging:
+//
+//   dY(px) = gamma invstd ( dZ(px) - S1/n - xhat(px) S2/n ),   dZ(px) = dOut(window of px) if px is the FIRST maximum of
+//   relu(z) in its 2x2 window and z(px) > 0, else 0            (bn_bwd_kernel<true, true, true>, torch's max_pool2d routing)
+//
+// Each thread owns one pooling window x 4 output channels of the 128-pixel dY tile: it loads the window's four raw conv
+// outputs y (the same four 16-byte loads the plain kernel spends on dY itself) + ONE pooled gradient quad, evaluates the
+// formula, writes the four dY quads into the LDS tile the MFMA phase reads AND to HBM for the data-gradient convolution of
+// the layer (blocks of the first input-channel block only).  The separate APPLY pass - y read, pooled dOut read, dY write
+// at HBM speed: 0.55 ms per step for the 240x320 layer alone - disappears; the weight gradient is MFMA-bound (2 TB/s of
+// HBM traffic), so the extra quarter-size read and the dY write ride for free; what it pays is ~110 VALU instructions per
+// tile and thread beside 128 MFMAs per wave.
+//
+// POOL = false: the same for a layer followed by BatchNorm + ReLU only (dZ = dOut [z > 0]): a thread's four pixel slots of the
+// plain kernel load y and dOut (8 quads instead of 4) and write dY.
+//
+// Registers: the plain kernel sits at 256 with 2 spills.  The per-thread staging offsets and halo slot coordinates are
+// PARKED IN LDS here (hipcc otherwise hoists every pp / WT, pp % WT out of the tile loop: wgrad_wino4.hip.h).
+#pragma once
+#include "conv_wino.hip.h"
+
+namespace sspk {
+
+template <bool WIDE>
+struct WgradFusedGeom {
+  using G = WgradWinoGeom<WIDE>;
+  static constexpr int NX = (G::HT * G::WT + 31) / 32;  // halo pixels per thread (pp = (tid >> 4) + 32 i)
+  static constexpr int F_FLOATS = 2 * 7 * 64;           // per problem: scale, shift, -mean invstd, invstd, gamma invstd, A, B
+  static constexpr int O_WORDS = (2 * NX + 9) * 512;    // parked per thread: halo offsets, halo coordinates, dY-side offsets / coordinates, mask
+  static constexpr int LDS_BYTES = (G::X_FLOATS + G::D_FLOATS + 256 + F_FLOATS + O_WORDS) * 4;
+};
+
+template <int IN_MODE, bool WIDE, bool POOL>
+__global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a) {
+  using G = WgradWinoGeom<WIDE>;
+  using GF = WgradFusedGeom<WIDE>;
+  constexpr int NX = GF::NX;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem;
+  float* sD = smem + G::X_FLOATS;
+  float* sS = smem + G::X_FLOATS + G::D_FLOATS;
+  float* sF = sS + 256;
+  unsigned* const sO = reinterpret_cast<unsigned*>(sF + GF::F_FLOATS) + threadIdx.x;  // [item][512]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar wave roles
+  const int li = lane & 31, lh = lane >> 5;
+  const int coh = wave & 1, irow = wave >> 1;
+
+  int bid = blockIdx.x;
+  const int split = bid % a.nsplit;
+  bid /= a.nsplit;
+  const int cob = bid % a.ncob;
+  const int cib = bid / a.ncob;
+  const int tot_tiles = a.ntiles * a.nprob;
+  const int per = (tot_tiles + a.nsplit - 1) / a.nsplit;
+  const int t_begin = split * per, t_end = min(tot_tiles, t_begin + per);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][e][r] = 0.f;
+
+  const int q16 = tid & 15;
+  const int ci0 = cib * 64 + q16 * 4;
+  const bool civalid = ci0 < a.Cin;
+  if (IN_MODE != 0 && tid < 32) {
+    const int pr = tid >> 4;
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
+    if (civalid && pr < a.nprob) {
+      sc0 = *reinterpret_cast<const f32x4*>((pr ? a.in_scale2 : a.in_scale) + ci0);
+      sh0 = *reinterpret_cast<const f32x4*>((pr ? a.in_shift2 : a.in_shift) + ci0);
+    }
+    *reinterpret_cast<f32x4*>(sS + pr * 128 + q16 * 4) = sc0;
+    *reinterpret_cast<f32x4*>(sS + pr * 128 + 64 + q16 * 4) = sh0;
+  }
+  // BatchNorm-backward parameters of this block's 64 output channels, per problem: dY = gs dZ + (A xhat + B),
+  // xhat = y invstd + cc;  gs = gamma invstd, A = -gs S2/n, B = -gs S1/n, cc = -mean invstd
+  if (tid >= 64 && tid < 64 + 128) {
+    const int pr = (tid - 64) >> 6, ch = (tid - 64) & 63, co = cob * 64 + ch;
+    float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (co < a.Cout && pr < a.nprob) {
+      const float is = a.f_invstd[pr][co], gs = a.f_gamma[co] * is;
+      v[0] = a.f_scale[pr][co]; v[1] = a.f_shift[pr][co]; v[2] = -a.f_mean[pr][co] * is; v[3] = is; v[4] = gs;
+      v[5] = -gs * a.f_k12[pr][a.Cout + co]; v[6] = -gs * a.f_k12[pr][co];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sF[(pr * 7 + k) * 64 + ch] = v[k];
+  }
+  const int co0 = cob * 64 + q16 * 4;
+  const bool covalid = co0 < a.Cout;
+
+  constexpr int NP = POOL ? 1 : 4;  // gradient quads per thread: the window's pooled one / one per pixel slot
+  f32x4 xreg[NX], yreg[4], preg[NP];
+  unsigned xmask = 0;
+  unsigned wvalid = 0;  // POOL: the prefetched window lies inside the map (bit 0); else: validity bits of the four pixel slots
+
+  const int xpix = a.in_cs * 4, xrow = a.W * xpix;
+  const int ypix = a.f_ycs * 4, yrow = a.W * ypix;       // y and dY share the geometry [N,H,W,f_ycs], channel offset 0
+  const int ppix = a.dout_cs * 4, prow = (POOL ? (a.W >> 1) : a.W) * ppix;  // gradient wrt the (pooled) activation
+  const int xq = civalid ? (a.in_co + ci0) * 4 : -1;
+  constexpr unsigned OOB = 0x80000000u;
+  // this thread's pooling window of the dY tile: window w = tid >> 4 (32 windows of 2x2 pixels), channel quad q16
+  const int w_ = tid >> 4;
+  const int wy = WIDE ? (w_ >> 4) : (w_ >> 2), wx = WIDE ? (w_ & 15) : (w_ & 3);
+  {
+    unsigned xmask_in = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int pp = (tid >> 4) + 32 * i, r = pp / G::WT, c = pp - r * G::WT;
+      const bool ok = xq >= 0 && pp < G::HT * G::WT;
+      sO[i * 512] = ok ? (unsigned)(r * xrow + c * xpix + xq) : OOB;
+      sO[(NX + i) * 512] = ok ? (unsigned)((r << 16) | c) : 0xFFFFFFFFu;
+      xmask_in |= (ok ? 1u : 0u) << i;
+    }
+    if (POOL) {
+      sO[(2 * NX) * 512] = covalid ? (unsigned)(2 * wy * yrow + 2 * wx * ypix + co0 * 4) : OOB;               // y / dY window
+      sO[(2 * NX + 1) * 512] = covalid ? (unsigned)(wy * prow + wx * ppix + (a.dout_co + co0) * 4) : OOB;     // pooled gradient
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // pixel slot i = pixel (tid >> 4) + 32 i of the dY raster: y / dY offset, coordinates
+        const int pp = (tid >> 4) + 32 * i, r = pp / G::TW, c = pp - r * G::TW;
+        sO[(2 * NX + i) * 512] = covalid ? (unsigned)(r * yrow + c * ypix + co0 * 4) : OOB;
+        sO[(2 * NX + 4 + i) * 512] = covalid ? (unsigned)((r << 16) | c) : 0xFFFFFFFFu;
+      }
+    }
+    sO[(2 * NX + 8) * 512] = xmask_in;
+  }
+  bool nxt_inside = false;  // wave-uniform: the prefetched tile is an interior tile
+#define WGF_ISSUE(TILE)                                                                                       \
+  {                                                                                                           \
+    const int pr_ = (TILE) >= a.ntiles ? 1 : 0;                                                               \
+    const int tl_ = (TILE) - pr_ * a.ntiles;                                                                  \
+    const int tx_ = tl_ % a.tiles_x, t2_ = tl_ / a.tiles_x;                                                   \
+    const int ty0_ = (t2_ % a.tiles_y) * G::TH, tx0_ = tx_ * G::TW, n_ = t2_ / a.tiles_y;                     \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
+        const_cast<float*>(pr_ ? a.in2 : a.in) + (size_t)n_ * a.H * a.W * a.in_cs, 0, a.H * xrow, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
+        const_cast<float*>(a.f_y[pr_]) + (size_t)n_ * a.H * a.W * a.f_ycs, 0, a.H * yrow, 0x00020000);        \
+    const __amdgpu_buffer_rsrc_t rp_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
+        const_cast<float*>(pr_ ? a.dout2 : a.dout) + (size_t)n_ * (POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.dout_cs, 0, \
+        (POOL ? (a.H >> 1) : a.H) * prow, 0x00020000);                                                        \
+    nxt_inside = ty0_ >= 1 && ty0_ + G::TH + 1 <= a.H && tx0_ >= 1 && tx0_ + G::TW + 1 <= a.W;               \
+    const int yb_ = ty0_ * yrow + tx0_ * ypix;                                                                \
+    const int pb_ = POOL ? (ty0_ >> 1) * prow + (tx0_ >> 1) * ppix : ty0_ * prow + tx0_ * ppix + a.dout_co * 4; \
+    if (nxt_inside) {                                                                                         \
+      const int xb_ = (ty0_ - 1) * xrow + (tx0_ - 1) * xpix;                                                  \
+      _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                          \
+        xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, sO[i * 512], xb_, 0)); \
+      xmask = sO[(2 * NX + 8) * 512];                                                                         \
+    } else {                                                                                                  \
+      xmask = 0;                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                        \
+        const unsigned rc_ = sO[(NX + i) * 512];                                                              \
+        const int gy = ty0_ - 1 + (int)(rc_ >> 16), gx = tx0_ - 1 + (int)(rc_ & 0xFFFFu);                     \
+        const bool ok = rc_ != 0xFFFFFFFFu && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   \
+        xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                            \
+            rx_, ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB, 0, 0));                                   \
+        xmask |= (ok ? 1u : 0u) << i;                                                                         \
+      }                                                                                                       \
+    }                                                                                                         \
+    if (POOL) {                                                                                               \
+      unsigned yo_ = sO[(2 * NX) * 512], po_ = sO[(2 * NX + 1) * 512];                                        \
+      /* H and W are even: a window is inside the map or outside as a whole */                               \
+      wvalid = (yo_ != OOB && (nxt_inside || (ty0_ + 2 * wy < a.H && tx0_ + 2 * wx < a.W))) ? 1u : 0u;       \
+      if (!wvalid) { yo_ = OOB; po_ = OOB; }                                                                  \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
+        yreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry_, yo_, yb_ + (k >> 1) * yrow + (k & 1) * ypix, 0)); \
+      preg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp_, po_, pb_, 0));           \
+    } else {                                                                                                  \
+      wvalid = 0;                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+        unsigned yo_ = sO[(2 * NX + i) * 512];                                                                \
+        if (!nxt_inside) {                                                                                    \
+          const unsigned rc_ = sO[(2 * NX + 4 + i) * 512];                                                    \
+          if (!(rc_ != 0xFFFFFFFFu && ty0_ + (int)(rc_ >> 16) < a.H && tx0_ + (int)(rc_ & 0xFFFFu) < a.W)) yo_ = OOB; \
+        }                                                                                                     \
+        wvalid |= (yo_ != OOB ? 1u : 0u) << i;                                                                \
+        yreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry_, yo_, yb_, 0));         \
+        /* y and the gradient share the pixel geometry; their channel strides may differ only by the scalar part */ \
+        preg[POOL ? 0 : i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp_, yo_, pb_, 0)); \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+
+  // per-wave constants of component row i:  T[i][c] = d[ra][c] + sg d[rb][c];  R[q] = c0 dy[0][q] + c1 dy[1][q]
+  const int ra = irow == 0 ? 0 : irow == 2 ? 2 : 1;
+  const int rb = irow == 2 ? 1 : irow == 3 ? 3 : 2;
+  const float sg = irow == 1 ? 1.f : -1.f;
+  const float c0 = irow == 3 ? 0.f : 1.f;
+  const float c1 = irow == 0 ? 0.f : irow == 1 ? 1.f : -1.f;
+
+  __syncthreads();  // sF / sS
+  if (t_begin < t_end) WGF_ISSUE(t_begin)
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();  // all waves finished reading the previous tile's LDS image
+    {
+      const int cur_prob = tile >= a.ntiles ? 1 : 0;
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (IN_MODE != 0) {
+        sc = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + q16 * 4);
+        sh = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + 64 + q16 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int pp = (tid >> 4) + 32 * i;
+        if (pp < G::HT * G::WT) {
+          f32x4 v = xreg[i];  // 0 from the buffer load where the pixel / channel quad is outside
+          if (IN_MODE != 0) v = bn_relu_quad(v, sc, sh, !((xmask >> i) & 1u));
+          *reinterpret_cast<f32x4*>(sX + pp * 64 + q16 * 4) = v;
+        }
+      }
+      // ---- the layer's BatchNorm + ReLU + MaxPool backward APPLY on this thread's window ----
+      const float* pf = sF + cur_prob * 7 * 64 + q16 * 4;
+      const f32x4 fsc = *reinterpret_cast<const f32x4*>(pf), fsh = *reinterpret_cast<const f32x4*>(pf + 64);
+      const f32x4 fcc = *reinterpret_cast<const f32x4*>(pf + 128), fis = *reinterpret_cast<const f32x4*>(pf + 192);
+      const f32x4 fgs = *reinterpret_cast<const f32x4*>(pf + 256), fA = *reinterpret_cast<const f32x4*>(pf + 320);
+      const f32x4 fB = *reinterpret_cast<const f32x4*>(pf + 384);
+      f32x4 o[4];
+      if (POOL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // first maximum of relu(z) in window scan order (torch: strictly greater replaces)
+          float z[4], best = -1.f;
+          int bk = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            z[k] = fmaf(yreg[k][e], fsc[e], fsh[e]);
+            const float av = fmaxf(z[k], 0.f);
+            if (av > best) { best = av; bk = k; }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float dz = (k == bk && z[k] > 0.f) ? preg[0][e] : 0.f;
+            const float xh = fmaf(yreg[k][e], fis[e], fcc[e]);
+            const float v = fmaf(fgs[e], dz, fmaf(fA[e], xh, fB[e]));
+            o[k][e] = wvalid ? v : 0.f;  // 0 outside the map / the tensor, like a zero-filled dY load
+          }
+        }
+        // tile image for the MFMA phase
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          *reinterpret_cast<f32x4*>(sD + ((2 * wy + (k >> 1)) * G::TW + 2 * wx + (k & 1)) * 64 + q16 * 4) = o[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(yreg[k][e], fsc[e], fsh[e]);
+            const float dz = z > 0.f ? preg[POOL ? 0 : k][e] : 0.f;
+            const float xh = fmaf(yreg[k][e], fis[e], fcc[e]);
+            const float v = fmaf(fgs[e], dz, fmaf(fA[e], xh, fB[e]));
+            o[k][e] = ((wvalid >> k) & 1u) ? v : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(sD + ((tid >> 4) + 32 * k) * 64 + q16 * 4) = o[k];
+        }
+      }
+      // dY for the data-gradient convolution of this layer (every tile exactly once: the blocks of input-channel block 0)
+      if (cib == 0) {
+        const int tl = tile - cur_prob * a.ntiles;
+        const int tx_i = tl % a.tiles_x, t2 = tl / a.tiles_x;
+        const int ty0 = (t2 % a.tiles_y) * G::TH, tx0 = tx_i * G::TW, n = t2 / a.tiles_y;
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+            a.f_dy[cur_prob] + (size_t)n * a.H * a.W * a.f_ycs, 0, a.H * yrow, 0x00020000);
+        const int yb = ty0 * yrow + tx0 * ypix;
+        if (POOL) {
+          const unsigned yo = wvalid ? sO[(2 * NX) * 512] : OOB;  // stores beyond the descriptor are dropped
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o[k]),
+                                                   rdy, yo, yb + (k >> 1) * yrow + (k & 1) * ypix, 0);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o[k]),
+                                                   rdy, ((wvalid >> k) & 1u) ? sO[(2 * NX + k) * 512] : OOB, yb, 0);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int nxt = min(tile + 1, t_end - 1);  // unconditional prefetch (redundant on the last tile)
+      WGF_ISSUE(nxt)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      // lane bases: channel pair 2 li of the raw rows ra / rb, tile column offset of the lane half; dY column of this lane
+      const float* xa0 = sX + (ra * G::WT + 2 * lh) * 64 + 2 * li;
+      const float* xb0 = sX + (rb * G::WT + 2 * lh) * 64 + 2 * li;
+      const float* db0 = sD + (2 * lh) * 64 + coh * 32 + li;
+      wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1});
+    }
+  }
+#undef WGF_ISSUE
+  // partial slab: [blk][component][ci 64][co 64]; M-tile e, row m <-> input channel 2 m + e
+  float* dst = a.partial + (size_t)blockIdx.x * WC * 4096;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        dst[(irow * 4 + j) * 4096 + (2 * m + e) * 64 + coh * 32 + li] = acc[j][e][r];
+      }
+}
+
+}  // namespace sspk
