@@ -725,11 +725,11 @@ struct WgradCall {
 
 // Can the weight gradient of a layer whose output feeds BatchNorm + ReLU + MaxPool2d(2) take that layer's APPLY pass along
 // (wgrad_wino_fused_kernel)?  fp32 Winograd F(3x3,2x2) weight gradient, even map, whole 4-channel quads, dense y / dY.
-static bool wgrad_can_fuse_apply(int ks, int in_mode, int H, int W, int cout, int y_cs, int y_co) {
+static bool wgrad_can_fuse_apply(int ks, int in_mode, int H, int W, int cout) {
   static const int env = getenv("SSP_FUSE_APPLY") ? atoi(getenv("SSP_FUSE_APPLY")) : 1;  // (perf-debug A/B)
   static const int f4 = getenv("SSP_WGRAD_F4") ? atoi(getenv("SSP_WGRAD_F4")) : 0;        // (forces wgrad_wino4_kernel)
   return env != 0 && f4 == 0 && (g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10) && ks == 3 && in_mode != 2 && H % 2 == 0 &&
-         W % 2 == 0 && cout % 4 == 0 && y_cs == cout && y_co == 0;
+         W % 2 == 0 && cout % 4 == 0;
 }
 
 // sums the pending partial slabs of the deferred Winograd weight-gradient launches into the OIHW gradients
@@ -1277,15 +1277,16 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     // pass 2: inside the layer's weight gradient (it stages dY anyway and writes it for the data gradient) where possible
     // (the pooled layers 1, 3, 5 read the un-pooled activation of layers 0, 2, 4: input mode 1)
-    const bool defer = l >= 1 && l < 8 && layer_in_mode(l) == 1 && dy_cs == d.cout && dy_co == 0 &&
-                       wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout, SS.s[0]->y_cs[l], SS.s[0]->y_co[l]);
+    const bool defer = l >= 1 && l < 8 && layer_in_mode(l) == 1 && dy_cs == d.cout && dy_co == 0 && SS.s[0]->y_cs[l] == d.cout &&
+                       SS.s[0]->y_co[l] == 0 && wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout);
     h->apply_fused[l] = defer;
     if (!defer) hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
   } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st, fused)));
   else if (relu) {
-    // encoder layers 2, 4, 6, 7 (dense [N,H,W,C] tensors): pass 2 inside the weight gradient as well
-    const bool defer = l >= 1 && l < 8 && d_cs == d.cout && d_co == 0 && dy_cs == d.cout && dy_co == 0 &&
-                       wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout, SS.s[0]->y_cs[l], SS.s[0]->y_co[l]);
+    // encoder layers 2, 4, 6, 7 (dense [N,H,W,C] tensors) and the 3x3 heads (slices of [cells][256 heads] tensors: y, the
+    // gradient and dY share channel stride and offset): pass 2 inside the weight gradient as well
+    const bool defer = l >= 1 && d_cs == SS.s[0]->y_cs[l] && d_co == SS.s[0]->y_co[l] && dy_cs == d_cs && dy_co == d_co &&
+                       wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout);
     h->apply_fused[l] = defer;
     CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused, defer)));
   }
@@ -1457,6 +1458,18 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
       if (SS.n == 2) {
         Slot& B = *SS.s[1];
         w.nprob = 2; w.in2 = B.Y[7]; w.dout2 = gQ[1]; w.in_scale2 = B.bn[7].scale; w.in_shift2 = B.bn[7].shift;
+      }
+      if (h->apply_fused[heads[hk]]) {  // bn_layer_backward above left the APPLY pass to this launch
+        h->apply_fused[heads[hk]] = false;
+        w.fuse_apply = true; w.fuse_pool = false;
+        w.dout_cs = hcs; w.dout_co = 0; w.f_gamma = P(h, d.g_off); w.f_ycs = hcs;
+        for (int k = 0; k < SS.n; ++k) {
+          Slot& S = *SS.s[k];
+          (k ? w.dout2 : w.dout) = gP[k] + 256 * hk;  // the slices start at channel 256 hk of every pixel
+          w.f_y[k] = S.Y[heads[hk]] + S.y_co[heads[hk]]; w.f_dy[k] = gQ[k] + 256 * hk;
+          w.f_scale[k] = S.bn[heads[hk]].scale; w.f_shift[k] = S.bn[heads[hk]].shift; w.f_mean[k] = S.bn[heads[hk]].mean;
+          w.f_invstd[k] = S.bn[heads[hk]].invstd; w.f_k12[k] = S.bn[heads[hk]].k12;
+        }
       }
       CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
     }
