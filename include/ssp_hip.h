@@ -167,6 +167,9 @@ int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops
 enum { SSP_PROF_K_CONV_WINO4 = 0 /* conv_wino4_kernel, Winograd F(4x4,3x3) */, SSP_PROF_K_CONV_WINO_PIPE = 1, SSP_PROF_K_CONV_WINO_P2 = 2,
        SSP_PROF_K_WGRAD_WINO = 3 /* wgrad_wino_kernel, F(3x3,2x2) */, SSP_PROF_K_WGRAD_WINO4 = 4 /* wgrad_wino4_kernel, F(3x3,4x4) */,
        SSP_PROF_K_OTHER = 5 /* direct implicit GEMM, bf16-operand kernels */, SSP_PROF_K_COUNT = 6 };
+/* Suspends (paused != 0) / resumes the bracketing without resetting the counters: bench.py brackets every n-th step of the
+ * timed region only (the event records of ~30 launches per step cost ~1.7 % of the step when every step carries them). */
+int ssp_profile_pause(ssp_handle* h, int paused);
 int ssp_profile_read_kernel(ssp_handle* h, int kernel, double* ms, int64_t* launches, double* flops, double* executed_flops,
                             double* bytes);
 /* FLOPs the tagged launches since ssp_profile_enable EXECUTED on the matrix cores (ssp_profile_read's `flops` are the
@@ -228,6 +231,9 @@ int ssp_op_warp_labels_full(const float* labels_dev, const float* h_dev, float* 
                             float* bi_out_dev, int b, int h, int w, void* stream);
 int ssp_op_warp_labels_full_px(const float* labels_dev, const float* hpx_dev, float* labels_out_dev, float* res_out_dev,
                                float* bi_out_dev, int b, int h, int w, void* stream);
+/* ssp_op_label_quantize : the `*_gaussian` label maps of datasets/Coco.py:378,400 (ImgAugTransform with GaussianBlur sigma 0.2,
+ * utils/photometric.py:59-78): uint8 quantisation floor(x * 255) / 255; the sigma-0.2 blur itself is the identity on 8 bits. */
+int ssp_op_label_quantize(const float* in_dev, float* out_dev, size_t n, void* stream);
 int ssp_op_sem_finalize(const float* sem_warped_dev, const float* valid_dev, int64_t* out_dev, size_t n, int n_classes,
                         void* stream);
 

@@ -873,6 +873,15 @@ def warp_labels_full(pnts_xy, H, W, homography):
     return lab.view(1, H, W), res.permute(2, 0, 1).contiguous(), bi.view(1, H, W)
 
 
+def gaussian_label_u8(x):
+    """datasets/Coco.py:378,400 `self.gaussian_blur(...)` = ImgAugTransform (utils/photometric.py:59-78) with GaussianBlur(sigma
+    0.2): (x * 255).astype(np.uint8) -> blur -> astype(float32) / 255.  imgaug / cv2 are absent here: the blur is restated as
+    the identity on 8-bit data (the 5-tap kernel of sigma 0.2 has off-centre weights exp(-12.5) = 3.7e-6 - below the 8-bit
+    fixed-point resolution of the blur); the uint8 quantisation is exact numpy.  Parity unpinned for the blur itself."""
+    a = (np.asarray(x, dtype=np.float32) * 255).astype(np.uint8)
+    return torch.from_numpy(a.astype(np.float32) / 255)
+
+
 def warp_semantic(sem, inv_homography, valid_mask, n_classes=133):
     """datasets/Coco_sem.py:406-450: bilinear warp of the class-id map as floats, invalid pixels -> n_classes."""
     w = inv_warp_image_batch(sem.float().view(1, 1, *sem.shape[-2:]), inv_homography.view(1, 3, 3)).view(sem.shape[-2:])

@@ -181,6 +181,18 @@ __global__ void sem_finalize_kernel(const float* __restrict__ sem_w, const float
   if (i < n) out[i] = valid[i] == 0.f ? (int64_t)n_classes : (int64_t)sem_w[i];
 }
 
+// datasets/Coco.py:378,400 `gaussian_blur` = ImgAugTransform (utils/photometric.py:59-78) with GaussianBlur(sigma 0.2): the map goes
+// float -> uint8 ((x * 255).astype(np.uint8): truncation) -> blur -> float / 255.  The 5-tap kernel of sigma 0.2 has off-centre
+// weights exp(-12.5) = 3.7e-6, which vanish in the 8-bit fixed-point path of the blur: what is left is the quantisation.
+__global__ void label_quantize_u8_kernel(const float* __restrict__ in, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float v = in[i] * 255.f;                                    // float32 product, like numpy
+    const float q = v >= 255.f ? 255.f : v > 0.f ? floorf(v) : 0.f;    // astype(uint8) of a value in [0, 255]
+    out[i] = q / 255.f;                                                 // float32 division, like numpy
+  }
+}
+
 // ---- homography sampler (utils/homographies.py:12-141 sample_homography_np + the inversion of datasets/Coco.py:342-350)
 // with a counter-based device RNG: distribution-level equivalent of the numpy / scipy streams (parity unpinned, like
 // the host generator in synth.py).  One thread per homography.

@@ -30,6 +30,13 @@
 
 using namespace sspk;
 
+// A/B-only convolution algorithms of rounds 1-2 that no shipped configuration selects: 2 (conv_wino_kernel, the un-pipelined
+// F(2x2,3x3) convolution) and 5 (conv_wino_pipe_kernel with the weights staged through LDS).  Compiled out by default
+// (8 kernel instances, ~10 s of build time); -DSSP_LEGACY_ALGOS=1 (SSP_HIPCC_EXTRA) brings them back.
+#ifndef SSP_LEGACY_ALGOS
+#define SSP_LEGACY_ALGOS 0
+#endif
+
 static thread_local std::string g_err;
 static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_kernel (tools/ablate_conv.py)
 // ssp_set_conv_algo: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) where eligible (software-pipelined kernel),
@@ -157,8 +164,14 @@ struct ssp_handle {
   struct GraphEntry { std::vector<unsigned char> key; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
   uint64_t* graph_seed;  // device word: sampler seed of the captured steps (set by a one-thread kernel before each replay)
+  // loss phase of the pair step: the descriptor-loss kernels (L2 gathers / atomics, latency-bound) run on a side stream beside
+  // the detector / segmentation-loss kernels (vector-ALU-bound) of the caller's stream; fork / join by events (captured as a
+  // fork-join into the hipGraph form).  Created at the first pair step, per device of the handle.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling
   int prof_family;
+  bool prof_paused = false;  // ssp_profile_pause: launches are not bracketed while set (bench.py samples every n-th step)
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used;
   double prof_flops, prof_bytes, prof_exec_flops;
@@ -337,7 +350,7 @@ struct ProfScope {
   ProfScope(ssp_handle* h_, int family, hipStream_t s, double flops, double bytes, double exec_flops = -1.0,
             int kernel = SSP_PROF_K_OTHER) : h(h_), st(s), on(false) {
     const bool conv = family == SSP_PROF_CONV3X3_FWD || family == SSP_PROF_CONV3X3_DGRAD;
-    const bool match = h && family > 0 && (h->prof_family == family || (h->prof_family == SSP_PROF_CONV3X3_ALL && conv) ||
+    const bool match = h && family > 0 && !h->prof_paused && (h->prof_family == family || (h->prof_family == SSP_PROF_CONV3X3_ALL && conv) ||
         (h->prof_family == SSP_PROF_CONV3X3_EVERY && (conv || family == SSP_PROF_CONV3X3_WGRAD)));
     if (match && h->ev_used + 2 <= h->ev_pool.size()) {
       on = true;
@@ -479,6 +492,7 @@ static int launch_wino_bf16_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
+#if SSP_LEGACY_ALGOS
 template <int IN_MODE, bool WIDE>
 static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   static AttrOnce attr_once;
@@ -490,6 +504,7 @@ static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+#endif
 
 // default algorithm (1): maps with few first-generation work items per CU (the 30x40 layers: 640 items on 256 CUs =
 // 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
@@ -621,6 +636,7 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true, true>(a, nblocks, st) : launch_wino_pipe_t<0, false, true>(a, nblocks, st);
     return wide ? launch_wino_pipe_t<1, true, true>(a, nblocks, st) : launch_wino_pipe_t<1, false, true>(a, nblocks, st);
   }
+#if SSP_LEGACY_ALGOS
   if (c.wino && g_conv_algo == 5) {  // the same pipeline with the weights staged through LDS
     if (c.in_mode == 0) return wide ? launch_wino_pipe_t<0, true>(a, nblocks, st) : launch_wino_pipe_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_pipe_t<1, true>(a, nblocks, st) : launch_wino_pipe_t<1, false>(a, nblocks, st);
@@ -629,6 +645,9 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     if (c.in_mode == 0) return wide ? launch_wino_t<0, true>(a, nblocks, st) : launch_wino_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_t<1, true>(a, nblocks, st) : launch_wino_t<1, false>(a, nblocks, st);
   }
+#else
+  if (c.wino) return fail(-3, "conv algorithm %d is compiled out (build with -DSSP_LEGACY_ALGOS=1)", g_conv_algo);
+#endif
 #define CONV_CASE(KS_, M_)                                                          \
   if (c.ks == KS_ && c.in_mode == M_) {                                             \
     return wide ? launch_conv_t<KS_, M_, 1, 32>(a, nblocks, st) : launch_conv_t<KS_, M_, 4, 8>(a, nblocks, st); \
@@ -951,6 +970,9 @@ void ssp_destroy(ssp_handle* h) {
   if (!h) return;
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   delete h;
 }
 
@@ -982,12 +1004,19 @@ int ssp_zero_grad(ssp_handle* h, void* stream) {
 int ssp_profile_enable(ssp_handle* h, int family) {
   if (!h) return fail(-1, "null handle");
   h->prof_family = family; h->ev_used = 0; h->prof_flops = h->prof_bytes = h->prof_exec_flops = 0; h->prof_launches = 0;
+  h->prof_paused = false;
   for (auto& k : h->prof_k) k = ssp_handle::ProfKernel();
   if (family != 0 && h->ev_pool.empty()) {
     h->ev_pool.resize(8192);
     h->ev_kernel.assign(4096, (unsigned char)SSP_PROF_K_OTHER);
     for (auto& e : h->ev_pool) HIPCHK(hipEventCreate(&e));
   }
+  return 0;
+}
+
+int ssp_profile_pause(ssp_handle* h, int paused) {
+  if (!h) return fail(-1, "null handle");
+  h->prof_paused = paused != 0;
   return 0;
 }
 
@@ -1615,13 +1644,69 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     CHK(run_forward(h, SS, xs, B, H, W, 1, in->train != 0, st));
   }
   const float* masks[2] = {in->valid_mask_dev, in->warped_valid_mask_dev};
-  const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
-  const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
   for (int v = 0; v < 2; ++v) {
     Slot& S = h->slot[v];
     hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, st, masks[v], S.cellmask,
                        &h->accum->mask_cnt[v], B, H, W);
   }
+  // ---- descriptor loss on the side stream (fork) ----
+  static const int loss_stream_env = getenv("SSP_LOSS_STREAM") ? atoi(getenv("SSP_LOSS_STREAM")) : 1;  // (perf-debug: 0 = one stream)
+  hipStream_t sd = st;
+  const bool forked = loss_stream_env != 0 && use_desc && !dense;  // (the dense loss reads the cell mask of the main stream's kernels)
+  if (forked) {
+    if (h->aux_stream == nullptr) {
+      HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    sd = h->aux_stream;
+    HIPCHK(hipEventRecord(h->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(sd, h->ev_fork, 0));
+  }
+  if (dense) {  // utils/utils.py:779-893: Gram matrix + loss sums + d total / d dot, then the two backward GEMMs
+    Slot &A = h->slot[0], &Bs = h->slot[1];
+    const int pc = Hc * Wc;
+    DenseArgs da;
+    da.da = A.desc; da.db = Bs.desc; da.hn = in->homographies_dev; da.valid = Bs.cellmask;
+    da.coef = in->train ? h->dense_coef : nullptr; da.acc = h->accum; da.B = B; da.Hc = Hc; da.Wc = Wc;
+    da.lamda_d = in->dense_lamda_d; da.dist = in->descriptor_dist; da.multi_task = in->multi_task;
+    hipLaunchKernelGGL(dense_dots_kernel, dim3(cdiv(pc, 64), cdiv(pc, 64), B), dim3(256), 0, sd, da);
+    if (in->train) {
+      hipLaunchKernelGGL((dense_grad_kernel<false>), dim3(4, cdiv(pc, 64), B), dim3(256), 0, sd, h->dense_coef, Bs.desc,
+                         A.ddesc, pc);
+      hipLaunchKernelGGL((dense_grad_kernel<true>), dim3(4, cdiv(pc, 64), B), dim3(256), 0, sd, h->dense_coef, A.desc,
+                         Bs.ddesc, pc);
+      for (int v = 0; v < 2; ++v) {
+        Slot& S = h->slot[v];
+        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, sd, S.desc, S.inv_norm, S.ddesc, ncells);
+      }
+    }
+    HIPCHK(hipGetLastError());
+  } else if (use_desc) {
+    Slot &A = h->slot[0], &Bs = h->slot[1];
+    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
+                       in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
+    hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
+                       in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match,
+                       h->cfg.n_non);
+    hipLaunchKernelGGL(desc_counts_kernel, dim3(1), dim3(64), 0, sd, h->accum, B);
+    if (in->train) {
+      CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
+      CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
+      hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
+                         in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
+      hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
+                         in->nonmatch_b_dev, h->dots, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
+                         h->cfg.n_non);
+      for (int v = 0; v < 2; ++v) {
+        Slot& S = h->slot[v];
+        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, sd, S.desc, S.inv_norm, S.ddesc, ncells);
+      }
+    }
+    HIPCHK(hipGetLastError());
+  }
+  const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
+  const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
   for (int v = 0; v < 2; ++v) {
     Slot& S = h->slot[v];
     hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
@@ -1647,47 +1732,9 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     }
     HIPCHK(hipGetLastError());
   }
-  if (dense) {  // utils/utils.py:779-893: Gram matrix + loss sums + d total / d dot, then the two backward GEMMs
-    Slot &A = h->slot[0], &Bs = h->slot[1];
-    const int pc = Hc * Wc;
-    DenseArgs da;
-    da.da = A.desc; da.db = Bs.desc; da.hn = in->homographies_dev; da.valid = Bs.cellmask;
-    da.coef = in->train ? h->dense_coef : nullptr; da.acc = h->accum; da.B = B; da.Hc = Hc; da.Wc = Wc;
-    da.lamda_d = in->dense_lamda_d; da.dist = in->descriptor_dist; da.multi_task = in->multi_task;
-    hipLaunchKernelGGL(dense_dots_kernel, dim3(cdiv(pc, 64), cdiv(pc, 64), B), dim3(256), 0, st, da);
-    if (in->train) {
-      hipLaunchKernelGGL((dense_grad_kernel<false>), dim3(4, cdiv(pc, 64), B), dim3(256), 0, st, h->dense_coef, Bs.desc,
-                         A.ddesc, pc);
-      hipLaunchKernelGGL((dense_grad_kernel<true>), dim3(4, cdiv(pc, 64), B), dim3(256), 0, st, h->dense_coef, A.desc,
-                         Bs.ddesc, pc);
-      for (int v = 0; v < 2; ++v) {
-        Slot& S = h->slot[v];
-        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.desc, S.inv_norm, S.ddesc, ncells);
-      }
-    }
-    HIPCHK(hipGetLastError());
-  } else if (use_desc) {
-    Slot &A = h->slot[0], &Bs = h->slot[1];
-    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
-                       in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
-    hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
-                       in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match,
-                       h->cfg.n_non);
-    hipLaunchKernelGGL(desc_counts_kernel, dim3(1), dim3(64), 0, st, h->accum, B);
-    if (in->train) {
-      CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), st));
-      CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), st));
-      hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
-                         in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
-      hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, st, A.desc, Bs.desc, in->match_a_dev,
-                         in->nonmatch_b_dev, h->dots, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
-                         h->cfg.n_non);
-      for (int v = 0; v < 2; ++v) {
-        Slot& S = h->slot[v];
-        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.desc, S.inv_norm, S.ddesc, ncells);
-      }
-    }
-    HIPCHK(hipGetLastError());
+  if (forked) {  // join: the scalars and the backward pass need both loss families
+    HIPCHK(hipEventRecord(h->ev_join, sd));
+    HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
   }
   hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(64), 0, st, h->accum, eta,
                      in->train ? h->buf.grads_dev + h->n_params : (float*)nullptr, scalars_dev, B, h->cfg.n_match,
@@ -1747,6 +1794,7 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
   if (algo < 0 || algo > 11 || algo == 4) return fail(-1, "conv algo must be 0..3 or 5..11 (see ssp_set_conv_algo)");
+  if (!SSP_LEGACY_ALGOS && (algo == 2 || algo == 5)) return fail(-1, "conv algo %d is compiled out (-DSSP_LEGACY_ALGOS=1)", algo);
   h->conv_algo = algo;
   return 0;
 }
@@ -2118,6 +2166,13 @@ int ssp_op_warp_labels_full_px(const float* labels_dev, const float* hpx_dev, fl
   return warp_labels_full_impl(labels_dev, nullptr, hpx_dev, labels_out_dev, res_out_dev, bi_out_dev, b, hh, w, (hipStream_t)stream);
 }
 
+int ssp_op_label_quantize(const float* in_dev, float* out_dev, size_t n, void* stream) {
+  if (!in_dev || !out_dev) return fail(-1, "label_quantize: null pointer");
+  hipLaunchKernelGGL(label_quantize_u8_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev, (long)n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int ssp_op_sem_finalize(const float* sem_warped_dev, const float* valid_dev, int64_t* out_dev, size_t n, int n_classes,
                         void* stream) {
   hipLaunchKernelGGL(sem_finalize_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, sem_warped_dev,
@@ -2164,6 +2219,7 @@ int ssp_set_conv_algo(int algo) {
                     ", 7 (Winograd, split-bf16 hi + lo operands), 8 (forward split-bf16, backward bf16), 9 (Winograd "
                     "F(2x2,3x3) only: algorithm 1 without F(4x4,3x3) on the large maps), 10 (F(4x4,3x3) wherever legal) or 11 (algorithm 1 "
                     "with the F(3x3,4x4) weight gradient)");
+  if (!SSP_LEGACY_ALGOS && (algo == 2 || algo == 5)) return fail(-1, "conv algo %d is compiled out (-DSSP_LEGACY_ALGOS=1)", algo);
   g_default_conv_algo = algo;
   return 0;
 }

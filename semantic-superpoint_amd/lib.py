@@ -71,7 +71,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
-           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel"]
+           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause"]
 
 
 def load_library(path=None):
@@ -122,6 +122,11 @@ def load_library(path=None):
     lib.ssp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
     lib.ssp_profile_read_executed.argtypes = [vp, C.POINTER(C.c_double)]
+    try:
+        lib.ssp_profile_pause.argtypes = [vp, i]
+    except AttributeError:
+        if os.environ.get("SSP_HIP_LIB") is None:
+            raise
     lib.ssp_profile_read_kernel.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
@@ -152,6 +157,11 @@ def load_library(path=None):
     lib.ssp_op_sample_homographies.argtypes = [C.c_uint64, C.POINTER(SspHomographyParams), i, vp, vp, vp]
     lib.ssp_op_warp_labels_full.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_sem_finalize.argtypes = [vp, vp, vp, C.c_size_t, i, vp]
+    try:  # (entry points newer than an A/B library of an older revision, SSP_HIP_LIB)
+        lib.ssp_op_label_quantize.argtypes = [vp, vp, C.c_size_t, vp]
+    except AttributeError:
+        if os.environ.get("SSP_HIP_LIB") is None:
+            raise
     lib.ssp_op_dense_loss.argtypes = [vp, vp, vp, vp, i, i, i, f, f, i, f, vp, C.c_size_t, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -549,6 +559,10 @@ class Engine:
     def profile_enable(self, family):
         _check(self.lib.ssp_profile_enable(self.h, PROF[family] if isinstance(family, str) else int(family)))
 
+    def profile_pause(self, paused):
+        if hasattr(self.lib, "ssp_profile_pause"):
+            _check(self.lib.ssp_profile_pause(self.h, int(bool(paused))))
+
     def profile_read(self):
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         _check(self.lib.ssp_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
@@ -912,6 +926,17 @@ def op_warp_labels_full(labels, hn, exact=True):
             hn = hn.to(labels.device, torch.float32).contiguous()
             _check(lib.ssp_op_warp_labels_full(_ptr(labels), _ptr(hn), _ptr(lab), _ptr(res), _ptr(bi), B, H, W, _stream()))
     return lab, res, bi
+
+
+def op_label_quantize(labels):
+    """The reference's `*_gaussian` label maps (datasets/Coco.py:378,400): uint8 quantisation floor(x * 255) / 255 of a float map
+    (the sigma-0.2 blur behind it is the identity on 8-bit data)."""
+    lib = load_library()
+    _need_gpu(labels, "labels")
+    out = torch.empty_like(labels)
+    with torch.cuda.device(labels.device):
+        _check(lib.ssp_op_label_quantize(_ptr(labels), _ptr(out), labels.numel(), _stream()))
+    return out
 
 
 def op_sem_finalize(sem_warped, valid, n_classes=133):

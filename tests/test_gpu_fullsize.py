@@ -478,7 +478,7 @@ def test_graph_replay_equals_eager():
 # ------------------------------------------------------------------------------------------------
 # data parallel: two ranks through the engine on ONE device (gloo), overlapped all-reduce
 # ------------------------------------------------------------------------------------------------
-def _dp_worker(rank, world, port, out_dir):
+def _dp_worker(rank, world, port, out_dir, algo=1):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -488,6 +488,7 @@ def _dp_worker(rank, world, port, out_dir):
     dev = torch.device("cuda:0")
     sd = C.init_state_dict(arch, seed=3)
     e = Engine(arch, B, H, W, dev)
+    e.set_conv_algo(algo)
     e.load_state_dict(sd)
     ds = {k: v.to(dev).contiguous() for k, v in C.make_synthetic_pair(B, H, W, seed=20 + rank, semantic=True, kp_prob=0.01).items()}
     for it in range(2):
@@ -502,15 +503,16 @@ def _dp_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_device_overlapped_allreduce(tmp_path):
+@pytest.mark.parametrize("algo", [1, 8])
+def test_two_ranks_one_device_overlapped_allreduce(tmp_path, algo):
     """2 ranks on cuda:0 over gloo through the ENGINE (parallel.pair_step_overlapped): bit-identical parameters on both
     ranks after 2 steps, and the all-reduced gradient of step 1 == the sum of the two ranks' single-rank gradients
-    (BatchNorm statistics stay per replica)."""
+    (BatchNorm statistics stay per replica).  algo 8 = the mixed bf16 mode of BASELINE configs[3] under data parallelism."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), algo), nprocs=2, join=True)
     p0, p1 = torch.load(tmp_path / "params0.pt"), torch.load(tmp_path / "params1.pt")
     assert torch.equal(p0, p1)
     gs0, gs1 = torch.load(tmp_path / "gsum0.pt"), torch.load(tmp_path / "gsum1.pt")
@@ -521,13 +523,16 @@ def test_two_ranks_one_device_overlapped_allreduce(tmp_path):
     tot = None
     for rank in range(2):
         e = _engine(arch, B, H, W, sd)
+        e.set_conv_algo(algo)
         ds = _to_dev(C.make_synthetic_pair(B, H, W, seed=20 + rank, semantic=True, kp_prob=0.01))
         e.zero_grad()
         e.pair_step(ds, indices=None, seed=rank, train=True)
         torch.cuda.synchronize()
         tot = e.grads.cpu().clone() if tot is None else tot + e.grads.cpu()
     l2, mx = _rel(gs0, tot)
-    assert l2 < 1e-5 and mx < 1e-4, (l2, mx)
+    # fp32: two runs differ by the commit order of the atomics only.  Mixed bf16: that 1e-7 noise in the BatchNorm statistics
+    # moves 16-bit-rounded operands across ReLU gates - two runs of the SAME step differ by ~5e-3 (measured 4.9e-3)
+    assert (l2 < 1e-5 and mx < 1e-4) if algo == 1 else (l2 < 2e-2 and mx < 5e-2), (l2, mx)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -434,11 +434,11 @@ def test_odd_shapes_forward_and_step(B, H, W):
             _grad_close(gd[k].cpu(), tr.last_grads[k], k, l2=3e-2, mx=0.2)
 
 
-@pytest.mark.parametrize("algo", [0, 2, 5, 6, 10])
+@pytest.mark.parametrize("algo", [0, 6, 9, 10, 11])
 def test_conv_algorithms_agree_on_a_training_step(algo):
-    """ssp_set_conv_algo: the direct implicit-GEMM kernels (0), the un-pipelined Winograd kernels (2), the pipelined
-    kernel with LDS-staged weights (5) and Winograd F(4x4,3x3) on every 3x3 layer (10: pooled raw outputs, fused
-    BatchNorm-backward sums and partial tile blocks of conv_wino4_kernel) give the
+    """ssp_set_conv_algo: the direct implicit-GEMM kernels (0), the two-workgroup Winograd kernel (6), F(2x2,3x3) only (9),
+    Winograd F(4x4,3x3) on every 3x3 layer (10: pooled raw outputs, fused BatchNorm-backward sums and partial tile blocks
+    of conv_wino4_kernel) and the F(3x3,4x4) weight gradient (11) give the
     losses and gradients of the default (pipelined Winograd, 1) on the same step (fp32 everywhere; only the summation
     order / the Winograd transforms differ)."""
     from semantic_superpoint_amd import lib as L

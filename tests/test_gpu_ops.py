@@ -27,12 +27,12 @@ def _ref_input(x_nhwc, in_mode, sc, sh):
     return x
 
 
-@pytest.fixture(params=[1, 0, 2, 5, 6, 7, 10, 11], ids=["winograd_pipelined", "direct", "winograd_unpipelined", "winograd_lds_weights",
-                                                         "winograd_two_workgroups", "winograd_bf16x2", "winograd_f4x4", "wgrad_f3x3_4x4"])
+@pytest.fixture(params=[1, 0, 6, 7, 10, 11], ids=["winograd_pipelined", "direct", "winograd_two_workgroups", "winograd_bf16x2",
+                                                   "winograd_f4x4", "wgrad_f3x3_4x4"])
 def conv_algo(request):
     """ssp_set_conv_algo: every convolution / weight-gradient operator test runs under the fp32 implementations
-    (1 = default: software-pipelined Winograd; 0 = direct implicit GEMM; 2 = Winograd without the software pipeline;
-    5 = the pipelined kernel with the weights staged through LDS instead of loaded from L2 into the operand registers;
+    (1 = default: software-pipelined Winograd; 0 = direct implicit GEMM; [2 = Winograd without the software pipeline and
+    5 = the pipelined kernel with LDS-staged weights are compiled out by default: SSP_LEGACY_ALGOS];
     6 = the second-generation pipelined Winograd kernel: two independent 4-wave workgroups per CU;
     7 = split-bf16 operands (hi + lo, 16 significant bits, three bf16 MFMAs per product block, fp32 accumulation):
     product rounding ~2^-16, i.e. ~1e-5 of the output scale - inside this file's 2e-4 tolerance;

@@ -120,3 +120,15 @@ def test_make_pairs_trains():
     e.zero_grad()
     sc = dict(zip(SCALAR_NAMES, e.pair_step(s, seed=1, train=True, gaussian=False).cpu().tolist()))
     assert np.isfinite(sc["loss"]) and sc["loss_sem_warp"] > 0 and float(e.grads.abs().sum()) > 0
+
+
+def test_gaussian_label_quantisation_matches_numpy():
+    """ssp_op_label_quantize = (x * 255).astype(np.uint8).astype(np.float32) / 255 (utils/photometric.py:74-78) bit for bit,
+    on bilinear label weights, exact k / 255 values, 0 and 1."""
+    from semantic_superpoint_amd import lib as L
+    rs = np.random.RandomState(3)
+    x = rs.uniform(0, 1, (2, 1, 40, 56)).astype(np.float32)
+    x[0, 0, :2] = (np.arange(112).reshape(2, 56) % 256 / 255.0).astype(np.float32)
+    x[0, 0, 2, :4] = [0.0, 1.0, 0.5, 1.0 / 255]
+    out = L.op_label_quantize(t(x).to(_dev())).cpu()
+    assert torch.equal(out, C.gaussian_label_u8(x))
