@@ -194,8 +194,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   }
   const bool r4 = tid + 4 * W4_THREADS < NHALO * 2;  // the fifth item exists
   const int pixb = a.in_cs * 4, rowb = a.W * pixb;
-  f32x4 hreg[NH];
-  int h_chunk = 0;  // 8-channel chunk of the halo loads in hreg (BatchNorm parameters of the producer at W4_HALO_BN)
+  // TWO halo register sets, loaded two stages ahead of their use (set = stage parity): a stage (~2 us) is not enough distance
+  // for an HBM round trip under load, and one wave per SIMD hides no latency by itself (0.065 of a 0.68 ms launch was this
+  // wait).  Each set carries the 8-channel chunk of its loads (BatchNorm parameters at W4_HALO_BN) and the padding mask of
+  // its slots - hoff[] belongs to the tile being LOADED and is rewritten when the loads move on to the next tile.
+  f32x4 hregA[NH], hregB[NH];
+  int h_chunkA = 0, h_chunkB = 0;
+  unsigned h_padA = 0, h_padB = 0;  // bit k: slot k of the set is zero padding (outside the map)
   constexpr unsigned OOB = 0x80000000u;
   unsigned hoff[NH];
 #pragma unroll
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
 
   int ld_tile = tile0, ld_chunk = 0;
-#define W4_ISSUE_HALO()                                                                                     \
+#define W4_ISSUE_HALO(SET)                                                                                  \
   {                                                                                                         \
     if (ld_chunk == 0) {                                                                                    \
       const int tt_ = min(ld_tile, t_end - 1);  /* past the end: harmless redundant loads of the last tile */ \
@@ -220,19 +225,22 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
       rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in) + (size_t)n_ * img_floats, 0,    \
                                                   a.in_bytes, 0x00020000);                                  \
     }                                                                                                       \
-    h_chunk = ld_chunk;                                                                                     \
-    _Pragma("unroll") for (int k = 0; k < NH; ++k)                                                          \
-      hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (W4_ABL & 1024) ? (hoff[k] & 0xFFFFu) : hoff[k], ld_chunk * PK * 4, 0)); \
+    h_chunk##SET = ld_chunk;                                                                                \
+    h_pad##SET = 0;                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < NH; ++k) {                                                        \
+      h_pad##SET |= (hoff[k] == OOB ? 1u : 0u) << k;                                                        \
+      hreg##SET[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (W4_ABL & 1024) ? (hoff[k] & 0xFFFFu) : hoff[k], ld_chunk * PK * 4, 0)); \
+    }                                                                                                       \
     if (++ld_chunk == nst) { ld_chunk = 0; ld_tile += per_cob; }                                            \
   }
   f32x4 psc, psh;
-#define W4_HALO_PAR()                                                                                       \
+#define W4_HALO_PAR(SET)                                                                                    \
   if (IN_MODE != 0) {                                                                                       \
-    psc = *reinterpret_cast<const f32x4*>(sS + h_chunk * PK + q2 * 4);                                      \
-    psh = *reinterpret_cast<const f32x4*>(sS + 1024 + h_chunk * PK + q2 * 4);                               \
+    psc = *reinterpret_cast<const f32x4*>(sS + h_chunk##SET * PK + q2 * 4);                                 \
+    psh = *reinterpret_cast<const f32x4*>(sS + 1024 + h_chunk##SET * PK + q2 * 4);                          \
   }
-#define W4_HALO_BN(K) if (IN_MODE != 0 && !(W4_ABL & 4)) hreg[K] = bn_relu_quad(hreg[K], psc, psh, hoff[K] == OOB);
-#define W4_HALO_WR(K) if (!(W4_ABL & 4) && ((K) < NH - 1 || r4)) *reinterpret_cast<f32x4*>(sR + r_lds[K]) = hreg[K];
+#define W4_HALO_BN(K, SET) if (IN_MODE != 0 && !(W4_ABL & 4)) hreg##SET[K] = bn_relu_quad(hreg##SET[K], psc, psh, (h_pad##SET >> (K)) & 1u);
+#define W4_HALO_WR(K, SET) if (!(W4_ABL & 4) && ((K) < NH - 1 || r4)) *reinterpret_cast<f32x4*>(sR + r_lds[K]) = hreg##SET[K];
 
   // ---- transform roles: wave w computes row w (and, waves 0 / 1, row w + 4) of V = B^T d B for (tile, channel quad) =
   // (tid >> 1) & 31, tid & 1:   T[c] = k0 d[r0][c] + k1 d[r0+1][c] + k2 d[r0+2][c] + d[rl][c]
@@ -330,18 +338,19 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   __syncthreads();
 
   // ---- prologue: sA[0] = transformed stage 0, sR = raw halo of stage 1, halo loads of stage 2 in flight ----
-#define W4_HALO_ALL()                                                                                       \
-  W4_HALO_PAR() W4_HALO_BN(0) W4_HALO_BN(1) W4_HALO_BN(2) W4_HALO_BN(3) W4_HALO_BN(4)                       \
-  W4_HALO_WR(0) W4_HALO_WR(1) W4_HALO_WR(2) W4_HALO_WR(3) W4_HALO_WR(4)
-  W4_ISSUE_HALO()
-  W4_HALO_ALL()
+#define W4_HALO_ALL(SET)                                                                                    \
+  W4_HALO_PAR(SET) W4_HALO_BN(0, SET) W4_HALO_BN(1, SET) W4_HALO_BN(2, SET) W4_HALO_BN(3, SET) W4_HALO_BN(4, SET) \
+  W4_HALO_WR(0, SET) W4_HALO_WR(1, SET) W4_HALO_WR(2, SET) W4_HALO_WR(3, SET) W4_HALO_WR(4, SET)
+  W4_ISSUE_HALO(A)     // stage 0
+  W4_ISSUE_HALO(B)     // stage 1
+  W4_HALO_ALL(A)
   __syncthreads();
   W4_TRANSFORM_ROW(sA, 0, 0, tka0, tka1, tka2)
   W4_TRANSFORM_ROW(sA + DST_B, dAb, dLb, tkb0, tkb1, tkb2)
-  W4_ISSUE_HALO()
+  W4_ISSUE_HALO(A)     // stage 2: consumed by stage 0 of the loop (even stages use set A)
   __syncthreads();
-  W4_HALO_ALL()
-  W4_ISSUE_HALO()
+  W4_HALO_ALL(B)
+  W4_ISSUE_HALO(B)     // stage 3: consumed by stage 1 of the loop
   __syncthreads();
 #undef W4_HALO_ALL
 
@@ -416,61 +425,72 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   M10 if (COND) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(te, tc)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(te, tc)) } W4_FENCE(); \
   M11 W4_FENCE();
 
+  // One stage (8 input channels, 72 MFMAs per wave) of the pipeline; SET = the halo register set of the stage's parity, BUFV
+  // = the transformed-input buffer it consumes (both = the stage parity: the stage loop is unrolled by two, nst is even).
+  //   first half : pairs 0..4  ||  transform of stage g+1 (barrier A: sA[~g&1] complete, sR free)
+  //   second half: pairs 5..8  ||  halo (g+2): set -> sR, then the halo loads of stage g+4 into the same set; every weight
+  //                needed before those loads come back is fetched BEFORE them (in-order load counter), incl. pairs 0, 1 of
+  //                the next stage; barrier B: sR = raw(g+2) complete, sA[g&1] consumed
+#define W4_STAGE(SET, BUFV)                                                                                           \
+    const int buf = (BUFV);                                                                                           \
+    const float* const cA = sA + buf * W4_A_FLOATS;                                                                   \
+    float* const nA = sA + (buf ^ 1) * W4_A_FLOATS;                                                                   \
+    const int nchunk = chunk + 1 == nst ? 0 : chunk + 1;                                                              \
+    f32x4 rx0, rx1, rx2, rx3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;                                                 \
+    W4_FETCH_F(1, cA, 1)                                                                                              \
+    W4_FENCE();                                                                                                       \
+    W4_ROW_SLICES(!(W4_ABL & 2), nA, 0, 0, tka0, tka1, tka2,                                                          \
+                  W4_MMX(0, 0, 0, 3), W4_MMX(0, 1, 0, 3), W4_MMX(0, 2, 0, 3), W4_MMX(0, 3, 0, 3), W4_MMX(0, 4, 0, 3), W4_MMX(0, 5, 0, 3),\
+                  W4_MMX(0, 6, 0, 3), W4_MMX(0, 7, 0, 3) W4_FETCH(2, cA, 2, chunk) W4_FENCE();, W4_MMX(1, 0, 1, 4), W4_MMX(1, 1, 1, 4),\
+                  W4_MMX(1, 2, 1, 4), W4_MMX(1, 3, 1, 4))                                                             \
+    W4_MMX(1, 4, 1, 4) W4_MMX(1, 5, 1, 4) W4_MMX(1, 6, 1, 4) W4_MMX(1, 7, 1, 4)                                       \
+    W4_FETCH(0, cA, 3, chunk)                                                                                         \
+    W4_FENCE();                                                                                                       \
+    W4_ROW_SLICES(twB, nA + DST_B, dAb, dLb, tkb0, tkb1, tkb2,                                                        \
+                  W4_MM(2, 0, 2), W4_MM(2, 1, 2), W4_MM(2, 2, 2), W4_MM(2, 3, 2), W4_MM(2, 4, 2), W4_MM(2, 5, 2), W4_MM(2, 6, 2),\
+                  W4_MM(2, 7, 2) W4_FETCH(1, cA, 4, chunk) W4_FENCE();, W4_MM(3, 0, 0), W4_MM(3, 1, 0), W4_MM(3, 2, 0), W4_MM(3, 3, 0))\
+    W4_MM(3, 4, 0) W4_MM(3, 5, 0) W4_MM(3, 6, 0) W4_MM(3, 7, 0)                                                       \
+    W4_FETCH(2, cA, 5, chunk)                                                                                         \
+    W4_FENCE();                                                                                                       \
+    W4_MM8(4, 1)                                                                                                      \
+    if (!(W4_ABL & 128)) __syncthreads();                                                                             \
+    W4_FETCH(0, cA, 6, chunk)                                                                                         \
+    W4_FENCE();                                                                                                       \
+    W4_MM(5, 0, 2) W4_HALO_PAR(SET) W4_HALO_BN(0, SET) W4_FENCE();                                                    \
+    W4_MM(5, 1, 2) W4_HALO_WR(0, SET) W4_FENCE();                                                                     \
+    W4_MM(5, 2, 2) W4_HALO_BN(1, SET) W4_FENCE();                                                                     \
+    W4_MM(5, 3, 2) W4_HALO_WR(1, SET) W4_FENCE();                                                                     \
+    W4_MM(5, 4, 2) W4_HALO_BN(2, SET) W4_FENCE();                                                                     \
+    W4_MM(5, 5, 2) W4_HALO_WR(2, SET) W4_FENCE();                                                                     \
+    W4_MM(5, 6, 2) W4_HALO_BN(3, SET) W4_FENCE();                                                                     \
+    W4_MM(5, 7, 2) W4_HALO_WR(3, SET) W4_FENCE();                                                                     \
+    W4_FETCH(1, cA, 7, chunk)                                                                                         \
+    W4_FETCH_W(2, 8, chunk)                                                                                           \
+    W4_FETCH_W(3, 0, nchunk)                                                                                          \
+    W4_FETCH_W(4, 1, nchunk)                                                                                          \
+    W4_FENCE();                                                                                                       \
+    W4_MM(6, 0, 0) W4_HALO_BN(4, SET) W4_FENCE();                                                                     \
+    W4_MM(6, 1, 0) W4_HALO_WR(4, SET) W4_FENCE();                                                                     \
+    W4_MM(6, 2, 0)                                                                                                    \
+    W4_ISSUE_HALO(SET)                                                                                                \
+    W4_FENCE();                                                                                                       \
+    W4_MM(6, 3, 0) W4_MM(6, 4, 0) W4_MM(6, 5, 0) W4_MM(6, 6, 0) W4_MM(6, 7, 0)                                        \
+    W4_FETCH_F(2, cA, 8)                                                                                              \
+    W4_FENCE();                                                                                                       \
+    W4_MM8(7, 1)                                                                                                      \
+    if (nchunk != 0) W4_FETCH_F(0, nA, 0)                                                                             \
+    W4_FENCE();                                                                                                       \
+    W4_MM8(8, 2)                                                                                                      \
+    if (!(W4_ABL & 128)) __syncthreads();
+
+  static_assert(PK == 8, "stage = 8 input channels");
   int tile = tile0, chunk = 0;
-  for (g = 0; g < nstages; ++g) {
-    const int buf = g & 1;
-    const float* const cA = sA + buf * W4_A_FLOATS;
-    float* const nA = sA + (buf ^ 1) * W4_A_FLOATS;
-    const int nchunk = chunk + 1 == nst ? 0 : chunk + 1;
-    f32x4 rx0, rx1, rx2, rx3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;
-    // ---- first half: pairs 0..4 || transform of stage g+1 ----
-    W4_FETCH_F(1, cA, 1)
-    W4_FENCE();
-    W4_ROW_SLICES(!(W4_ABL & 2), nA, 0, 0, tka0, tka1, tka2,
-                  W4_MMX(0, 0, 0, 3), W4_MMX(0, 1, 0, 3), W4_MMX(0, 2, 0, 3), W4_MMX(0, 3, 0, 3), W4_MMX(0, 4, 0, 3), W4_MMX(0, 5, 0, 3),
-                  W4_MMX(0, 6, 0, 3), W4_MMX(0, 7, 0, 3) W4_FETCH(2, cA, 2, chunk) W4_FENCE();, W4_MMX(1, 0, 1, 4), W4_MMX(1, 1, 1, 4),
-                  W4_MMX(1, 2, 1, 4), W4_MMX(1, 3, 1, 4))
-    W4_MMX(1, 4, 1, 4) W4_MMX(1, 5, 1, 4) W4_MMX(1, 6, 1, 4) W4_MMX(1, 7, 1, 4)
-    W4_FETCH(0, cA, 3, chunk)
-    W4_FENCE();
-    W4_ROW_SLICES(twB, nA + DST_B, dAb, dLb, tkb0, tkb1, tkb2,
-                  W4_MM(2, 0, 2), W4_MM(2, 1, 2), W4_MM(2, 2, 2), W4_MM(2, 3, 2), W4_MM(2, 4, 2), W4_MM(2, 5, 2), W4_MM(2, 6, 2),
-                  W4_MM(2, 7, 2) W4_FETCH(1, cA, 4, chunk) W4_FENCE();, W4_MM(3, 0, 0), W4_MM(3, 1, 0), W4_MM(3, 2, 0), W4_MM(3, 3, 0))
-    W4_MM(3, 4, 0) W4_MM(3, 5, 0) W4_MM(3, 6, 0) W4_MM(3, 7, 0)
-    W4_FETCH(2, cA, 5, chunk)
-    W4_FENCE();
-    W4_MM8(4, 1)
-    if (!(W4_ABL & 128)) __syncthreads();  // barrier A: sA[~g&1] complete, sR free
-    // ---- second half: pairs 5..8 || halo (g+2): registers -> sR, halo loads (g+3) ----
-    W4_FETCH(0, cA, 6, chunk)
-    W4_FENCE();
-    W4_MM(5, 0, 2) W4_HALO_PAR() W4_HALO_BN(0) W4_FENCE();
-    W4_MM(5, 1, 2) W4_HALO_WR(0) W4_FENCE();
-    W4_MM(5, 2, 2) W4_HALO_BN(1) W4_FENCE();
-    W4_MM(5, 3, 2) W4_HALO_WR(1) W4_FENCE();
-    W4_MM(5, 4, 2) W4_HALO_BN(2) W4_FENCE();
-    W4_MM(5, 5, 2) W4_HALO_WR(2) W4_FENCE();
-    W4_MM(5, 6, 2) W4_HALO_BN(3) W4_FENCE();
-    W4_MM(5, 7, 2) W4_HALO_WR(3) W4_FENCE();
-    W4_FETCH(1, cA, 7, chunk)
-    W4_FETCH_W(2, 8, chunk)   // every weight needed before the halo loads come back ..
-    W4_FETCH_W(3, 0, nchunk)  // .. incl. pairs 0, 1 of the next stage
-    W4_FETCH_W(4, 1, nchunk)
-    W4_FENCE();
-    W4_MM(6, 0, 0) W4_HALO_BN(4) W4_FENCE();
-    W4_MM(6, 1, 0) W4_HALO_WR(4) W4_FENCE();
-    W4_MM(6, 2, 0)
-    W4_ISSUE_HALO()  // a full stage ahead of their use
-    W4_FENCE();
-    W4_MM(6, 3, 0) W4_MM(6, 4, 0) W4_MM(6, 5, 0) W4_MM(6, 6, 0) W4_MM(6, 7, 0)
-    // first pairs of the next stage (after a tile epilogue they are fetched behind it)
-    W4_FETCH_F(2, cA, 8)
-    W4_FENCE();
-    W4_MM8(7, 1)
-    if (nchunk != 0) W4_FETCH_F(0, nA, 0)
-    W4_FENCE();
-    W4_MM8(8, 2)
-    if (!(W4_ABL & 128)) __syncthreads();  // barrier B: sR = raw(g+2) complete, sA[g&1] consumed
+  for (g = 0; g < nstages; g += 2) {  // nst = Cin / 8 is even (Cin % 16 == 0): a tile ends behind an odd stage
+    { W4_STAGE(A, 0) }
+    ++chunk;
+    { W4_STAGE(B, 1) }
+    const int buf = 1;
+    float* const nA = sA;
 
     if (++chunk == nst) {
 #if W4_ABL & 1
@@ -661,6 +681,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     }
   }
 #undef W4_ISSUE_HALO
+#undef W4_STAGE
 #undef W4_CLEAR_V
 #undef W4_HALO_PAR
 #undef W4_HALO_BN

@@ -304,8 +304,8 @@ def test_f4x4_kernel_accumulators_are_private_to_its_inline_asm(tmp_path):
     for name, body in kernels:
         assert not re.search(r"v_accvgpr_(write|read)_b32 [^\n]*\ba\d+\b", body), name   # compiler-allocated aN
         assert "v_accvgpr_mov" not in body and "scratch_" not in body, name
-        assert len(re.findall(r"v_mfma_f32_32x32x2_f32 a\[", body)) == 64, name          # 16 accumulators x 4 k pairs
-        assert len(re.findall(r"v_mfma_f32_32x32x2_f32 v\[", body)) == 8, name           # the pair in vector registers
+        assert len(re.findall(r"v_mfma_f32_32x32x2_f32 a\[", body)) == 128, name         # 16 accumulators x 4 k pairs x 2 stage instances
+        assert len(re.findall(r"v_mfma_f32_32x32x2_f32 v\[", body)) == 16, name          # the pair in vector registers
     for accum, nxt in zip(re.findall(r"\.amdhsa_accum_offset (\d+)", text), re.findall(r"\.amdhsa_next_free_vgpr (\d+)", text)):
         if int(nxt) > 256:  # the four conv_wino4_kernel instances
             assert int(nxt) == int(accum) + 256
@@ -314,7 +314,7 @@ def test_f4x4_kernel_accumulators_are_private_to_its_inline_asm(tmp_path):
 def test_shipped_binary_keeps_the_accumulation_register_contract():
     """hipbuild.verify_binary on the in-tree .so (the file that ships with the gpurun snapshot): the gfx950 code object is
     unbundled and disassembled; conv_wino4_kernel must contain exactly its inline asm's accumulation-register instructions
-    (64 MFMAs, 2 x 256 clears, 2 x 256 reads; wgrad_wino4_kernel: 256 / 256 / 256), no scratch, no spilled vector registers, 256 reserved accumulation registers.
+    (128 MFMAs, 2 x 256 clears, 2 x 256 reads; wgrad_wino4_kernel: 256 / 256 / 256), no scratch, no spilled vector registers, 256 reserved accumulation registers.
     A tampered contract (one instruction less expected) must be rejected."""
     from semantic_superpoint_amd import hipbuild
     if not os.path.exists(os.path.join(hipbuild.LLVM_BIN, "llvm-objdump")):
