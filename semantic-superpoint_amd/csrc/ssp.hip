@@ -169,6 +169,7 @@ struct ssp_handle {
   // fork-join into the hipGraph form).  Created at the first pair step, per device of the handle.
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_pack_fork = nullptr, ev_pack_join = nullptr;  // the weight images are packed beside the first-layer conv
   // profiling
   int prof_family;
   bool prof_paused = false;  // ssp_profile_pause: launches are not bracketed while set (bench.py samples every n-th step)
@@ -972,6 +973,8 @@ void ssp_destroy(ssp_handle* h) {
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_pack_fork) (void)hipEventDestroy(h->ev_pack_fork);
+  if (h->ev_pack_join) (void)hipEventDestroy(h->ev_pack_join);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   delete h;
 }
@@ -1156,6 +1159,17 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
   return 0;
 }
 
+// side stream + events of the handle (fork / join by events; inside a stream capture they become graph dependencies)
+static int ensure_aux_stream(ssp_handle* h) {
+  if (h->aux_stream != nullptr) return 0;
+  HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_pack_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_pack_join, hipEventDisableTiming));
+  return 0;
+}
+
 // One or two activation slots processed together: the two views of a pair are independent problems of identical
 // shape that share the weights, so the MFMA kernels take both in ONE launch (conv: XCDs 0-3 / 4-7; wgrad: one
 // gradient accumulated over both) while the BatchNorm statistics stay per view (Train_model_heatmap_all.py:258,262).
@@ -1218,7 +1232,19 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     CHK(dev_zero(S.stats_region, S.stats_bytes, st));
     S.bsums_dirty = false;
   }
-  CHK(pack_all(h, for_backward, SS.n, N, H, W, st));
+  // The Winograd weight images (a ~95 us latency-bound launch over 2.6 M floats) are packed on the side stream beside the
+  // HBM-bound first-layer convolution, which needs none of them; layer 1 waits for the join.
+  static const int pack_stream_env = getenv("SSP_PACK_STREAM") ? atoi(getenv("SSP_PACK_STREAM")) : 1;  // (perf-debug: 0 = in line)
+  const bool pack_forked = pack_stream_env != 0;
+  if (pack_forked) {
+    CHK(ensure_aux_stream(h));
+    HIPCHK(hipEventRecord(h->ev_pack_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_pack_fork, 0));
+    CHK(pack_all(h, for_backward, SS.n, N, H, W, h->aux_stream));
+    HIPCHK(hipEventRecord(h->ev_pack_join, h->aux_stream));
+  } else {
+    CHK(pack_all(h, for_backward, SS.n, N, H, W, st));
+  }
   // layer 0: direct 1->64 conv (HBM-bound; the views ride one launch, blockIdx.y)
   {
     const LayerDesc& d = h->L[0];
@@ -1229,6 +1255,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     HIPCHK(hipGetLastError());
     CHK(bn_finalize(h, SS.s, SS.n, 0, (double)N * H * W, train, st));
   }
+  if (pack_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_pack_join, 0));
   for (int l = 1; l < 8; ++l) {
     int lh, lw; layer_res(l, H, W, lh, lw);
     CHK(conv_layer_fwd(h, SS, l, l - 1, N, lh, lw, layer_in_mode(l), train, st));
@@ -1654,11 +1681,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   hipStream_t sd = st;
   const bool forked = loss_stream_env != 0 && use_desc && !dense;  // (the dense loss reads the cell mask of the main stream's kernels)
   if (forked) {
-    if (h->aux_stream == nullptr) {
-      HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
+    CHK(ensure_aux_stream(h));
     sd = h->aux_stream;
     HIPCHK(hipEventRecord(h->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sd, h->ev_fork, 0));
