@@ -784,7 +784,7 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   // Winograd F(3x3,4x4) (wgrad_wino4_kernel: 1/4 of the direct multiplies), OPT-IN: conv algorithm 11 (= algorithm 1 with this
   // weight gradient) or SSP_WGRAD_F4=1 under algorithms 1 / 10.  Correct on every 3x3 layer with a prefetchable input and any
   // map size (dY is zero-filled outside the map); 64 ci x 32 co slabs over the same 128-pixel block tiles as F(3x3,2x2).
-  // Not the default: measured equal at 240x320 and 10-50 % slower below (profiles/r03_wgrad4_ablation.txt, DESIGN.md s. 12).
+  // Not the default: measured equal at 240x320 and 10-50 % slower below (profiles/r03_kernel_experiments.txt, DESIGN.md s. 12).
   static const int wg4_env = getenv("SSP_WGRAD_F4") ? atoi(getenv("SSP_WGRAD_F4")) : 0;
   const bool wino4 = (g_conv_algo == 11 || (wg4_env != 0 && (g_conv_algo == 1 || g_conv_algo == 10))) && c.ks == 3 && c.in_mode != 2;
   const bool wino = wino4 || (g_conv_algo != 0 && c.ks == 3 && c.in_mode != 2 && c.H % 2 == 0 && c.W % 2 == 0);
