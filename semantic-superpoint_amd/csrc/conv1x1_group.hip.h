@@ -1,0 +1,270 @@
+// Grouped pointwise (1x1) convolutions of the heads on v_mfma_f32_32x32x2_f32: convPb 256 -> 65, convDb 256 -> 256, convSout
+// 256 -> 133 (models/SuperPointNet_gauss2.py:59-66, SuperPointNet_gauss2_ssmall.py:57-70 of the reference), forward and data
+// gradient, BOTH views, in ONE launch.
+//
+// Why not conv_mfma_kernel<1, ...> (the implicit-GEMM kernel these layers used before): it stages the pixels through LDS in
+// 16-channel chunks (32 MFMAs per wave between two barriers), once per 64-channel output block (4x for 256 outputs), rounds
+// 65 / 133 outputs up to 128 / 192, and three launches of 0.6-2.3 rounds over the chip each pay their own tail.
+//
+// This kernel is a plain GEMM, D[pixel][cout] = sum_k A[pixel][k] W[k][cout]:
+//   * a pointwise conv has no halo, so a lane's A operand IS its own pixel's channel vector: loaded straight from global
+//     memory into the MFMA operand registers (four 16-byte loads per lane and 32-channel chunk, 64 contiguous bytes per lane -
+//     every 128-byte line is consumed by its two half-waves inside the same four instructions), BatchNorm + ReLU of the
+//     producing layer applied in registers; no LDS round trip, no re-staging per output block;
+//   * W is packed in operand order [chunk][n-tile][k-quad][lane][4] (pack_g1_kernel), copied chunk by chunk into a
+//     double-buffered LDS image (one barrier per chunk) and read back with one ds_read_b128 per four MFMAs;
+//   * a wave owns 32 pixels x (up to 4) 32-channel n-tiles, a workgroup item is 128 pixels of one problem; outputs wider than
+//     128 channels are split into problems of <= 4 n-tiles (65 -> 3, 133 -> 3 + 2, 256 -> 4 + 4 tiles), <= 170 registers,
+//     three workgroups per CU;
+//   * the items of all problems of a launch sit in one list, heaviest first, handed out through an atomic counter
+//     (longest-processing-time-first): the tails of the small problems fill with each other.  The last workgroup to
+//     leave resets the counter pair, so a launch needs no memset and replays inside a captured graph.
+// Partial K (65 / 133 input channels of the data gradient): the last chunk runs only the k-quads that hold channels; channels
+// past K are masked in registers (the rows of the packed image are zero as well).
+// Forward launches accumulate the BatchNorm statistics (per-lane channel sums kept across the items of a problem, flushed when
+// the workgroup moves to another problem).
+#pragma once
+#include "conv_mfma.hip.h"
+
+namespace sspk {
+
+constexpr int G1_KC = 32;      // input channels per K-chunk
+constexpr int G1_NT = 4;       // 32-channel n-tiles per problem
+constexpr int G1_PX = 128;     // pixels per workgroup item
+constexpr int G1_KMAX = 512;   // input channels (scale / shift image in LDS)
+constexpr int G1_MAXP = 12;    // problems per launch
+constexpr int G1_TILE_FLOATS = 4 * 64 * 4;  // one (chunk, n-tile) of the packed image: [k-quad][lane][4]
+constexpr int G1_LDS_BYTES = (2 * G1_NT * G1_TILE_FLOATS + 2 * G1_KMAX + 4 * G1_NT * 64) * 4;
+
+struct G1Prob {
+  const float* in;        // [npx][in_cs], channels in_co .. in_co + K
+  float* out;             // [npx][out_cs], channels out_co .. out_co + N
+  const float* wpk;       // packed image of this problem's FIRST n-tile: [chunk][nt_total][4][64][4]
+  const float* bias;      // [N] or nullptr
+  const float* in_scale;  // [K] (IN_MODE 1)
+  const float* in_shift;
+  double* stats;          // [NREP][2 stats_c] at this problem's first channel, or nullptr
+  int stats_c;            // channels of the whole layer (row pitch of stats)
+  int in_cs, in_co, out_cs, out_co;
+  int K, N;               // input channels, output channels of THIS problem (<= 128)
+  int nchunks, nt, nt_total;
+  int npx;
+  int item0;              // index of this problem's first item in the launch's list
+  unsigned in_bytes, out_bytes;
+};
+struct G1Args {
+  G1Prob p[G1_MAXP];
+  int nprob, nitems;
+  int* counter;           // {next item, finished workgroups}: zero between launches
+};
+
+// One workgroup item (128 pixels of problem p) with NT n-tiles; ssum / ssq: the BatchNorm partial sums of the problem.
+template <int IN_MODE, int NT>
+__device__ __forceinline__ void g1_item(const G1Prob& p, int px0, float* sB, const float* sSc, float (&ssum)[G1_NT],
+                                        float (&ssq)[G1_NT], int tid, int lane, int li, int lh) {
+  constexpr unsigned OOB = 0x80000000u;
+  const int nchunks = p.nchunks, K = p.K;
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const unsigned voffA = (px0 + li < p.npx) ? (unsigned)(((px0 + li) * p.in_cs + p.in_co + 16 * lh) * 4) : OOB;
+  const float* const wsrc = p.wpk + tid * 4;  // + (chunk * nt_total + t) * G1_TILE_FLOATS
+  const int wstride = p.nt_total * G1_TILE_FLOATS;
+
+  f32x4 araw[4], wreg[NT];
+#define G1_ISSUE(CHUNK)                                                                                               \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                   \
+      const unsigned vo_ = ((CHUNK) * G1_KC + 16 * lh + 4 * q < K) ? voffA : OOB;                                     \
+      araw[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo_ + q * 16, (CHUNK) * G1_KC * 4, 0)); \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
+      wreg[t] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(CHUNK) * wstride + t * G1_TILE_FLOATS);               \
+  }
+  G1_ISSUE(0)
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    float* const sBc = sB + (chunk & 1) * (G1_NT * G1_TILE_FLOATS);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(sBc + t * G1_TILE_FLOATS + tid * 4) = wreg[t];
+    __syncthreads();  // this chunk's weights are in LDS (and, at chunk 0, the scale / shift image of the problem)
+    // the lane's 16 channels of this chunk: [32 chunk + 16 lh, + 16)
+    float av[16];
+    {
+      const int kb = chunk * G1_KC + 16 * lh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = araw[q];
+        if (IN_MODE != 0) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(sSc + kb + 4 * q);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(sSc + G1_KMAX + kb + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[4 * q + e] = v[e];
+      }
+      if (kb + 16 > K) {  // channels past K (the last chunk of a 65 / 133-channel data gradient)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) av[e] = (kb + e < K) ? av[e] : 0.f;
+      }
+    }
+    if (chunk + 1 < nchunks) G1_ISSUE(chunk + 1)
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay above the MFMAs
+    const int nq = min(4, (K - chunk * G1_KC + 3) >> 2);  // k-quads of this chunk that hold channels (of the lh = 0 half)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < nq) {
+        f32x4 bq[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const f32x4*>(sBc + (t * 4 + q) * 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * q + e], bq[t][e], acc[t], 0, 0, 0);
+      }
+    }
+  }
+#undef G1_ISSUE
+
+  // ---- epilogue: lane = output channel 32 t + li, register r = pixel (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 ----
+  const bool full = px0 + 32 <= p.npx;
+  const bool want_stats = p.stats != nullptr;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ch = 32 * t + li;
+    const bool chok = ch < p.N;
+    const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.f;
+    const unsigned vbase = (unsigned)(((px0 + 4 * lh) * p.out_cs + p.out_co + ch) * 4);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2);
+      const float v = acc[t][r] + bv;
+      const bool ok = chok && (full || px0 + 4 * lh + m < p.npx);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_out, ok ? vbase : OOB, m * p.out_cs * 4, 0);
+      const float vm = ok ? v : 0.f;
+      s1 += vm;
+      s2 = fmaf(vm, vm, s2);
+    }
+    if (want_stats) { ssum[t] += s1; ssq[t] += s2; }
+  }
+}
+
+template <int IN_MODE>
+__global__ __launch_bounds__(256, 3) void conv1x1_group_kernel(const G1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const sB = smem;                                  // [2][G1_NT][4][64][4]
+  float* const sSc = smem + 2 * G1_NT * G1_TILE_FLOATS;    // scale[G1_KMAX], shift[G1_KMAX]
+  float* const sRed = sSc + 2 * G1_KMAX;                   // [4 waves][G1_NT][32][2]
+  __shared__ int s_item;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+
+  float ssum[G1_NT], ssq[G1_NT];
+#pragma unroll
+  for (int t = 0; t < G1_NT; ++t) ssum[t] = ssq[t] = 0.f;
+  int cur = -1;  // problem whose scale / shift image sits in LDS and whose statistics sit in ssum / ssq
+
+  auto flush_stats = [&](int pi) {  // workgroup-uniform call
+    const G1Prob& q = a.p[pi];
+    if (q.stats == nullptr) return;
+#pragma unroll
+    for (int t = 0; t < G1_NT; ++t) {
+      const float s = ssum[t] + __shfl_xor(ssum[t], 32), v = ssq[t] + __shfl_xor(ssq[t], 32);
+      if (lh == 0) {
+        sRed[((wave * G1_NT + t) * 32 + li) * 2 + 0] = s;
+        sRed[((wave * G1_NT + t) * 32 + li) * 2 + 1] = v;
+      }
+      ssum[t] = ssq[t] = 0.f;
+    }
+    __syncthreads();
+    {
+      const int ch = tid >> 1, which = tid & 1;  // 128 channels x {sum, sum of squares}
+      if (ch < q.N) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tsum += sRed[((w * G1_NT + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
+        unsafeAtomicAdd(q.stats + (size_t)(blockIdx.x % NREP) * 2 * q.stats_c + which * q.stats_c + ch, (double)tsum);
+      }
+    }
+    __syncthreads();
+  };
+
+  for (;;) {
+    __syncthreads();  // every wave is done with s_item and with the LDS images of the previous item
+    if (tid == 0) s_item = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(s_item);
+    if (item >= a.nitems) break;
+    int pi = 0;
+    while (pi + 1 < a.nprob && item >= a.p[pi + 1].item0) ++pi;
+    const G1Prob& p = a.p[pi];
+    if (pi != cur) {
+      if (cur >= 0) flush_stats(cur);
+      cur = pi;
+      if (IN_MODE != 0) {
+        for (int k = tid; k < G1_KMAX; k += 256) {
+          const bool ok = k < p.K;
+          sSc[k] = ok ? p.in_scale[k] : 0.f;
+          sSc[G1_KMAX + k] = ok ? p.in_shift[k] : 0.f;
+        }
+      }
+      // (the first barrier of the chunk loop orders these writes before the first read)
+    }
+    const int px0 = (item - p.item0) * G1_PX + wave * 32;
+    switch (p.nt) {
+      case 1: g1_item<IN_MODE, 1>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
+      case 2: g1_item<IN_MODE, 2>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
+      case 3: g1_item<IN_MODE, 3>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
+      default: g1_item<IN_MODE, 4>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
+    }
+  }
+  if (cur >= 0) flush_stats(cur);
+  // the last workgroup out re-arms the counters for the next launch (kernel boundaries order it)
+  if (tid == 0) {
+    __threadfence();
+    const int done = atomicAdd(a.counter + 1, 1);
+    if (done == (int)gridDim.x - 1) {
+      a.counter[0] = 0;
+      a.counter[1] = 0;
+    }
+  }
+}
+
+// Packed operand image of one pointwise layer: dst[chunk][tile][q][lh][li][j] = W[k = 32 chunk + 16 lh + 4 q + j][n = 32 tile + li],
+// W[k][n] = w[n][k] (forward: n = output channel of the OIHW tensor) or w[k][n] (transpose: the data gradient), zero outside.
+struct G1PackJob {
+  const float* w;
+  float* dst;
+  int cout_w, cin_w, transpose;
+  int nchunks, nt_total;
+  int block0;
+};
+constexpr int G1_PACK_MAX_JOBS = 8;
+struct G1PackJobs {
+  int n;
+  G1PackJob j[G1_PACK_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void pack_g1_kernel(const G1PackJobs J) {
+  int k = 0;
+  while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;
+  const G1PackJob& q = J.j[k];
+  const int idx = ((int)blockIdx.x - q.block0) * 256 + threadIdx.x;
+  const int total = q.nchunks * q.nt_total * G1_TILE_FLOATS;
+  if (idx >= total) return;
+  const int j = idx & 3, li = (idx >> 2) & 31, lh = (idx >> 7) & 1, kq = (idx >> 8) & 3;
+  const int tile = (idx >> 10) % q.nt_total, chunk = (idx >> 10) / q.nt_total;
+  const int kk = G1_KC * chunk + 16 * lh + 4 * kq + j, n = 32 * tile + li;
+  const int K = q.transpose ? q.cout_w : q.cin_w, N = q.transpose ? q.cin_w : q.cout_w;
+  float v = 0.f;
+  if (kk < K && n < N) v = q.transpose ? q.w[(size_t)kk * q.cin_w + n] : q.w[(size_t)n * q.cin_w + kk];
+  q.dst[idx] = v;
+}
+
+}  // namespace sspk

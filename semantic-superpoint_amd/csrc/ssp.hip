@@ -15,6 +15,7 @@
 
 #include "bn_kernels.hip.h"
 #include "conv_mfma.hip.h"
+#include "conv1x1_group.hip.h"
 #include "conv_wino.hip.h"
 #include "conv_wino_pipe.hip.h"
 #include "conv_wino_p2.hip.h"
@@ -158,6 +159,11 @@ struct ssp_handle {
   // shape (a forward of another shape / view count on the other slot, or ssp_handle_set_conv_algo, between a forward and its
   // backward would otherwise run an F(2x2,3x3) kernel on an F(4x4,3x3) image or the reverse)
   bool pk_w4_fwd[16] = {}, pk_w4_bwd[16] = {};
+  // pointwise layers (Pb, Db, Sout): operand images of conv1x1_group_kernel (forward / data gradient), whether pack_all wrote
+  // them (else the layer runs conv_mfma_kernel<1, ...> on the wpk_fwd / wpk_bwd images), and the kernel's work-queue counters
+  float *wpk_g1_fwd[16] = {}, *wpk_g1_bwd[16] = {};
+  bool pk_g1[16] = {};
+  int* g1_counter = nullptr;
   int packed_algo = -1;      // conv algorithm the images were packed for
   bool packed_bwd = false;   // the data-gradient images were packed too
   // captured pair steps (ssp_pair_step_graph): one executable graph per (phase, input signature)
@@ -280,6 +286,14 @@ static size_t carve(ssp_handle* h, void* base) {
   h->wpk_fwd = c.take<float>(pf);
   h->wpk_bwd = c.take<float>(pb);
   h->wpk_heads_bwd = c.take<float>((size_t)2 * 16 * h->nheads * WC * CK * NB);
+  for (int i = 0; i < h->nlayers; ++i) {
+    const LayerDesc& d = h->L[i];
+    h->wpk_g1_fwd[i] = h->wpk_g1_bwd[i] = nullptr;
+    if (d.ks != 1) continue;
+    h->wpk_g1_fwd[i] = c.take<float>((size_t)cdiv(d.cin, G1_KC) * cdiv(d.cout, 32) * G1_TILE_FLOATS);
+    h->wpk_g1_bwd[i] = c.take<float>((size_t)cdiv(d.cout, G1_KC) * cdiv(d.cin, 32) * G1_TILE_FLOATS);
+  }
+  h->g1_counter = c.take<int>(64);
   for (int s = 0; s < 2; ++s) {
     Slot& S = h->slot[s];
     for (int l = 0; l < 8; ++l) {
@@ -656,6 +670,89 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   CONV_CASE(3, 0) CONV_CASE(3, 1) CONV_CASE(3, 2) CONV_CASE(1, 0) CONV_CASE(1, 1)
 #undef CONV_CASE
   return fail(-3, "unsupported conv variant ks=%d in_mode=%d", c.ks, c.in_mode);
+}
+
+// ---- grouped pointwise convolutions (conv1x1_group.hip.h): several layers x views in one launch ----
+struct G1Layer {
+  const float* in[2] = {nullptr, nullptr}; int in_cs = 0, in_co = 0;
+  float* out[2] = {nullptr, nullptr}; int out_cs = 0, out_co = 0;
+  const float* wpk = nullptr;   // pack_g1_kernel's image of the whole layer
+  const float* bias = nullptr;
+  const float* scale[2] = {nullptr, nullptr}; const float* shift[2] = {nullptr, nullptr};  // BatchNorm + ReLU on load (in_mode 1)
+  double* stats[2] = {nullptr, nullptr};                                                   // BatchNorm statistics of the output
+  int K = 0, N = 0;
+};
+static inline size_t g1_image_floats(int K, int N) { return (size_t)cdiv(K, G1_KC) * cdiv(N, 32) * G1_TILE_FLOATS; }
+// SSP_G1=0 (perf-debug) and the direct algorithm 0 keep the pointwise layers on conv_mfma_kernel<1, ...>
+static bool g1_enabled() {
+  static const int env = getenv("SSP_G1") ? atoi(getenv("SSP_G1")) : 1;
+  return env != 0 && g_conv_algo != 0;
+}
+static bool g1_fits(int K, int N, long npx, int in_cs, int out_cs, int nviews) {
+  const long parts = cdiv(cdiv(N, 32), G1_NT);
+  return K >= 1 && K <= G1_KMAX && N >= 1 && parts * nviews <= G1_MAXP && npx > 0 &&
+         (double)npx * in_cs * 4.0 < 2147483648.0 && (double)npx * out_cs * 4.0 < 2147483648.0;
+}
+static int launch_g1(const G1Layer* L, int nl, int nviews, long npx, int in_mode, int* counter, int n_cu, hipStream_t st) {
+  struct Tmp { G1Prob p; long cost; };
+  std::vector<Tmp> v;
+  for (int i = 0; i < nl; ++i) {
+    const G1Layer& y = L[i];
+    if (!g1_fits(y.K, y.N, npx, y.in_cs, y.out_cs, nviews)) return fail(-3, "pointwise conv %d -> %d does not fit the grouped kernel", y.K, y.N);
+    const int ntt = cdiv(y.N, 32), nparts = cdiv(ntt, G1_NT);
+    int t0 = 0;
+    for (int part = 0; part < nparts; ++part) {
+      const int size = ntt / nparts + (part < ntt % nparts ? 1 : 0);
+      for (int k = 0; k < nviews; ++k) {
+        Tmp t;
+        G1Prob& q = t.p;
+        q.in = y.in[k]; q.out = y.out[k]; q.wpk = y.wpk + (size_t)t0 * G1_TILE_FLOATS; q.bias = y.bias ? y.bias + 32 * t0 : nullptr;
+        q.in_scale = y.scale[k]; q.in_shift = y.shift[k]; q.stats = y.stats[k] ? y.stats[k] + 32 * t0 : nullptr; q.stats_c = y.N;
+        q.in_cs = y.in_cs; q.in_co = y.in_co; q.out_cs = y.out_cs; q.out_co = y.out_co + 32 * t0;
+        q.K = y.K; q.N = std::min(y.N - 32 * t0, 32 * size); q.nchunks = cdiv(y.K, G1_KC); q.nt = size; q.nt_total = ntt;
+        q.npx = (int)npx; q.item0 = 0;
+        q.in_bytes = (unsigned)((size_t)npx * y.in_cs * 4); q.out_bytes = (unsigned)((size_t)npx * y.out_cs * 4);
+        if (in_mode != 0 && (!q.in_scale || !q.in_shift)) return fail(-1, "pointwise conv: in_mode 1 needs scale / shift");
+        t.cost = (long)size * cdiv(y.K, 4);
+        v.push_back(t);
+      }
+      t0 += size;
+    }
+  }
+  if (v.empty()) return 0;
+  if ((int)v.size() > G1_MAXP) return fail(-3, "grouped pointwise launch: %d problems (max %d)", (int)v.size(), G1_MAXP);
+  std::stable_sort(v.begin(), v.end(), [](const Tmp& x, const Tmp& y) { return x.cost > y.cost; });  // heaviest items first
+  G1Args a;
+  a.nprob = (int)v.size();
+  int items = 0;
+  for (int i = 0; i < a.nprob; ++i) {
+    a.p[i] = v[i].p;
+    a.p[i].item0 = items;
+    items += cdiv(npx, G1_PX);
+  }
+  a.nitems = items;
+  a.counter = counter;
+  const int grid = std::max(1, std::min(items, 3 * n_cu));
+  static AttrOnce attr0, attr1;
+  if (in_mode != 0) {
+    auto kern = conv1x1_group_kernel<1>;
+    if (attr1.need()) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G1_LDS_BYTES, st, a);
+  } else {
+    auto kern = conv1x1_group_kernel<0>;
+    if (attr0.need()) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G1_LDS_BYTES, st, a);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// one launch packs the operand images of up to G1_PACK_MAX_JOBS (layer, direction) pairs
+static void g1_add_pack(G1PackJobs& J, int& nblocks, const float* w, float* dst, int cout_w, int cin_w, int transpose) {
+  G1PackJob& q = J.j[J.n++];
+  q.w = w; q.dst = dst; q.cout_w = cout_w; q.cin_w = cin_w; q.transpose = transpose;
+  const int K = transpose ? cout_w : cin_w, N = transpose ? cin_w : cout_w;
+  q.nchunks = cdiv(K, G1_KC); q.nt_total = cdiv(N, 32); q.block0 = nblocks;
+  nblocks += cdiv((long)q.nchunks * q.nt_total * G1_TILE_FLOATS, 256);
 }
 
 template <int KS, int IN_MODE, int SH, int SW>
@@ -1114,11 +1211,27 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     }
     return launch_pack(w, dst, cout_w, cin_w, ks, tf, wino, st, w4);
   };
+  G1PackJobs G;
+  G.n = 0;
+  int g1_blocks = 0;
   for (int l = 1; l < h->nlayers; ++l) {
     const LayerDesc& d = h->L[l];
     // the encoder's 3x3 layers at their resolution: the same F(4x4,3x3) predicate as the launches (conv_uses_w4)
     int lh = H / 8, lw = W / 8;
     if (l < 8) layer_res(l, H, W, lh, lw);
+    h->pk_g1[l] = false;
+    if (d.ks == 1 && g1_enabled() && G.n + 2 <= G1_PACK_MAX_JOBS) {
+      const long npx = (long)N * lh * lw;
+      const Slot& S0 = h->slot[0];
+      const int src = l - 1, hcs = 256 * h->nheads;  // Pb <- Pa, Db <- Da, Sout <- DS: the layer before it in the table
+      if (g1_fits(d.cin, d.cout, npx, S0.y_cs[src], S0.y_cs[l], nprob) &&
+          g1_fits(d.cout, d.cin, npx, std::max(S0.y_cs[l], 80), hcs, nprob)) {
+        h->pk_g1[l] = true;
+        g1_add_pack(G, g1_blocks, P(h, d.w_off), h->wpk_g1_fwd[l], d.cout, d.cin, 0);
+        if (with_bwd) g1_add_pack(G, g1_blocks, P(h, d.w_off), h->wpk_g1_bwd[l], d.cout, d.cin, 1);
+        continue;
+      }
+    }
     const bool wf = wino_ok(d.ks, d.cin), wb = wino_ok(d.ks, d.cout);
     h->pk_w4_fwd[l] = wf && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, d.cin, d.cout);
     CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wf, h->pk_w4_fwd[l]));
@@ -1154,6 +1267,10 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
   }
   if (J.n > 0) {
     hipLaunchKernelGGL(pack_weights_wino8_multi_kernel, dim3(nblocks), dim3(256), 0, st, J);
+    HIPCHK(hipGetLastError());
+  }
+  if (G.n > 0) {
+    hipLaunchKernelGGL(pack_g1_kernel, dim3(g1_blocks), dim3(256), 0, st, G);
     HIPCHK(hipGetLastError());
   }
   return 0;
@@ -1261,14 +1378,43 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     CHK(conv_layer_fwd(h, SS, l, l - 1, N, lh, lw, layer_in_mode(l), train, st));
   }
   const int Hc = H / 8, Wc = W / 8;
+  // the pointwise layers Pb, Db, Sout of both views: ONE grouped launch after the 3x3 head convs (conv1x1_group_kernel) when
+  // pack_all wrote their images, else one conv_mfma_kernel<1, ...> launch each
+  auto pointwise = [&](const int* layers, int n) -> int {
+    bool grouped = true;
+    for (int i = 0; i < n; ++i) grouped = grouped && h->pk_g1[layers[i]];
+    if (!grouped) {
+      for (int i = 0; i < n; ++i) CHK(conv_layer_fwd(h, SS, layers[i], layers[i] - 1, N, Hc, Wc, 1, train, st));
+      return 0;
+    }
+    G1Layer Lg[3];
+    for (int i = 0; i < n; ++i) {
+      const int l = layers[i], src = l - 1;
+      const LayerDesc& d = h->L[l];
+      G1Layer& y = Lg[i];
+      y.in_cs = SS.s[0]->y_cs[src]; y.in_co = SS.s[0]->y_co[src]; y.out_cs = SS.s[0]->y_cs[l]; y.out_co = SS.s[0]->y_co[l];
+      y.wpk = h->wpk_g1_fwd[l]; y.bias = P(h, d.b_off); y.K = d.cin; y.N = d.cout;
+      for (int k = 0; k < SS.n; ++k) {
+        Slot& S = *SS.s[k];
+        y.in[k] = S.Y[src]; y.out[k] = S.Y[l]; y.scale[k] = S.bn[src].scale; y.shift[k] = S.bn[src].shift;
+        y.stats[k] = (d.bn && train) ? S.bn[l].stats : nullptr;
+      }
+    }
+    CHK(launch_g1(Lg, n, SS.n, (long)N * Hc * Wc, 1, h->g1_counter, h->n_cu, st));
+    for (int i = 0; i < n; ++i)
+      if (h->L[layers[i]].bn) CHK(bn_finalize(h, SS.s, SS.n, layers[i], (double)N * Hc * Wc, train, st));
+    return 0;
+  };
+  const int pw[3] = {L_DB, L_SOUT, L_PB};
   CHK(conv_layer_fwd(h, SS, L_PA, 7, N, Hc, Wc, 1, train, st));
-  if (detector_only) return conv_layer_fwd(h, SS, L_PB, L_PA, N, Hc, Wc, 1, train, st);
+  if (detector_only) return pointwise(pw + 2, 1);
   CHK(conv_layer_fwd(h, SS, L_DA, 7, N, Hc, Wc, 1, train, st));
-  CHK(conv_layer_fwd(h, SS, L_PB, L_PA, N, Hc, Wc, 1, train, st));
-  CHK(conv_layer_fwd(h, SS, L_DB, L_DA, N, Hc, Wc, 1, train, st));
   if (h->nheads == 3) {
     CHK(conv_layer_fwd(h, SS, L_DS, 7, N, Hc, Wc, 1, train, st));
-    CHK(conv_layer_fwd(h, SS, L_SOUT, L_DS, N, Hc, Wc, 1, train, st));
+    CHK(pointwise(pw, 3));
+  } else {
+    const int pw2[2] = {L_DB, L_PB};
+    CHK(pointwise(pw2, 2));
   }
   const int ncells = N * Hc * Wc;
   for (int k = 0; k < SS.n; ++k) {
@@ -1390,7 +1536,7 @@ static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, Co
 // dY of each view in dy[k] (channel stride dy_cs, offset dy_co); the data gradient goes to din[k].
 static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src, float* const* dy, int dy_cs, int dy_co,
                                float* const* din, int din_cs, int din_co, int N, int H, int W, int in_mode,
-                               hipStream_t st) {
+                               hipStream_t st, bool skip_dgrad = false) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
   const bool pooled = in_mode == 2;  // Apool[src] holds the pooled input: raw pooled y (pool_raw: BatchNorm + ReLU on load)
@@ -1430,6 +1576,7 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
     }
   }
   CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
+  if (skip_dgrad) return 0;  // the caller runs the data gradient itself (the grouped pointwise launch of the heads)
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_DGRAD : 0));
   return 0;
 }
@@ -1481,13 +1628,30 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
   }
   // ---- 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only); gP = dHeadsAct [cells][hcs], gQ = dY scratch ----
   float* dact[2] = {gP[0], gP[1]};
+  // The three data gradients ride ONE grouped launch (conv1x1_group_kernel) when pack_all wrote the images of every head that
+  // has a gradient; dY of Pb and Db then sit side by side in gQ ([cells][80] | [cells][256]) until that launch has read them.
+  const bool grouped = (!has_semi || h->pk_g1[L_PB]) && (!has_desc || h->pk_g1[L_DB]) && (!has_sem || h->pk_g1[L_SOUT]);
+  const size_t ncells_all = (size_t)N * Hc * Wc;
+  float* gQd[2] = {gQ[0], gQ[1]};  // Db's dY
+  if (grouped && has_semi)
+    for (int k = 0; k < SS.n; ++k) gQd[k] = gQ[k] + ncells_all * 80;
+  G1Layer Lg[3];
+  int ng = 0;
+  auto add_dgrad = [&](int l, float* const* dy, int dy_cs, int co) {
+    const LayerDesc& d = h->L[l];
+    G1Layer& y = Lg[ng++];
+    y.in_cs = dy_cs; y.in_co = 0; y.out_cs = hcs; y.out_co = co; y.wpk = h->wpk_g1_bwd[l]; y.K = d.cout; y.N = d.cin;
+    for (int k = 0; k < SS.n; ++k) { y.in[k] = dy[k]; y.out[k] = dact[k]; }
+  };
   if (has_semi) {
     CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQ, 80, 0, N, Hc, Wc, st));
-    CHK(conv_layer_backward(h, SS, L_PB, L_PA, gQ, 80, 0, dact, hcs, 0, N, Hc, Wc, 1, st));
+    CHK(conv_layer_backward(h, SS, L_PB, L_PA, gQ, 80, 0, dact, hcs, 0, N, Hc, Wc, 1, st, grouped));
+    if (grouped) add_dgrad(L_PB, gQ, 80, 0);
   }
   if (has_desc) {
-    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQ, 256, 0, N, Hc, Wc, st));
-    CHK(conv_layer_backward(h, SS, L_DB, L_DA, gQ, 256, 0, dact, hcs, 256, N, Hc, Wc, 1, st));
+    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st));
+    CHK(conv_layer_backward(h, SS, L_DB, L_DA, gQd, 256, 0, dact, hcs, 256, N, Hc, Wc, 1, st, grouped));
+    if (grouped) add_dgrad(L_DB, gQd, 256, 256);
   }
   if (has_sem) {
     const LayerDesc& d = h->L[L_SOUT];
@@ -1497,8 +1661,10 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
       hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, COLSUM_ROWS)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), ncells, d.cout,
                          h->sout_cs);
     HIPCHK(hipGetLastError());
-    CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st));
+    CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st, grouped));
+    if (grouped) add_dgrad(L_SOUT, dsout, h->sout_cs, 512);
   }
+  if (grouped && ng > 0) CHK(launch_g1(Lg, ng, SS.n, (long)ncells_all, 0, h->g1_counter, h->n_cu, st));
   // ---- 3x3 heads: BN+ReLU backward gP -> gQ [cells][hcs]; weight gradients; ONE data-gradient conv over the
   // concatenated dY channels (sums the heads' contributions) gQ -> gP [cells][128] ----
   {
@@ -1906,6 +2072,26 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
                 double* stats_dev, int transpose_flip, void* workspace_dev, size_t workspace_bytes, void* stream) {
   // with transpose_flip the weight tensor is [cin_conv... see header]: w is OIHW with O = (tf ? cin : cout)
   AlgoScope algo(nullptr);
+  if (ksize == 1 && in_mode != 2 && g1_enabled() && g1_fits(cin, cout, (long)n * hh * w, cin, cout, 1)) {
+    // pointwise layer: the grouped kernel of the heads, one problem set (conv1x1_group.hip.h); workspace = image | counters
+    const size_t img = align_up(g1_image_floats(cin, cout) * sizeof(float), 256);
+    if (workspace_bytes >= img + 256) {
+      hipStream_t st = (hipStream_t)stream;
+      float* wpk = reinterpret_cast<float*>(workspace_dev);
+      int* counter = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace_dev) + img);
+      G1PackJobs G;
+      G.n = 0;
+      int nb = 0;
+      g1_add_pack(G, nb, w_oihw_dev, wpk, transpose_flip ? cin : cout, transpose_flip ? cout : cin, transpose_flip ? 1 : 0);
+      hipLaunchKernelGGL(pack_g1_kernel, dim3(nb), dim3(256), 0, st, G);
+      HIPCHK(hipGetLastError());
+      CHK(dev_zero(counter, 256, st));
+      G1Layer y;
+      y.in[0] = in_dev; y.in_cs = cin; y.in_co = 0; y.out[0] = out_dev; y.out_cs = cout; y.out_co = 0; y.wpk = wpk; y.bias = bias_dev;
+      y.scale[0] = in_scale_dev; y.shift[0] = in_shift_dev; y.stats[0] = stats_dev; y.K = cin; y.N = cout;
+      return launch_g1(&y, 1, 1, (long)n * hh * w, in_mode, counter, 256, st);
+    }
+  }
   const bool wino = wino_ok(ksize, cin) && in_mode != 2;
   const int nchunks = cdiv(cin, CK), ncob = cdiv(cout, NB);
   const size_t need = (size_t)ncob * nchunks * pk_taps(ksize) * CK * NB * sizeof(float);

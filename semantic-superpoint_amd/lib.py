@@ -634,8 +634,9 @@ def op_conv(x_nhwc, w_oihw, bias, ksize, in_mode=0, in_scale=None, in_shift=None
     H, W = (Hin // 2, Win // 2) if in_mode == 2 else (Hin, Win)
     cout = w_oihw.shape[1] if transpose_flip else w_oihw.shape[0]
     out = torch.empty(N, H, W, cout, dtype=torch.float32, device=x_nhwc.device)
-    ws = torch.empty(((cin + 15) // 16) * ((cout + 63) // 64) * (36 if ksize == 3 else 1) * 16 * 64 * 4 + 1024, dtype=torch.uint8,
-                     device=x_nhwc.device)
+    # packed weight image of the kernel family (3x3: Winograd components; 1x1: 32 x 32 operand tiles + the work-queue counters)
+    ws = torch.empty(max(((cin + 15) // 16) * ((cout + 63) // 64) * (36 if ksize == 3 else 1) * 16 * 64 * 4,
+                         ((cin + 31) // 32) * ((cout + 31) // 32) * 4096 + 512) + 1024, dtype=torch.uint8, device=x_nhwc.device)
     with torch.cuda.device(x_nhwc.device):
         _check(lib.ssp_op_conv(_ptr(x_nhwc), _ptr(w_oihw), _ptr(bias), _ptr(out), N, H, W, cin, cout, ksize, in_mode,
                                _ptr(in_scale), _ptr(in_shift), _ptr(stats), int(transpose_flip), _ptr(ws), ws.numel(),

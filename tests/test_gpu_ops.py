@@ -55,6 +55,8 @@ CONV_CASES = [
     (2, 30, 40, 256, 65, 1, 1),   # convPb: 1x1, cout tail
     (1, 4, 6, 256, 256, 1, 1),    # convDb
     (1, 16, 32, 256, 133, 1, 0),  # 1x1 raw input, wide
+    (3, 7, 9, 40, 200, 1, 1),     # 1x1: partial 32-channel chunk under BatchNorm-on-load, 7 n-tiles = two grouped problems, ragged pixels
+    (1, 3, 5, 300, 20, 1, 0),     # 1x1: ten chunks, one partial n-tile, 15 pixels
     (1, 9, 11, 64, 64, 3, 1),     # odd map: partial 2x2 Winograd tiles at the right / bottom edge
     (2, 14, 20, 32, 64, 3, 0),    # 32 input channels (four 8-channel stages), narrow partial tiles
     (1, 8, 32, 48, 70, 3, 1),     # Cin = 48, cout tail (70 = 64 + 6)
@@ -88,7 +90,7 @@ def test_conv_forward(N, H, W, cin, cout, ks, mode, conv_algo):
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,ks", [(2, 16, 32, 64, 64, 3), (1, 30, 40, 128, 256, 3), (2, 6, 8, 256, 65, 1),
-                                                 (1, 8, 32, 64, 128, 3)])
+                                                 (1, 8, 32, 64, 128, 3), (2, 30, 40, 256, 133, 1), (1, 5, 7, 256, 256, 1)])
 def test_conv_dgrad(N, H, W, cin, cout, ks, conv_algo):
     """data gradient = conv with transposed/flipped weights; `cin/cout` are those of the FORWARD conv."""
     from semantic_superpoint_amd import lib as L
