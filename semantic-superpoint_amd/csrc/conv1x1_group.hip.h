@@ -25,6 +25,7 @@
 // the workgroup moves to another problem).
 #pragma once
 #include "conv_mfma.hip.h"
+#include <type_traits>
 
 namespace sspk {
 
@@ -45,6 +46,12 @@ struct G1Prob {
   const float* in_shift;
   double* stats;          // [NREP][2 stats_c] at this problem's first channel, or nullptr
   int stats_c;            // channels of the whole layer (row pitch of stats)
+  // BNR launches (data gradients): `stats` receives pass 1 of the BatchNorm backward of the layer BELOW, whose activation
+  // gradient this problem writes - S1 = sum dZ, S2 = sum dZ xhat with dZ = out [y scale + shift > 0], xhat = (y - mean) invstd.
+  // bnr_y: that layer's raw conv output, same geometry as `out` ([npx][out_cs], channel out_co); parameters at the problem's
+  // first channel.
+  const float* bnr_y;
+  const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_invstd;
   int in_cs, in_co, out_cs, out_co;
   int K, N;               // input channels, output channels of THIS problem (<= 128)
   int nchunks, nt, nt_total;
@@ -59,9 +66,9 @@ struct G1Args {
 };
 
 // One workgroup item (128 pixels of problem p) with NT n-tiles; ssum / ssq: the BatchNorm partial sums of the problem.
-template <int IN_MODE, int NT>
+template <int IN_MODE, int NT, bool BNR>
 __device__ __forceinline__ void g1_item(const G1Prob& p, int px0, float* sB, const float* sSc, float (&ssum)[G1_NT],
-                                        float (&ssq)[G1_NT], int tid, int lane, int li, int lh) {
+                                        float (&ssq)[G1_NT], int tid, int lane, int li, int lh, int* counter, int& nxt) {
   constexpr unsigned OOB = 0x80000000u;
   const int nchunks = p.nchunks, K = p.K;
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -81,6 +88,9 @@ __device__ __forceinline__ void g1_item(const G1Prob& p, int px0, float* sB, con
       wreg[t] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(CHUNK) * wstride + t * G1_TILE_FLOATS);               \
   }
   G1_ISSUE(0)
+  // the index of the NEXT item is requested now, BEHIND the first loads (returns come back in order), and looked at after this
+  // item: an L2 atomic round trip off the critical path
+  if (tid == 0) nxt = atomicAdd(counter, 1);
 
   f32x16 acc[NT];
 #pragma unroll
@@ -133,30 +143,65 @@ __device__ __forceinline__ void g1_item(const G1Prob& p, int px0, float* sB, con
 #undef G1_ISSUE
 
   // ---- epilogue: lane = output channel 32 t + li, register r = pixel (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 ----
+  // Addresses advance in a vector register (an out-of-range marker stays out of range under these additions): sixteen scalar
+  // row offsets per n-tile would be hoisted and spilled through v_writelane / v_readlane.  Channels past N hold exact zeros
+  // (zero weights, no bias), so a full 32-pixel tile needs no per-element validity selects.
   const bool full = px0 + 32 <= p.npx;
   const bool want_stats = p.stats != nullptr;
+  const unsigned pitch = (unsigned)p.out_cs * 4u;
+  __amdgpu_buffer_rsrc_t rsrc_y = rsrc_out;
+  if (BNR) rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bnr_y), 0, p.out_bytes, 0x00020000);
+  auto tiles = [&](auto FULL_) {  // straight-line per (full 32-pixel tile or not): wave-uniform
+    constexpr bool FULL = decltype(FULL_)::value;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int ch = 32 * t + li;
-    const bool chok = ch < p.N;
-    const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.f;
-    const unsigned vbase = (unsigned)(((px0 + 4 * lh) * p.out_cs + p.out_co + ch) * 4);
-    float s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < NT; ++t) {
+      const int ch = 32 * t + li;
+      const bool chok = ch < p.N;
+      const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.f;
+      const unsigned vbase = chok ? (unsigned)(((px0 + 4 * lh) * p.out_cs + p.out_co + ch) * 4) : OOB;
+      const int rows_left = p.npx - px0 - 4 * lh;  // pixel m of this lane exists while m < rows_left
+      float s1 = 0.f, s2 = 0.f;
+      float bsc = 0.f, bsh = 0.f, bis = 0.f, bnm = 0.f;
+      float yv[BNR ? 16 : 1];
+      if (BNR) {
+        if (chok) { bsc = p.bnr_scale[ch]; bsh = p.bnr_shift[ch]; bis = p.bnr_invstd[ch]; bnm = -p.bnr_mean[ch] * bis; }
+        unsigned vo = vbase;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2);
-      const float v = acc[t][r] + bv;
-      const bool ok = chok && (full || px0 + 4 * lh + m < p.npx);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_out, ok ? vbase : OOB, m * p.out_cs * 4, 0);
-      const float vm = ok ? v : 0.f;
-      s1 += vm;
-      s2 = fmaf(vm, vm, s2);
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2);
+          const unsigned vr = (FULL || m < rows_left) ? vo : OOB;
+          yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_y, vr, 0, 0));
+          vo += ((r & 3) == 3 ? 5u : 1u) * pitch;
+        }
+      }
+      unsigned vo = vbase;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2);
+        const float v = BNR ? acc[t][r] : acc[t][r] + bv;
+        const bool ok = FULL || m < rows_left;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_out, ok ? vo : OOB, 0, 0);
+        vo += ((r & 3) == 3 ? 5u : 1u) * pitch;
+        if (BNR) {
+          // (a load outside the tensor returned y = 0: the gate then depends on the shift alone, but v of such a position is
+          // an exact zero for channels past N and is masked by `ok` for pixels past the end)
+          const float dz = (ok && fmaf(yv[r], bsc, bsh) > 0.f) ? v : 0.f;
+          s1 += dz;
+          s2 = fmaf(dz, fmaf(yv[r], bis, bnm), s2);
+        } else {
+          const float vm = (FULL || (ok && chok)) ? v : 0.f;
+          s1 += vm;
+          s2 = fmaf(vm, vm, s2);
+        }
+      }
+      if (want_stats) { ssum[t] += s1; ssq[t] += s2; }
     }
-    if (want_stats) { ssum[t] += s1; ssq[t] += s2; }
-  }
+  };
+  if (full) tiles(std::true_type{});
+  else tiles(std::false_type{});
 }
 
-template <int IN_MODE>
+template <int IN_MODE, bool BNR>
 __global__ __launch_bounds__(256, 3) void conv1x1_group_kernel(const G1Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const sB = smem;                                  // [2][G1_NT][4][64][4]
@@ -196,12 +241,11 @@ __global__ __launch_bounds__(256, 3) void conv1x1_group_kernel(const G1Args a) {
     __syncthreads();
   };
 
-  for (;;) {
-    __syncthreads();  // every wave is done with s_item and with the LDS images of the previous item
-    if (tid == 0) s_item = atomicAdd(a.counter, 1);
-    __syncthreads();
-    const int item = __builtin_amdgcn_readfirstlane(s_item);
-    if (item >= a.nitems) break;
+  if (tid == 0) s_item = atomicAdd(a.counter, 1);
+  __syncthreads();
+  int item = __builtin_amdgcn_readfirstlane(s_item);
+  while (item < a.nitems) {
+    int nxt = 0;
     int pi = 0;
     while (pi + 1 < a.nprob && item >= a.p[pi + 1].item0) ++pi;
     const G1Prob& p = a.p[pi];
@@ -219,11 +263,15 @@ __global__ __launch_bounds__(256, 3) void conv1x1_group_kernel(const G1Args a) {
     }
     const int px0 = (item - p.item0) * G1_PX + wave * 32;
     switch (p.nt) {
-      case 1: g1_item<IN_MODE, 1>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
-      case 2: g1_item<IN_MODE, 2>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
-      case 3: g1_item<IN_MODE, 3>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
-      default: g1_item<IN_MODE, 4>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh); break;
+      case 1: g1_item<IN_MODE, 1, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
+      case 2: g1_item<IN_MODE, 2, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
+      case 3: g1_item<IN_MODE, 3, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
+      default: g1_item<IN_MODE, 4, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
     }
+    __syncthreads();  // every wave is done with s_item and with the LDS images of this item
+    if (tid == 0) s_item = nxt;
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(s_item);
   }
   if (cur >= 0) flush_stats(cur);
   // the last workgroup out re-arms the counters for the next launch (kernel boundaries order it)
@@ -265,6 +313,158 @@ __global__ __launch_bounds__(256) void pack_g1_kernel(const G1PackJobs J) {
   float v = 0.f;
   if (kk < K && n < N) v = q.transpose ? q.w[(size_t)kk * q.cin_w + n] : q.w[(size_t)n * q.cin_w + kk];
   q.dst[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Grouped weight gradient of the pointwise layers: dW[n][k] = sum over the pixels of both views of Xact[px][k] dY[px][n],
+// Xact = relu(scale x + shift) of the layer's input (BatchNorm + ReLU on load).  M = input channels, N = output channels, the
+// MFMA K dimension runs over PIXELS, so neither operand needs LDS: a lane's A value of K-step s is its channel of pixel
+// p + 2 s + lh, a B value its output channel of the same pixel - both straight from global memory, eight K-steps ahead.
+//   * The 32 rows of m-tile j of channel group g are the channels 128 g + 4 row + j: a lane's 8-byte load (4 row + 2 (w & 1),
+//     + 1) feeds the TWO m-tiles of its wave, and the four waves of a workgroup cover 256 channels with fully used lines.
+//   * A part = (layer, <= 4 n-tiles = 128 output channels); every part gets a share of the grid proportional to its MFMA
+//     count, each workgroup a contiguous pixel range of one view (static split: one [256][128] partial slab per workgroup,
+//     summed into the OIHW gradient by wgrad1x1_reduce_kernel).  Wave = 2 m-tiles x NT n-tiles = <= 128 accumulator registers.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int G1W_MAXP = 8;          // parts per launch
+constexpr int G1W_DEPTH = 8;         // K-steps (pixel pairs) in flight per wave
+constexpr int G1W_SLAB = 256 * 128;  // floats of a partial slab: [256 input channels][128 output channels]
+
+struct G1WPart {
+  const float* x[2];       // [npx][x_cs] raw input of the layer (the conv output of the 3x3 head below), per view
+  const float* scale[2];   // BatchNorm + ReLU on load, [256]
+  const float* shift[2];
+  const float* dy[2];      // [npx][dy_cs], channels dy_co .. dy_co + N of THIS part
+  float* dw;               // OIHW gradient [cout][256] of the layer, at this part's first output channel (row n0)
+  int x_cs, x_co, dy_cs, dy_co;
+  int N, nt;               // output channels / n-tiles of this part
+  int npx;
+  int wg0, nwg;            // workgroups [wg0, wg0 + nwg) of the launch: the first nwg / 2 on view 0 (nwg for a single view)
+  int nviews;
+};
+struct G1WArgs {
+  G1WPart p[G1W_MAXP];
+  int nparts;
+  float* partial;          // [gridDim.x][256][128]
+};
+
+template <int NT>
+__device__ __forceinline__ void g1w_run(const G1WPart& p, int view, int px_lo, int px_hi, float* slab, int wave, int li, int lh) {
+  constexpr unsigned OOB = 0x80000000u;
+  const int g = wave >> 1, jh = wave & 1;
+  const int ch0 = 128 * g + 4 * li + 2 * jh;  // this lane's two input channels (rows li of m-tiles 4 g + 2 jh, + 1)
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[view]), 0, (unsigned)((size_t)p.npx * p.x_cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy[view]), 0, (unsigned)((size_t)p.npx * p.dy_cs * 4), 0x00020000);
+  const f32x2 sc = *reinterpret_cast<const f32x2*>(p.scale[view] + ch0), sh = *reinterpret_cast<const f32x2*>(p.shift[view] + ch0);
+  // lane parts of the addresses of pixel px_lo + lh; a K-step advances two pixels (scalar offsets)
+  const unsigned vx = (unsigned)(((px_lo + lh) * p.x_cs + p.x_co + ch0) * 4);
+  unsigned vd[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) vd[t] = (32 * t + li < p.N) ? (unsigned)(((px_lo + lh) * p.dy_cs + p.dy_co + 32 * t + li) * 4) : OOB;
+  const int sx = 2 * p.x_cs * 4, sd = 2 * p.dy_cs * 4;
+  const int nsteps = (px_hi - px_lo + 1) >> 1;
+  const int npix = px_hi - px_lo;  // pixel 2 s + lh of the range exists while 2 s + lh < npix
+
+  f32x2 xa[G1W_DEPTH];
+  float db[G1W_DEPTH][NT];
+#define G1W_ISSUE(U, S)                                                                                      \
+  {                                                                                                          \
+    const bool ok_ = 2 * (S) + lh < npix;                                                                    \
+    xa[U] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, ok_ ? vx : OOB, (S) * sx, 0)); \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                           \
+      db[U][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_d, ok_ ? vd[t] : OOB, (S) * sd, 0)); \
+  }
+  // (fenced: in the order of consumption, or the first use of slot 0 - and with it every trip of the loop - would have to wait
+  // for ALL loads: hipcc otherwise issues the input-side loads of the eight slots last, slot 0 at the very end)
+#pragma unroll
+  for (int u = 0; u < G1W_DEPTH; ++u) {
+    G1W_ISSUE(u, u)
+    asm volatile("" ::: "memory");  // (the scheduler fence alone does not bind the IR passes)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  for (int s0 = 0; s0 < nsteps; s0 += G1W_DEPTH) {
+#pragma unroll
+    for (int u = 0; u < G1W_DEPTH; ++u) {
+      // (steps past the range hold zeros in dY: whatever relu(shift) the input side produces there is multiplied by 0)
+      const float a0 = fmaxf(fmaf(xa[u][0], sc[0], sh[0]), 0.f), a1 = fmaxf(fmaf(xa[u][1], sc[1], sh[1]), 0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, db[u][t], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, db[u][t], acc[1][t], 0, 0, 0);
+      }
+      // The slot is reloaded BEHIND the MFMAs that consumed it (its registers are dead: the loads land in place), seven steps
+      // before its next use.  Issued ahead of them, hipcc gives the loads fresh registers and copies them into the ring at the
+      // end of the loop body behind an s_waitcnt vmcnt(0).  The fences keep hipcc from moving the loads across MFMA groups.
+      __builtin_amdgcn_sched_barrier(0);
+      G1W_ISSUE(u, s0 + u + G1W_DEPTH)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef G1W_ISSUE
+  // slab[channel][n]: accumulator (m, t), register r, lane (li, lh) = channel 128 g + 4 ((r & 3) + 8 (r >> 2) + 4 lh) + 2 jh + m,
+  // output channel 32 t + li; the part's unused n-tiles are never read by the reduction
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slab[(128 * g + 4 * row + 2 * jh + m) * 128 + 32 * t + li] = acc[m][t][r];
+      }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad1x1_group_kernel(const G1WArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  int pi = 0;
+  while (pi + 1 < a.nparts && (int)blockIdx.x >= a.p[pi + 1].wg0) ++pi;
+  const G1WPart& p = a.p[pi];
+  const int w = (int)blockIdx.x - p.wg0;
+  if (w >= p.nwg) return;
+  const int per_view = p.nwg / p.nviews;
+  const int view = w / per_view, wv = w - view * per_view;
+  // contiguous, even-length pixel ranges (a K-step is a pixel pair)
+  const int pairs = (p.npx + 1) >> 1;
+  const int lo = (int)(((long)pairs * wv) / per_view) * 2, hi = min(p.npx, (int)(((long)pairs * (wv + 1)) / per_view) * 2);
+  float* const slab = a.partial + (size_t)blockIdx.x * G1W_SLAB;
+  switch (p.nt) {
+    case 1: g1w_run<1>(p, view, lo, hi, slab, wave, li, lh); break;
+    case 2: g1w_run<2>(p, view, lo, hi, slab, wave, li, lh); break;
+    case 3: g1w_run<3>(p, view, lo, hi, slab, wave, li, lh); break;
+    default: g1w_run<4>(p, view, lo, hi, slab, wave, li, lh); break;
+  }
+}
+
+// dw[n][k] += sum over the part's workgroups of slab[k][n]; block = 256 threads = 8 input channels x 32 output channels
+__global__ __launch_bounds__(256) void wgrad1x1_reduce_kernel(const G1WArgs a) {
+  int pi = 0;
+  int b = blockIdx.x;
+  // blocks per part: 32 channel groups x nt
+  while (pi + 1 < a.nparts && b >= 32 * a.p[pi].nt) { b -= 32 * a.p[pi].nt; ++pi; }
+  const G1WPart& p = a.p[pi];
+  if (b >= 32 * p.nt) return;
+  const int t = b / 32, kg = b - t * 32;
+  const int n = 32 * t + (threadIdx.x & 31), k = 8 * kg + (threadIdx.x >> 5);
+  if (n >= p.N) return;
+  const float* src = a.partial + (size_t)p.wg0 * G1W_SLAB + k * 128 + n;
+  float s0 = 0.f, s1 = 0.f;
+  int w = 0;
+  for (; w + 1 < p.nwg; w += 2) {
+    s0 += src[(size_t)w * G1W_SLAB];
+    s1 += src[(size_t)(w + 1) * G1W_SLAB];
+  }
+  if (w < p.nwg) s0 += src[(size_t)w * G1W_SLAB];
+  p.dw[(size_t)n * 256 + k] += s0 + s1;
 }
 
 }  // namespace sspk

@@ -164,6 +164,8 @@ struct ssp_handle {
   float *wpk_g1_fwd[16] = {}, *wpk_g1_bwd[16] = {};
   bool pk_g1[16] = {};
   int* g1_counter = nullptr;
+  float* g1_partial = nullptr;  // wgrad1x1_group_kernel: one [256][128] slab per workgroup (2 per CU)
+  int g1_partial_slabs = 0;
   int packed_algo = -1;      // conv algorithm the images were packed for
   bool packed_bwd = false;   // the data-gradient images were packed too
   // captured pair steps (ssp_pair_step_graph): one executable graph per (phase, input signature)
@@ -294,6 +296,8 @@ static size_t carve(ssp_handle* h, void* base) {
     h->wpk_g1_bwd[i] = c.take<float>((size_t)cdiv(d.cout, G1_KC) * cdiv(d.cin, 32) * G1_TILE_FLOATS);
   }
   h->g1_counter = c.take<int>(64);
+  h->g1_partial_slabs = 2 * 512;  // up to 512 CUs
+  h->g1_partial = c.take<float>((size_t)h->g1_partial_slabs * G1W_SLAB);
   for (int s = 0; s < 2; ++s) {
     Slot& S = h->slot[s];
     for (int l = 0; l < 8; ++l) {
@@ -680,6 +684,10 @@ struct G1Layer {
   const float* bias = nullptr;
   const float* scale[2] = {nullptr, nullptr}; const float* shift[2] = {nullptr, nullptr};  // BatchNorm + ReLU on load (in_mode 1)
   double* stats[2] = {nullptr, nullptr};                                                   // BatchNorm statistics of the output
+  // data gradient: pass 1 of the BatchNorm backward of the layer below into stats[] (G1Prob::bnr_y); parameters [N]
+  const float* bnr_y[2] = {nullptr, nullptr};
+  const float* bnr_scale[2] = {nullptr, nullptr}; const float* bnr_shift[2] = {nullptr, nullptr};
+  const float* bnr_mean[2] = {nullptr, nullptr}; const float* bnr_invstd[2] = {nullptr, nullptr};
   int K = 0, N = 0;
 };
 static inline size_t g1_image_floats(int K, int N) { return (size_t)cdiv(K, G1_KC) * cdiv(N, 32) * G1_TILE_FLOATS; }
@@ -696,8 +704,10 @@ static bool g1_fits(int K, int N, long npx, int in_cs, int out_cs, int nviews) {
 static int launch_g1(const G1Layer* L, int nl, int nviews, long npx, int in_mode, int* counter, int n_cu, hipStream_t st) {
   struct Tmp { G1Prob p; long cost; };
   std::vector<Tmp> v;
+  bool bnr = nl > 0 && L[0].bnr_y[0] != nullptr;
   for (int i = 0; i < nl; ++i) {
     const G1Layer& y = L[i];
+    if ((y.bnr_y[0] != nullptr) != bnr || (bnr && in_mode != 0)) return fail(-1, "grouped pointwise launch: mixed BatchNorm-backward fusion");
     if (!g1_fits(y.K, y.N, npx, y.in_cs, y.out_cs, nviews)) return fail(-3, "pointwise conv %d -> %d does not fit the grouped kernel", y.K, y.N);
     const int ntt = cdiv(y.N, 32), nparts = cdiv(ntt, G1_NT);
     int t0 = 0;
@@ -712,6 +722,9 @@ static int launch_g1(const G1Layer* L, int nl, int nviews, long npx, int in_mode
         q.K = y.K; q.N = std::min(y.N - 32 * t0, 32 * size); q.nchunks = cdiv(y.K, G1_KC); q.nt = size; q.nt_total = ntt;
         q.npx = (int)npx; q.item0 = 0;
         q.in_bytes = (unsigned)((size_t)npx * y.in_cs * 4); q.out_bytes = (unsigned)((size_t)npx * y.out_cs * 4);
+        q.bnr_y = y.bnr_y[k];
+        q.bnr_scale = bnr ? y.bnr_scale[k] + 32 * t0 : nullptr; q.bnr_shift = bnr ? y.bnr_shift[k] + 32 * t0 : nullptr;
+        q.bnr_mean = bnr ? y.bnr_mean[k] + 32 * t0 : nullptr; q.bnr_invstd = bnr ? y.bnr_invstd[k] + 32 * t0 : nullptr;
         if (in_mode != 0 && (!q.in_scale || !q.in_shift)) return fail(-1, "pointwise conv: in_mode 1 needs scale / shift");
         t.cost = (long)size * cdiv(y.K, 4);
         v.push_back(t);
@@ -733,16 +746,73 @@ static int launch_g1(const G1Layer* L, int nl, int nviews, long npx, int in_mode
   a.nitems = items;
   a.counter = counter;
   const int grid = std::max(1, std::min(items, 3 * n_cu));
-  static AttrOnce attr0, attr1;
-  if (in_mode != 0) {
-    auto kern = conv1x1_group_kernel<1>;
-    if (attr1.need()) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G1_LDS_BYTES, st, a);
-  } else {
-    auto kern = conv1x1_group_kernel<0>;
-    if (attr0.need()) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G1_LDS_BYTES, st, a);
+  static AttrOnce attr0, attr1, attr2;
+#define SSP_G1_LAUNCH(M_, B_, ATTR_)                                                                                                  \
+  {                                                                                                                                   \
+    auto kern = conv1x1_group_kernel<M_, B_>;                                                                                         \
+    if (ATTR_.need()) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS_BYTES)); \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G1_LDS_BYTES, st, a);                                                             \
   }
+  if (in_mode != 0) SSP_G1_LAUNCH(1, false, attr1)
+  else if (bnr) SSP_G1_LAUNCH(0, true, attr2)
+  else SSP_G1_LAUNCH(0, false, attr0)
+#undef SSP_G1_LAUNCH
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// grouped weight gradient of pointwise layers with 256 input channels (wgrad1x1_group_kernel + wgrad1x1_reduce_kernel)
+struct G1WLayer {
+  const float* x[2] = {nullptr, nullptr}; int x_cs = 0, x_co = 0;
+  const float* scale[2] = {nullptr, nullptr}; const float* shift[2] = {nullptr, nullptr};
+  const float* dy[2] = {nullptr, nullptr}; int dy_cs = 0, dy_co = 0;
+  float* dw = nullptr;  // OIHW [N][256], accumulated
+  int N = 0;
+};
+static bool g1w_fits(int cin, int cout, long npx, int x_cs, int dy_cs) {
+  return cin == 256 && cout >= 1 && npx >= 2 && (double)npx * x_cs * 4.0 < 2147483648.0 && (double)npx * dy_cs * 4.0 < 2147483648.0;
+}
+static int launch_g1_wgrad(const G1WLayer* L, int nl, int nviews, long npx, float* partial, int partial_slabs, int n_cu, hipStream_t st) {
+  G1WArgs a;
+  a.nparts = 0;
+  a.partial = partial;
+  long cost[G1W_MAXP], total = 0;
+  for (int i = 0; i < nl; ++i) {
+    const G1WLayer& y = L[i];
+    const int ntt = cdiv(y.N, 32), nparts = cdiv(ntt, G1_NT);
+    int t0 = 0;
+    for (int part = 0; part < nparts; ++part) {
+      if (a.nparts >= G1W_MAXP) return fail(-3, "grouped pointwise weight gradient: more than %d parts", G1W_MAXP);
+      const int size = ntt / nparts + (part < ntt % nparts ? 1 : 0);  // balanced (133 outputs: 3 + 2 n-tiles; a 1-tile part
+                                                                      // would issue one load per MFMA)
+      G1WPart& q = a.p[a.nparts];
+      for (int k = 0; k < 2; ++k) {
+        const int kk = k < nviews ? k : 0;
+        q.x[k] = y.x[kk]; q.scale[k] = y.scale[kk]; q.shift[k] = y.shift[kk]; q.dy[k] = y.dy[kk];
+      }
+      q.dw = y.dw + (size_t)32 * t0 * 256;
+      q.x_cs = y.x_cs; q.x_co = y.x_co; q.dy_cs = y.dy_cs; q.dy_co = y.dy_co + 32 * t0;
+      q.N = std::min(y.N - 32 * t0, 32 * size); q.nt = size; q.npx = (int)npx; q.nviews = nviews;
+      cost[a.nparts] = size; total += size;
+      ++a.nparts;
+      t0 += size;
+    }
+  }
+  if (a.nparts == 0) return 0;
+  // grid shares proportional to the MFMA count of a part, a multiple of the view count each
+  const int grid_max = std::min(2 * n_cu, partial_slabs);
+  const long pairs = (npx + 1) / 2;
+  int wg = 0;
+  for (int i = 0; i < a.nparts; ++i) {
+    long n = (long)grid_max * cost[i] / total / nviews * nviews;
+    n = std::max<long>(nviews, std::min<long>(n, pairs * nviews));
+    a.p[i].wg0 = wg; a.p[i].nwg = (int)n;
+    wg += (int)n;
+  }
+  if (wg > partial_slabs) return fail(-4, "grouped pointwise weight gradient: %d partial slabs needed, %d available", wg, partial_slabs);
+  hipLaunchKernelGGL(wgrad1x1_group_kernel, dim3(wg), dim3(256), 0, st, a);
+  int rblocks = 0;
+  for (int i = 0; i < a.nparts; ++i) rblocks += 32 * a.p[i].nt;
+  hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3(rblocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1536,7 +1606,7 @@ static void setup_bnr(ssp_handle* h, const SlotSet& SS, int src, bool pooled, Co
 // dY of each view in dy[k] (channel stride dy_cs, offset dy_co); the data gradient goes to din[k].
 static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src, float* const* dy, int dy_cs, int dy_co,
                                float* const* din, int din_cs, int din_co, int N, int H, int W, int in_mode,
-                               hipStream_t st, bool skip_dgrad = false) {
+                               hipStream_t st, bool skip_dgrad = false, bool skip_wgrad = false) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
   const bool pooled = in_mode == 2;  // Apool[src] holds the pooled input: raw pooled y (pool_raw: BatchNorm + ReLU on load)
@@ -1575,7 +1645,7 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
       w.f_mean[k] = S.bn[l].mean; w.f_invstd[k] = S.bn[l].invstd; w.f_k12[k] = S.bn[l].k12;
     }
   }
-  CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
+  if (!skip_wgrad) CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
   if (skip_dgrad) return 0;  // the caller runs the data gradient itself (the grouped pointwise launch of the heads)
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_DGRAD : 0));
   return 0;
@@ -1637,21 +1707,51 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     for (int k = 0; k < SS.n; ++k) gQd[k] = gQ[k] + ncells_all * 80;
   G1Layer Lg[3];
   int ng = 0;
+  // ... and so do the three weight gradients (wgrad1x1_group_kernel; SSP_G1_WGRAD=0, perf-debug: wgrad_mfma_kernel per layer)
+  static const int g1_wgrad_env = getenv("SSP_G1_WGRAD") ? atoi(getenv("SSP_G1_WGRAD")) : 1;
+  const bool gw = grouped && g1_wgrad_env != 0 && g1w_fits(256, 65, (long)ncells_all, hcs, std::max(256, h->sout_cs));
+  G1WLayer Lw[3];
+  int nw = 0;
+  auto add_wgrad = [&](int l, float* const* dy, int dy_cs) {
+    const LayerDesc& d = h->L[l];
+    const int src = l - 1;
+    G1WLayer& y = Lw[nw++];
+    y.x_cs = S0.y_cs[src]; y.x_co = S0.y_co[src]; y.dy_cs = dy_cs; y.dy_co = 0; y.dw = Gd(h, d.w_off); y.N = d.cout;
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      y.x[k] = S.Y[src]; y.scale[k] = S.bn[src].scale; y.shift[k] = S.bn[src].shift; y.dy[k] = dy[k];
+    }
+  };
+  // ... and accumulates pass 1 of the BatchNorm backward of the 3x3 head below (Pa, Da, DS: dact has the geometry of their
+  // raw outputs, [cells][hcs] at channel 256 k) on the way: bn_layer_backward of those layers then skips its reduction pass
+  static const int g1_bnr_env = getenv("SSP_G1_BNR") ? atoi(getenv("SSP_G1_BNR")) : 1;  // (perf-debug: 0 = separate pass)
   auto add_dgrad = [&](int l, float* const* dy, int dy_cs, int co) {
     const LayerDesc& d = h->L[l];
+    const int src = l - 1;
     G1Layer& y = Lg[ng++];
     y.in_cs = dy_cs; y.in_co = 0; y.out_cs = hcs; y.out_co = co; y.wpk = h->wpk_g1_bwd[l]; y.K = d.cout; y.N = d.cin;
-    for (int k = 0; k < SS.n; ++k) { y.in[k] = dy[k]; y.out[k] = dact[k]; }
+    const bool bnr = g1_bnr_env != 0 && h->L[src].bn && S0.y_cs[src] == hcs && S0.y_co[src] == co && h->L[src].cout == d.cin;
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      y.in[k] = dy[k]; y.out[k] = dact[k];
+      if (bnr) {
+        y.bnr_y[k] = S.Y[src]; y.bnr_scale[k] = S.bn[src].scale; y.bnr_shift[k] = S.bn[src].shift; y.bnr_mean[k] = S.bn[src].mean;
+        y.bnr_invstd[k] = S.bn[src].invstd; y.stats[k] = S.bn[src].bsums;
+      }
+    }
+    if (bnr) h->bsums_fused[src] = true;
   };
   if (has_semi) {
     CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQ, 80, 0, N, Hc, Wc, st));
-    CHK(conv_layer_backward(h, SS, L_PB, L_PA, gQ, 80, 0, dact, hcs, 0, N, Hc, Wc, 1, st, grouped));
+    CHK(conv_layer_backward(h, SS, L_PB, L_PA, gQ, 80, 0, dact, hcs, 0, N, Hc, Wc, 1, st, grouped, gw));
     if (grouped) add_dgrad(L_PB, gQ, 80, 0);
+    if (gw) add_wgrad(L_PB, gQ, 80);
   }
   if (has_desc) {
     CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st));
-    CHK(conv_layer_backward(h, SS, L_DB, L_DA, gQd, 256, 0, dact, hcs, 256, N, Hc, Wc, 1, st, grouped));
+    CHK(conv_layer_backward(h, SS, L_DB, L_DA, gQd, 256, 0, dact, hcs, 256, N, Hc, Wc, 1, st, grouped, gw));
     if (grouped) add_dgrad(L_DB, gQd, 256, 256);
+    if (gw) add_wgrad(L_DB, gQd, 256);
   }
   if (has_sem) {
     const LayerDesc& d = h->L[L_SOUT];
@@ -1661,9 +1761,11 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
       hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, COLSUM_ROWS)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), ncells, d.cout,
                          h->sout_cs);
     HIPCHK(hipGetLastError());
-    CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st, grouped));
+    CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st, grouped, gw));
     if (grouped) add_dgrad(L_SOUT, dsout, h->sout_cs, 512);
+    if (gw) add_wgrad(L_SOUT, dsout, h->sout_cs);
   }
+  if (gw && nw > 0) CHK(launch_g1_wgrad(Lw, nw, SS.n, (long)ncells_all, h->g1_partial, h->g1_partial_slabs, h->n_cu, st));
   if (grouped && ng > 0) CHK(launch_g1(Lg, ng, SS.n, (long)ncells_all, 0, h->g1_counter, h->n_cu, st));
   // ---- 3x3 heads: BN+ReLU backward gP -> gQ [cells][hcs]; weight gradients; ONE data-gradient conv over the
   // concatenated dY channels (sums the heads' contributions) gQ -> gP [cells][128] ----
@@ -2113,6 +2215,15 @@ int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw
                       int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream) {
   AlgoScope algo(nullptr);
+  if (ksize == 1 && in_mode == 1 && g1_enabled() && g1w_fits(cin, cout, (long)n * hh * w, cin, cout) && cdiv(cdiv(cout, 32), G1_NT) <= G1W_MAXP &&
+      workspace_bytes >= (size_t)64 * G1W_SLAB * sizeof(float)) {
+    // pointwise layer with 256 input channels under BatchNorm + ReLU on load: the grouped kernel of the heads
+    G1WLayer y;
+    y.x[0] = in_dev; y.x_cs = cin; y.x_co = 0; y.scale[0] = in_scale_dev; y.shift[0] = in_shift_dev; y.dy[0] = dout_dev;
+    y.dy_cs = cout; y.dy_co = 0; y.dw = dw_oihw_dev; y.N = cout;
+    return launch_g1_wgrad(&y, 1, 1, (long)n * hh * w, reinterpret_cast<float*>(workspace_dev),
+                           (int)std::min<size_t>(workspace_bytes / (G1W_SLAB * sizeof(float)), 512), 256, (hipStream_t)stream);
+  }
   WgradCall c;
   c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.dout = dout_dev; c.dout_cs = cout; c.dout_co = 0; c.cout = cout;
   c.in_scale = in_scale_dev; c.in_shift = in_shift_dev; c.dw = dw_oihw_dev; c.N = n; c.H = hh; c.W = w; c.ks = ksize;

@@ -649,7 +649,8 @@ def op_conv_wgrad(x_nhwc, dout_nhwc, ksize, in_mode=0, in_scale=None, in_shift=N
     N, Hin, Win, cin = x_nhwc.shape
     _, H, W, cout = dout_nhwc.shape
     dw = torch.zeros(cout, cin, ksize, ksize, dtype=torch.float32, device=x_nhwc.device)
-    ws = torch.empty(512 * ksize * ksize * 4096 * 4, dtype=torch.uint8, device=x_nhwc.device)
+    # partial slabs: 512 x taps x [64][64] (3x3 / generic 1x1) or 512 x [256][128] (grouped pointwise kernel, 256 input channels)
+    ws = torch.empty(512 * max(ksize * ksize * 4096, 32768 if ksize == 1 else 0) * 4, dtype=torch.uint8, device=x_nhwc.device)
     with torch.cuda.device(x_nhwc.device):
         _check(lib.ssp_op_conv_wgrad(_ptr(x_nhwc), _ptr(dout_nhwc), _ptr(dw), N, H, W, cin, cout, ksize, in_mode,
                                      _ptr(in_scale), _ptr(in_shift), _ptr(ws), ws.numel(), _stream()))

@@ -112,6 +112,7 @@ def test_conv_dgrad(N, H, W, cin, cout, ks, conv_algo):
 @pytest.mark.parametrize("N,H,W,cin,cout,ks,mode", [(2, 16, 64, 64, 64, 3, 1), (2, 30, 40, 128, 128, 3, 1),
                                                       (2, 8, 32, 64, 128, 3, 2), (1, 12, 24, 128, 256, 3, 0),
                                                       (2, 30, 40, 256, 64, 1, 1), (3, 5, 8, 256, 256, 1, 0),
+                                                      (2, 30, 40, 256, 133, 1, 1), (1, 3, 5, 256, 65, 1, 1), (2, 15, 20, 256, 256, 1, 1),
                                                       (1, 9, 11, 64, 64, 3, 1),     # odd map (direct kernel)
                                                       (2, 10, 12, 48, 70, 3, 0),    # even map, ragged tiles, tails
                                                       (1, 36, 64, 64, 64, 3, 1),    # several block tiles per image
