@@ -6,36 +6,43 @@
 // 16-channel chunks (32 MFMAs per wave between two barriers), once per 64-channel output block (4x for 256 outputs), rounds
 // 65 / 133 outputs up to 128 / 192, and three launches of 0.6-2.3 rounds over the chip each pay their own tail.
 //
-// This kernel is a plain GEMM, D[pixel][cout] = sum_k A[pixel][k] W[k][cout]:
+// This kernel is a plain GEMM, D[pixel][cout] = sum_k A[pixel][k] W[k][cout], with the WEIGHTS STATIONARY in LDS:
+//   * a problem = (layer, <= 4 n-tiles = 128 output channels, view); its weight image (<= 256 x 128 floats = 128 KB, packed in
+//     operand order [chunk][n-tile][k-quad][lane][4] by pack_g1_kernel) is copied into LDS ONCE by the workgroups assigned to
+//     it - one 8-wave workgroup per CU, the CUs shared out between the problems in proportion to their MFMA counts - and read
+//     back with one ds_read_b128 per four MFMAs (fetched one k-quad ahead).  After that copy there is no barrier: each wave
+//     walks its own 32-pixel tiles (tile = wave index + k x waves of the problem).
 //   * a pointwise conv has no halo, so a lane's A operand IS its own pixel's channel vector: loaded straight from global
 //     memory into the MFMA operand registers (four 16-byte loads per lane and 32-channel chunk, 64 contiguous bytes per lane -
-//     every 128-byte line is consumed by its two half-waves inside the same four instructions), BatchNorm + ReLU of the
-//     producing layer applied in registers; no LDS round trip, no re-staging per output block;
-//   * W is packed in operand order [chunk][n-tile][k-quad][lane][4] (pack_g1_kernel), copied chunk by chunk into a
-//     double-buffered LDS image (one barrier per chunk) and read back with one ds_read_b128 per four MFMAs;
-//   * a wave owns 32 pixels x (up to 4) 32-channel n-tiles, a workgroup item is 128 pixels of one problem; outputs wider than
-//     128 channels are split into problems of <= 4 n-tiles (65 -> 3, 133 -> 3 + 2, 256 -> 4 + 4 tiles), <= 170 registers,
-//     three workgroups per CU;
-//   * the items of all problems of a launch sit in one list, heaviest first, handed out through an atomic counter
-//     (longest-processing-time-first): the tails of the small problems fill with each other.  The last workgroup to
-//     leave resets the counter pair, so a launch needs no memset and replays inside a captured graph.
+//     every 128-byte line is consumed by its two half-waves inside the same four instructions), one chunk ahead, across tile
+//     boundaries too; BatchNorm + ReLU of the producing layer applied in registers.
+// History (same box, forward + data gradient of the three heads): work-queue version with the weights re-staged per 128-pixel
+// item through a double-buffered LDS image and one barrier per chunk 0.24 + 0.22 ms - its ablation (G1_ABL) showed 0.17 ms of
+// non-MFMA time that did not overlap with the 0.14 ms of MFMAs; weights straight from L2 without LDS 0.34 + 0.39 ms.
 // Partial K (65 / 133 input channels of the data gradient): the last chunk runs only the k-quads that hold channels; channels
 // past K are masked in registers (the rows of the packed image are zero as well).
-// Forward launches accumulate the BatchNorm statistics (per-lane channel sums kept across the items of a problem, flushed when
-// the workgroup moves to another problem).
+// Forward launches accumulate the BatchNorm statistics, data-gradient launches pass 1 of the BatchNorm backward of the layer
+// below (per-lane channel sums over the wave's tiles, one cross-wave reduction and one atomic per channel and workgroup).
 #pragma once
 #include "conv_mfma.hip.h"
 #include <type_traits>
+
+#ifndef G1_ABL
+#define G1_ABL 0  // compile-time perf ablation (SSP_HIPCC_EXTRA=-DG1_ABL=n): 1 no MFMA, 2 no pixel-operand loads, 4 no stores / no
+                  // BatchNorm-backward tensor loads
+#endif
 
 namespace sspk {
 
 constexpr int G1_KC = 32;      // input channels per K-chunk
 constexpr int G1_NT = 4;       // 32-channel n-tiles per problem
-constexpr int G1_PX = 128;     // pixels per workgroup item
+constexpr int G1_PX = 32;      // pixels per wave tile
 constexpr int G1_KMAX = 512;   // input channels (scale / shift image in LDS)
 constexpr int G1_MAXP = 12;    // problems per launch
-constexpr int G1_TILE_FLOATS = 4 * 64 * 4;  // one (chunk, n-tile) of the packed image: [k-quad][lane][4]
-constexpr int G1_LDS_BYTES = (2 * G1_NT * G1_TILE_FLOATS + 2 * G1_KMAX + 4 * G1_NT * 64) * 4;
+constexpr int G1_WAVES = 8;    // waves per workgroup (one workgroup per CU)
+constexpr int G1_TILE_FLOATS = 4 * 64 * 4;   // one (chunk, n-tile) of the packed image: [k-quad][lane][4]
+constexpr int G1_W_FLOATS = 32 * G1_TILE_FLOATS;  // resident weight image: chunks x n-tiles <= 32 (128 KB)
+constexpr int G1_LDS_BYTES = (G1_W_FLOATS + 2 * G1_KMAX) * 4;
 
 struct G1Prob {
   const float* in;        // [npx][in_cs], channels in_co .. in_co + K
@@ -56,231 +63,233 @@ struct G1Prob {
   int K, N;               // input channels, output channels of THIS problem (<= 128)
   int nchunks, nt, nt_total;
   int npx;
-  int item0;              // index of this problem's first item in the launch's list
+  int wg0, nwg;           // workgroups [wg0, wg0 + nwg) of the launch work on this problem
   unsigned in_bytes, out_bytes;
 };
 struct G1Args {
   G1Prob p[G1_MAXP];
-  int nprob, nitems;
-  int* counter;           // {next item, finished workgroups}: zero between launches
+  int nprob;
 };
 
-// One workgroup item (128 pixels of problem p) with NT n-tiles; ssum / ssq: the BatchNorm partial sums of the problem.
+// All tiles of one wave: tile = gw, gw + tw, ... (32 pixels each) of problem p with NT n-tiles.
 template <int IN_MODE, int NT, bool BNR>
-__device__ __forceinline__ void g1_item(const G1Prob& p, int px0, float* sB, const float* sSc, float (&ssum)[G1_NT],
-                                        float (&ssq)[G1_NT], int tid, int lane, int li, int lh, int* counter, int& nxt) {
+__device__ __forceinline__ void g1_run(const G1Prob& p, const float* sW, const float* sSc, float (&ssum)[G1_NT],
+                                       float (&ssq)[G1_NT], int gw, int tw, int lane, int li, int lh) {
   constexpr unsigned OOB = 0x80000000u;
   const int nchunks = p.nchunks, K = p.K;
+  const int ntiles = (p.npx + G1_PX - 1) / G1_PX;
+  if (gw >= ntiles) return;
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-  const unsigned voffA = (px0 + li < p.npx) ? (unsigned)(((px0 + li) * p.in_cs + p.in_co + 16 * lh) * 4) : OOB;
-  const float* const wsrc = p.wpk + tid * 4;  // + (chunk * nt_total + t) * G1_TILE_FLOATS
-  const int wstride = p.nt_total * G1_TILE_FLOATS;
-
-  f32x4 araw[4], wreg[NT];
-#define G1_ISSUE(CHUNK)                                                                                               \
-  {                                                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                   \
-      const unsigned vo_ = ((CHUNK) * G1_KC + 16 * lh + 4 * q < K) ? voffA : OOB;                                     \
-      araw[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo_ + q * 16, (CHUNK) * G1_KC * 4, 0)); \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
-      wreg[t] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(CHUNK) * wstride + t * G1_TILE_FLOATS);               \
-  }
-  G1_ISSUE(0)
-  // the index of the NEXT item is requested now, BEHIND the first loads (returns come back in order), and looked at after this
-  // item: an L2 atomic round trip off the critical path
-  if (tid == 0) nxt = atomicAdd(counter, 1);
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    float* const sBc = sB + (chunk & 1) * (G1_NT * G1_TILE_FLOATS);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(sBc + t * G1_TILE_FLOATS + tid * 4) = wreg[t];
-    __syncthreads();  // this chunk's weights are in LDS (and, at chunk 0, the scale / shift image of the problem)
-    // the lane's 16 channels of this chunk: [32 chunk + 16 lh, + 16)
-    float av[16];
-    {
-      const int kb = chunk * G1_KC + 16 * lh;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v = araw[q];
-        if (IN_MODE != 0) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(sSc + kb + 4 * q);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(sSc + G1_KMAX + kb + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) av[4 * q + e] = v[e];
-      }
-      if (kb + 16 > K) {  // channels past K (the last chunk of a 65 / 133-channel data gradient)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) av[e] = (kb + e < K) ? av[e] : 0.f;
-      }
-    }
-    if (chunk + 1 < nchunks) G1_ISSUE(chunk + 1)
-    __builtin_amdgcn_sched_barrier(0);  // the loads stay above the MFMAs
-    const int nq = min(4, (K - chunk * G1_KC + 3) >> 2);  // k-quads of this chunk that hold channels (of the lh = 0 half)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < nq) {
-        f32x4 bq[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const f32x4*>(sBc + (t * 4 + q) * 256 + lane * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * q + e], bq[t][e], acc[t], 0, 0, 0);
-      }
-    }
-  }
-#undef G1_ISSUE
-
-  // ---- epilogue: lane = output channel 32 t + li, register r = pixel (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 ----
-  // Addresses advance in a vector register (an out-of-range marker stays out of range under these additions): sixteen scalar
-  // row offsets per n-tile would be hoisted and spilled through v_writelane / v_readlane.  Channels past N hold exact zeros
-  // (zero weights, no bias), so a full 32-pixel tile needs no per-element validity selects.
-  const bool full = px0 + 32 <= p.npx;
-  const bool want_stats = p.stats != nullptr;
-  const unsigned pitch = (unsigned)p.out_cs * 4u;
   __amdgpu_buffer_rsrc_t rsrc_y = rsrc_out;
   if (BNR) rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bnr_y), 0, p.out_bytes, 0x00020000);
-  auto tiles = [&](auto FULL_) {  // straight-line per (full 32-pixel tile or not): wave-uniform
-    constexpr bool FULL = decltype(FULL_)::value;
+  const float* const wl = sW + lane * 4;  // + ((chunk * NT + t) * 4 + q) * 256
+  const unsigned pitch = (unsigned)p.out_cs * 4u;
+  const bool want_stats = p.stats != nullptr;
+
+  f32x4 araw[4];
+#define G1_ISSUE_A(VOFF, CHUNK)                                                                                       \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                   \
+      const unsigned vo_ = ((CHUNK) * G1_KC + 16 * lh + 4 * q < K) ? (VOFF) : OOB;                                    \
+      if (!(G1_ABL & 2)) araw[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo_ + q * 16, (CHUNK) * G1_KC * 4, 0)); \
+      else araw[q] = f32x4{1.f, 2.f, 3.f, (float)(CHUNK)};                                                           \
+    }                                                                                                                 \
+  }
+#define G1_VOFF(TILE) (((TILE) * G1_PX + li < p.npx) ? (unsigned)((((TILE) * G1_PX + li) * p.in_cs + p.in_co + 16 * lh) * 4) : OOB)
+  unsigned voffA = G1_VOFF(gw);
+  G1_ISSUE_A(voffA, 0)
+
+  for (int tile = gw; tile < ntiles; tile += tw) {
+    const int px0 = tile * G1_PX;
+    const bool full = px0 + G1_PX <= p.npx;
+    const int rows_left = p.npx - px0 - 4 * lh;  // pixel m of this lane exists while m < rows_left
+    float yv[BNR ? 2 : 1][BNR ? 16 : 1];
+    // BatchNorm-backward tensor values of n-tile T into yv[SET]: the addresses of that n-tile's stores
+#define G1_LOAD_Y(T, SET)                                                                                             \
+    {                                                                                                                 \
+      unsigned vo_ = (32 * (T) + li < p.N) ? (unsigned)(((px0 + 4 * lh) * p.out_cs + p.out_co + 32 * (T) + li) * 4) : OOB; \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
+        const int m_ = (r & 3) + 8 * (r >> 2);                                                                        \
+        const unsigned vr_ = (full || m_ < rows_left) ? vo_ : OOB;                                                    \
+        if (!(G1_ABL & 4)) yv[SET][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_y, vr_, 0, 0)); \
+        else yv[SET][r] = (float)vr_;                                                                                 \
+        vo_ += ((r & 3) == 3 ? 5u : 1u) * pitch;                                                                      \
+      }                                                                                                               \
+    }
+    // the pixel operand of the wave's NEXT tile (this one again at the end: redundant loads, but no branch around them)
+    const unsigned voffN = tile + tw < ntiles ? G1_VOFF(tile + tw) : voffA;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int ch = 32 * t + li;
-      const bool chok = ch < p.N;
-      const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.f;
-      const unsigned vbase = chok ? (unsigned)(((px0 + 4 * lh) * p.out_cs + p.out_co + ch) * 4) : OOB;
-      const int rows_left = p.npx - px0 - 4 * lh;  // pixel m of this lane exists while m < rows_left
-      float s1 = 0.f, s2 = 0.f;
-      float bsc = 0.f, bsh = 0.f, bis = 0.f, bnm = 0.f;
-      float yv[BNR ? 16 : 1];
-      if (BNR) {
-        if (chok) { bsc = p.bnr_scale[ch]; bsh = p.bnr_shift[ch]; bis = p.bnr_invstd[ch]; bnm = -p.bnr_mean[ch] * bis; }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4 bq[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bq[0][t] = *reinterpret_cast<const f32x4*>(wl + (t * 4) * 256);
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      // the lane's 16 channels of this chunk: [32 chunk + 16 lh, + 16)
+      float av[16];
+      {
+        const int kb = chunk * G1_KC + 16 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = araw[q];
+          if (IN_MODE != 0) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sSc + kb + 4 * q);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(sSc + G1_KMAX + kb + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[4 * q + e] = v[e];
+        }
+        if (kb + 16 > K) {  // channels past K (the last chunk of a 65 / 133-channel data gradient)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) av[e] = (kb + e < K) ? av[e] : 0.f;
+        }
+      }
+      if (BNR && chunk + 1 == nchunks) G1_LOAD_Y(0, 0)  // the epilogue's first BatchNorm-backward tensor values, under the last MFMAs
+      {  // next chunk of this tile, or chunk 0 of the next tile
+        const bool last = chunk + 1 == nchunks;
+        const unsigned vn = last ? voffN : voffA;
+        const int cn = last ? 0 : chunk + 1;
+        G1_ISSUE_A(vn, cn)
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the loads stay above the MFMAs
+      const int nq = min(4, (K - chunk * G1_KC + 3) >> 2);  // k-quads of this chunk that hold channels (of the lh = 0 half)
+      const float* const wc = wl + chunk * (NT * G1_TILE_FLOATS);
+      const float* const wn = wl + min(chunk + 1, nchunks - 1) * (NT * G1_TILE_FLOATS);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // fragments of the next k-quad (of the next chunk's first one at q = 3) while this one is multiplied
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          bq[(q + 1) & 1][t] = *reinterpret_cast<const f32x4*>((q < 3 ? wc : wn) + (t * 4 + ((q + 1) & 3)) * 256);
+        if (q < nq) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              if (!(G1_ABL & 1)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * q + e], bq[q & 1][t][e], acc[t], 0, 0, 0);
+              else acc[t][e] += av[4 * q + e] * bq[q & 1][t][e];
+            }
+        }
+      }
+    }
+    voffA = voffN;
+
+    // ---- epilogue: lane = output channel 32 t + li, register r = pixel (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 ----
+    // Addresses advance in a vector register (an out-of-range marker stays out of range under these additions): sixteen scalar
+    // row offsets per n-tile would be hoisted and spilled through v_writelane / v_readlane.  Channels past N hold exact zeros
+    // (zero weights, no bias), so a full 32-pixel tile needs no per-element validity selects.
+    auto tiles = [&](auto FULL_) {  // straight-line per (full 32-pixel tile or not): wave-uniform
+      constexpr bool FULL = decltype(FULL_)::value;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ch = 32 * t + li;
+        const bool chok = ch < p.N;
+        const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.f;
+        const unsigned vbase = chok ? (unsigned)(((px0 + 4 * lh) * p.out_cs + p.out_co + ch) * 4) : OOB;
+        float s1 = 0.f, s2 = 0.f;
+        float bsc = 0.f, bsh = 0.f, bis = 0.f, bnm = 0.f;
+        if (BNR) {
+          if (chok) { bsc = p.bnr_scale[ch]; bsh = p.bnr_shift[ch]; bis = p.bnr_invstd[ch]; bnm = -p.bnr_mean[ch] * bis; }
+          if (t + 1 < NT) G1_LOAD_Y(t + 1, (t + 1) & 1)  // the next n-tile's values while this one is finished
+        }
         unsigned vo = vbase;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = (r & 3) + 8 * (r >> 2);
-          const unsigned vr = (FULL || m < rows_left) ? vo : OOB;
-          yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_y, vr, 0, 0));
+          const float v = BNR ? acc[t][r] : acc[t][r] + bv;
+          const bool ok = FULL || m < rows_left;
+          if (!(G1_ABL & 4) || v == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_out, ok ? vo : OOB, 0, 0);
           vo += ((r & 3) == 3 ? 5u : 1u) * pitch;
+          if (BNR) {
+            // (a load outside the tensor returned y = 0: the gate then depends on the shift alone, but v of such a position is
+            // an exact zero for channels past N and is masked by `ok` for pixels past the end)
+            const float dz = (ok && fmaf(yv[t & 1][r], bsc, bsh) > 0.f) ? v : 0.f;
+            s1 += dz;
+            s2 = fmaf(dz, fmaf(yv[t & 1][r], bis, bnm), s2);
+          } else {
+            const float vm = (FULL || (ok && chok)) ? v : 0.f;
+            s1 += vm;
+            s2 = fmaf(vm, vm, s2);
+          }
         }
+        if (want_stats) { ssum[t] += s1; ssq[t] += s2; }
       }
-      unsigned vo = vbase;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2);
-        const float v = BNR ? acc[t][r] : acc[t][r] + bv;
-        const bool ok = FULL || m < rows_left;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_out, ok ? vo : OOB, 0, 0);
-        vo += ((r & 3) == 3 ? 5u : 1u) * pitch;
-        if (BNR) {
-          // (a load outside the tensor returned y = 0: the gate then depends on the shift alone, but v of such a position is
-          // an exact zero for channels past N and is masked by `ok` for pixels past the end)
-          const float dz = (ok && fmaf(yv[r], bsc, bsh) > 0.f) ? v : 0.f;
-          s1 += dz;
-          s2 = fmaf(dz, fmaf(yv[r], bis, bnm), s2);
-        } else {
-          const float vm = (FULL || (ok && chok)) ? v : 0.f;
-          s1 += vm;
-          s2 = fmaf(vm, vm, s2);
-        }
-      }
-      if (want_stats) { ssum[t] += s1; ssq[t] += s2; }
-    }
-  };
-  if (full) tiles(std::true_type{});
-  else tiles(std::false_type{});
+    };
+    if (full) tiles(std::true_type{});
+    else tiles(std::false_type{});
+#undef G1_LOAD_Y
+  }
+#undef G1_ISSUE_A
+#undef G1_VOFF
 }
 
 template <int IN_MODE, bool BNR>
-__global__ __launch_bounds__(256, 3) void conv1x1_group_kernel(const G1Args a) {
+__global__ __launch_bounds__(64 * G1_WAVES) void conv1x1_group_kernel(const G1Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const sB = smem;                                  // [2][G1_NT][4][64][4]
-  float* const sSc = smem + 2 * G1_NT * G1_TILE_FLOATS;    // scale[G1_KMAX], shift[G1_KMAX]
-  float* const sRed = sSc + 2 * G1_KMAX;                   // [4 waves][G1_NT][32][2]
-  __shared__ int s_item;
+  float* const sW = smem;                      // [chunk][nt][4][64][4] of this workgroup's problem
+  float* const sSc = smem + G1_W_FLOATS;       // scale[G1_KMAX], shift[G1_KMAX]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].wg0) ++pi;
+  const G1Prob& p = a.p[pi];
+  const int w = (int)blockIdx.x - p.wg0;
+  if (w >= p.nwg) return;  // (whole workgroup)
+  // ---- the problem's weights and input affine become resident ----
+  {
+    const int per_chunk = p.nt * (G1_TILE_FLOATS / 4);  // float4s
+    const int total = p.nchunks * per_chunk;
+    for (int i = tid; i < total; i += 64 * G1_WAVES) {
+      const int c = i / per_chunk, r = i - c * per_chunk;
+      *reinterpret_cast<f32x4*>(sW + (size_t)i * 4) =
+          *reinterpret_cast<const f32x4*>(p.wpk + ((size_t)c * p.nt_total * (G1_TILE_FLOATS / 4) + r) * 4);
+    }
+    if (IN_MODE != 0) {
+      for (int k = tid; k < G1_KMAX; k += 64 * G1_WAVES) {
+        const bool ok = k < p.K;
+        sSc[k] = ok ? p.in_scale[k] : 0.f;
+        sSc[G1_KMAX + k] = ok ? p.in_shift[k] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
 
   float ssum[G1_NT], ssq[G1_NT];
 #pragma unroll
   for (int t = 0; t < G1_NT; ++t) ssum[t] = ssq[t] = 0.f;
-  int cur = -1;  // problem whose scale / shift image sits in LDS and whose statistics sit in ssum / ssq
-
-  auto flush_stats = [&](int pi) {  // workgroup-uniform call
-    const G1Prob& q = a.p[pi];
-    if (q.stats == nullptr) return;
-#pragma unroll
-    for (int t = 0; t < G1_NT; ++t) {
-      const float s = ssum[t] + __shfl_xor(ssum[t], 32), v = ssq[t] + __shfl_xor(ssq[t], 32);
-      if (lh == 0) {
-        sRed[((wave * G1_NT + t) * 32 + li) * 2 + 0] = s;
-        sRed[((wave * G1_NT + t) * 32 + li) * 2 + 1] = v;
-      }
-      ssum[t] = ssq[t] = 0.f;
-    }
-    __syncthreads();
-    {
-      const int ch = tid >> 1, which = tid & 1;  // 128 channels x {sum, sum of squares}
-      if (ch < q.N) {
-        float tsum = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) tsum += sRed[((w * G1_NT + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
-        unsafeAtomicAdd(q.stats + (size_t)(blockIdx.x % NREP) * 2 * q.stats_c + which * q.stats_c + ch, (double)tsum);
-      }
-    }
-    __syncthreads();
-  };
-
-  if (tid == 0) s_item = atomicAdd(a.counter, 1);
-  __syncthreads();
-  int item = __builtin_amdgcn_readfirstlane(s_item);
-  while (item < a.nitems) {
-    int nxt = 0;
-    int pi = 0;
-    while (pi + 1 < a.nprob && item >= a.p[pi + 1].item0) ++pi;
-    const G1Prob& p = a.p[pi];
-    if (pi != cur) {
-      if (cur >= 0) flush_stats(cur);
-      cur = pi;
-      if (IN_MODE != 0) {
-        for (int k = tid; k < G1_KMAX; k += 256) {
-          const bool ok = k < p.K;
-          sSc[k] = ok ? p.in_scale[k] : 0.f;
-          sSc[G1_KMAX + k] = ok ? p.in_shift[k] : 0.f;
-        }
-      }
-      // (the first barrier of the chunk loop orders these writes before the first read)
-    }
-    const int px0 = (item - p.item0) * G1_PX + wave * 32;
-    switch (p.nt) {
-      case 1: g1_item<IN_MODE, 1, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
-      case 2: g1_item<IN_MODE, 2, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
-      case 3: g1_item<IN_MODE, 3, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
-      default: g1_item<IN_MODE, 4, BNR>(p, px0, sB, sSc, ssum, ssq, tid, lane, li, lh, a.counter, nxt); break;
-    }
-    __syncthreads();  // every wave is done with s_item and with the LDS images of this item
-    if (tid == 0) s_item = nxt;
-    __syncthreads();
-    item = __builtin_amdgcn_readfirstlane(s_item);
+  const int gw = w * G1_WAVES + wave, tw = p.nwg * G1_WAVES;
+  switch (p.nt) {
+    case 1: g1_run<IN_MODE, 1, BNR>(p, sW, sSc, ssum, ssq, gw, tw, lane, li, lh); break;
+    case 2: g1_run<IN_MODE, 2, BNR>(p, sW, sSc, ssum, ssq, gw, tw, lane, li, lh); break;
+    case 3: g1_run<IN_MODE, 3, BNR>(p, sW, sSc, ssum, ssq, gw, tw, lane, li, lh); break;
+    default: g1_run<IN_MODE, 4, BNR>(p, sW, sSc, ssum, ssq, gw, tw, lane, li, lh); break;
   }
-  if (cur >= 0) flush_stats(cur);
-  // the last workgroup out re-arms the counters for the next launch (kernel boundaries order it)
-  if (tid == 0) {
-    __threadfence();
-    const int done = atomicAdd(a.counter + 1, 1);
-    if (done == (int)gridDim.x - 1) {
-      a.counter[0] = 0;
-      a.counter[1] = 0;
+  if (p.stats == nullptr) return;  // (whole workgroup)
+  // ---- channel sums: the eight waves through LDS (the weight image is dead), one atomic per channel and workgroup ----
+  __syncthreads();
+  float* const sRed = smem;  // [wave][G1_NT][32][2]
+#pragma unroll
+  for (int t = 0; t < G1_NT; ++t) {
+    const float s = ssum[t] + __shfl_xor(ssum[t], 32), v = ssq[t] + __shfl_xor(ssq[t], 32);
+    if (lh == 0) {
+      sRed[((wave * G1_NT + t) * 32 + li) * 2 + 0] = s;
+      sRed[((wave * G1_NT + t) * 32 + li) * 2 + 1] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int ch = tid >> 1, which = tid & 1;  // 128 channels x {sum, second sum}
+    if (ch < p.N) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < G1_WAVES; ++ww) tsum += sRed[((ww * G1_NT + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
+      unsafeAtomicAdd(p.stats + (size_t)(blockIdx.x % NREP) * 2 * p.stats_c + which * p.stats_c + ch, (double)tsum);
     }
   }
 }

@@ -160,10 +160,9 @@ struct ssp_handle {
   // backward would otherwise run an F(2x2,3x3) kernel on an F(4x4,3x3) image or the reverse)
   bool pk_w4_fwd[16] = {}, pk_w4_bwd[16] = {};
   // pointwise layers (Pb, Db, Sout): operand images of conv1x1_group_kernel (forward / data gradient), whether pack_all wrote
-  // them (else the layer runs conv_mfma_kernel<1, ...> on the wpk_fwd / wpk_bwd images), and the kernel's work-queue counters
+  // them (else the layer runs conv_mfma_kernel<1, ...> on the wpk_fwd / wpk_bwd images), and the partial slabs of the grouped weight gradient
   float *wpk_g1_fwd[16] = {}, *wpk_g1_bwd[16] = {};
   bool pk_g1[16] = {};
-  int* g1_counter = nullptr;
   float* g1_partial = nullptr;  // wgrad1x1_group_kernel: one [256][128] slab per workgroup (2 per CU)
   int g1_partial_slabs = 0;
   int packed_algo = -1;      // conv algorithm the images were packed for
@@ -295,7 +294,6 @@ static size_t carve(ssp_handle* h, void* base) {
     h->wpk_g1_fwd[i] = c.take<float>((size_t)cdiv(d.cin, G1_KC) * cdiv(d.cout, 32) * G1_TILE_FLOATS);
     h->wpk_g1_bwd[i] = c.take<float>((size_t)cdiv(d.cout, G1_KC) * cdiv(d.cin, 32) * G1_TILE_FLOATS);
   }
-  h->g1_counter = c.take<int>(64);
   h->g1_partial_slabs = 2 * 512;  // up to 512 CUs
   h->g1_partial = c.take<float>((size_t)h->g1_partial_slabs * G1W_SLAB);
   for (int s = 0; s < 2; ++s) {
@@ -696,62 +694,85 @@ static bool g1_enabled() {
   static const int env = getenv("SSP_G1") ? atoi(getenv("SSP_G1")) : 1;
   return env != 0 && g_conv_algo != 0;
 }
+static inline int g1_ntmax(int K) { return std::min(G1_NT, 32 / cdiv(K, G1_KC)); }  // n-tiles whose weight image fits the 128 KB of LDS
 static bool g1_fits(int K, int N, long npx, int in_cs, int out_cs, int nviews) {
-  const long parts = cdiv(cdiv(N, 32), G1_NT);
-  return K >= 1 && K <= G1_KMAX && N >= 1 && parts * nviews <= G1_MAXP && npx > 0 &&
-         (double)npx * in_cs * 4.0 < 2147483648.0 && (double)npx * out_cs * 4.0 < 2147483648.0;
+  if (K < 1 || K > G1_KMAX || N < 1 || npx <= 0) return false;
+  const long parts = cdiv(cdiv(N, 32), g1_ntmax(K));
+  return parts * nviews <= G1_MAXP && (double)npx * in_cs * 4.0 < 2147483648.0 && (double)npx * out_cs * 4.0 < 2147483648.0;
 }
-static int launch_g1(const G1Layer* L, int nl, int nviews, long npx, int in_mode, int* counter, int n_cu, hipStream_t st) {
-  struct Tmp { G1Prob p; long cost; };
-  std::vector<Tmp> v;
+static int launch_g1(const G1Layer* L, int nl, int nviews, long npx, int in_mode, int n_cu, hipStream_t st) {
+  G1Args a;
+  a.nprob = 0;
+  long cost[G1_MAXP], total = 0;
   bool bnr = nl > 0 && L[0].bnr_y[0] != nullptr;
   for (int i = 0; i < nl; ++i) {
     const G1Layer& y = L[i];
     if ((y.bnr_y[0] != nullptr) != bnr || (bnr && in_mode != 0)) return fail(-1, "grouped pointwise launch: mixed BatchNorm-backward fusion");
     if (!g1_fits(y.K, y.N, npx, y.in_cs, y.out_cs, nviews)) return fail(-3, "pointwise conv %d -> %d does not fit the grouped kernel", y.K, y.N);
-    const int ntt = cdiv(y.N, 32), nparts = cdiv(ntt, G1_NT);
+    const int ntt = cdiv(y.N, 32), nparts = cdiv(ntt, g1_ntmax(y.K));
     int t0 = 0;
     for (int part = 0; part < nparts; ++part) {
       const int size = ntt / nparts + (part < ntt % nparts ? 1 : 0);
       for (int k = 0; k < nviews; ++k) {
-        Tmp t;
-        G1Prob& q = t.p;
+        if (a.nprob >= G1_MAXP) return fail(-3, "grouped pointwise launch: more than %d problems", G1_MAXP);
+        G1Prob& q = a.p[a.nprob];
         q.in = y.in[k]; q.out = y.out[k]; q.wpk = y.wpk + (size_t)t0 * G1_TILE_FLOATS; q.bias = y.bias ? y.bias + 32 * t0 : nullptr;
         q.in_scale = y.scale[k]; q.in_shift = y.shift[k]; q.stats = y.stats[k] ? y.stats[k] + 32 * t0 : nullptr; q.stats_c = y.N;
         q.in_cs = y.in_cs; q.in_co = y.in_co; q.out_cs = y.out_cs; q.out_co = y.out_co + 32 * t0;
         q.K = y.K; q.N = std::min(y.N - 32 * t0, 32 * size); q.nchunks = cdiv(y.K, G1_KC); q.nt = size; q.nt_total = ntt;
-        q.npx = (int)npx; q.item0 = 0;
+        q.npx = (int)npx; q.wg0 = 0; q.nwg = 0;
         q.in_bytes = (unsigned)((size_t)npx * y.in_cs * 4); q.out_bytes = (unsigned)((size_t)npx * y.out_cs * 4);
         q.bnr_y = y.bnr_y[k];
         q.bnr_scale = bnr ? y.bnr_scale[k] + 32 * t0 : nullptr; q.bnr_shift = bnr ? y.bnr_shift[k] + 32 * t0 : nullptr;
         q.bnr_mean = bnr ? y.bnr_mean[k] + 32 * t0 : nullptr; q.bnr_invstd = bnr ? y.bnr_invstd[k] + 32 * t0 : nullptr;
         if (in_mode != 0 && (!q.in_scale || !q.in_shift)) return fail(-1, "pointwise conv: in_mode 1 needs scale / shift");
-        t.cost = (long)size * cdiv(y.K, 4);
-        v.push_back(t);
+        // cycles of a wave per 32-pixel tile (every problem of a launch has the same pixels): 4 MFMAs of 64 cycles per k-quad and
+        // n-tile, plus the epilogue of an n-tile (16 stores and the channel sums; with the BatchNorm-backward sums 16 loads and the
+        // gates as well) - without that term the 65-channel data gradient (9 k-quads) got half the CUs it needed
+        static const long e_plain = getenv("SSP_G1_ECOST") ? atol(getenv("SSP_G1_ECOST")) : 2000;      // (perf-debug knobs)
+        static const long e_bnr = getenv("SSP_G1_ECOST_BNR") ? atol(getenv("SSP_G1_ECOST_BNR")) : 5000;
+        cost[a.nprob] = (long)size * (256L * cdiv(y.K, 4) + (bnr ? e_bnr : e_plain));
+        total += cost[a.nprob];
+        ++a.nprob;
       }
       t0 += size;
     }
   }
-  if (v.empty()) return 0;
-  if ((int)v.size() > G1_MAXP) return fail(-3, "grouped pointwise launch: %d problems (max %d)", (int)v.size(), G1_MAXP);
-  std::stable_sort(v.begin(), v.end(), [](const Tmp& x, const Tmp& y) { return x.cost > y.cost; });  // heaviest items first
-  G1Args a;
-  a.nprob = (int)v.size();
-  int items = 0;
+  if (a.nprob == 0) return 0;
+  // One 8-wave workgroup per CU; the CUs are shared out in proportion to the MFMA counts (largest remainders), at least one
+  // workgroup per problem, no more workgroups than a problem has 8-tile groups.
+  const int grid = std::max(n_cu, a.nprob);
+  const int max_wg = std::max(1, cdiv(cdiv(npx, G1_PX), G1_WAVES));
+  int given = 0;
+  double frac[G1_MAXP];
   for (int i = 0; i < a.nprob; ++i) {
-    a.p[i] = v[i].p;
-    a.p[i].item0 = items;
-    items += cdiv(npx, G1_PX);
+    const double share = (double)grid * cost[i] / total;
+    a.p[i].nwg = std::max(1, std::min((int)share, max_wg));
+    frac[i] = share - (int)share;
+    given += a.p[i].nwg;
   }
-  a.nitems = items;
-  a.counter = counter;
-  const int grid = std::max(1, std::min(items, 3 * n_cu));
+  while (given < grid) {
+    int best = -1;
+    for (int i = 0; i < a.nprob; ++i)
+      if (a.p[i].nwg < max_wg && (best < 0 || frac[i] > frac[best])) best = i;
+    if (best < 0) break;
+    a.p[best].nwg += 1; frac[best] -= 1.0; ++given;
+  }
+  while (given > grid) {
+    int best = 0;
+    for (int i = 1; i < a.nprob; ++i)
+      if (a.p[i].nwg > a.p[best].nwg) best = i;
+    if (a.p[best].nwg <= 1) break;
+    a.p[best].nwg -= 1; --given;
+  }
+  int wg = 0;
+  for (int i = 0; i < a.nprob; ++i) { a.p[i].wg0 = wg; wg += a.p[i].nwg; }
   static AttrOnce attr0, attr1, attr2;
 #define SSP_G1_LAUNCH(M_, B_, ATTR_)                                                                                                  \
   {                                                                                                                                   \
     auto kern = conv1x1_group_kernel<M_, B_>;                                                                                         \
     if (ATTR_.need()) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS_BYTES)); \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G1_LDS_BYTES, st, a);                                                             \
+    hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * G1_WAVES), G1_LDS_BYTES, st, a);                                                     \
   }
   if (in_mode != 0) SSP_G1_LAUNCH(1, false, attr1)
   else if (bnr) SSP_G1_LAUNCH(0, true, attr2)
@@ -1470,7 +1491,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
         y.stats[k] = (d.bn && train) ? S.bn[l].stats : nullptr;
       }
     }
-    CHK(launch_g1(Lg, n, SS.n, (long)N * Hc * Wc, 1, h->g1_counter, h->n_cu, st));
+    CHK(launch_g1(Lg, n, SS.n, (long)N * Hc * Wc, 1, h->n_cu, st));
     for (int i = 0; i < n; ++i)
       if (h->L[layers[i]].bn) CHK(bn_finalize(h, SS.s, SS.n, layers[i], (double)N * Hc * Wc, train, st));
     return 0;
@@ -1766,7 +1787,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     if (gw) add_wgrad(L_SOUT, dsout, h->sout_cs);
   }
   if (gw && nw > 0) CHK(launch_g1_wgrad(Lw, nw, SS.n, (long)ncells_all, h->g1_partial, h->g1_partial_slabs, h->n_cu, st));
-  if (grouped && ng > 0) CHK(launch_g1(Lg, ng, SS.n, (long)ncells_all, 0, h->g1_counter, h->n_cu, st));
+  if (grouped && ng > 0) CHK(launch_g1(Lg, ng, SS.n, (long)ncells_all, 0, h->n_cu, st));
   // ---- 3x3 heads: BN+ReLU backward gP -> gQ [cells][hcs]; weight gradients; ONE data-gradient conv over the
   // concatenated dY channels (sums the heads' contributions) gQ -> gP [cells][128] ----
   {
@@ -2175,23 +2196,26 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
   // with transpose_flip the weight tensor is [cin_conv... see header]: w is OIHW with O = (tf ? cin : cout)
   AlgoScope algo(nullptr);
   if (ksize == 1 && in_mode != 2 && g1_enabled() && g1_fits(cin, cout, (long)n * hh * w, cin, cout, 1)) {
-    // pointwise layer: the grouped kernel of the heads, one problem set (conv1x1_group.hip.h); workspace = image | counters
-    const size_t img = align_up(g1_image_floats(cin, cout) * sizeof(float), 256);
-    if (workspace_bytes >= img + 256) {
+    // pointwise layer: the grouped kernel of the heads, one problem set (conv1x1_group.hip.h); workspace = operand image
+    const size_t img = g1_image_floats(cin, cout) * sizeof(float);
+    if (workspace_bytes >= img) {
       hipStream_t st = (hipStream_t)stream;
       float* wpk = reinterpret_cast<float*>(workspace_dev);
-      int* counter = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace_dev) + img);
       G1PackJobs G;
       G.n = 0;
       int nb = 0;
       g1_add_pack(G, nb, w_oihw_dev, wpk, transpose_flip ? cin : cout, transpose_flip ? cout : cin, transpose_flip ? 1 : 0);
       hipLaunchKernelGGL(pack_g1_kernel, dim3(nb), dim3(256), 0, st, G);
       HIPCHK(hipGetLastError());
-      CHK(dev_zero(counter, 256, st));
       G1Layer y;
       y.in[0] = in_dev; y.in_cs = cin; y.in_co = 0; y.out[0] = out_dev; y.out_cs = cout; y.out_co = 0; y.wpk = wpk; y.bias = bias_dev;
       y.scale[0] = in_scale_dev; y.shift[0] = in_shift_dev; y.stats[0] = stats_dev; y.K = cin; y.N = cout;
-      return launch_g1(&y, 1, 1, (long)n * hh * w, in_mode, counter, 256, st);
+      int n_cu = 256;
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+      return launch_g1(&y, 1, 1, (long)n * hh * w, in_mode, n_cu, st);
     }
   }
   const bool wino = wino_ok(ksize, cin) && in_mode != 2;
