@@ -627,6 +627,12 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   }
 }
 
+// a x + b y + c z with ONE rounding pattern everywhere (hipcc otherwise picks, per call site, which of the three products stays
+// unfused - the per-element and the per-cell packing kernels would produce images that differ in the last bit)
+__device__ __forceinline__ float wino_dot3(float a, float x, float b, float y, float c, float z) {
+  return __builtin_fmaf(c, z, __builtin_fmaf(b, y, __fmul_rn(a, x)));
+}
+
 // OIHW 3x3 weights -> U = G g G^T in the LDS image of conv_wino_pipe_kernel: [cob][chunk8][component][h][64][4]
 __device__ __forceinline__ void pack_wino8_element(const float* __restrict__ w, float* __restrict__ dst, int Cout_w,
                                                    int Cin_w, int transpose_flip, int nchunks_total, int chunk_off,
@@ -714,8 +720,8 @@ __device__ __forceinline__ void pack_wino4_element(const float* __restrict__ w, 
   const float g2j = j == 0 ? 0.f : j == 1 || j == 2 ? -1.f / 6.f : j == 5 ? 1.f : 1.f / 6.f;
   float r[3];
 #pragma unroll
-  for (int x = 0; x < 3; ++x) r[x] = g0i * k[0][x] + g1i * k[1][x] + g2i * k[2][x];
-  const float u = g0j * r[0] + g1j * r[1] + g2j * r[2];
+  for (int x = 0; x < 3; ++x) r[x] = wino_dot3(g0i, k[0][x], g1i, k[1][x], g2i, k[2][x]);
+  const float u = wino_dot3(g0j, r[0], g1j, r[1], g2j, r[2]);
   dst[((size_t)(cob + cob_off) * nchunks_total + chunk + chunk_off) * per_chunk + ((comp * 2 + h) * NB + nn) * 4 + e] = u;
 }
 
@@ -747,16 +753,74 @@ struct PackJobs {
   int n;
   PackJob j[PACK_MAX_JOBS];
 };
-__global__ void pack_weights_wino8_multi_kernel(const PackJobs J) {
+// One thread per (cob, chunk, h, output channel, input-channel quad element) CELL: the 3x3 filter is read once and all 36 / 16
+// components are produced from registers with the expressions of pack_wino4_element / pack_wino8_element.  The per-element form read each filter 36 / 16 times with a stride of 9 floats between lanes: ~95 us for the 2.6 M
+// floats of a step's images, latency-bound, 0.29 ms beside the first-layer convolution it is meant to hide under.
+template <bool W4>
+__device__ __forceinline__ void pack_wino_cell(const PackJob& q, int cell) {
+  constexpr int NC = W4 ? 36 : WC;
+  constexpr int per_chunk = NC * PK * NB;
+  const int cells = q.ncob * q.nchunks * (PK * NB);
+  if (cell >= cells) return;
+  int t = cell;
+  const int e = t & 3;
+  t >>= 2;
+  const int nn = t & 63;
+  t >>= 6;
+  const int h = t & 1;
+  t >>= 1;
+  const int chunk = t % q.nchunks;
+  const int cob = t / q.nchunks;
+  const int co = cob * NB + nn;
+  const int ci = chunk * PK + h * 4 + e;
+  float k[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float v = 0.f;
+      if (!q.tf) {
+        if (co < q.cout_w && ci < q.cin_w) v = q.w[(((size_t)co * q.cin_w + ci) * 3 + ky) * 3 + kx];
+      } else {
+        if (co < q.cin_w && ci < q.cout_w) v = q.w[(((size_t)ci * q.cin_w + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+      }
+      k[ky][kx] = v;
+    }
+  float* const d = q.dst + ((size_t)(cob + q.cob_off) * q.nchunks_total + chunk + q.chunk_off) * per_chunk + (h * NB + nn) * 4 + e;
+#pragma unroll
+  for (int comp = 0; comp < NC; ++comp) {
+    float u;
+    if (W4) {
+      const int i = comp / 6, j = comp % 6;
+      const float g0i = i == 0 ? 0.25f : i == 1 || i == 2 ? -1.f / 6.f : i == 5 ? 0.f : 1.f / 24.f;
+      const float g1i = i == 0 || i == 5 ? 0.f : i == 1 ? -1.f / 6.f : i == 2 ? 1.f / 6.f : i == 3 ? 1.f / 12.f : -1.f / 12.f;
+      const float g2i = i == 0 ? 0.f : i == 1 || i == 2 ? -1.f / 6.f : i == 5 ? 1.f : 1.f / 6.f;
+      const float g0j = j == 0 ? 0.25f : j == 1 || j == 2 ? -1.f / 6.f : j == 5 ? 0.f : 1.f / 24.f;
+      const float g1j = j == 0 || j == 5 ? 0.f : j == 1 ? -1.f / 6.f : j == 2 ? 1.f / 6.f : j == 3 ? 1.f / 12.f : -1.f / 12.f;
+      const float g2j = j == 0 ? 0.f : j == 1 || j == 2 ? -1.f / 6.f : j == 5 ? 1.f : 1.f / 6.f;
+      float r[3];
+#pragma unroll
+      for (int x = 0; x < 3; ++x) r[x] = wino_dot3(g0i, k[0][x], g1i, k[1][x], g2i, k[2][x]);
+      u = wino_dot3(g0j, r[0], g1j, r[1], g2j, r[2]);
+    } else {
+      const int i = comp >> 2, j = comp & 3;
+      float r[3];
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+        r[x] = i == 0 ? k[0][x] : i == 1 ? 0.5f * (k[0][x] + k[1][x] + k[2][x]) : i == 2 ? 0.5f * (k[0][x] - k[1][x] + k[2][x]) : k[2][x];
+      u = j == 0 ? r[0] : j == 1 ? 0.5f * (r[0] + r[1] + r[2]) : j == 2 ? 0.5f * (r[0] - r[1] + r[2]) : r[2];
+    }
+    d[(size_t)comp * 2 * NB * 4] = u;
+  }
+}
+// block0 counts blocks of 256 CELLS (pack_all: cdiv(ncob * nchunks * PK * NB, 256) per job)
+__global__ __launch_bounds__(256) void pack_weights_wino8_multi_kernel(const PackJobs J) {
   int k = 0;
   while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;  // wave-uniform linear search, <= 32 jobs
   const PackJob& q = J.j[k];
-  if (q.w4)
-    pack_wino4_element(q.w, q.dst, q.cout_w, q.cin_w, q.tf, q.nchunks_total, q.chunk_off, q.cob_off, q.ncob, q.nchunks,
-                       ((int)blockIdx.x - q.block0) * blockDim.x + threadIdx.x);
-  else
-  pack_wino8_element(q.w, q.dst, q.cout_w, q.cin_w, q.tf, q.nchunks_total, q.chunk_off, q.cob_off, q.ncob, q.nchunks,
-                     ((int)blockIdx.x - q.block0) * blockDim.x + threadIdx.x);
+  const int cell = ((int)blockIdx.x - q.block0) * blockDim.x + threadIdx.x;
+  if (q.w4) pack_wino_cell<true>(q, cell);
+  else pack_wino_cell<false>(q, cell);
 }
 
 }  // namespace sspk

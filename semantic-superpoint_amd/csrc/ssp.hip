@@ -1291,7 +1291,7 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     PackJob& q = J.j[J.n++];
     q.w = w; q.dst = dst; q.cout_w = cout_w; q.cin_w = cin_w; q.tf = tf; q.nchunks_total = nchunks_total;
     q.chunk_off = chunk_off; q.cob_off = cob_off; q.ncob = ncob; q.nchunks = nchunks; q.block0 = nblocks; q.w4 = w4 ? 1 : 0;
-    nblocks += cdiv((long)ncob * nchunks * (w4 ? W4_B_FLOATS : PB_FLOATS), 256);
+    nblocks += cdiv((long)ncob * nchunks * PK * NB, 256);  // one thread per (channel pair) cell: all components of a filter
   };
   auto pack = [&](const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino, bool w4) -> int {
     if (multi && wino && J.n < PACK_MAX_JOBS) {
