@@ -18,6 +18,7 @@ python3 $R/bench.py --conv-algo 9 --steps 20 --warmup 5 $Q > $O/bench_ssp_f2x2_o
 python3 $R/bench.py --conv-algo 11 --steps 20 --warmup 5 $Q > $O/bench_ssp_wgrad_f3x3_4x4.json 2>/dev/null
 SSP_FUSE_APPLY=0 python3 $R/bench.py --steps 20 --warmup 5 $Q > $O/bench_ssp_no_fused_apply.json 2>/dev/null
 SSP_LOSS_STREAM=0 python3 $R/bench.py --steps 20 --warmup 5 $Q > $O/bench_ssp_one_stream.json 2>/dev/null
+SSP_G1=0 python3 $R/bench.py --steps 20 --warmup 5 $Q > $O/bench_ssp_no_grouped_pointwise.json 2>/dev/null
 python3 $R/bench.py --desc-loss dense --steps 10 --warmup 3 $Q > $O/bench_ssp_dense_loss.json 2>/dev/null
 python3 $R/bench_export.py --steps 5 --warmup 2 > $O/bench_export_480x640.json 2>/dev/null
 python3 $R/bench_export.py --height 240 --width 320 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_export_240x320.json 2>/dev/null
