@@ -2029,8 +2029,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     const long npx = (long)B * H * W;
     const long ntile = (long)B * (Hc + 1) * (Wc + 1);
     const int grid = (int)std::min<long>((ntile + 3) / 4, 4096);
-    for (int v = 0; v < 2; ++v)
-      hipLaunchKernelGGL(sem_count_kernel, dim3(1024), dim3(256), 0, st, sems[v], npx, h->cfg.n_classes, h->accum, v);
+    hipLaunchKernelGGL(sem_count_kernel, dim3(512, 2), dim3(256), 0, st, sems[0], sems[1], npx, h->cfg.n_classes, h->accum);
     for (int v = 0; v < 2; ++v) {
       Slot& S = h->slot[v];
       if (in->train) {  // loss sum and d(convSout) in one pass (coef_sem: step_begin_kernel, sem_cnt: sem_count_kernel)
