@@ -49,7 +49,8 @@
 #define W4_ABL 0  // compile-time perf ablation: 1 no tile epilogue, 2 no transform, 4 no halo staging, 16 no output stores,
                   // 32 no barrier in the epilogue rounds, 64 accumulators not cleared, 128 no barriers in the stage loop, 256 no
                   // weight loads, 512 no fragment reads from LDS in the stage loop, 1024 halo loads confined to 64 KB (cache
-                  // hits); results: profiles/r02_w4_ablation.txt
+                  // hits), 2048 constants instead of the fused BatchNorm-backward tensor loads of the epilogue; results:
+                  // profiles/r02_w4_ablation.txt, r03_kernel_experiments.txt
 #endif
 
 namespace sspk {
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
           if (MODE != 0) {                                                                                  \
             _Pragma("unroll") for (int p = (P0); p < (P0) + 4; ++p)                                         \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                   \
-              tq[p][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, W4_VOFF(t, e, p), W4_SOFF(e, p, t), W4_NT)); \
+              tq[p][e] = (W4_ABL & 2048) ? 0.5f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, W4_VOFF(t, e, p), W4_SOFF(e, p, t), W4_NT)); \
           }
           W4_TQ(0)
           if (!(W4_ABL & 32)) __syncthreads();
