@@ -607,3 +607,30 @@ def test_mixed_bf16_mode_at_the_benchmark_size():
             assert all(np.isfinite(x) for x in v.values()), v
             first, last = (v, last) if it == 0 else (first, v)
     assert last["loss"] < first["loss"], (first["loss"], last["loss"])
+
+
+@pytest.mark.parametrize("n_classes", [21, 150])
+def test_segmentation_head_with_another_class_count(n_classes):
+    """convSout with 21 (one 32-channel n-tile, sout stride 24) and 150 (five n-tiles = 3 + 2) classes through the grouped
+    pointwise kernels (forward, data gradient with the fused BatchNorm-backward sums of bnS1, weight gradient) against
+    autograd through the oracle's forward: outputs, and the gradients of convSout / convDS / the encoder below."""
+    arch = ARCHS[1]
+    B, H, W = 2, 96, 128
+    sd = C.init_state_dict(arch, seed=5, n_classes=n_classes)
+    e = _engine(arch, B, H, W, sd, n_classes=n_classes)
+    rs = np.random.RandomState(n_classes)
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32))
+    out = e.forward(x.to(_dev()), slot=0, train=True, want=("semi", "desc", "sem"))
+    tsd = C.to_torch(sd, requires_grad=True)
+    ref = C.forward(tsd, x, arch, n_classes=n_classes)
+    for k in ("semi", "desc", "sem"):
+        assert (out[k].cpu() - ref[k].detach()).abs().max() < TOL, k
+    gs = {k: torch.from_numpy(rs.randn(*ref[k].shape).astype(np.float32)) for k in ("semi", "desc", "sem")}
+    sum((ref[k] * gs[k]).sum() for k in gs).backward()
+    e.zero_grad()
+    e.backward(0, gs["semi"].to(_dev()), gs["desc"].to(_dev()), gs["sem"].to(_dev()))
+    torch.cuda.synchronize()
+    gd = e.grad_dict()
+    for k in ("convSout.weight", "convSout.bias", "convDS.weight", "bnS1.weight", "convPb.weight", "convDb.weight",
+              "down3.mpconv.1.conv.3.weight"):
+        _grad_close(gd[k].cpu(), tsd[k].grad, k, **SMALL)
