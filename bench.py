@@ -94,7 +94,8 @@ def parse_args(argv=None):
                          "as dtype bf16x2")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="f32 = --conv-algo 1 (the headline); bf16 = --conv-algo 8, the validated mixed bf16 mode of BASELINE "
-                         "configs[3] (forward convs split-bf16, backward convs bf16, everything else fp32)")
+                         "configs[3] (fp32 forward, data / weight gradients of the 3x3 layers with bf16 matrix-core operands, everything "
+                         "else fp32)")
     ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
                     help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
     ap.add_argument("--graph", action="store_true", help="replay the pair step as a hipGraph (ssp_pair_step_graph)")
@@ -345,8 +346,8 @@ def main():
         prec = {3: ("bf16", "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)"),
                 7: ("bf16x2", "split-bf16 (hi + lo = 16 significant bits) matrix-core operands, three bf16 MFMAs per product / "
                               "fp32 accumulate + master (NOT the headline precision)"),
-                8: ("bf16", "mixed bf16: forward convolutions with split-bf16 (hi + lo) operands, data / weight gradients with "
-                            "bf16 operands; fp32 accumulate, BatchNorm, master weights, Adam (NOT the headline precision)")
+                8: ("bf16", "mixed bf16: fp32 forward, data / weight gradients of the 3x3 layers with bf16 matrix-core operands; "
+                            "fp32 tensors, accumulate, BatchNorm, master weights, Adam (NOT the headline precision)")
                 }.get(args.conv_algo, ("f32", "fp32"))
         out = {"metric": "image-pairs/sec at %dx%d bs%d (pair training step)" % (H, W, B), "value": round(pairs_s, 2),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

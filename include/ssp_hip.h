@@ -317,7 +317,10 @@ int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float
  * 2 = Winograd without the software pipeline (both for A/B measurements), 0 = direct implicit GEMM,
  * 3 = EXPERIMENTAL reduced precision: the Winograd kernels with bf16 matrix-core operands (fp32 storage, transforms,
  * accumulation and master weights); outputs within ~4e-3 relative RMS of fp32, gradients of the first layers up to
- * ~25 % off per step; never used for a reported fp32 number. */
+ * ~25 % off per step; never used for a reported fp32 number,
+ * 7 = the same with split-bf16 (hi + lo) operands everywhere, 8 = MIXED (BASELINE configs[3], bench.py --dtype bf16): fp32
+ * forward (algorithm 1), data / weight gradients of the 3x3 layers with one-part bf16 operands; losses equal the fp32 step's,
+ * gradients within ~1e-2 per tensor, 11 = algorithm 1 with the Winograd F(3x3,4x4) weight gradient. */
 int ssp_set_conv_algo(int algo);
 /* the same choice for ONE handle (a new handle starts with the process-wide value of ssp_set_conv_algo, which also
  * governs the handle-less ssp_op_conv / ssp_op_conv_wgrad) */

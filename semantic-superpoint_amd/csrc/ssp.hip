@@ -48,8 +48,9 @@ static thread_local int g_conv_algo = 1;        // algorithm of the call in flig
 // 3x3 convolutions whose input channels fill whole 16-channel K-chunks run as Winograd F(2x2,3x3)
 static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks == 3 && conv_cin % CK == 0; }
 // bf16 Winograd modes: number of bf16 parts per operand element.  3: one part everywhere; 7: hi + lo everywhere;
-// 8 (mixed): hi + lo in the FORWARD convolutions (the activations every later layer and the ReLU gates depend on), one
-// part in the data-gradient and weight-gradient kernels (unbiased 2^-9 noise on the gradients, like any bf16 training)
+// 8 (mixed): the FORWARD convolutions (the activations every later layer and the ReLU gates depend on) run the fp32 default
+// algorithm (FwdAlgoScope), the data-gradient and weight-gradient kernels take one part (unbiased 2^-9 noise on the gradients,
+// like any bf16 training)
 // fp32 pipelined Winograd family: 1 (default: F(4x4,3x3) on the large maps - conv_uses_w4 -, F(2x2,3x3) elsewhere), 9 = F(2x2,3x3)
 // only (the default of rounds 1-2), 10 = F(4x4,3x3) wherever legal
 // 11 = algorithm 1 with the Winograd F(3x3,4x4) weight gradient (wgrad_wino4_kernel: opt-in, measured not faster)
@@ -193,6 +194,15 @@ struct AlgoScope {  // makes the handle's conv algorithm the current one for the
   int prev;
   explicit AlgoScope(const ssp_handle* h) : prev(g_conv_algo) { g_conv_algo = h ? h->conv_algo : g_default_conv_algo; }
   ~AlgoScope() { g_conv_algo = prev; }
+};
+
+// Mixed mode 8 = fp32 FORWARD (the default algorithm's kernels: F(4x4,3x3) on the large maps is faster than the split-bf16
+// F(2x2,3x3) forward this mode used to run, and exact), bf16 operands in the data-gradient and weight-gradient convolutions.
+// Forward launches and the packing of the forward images run under this scope.
+struct FwdAlgoScope {
+  int prev;
+  FwdAlgoScope() : prev(g_conv_algo) { if (prev == 8) g_conv_algo = 1; }
+  ~FwdAlgoScope() { g_conv_algo = prev; }
 };
 
 enum { L_PA = 8, L_PB = 9, L_DA = 10, L_DB = 11, L_DS = 12, L_SOUT = 13 };
@@ -872,11 +882,11 @@ static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) 
   return 0;
 }
 
-template <int IN_MODE, bool WIDE, bool POOL>
+template <int IN_MODE, bool WIDE, bool POOL, bool BF16 = false>
 static int launch_wgrad_wino_fused_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using GF = WgradFusedGeom<WIDE>;
   static AttrOnce attr_once;
-  auto kern = wgrad_wino_fused_kernel<IN_MODE, WIDE, POOL>;
+  auto kern = wgrad_wino_fused_kernel<IN_MODE, WIDE, POOL, BF16>;
   if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GF::LDS_BYTES));
   }
@@ -936,8 +946,8 @@ struct WgradCall {
 static bool wgrad_can_fuse_apply(int ks, int in_mode, int H, int W, int cout) {
   static const int env = getenv("SSP_FUSE_APPLY") ? atoi(getenv("SSP_FUSE_APPLY")) : 1;  // (perf-debug A/B)
   static const int f4 = getenv("SSP_WGRAD_F4") ? atoi(getenv("SSP_WGRAD_F4")) : 0;        // (forces wgrad_wino4_kernel)
-  return env != 0 && f4 == 0 && (g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10) && ks == 3 && in_mode != 2 && H % 2 == 0 &&
-         W % 2 == 0 && cout % 4 == 0;
+  const bool algo_ok = g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10 || (bf16_algo() && bf16_parts(true) == 1);
+  return env != 0 && f4 == 0 && algo_ok && ks == 3 && in_mode != 2 && H % 2 == 0 && W % 2 == 0 && cout % 4 == 0;
 }
 
 // sums the pending partial slabs of the deferred Winograd weight-gradient launches into the OIHW gradients
@@ -1012,9 +1022,12 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
     ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes, flops * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0),
                  wino4 ? SSP_PROF_K_WGRAD_WINO4 : wino && !bf16_algo() ? SSP_PROF_K_WGRAD_WINO : SSP_PROF_K_OTHER);
     if (c.fuse_apply) {
-      if (!wino || wino4 || bf16_algo()) return fail(-3, "fused BatchNorm apply needs the fp32 F(3x3,2x2) weight gradient");
+      const bool b16 = bf16_algo();
+      if (!wino || wino4 || (b16 && bf16_parts(true) != 1))
+        return fail(-3, "fused BatchNorm apply needs the F(3x3,2x2) weight gradient (fp32, or bf16 operands in one part)");
 #define WGF_CASE(M_, P_) \
-      if (c.in_mode == M_ && c.fuse_pool == P_) CHK((wide ? launch_wgrad_wino_fused_t<M_, true, P_>(a, nblocks, st) : launch_wgrad_wino_fused_t<M_, false, P_>(a, nblocks, st)));
+      if (c.in_mode == M_ && c.fuse_pool == P_ && !b16) CHK((wide ? launch_wgrad_wino_fused_t<M_, true, P_>(a, nblocks, st) : launch_wgrad_wino_fused_t<M_, false, P_>(a, nblocks, st))); \
+      if (c.in_mode == M_ && c.fuse_pool == P_ && b16) CHK((wide ? launch_wgrad_wino_fused_t<M_, true, P_, true>(a, nblocks, st) : launch_wgrad_wino_fused_t<M_, false, P_, true>(a, nblocks, st)));
       WGF_CASE(0, false) WGF_CASE(0, true) WGF_CASE(1, false) WGF_CASE(1, true)
 #undef WGF_CASE
     } else if (wino4) {
@@ -1294,7 +1307,8 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     nblocks += cdiv((long)ncob * nchunks * PK * NB, 256);  // one thread per (channel pair) cell: all components of a filter
   };
   auto pack = [&](const float* w, float* dst, int cout_w, int cin_w, int ks, int tf, bool wino, bool w4) -> int {
-    if (multi && wino && J.n < PACK_MAX_JOBS) {
+    const bool multi_now = pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6;  // (the forward images of mode 8 are packed as algorithm 1)
+    if (multi_now && wino && J.n < PACK_MAX_JOBS) {
       const int conv_cin = tf ? cout_w : cin_w, conv_cout = tf ? cin_w : cout_w;
       const int nchunks = 2 * cdiv(conv_cin, CK), ncob = cdiv(conv_cout, NB);
       add_job(w, dst, cout_w, cin_w, tf, nchunks, 0, 0, ncob, nchunks, w4);
@@ -1324,8 +1338,11 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
       }
     }
     const bool wf = wino_ok(d.ks, d.cin), wb = wino_ok(d.ks, d.cout);
-    h->pk_w4_fwd[l] = wf && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, d.cin, d.cout);
-    CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wf, h->pk_w4_fwd[l]));
+    {
+      FwdAlgoScope fwd;
+      h->pk_w4_fwd[l] = wf && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, d.cin, d.cout);
+      CHK(pack(P(h, d.w_off), h->wpk_fwd + d.pk_fwd, d.cout, d.cin, d.ks, 0, wf, h->pk_w4_fwd[l]));
+    }
     if (with_bwd) {
       h->pk_w4_bwd[l] = wb && d.ks == 3 && w4_eligible(h, nprob, N, lh, lw, (int)align_up(d.cout, 4), d.cin);
       CHK(pack(P(h, d.w_off), h->wpk_bwd + d.pk_bwd, d.cout, d.cin, d.ks, 1, wb, h->pk_w4_bwd[l]));
@@ -1390,6 +1407,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
                           hipStream_t st) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
+  FwdAlgoScope fwd_algo;
   const bool pooled = in_mode == 2;  // input = pooled output of layer src: raw pooled y (BatchNorm + ReLU on load, mode 1)
                                      // when its conv wrote it (pool_raw), else materialised maxpool(relu(bn(Y_src))) (mode 0)
   if (pooled && A.pool_raw[src]) {

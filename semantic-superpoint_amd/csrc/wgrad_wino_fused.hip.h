@@ -19,6 +19,7 @@
 // PARKED IN LDS here (hipcc otherwise hoists every pp / WT, pp % WT out of the tile loop: wgrad_wino4.hip.h).
 #pragma once
 #include "conv_wino.hip.h"
+#include "conv_wino_bf16.hip.h"
 
 namespace sspk {
 
@@ -31,7 +32,9 @@ struct WgradFusedGeom {
   static constexpr int LDS_BYTES = (G::X_FLOATS + G::D_FLOATS + 256 + F_FLOATS + O_WORDS) * 4;
 };
 
-template <int IN_MODE, bool WIDE, bool POOL>
+// BF16: the MFMA phase of wgrad_wino_bf16_kernel<.., NT = 1> (transformed operands rounded to bf16 in registers, one
+// v_mfma_f32_32x32x8_bf16 per 8 tiles; the mixed bf16 mode 8) on the same fp32 LDS tile images.
+template <int IN_MODE, bool WIDE, bool POOL, bool BF16 = false>
 __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a) {
   using G = WgradWinoGeom<WIDE>;
   using GF = WgradFusedGeom<WIDE>;
@@ -292,7 +295,43 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
       const float* xa0 = sX + (ra * G::WT + 2 * lh) * 64 + 2 * li;
       const float* xb0 = sX + (rb * G::WT + 2 * lh) * 64 + 2 * li;
       const float* db0 = sD + (2 * lh) * 64 + coh * 32 + li;
-      wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1});
+      if (!BF16) wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1});
+    }
+    if (BF16) {
+#pragma unroll 1
+      for (int s = 0; s < 4; ++s) {  // 8 Winograd tiles per MFMA: lane half lh supplies tiles 8 s + 4 lh .. + 3
+        bf16x4 Vb[4][2], Db[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int t = 8 * s + 4 * lh + tt;
+          const int ty = t / G::TTX, tx = t - ty * G::TTX;
+          const float* xa = sX + ((2 * ty + ra) * G::WT + 2 * tx) * 64 + 2 * li;
+          const float* xb = sX + ((2 * ty + rb) * G::WT + 2 * tx) * 64 + 2 * li;
+          f32x2 T[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x2 u = *reinterpret_cast<const f32x2*>(xa + c * 64), w = *reinterpret_cast<const f32x2*>(xb + c * 64);
+            T[c][0] = fmaf(sg, w[0], u[0]);
+            T[c][1] = fmaf(sg, w[1], u[1]);
+          }
+          const f32x2 V[4] = {T[0] - T[2], T[1] + T[2], T[2] - T[1], T[1] - T[3]};
+          const float* db = sD + ((2 * ty) * G::TW + 2 * tx) * 64 + coh * 32 + li;
+          const float r0 = c0 * db[0] + c1 * db[G::TW * 64];
+          const float r1 = c0 * db[64] + c1 * db[G::TW * 64 + 64];
+          const float Dv[4] = {r0, r0 + r1, r0 - r1, -r1};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            Vb[j][0][tt] = (__bf16)V[j][0];
+            Vb[j][1][tt] = (__bf16)V[j][1];
+            Db[j][tt] = (__bf16)Dv[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            acc[j][e] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, Vb[j][e]), __builtin_bit_cast(s16x4, Db[j]), acc[j][e], 0, 0, 0);
+      }
     }
   }
 #undef WGF_ISSUE

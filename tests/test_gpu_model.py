@@ -529,12 +529,12 @@ def test_bf16x2_mode_tracks_the_fp32_step(arch):
 @pytest.mark.parametrize("arch", ARCHS)
 def test_mixed_bf16_mode_tracks_the_fp32_step(arch):
     """ssp_set_conv_algo(8) = `bench.py --dtype bf16`, the BASELINE configs[3] candidate ("bf16 compute / fp32 master"):
-    forward 3x3 convolutions with split-bf16 (hi + lo) operands, data / weight gradients with one bf16 part, fp32 storage,
-    accumulation, BatchNorm, master weights and Adam.  Against the fp32 step at 120x160, B = 2: losses within 1e-3, every
-    gradient tensor within 3e-2 relative L2 (one-part backward operands add unbiased 2^-9 noise on top of the gate flips of
-    the 16-bit forward products; measured 2.2e-2 on the first layer's BatchNorm bias at this small size - at B = 32, 240x320
-    the flips average out and the bounds are 2e-2 / 5e-3: next test), flat gradient within 2e-2 (measured 1.2e-2 - 1.3e-2 here,
-    the same as the hi + lo everywhere mode 7: it is the forward's gate flips, not the one-part backward), cosine > 0.9998."""
+    fp32 forward (the default algorithm's kernels, so every loss equals the fp32 step's), data / weight gradients of the 3x3
+    layers with bf16 matrix-core operands (one part), fp32 storage, accumulation, BatchNorm, master weights and Adam.
+    Against the fp32 step at 120x160, B = 2: losses within 1e-5 (identical forward; the summation order of the atomics
+    differs), every gradient tensor within 2e-2 relative L2 (unbiased 2^-9 operand noise accumulated down the backward chain:
+    measured 1.4e-2 on the first layer's BatchNorm bias; 2.2e-2 while the forward still ran on split-bf16 operands and
+    moved ReLU gates), flat gradient within 1e-2 (measured 6.6e-3 - 7.6e-3), cosine > 0.9999."""
     from semantic_superpoint_amd.lib import SCALAR_NAMES
     B, H, W = 2, 120, 160
     sd = C.init_state_dict(arch, seed=21)
@@ -549,7 +549,7 @@ def test_mixed_bf16_mode_tracks_the_fp32_step(arch):
         out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), {k: v.clone().cpu().double() for k, v in e.grad_dict().items()},
                   e.grads.clone().cpu().double())
     for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
-        assert abs(out[1][0][name] - out[8][0][name]) < 1e-3 * max(1.0, abs(out[1][0][name])), name
+        assert abs(out[1][0][name] - out[8][0][name]) < 1e-5 * max(1.0, abs(out[1][0][name])), name
     noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
     worst = (0.0, "")
     for k, g1 in out[1][1].items():
@@ -557,18 +557,18 @@ def test_mixed_bf16_mode_tracks_the_fp32_step(arch):
             continue
         rel = float((g1 - out[8][1][k]).norm() / (g1.norm() + 1e-30))
         worst = max(worst, (rel, k))
-        assert rel <= 3e-2, (k, rel)
+        assert rel <= 2e-2, (k, rel)
     g1, g8 = out[1][2], out[8][2]
     flat = float((g1 - g8).norm() / g1.norm())
     print("mixed bf16 vs fp32 (%s, 120x160): worst per-tensor rel-L2 %.2e (%s), flat %.2e" % (arch, worst[0], worst[1], flat))
-    assert flat < 2e-2
-    assert float((g1 * g8).sum() / (g1.norm() * g8.norm())) > 0.9998
+    assert flat < 1e-2
+    assert float((g1 * g8).sum() / (g1.norm() * g8.norm())) > 0.9999
 
 
 def test_mixed_bf16_mode_at_the_benchmark_size():
-    """The same comparison at B = 32, 240x320 (SSp, configs[3]'s per-GPU shape; tools/bf16_grad_probe.py measured 1.4e-2
-    worst per tensor, 3.7e-3 flat): per-tensor <= 2e-2, flat <= 5e-3, every scalar within 1e-3; then 10 optimizer steps
-    in mode 8 stay finite and lower the loss."""
+    """The same comparison at B = 32, 240x320 (SSp, configs[3]'s per-GPU shape; measured 1.1e-2 worst per tensor, 2.0e-3
+    flat - 1.4e-2 / 3.7e-3 before the forward went back to fp32): per-tensor <= 1.5e-2, flat <= 3e-3, every scalar within
+    1e-5; then 10 optimizer steps in mode 8 stay finite and lower the loss."""
     from semantic_superpoint_amd import synth
     from semantic_superpoint_amd.lib import SCALAR_NAMES, layer_table
     arch = ARCHS[1]
@@ -586,7 +586,7 @@ def test_mixed_bf16_mode_at_the_benchmark_size():
         out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), {k: v.clone().double() for k, v in e.grad_dict().items()},
                   e.grads.clone().double())
     for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
-        assert abs(out[1][0][name] - out[8][0][name]) < 1e-3 * max(1.0, abs(out[1][0][name])), name
+        assert abs(out[1][0][name] - out[8][0][name]) < 1e-5 * max(1.0, abs(out[1][0][name])), name
     noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
     worst = (0.0, "")
     for k, g1 in out[1][1].items():
@@ -595,7 +595,7 @@ def test_mixed_bf16_mode_at_the_benchmark_size():
         worst = max(worst, (float((g1 - out[8][1][k]).norm() / (g1.norm() + 1e-30)), k))
     flat = float((out[1][2] - out[8][2]).norm() / out[1][2].norm())
     print("mixed bf16 vs fp32 (B = 32, 240x320): worst per-tensor rel-L2 %.2e (%s), flat %.2e" % (worst[0], worst[1], flat))
-    assert worst[0] <= 2e-2 and flat <= 5e-3, (worst, flat)
+    assert worst[0] <= 1.5e-2 and flat <= 3e-3, (worst, flat)
     e.load_state_dict(sd)
     first = last = None
     for it in range(10):
