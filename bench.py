@@ -367,8 +367,8 @@ def main():
                "final_loss": round(scal["loss"], 4)}
         if profiled:
             peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
-            # the split-bf16 modes issue 3 (hi + lo everywhere) / 2 (mixed: forward only, averaged) bf16 MFMAs per product block
-            mult = {7: 3.0, 8: 2.0}.get(args.conv_algo, 1.0)
+            # the split-bf16 mode 7 issues 3 bf16 MFMAs per product block (hi + lo operands); the mixed mode 8 one (its forward is fp32)
+            mult = {7: 3.0}.get(args.conv_algo, 1.0)
             what = {"conv_wino4_kernel": "3x3 forward + data gradient, Winograd F(4x4,3x3): 1/4 of the direct multiplies",
                     "conv_wino_pipe_kernel": "3x3 forward + data gradient, Winograd F(2x2,3x3): 16/36",
                     "conv_wino_p2_kernel": "3x3 forward + data gradient on the 30x40 maps, Winograd F(2x2,3x3): 16/36",
@@ -381,14 +381,17 @@ def main():
                 if k["ms"] <= 0:
                     continue
                 sec = k["ms"] * 1e-3
-                alg, ex = k["flops"] / sec / 1e12, mult * k["exec_flops"] / sec / 1e12
+                alg, ex = k["flops"] / sec / 1e12, (mult if name == "other" else 1.0) * k["exec_flops"] / sec / 1e12
                 c = pmc.get(name, {})
-                kernels[name] = {"what": what.get(name, ""), "launches": k["launches"],
+                # per-kernel peak: the fp32 kernel families price against the fp32 MFMA peak under every algorithm (the mixed bf16
+                # mode runs its forward on them); only the bf16-operand bucket of a reduced-precision line uses the bf16 peak
+                kpeak = PEAK_BF16_MFMA_TF if (reduced and name == "other") else PEAK_FP32_MFMA_TF
+                kernels[name] = {"what": what.get(name, ""), "launches": k["launches"], "peak": kpeak,
                                  "avg_launch_ms": round(k["ms"] / k["launches"], 4),
                                  "ms_per_step": round(k["ms"] / n_prof_steps, 3),
-                                 "algorithmic_tflops": round(alg, 2), "algorithmic_frac": round(alg / peak, 4),
-                                 "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4),
-                                 "frac": round(ex / peak, 4),
+                                 "algorithmic_tflops": round(alg, 2), "algorithmic_frac": round(alg / kpeak, 4),
+                                 "executed_tflops": round(ex, 2), "executed_frac": round(ex / kpeak, 4),
+                                 "frac": round(ex / kpeak, 4),
                                  "mfma_busy": None if c.get("mfma_busy") is None else round(c["mfma_busy"], 4),
                                  "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]),
                                  "traffic": None if c.get("traffic") is None else round(c["traffic"])}
@@ -396,7 +399,7 @@ def main():
                 dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])  # the kernel with the most time per step
                 d = kernels[dom]
                 out["roofline"] = {"bound": "mfma", "kernel": "%s (%s; v_mfma_f32_32x32x2_f32)" % (dom, d["what"]),
-                                   "achieved": d["executed_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["executed_frac"],
+                                   "achieved": d["executed_tflops"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["executed_frac"],
                                    "note": "achieved / frac = multiplies EXECUTED on the matrix cores per second / fp32 MFMA peak "
                                            "(the hardware fraction); algorithmic_* = direct-convolution FLOPs / time, which "
                                            "Winograd undercuts by 4x resp. 36/16, so that ratio may exceed 1",
