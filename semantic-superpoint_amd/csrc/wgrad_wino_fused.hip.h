@@ -298,39 +298,62 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
       if (!BF16) wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1});
     }
     if (BF16) {
+      // (pinned: hipcc converts each value on its own as soon as it exists and merges the halves with v_perm_b32)
+      auto cvt2 = [](float lo, float hi) -> unsigned {
+        unsigned d;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+        return d;
+      };
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll 1
       for (int s = 0; s < 4; ++s) {  // 8 Winograd tiles per MFMA: lane half lh supplies tiles 8 s + 4 lh .. + 3
-        bf16x4 Vb[4][2], Db[4];
+        // Two tiles at a time: the values of tiles (tt, tt + 1) convert PAIRWISE (one v_cvt_pk_bf16_f32 per two values, already
+        // in operand order) - converted one by one, the four values of an operand register were assembled with a v_perm_b32
+        // each; the loop is bound by its vector instructions (8 bf16 MFMAs = 128 matrix-pipe cycles beside ~150 of them)
+        unsigned Vp[4][2][2], Dp[4][2];  // [component][m-tile][tile pair]: two bf16 values each
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          const int t = 8 * s + 4 * lh + tt;
-          const int ty = t / G::TTX, tx = t - ty * G::TTX;
-          const float* xa = sX + ((2 * ty + ra) * G::WT + 2 * tx) * 64 + 2 * li;
-          const float* xb = sX + ((2 * ty + rb) * G::WT + 2 * tx) * 64 + 2 * li;
-          f32x2 T[4];
+        for (int tp = 0; tp < 2; ++tp) {
+          f32x2 Vt[2][4];
+          float Dt[2][4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const f32x2 u = *reinterpret_cast<const f32x2*>(xa + c * 64), w = *reinterpret_cast<const f32x2*>(xb + c * 64);
-            T[c][0] = fmaf(sg, w[0], u[0]);
-            T[c][1] = fmaf(sg, w[1], u[1]);
+          for (int u = 0; u < 2; ++u) {
+            const int t = 8 * s + 4 * lh + 2 * tp + u;
+            const int ty = t / G::TTX, tx = t - ty * G::TTX;
+            const float* xa = sX + ((2 * ty + ra) * G::WT + 2 * tx) * 64 + 2 * li;
+            const float* xb = sX + ((2 * ty + rb) * G::WT + 2 * tx) * 64 + 2 * li;
+            f32x2 T[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x2 uu = *reinterpret_cast<const f32x2*>(xa + c * 64), w = *reinterpret_cast<const f32x2*>(xb + c * 64);
+              T[c][0] = fmaf(sg, w[0], uu[0]);
+              T[c][1] = fmaf(sg, w[1], uu[1]);
+            }
+            Vt[u][0] = T[0] - T[2]; Vt[u][1] = T[1] + T[2]; Vt[u][2] = T[2] - T[1]; Vt[u][3] = T[1] - T[3];
+            const float* db = sD + ((2 * ty) * G::TW + 2 * tx) * 64 + coh * 32 + li;
+            const float r0 = c0 * db[0] + c1 * db[G::TW * 64];
+            const float r1 = c0 * db[64] + c1 * db[G::TW * 64 + 64];
+            Dt[u][0] = r0; Dt[u][1] = r0 + r1; Dt[u][2] = r0 - r1; Dt[u][3] = -r1;
           }
-          const f32x2 V[4] = {T[0] - T[2], T[1] + T[2], T[2] - T[1], T[1] - T[3]};
-          const float* db = sD + ((2 * ty) * G::TW + 2 * tx) * 64 + coh * 32 + li;
-          const float r0 = c0 * db[0] + c1 * db[G::TW * 64];
-          const float r1 = c0 * db[64] + c1 * db[G::TW * 64 + 64];
-          const float Dv[4] = {r0, r0 + r1, r0 - r1, -r1};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            Vb[j][0][tt] = (__bf16)V[j][0];
-            Vb[j][1][tt] = (__bf16)V[j][1];
-            Db[j][tt] = (__bf16)Dv[j];
+            Vp[j][0][tp] = cvt2(Vt[0][j][0], Vt[1][j][0]);
+            Vp[j][1][tp] = cvt2(Vt[0][j][1], Vt[1][j][1]);
+            Dp[j][tp] = cvt2(Dt[0][j], Dt[1][j]);
           }
         }
+        // hipcc inserts no wait states between an inline-asm result and an MFMA that reads it: all operands complete, then the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+          const u32x2_t db4 = {Dp[j][0], Dp[j][1]};
 #pragma unroll
-          for (int e = 0; e < 2; ++e)
-            acc[j][e] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, Vb[j][e]), __builtin_bit_cast(s16x4, Db[j]), acc[j][e], 0, 0, 0);
+          for (int e = 0; e < 2; ++e) {
+            const u32x2_t vb4 = {Vp[j][e][0], Vp[j][e][1]};
+            acc[j][e] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, vb4), __builtin_bit_cast(s16x4, db4), acc[j][e], 0, 0, 0);
+          }
+        }
       }
     }
   }
