@@ -91,6 +91,17 @@ struct AttrOnce {
 };
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// CUs of the current device (handle-less operator entry points; queried once per device)
+static int device_cu_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
@@ -2227,12 +2238,7 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
       G1Layer y;
       y.in[0] = in_dev; y.in_cs = cin; y.in_co = 0; y.out[0] = out_dev; y.out_cs = cout; y.out_co = 0; y.wpk = wpk; y.bias = bias_dev;
       y.scale[0] = in_scale_dev; y.shift[0] = in_shift_dev; y.stats[0] = stats_dev; y.K = cin; y.N = cout;
-      int n_cu = 256;
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        n_cu = prop.multiProcessorCount;
-      return launch_g1(&y, 1, 1, (long)n * hh * w, in_mode, n_cu, st);
+      return launch_g1(&y, 1, 1, (long)n * hh * w, in_mode, device_cu_count(), st);
     }
   }
   const bool wino = wino_ok(ksize, cin) && in_mode != 2;
