@@ -86,7 +86,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11],
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12],
                     help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
                          "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
                          "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
@@ -342,10 +342,13 @@ def main():
     if rank == 0:
         scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
         pairs_s = world * B * args.steps / dt
-        reduced = args.conv_algo in (3, 7, 8)
+        reduced = args.conv_algo in (3, 7, 8, 12)
         prec = {3: ("bf16", "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)"),
                 7: ("bf16x2", "split-bf16 (hi + lo = 16 significant bits) matrix-core operands, three bf16 MFMAs per product / "
                               "fp32 accumulate + master (NOT the headline precision)"),
+                12: ("bf16", "bf16 path: bf16 NHWC activations / activation gradients in HBM, direct 3x3 convolutions, data and weight "
+                             "gradients on v_mfma_f32_32x32x16_bf16; fp32 accumulate, BatchNorm statistics, losses, master weights, Adam; "
+                             "pointwise heads fp32 (NOT the headline precision)"),
                 8: ("bf16", "mixed bf16: fp32 forward, data / weight gradients of the 3x3 layers with bf16 matrix-core operands; "
                             "fp32 tensors, accumulate, BatchNorm, master weights, Adam (NOT the headline precision)")
                 }.get(args.conv_algo, ("f32", "fp32"))

@@ -166,7 +166,9 @@ int ssp_profile_read(ssp_handle* h, double* ms, int64_t* launches, double* flops
 /* The same measurement split by the KERNEL that ran each tagged launch (bench.py's per-kernel roofline entries). */
 enum { SSP_PROF_K_CONV_WINO4 = 0 /* conv_wino4_kernel, Winograd F(4x4,3x3) */, SSP_PROF_K_CONV_WINO_PIPE = 1, SSP_PROF_K_CONV_WINO_P2 = 2,
        SSP_PROF_K_WGRAD_WINO = 3 /* wgrad_wino_kernel, F(3x3,2x2) */, SSP_PROF_K_WGRAD_WINO4 = 4 /* wgrad_wino4_kernel, F(3x3,4x4) */,
-       SSP_PROF_K_OTHER = 5 /* direct implicit GEMM, bf16-operand kernels */, SSP_PROF_K_COUNT = 6 };
+       SSP_PROF_K_OTHER = 5 /* direct implicit GEMM, bf16-operand Winograd kernels */,
+       SSP_PROF_K_CONV_BF16 = 6 /* conv_bf16_kernel (forward + data gradient of the bf16 path) */,
+       SSP_PROF_K_WGRAD_BF16 = 7 /* wgrad_bf16_kernel */, SSP_PROF_K_COUNT = 8 };
 /* Suspends (paused != 0) / resumes the bracketing without resetting the counters: bench.py brackets every n-th step of the
  * timed region only (the event records of ~30 launches per step cost ~1.7 % of the step when every step carries them). */
 int ssp_profile_pause(ssp_handle* h, int paused);
@@ -188,6 +190,26 @@ int ssp_op_conv(const float* in_dev, const float* w_oihw_dev, const float* bias_
 int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw_dev, int n, int h, int w, int cin,
                       int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- bf16 path (conv algorithm 12, BASELINE configs[3]): bf16 NHWC activations in HBM, v_mfma_f32_32x32x16_bf16 ----
+ * Convolution of models/unet_parts.py:14-21 as a direct implicit GEMM (csrc/conv_bf16.hip.h).  in: bf16 (fp32 when in_f32)
+ * NHWC [n,h,w,cin]; w: OIHW fp32 (rounded to bf16 when packed; transpose_flip: O = cin, the data-gradient convolution);
+ * in_mode 1: operand = bf16(relu(in * scale + shift)); out: bf16 (fp32 when out_f32) NHWC [n,h,w,cout] = round(acc + bias);
+ * stats (optional, double [SSP_NREP][2 cout], zeroed by the caller): sum / sum of squares of the STORED output;
+ * pool_out (optional, bf16 [n,h/2,w/2,cout]): per-channel max (pool_gamma >= 0) / min (< 0) of every 2x2 window of out.
+ * workspace: >= ceil(cout/64) * ceil(cin/32) * ksize^2 * 4096 bytes (the packed bf16 weight image). */
+int ssp_op_conv_bf16(const void* in_dev, const float* w_oihw_dev, const float* bias_dev, void* out_dev, int n, int h, int w,
+                     int cin, int cout, int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev,
+                     double* stats_dev, int transpose_flip, int in_f32, int out_f32, void* pool_out_dev,
+                     const float* pool_gamma_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Weight gradient of the same convolution (csrc/wgrad_bf16.hip.h): x bf16 NHWC [n,h,w,cin] (in_mode 1: operand =
+ * bf16(relu(x * scale + shift))), dy bf16 (fp32 when dy_f32, rounded to bf16 on load) NHWC [n,h,w,cout]; the fp32 OIHW gradient is
+ * ACCUMULATED into dw_oihw_dev.  workspace: partial slabs, >= ceil(cin/64) * ceil(cout/64) * ksize^2 * 16 KiB (more = more
+ * workgroups, up to 2 per CU). */
+int ssp_op_conv_wgrad_bf16(const void* x_dev, const void* dy_dev, float* dw_oihw_dev, int n, int h, int w, int cin, int cout,
+                           int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev, int dy_f32,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* labels2Dto3D (utils/utils.py:408-440, add_dustbin=True) -> target [B,65,H/8,W/8] NCHW and getMasks
  * (Train_model_frontend_all.py:373-386) -> cellmask [B,H/8,W/8]; either pair of pointers may be NULL. */

@@ -8,6 +8,28 @@
 
 namespace sspk {
 
+// ---- 4 consecutive channels of an NHWC tensor of fp32 (T = float) or bf16 (T = uint16_t: the bf16 path) elements ----
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const float4*>(p);
+  } else {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    return make_float4(bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1]));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, float4 v) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4*>(p) = v;
+  } else {
+    u32x2 o;
+    o[0] = pack_bf16(v.x, v.y);
+    o[1] = pack_bf16(v.z, v.w);
+    *reinterpret_cast<u32x2*>(p) = o;
+  }
+}
+
 // ---- block reduction helper: per-thread `NV` floats, threads with the same (tid % nq) are summed ----
 // smem must hold blockDim.x * NV floats.  Result valid for tid < nq (returned in v[]).
 template <int NV>
@@ -119,14 +141,15 @@ struct L0Conv {
   }
 };
 
+template <typename TO = float>  // TO = uint16_t: bf16 output (conv algorithm 12); the statistics are those of the STORED values
 __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           TO* __restrict__ out0, TO* __restrict__ out1,
                                                            double* __restrict__ stats0, double* __restrict__ stats1, int N,
                                                            int H, int W) {
   // blockIdx.y = view of the pair
   const float* __restrict__ x = blockIdx.y ? x1 : x0;
-  float* __restrict__ out = blockIdx.y ? out1 : out0;
+  TO* __restrict__ out = blockIdx.y ? out1 : out0;
   double* __restrict__ stats = blockIdx.y ? stats1 : stats0;
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x;
@@ -145,14 +168,23 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
     float* const img = l0_rows + par * 3 * (W + 2);
     l0_stage_rows(img, xr, up, down, W);
     __syncthreads();
-    float* orow = out + (size_t)row * W * 64 + q * 4;
+    TO* orow = out + (size_t)row * W * 64 + q * 4;
     for (int ox = pl; ox < W; ox += 16) {
       float v[9];
       l0_taps_lds(img, ox, W, v);
       L0Taps xt;
       xt.set(v);
-      const f32x2 o01 = cv.y2(0, xt), o23 = cv.y2(1, xt);
-      *reinterpret_cast<f32x4*>(orow + (size_t)ox * 64) = cat2(o01, o23);
+      f32x2 o01 = cv.y2(0, xt), o23 = cv.y2(1, xt);
+      if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<f32x4*>(orow + (size_t)ox * 64) = cat2(o01, o23);
+      } else {
+        u32x2 pk;
+        pk[0] = pack_bf16(o01[0], o01[1]);
+        pk[1] = pack_bf16(o23[0], o23[1]);
+        *reinterpret_cast<u32x2*>(orow + (size_t)ox * 64) = pk;
+        o01 = f32x2{bf16_lo(pk[0]), bf16_hi(pk[0])};
+        o23 = f32x2{bf16_lo(pk[1]), bf16_hi(pk[1])};
+      }
       s01 = pk_add(s01, o01); s23 = pk_add(s23, o23);
       q01 = pk_fma(o01, o01, q01); q23 = pk_fma(o23, o23, q23);
     }
@@ -300,9 +332,13 @@ struct BnBwdArgs {
   double count;
 };
 
-template <bool RELU, bool POOL, bool APPLY>
+// T = float, or uint16_t for the bf16 path (y, dout and dy are bf16 tensors behind the float* fields; offsets in elements)
+template <bool RELU, bool POOL, bool APPLY, typename T = float>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const BnBwdArgs a1) {
   const BnBwdArgs& a = blockIdx.y ? a1 : a0;  // the two views of a pair ride one launch
+  const T* const t_y = reinterpret_cast<const T*>(a.y);
+  const T* const t_dout = reinterpret_cast<const T*>(a.dout);
+  T* const t_dy = reinterpret_cast<T*>(a.dy);
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x;
   const int nq = (a.C + 3) / 4;                 // channel quads
@@ -316,7 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const B
   bool cv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) cv[i] = (c0 + i) < a.C;
-  auto ld4 = [&](const float* p) {
+  auto ldp = [&](const float* p) {
     float4 v = make_float4(0, 0, 0, 0);
     if (cv[0]) v.x = p[c0];
     if (cv[1]) v.y = p[c0 + 1];
@@ -325,12 +361,12 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const B
     return v;
   };
   if (active) {
-    sc = ld4(a.scale);
-    sh = ld4(a.shift);
-    mu = ld4(a.mean);
-    is = ld4(a.invstd);
+    sc = ldp(a.scale);
+    sh = ldp(a.shift);
+    mu = ldp(a.mean);
+    is = ldp(a.invstd);
     if (APPLY) {
-      const float4 g = ld4(a.gamma);
+      const float4 g = ldp(a.gamma);
       float s1[4], s2[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -352,11 +388,11 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const B
       const int ox = (int)(p % Wo);
       const int oy = (int)((p / Wo) % Ho);
       const int n = (int)(p / ((long)Wo * Ho));
-      const float4 d4 = *reinterpret_cast<const float4*>(a.dout + (size_t)p * a.d_cs + a.d_co + c0);
+      const float4 d4 = ld4<T>(t_dout + (size_t)p * a.d_cs + a.d_co + c0);
       const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
       if (!POOL) {
         const size_t yo = (size_t)p * a.y_cs + a.y_co + c0;
-        const float4 y4 = *reinterpret_cast<const float4*>(a.y + yo);
+        const float4 y4 = ld4<T>(t_y + yo);
         const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
         float o[4];
 #pragma unroll
@@ -372,8 +408,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const B
             acc[i] += o[i];
           }
         }
-        if (APPLY)
-          *reinterpret_cast<float4*>(a.dy + (size_t)p * a.dy_cs + a.dy_co + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (APPLY) st4<T>(t_dy + (size_t)p * a.dy_cs + a.dy_co + c0, make_float4(o[0], o[1], o[2], o[3]));
       } else {
         float yv[4][4], o[4][4];
         size_t yo[4];
@@ -381,7 +416,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const B
         for (int k = 0; k < 4; ++k) {
           const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
           yo[k] = ((size_t)(n * a.H + yy) * a.W + xx);
-          const float4 y4 = *reinterpret_cast<const float4*>(a.y + yo[k] * a.y_cs + a.y_co + c0);
+          const float4 y4 = ld4<T>(t_y + yo[k] * a.y_cs + a.y_co + c0);
           yv[k][0] = y4.x; yv[k][1] = y4.y; yv[k][2] = y4.z; yv[k][3] = y4.w;
         }
 #pragma unroll
@@ -414,9 +449,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const B
         }
         if (APPLY) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            *reinterpret_cast<float4*>(a.dy + yo[k] * a.dy_cs + a.dy_co + c0) =
-                make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+          for (int k = 0; k < 4; ++k) st4<T>(t_dy + yo[k] * a.dy_cs + a.dy_co + c0, make_float4(o[k][0], o[k][1], o[k][2], o[k][3]));
         }
       }
     }
@@ -520,6 +553,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs
 // input image (L0Conv::y, 9 fma per value) instead of reading it back: 629 MB less HBM traffic per pass and view at
 // B = 32.  Row-based like conv0_direct_kernel; L0_UNROLL pixels per thread are loaded before the arithmetic.
 // pass 1: S1 = sum dZ, S2 = sum dZ * xhat over one view (reads dOut only)
+// TD = uint16_t (bf16 path): dOut is a bf16 tensor and the recomputed y0 is rounded to bf16 like the stored activation was
+template <typename TD = float>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a0, const BnBwdArgs a1,
                                                                const float* __restrict__ w0,
                                                                const float* __restrict__ b0) {
@@ -551,7 +586,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
     float* const img = l0_rows + par * 3 * (W + 2);
     l0_stage_rows(img, xr, up, down, W);
     __syncthreads();
-    const float* drow = a.dout + (size_t)row * W * 64 + c0;
+    const TD* drow = reinterpret_cast<const TD*>(a.dout) + (size_t)row * W * 64 + c0;
     for (int ox0 = pl; ox0 < W; ox0 += 16 * L0_UNROLL) {
       float4 d4[L0_UNROLL];
       float xv[L0_UNROLL][9];
@@ -559,7 +594,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
       for (int j = 0; j < L0_UNROLL; ++j) {
         const bool ok = ox0 + 16 * j < W;
         const int ox = ok ? ox0 + 16 * j : W - 1;  // clamped: the loads stay branch-free
-        const float4 d = *reinterpret_cast<const float4*>(drow + (size_t)ox * 64);
+        const float4 d = ld4<TD>(drow + (size_t)ox * 64);
         d4[j] = ok ? d : make_float4(0.f, 0.f, 0.f, 0.f);  // dZ == 0 past the end of the row
         l0_taps_lds(img, ox, W, xv[j]);
       }
@@ -570,7 +605,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
         xt.set(xv[j]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const f32x2 yv = cv.y2(h, xt);
+          f32x2 yv = cv.y2(h, xt);
+          if constexpr (sizeof(TD) == 2) {
+            const uint32_t pk = pack_bf16(yv[0], yv[1]);
+            yv = f32x2{bf16_lo(pk), bf16_hi(pk)};
+          }
           const f32x2 z = pk_fma(yv, sc2[h], sh2[h]);
           const f32x2 dz = {z[0] > 0.f ? dv[2 * h] : 0.f, z[1] > 0.f ? dv[2 * h + 1] : 0.f};
           s1[h] = pk_add(s1[h], dz);
@@ -593,6 +632,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
 
 // pass 2 FUSED with the first layer's weight gradient.  dY0 is consumed in registers (dW0[co][tap] += dY0[p][co] *
 // x[p+tap]) and never written: the input image needs no data gradient, so nothing else reads dY0.
+template <typename TD = float>
 __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0, const BnBwdArgs a1,
                                                               const float* __restrict__ w0, const float* __restrict__ b0,
                                                               float* __restrict__ dw) {
@@ -631,7 +671,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
     float* const img = l0_rows + par * 3 * (W + 2);
     l0_stage_rows(img, xr, up, down, W);
     __syncthreads();
-    const float* drow = a.dout + (size_t)row * W * 64 + c0;
+    const TD* drow = reinterpret_cast<const TD*>(a.dout) + (size_t)row * W * 64 + c0;
     for (int ox0 = pl; ox0 < W; ox0 += 16 * L0_UNROLL_APPLY) {
       float4 d4[L0_UNROLL_APPLY];
       float xv[L0_UNROLL_APPLY][9];
@@ -640,7 +680,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
       for (int j = 0; j < L0_UNROLL_APPLY; ++j) {
         ok[j] = ox0 + 16 * j < W;
         const int ox = ok[j] ? ox0 + 16 * j : W - 1;  // clamped: the loads stay branch-free
-        d4[j] = *reinterpret_cast<const float4*>(drow + (size_t)ox * 64);
+        d4[j] = ld4<TD>(drow + (size_t)ox * 64);
         l0_taps_lds(img, ox, W, xv[j]);
       }
 #pragma unroll
@@ -651,7 +691,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
         xt.set(xv[j]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const f32x2 yv = cv.y2(h, xt);
+          f32x2 yv = cv.y2(h, xt);
+          if constexpr (sizeof(TD) == 2) {
+            const uint32_t pk = pack_bf16(yv[0], yv[1]);
+            yv = f32x2{bf16_lo(pk), bf16_hi(pk)};
+          }
           const f32x2 z = pk_fma(yv, sc2[h], sh2[h]);
           const f32x2 dz = {z[0] > 0.f ? dv[2 * h] : 0.f, z[1] > 0.f ? dv[2 * h + 1] : 0.f};
           const f32x2 xh = pk_fma(yv, is2[h], nm2[h]);

@@ -1,0 +1,424 @@
+// Direct (implicit-GEMM) 3x3 / 1x1 convolution on the bf16 matrix cores of gfx950 with bf16 NHWC activations in HBM
+// (BASELINE configs[3]: "bf16 compute / fp32 master"; conv algorithm 12).  v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+//
+//   conv_bf16_kernel   forward convolution and data-gradient convolution (= convolution with the flipped / transposed
+//                      weight image) of models/unet_parts.py:14-21 and the heads of models/SuperPointNet_gauss2*.py
+//
+// Operand roles: A = weights (M = 64 output channels of the block, two 32-row tiles), B = pixels (N = 32 pixels per tile:
+// two rows of 16 of the 16x16 output tile), K = 16 input channels of one tap per instruction.  A lane therefore holds ONE
+// pixel and 16 output channels per accumulator tile: the epilogue rounds channel pairs to bf16 in registers and writes
+// 8-byte items into a [pixel][64 channel] LDS tile, which leaves as 128 contiguous bytes per pixel.
+// The BatchNorm + ReLU of the PRODUCING layer is applied while the input halo is staged into LDS (raw bf16 y -> fp32 ->
+// fma, max -> bf16 operand), padding pixels are zero in the ACTIVATED domain.
+// Semantics (= oracle/cpu_ref.py, operand_dtype=torch.bfloat16): operands = bf16(activated input), bf16(weight); products
+// accumulated in fp32; the stored output is bf16(acc + bias); BatchNorm statistics are those of the STORED tensor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_mfma.hip.h"
+
+namespace sspk {
+
+constexpr int CB_T = 16;     // output tile: 16 x 16 pixels = 8 pixel tiles of 2 rows x 16 columns (2 per wave)
+constexpr int CB_KC = 32;    // input channels per LDS stage (two MFMA k-steps)
+constexpr int CB_PS = 80;    // bytes per halo pixel slot: 64 of data + 16 (20 dwords: 16 pixels with distinct slot index
+                             // modulo 16 cover the 64 banks once per ds_read_b128 lane group)
+constexpr int CB_NB = 64;    // output channels per work unit
+constexpr int CB_OS_BF16 = 144;  // bytes per pixel of the bf16 output tile in LDS (128 + 16)
+constexpr int CB_OS_F32 = 272;   // fp32 output half tile (256 + 16)
+
+template <int KS>
+struct ConvBGeom {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int HT = CB_T + KS - 1;             // halo rows / columns
+  static constexpr int H_BYTES = HT * HT * CB_PS;
+  static constexpr int W_BYTES = TAPS * 2 * 2 * 1024;  // [tap][k-step][m-tile][lane] x 16 bytes
+  static constexpr int O_BYTES = 256 * CB_OS_BF16;     // >= 128 * CB_OS_F32
+  static constexpr int STAGE_BYTES = H_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = (STAGE_BYTES > O_BYTES ? STAGE_BYTES : O_BYTES);
+};
+
+struct ConvBArgs {
+  const void* in[2];         // NHWC [N,H,W,in_cs], bf16 (or fp32: IN_F32) per view
+  const uint16_t* wpk;       // pack_weights_bf16_kernel: [cob][chunk32][tap][kstep][mtile][lane][8] bf16
+  const float* bias;         // [Cout] or nullptr
+  void* out[2];              // NHWC [N,H,W,out_cs], bf16 (or fp32: OUT_F32)
+  const float* in_scale[2];  // [Cin] BatchNorm affine of the producing layer (IN_MODE 1)
+  const float* in_shift[2];
+  double* stats[2];          // [NREP][2 Cout] sum, sum of squares of the stored output, or nullptr
+  uint16_t* pool_out[2];     // [N,H/2,W/2,Cout] raw pooled copy (per-channel max for gamma >= 0, min for gamma < 0) or nullptr
+  const float* pool_gamma;
+  int nviews, N, H, W;
+  int Cin, in_cs, in_co;
+  int Cout, out_cs, out_co;
+  int tiles_x, tiles_y, nchunks, ncob;
+  unsigned in_img_bytes;     // bytes of ONE input image (buffer descriptor range)
+};
+
+// lane (0..31) of a pixel tile -> (row 0..1, column 0..15).  With RS = halo row pitch (18 for 3x3, 16 for 1x1) the slot index
+// r * RS + c of the 16 lanes of each ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}) is distinct modulo 16.
+template <int RS>
+__device__ __forceinline__ void cb_lane_pixel(int j, int& r, int& c) {
+  int k;
+  if (j < 4) { r = 0; k = j; }
+  else if (j < 12) { r = 0; k = j + 4; }
+  else if (j < 16) { r = 0; k = j - 8; }
+  else if (j < 20) { r = 1; k = j - 16; }
+  else if (j < 28) { r = 1; k = j - 12; }
+  else { r = 1; k = j - 24; }
+  c = (k - (RS & 15) * r) & 15;
+}
+
+// IN_MODE 0: plain input; 1: BatchNorm + ReLU of the producing layer on load.  IN_F32 / OUT_F32: fp32 tensors at that end.
+template <int KS, int IN_MODE, bool IN_F32, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
+  using G = ConvBGeom<KS>;
+  constexpr int HT = G::HT, PAD = KS / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char* const sH = smem_b;
+  unsigned char* const sW = smem_b + G::H_BYTES;
+  unsigned char* const sO = smem_b;
+  float* const s_red = reinterpret_cast<float*>(smem_b);  // [256][17] of the statistics flush (between two units)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lj = lane & 31, lg = lane >> 5;
+
+  // ---- work assignment: contiguous unit range per XCD, blocks of an XCD interleaved ----
+  const int T = a.N * a.tiles_y * a.tiles_x;
+  const int U = a.nviews * a.ncob * T;
+  const int nslot = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per = (U + 7) >> 3;
+  const int u_end = min(U, (xcd + 1) * per);
+  int u = xcd * per + slot;
+  if (u >= u_end) return;
+
+  int pr, pc;
+  cb_lane_pixel<HT>(lj, pr, pc);
+  // byte offset of this lane's two pixels (tap (0,0)) in the halo image, + k-half
+  int boff[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) boff[nt] = ((4 * wave + 2 * nt + pr) * HT + pc) * CB_PS + lg * 16;
+  const int aoff = lane * 16;
+
+  // staging slots of this thread: halo slot = (tid >> 2) + 64 i, 16-byte part = tid & 3 (8 channels)
+  constexpr int NHS = (HT * HT * 4 + 255) / 256;
+  const int part = tid & 3;
+  int hs_lds[NHS];
+#pragma unroll
+  for (int i = 0; i < NHS; ++i) {
+    const int s = (tid >> 2) + 64 * i;
+    hs_lds[i] = s < HT * HT ? s * CB_PS + part * 16 : -1;
+  }
+  constexpr int NWS = G::W_BYTES / 16 / 256;  // weight items per thread (9 for 3x3, 1 for 1x1)
+
+  constexpr int CPT = OUT_F32 ? 4 : 8;   // output channels per copy-out item (16 bytes)
+  constexpr int TPP = CB_NB / CPT;       // threads per pixel
+  float st_s[CPT], st_q[CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) st_s[e] = st_q[e] = 0.f;
+  int st_key = -1;
+
+  auto flush_stats = [&](int key) {
+    // block reduction of the per-thread sums over the threads with the same channel item, then fp64 atomics
+    const int view = key / a.ncob, cob = key - view * a.ncob;
+    double* const p_stats = a.stats[view];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      s_red[tid * 17 + e] = st_s[e];
+      s_red[tid * 17 + 8 + e] = st_q[e];
+      st_s[e] = st_q[e] = 0.f;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid & 63, which = tid >> 6;   // channel of the block, 0 = sum / 1 = sum of squares
+      const int item = ch / CPT, e = ch - item * CPT;
+      double t = 0.0;
+      for (int k = item; k < 256; k += TPP) t += (double)s_red[k * 17 + which * 8 + e];
+      const int co = cob * CB_NB + ch;
+      if (co < a.Cout && p_stats != nullptr)
+        unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, t);
+    }
+  };
+
+  for (; u < u_end; u += nslot) {
+    const int vc = u / T, t = u - vc * T;
+    const int view = vc / a.ncob, cob = vc - view * a.ncob;
+    const int txi = t % a.tiles_x, t2 = t / a.tiles_x;
+    const int tyi = t2 % a.tiles_y, n = t2 / a.tiles_y;
+    const int ty0 = tyi * CB_T, tx0 = txi * CB_T;
+    if (a.stats[0] != nullptr && vc != st_key) {
+      if (st_key >= 0) flush_stats(st_key);
+      st_key = vc;
+    }
+    const unsigned char* const p_in = reinterpret_cast<const unsigned char*>(a.in[view]);
+    const float* const p_scale = a.in_scale[view];
+    const float* const p_shift = a.in_shift[view];
+    constexpr int IN_ES = IN_F32 ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(p_in) + (size_t)n * a.in_img_bytes, 0, a.in_img_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned hs_g[NHS];
+#pragma unroll
+    for (int i = 0; i < NHS; ++i) {
+      const int s = (tid >> 2) + 64 * i;
+      const int hy = s / HT, hx = s - hy * HT;
+      const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+      const bool ok = s < HT * HT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      hs_g[i] = ok ? (unsigned)(((gy * a.W + gx) * a.in_cs + a.in_co + part * 8) * IN_ES) : OOB;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+      // ---- stage the halo of 32 channels and the 64 x 32 x taps weight image ----
+      const int c0 = chunk * CB_KC + part * 8;
+      const bool cfull = c0 + 8 <= a.Cin;
+      u32x4 hv[NHS], hv2[NHS];
+#pragma unroll
+      for (int i = 0; i < NHS; ++i) {
+        const unsigned vo = c0 < a.Cin ? hs_g[i] : OOB;
+        hv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo, chunk * CB_KC * IN_ES, 0));
+        if (IN_F32) hv2[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo, chunk * CB_KC * IN_ES + 16, 0));
+      }
+      u32x4 wv[NWS];
+      {
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)(cob * a.nchunks + chunk) * (G::W_BYTES / 16);
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) wv[i] = wsrc[tid + 256 * i];
+      }
+      float sc[8], sh[8];
+      if (IN_MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = min(c0 + e, a.Cin - 1);
+          sc[e] = p_scale[c];
+          sh[e] = p_shift[c];
+        }
+      }
+      __syncthreads();  // every wave has finished reading the previous stage (or the output tile of the previous unit)
+#pragma unroll
+      for (int i = 0; i < NHS; ++i) {
+        if (hs_lds[i] < 0) continue;
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (hs_g[i] != OOB && c0 < a.Cin) {
+          float f[8];
+          if (IN_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              f[e] = u32_as_f32(hv[i][e]);
+              f[4 + e] = u32_as_f32(hv2[i][e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              f[2 * e] = bf16_lo(hv[i][e]);
+              f[2 * e + 1] = bf16_hi(hv[i][e]);
+            }
+          }
+          if (IN_MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+          }
+          if (!cfull) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e >= a.Cin) f[e] = 0.f;
+          }
+          if (IN_F32 || IN_MODE == 1 || !cfull) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
+          } else {
+            o = hv[i];
+          }
+        }
+        *reinterpret_cast<u32x4*>(sH + hs_lds[i]) = o;
+      }
+#pragma unroll
+      for (int i = 0; i < NWS; ++i) *reinterpret_cast<u32x4*>(sW + (tid + 256 * i) * 16) = wv[i];
+      __syncthreads();
+      // ---- MFMA: taps x 2 k-steps x (2 channel tiles x 2 pixel tiles) ----
+#pragma unroll
+      for (int tap = 0; tap < G::TAPS; ++tap) {
+        const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const s16x8 a0 = *reinterpret_cast<const s16x8*>(sW + aoff + ((tap * 2 + ks) * 2 + 0) * 1024);
+          const s16x8 a1 = *reinterpret_cast<const s16x8*>(sW + aoff + ((tap * 2 + ks) * 2 + 1) * 1024);
+          const s16x8 b0 = *reinterpret_cast<const s16x8*>(sH + boff[0] + (dy * HT + dx) * CB_PS + ks * 32);
+          const s16x8 b1 = *reinterpret_cast<const s16x8*>(sH + boff[1] + (dy * HT + dx) * CB_PS + ks * 32);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue: bias, rounding, [pixel][channel] tile through LDS, 16-byte stores, statistics of the stored values ----
+    f32x4 bias4[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = cob * CB_NB + mt * 32 + 8 * q + 4 * lg;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
+        }
+        bias4[mt][q] = b;
+      }
+    unsigned char* const p_out = reinterpret_cast<unsigned char*>(a.out[view]);
+    const bool do_stats = a.stats[0] != nullptr;
+    constexpr int NROUND = OUT_F32 ? 2 : 1;
+#pragma unroll
+    for (int round = 0; round < NROUND; ++round) {
+      __syncthreads();  // MFMA reads of the stage (round 0) / copy-out of the previous half (round 1) are done
+      if (!OUT_F32) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int lp = (4 * wave + 2 * nt + pr) * 16 + pc;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              u32x2 o;
+              o[0] = pack_bf16(acc[mt][nt][4 * q] + bias4[mt][q][0], acc[mt][nt][4 * q + 1] + bias4[mt][q][1]);
+              o[1] = pack_bf16(acc[mt][nt][4 * q + 2] + bias4[mt][q][2], acc[mt][nt][4 * q + 3] + bias4[mt][q][3]);
+              *reinterpret_cast<u32x2*>(sO + lp * CB_OS_BF16 + (mt * 32 + 8 * q + 4 * lg) * 2) = o;
+            }
+        }
+      } else {
+        const int lp = wave * 32 + lj;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (round == 0 ? acc[mt][0][4 * q + e] : acc[mt][1][4 * q + e]) + bias4[mt][q][e];
+            *reinterpret_cast<f32x4*>(sO + lp * CB_OS_F32 + (mt * 32 + 8 * q + 4 * lg) * 4) = o;
+          }
+      }
+      __syncthreads();
+      const int item = tid % TPP;                 // 16-byte item of the pixel's 64 channels
+      const int co0 = cob * CB_NB + item * CPT;
+      const int nvalid = min(CPT, a.Cout - co0);  // <= 0: none
+      constexpr int NPX = OUT_F32 ? 128 : 256;
+      constexpr int PSTEP = 256 / TPP;
+#pragma unroll 4
+      for (int k = 0; k < NPX / PSTEP; ++k) {
+        const int lp = tid / TPP + PSTEP * k;
+        int row, col;
+        if (!OUT_F32) { row = lp >> 4; col = lp & 15; }
+        else {
+          int rr, cc;
+          cb_lane_pixel<HT>(lp & 31, rr, cc);
+          row = 4 * (lp >> 5) + 2 * round + rr; col = cc;
+        }
+        const int oy = ty0 + row, ox = tx0 + col;
+        if (nvalid <= 0 || oy >= a.H || ox >= a.W) continue;
+        const size_t eo = ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co0;
+        if (!OUT_F32) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(sO + lp * CB_OS_BF16 + item * 16);
+          *reinterpret_cast<u32x4*>(p_out + eo * 2) = v;   // Cout % 8 == 0 (host-checked)
+          if (do_stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f0 = bf16_lo(v[e]), f1 = bf16_hi(v[e]);
+              st_s[2 * e] += f0; st_q[2 * e] = fmaf(f0, f0, st_q[2 * e]);
+              st_s[2 * e + 1] += f1; st_q[2 * e + 1] = fmaf(f1, f1, st_q[2 * e + 1]);
+            }
+          }
+        } else {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sO + lp * CB_OS_F32 + item * 16);
+          float* p = reinterpret_cast<float*>(p_out) + eo;
+          if (nvalid == 4) *reinterpret_cast<f32x4*>(p) = v;
+          else {
+            p[0] = v[0];
+            if (nvalid > 1) p[1] = v[1];
+            if (nvalid > 2) p[2] = v[2];
+          }
+          if (do_stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < nvalid) { st_s[e] += v[e]; st_q[e] = fmaf(v[e], v[e], st_q[e]); }
+          }
+        }
+      }
+      if (!OUT_F32 && a.pool_out[0] != nullptr && nvalid > 0) {
+        // raw 2x2-pooled copy: per-channel max (gamma >= 0) or min (gamma < 0) of the window, so that
+        // maxpool(relu(bn(y))) == relu(bn(pooled)) bit for bit (scale = gamma * invstd has the sign of gamma)
+        uint16_t* const p_pool = a.pool_out[view];
+        float gsign[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gsign[e] = a.pool_gamma[co0 + e];
+        const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pp = (tid >> 3) + 32 * k;   // pooled pixel of the 8 x 8 pooled tile
+          const int py = pp >> 3, px = pp & 7;
+          const int oy = (ty0 >> 1) + py, ox = (tx0 >> 1) + px;
+          if (oy >= Hp || ox >= Wp) continue;
+          const int lp = (2 * py) * 16 + 2 * px;
+          const u32x4 v0 = *reinterpret_cast<const u32x4*>(sO + lp * CB_OS_BF16 + item * 16);
+          const u32x4 v1 = *reinterpret_cast<const u32x4*>(sO + (lp + 1) * CB_OS_BF16 + item * 16);
+          const u32x4 v2 = *reinterpret_cast<const u32x4*>(sO + (lp + 16) * CB_OS_BF16 + item * 16);
+          const u32x4 v3 = *reinterpret_cast<const u32x4*>(sO + (lp + 17) * CB_OS_BF16 + item * 16);
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float l0 = bf16_lo(v0[e]), l1 = bf16_lo(v1[e]), l2 = bf16_lo(v2[e]), l3 = bf16_lo(v3[e]);
+            const float h0 = bf16_hi(v0[e]), h1 = bf16_hi(v1[e]), h2 = bf16_hi(v2[e]), h3 = bf16_hi(v3[e]);
+            const float lo = gsign[2 * e] >= 0.f ? fmaxf(fmaxf(l0, l1), fmaxf(l2, l3)) : fminf(fminf(l0, l1), fminf(l2, l3));
+            const float hi = gsign[2 * e + 1] >= 0.f ? fmaxf(fmaxf(h0, h1), fmaxf(h2, h3)) : fminf(fminf(h0, h1), fminf(h2, h3));
+            o[e] = (__builtin_bit_cast(uint32_t, lo) >> 16) | (__builtin_bit_cast(uint32_t, hi) & 0xffff0000u);
+          }
+          *reinterpret_cast<u32x4*>(p_pool + ((size_t)(n * Hp + oy) * Wp + ox) * a.Cout + co0) = o;
+        }
+      }
+    }
+  }
+  if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
+}
+
+// OIHW fp32 weights -> bf16 operand image of conv_bf16_kernel: [cob][chunk32][tap][kstep 2][mtile 2][lane 64][8]:
+// lane l holds output channel cob 64 + mtile 32 + (l & 31), input channels chunk 32 + kstep 16 + 8 (l >> 5) + e.
+// transpose_flip: the data-gradient convolution (conv input channels = Cout_w, output = Cin_w, taps mirrored).
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ dst, int Cout_w, int Cin_w, int KS,
+                                         int transpose_flip, int nchunks_total, int chunk_off, int ncob, int nchunks) {
+  const int taps = KS * KS;
+  const int per_chunk = taps * 2 * 2 * 64 * 8;
+  const long total = (long)ncob * nchunks * per_chunk;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  long t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int l = (int)(t & 63); t >>= 6;
+  const int mt = (int)(t & 1); t >>= 1;
+  const int ks = (int)(t & 1); t >>= 1;
+  const int tap = (int)(t % taps); t /= taps;
+  const int chunk = (int)(t % nchunks);
+  const int cob = (int)(t / nchunks);
+  const int co = cob * 64 + mt * 32 + (l & 31);
+  const int ci = chunk * 32 + ks * 16 + (l >> 5) * 8 + e;
+  const int ky = tap / KS, kx = tap % KS;
+  float v = 0.f;
+  if (!transpose_flip) {
+    if (co < Cout_w && ci < Cin_w) v = w[(((size_t)co * Cin_w + ci) * KS + ky) * KS + kx];
+  } else {
+    if (co < Cin_w && ci < Cout_w) v = w[(((size_t)ci * Cin_w + co) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)];
+  }
+  const uint32_t pk = pack_bf16(v, 0.f);
+  dst[((size_t)cob * nchunks_total + chunk + chunk_off) * per_chunk + (idx % per_chunk)] = (uint16_t)(pk & 0xffffu);
+}
+
+}  // namespace sspk

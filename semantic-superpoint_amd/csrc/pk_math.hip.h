@@ -2,6 +2,7 @@
 // kernels and the first-layer kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -60,6 +61,22 @@ __device__ __forceinline__ void mfma_results_guard() {
   asm volatile("s_nop 15\n\ts_nop 3");
   __builtin_amdgcn_sched_barrier(0);
 }
+
+// ---- bf16 <-> fp32 (the bf16 path, conv algorithm 12): two bf16 values per dword, element 0 in the low half ----
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// (NOT __builtin_bit_cast(float, v[e]) on a vector ELEMENT: hipcc / ROCm 7.2 reads element 0 for every e - pass the element
+// by value through these helpers)
+__device__ __forceinline__ float u32_as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {  // round to nearest even (v_cvt_pk_bf16_f32)
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float round_bf16(float v) { return bf16_lo(pack_bf16(v, 0.f)); }  // fp32 value of bf16(v)
 
 // x.lo (BCAST_HI = false) or x.hi (true) broadcast to both halves, times y, plus z: a scalar operand that lives in one
 // half of a register pair feeds two channels (the 1 -> 64 first-layer kernels: taps x channel pairs).

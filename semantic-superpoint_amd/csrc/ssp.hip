@@ -23,6 +23,8 @@
 #include "wgrad_wino4.hip.h"
 #include "wgrad_wino_fused.hip.h"
 #include "conv_wino_bf16.hip.h"
+#include "conv_bf16.hip.h"
+#include "wgrad_bf16.hip.h"
 #include "loss_kernels.hip.h"
 #include "dense_loss.hip.h"
 #include "pair_kernels.hip.h"
@@ -56,6 +58,10 @@ static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks
 // 11 = algorithm 1 with the Winograd F(3x3,4x4) weight gradient (wgrad_wino4_kernel: opt-in, measured not faster)
 static inline bool pipe_algo() { return g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10 || g_conv_algo == 11; }
 static inline bool bf16_algo() { return g_conv_algo == 3 || g_conv_algo == 7 || g_conv_algo == 8; }
+// 12 = the bf16 PATH (BASELINE configs[3]): bf16 NHWC activations / activation gradients in HBM, direct implicit-GEMM 3x3 convolutions,
+// data and weight gradients on v_mfma_f32_32x32x16_bf16 (conv_bf16.hip.h, wgrad_bf16.hip.h); fp32 master weights, BatchNorm
+// statistics, losses and Adam; the pointwise heads and everything behind them stay on the fp32 kernels
+static inline bool bf16_path() { return g_conv_algo == 12; }
 static inline int bf16_parts(bool backward) { return g_conv_algo == 7 || (g_conv_algo == 8 && !backward) ? 2 : 1; }
 static inline int pk_taps(int ks) { return ks == 3 ? W4C : ks * ks; }  // packed-weight capacity per (chunk, 16 ci, 64 co)
 static int fail(int code, const char* fmt, ...) {
@@ -1109,7 +1115,7 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
 }
 
 // pass 1 (sums) -> replica reduction + dgamma/dbeta -> pass 2 (apply); a[0 .. nviews-1] ride the same launches
-template <bool RELU, bool POOL>
+template <bool RELU, bool POOL, typename T = float>
 static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* dbeta, hipStream_t st,
                          bool sums_done = false, bool skip_apply = false) {
   // a.dbias (conv bias gradient, may be null) is produced by bn_bwd_sums_kernel
@@ -1120,10 +1126,10 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
   int nb = cdiv(npix, rows);
   if (nb > 1024) nb = 1024;
   if (!sums_done)  // else: pass 1 was accumulated by the data-gradient conv that produced dOut
-    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
+    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a0.C * 32, 256)), dim3(256), 0, st, a0, a1, nviews, dgamma, dbeta);
   if (!skip_apply)  // else: pass 2 rides the layer's weight gradient (wgrad_wino_fused_kernel)
-    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
+    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1143,6 +1149,8 @@ static int l0_resident_grid(K kern, const ssp_handle* h, int nviews, long rows, 
   const long g = std::max(1L, (long)per_cu * (h ? h->n_cu : 256) / std::max(1, nviews));
   return (int)std::min(rows, g);
 }
+
+#include "bf16_host.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -1348,6 +1356,13 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
         continue;
       }
     }
+    if (bf16_path() && d.ks == 3) {  // bf16 operand images of conv_bf16_kernel (forward; mirrored / transposed for the data gradient)
+      h->pk_w4_fwd[l] = h->pk_w4_bwd[l] = false;
+      CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_fwd + d.pk_fwd), d.cout, d.cin, 3, 0, 0, 0, st));
+      if (with_bwd && l < 8)
+        CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_bwd + d.pk_bwd), d.cout, d.cin, 3, 1, 0, 0, st));
+      continue;
+    }
     const bool wf = wino_ok(d.ks, d.cin), wb = wino_ok(d.ks, d.cout);
     {
       FwdAlgoScope fwd;
@@ -1361,7 +1376,11 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
   }
   h->packed_algo = g_conv_algo;
   h->packed_bwd = with_bwd;
-  if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
+  if (with_bwd && bf16_path()) {  // the same concatenation as a bf16 image: 8 chunks of 32 dY channels per head
+    const int heads[3] = {L_PA, L_DA, L_DS};
+    for (int k = 0; k < h->nheads; ++k)
+      CHK(launch_pack_bf16(P(h, h->L[heads[k]].w_off), reinterpret_cast<uint16_t*>(h->wpk_heads_bwd), 256, 128, 3, 1, 8 * h->nheads, 8 * k, st));
+  } else if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
     const int heads[3] = {L_PA, L_DA, L_DS};
     const bool wino = wino_ok(3, 256 * h->nheads);
     const int total = 2 * 16 * (wino ? WC : 9) * CK * NB;
@@ -1414,10 +1433,45 @@ struct SlotSet {
   Slot* s[2];
 };
 
+// bf16 path (conv algorithm 12): 3x3 layer l on conv_bf16_kernel.  Encoder outputs Y[l] (and the raw pooled copies Apool[l]) are
+// bf16 tensors in the slot's buffers; the 3x3 heads write fp32 (the pointwise heads behind them run the fp32 kernels).
+static int conv_layer_fwd_bf16(ssp_handle* h, const SlotSet& SS, int l, int src, int N, int H, int W, int in_mode, int train,
+                               hipStream_t st) {
+  const LayerDesc& d = h->L[l];
+  const bool pooled = in_mode == 2;  // input = raw pooled y of layer src (written by its conv), BatchNorm + ReLU on load
+  ConvBCall c;
+  c.nviews = SS.n; c.N = N; c.H = H; c.W = W; c.ks = 3; c.in_mode = 1;
+  c.in_cs = pooled ? d.cin : SS.s[0]->y_cs[src]; c.in_co = pooled ? 0 : SS.s[0]->y_co[src]; c.cin = d.cin;
+  c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_fwd + d.pk_fwd); c.bias = P(h, d.b_off);
+  c.out_cs = SS.s[0]->y_cs[l]; c.out_co = SS.s[0]->y_co[l]; c.cout = d.cout;
+  c.out_f32 = l >= 8;
+  const bool pool_out = l < 8 && SS.s[0]->Apool[l] != nullptr && d.bn;
+  for (int k = 0; k < SS.n; ++k) {
+    Slot& S = *SS.s[k];
+    if (pooled && !S.pool_raw[src]) return fail(-3, "bf16 path: layer %d has no raw pooled output", src);
+    c.in[k] = pooled ? S.Apool[src] : S.Y[src];
+    c.out[k] = S.Y[l];
+    c.in_scale[k] = S.bn[src].scale; c.in_shift[k] = S.bn[src].shift;
+    c.stats[k] = (d.bn && train) ? S.bn[l].stats : nullptr;
+    c.pool_out[k] = pool_out ? reinterpret_cast<uint16_t*>(S.Apool[l]) : nullptr;
+    if (l < 8) S.pool_raw[l] = pool_out;
+  }
+  if (pool_out) c.pool_gamma = P(h, d.g_off);
+  {
+    const double flops = 2.0 * SS.n * N * H * W * (double)d.cin * d.cout * 9;
+    const double bytes = 2.0 * SS.n * N * H * W * ((double)d.cin + d.cout);
+    ProfScope ps(h, SSP_PROF_CONV3X3_FWD, st, flops, bytes, flops, SSP_PROF_K_CONV_BF16);
+    CHK(launch_conv_bf16(c, h->n_cu, st));
+  }
+  if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));
+  return 0;
+}
+
 static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int N, int H, int W, int in_mode, int train,
                           hipStream_t st) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
+  if (bf16_path() && d.ks == 3) return conv_layer_fwd_bf16(h, SS, l, src, N, H, W, in_mode, train, st);
   FwdAlgoScope fwd_algo;
   const bool pooled = in_mode == 2;  // input = pooled output of layer src: raw pooled y (BatchNorm + ReLU on load, mode 1)
                                      // when its conv wrote it (pool_raw), else materialised maxpool(relu(bn(Y_src))) (mode 0)
@@ -1486,7 +1540,12 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   {
     const LayerDesc& d = h->L[0];
     Slot &S0 = *SS.s[0], &S1 = *SS.s[SS.n - 1];
-    hipLaunchKernelGGL(conv0_direct_kernel, dim3(l0_resident_grid(conv0_direct_kernel, h, SS.n, (long)N * H, W), SS.n), dim3(256), l0_lds_bytes(W), st, S0.x, S1.x, P(h, d.w_off),
+    if (bf16_path())
+      hipLaunchKernelGGL(conv0_direct_kernel<uint16_t>, dim3(l0_resident_grid(conv0_direct_kernel<uint16_t>, h, SS.n, (long)N * H, W), SS.n), dim3(256), l0_lds_bytes(W), st, S0.x, S1.x, P(h, d.w_off),
+                         P(h, d.b_off), reinterpret_cast<uint16_t*>(S0.Y[0]), reinterpret_cast<uint16_t*>(S1.Y[0]),
+                         train ? S0.bn[0].stats : nullptr, train ? S1.bn[0].stats : nullptr, N, H, W);
+    else
+    hipLaunchKernelGGL(conv0_direct_kernel<float>, dim3(l0_resident_grid(conv0_direct_kernel<float>, h, SS.n, (long)N * H, W), SS.n), dim3(256), l0_lds_bytes(W), st, S0.x, S1.x, P(h, d.w_off),
                        P(h, d.b_off), S0.Y[0], S1.Y[0], train ? S0.bn[0].stats : nullptr, train ? S1.bn[0].stats : nullptr,
                        N, H, W);
     HIPCHK(hipGetLastError());
@@ -1574,12 +1633,12 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
   if (l == 0) {
     // pass 1 (sums), then pass 2 fused with the first layer's weight gradient (dY0 is never materialised);
     // both passes recompute Y0 from the image instead of reading S.Y[0]
-    const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel, h, SS.n, (long)N * H, W);
-    const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel, h, SS.n, (long)N * H, W);
+    const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel<float>, h, SS.n, (long)N * H, W);
+    const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel<float>, h, SS.n, (long)N * H, W);
     if (!fused)  // else: S1 / S2 were accumulated by the data-gradient conv of layer 1 (setup_bnr)
-      hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
+      hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel<float>, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
-    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
+    hipLaunchKernelGGL(bn_bwd_apply_l0_kernel<float>, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                        Gd(h, d.w_off));
   } else if (relu && pool_after && have_pool && d.cout % 4 == 0 && d_cs == d.cout && d_co == 0) {
     // pass 1 from the pooled activation (1/4 of Y's bytes), pass 2 over Y
@@ -1701,6 +1760,71 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
   return 0;
 }
 
+// bf16 path (conv algorithm 12): encoder layers l_hi .. l_lo.  gP holds dOut of layer l_hi (bf16, grad wrt its (pooled) activation);
+// per layer: BatchNorm + ReLU (+ pool) backward in fp32 arithmetic on the bf16 tensors (sums, then apply: dY -> gQ, bf16), weight
+// gradient and data gradient on the bf16 matrix cores (-> gP, bf16).
+static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int l_lo, hipStream_t st) {
+  Slot& S0 = *SS.s[0];
+  const int N = S0.N, H = S0.H, W = S0.W;
+  for (int l = l_hi; l >= l_lo; --l) {
+    const LayerDesc& d = h->L[l];
+    int lh, lw; layer_res(l, H, W, lh, lw);
+    const bool pool_after = (l == 1 || l == 3 || l == 5);
+    const int C = d.cout;
+    BnBwdArgs a[2];
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      BnBwdArgs& v = a[k];
+      v.y = S.Y[l]; v.dout = S.gP; v.dy = S.gQ; v.scale = S.bn[l].scale; v.shift = S.bn[l].shift; v.mean = S.bn[l].mean;
+      v.invstd = S.bn[l].invstd; v.gamma = P(h, d.g_off); v.sums = S.bn[l].bsums; v.dbias = Gd(h, d.b_off);
+      v.x = S.x; v.apool = nullptr; v.beta = P(h, d.be_off); v.pool_fix = 0;
+      v.N = N; v.H = lh; v.W = lw; v.C = C; v.y_cs = C; v.y_co = 0; v.d_cs = C; v.d_co = 0; v.dy_cs = C; v.dy_co = 0;
+      v.count = (double)N * lh * lw; v.k12 = S.bn[l].k12;
+    }
+    float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
+    if (l == 0) {
+      const BnBwdArgs &a0 = a[0], &a1 = a[SS.n - 1];
+      const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel<uint16_t>, h, SS.n, (long)N * H, W);
+      const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel<uint16_t>, h, SS.n, (long)N * H, W);
+      hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel<uint16_t>, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
+      hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
+      hipLaunchKernelGGL(bn_bwd_apply_l0_kernel<uint16_t>, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
+                         Gd(h, d.w_off));
+      HIPCHK(hipGetLastError());
+      continue;
+    }
+    if (pool_after) CHK((launch_bn_bwd<true, true, uint16_t>(a, SS.n, dg, db, st)));
+    else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st)));
+    // weight gradient: X = (pooled) raw output of layer l - 1 under its BatchNorm + ReLU, dY = gQ
+    const int src = l - 1;
+    const bool pooled_in = layer_in_mode(l) == 2;
+    {
+      WgradBCall w;
+      w.nviews = SS.n; w.N = N; w.H = lh; w.W = lw; w.ks = 3; w.in_mode = 1;
+      w.x_cs = d.cin; w.x_co = 0; w.cin = d.cin; w.dy_cs = C; w.dy_co = 0; w.cout = C; w.dw = Gd(h, d.w_off);
+      for (int k = 0; k < SS.n; ++k) {
+        Slot& S = *SS.s[k];
+        if (pooled_in && !S.pool_raw[src]) return fail(-3, "bf16 path: layer %d has no raw pooled output", src);
+        w.x[k] = pooled_in ? S.Apool[src] : S.Y[src]; w.dy[k] = S.gQ; w.x_scale[k] = S.bn[src].scale; w.x_shift[k] = S.bn[src].shift;
+      }
+      const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
+      ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_WGRAD_BF16);
+      CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
+    }
+    {
+      ConvBCall c;
+      c.nviews = SS.n; c.N = N; c.H = lh; c.W = lw; c.ks = 3; c.in_mode = 0;
+      c.in_cs = C; c.in_co = 0; c.cin = C; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_bwd + d.pk_bwd);
+      c.out_cs = d.cin; c.out_co = 0; c.cout = d.cin;
+      for (int k = 0; k < SS.n; ++k) { c.in[k] = SS.s[k]->gQ; c.out[k] = SS.s[k]->gP; }
+      const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
+      ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_CONV_BF16);
+      CHK(launch_conv_bf16(c, h->n_cu, st));
+    }
+  }
+  return 0;
+}
+
 // dsemi[k]: [cells][80] grad wrt semi (post bnPb); draw_desc[k]: [cells][256] grad wrt bnDb output (pre-normalisation);
 // dsout[k]: [cells][sout_cs] grad wrt convSout output (ssmall).  A null entry means "no gradient from that head" and
 // must be null for every view of the set.
@@ -1723,6 +1847,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
   float *gP[2] = {nullptr, nullptr}, *gQ[2] = {nullptr, nullptr};
   for (int k = 0; k < SS.n; ++k) { gP[k] = SS.s[k]->gP; gQ[k] = SS.s[k]->gQ; }
   auto encoder = [&](int l_hi, int l_lo) -> int {  // dOut (gP) -> dY (gQ) -> weight gradient + data gradient (gP)
+    if (bf16_path()) return encoder_backward_bf16(h, SS, l_hi, l_lo, st);
     for (int l = l_hi; l >= l_lo; --l) {
       int lh, lw; layer_res(l, H, W, lh, lw);
       const bool pool_after = (l == 1 || l == 3 || l == 5);
@@ -1823,6 +1948,35 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     const int heads[3] = {L_PA, L_DA, L_DS};
     for (int hk = 0; hk < h->nheads; ++hk)
       CHK(bn_layer_backward(h, SS, heads[hk], gP, hcs, 256 * hk, true, false, gQ, hcs, 256 * hk, N, Hc, Wc, st));
+    if (bf16_path()) {
+      // bf16 path: the fp32 dY slices of the three heads (gQ) are rounded to bf16 on load by the bf16 kernels; the data
+      // gradient over the concatenated dY channels leaves as the bf16 tensor [cells][128] in gP
+      for (int hk = 0; hk < h->nheads; ++hk) {
+        const LayerDesc& d = h->L[heads[hk]];
+        WgradBCall w;
+        w.nviews = SS.n; w.N = N; w.H = Hc; w.W = Wc; w.ks = 3; w.in_mode = 1; w.dy_f32 = true;
+        w.x_cs = 128; w.x_co = 0; w.cin = 128; w.dy_cs = hcs; w.dy_co = 256 * hk; w.cout = 256; w.dw = Gd(h, d.w_off);
+        for (int k = 0; k < SS.n; ++k) {
+          Slot& S = *SS.s[k];
+          w.x[k] = S.Y[7]; w.dy[k] = gQ[k]; w.x_scale[k] = S.bn[7].scale; w.x_shift[k] = S.bn[7].shift;
+        }
+        const double flops = 2.0 * SS.n * N * Hc * Wc * 128.0 * 256 * 9;
+        ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * N * Hc * Wc * (128.0 + 512.0), flops, SSP_PROF_K_WGRAD_BF16);
+        CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
+      }
+      ConvBCall c;
+      c.nviews = SS.n; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.in_f32 = true;
+      c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_heads_bwd);
+      c.out_cs = 128; c.out_co = 0; c.cout = 128;
+      for (int k = 0; k < SS.n; ++k) { c.in[k] = gQ[k]; c.out[k] = gP[k]; }
+      {
+        const double flops = 2.0 * SS.n * N * Hc * Wc * (double)hcs * 128 * 9;
+        ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, SS.n * (double)N * Hc * Wc * (4.0 * hcs + 2.0 * 128), flops, SSP_PROF_K_CONV_BF16);
+        CHK(launch_conv_bf16(c, h->n_cu, st));
+      }
+      if (part == 1) return encoder(7, EARLY_SPLIT_LAYER);
+      return encoder(7, 0);
+    }
     for (int hk = 0; hk < h->nheads; ++hk) {
       const LayerDesc& d = h->L[heads[hk]];
       WgradCall w;
@@ -2133,7 +2287,7 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
-  if (algo < 0 || algo > 11 || algo == 4) return fail(-1, "conv algo must be 0..3 or 5..11 (see ssp_set_conv_algo)");
+  if (algo < 0 || algo > 12 || algo == 4) return fail(-1, "conv algo must be 0..3 or 5..12 (see ssp_set_conv_algo)");
   if (!SSP_LEGACY_ALGOS && (algo == 2 || algo == 5)) return fail(-1, "conv algo %d is compiled out (-DSSP_LEGACY_ALGOS=1)", algo);
   h->conv_algo = algo;
   return 0;
@@ -2580,8 +2734,8 @@ int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float
 
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
-  if (algo < 0 || algo > 11 || algo == 4)
-    return fail(-1, "conv algo must be 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
+  if (algo < 0 || algo > 12 || algo == 4)
+    return fail(-1, "conv algo must be 12 (the bf16 path: bf16 activations in HBM, direct bf16 matrix-core convolutions), 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "
                     "operands), 5 (Winograd, pipelined, weights staged through LDS), 6 (Winograd, two 4-wave workgroups per CU) "
                     ", 7 (Winograd, split-bf16 hi + lo operands), 8 (forward split-bf16, backward bf16), 9 (Winograd "
                     "F(2x2,3x3) only: algorithm 1 without F(4x4,3x3) on the large maps), 10 (F(4x4,3x3) wherever legal) or 11 (algorithm 1 "

@@ -22,7 +22,7 @@ SAMPLER_MAX_MATCHES = 8192  # SAMPLER_MAX_CELLS of csrc/sem_kernels.hip.h (biton
 PROF = {"none": 0, "conv3x3_fwd": 1, "conv3x3_dgrad": 2, "conv3x3_wgrad": 3, "conv_big_fwd": 4, "conv3x3_all": 5,
         "conv3x3_every": 6}
 PROF_KERNELS = ["conv_wino4_kernel", "conv_wino_pipe_kernel", "conv_wino_p2_kernel", "wgrad_wino_kernel", "wgrad_wino4_kernel",
-                "other"]  # SSP_PROF_K_*
+                "other", "conv_bf16_kernel", "wgrad_bf16_kernel"]  # SSP_PROF_K_*
 
 
 class SspConfig(C.Structure):
@@ -71,7 +71,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
-           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause"]
+           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16"]
 
 
 def load_library(path=None):
@@ -131,6 +131,8 @@ def load_library(path=None):
                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
+    lib.ssp_op_conv_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, vp, vp, C.c_size_t, vp]
+    lib.ssp_op_conv_wgrad_bf16.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.ssp_debug_conv_knobs.argtypes = [i, i]
     lib.ssp_debug_occupancy.argtypes = [i]
@@ -642,6 +644,45 @@ def op_conv(x_nhwc, w_oihw, bias, ksize, in_mode=0, in_scale=None, in_shift=None
                                _ptr(in_scale), _ptr(in_shift), _ptr(stats), int(transpose_flip), _ptr(ws), ws.numel(),
                                _stream()))
     return out
+
+
+def op_conv_bf16(x_nhwc, w_oihw, bias, ksize, in_mode=0, in_scale=None, in_shift=None, stats=None, transpose_flip=False,
+                 out_f32=False, pool_gamma=None):
+    """conv_bf16_kernel as an operator: x bf16 (or fp32) NHWC, fp32 OIHW weights -> bf16 (or fp32) NHWC output
+    (+ the raw pooled copy when pool_gamma is given)."""
+    lib = load_library()
+    _need_gpu(x_nhwc, "x")
+    N, H, W, cin = x_nhwc.shape
+    cout = w_oihw.shape[1] if transpose_flip else w_oihw.shape[0]
+    in_f32 = x_nhwc.dtype == torch.float32
+    if not in_f32 and x_nhwc.dtype != torch.bfloat16:
+        raise RuntimeError("x must be bfloat16 or float32")
+    out = torch.empty(N, H, W, cout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_nhwc.device)
+    pool = torch.empty(N, H // 2, W // 2, cout, dtype=torch.bfloat16, device=x_nhwc.device) if pool_gamma is not None else None
+    ws = torch.empty(((cout + 63) // 64) * ((cin + 31) // 32) * ksize * ksize * 4096, dtype=torch.uint8, device=x_nhwc.device)
+    with torch.cuda.device(x_nhwc.device):
+        _check(lib.ssp_op_conv_bf16(_ptr(x_nhwc), _ptr(w_oihw), _ptr(bias), _ptr(out), N, H, W, cin, cout, ksize, in_mode,
+                                    _ptr(in_scale), _ptr(in_shift), _ptr(stats), int(transpose_flip), int(in_f32), int(out_f32),
+                                    _ptr(pool), _ptr(pool_gamma), _ptr(ws), ws.numel(), _stream()))
+    return (out, pool) if pool_gamma is not None else out
+
+
+def op_conv_wgrad_bf16(x_nhwc, dy_nhwc, ksize, in_mode=0, in_scale=None, in_shift=None, dw=None):
+    """wgrad_bf16_kernel as an operator: x bf16 NHWC, dY bf16 (or fp32) NHWC -> fp32 OIHW gradient (accumulated into dw)."""
+    lib = load_library()
+    _need_gpu(x_nhwc, "x")
+    N, H, W, cin = x_nhwc.shape
+    cout = dy_nhwc.shape[3]
+    if x_nhwc.dtype != torch.bfloat16:
+        raise RuntimeError("x must be bfloat16")
+    dy_f32 = dy_nhwc.dtype == torch.float32
+    if dw is None:
+        dw = torch.zeros(cout, cin, ksize, ksize, dtype=torch.float32, device=x_nhwc.device)
+    ws = torch.empty(512 * ksize * ksize * 4096 * 4, dtype=torch.uint8, device=x_nhwc.device)
+    with torch.cuda.device(x_nhwc.device):
+        _check(lib.ssp_op_conv_wgrad_bf16(_ptr(x_nhwc), _ptr(dy_nhwc), _ptr(dw), N, H, W, cin, cout, ksize, in_mode,
+                                          _ptr(in_scale), _ptr(in_shift), int(dy_f32), _ptr(ws), ws.numel(), _stream()))
+    return dw
 
 
 def op_conv_wgrad(x_nhwc, dout_nhwc, ksize, in_mode=0, in_scale=None, in_shift=None):
