@@ -211,6 +211,11 @@ int ssp_op_conv_wgrad_bf16(const void* x_dev, const void* dy_dev, float* dw_oihw
                            int ksize, int in_mode, const float* in_scale_dev, const float* in_shift_dev, int dy_f32,
                            void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ssp_op_bn_bwd_strided on bf16 tensors (y, dout, dy: bf16 NHWC, channel stride cs; ReLU layers only). */
+int ssp_op_bn_bwd_bf16(const void* y_dev, const void* dout_dev, const float* gamma_dev, const float* stats4_dev, void* dy_dev,
+                       float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int h, int w, int c, int cs,
+                       int relu, int pool, void* stream);
+
 /* labels2Dto3D (utils/utils.py:408-440, add_dustbin=True) -> target [B,65,H/8,W/8] NCHW and getMasks
  * (Train_model_frontend_all.py:373-386) -> cellmask [B,H/8,W/8]; either pair of pointers may be NULL. */
 int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* target_dev, float* cellmask_dev, int b,
@@ -355,7 +360,8 @@ int ssp_debug_conv_knobs(int ablate, int grid);
  * (0 conv_wino_p2_kernel, 1 conv_wino_pipe_kernel, 2 wgrad_wino_kernel); negative = error */
 int ssp_debug_occupancy(int which);
 
-/* test hook: device pointer of an internal buffer ("gP","gQ","dsemi","ddesc","desc","dsout","Y<l>","scale<l>","shift<l>") */
+/* test hook: device pointer of an internal buffer ("gP","gQ","dsemi","ddesc","desc","dsout","Y<l>","A<l>" (pooled copy of layer l),
+ * "scale<l>","shift<l>","mean<l>","invstd<l>"); under the bf16 path Y<l> / A<l> of the 3x3 layers, gP and gQ hold bf16 elements */
 int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, size_t* nfloats);
 
 /* forward of batch_descriptor_loss_sparse (utils/loss_functions/sparse_loss.py:267-284) on NHWC descriptor

@@ -126,14 +126,120 @@ def _forced_pool(h, idx):
     return torch.gather(win, 4, idx.long().unsqueeze(-1)).squeeze(-1)
 
 
-def forward(sd, x, arch="SuperPointNet_gauss2", train=True, n_classes=133, return_x4=False, forced=None):
+# --------------------------------------------------------------------------------------
+# bf16 leg (BASELINE configs[3]: "bf16 compute / fp32 master").  The reference itself is fp32-only (models/unet_parts.py:14-21);
+# this restates the SAME network with the rounding points of the HIP bf16 path (conv algorithm 12, csrc/conv_bf16.hip.h),
+# everything else in fp32 or better:
+#   * matrix-core operands: bf16(activated input), bf16(weight); products exact, accumulation fp32 (here: torch's fp32 conv);
+#   * every 3x3 layer stores its raw output y as bf16; BatchNorm statistics are those of the STORED tensor; the affine is one
+#     fp32 fma per element, z = fma(y, scale, shift) with scale = gamma * invstd, shift = beta - mean * scale;
+#   * backward: the gradient wrt a stored activation (dOut) and wrt a raw conv output (dY) are bf16 tensors; BatchNorm backward
+#     runs in fp32 on them; weight gradients accumulate in fp32 into the fp32 master gradient;
+#   * the first layer (K = 9, fp32 vector arithmetic on the fp32 image) rounds only its stored output; the pointwise heads write
+#     fp32 logits / descriptors, their fp32 gradients are rounded to bf16 on load by the data- and weight-gradient convolutions.
+# --------------------------------------------------------------------------------------
+def _bf16(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _QuantBoth(torch.autograd.Function):  # a tensor that lives in HBM as bf16, and so does its gradient
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class _QuantFwd(torch.autograd.Function):  # rounded on the way in (weights; layer-0 output), gradient untouched
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _QuantBwd(torch.autograd.Function):  # fp32 tensor whose GRADIENT is rounded to bf16 by its consumers
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+def _bn_affine_fma(y, sd, bn, train):
+    """BatchNorm2d as the HIP path evaluates it (csrc/bn_kernels.hip.h bn_finalize_kernel + one fp32 fma per element): batch
+    statistics in fp64, invstd / scale / shift rounded to fp32, z = fma(y, scale, shift) (emulated exactly in fp64)."""
+    yd = y.double()
+    if train:
+        mean = yd.mean(dim=(0, 2, 3))
+        var = yd.var(dim=(0, 2, 3), unbiased=False)
+        n = y.numel() // y.shape[1]
+        with torch.no_grad():
+            rm, rv = sd[bn + ".running_mean"], sd[bn + ".running_var"]
+            rm.copy_((0.9 * rm.double() + 0.1 * mean).float())
+            rv.copy_((0.9 * rv.double() + 0.1 * var * (n / (n - 1) if n > 1 else 1.0)).float())
+            sd[bn + ".num_batches_tracked"] += 1
+    else:
+        mean, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
+    invstd = (var + 1e-5).rsqrt().float()
+    scale = sd[bn + ".weight"] * invstd
+    shift = sd[bn + ".bias"] - mean.float() * scale
+    z = yd * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    return z.float()
+
+
+def _forward_bf16(sd, x, arch, train, n_classes, return_x4):
+    t = layer_table(arch, n_classes)
+    op = x
+    for i, (conv, bn, cin, cout, k) in enumerate(t[:8]):
+        if i == 0:  # first layer: fp32 arithmetic on the fp32 image, stored as bf16
+            y = _QuantFwd.apply(F.conv2d(op, sd[conv + ".weight"], sd[conv + ".bias"], padding=1))
+        else:
+            y = _QuantBoth.apply(F.conv2d(op, _QuantFwd.apply(sd[conv + ".weight"]), sd[conv + ".bias"], padding=1))
+        a = F.relu(_bn_affine_fma(y, sd, bn, train))
+        if i in (1, 3, 5):  # the next layer sits behind MaxPool2d(2) (unet_parts.py:41-44)
+            a = F.max_pool2d(a, 2)
+        op = _QuantBoth.apply(a)
+    x4 = op
+
+    def head(c3, b3, c1, b1):
+        y = _QuantBoth.apply(F.conv2d(x4, _QuantFwd.apply(sd[c3 + ".weight"]), sd[c3 + ".bias"], padding=1))
+        a = _QuantBoth.apply(F.relu(_bn_affine_fma(y, sd, b3, train)))
+        o = _QuantBwd.apply(F.conv2d(a, _QuantFwd.apply(sd[c1 + ".weight"]), sd[c1 + ".bias"]))
+        return _bn_affine_fma(o, sd, b1, train) if b1 is not None else o
+
+    semi = head("convPa", "bnPa", "convPb", "bnPb")
+    desc = head("convDa", "bnDa", "convDb", "bnDb")
+    out = {}
+    if arch.endswith("ssmall"):
+        out["sem"] = F.interpolate(head("convDS", "bnS1", "convSout", None), x.shape[2:], mode="bilinear", align_corners=False)
+    dn = torch.norm(desc, p=2, dim=1)
+    out["semi"] = semi
+    out["desc"] = desc.div(dn.unsqueeze(1))
+    if return_x4:
+        out["x4"] = x4
+    return out
+
+
+def forward(sd, x, arch="SuperPointNet_gauss2", train=True, n_classes=133, return_x4=False, forced=None, operand_dtype=None):
     """x [N,1,H,W] -> {"semi","desc"[,"sem"]}.  `sd` is a dict of torch tensors; BN running
     statistics are updated in place when train=True (module default; the reference never calls
     .eval() while training: SURVEY.md section 7 'Hard parts').
     forced (test hook, not reference behaviour): {"relu": {conv name: 0/1 gate [N,C,H,W]}, "pool": {layer index:
     winner index [N,C,H/2,W/2]}} replaces the data-dependent ReLU gates and max-pool winners by the given ones, which
     makes the network a smooth function of its parameters: used to show that the end-to-end gradient differences
-    between the HIP path and the oracle come from gate flips of activations within rounding distance of 0 only."""
+    between the HIP path and the oracle come from gate flips of activations within rounding distance of 0 only.
+    operand_dtype=torch.bfloat16: the bf16 leg above (not reference behaviour: the reference is fp32-only)."""
+    if operand_dtype is not None:
+        if operand_dtype != torch.bfloat16 or forced is not None:
+            raise ValueError("operand_dtype must be None or torch.bfloat16 (without forced gates)")
+        return _forward_bf16(sd, x, arch, train, n_classes, return_x4)
     t = layer_table(arch, n_classes)
     h = x
     for i, (conv, bn, cin, cout, k) in enumerate(t[:8]):
@@ -322,13 +428,13 @@ def multi_task_loss(eta, det, pos, neg, sem=None):
 # --------------------------------------------------------------------------------------
 def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lambda_loss=1.0, lamda_d=1.0,
                 multi_task=True, gaussian=True, n_match=1000, n_non=100, np_rng=np.random, torch_gen=None,
-                train=True, dense=None, forced=None):
+                train=True, dense=None, forced=None, operand_dtype=None):
     """Forward of both views + all losses.  Returns (loss, scalars dict, aux dict).
     dense: None (sparse descriptor loss) or the dict of model.dense_loss.params (Train_model_heatmap_all.py:131-137)."""
     semantic = arch.endswith("ssmall")
-    out = forward(sd, sample["image"], arch, train=train, forced=None if forced is None else forced[0])
+    out = forward(sd, sample["image"], arch, train=train, forced=None if forced is None else forced[0], operand_dtype=operand_dtype)
     out_w = forward(sd, sample["warped_img"], arch, train=train,  # separate BN statistics (:258,262)
-                    forced=None if forced is None else forced[1])
+                    forced=None if forced is None else forced[1], operand_dtype=operand_dtype)
     lab = sample["labels_2D_gaussian"] if gaussian else sample["labels_2D"]
     lab_w = sample["warped_labels_gaussian"] if gaussian else sample["warped_labels"]
     l3 = labels2Dto3D(lab).float()

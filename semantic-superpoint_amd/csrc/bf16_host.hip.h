@@ -56,8 +56,7 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   nblocks = std::max(nblocks, 8);
 #define CONVB_CASE(KS_, M_, I_, O_) \
   if (c.ks == KS_ && c.in_mode == M_ && c.in_f32 == I_ && c.out_f32 == O_) return launch_conv_bf16_t<KS_, M_, I_, O_>(a, nblocks, st);
-  CONVB_CASE(3, 1, false, false) CONVB_CASE(3, 1, false, true) CONVB_CASE(3, 0, false, false) CONVB_CASE(3, 0, true, false)
-  CONVB_CASE(1, 1, false, true) CONVB_CASE(1, 0, true, false)
+  CONVB_CASE(3, 1, false, false) CONVB_CASE(3, 0, false, false) CONVB_CASE(1, 1, false, true) CONVB_CASE(1, 0, true, false)
 #undef CONVB_CASE
   return fail(-3, "bf16 conv: unsupported variant ks=%d in_mode=%d in_f32=%d out_f32=%d", c.ks, c.in_mode, (int)c.in_f32, (int)c.out_f32);
 }
@@ -117,7 +116,7 @@ static int launch_wgrad_bf16(const WgradBCall& c, float* partial, size_t partial
   const int nblocks = pairs * (int)nsplit;
 #define WGB_CASE(KS_, M_, F_) \
   if (c.ks == KS_ && c.in_mode == M_ && c.dy_f32 == F_) { CHK((launch_wgrad_bf16_t<KS_, M_, F_>(a, nblocks, st))); } else
-  WGB_CASE(3, 1, false) WGB_CASE(3, 0, false) WGB_CASE(3, 1, true) WGB_CASE(1, 1, true)
+  WGB_CASE(3, 1, false) WGB_CASE(3, 0, false) WGB_CASE(1, 1, true)
   return fail(-3, "bf16 wgrad: unsupported variant ks=%d in_mode=%d dy_f32=%d", c.ks, c.in_mode, (int)c.dy_f32);
 #undef WGB_CASE
   const int total = c.cout * c.cin * taps;

@@ -1344,7 +1344,7 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     int lh = H / 8, lw = W / 8;
     if (l < 8) layer_res(l, H, W, lh, lw);
     h->pk_g1[l] = false;
-    if (d.ks == 1 && g1_enabled() && G.n + 2 <= G1_PACK_MAX_JOBS) {
+    if (d.ks == 1 && !bf16_path() && g1_enabled() && G.n + 2 <= G1_PACK_MAX_JOBS) {
       const long npx = (long)N * lh * lw;
       const Slot& S0 = h->slot[0];
       const int src = l - 1, hcs = 256 * h->nheads;  // Pb <- Pa, Db <- Da, Sout <- DS: the layer before it in the table
@@ -1356,11 +1356,11 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
         continue;
       }
     }
-    if (bf16_path() && d.ks == 3) {  // bf16 operand images of conv_bf16_kernel (forward; mirrored / transposed for the data gradient)
-      h->pk_w4_fwd[l] = h->pk_w4_bwd[l] = false;
-      CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_fwd + d.pk_fwd), d.cout, d.cin, 3, 0, 0, 0, st));
-      if (with_bwd && l < 8)
-        CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_bwd + d.pk_bwd), d.cout, d.cin, 3, 1, 0, 0, st));
+    if (bf16_path()) {  // bf16 operand images of conv_bf16_kernel (forward; mirrored / transposed for the data gradient)
+      h->pk_w4_fwd[l] = h->pk_w4_bwd[l] = false; h->pk_g1[l] = false;
+      CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_fwd + d.pk_fwd), d.cout, d.cin, d.ks, 0, 0, 0, st));
+      if (with_bwd && (l < 8 || d.ks == 1))  // (the 3x3 heads share ONE concatenated data-gradient image, below)
+        CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_bwd + d.pk_bwd), d.cout, d.cin, d.ks, 1, 0, 0, st));
       continue;
     }
     const bool wf = wino_ok(d.ks, d.cin), wb = wino_ok(d.ks, d.cout);
@@ -1433,18 +1433,19 @@ struct SlotSet {
   Slot* s[2];
 };
 
-// bf16 path (conv algorithm 12): 3x3 layer l on conv_bf16_kernel.  Encoder outputs Y[l] (and the raw pooled copies Apool[l]) are
-// bf16 tensors in the slot's buffers; the 3x3 heads write fp32 (the pointwise heads behind them run the fp32 kernels).
+// bf16 path (conv algorithm 12): layer l on conv_bf16_kernel.  Every 3x3 layer writes a bf16 tensor (encoder: Y[l] and the raw
+// pooled copy Apool[l]; heads: a slice of the [cells][256 heads] tensor) in the slot's buffers; the pointwise heads read those
+// under BatchNorm + ReLU and write the fp32 logits / descriptors the loss kernels take.
 static int conv_layer_fwd_bf16(ssp_handle* h, const SlotSet& SS, int l, int src, int N, int H, int W, int in_mode, int train,
                                hipStream_t st) {
   const LayerDesc& d = h->L[l];
   const bool pooled = in_mode == 2;  // input = raw pooled y of layer src (written by its conv), BatchNorm + ReLU on load
   ConvBCall c;
-  c.nviews = SS.n; c.N = N; c.H = H; c.W = W; c.ks = 3; c.in_mode = 1;
+  c.nviews = SS.n; c.N = N; c.H = H; c.W = W; c.ks = d.ks; c.in_mode = 1;
   c.in_cs = pooled ? d.cin : SS.s[0]->y_cs[src]; c.in_co = pooled ? 0 : SS.s[0]->y_co[src]; c.cin = d.cin;
   c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_fwd + d.pk_fwd); c.bias = P(h, d.b_off);
   c.out_cs = SS.s[0]->y_cs[l]; c.out_co = SS.s[0]->y_co[l]; c.cout = d.cout;
-  c.out_f32 = l >= 8;
+  c.out_f32 = d.ks == 1;
   const bool pool_out = l < 8 && SS.s[0]->Apool[l] != nullptr && d.bn;
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
@@ -1458,9 +1459,9 @@ static int conv_layer_fwd_bf16(ssp_handle* h, const SlotSet& SS, int l, int src,
   }
   if (pool_out) c.pool_gamma = P(h, d.g_off);
   {
-    const double flops = 2.0 * SS.n * N * H * W * (double)d.cin * d.cout * 9;
-    const double bytes = 2.0 * SS.n * N * H * W * ((double)d.cin + d.cout);
-    ProfScope ps(h, SSP_PROF_CONV3X3_FWD, st, flops, bytes, flops, SSP_PROF_K_CONV_BF16);
+    const double flops = 2.0 * SS.n * N * H * W * (double)d.cin * d.cout * d.ks * d.ks;
+    const double bytes = SS.n * (double)N * H * W * (2.0 * d.cin + (c.out_f32 ? 4.0 : 2.0) * d.cout);
+    ProfScope ps(h, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : -1, st, flops, bytes, flops, SSP_PROF_K_CONV_BF16);
     CHK(launch_conv_bf16(c, h->n_cu, st));
   }
   if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));
@@ -1471,7 +1472,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
                           hipStream_t st) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
-  if (bf16_path() && d.ks == 3) return conv_layer_fwd_bf16(h, SS, l, src, N, H, W, in_mode, train, st);
+  if (bf16_path()) return conv_layer_fwd_bf16(h, SS, l, src, N, H, W, in_mode, train, st);
   FwdAlgoScope fwd_algo;
   const bool pooled = in_mode == 2;  // input = pooled output of layer src: raw pooled y (BatchNorm + ReLU on load, mode 1)
                                      // when its conv wrote it (pool_raw), else materialised maxpool(relu(bn(Y_src))) (mode 0)
@@ -1825,6 +1826,92 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
   return 0;
 }
 
+// bf16 path: backward of the heads.  fp32 BatchNorm backward of Pb / Db (their outputs feed the fp32 losses), pointwise weight and
+// data gradients with the fp32 dY rounded to bf16 on load (-> gP = bf16 gradient wrt the activations of the 3x3 heads,
+// [cells][256 heads]), BatchNorm + ReLU backward of Pa / Da / DS on the bf16 tensors (-> gQ), their weight gradients and ONE data
+// gradient over the concatenated dY channels (-> gP = bf16 [cells][128], gradient wrt the activation of encoder layer 7).
+static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
+                               float* const* dsout, hipStream_t st) {
+  Slot& S0 = *SS.s[0];
+  const int N = S0.N, Hc = S0.H / 8, Wc = S0.W / 8, hcs = 256 * h->nheads;
+  const size_t ncells = (size_t)N * Hc * Wc;
+  const bool has_semi = dsemi[0] != nullptr, has_desc = draw_desc[0] != nullptr, has_sem = dsout[0] != nullptr && h->nheads == 3;
+  float *gQs[2] = {nullptr, nullptr}, *gQd[2] = {nullptr, nullptr};
+  for (int k = 0; k < SS.n; ++k) { gQs[k] = SS.s[k]->gQ; gQd[k] = SS.s[k]->gQ + ncells * 80; }
+  auto pointwise = [&](int l, int src, const float* const* dy, int dy_cs, int co) -> int {
+    const LayerDesc& d = h->L[l];
+    WgradBCall w;
+    w.nviews = SS.n; w.N = N; w.H = Hc; w.W = Wc; w.ks = 1; w.in_mode = 1; w.dy_f32 = true;
+    w.x_cs = hcs; w.x_co = co; w.cin = 256; w.dy_cs = dy_cs; w.dy_co = 0; w.cout = d.cout; w.dw = Gd(h, d.w_off);
+    ConvBCall c;
+    c.nviews = SS.n; c.N = N; c.H = Hc; c.W = Wc; c.ks = 1; c.in_mode = 0; c.in_f32 = true;
+    c.in_cs = dy_cs; c.in_co = 0; c.cin = d.cout; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_bwd + d.pk_bwd);
+    c.out_cs = hcs; c.out_co = co; c.cout = 256;
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      w.x[k] = S.Y[src]; w.dy[k] = dy[k]; w.x_scale[k] = S.bn[src].scale; w.x_shift[k] = S.bn[src].shift;
+      c.in[k] = dy[k]; c.out[k] = S.gP;
+    }
+    CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
+    return launch_conv_bf16(c, h->n_cu, st);
+  };
+  if (has_semi) {
+    CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQs, 80, 0, N, Hc, Wc, st));
+    CHK(pointwise(L_PB, L_PA, gQs, 80, 0));
+  }
+  if (has_desc) {
+    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st));
+    CHK(pointwise(L_DB, L_DA, gQd, 256, 256));
+  }
+  if (has_sem) {
+    const LayerDesc& d = h->L[L_SOUT];
+    if (h->sout_cs > 256) return fail(-3, "segmentation head: more than 256 classes are not supported by colsum_kernel");
+    for (int k = 0; k < SS.n; ++k)
+      hipLaunchKernelGGL(colsum_kernel, dim3(cdiv((long)ncells, COLSUM_ROWS)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), (int)ncells, d.cout,
+                         h->sout_cs);
+    HIPCHK(hipGetLastError());
+    CHK(pointwise(L_SOUT, L_DS, dsout, h->sout_cs, 512));
+  }
+  // ---- 3x3 heads ----
+  const int heads[3] = {L_PA, L_DA, L_DS};
+  for (int hk = 0; hk < h->nheads; ++hk) {
+    const LayerDesc& d = h->L[heads[hk]];
+    BnBwdArgs a[2];
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      BnBwdArgs& v = a[k];
+      const int l = heads[hk];
+      v.y = S.Y[l]; v.dout = S.gP; v.dy = S.gQ; v.scale = S.bn[l].scale; v.shift = S.bn[l].shift; v.mean = S.bn[l].mean;
+      v.invstd = S.bn[l].invstd; v.gamma = P(h, d.g_off); v.sums = S.bn[l].bsums; v.dbias = Gd(h, d.b_off);
+      v.x = nullptr; v.apool = nullptr; v.beta = P(h, d.be_off); v.pool_fix = 0;
+      v.N = N; v.H = Hc; v.W = Wc; v.C = 256; v.y_cs = hcs; v.y_co = 256 * hk; v.d_cs = hcs; v.d_co = 256 * hk;
+      v.dy_cs = hcs; v.dy_co = 256 * hk; v.count = (double)ncells; v.k12 = S.bn[l].k12;
+    }
+    CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, Gd(h, d.g_off), Gd(h, d.be_off), st)));
+  }
+  for (int hk = 0; hk < h->nheads; ++hk) {
+    const LayerDesc& d = h->L[heads[hk]];
+    WgradBCall w;
+    w.nviews = SS.n; w.N = N; w.H = Hc; w.W = Wc; w.ks = 3; w.in_mode = 1;
+    w.x_cs = 128; w.x_co = 0; w.cin = 128; w.dy_cs = hcs; w.dy_co = 256 * hk; w.cout = 256; w.dw = Gd(h, d.w_off);
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      w.x[k] = S.Y[7]; w.dy[k] = S.gQ; w.x_scale[k] = S.bn[7].scale; w.x_shift[k] = S.bn[7].shift;
+    }
+    const double flops = 2.0 * SS.n * ncells * 128.0 * 256 * 9;
+    ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * ncells * (128.0 + 256.0), flops, SSP_PROF_K_WGRAD_BF16);
+    CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
+  }
+  ConvBCall c;
+  c.nviews = SS.n; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0;
+  c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_heads_bwd);
+  c.out_cs = 128; c.out_co = 0; c.cout = 128;
+  for (int k = 0; k < SS.n; ++k) { c.in[k] = SS.s[k]->gQ; c.out[k] = SS.s[k]->gP; }
+  const double flops = 2.0 * SS.n * ncells * (double)hcs * 128 * 9;
+  ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, 2.0 * SS.n * ncells * (hcs + 128.0), flops, SSP_PROF_K_CONV_BF16);
+  return launch_conv_bf16(c, h->n_cu, st);
+}
+
 // dsemi[k]: [cells][80] grad wrt semi (post bnPb); draw_desc[k]: [cells][256] grad wrt bnDb output (pre-normalisation);
 // dsout[k]: [cells][sout_cs] grad wrt convSout output (ssmall).  A null entry means "no gradient from that head" and
 // must be null for every view of the set.
@@ -1870,6 +1957,11 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     S.bsums_dirty = true;
     if (!has_semi || !has_desc || (h->nheads == 3 && !has_sem))
       CHK(dev_zero(S.gP, (size_t)N * Hc * Wc * hcs * sizeof(float), st));
+  }
+  if (bf16_path()) {
+    CHK(heads_backward_bf16(h, SS, dsemi, draw_desc, dsout, st));
+    if (part == 1) return encoder(7, EARLY_SPLIT_LAYER);
+    return encoder(7, 0);
   }
   // ---- 1x1 heads: Pb, Db (BN, no ReLU) and Sout (bias only); gP = dHeadsAct [cells][hcs], gQ = dY scratch ----
   float* dact[2] = {gP[0], gP[1]};
@@ -1948,35 +2040,6 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     const int heads[3] = {L_PA, L_DA, L_DS};
     for (int hk = 0; hk < h->nheads; ++hk)
       CHK(bn_layer_backward(h, SS, heads[hk], gP, hcs, 256 * hk, true, false, gQ, hcs, 256 * hk, N, Hc, Wc, st));
-    if (bf16_path()) {
-      // bf16 path: the fp32 dY slices of the three heads (gQ) are rounded to bf16 on load by the bf16 kernels; the data
-      // gradient over the concatenated dY channels leaves as the bf16 tensor [cells][128] in gP
-      for (int hk = 0; hk < h->nheads; ++hk) {
-        const LayerDesc& d = h->L[heads[hk]];
-        WgradBCall w;
-        w.nviews = SS.n; w.N = N; w.H = Hc; w.W = Wc; w.ks = 3; w.in_mode = 1; w.dy_f32 = true;
-        w.x_cs = 128; w.x_co = 0; w.cin = 128; w.dy_cs = hcs; w.dy_co = 256 * hk; w.cout = 256; w.dw = Gd(h, d.w_off);
-        for (int k = 0; k < SS.n; ++k) {
-          Slot& S = *SS.s[k];
-          w.x[k] = S.Y[7]; w.dy[k] = gQ[k]; w.x_scale[k] = S.bn[7].scale; w.x_shift[k] = S.bn[7].shift;
-        }
-        const double flops = 2.0 * SS.n * N * Hc * Wc * 128.0 * 256 * 9;
-        ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * N * Hc * Wc * (128.0 + 512.0), flops, SSP_PROF_K_WGRAD_BF16);
-        CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
-      }
-      ConvBCall c;
-      c.nviews = SS.n; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0; c.in_f32 = true;
-      c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_heads_bwd);
-      c.out_cs = 128; c.out_co = 0; c.cout = 128;
-      for (int k = 0; k < SS.n; ++k) { c.in[k] = gQ[k]; c.out[k] = gP[k]; }
-      {
-        const double flops = 2.0 * SS.n * N * Hc * Wc * (double)hcs * 128 * 9;
-        ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, SS.n * (double)N * Hc * Wc * (4.0 * hcs + 2.0 * 128), flops, SSP_PROF_K_CONV_BF16);
-        CHK(launch_conv_bf16(c, h->n_cu, st));
-      }
-      if (part == 1) return encoder(7, EARLY_SPLIT_LAYER);
-      return encoder(7, 0);
-    }
     for (int hk = 0; hk < h->nheads; ++hk) {
       const LayerDesc& d = h->L[heads[hk]];
       WgradCall w;
@@ -2732,6 +2795,28 @@ int ssp_op_bn_bwd_strided(const float* y_dev, const float* dout_dev, const float
   return 0;
 }
 
+// the same operator on bf16 tensors (the bf16 path: y, dout, dy are bf16 NHWC with channel stride cs; fp32 arithmetic and parameters)
+int ssp_op_bn_bwd_bf16(const void* y_dev, const void* dout_dev, const float* gamma_dev, const float* stats4_dev, void* dy_dev,
+                       float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int hh, int w, int c, int cs,
+                       int relu, int pool, void* stream) {
+  if (cs < c || (cs & 3)) return fail(-1, "ssp_op_bn_bwd_bf16: the channel stride must be a multiple of 4 and >= C");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(sums_dev, 0, 2 * (size_t)c * NREP * sizeof(double), st));
+  BnBwdArgs a;
+  a.y = reinterpret_cast<const float*>(y_dev); a.dout = reinterpret_cast<const float*>(dout_dev); a.dy = reinterpret_cast<float*>(dy_dev);
+  a.scale = stats4_dev; a.shift = stats4_dev + c; a.mean = stats4_dev + 2 * c;
+  a.invstd = stats4_dev + 3 * c; a.gamma = gamma_dev; a.sums = sums_dev; a.dbias = dbias_dev; a.N = n; a.H = hh; a.W = w;
+  a.C = c; a.y_cs = cs; a.y_co = 0; a.d_cs = cs; a.d_co = 0; a.dy_cs = cs; a.dy_co = 0; a.count = (double)n * hh * w;
+  float* k12 = nullptr;
+  HIPCHK(hipMallocAsync((void**)&k12, 2 * c * sizeof(float), st));
+  a.k12 = k12; a.x = nullptr; a.apool = nullptr; a.beta = nullptr; a.pool_fix = 0;
+  if (relu && pool) CHK((launch_bn_bwd<true, true, uint16_t>(&a, 1, dgamma_dev, dbeta_dev, st)));
+  else if (relu) CHK((launch_bn_bwd<true, false, uint16_t>(&a, 1, dgamma_dev, dbeta_dev, st)));
+  else return fail(-3, "ssp_op_bn_bwd_bf16: only the ReLU layers run on bf16 tensors");
+  HIPCHK(hipFreeAsync(k12, st));
+  return 0;
+}
+
 // perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
   if (algo < 0 || algo > 12 || algo == 4)
@@ -2786,6 +2871,7 @@ int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, siz
   else if (n == "desc") { p = S.desc; cnt = cells * 256; }
   else if (n == "dsout") { p = S.dsout; cnt = cells * h->sout_cs; }
   else if (n[0] == 'Y') { int l = atoi(name + 1); if (l < 0 || l >= h->nlayers) return fail(-1, "bad layer"); p = S.Y[l]; cnt = 0; }
+  else if (n[0] == 'A') { int l = atoi(name + 1); if (l < 0 || l >= 8 || !S.Apool[l]) return fail(-1, "no pooled copy of that layer"); p = S.Apool[l]; cnt = 0; }
   else if (n.rfind("scale", 0) == 0) { int l = atoi(name + 5); p = S.bn[l].scale; cnt = h->L[l].cout; }
   else if (n.rfind("shift", 0) == 0) { int l = atoi(name + 5); p = S.bn[l].shift; cnt = h->L[l].cout; }
   else if (n.rfind("mean", 0) == 0) { int l = atoi(name + 4); p = S.bn[l].mean; cnt = h->L[l].cout; }

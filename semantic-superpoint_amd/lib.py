@@ -71,7 +71,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
-           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16"]
+           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16", "ssp_op_bn_bwd_bf16"]
 
 
 def load_library(path=None):
@@ -142,6 +142,7 @@ def load_library(path=None):
     lib.ssp_op_warp_labels.argtypes = [vp, vp, vp, i, i, i, vp]
     lib.ssp_op_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
     lib.ssp_op_bn_bwd_strided.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
+    lib.ssp_op_bn_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
     ep = C.POINTER(SspExportParams)
@@ -548,15 +549,17 @@ class Engine:
             _check(self.lib.ssp_detector_heatmap(self.h, slot, _ptr(out), _stream()))
         return out
 
-    def debug_buffer(self, slot, name, shape):
-        """Test hook: copy of an internal NHWC buffer as a torch tensor of `shape`."""
+    def debug_buffer(self, slot, name, shape, dtype=torch.float32):
+        """Test hook: copy of an internal NHWC buffer as a torch tensor of `shape` (dtype bfloat16 for the activation /
+        gradient tensors of the bf16 path)."""
         p, n = C.c_void_p(), C.c_size_t()
         _check(self.lib.ssp_debug_buffer(self.h, slot, name.encode(), C.byref(p), C.byref(n)))
         numel = int(np.prod(shape))
+        es = 2 if dtype == torch.bfloat16 else 4
         base = self.workspace.data_ptr()
         off = p.value - base
-        assert 0 <= off and off + numel * 4 <= self.ws_bytes
-        return self.workspace[off:off + numel * 4].view(torch.float32).view(*shape).clone()
+        assert 0 <= off and off + numel * es <= self.ws_bytes
+        return self.workspace[off:off + numel * es].view(dtype).view(*shape).clone()
 
     def profile_enable(self, family):
         _check(self.lib.ssp_profile_enable(self.h, PROF[family] if isinstance(family, str) else int(family)))
@@ -786,6 +789,25 @@ def op_bn_bwd(y_nhwc, dout_nhwc, gamma, scale, shift, mean, invstd, relu=True, p
     with torch.cuda.device(dev):
         _check(lib.ssp_op_bn_bwd_strided(_ptr(y_nhwc), _ptr(dout_nhwc), _ptr(gamma), _ptr(stats4), _ptr(dy), _ptr(dg),
                                          _ptr(db), _ptr(dbias), _ptr(sums), N, H, W, Cc, cs, int(relu), int(pool), _stream()))
+    return dy, dg, db, dbias
+
+
+def op_bn_bwd_bf16(y_nhwc, dout_nhwc, gamma, scale, shift, mean, invstd, pool=False):
+    """op_bn_bwd on bf16 tensors (BatchNorm + ReLU (+ MaxPool2d(2)) backward of the bf16 path); dy is bf16."""
+    lib = load_library()
+    _need_gpu(y_nhwc, "y")
+    if y_nhwc.dtype != torch.bfloat16 or dout_nhwc.dtype != torch.bfloat16:
+        raise RuntimeError("y and dout must be bfloat16")
+    N, H, W, cs = y_nhwc.shape
+    Cc = gamma.numel()
+    dev = y_nhwc.device
+    stats4 = torch.cat([scale, shift, mean, invstd]).contiguous()
+    dy = torch.zeros_like(y_nhwc)
+    dg, db, dbias = (torch.zeros(Cc, dtype=torch.float32, device=dev) for _ in range(3))
+    sums = torch.zeros(NREP * 2 * Cc, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.ssp_op_bn_bwd_bf16(_ptr(y_nhwc), _ptr(dout_nhwc), _ptr(gamma), _ptr(stats4), _ptr(dy), _ptr(dg), _ptr(db),
+                                      _ptr(dbias), _ptr(sums), N, H, W, Cc, cs, 1, int(pool), _stream()))
     return dy, dg, db, dbias
 
 

@@ -42,8 +42,7 @@ CONV_CASES = [
     (2, 32, 32, 64, 64, 3, 1, "bf16", "bf16", True),     # full tiles, BatchNorm + ReLU on load, pooled raw output
     (1, 30, 40, 128, 128, 3, 1, "bf16", "bf16", False),  # ragged tiles, 4 chunks, 2 output blocks
     (2, 24, 48, 64, 128, 3, 0, "bf16", "bf16", False),   # plain input (data-gradient form)
-    (1, 12, 20, 128, 256, 3, 1, "bf16", "f32", False),   # 3x3 heads: fp32 output
-    (2, 16, 16, 64, 64, 3, 0, "f32", "bf16", False),     # fp32 input rounded on load
+    (1, 12, 20, 128, 256, 3, 1, "bf16", "bf16", False),  # 3x3 heads
     (1, 30, 40, 256, 65, 1, 1, "bf16", "f32", False),    # pointwise, ragged output channels
     (1, 14, 18, 136, 256, 1, 0, "f32", "bf16", False),   # pointwise data gradient: 133 (+3 zero) fp32 channels in
 ]
@@ -113,7 +112,6 @@ WGRAD_CASES = [
     (2, 32, 32, 64, 64, 3, 1, "bf16"),     # full tiles, BatchNorm + ReLU on load
     (1, 30, 40, 128, 128, 3, 1, "bf16"),   # ragged tiles, 2 x 2 slabs
     (2, 24, 48, 64, 128, 3, 0, "bf16"),    # plain input
-    (1, 30, 40, 128, 256, 3, 1, "f32"),    # 3x3 heads: fp32 dY rounded on load
     (1, 14, 18, 256, 136, 1, 1, "f32"),    # pointwise head, ragged output channels (133 + 3 zero)
 ]
 
@@ -141,3 +139,37 @@ def test_wgrad_bf16_matches_its_semantics(case):
     dw2 = L.op_conv_wgrad_bf16(x.to(torch.bfloat16).to(dev), dyd, ks, in_mode=in_mode, in_scale=sc.to(dev), in_shift=sh.to(dev), dw=dw.clone())
     torch.cuda.synchronize()
     assert float((dw2.cpu().double() - 2 * ref).abs().max() / ref.abs().max()) < 4e-4
+
+
+@pytest.mark.parametrize("N,H,W,Cc,pool", [(2, 16, 24, 64, False), (2, 16, 24, 64, True), (1, 30, 40, 128, False), (2, 12, 8, 256, True)])
+def test_bn_relu_pool_backward_on_bf16_tensors(N, H, W, Cc, pool):
+    """BatchNorm(train) + ReLU (+ MaxPool2d(2)) backward with bf16 y / dOut / dY (fp32 arithmetic inside) against autograd in
+    fp64 on the same bf16-valued tensors; dY is compared after its rounding to bf16 (one ulp on boundary cases)."""
+    from semantic_superpoint_amd import lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(3 + H + Cc)
+    y = _bf(torch.randn(N, H, W, Cc, generator=g))
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    dout = _bf(torch.randn(N, Ho, Wo, Cc, generator=g))
+    gamma = torch.randn(Cc, generator=g)
+    beta = torch.randn(Cc, generator=g) * 0.2
+    yd = y.double().permute(0, 3, 1, 2).requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean, var = yd.mean(dim=(0, 2, 3)), yd.var(dim=(0, 2, 3), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    z = (yd - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1)
+    a = F.relu(z)
+    if pool:
+        a = F.max_pool2d(a, 2)
+    a.backward(dout.double().permute(0, 3, 1, 2))
+    scale = (gamma.double() * invstd.detach()).float()
+    shift = (beta.double() - mean.detach() * scale.double()).float()
+    dy, dg, db, dbias = L.op_bn_bwd_bf16(y.to(torch.bfloat16).to(dev), dout.to(torch.bfloat16).to(dev), gamma.to(dev), scale.to(dev),
+                                         shift.to(dev), mean.detach().float().to(dev), invstd.detach().float().to(dev), pool=pool)
+    torch.cuda.synchronize()
+    ref = yd.grad.permute(0, 2, 3, 1)
+    nbad, worst = _ulp_close(dy.cpu(), ref, float(ref.abs().max()))
+    # a ReLU gate / pool winner whose z sits within fp32 rounding of 0 (or of its neighbour) may go the other way: none expected here
+    assert nbad <= 2, (nbad, worst)
+    assert (dg.cpu().double() - gd.grad).abs().max() <= 1e-4 * float(gd.grad.abs().max())
+    assert (db.cpu().double() - bd.grad).abs().max() <= 1e-4 * float(bd.grad.abs().max())

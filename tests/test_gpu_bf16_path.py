@@ -1,0 +1,237 @@
+"""GPU: the bf16 path (conv algorithm 12, BASELINE configs[3] "bf16 compute / fp32 master") through the Engine against the
+ORACLE evaluated with the same rounding points (oracle/cpu_ref.py, operand_dtype=torch.bfloat16: bf16 matrix-core operands,
+bf16 stored activations / activation gradients, fp32 accumulation, BatchNorm, losses, master weights).  The reference is
+fp32-only (models/unet_parts.py:14-21), so the anchor chain is: reference == fp32 oracle (goldens), fp32 oracle -> bf16 oracle by
+the rounding functions alone, bf16 oracle == HIP bf16 path (here).
+
+What "==" can mean.  A network that re-quantises every activation to 8 significant bits is NOT a continuous function of its
+fp32 summation order: an accumulation that lands within fp32 noise of a bf16 rounding boundary stores the other neighbour
+(one bf16 ulp = 2^-8), the next layer sums 576 - 2304 such inputs, re-quantises, and after ten layers two correct
+implementations are decorrelated at the level of the quantisation noise itself.  Measured on the ORACLE ALONE (the same bf16
+network with fp32- vs fp64-accumulated convolutions, 64x96): logits rel-L2 1.5e-2, max 0.09 of a scale of 6.6 - the "noise floor"
+every test below computes for itself.  Hence:
+  * LAYER-EXACT parity, teacher-forced: every layer of the HIP forward is re-evaluated on the CPU from the HIP path's own
+    stored input of that layer; the stored output must equal bf16(exact) up to one bf16 ulp on boundary cases
+    (test_bf16_forward_chain_teacher_forced; the kernels alone: tests/test_gpu_bf16_ops.py);
+  * END-TO-END parity against the bf16 oracle within 2x the oracle's own accumulation-order floor, and both at the same
+    distance from the fp32 oracle (forward, losses, every gradient tensor)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref as C
+
+pytestmark = pytest.mark.gpu
+ARCHS = ("SuperPointNet_gauss2", "SuperPointNet_gauss2_ssmall")
+BF16 = torch.bfloat16
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (run through gpurun)"
+    return torch.device("cuda:0")
+
+
+def _engine(arch, B, H, W, sd, **kw):
+    from semantic_superpoint_amd.lib import Engine
+    e = Engine(arch, B, H, W, _dev(), **kw)
+    e.set_conv_algo(12)
+    e.load_state_dict(sd)
+    return e
+
+
+def _to_dev(sample):
+    return {k: v.to(_dev()).contiguous() for k, v in sample.items()}
+
+
+def _idx_to_dev(idx, Wc):
+    ma = torch.stack([(i["uv_a"][:, 0] + i["uv_a"][:, 1] * Wc) for i in idx]).to(torch.int32)
+    mb = torch.stack([(i["uv_b"][:, 0] + i["uv_b"][:, 1] * Wc) for i in idx]).to(torch.int32)
+    nm = torch.stack([i["nm_b"] for i in idx]).to(torch.int32)
+    return ma.to(_dev()).contiguous(), mb.to(_dev()).contiguous(), nm.to(_dev()).contiguous()
+
+
+def _rel_l2(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _bf(x):
+    return x.to(BF16).to(torch.float32)
+
+
+class _Fp64Convs:
+    """The oracle's convolutions accumulated in fp64 instead of fp32: a second CORRECT evaluation of the same bf16 network, used
+    to measure how far two correct evaluations are apart (the noise floor of the end-to-end comparisons)."""
+
+    def __enter__(self):
+        self.orig = F.conv2d
+        orig = self.orig
+
+        def conv64(i, w, b=None, **kw):
+            return orig(i.double(), w.double(), None if b is None else b.double(), **kw).to(i.dtype)
+        F.conv2d = conv64
+
+    def __exit__(self, *a):
+        F.conv2d = self.orig
+
+
+def _ulp_bad(stored_bf16, exact_f64, noise):
+    """elements of a stored bf16 tensor further than one bf16 ulp (+ accumulation noise) from the exact value"""
+    err = (stored_bf16.double() - exact_f64).abs()
+    return int((err > exact_f64.abs() * 2.0 ** -7 + noise).sum())
+
+
+@pytest.mark.parametrize("arch,H,W,B", [(ARCHS[1], 64, 96, 2), (ARCHS[1], 120, 160, 2), (ARCHS[0], 240, 320, 2)])
+def test_bf16_forward_chain_teacher_forced(arch, H, W, B):
+    """Every layer of the HIP bf16 forward, re-evaluated from the HIP path's OWN stored input of that layer: operand =
+    bf16(relu(fma(y_prev, scale, shift))) (2x2 max-pooled where the reference pools), exact fp64 products and sums of bf16(weights),
+    + bias -> the stored bf16 (fp32 for the pointwise heads) output must be the correctly rounded value up to one ulp; the
+    BatchNorm affine the engine derived from the stored tensor must be that tensor's batch statistics."""
+    sd = C.init_state_dict(arch, seed=5)
+    x = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3))
+    e = _engine(arch, B, H, W, sd, with_grad=False)
+    e.forward(x.to(_dev()), slot=0, train=True, want=())
+    torch.cuda.synchronize()
+    t = C.layer_table(arch)
+    nheads = 3 if arch.endswith("ssmall") else 2
+    hcs = 256 * nheads
+    Hc, Wc = H // 8, W // 8
+
+    def res(l):
+        s = 0 if l < 2 else 1 if l < 4 else 2 if l < 6 else 3
+        return H >> s, W >> s
+
+    def affine_check(l, y_nchw):
+        conv, bn, cin, cout, k = t[l]
+        yd = y_nchw.double()
+        mean, var = yd.mean(dim=(0, 2, 3)), yd.var(dim=(0, 2, 3), unbiased=False)
+        invstd = (var + 1e-5).rsqrt()
+        sc = torch.from_numpy(sd[bn + ".weight"]).double() * invstd
+        sh = torch.from_numpy(sd[bn + ".bias"]).double() - mean * sc
+        msc = e.debug_buffer(0, "scale%d" % l, (cout,)).cpu().double()
+        msh = e.debug_buffer(0, "shift%d" % l, (cout,)).cpu().double()
+        assert (msc - sc).abs().max() <= 1e-5 * float(sc.abs().max()), ("scale", l)
+        assert (msh - sh).abs().max() <= 1e-5 * max(1.0, float(sh.abs().max())), ("shift", l)
+        return msc.float(), msh.float()
+
+    def operand(y_nchw, sc, sh):  # one fp32 fma per element, ReLU, rounded to bf16
+        z = (y_nchw.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+        return _bf(F.relu(z))
+
+    # layer 0: fp32 arithmetic on the fp32 image
+    y0 = e.debug_buffer(0, "Y0", (B, H, W, 64), BF16).cpu().float().permute(0, 3, 1, 2)
+    ex = F.conv2d(x.double(), torch.from_numpy(sd[t[0][0] + ".weight"]).double(), torch.from_numpy(sd[t[0][0] + ".bias"]).double(), padding=1)
+    assert _ulp_bad(y0, ex, 1e-5 * float(ex.abs().max())) == 0, "layer 0"
+    prev = y0
+    for l in range(1, 8):
+        conv, bn, cin, cout, k = t[l]
+        sc, sh = affine_check(l - 1, prev)
+        a = operand(prev, sc, sh)
+        if l in (2, 4, 6):
+            a = F.max_pool2d(a, 2)
+            # the engine's raw pooled copy: per-channel max / min (sign of gamma) of the stored tensor, BatchNorm + ReLU on load
+            hp, wp = res(l)
+            raw = e.debug_buffer(0, "A%d" % (l - 1), (B, hp, wp, cin), BF16).cpu().float().permute(0, 3, 1, 2)
+            gam = torch.from_numpy(sd[t[l - 1][1] + ".weight"]).view(1, -1, 1, 1)
+            want = torch.where(gam >= 0, F.max_pool2d(prev, 2), -F.max_pool2d(-prev, 2))
+            assert torch.equal(raw, want), ("pooled copy", l - 1)
+            assert torch.equal(operand(raw, sc, sh), a), ("pooled operand", l - 1)
+        hl, wl = res(l)
+        y = e.debug_buffer(0, "Y%d" % l, (B, hl, wl, cout), BF16).cpu().float().permute(0, 3, 1, 2)
+        ex = F.conv2d(a.double(), _bf(torch.from_numpy(sd[conv + ".weight"])).double(), torch.from_numpy(sd[conv + ".bias"]).double(), padding=1)
+        nbad = _ulp_bad(y, ex, 1e-4 * float(ex.abs().max()))
+        assert nbad == 0, ("layer", l, nbad)
+        prev = y
+    sc7, sh7 = affine_check(7, prev)
+    x4 = operand(prev, sc7, sh7)
+    yh = e.debug_buffer(0, "Y8", (B, Hc, Wc, hcs), BF16).cpu().float().permute(0, 3, 1, 2)   # [Pa | Da | DS] raw outputs
+    for hk, (l3, l1) in enumerate(((8, 9), (10, 11), (12, 13))[:nheads]):
+        conv, bn, cin, cout, k = t[l3]
+        ex = F.conv2d(x4.double(), _bf(torch.from_numpy(sd[conv + ".weight"])).double(), torch.from_numpy(sd[conv + ".bias"]).double(), padding=1)
+        y = yh[:, 256 * hk:256 * hk + 256]
+        assert _ulp_bad(y, ex, 1e-4 * float(ex.abs().max())) == 0, ("head", conv)
+        sc, sh = affine_check(l3, y)
+        a = operand(y, sc, sh)
+        c1, b1, cin1, cout1, _ = t[l1]
+        cs = {65: 80, 256: 256}.get(cout1, (cout1 + 3) // 4 * 4)
+        o = e.debug_buffer(0, "Y%d" % l1, (B, Hc, Wc, cs)).cpu().permute(0, 3, 1, 2)[:, :cout1]
+        ex = F.conv2d(a.double(), _bf(torch.from_numpy(sd[c1 + ".weight"])).double(), torch.from_numpy(sd[c1 + ".bias"]).double())
+        assert (o.double() - ex).abs().max() <= 2e-5 * float(ex.abs().max()), ("pointwise", c1)   # fp32 output, fp32 accumulation
+
+
+@pytest.mark.parametrize("arch,H,W,B", [(ARCHS[0], 64, 96, 2), (ARCHS[1], 120, 160, 2)])
+def test_bf16_forward_vs_bf16_oracle(arch, H, W, B):
+    """semi / desc (/ sem) of a train-mode forward against the bf16 oracle: within 2x the oracle's own accumulation-order floor, and
+    as far from the fp32 oracle as the bf16 oracle is; running statistics at 1e-2."""
+    sd = C.init_state_dict(arch, seed=5)
+    x = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3))
+    tsd = C.to_torch(sd)
+    with torch.no_grad():
+        ref = C.forward(tsd, x, arch, train=True, operand_dtype=BF16)
+        r32 = C.forward(C.to_torch(sd), x, arch, train=True)
+        with _Fp64Convs():
+            r64 = C.forward(C.to_torch(sd), x, arch, train=True, operand_dtype=BF16)
+    e = _engine(arch, B, H, W, sd, with_grad=False)
+    want = ("semi", "desc", "sem") if arch.endswith("ssmall") else ("semi", "desc")
+    out = e.forward(x.to(_dev()), slot=0, train=True, want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        r, m = ref[k], out[k].cpu()
+        floor, d32_ref, d32_hip = _rel_l2(r64[k], r), _rel_l2(r, r32[k]), _rel_l2(m, r32[k])
+        err = _rel_l2(m, r)
+        print("%s %dx%d %s: HIP vs bf16 oracle %.2e (oracle's own floor %.2e); distance to the fp32 oracle: HIP %.2e, bf16 oracle %.2e"
+              % (arch, H, W, k, err, floor, d32_hip, d32_ref))
+        assert err <= 2.0 * floor + 1e-4, (k, err, floor)
+        assert d32_hip <= 1.5 * d32_ref + 1e-4, (k, d32_hip, d32_ref)
+    st = e.state_dict()
+    for k in ("inc.conv.conv.1.running_mean", "inc.conv.conv.4.running_var", "down2.mpconv.1.conv.4.running_var", "bnPa.running_var",
+              "bnDb.running_mean"):
+        assert (st[k].cpu() - tsd[k]).abs().max() <= 1e-2 * max(1.0, float(tsd[k].abs().max())), k
+
+
+@pytest.mark.parametrize("arch", ARCHS)
+def test_bf16_pair_step_vs_bf16_oracle(arch):
+    """One pair step at 120x160, B = 2 against the bf16 oracle with the oracle's own sampled indices: the scalars, every gradient
+    tensor (rel-L2 within 2x the oracle's accumulation-order floor of that tensor, cosine >= 0.97), the eta gradient."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    B, H, W = 2, 120, 160
+    semantic = arch.endswith("ssmall")
+    sd = C.init_state_dict(arch, seed=9)
+    sample = C.make_synthetic_pair(B, H, W, seed=4, semantic=semantic, kp_prob=0.005)
+    tr = C.Trainer(arch, sd, lr=0.001, operand_dtype=BF16)
+    np.random.seed(50)
+    torch.manual_seed(60)
+    tr.train_val_sample(sample, n_iter=0, train=True)
+    used = tr.aux["indices"]
+    tr64 = C.Trainer(arch, sd, lr=0.001, operand_dtype=BF16)
+    with _Fp64Convs():
+        tr64.train_val_sample(sample, n_iter=0, train=True, indices=used)
+    idx = _idx_to_dev(used, W // 8)
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    sc = e.pair_step(_to_dev(sample), indices=idx, train=True)
+    torch.cuda.synchronize()
+    sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
+        ref, r64 = tr.scalar_dict[name], tr64.scalar_dict[name]
+        assert abs(sc[name] - ref) < 2.0 * abs(r64 - ref) + 1e-3 * max(1.0, abs(ref)), (name, sc[name], ref, r64)
+    gd = e.grad_dict()
+    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}  # conv bias under BatchNorm: exactly 0 + noise
+    worst = (0.0, None, 0.0)
+    for k in C.param_keys(arch):
+        if k in noisy:
+            continue
+        g, r, r64 = gd[k].cpu(), tr.last_grads[k], tr64.last_grads[k]
+        err, floor = _rel_l2(g, r), _rel_l2(r64, r)
+        cos = float((g.double().flatten() @ r.double().flatten()) / (g.double().norm() * r.double().norm() + 1e-30))
+        if err > worst[0]:
+            worst = (err, k, floor)
+        assert err <= 2.0 * floor + 2e-3, (k, err, floor)
+        assert cos >= 0.97, (k, cos)
+    print("bf16 path vs bf16 oracle, 120x160 %s: worst per-tensor gradient rel-L2 %.2e (%s; the oracle's own floor there %.2e)"
+          % (arch, worst[0], worst[1], worst[2]))
+    assert (gd["eta"].cpu() - tr.last_grads["eta"]).abs().max() < 2e-3
+    e.adam_step(0.001)
+    torch.cuda.synchronize()
+    assert (e.eta.cpu() - tr.eta.detach()).abs().max() < 1e-4
