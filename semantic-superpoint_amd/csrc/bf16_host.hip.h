@@ -45,6 +45,8 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   const double img = (double)c.H * c.W * c.in_cs * (c.in_f32 ? 4.0 : 2.0);
   if (img > 2147483647.0) return fail(-3, "bf16 conv: one input image [%d,%d,%d] exceeds 2 GiB", c.H, c.W, c.in_cs);
   a.in_img_bytes = (unsigned)img;
+  static const int ablate_env = getenv("SSP_CONVB_ABLATE") ? atoi(getenv("SSP_CONVB_ABLATE")) : 0;  // (perf-debug)
+  a.ablate = ablate_env;
   if (!c.out_f32 && (c.cout % 8 || c.out_cs % 8 || c.out_co % 8)) return fail(-3, "bf16 conv: bf16 output needs channel counts / offsets that are multiples of 8");
   if (!c.in_f32 && (c.in_cs % 8 || c.in_co % 8)) return fail(-3, "bf16 conv: bf16 input needs channel stride / offset that are multiples of 8");
   if (c.in_f32 && (c.in_cs % 4 || c.in_co % 4)) return fail(-3, "bf16 conv: fp32 input needs channel stride / offset that are multiples of 4");
@@ -54,6 +56,8 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   const long units = (long)c.nviews * a.ncob * c.N * a.tiles_x * a.tiles_y;
   int nblocks = (int)std::min<long>(2L * n_cu, cdiv(units, 8) * 8L) / 8 * 8;
   nblocks = std::max(nblocks, 8);
+  static const int grid_env = getenv("SSP_CONVB_GRID") ? atoi(getenv("SSP_CONVB_GRID")) : 0;  // (perf-debug)
+  if (grid_env > 0) nblocks = grid_env;
 #define CONVB_CASE(KS_, M_, I_, O_) \
   if (c.ks == KS_ && c.in_mode == M_ && c.in_f32 == I_ && c.out_f32 == O_) return launch_conv_bf16_t<KS_, M_, I_, O_>(a, nblocks, st);
   CONVB_CASE(3, 1, false, false) CONVB_CASE(3, 0, false, false) CONVB_CASE(1, 1, false, true) CONVB_CASE(1, 0, true, false)

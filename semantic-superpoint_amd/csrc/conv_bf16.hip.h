@@ -54,6 +54,7 @@ struct ConvBArgs {
   int Cout, out_cs, out_co;
   int tiles_x, tiles_y, nchunks, ncob;
   unsigned in_img_bytes;     // bytes of ONE input image (buffer descriptor range)
+  int ablate;                // perf-debug only (SSP_CONVB_ABLATE): 1 no global loads, 2 no LDS staging writes, 4 no epilogue, 8 no MFMA loop
 };
 
 // lane (0..31) of a pixel tile -> (row 0..1, column 0..15).  With RS = halo row pitch (18 for 3x3, 16 for 1x1) the slot index
@@ -104,12 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
   // staging slots of this thread: halo slot = (tid >> 2) + 64 i, 16-byte part = tid & 3 (8 channels)
   constexpr int NHS = (HT * HT * 4 + 255) / 256;
   const int part = tid & 3;
-  int hs_lds[NHS];
-#pragma unroll
-  for (int i = 0; i < NHS; ++i) {
-    const int s = (tid >> 2) + 64 * i;
-    hs_lds[i] = s < HT * HT ? s * CB_PS + part * 16 : -1;
-  }
+  const int hs_lds0 = (tid >> 2) * CB_PS + part * 16;   // LDS offset of slot i: + i * 64 * CB_PS (an immediate)
   constexpr int NWS = G::W_BYTES / 16 / 256;  // weight items per thread (9 for 3x3, 1 for 1x1)
 
   constexpr int CPT = OUT_F32 ? 4 : 8;   // output channels per copy-out item (16 bytes)
@@ -142,60 +138,73 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
     }
   };
 
-  for (; u < u_end; u += nslot) {
-    const int vc = u / T, t = u - vc * T;
-    const int view = vc / a.ncob, cob = vc - view * a.ncob;
+  // ---- software pipeline over the (unit, chunk) stages of this block: the global loads of stage s + 1 (halo, weight image,
+  // BatchNorm affine) are issued right after stage s has been written to LDS and stay in flight under its MFMAs and epilogue ----
+  constexpr int IN_ES = IN_F32 ? 4 : 2;
+  constexpr unsigned OOB = 0x80000000u;
+  // descriptors of the stage whose loads are in flight / being staged ("ld_"), decoded from a unit index.  The slot
+  // coordinates of this thread inside a halo are tile independent: per slot one base offset (relative to the tile origin) and
+  // its (row, column); a tile adds its origin, and only tiles that touch the image border test the coordinates.
+  int ld_view = 0, ld_cob = 0, ld_n = 0, ld_ty0 = 0, ld_tx0 = 0, ld_vc = 0;
+  unsigned hs_g[NHS];     // byte offset of slot i inside the image (OOB marker: outside the image / unused slot)
+  int hs_rel[NHS];        // ((hy - PAD) * W + (hx - PAD)) * in_cs * es + channel part: offset relative to the tile origin
+  int hs_yx[NHS];         // (row << 16) | (column & 0xffff) relative to the tile origin; row -30000: unused slot of the last round
+#pragma unroll
+  for (int i = 0; i < NHS; ++i) {
+    const int s = (tid >> 2) + 64 * i;
+    const int hy = s / HT, hx = s - hy * HT;
+    hs_yx[i] = ((s < HT * HT ? hy - PAD : -30000) << 16) | ((hx - PAD) & 0xffff);
+    hs_rel[i] = (((hy - PAD) * a.W + (hx - PAD)) * a.in_cs + a.in_co + part * 8) * IN_ES;
+  }
+  __amdgpu_buffer_rsrc_t rsrc_in;
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.wpk), 0, (unsigned)(a.ncob * a.nchunks * G::W_BYTES), 0x00020000);
+  auto decode = [&](int uu) {
+    const int vc = uu / T, t = uu - vc * T;
+    ld_vc = vc;
+    ld_view = vc / a.ncob; ld_cob = vc - ld_view * a.ncob;
     const int txi = t % a.tiles_x, t2 = t / a.tiles_x;
-    const int tyi = t2 % a.tiles_y, n = t2 / a.tiles_y;
-    const int ty0 = tyi * CB_T, tx0 = txi * CB_T;
-    if (a.stats[0] != nullptr && vc != st_key) {
-      if (st_key >= 0) flush_stats(st_key);
-      st_key = vc;
-    }
-    const unsigned char* const p_in = reinterpret_cast<const unsigned char*>(a.in[view]);
-    const float* const p_scale = a.in_scale[view];
-    const float* const p_shift = a.in_shift[view];
-    constexpr int IN_ES = IN_F32 ? 4 : 2;
-    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(p_in) + (size_t)n * a.in_img_bytes, 0, a.in_img_bytes, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    unsigned hs_g[NHS];
+    const int tyi = t2 % a.tiles_y;
+    ld_n = t2 / a.tiles_y;
+    ld_ty0 = tyi * CB_T; ld_tx0 = txi * CB_T;
+    rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.in[ld_view])) + (size_t)ld_n * a.in_img_bytes, 0, a.in_img_bytes, 0x00020000);
+    const int org = (ld_ty0 * a.W + ld_tx0) * a.in_cs * IN_ES;
+    const bool interior = ld_ty0 >= PAD && ld_tx0 >= PAD && ld_ty0 + CB_T + PAD <= a.H && ld_tx0 + CB_T + PAD <= a.W;
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < NHS; ++i) {
-      const int s = (tid >> 2) + 64 * i;
-      const int hy = s / HT, hx = s - hy * HT;
-      const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
-      const bool ok = s < HT * HT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      hs_g[i] = ok ? (unsigned)(((gy * a.W + gx) * a.in_cs + a.in_co + part * 8) * IN_ES) : OOB;
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-      // ---- stage the halo of 32 channels and the 64 x 32 x taps weight image ----
-      const int c0 = chunk * CB_KC + part * 8;
-      const bool cfull = c0 + 8 <= a.Cin;
-      u32x4 hv[NHS], hv2[NHS];
+      for (int i = 0; i < NHS; ++i) hs_g[i] = (hs_yx[i] >> 16) > -30000 ? (unsigned)(org + hs_rel[i]) : OOB;
+    } else {
 #pragma unroll
       for (int i = 0; i < NHS; ++i) {
-        const unsigned vo = c0 < a.Cin ? hs_g[i] : OOB;
-        hv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo, chunk * CB_KC * IN_ES, 0));
-        if (IN_F32) hv2[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo, chunk * CB_KC * IN_ES + 16, 0));
+        const int gy = ld_ty0 + (hs_yx[i] >> 16), gx = ld_tx0 + (short)(hs_yx[i] & 0xffff);
+        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // (unused slots: gy < 0)
+        hs_g[i] = ok ? (unsigned)(org + hs_rel[i]) : OOB;
       }
-      u32x4 wv[NWS];
-      {
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)(cob * a.nchunks + chunk) * (G::W_BYTES / 16);
+    }
+  };
+  u32x4 hv[NHS], hv2[IN_F32 ? NHS : 1], wv[NWS];
+  float sc[8], sh[8];
+  auto issue = [&](int chunk) {
+    const int c0 = chunk * CB_KC + part * 8;
 #pragma unroll
-        for (int i = 0; i < NWS; ++i) wv[i] = wsrc[tid + 256 * i];
-      }
-      float sc[8], sh[8];
-      if (IN_MODE == 1) {
+    for (int i = 0; i < NHS; ++i) {
+      const unsigned vo = (c0 < a.Cin && !(a.ablate & 1)) ? hs_g[i] : OOB;
+      hv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo, chunk * CB_KC * IN_ES, 0));
+      if constexpr (IN_F32) hv2[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, vo, chunk * CB_KC * IN_ES + 16, 0));
+    }
+    const int wbase = (ld_cob * a.nchunks + chunk) * G::W_BYTES;   // (wave-uniform: scalar offset of the buffer load)
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) wv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase + 4096 * i, 0));
+    if (IN_MODE == 1) {
+      const float* const p_scale = a.in_scale[ld_view];
+      const float* const p_shift = a.in_shift[ld_view];
+      if (c0 + 8 <= a.Cin && ((reinterpret_cast<uintptr_t>(p_scale + c0) | reinterpret_cast<uintptr_t>(p_shift + c0)) & 15) == 0) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p_scale + c0), s1 = *reinterpret_cast<const f32x4*>(p_scale + c0 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(p_shift + c0), h1 = *reinterpret_cast<const f32x4*>(p_shift + c0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = h0[e]; sh[4 + e] = h1[e]; }
+      } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int c = min(c0 + e, a.Cin - 1);
@@ -203,64 +212,123 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
           sh[e] = p_shift[c];
         }
       }
+    }
+  };
+  decode(u);
+  issue(0);
+  if ((a.ablate & 16) && blockIdx.x >= (gridDim.x >> 1)) {  // (perf-debug: start the second workgroup of a CU half a tile late)
+    for (int i = 0; i < (a.ablate >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  int chunk = 0;
+  f32x16 acc[2][2];
+  for (;;) {
+    // the stage being staged and computed now: unit u, `chunk`
+    const int view = ld_view, cob = ld_cob, n = ld_n, ty0 = ld_ty0, tx0 = ld_tx0;
+    if (chunk == 0) {
+      if (a.stats[0] != nullptr && ld_vc != st_key) {
+        if (st_key >= 0) flush_stats(st_key);
+        st_key = ld_vc;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    {
+      // ---- stage the halo of 32 channels and the 64 x 32 x taps weight image ----
+      const int c0 = chunk * CB_KC + part * 8;
+      const bool cfull = c0 + 8 <= a.Cin;
       __syncthreads();  // every wave has finished reading the previous stage (or the output tile of the previous unit)
+      if (!(a.ablate & 2)) {
 #pragma unroll
       for (int i = 0; i < NHS; ++i) {
-        if (hs_lds[i] < 0) continue;
-        u32x4 o = {0u, 0u, 0u, 0u};
-        if (hs_g[i] != OOB && c0 < a.Cin) {
-          float f[8];
-          if (IN_F32) {
+        if ((tid >> 2) + 64 * i >= HT * HT) continue;   // (only the last round has unused slots)
+        // branch-free: transform whatever the (possibly out-of-range, then zero) load returned, select zero for padding
+        u32x4 o;
+        float f[8];
+        if constexpr (IN_F32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              f[e] = u32_as_f32(hv[i][e]);
-              f[4 + e] = u32_as_f32(hv2[i][e]);
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              f[2 * e] = bf16_lo(hv[i][e]);
-              f[2 * e + 1] = bf16_hi(hv[i][e]);
-            }
+          for (int e = 0; e < 4; ++e) {
+            f[e] = u32_as_f32(hv[i][e]);
+            f[4 + e] = u32_as_f32(hv2[i][e]);
           }
-          if (IN_MODE == 1) {
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
-          }
-          if (!cfull) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (c0 + e >= a.Cin) f[e] = 0.f;
-          }
-          if (IN_F32 || IN_MODE == 1 || !cfull) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
-          } else {
-            o = hv[i];
+          for (int e = 0; e < 4; ++e) {
+            f[2 * e] = bf16_lo(hv[i][e]);
+            f[2 * e + 1] = bf16_hi(hv[i][e]);
           }
         }
-        *reinterpret_cast<u32x4*>(sH + hs_lds[i]) = o;
+        if (IN_MODE == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+        }
+        if (IN_F32 || IN_MODE == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
+        } else {
+          o = hv[i];
+        }
+        if (!cfull) {  // ragged input channels (the pointwise data gradients): zero beyond Cin
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (c0 + 2 * e >= a.Cin) o[e] = 0u;
+            else if (c0 + 2 * e + 1 >= a.Cin) o[e] &= 0xffffu;
+          }
+        }
+        if (IN_MODE == 1) {  // padding is zero in the ACTIVATED domain (an out-of-range load returned 0, relu(shift) need not be)
+          const bool pad = hs_g[i] == OOB || c0 >= a.Cin;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pad ? 0u : o[e];
+        }
+        *reinterpret_cast<u32x4*>(sH + hs_lds0 + i * 64 * CB_PS) = o;
       }
 #pragma unroll
       for (int i = 0; i < NWS; ++i) *reinterpret_cast<u32x4*>(sW + (tid + 256 * i) * 16) = wv[i];
-      __syncthreads();
-      // ---- MFMA: taps x 2 k-steps x (2 channel tiles x 2 pixel tiles) ----
-#pragma unroll
-      for (int tap = 0; tap < G::TAPS; ++tap) {
-        const int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const s16x8 a0 = *reinterpret_cast<const s16x8*>(sW + aoff + ((tap * 2 + ks) * 2 + 0) * 1024);
-          const s16x8 a1 = *reinterpret_cast<const s16x8*>(sW + aoff + ((tap * 2 + ks) * 2 + 1) * 1024);
-          const s16x8 b0 = *reinterpret_cast<const s16x8*>(sH + boff[0] + (dy * HT + dx) * CB_PS + ks * 32);
-          const s16x8 b1 = *reinterpret_cast<const s16x8*>(sH + boff[1] + (dy * HT + dx) * CB_PS + ks * 32);
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
       }
+      __syncthreads();
+      // ---- the next stage's loads: next chunk of this unit, or chunk 0 of the block's next unit ----
+      const bool last_chunk = chunk + 1 == a.nchunks;
+      const bool has_next = !last_chunk || u + nslot < u_end;
+      if (has_next) {
+        if (last_chunk) decode(u + nslot);
+        issue(last_chunk ? 0 : chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);  // (the loads are requested BEFORE the MFMA loop)
+      }
+      // ---- MFMA: taps x 2 k-steps x (2 channel tiles x 2 pixel tiles).  The four operand fragments of step s + 1 are requested
+      // before the four MFMAs of step s are issued (two register sets, pinned with sched_barrier). ----
+      constexpr int NSTEP = G::TAPS * 2;
+      s16x8 fa[2][2], fb[2][2];
+      auto fetch = [&](int step, s16x8 (&qa)[2], s16x8 (&qb)[2]) {
+        const int tap = step >> 1, ks = step & 1;
+        const int dy = tap / KS, dx = tap % KS;
+        qa[0] = *reinterpret_cast<const s16x8*>(sW + aoff + ((tap * 2 + ks) * 2 + 0) * 1024);
+        qa[1] = *reinterpret_cast<const s16x8*>(sW + aoff + ((tap * 2 + ks) * 2 + 1) * 1024);
+        qb[0] = *reinterpret_cast<const s16x8*>(sH + boff[0] + (dy * HT + dx) * CB_PS + ks * 32);
+        qb[1] = *reinterpret_cast<const s16x8*>(sH + boff[1] + (dy * HT + dx) * CB_PS + ks * 32);
+      };
+      if (!(a.ablate & 8)) {
+      fetch(0, fa[0], fb[0]);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < NSTEP) fetch(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      }
+      if (!last_chunk) { ++chunk; continue; }
+      chunk = 0;
+      if (!has_next) u = u_end; else u += nslot;   // (the descriptors "ld_" already belong to the next unit)
     }
+    const bool done = u >= u_end;
+    if (a.ablate & 4) { if (done) break; continue; }
 
     // ---- epilogue: bias, rounding, [pixel][channel] tile through LDS, 16-byte stores, statistics of the stored values ----
     f32x4 bias4[2][4];
@@ -271,8 +339,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
         const int co = cob * CB_NB + mt * 32 + 8 * q + 4 * lg;
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
         if (a.bias != nullptr) {
+          if (co + 4 <= a.Cout && (reinterpret_cast<uintptr_t>(a.bias + co) & 15) == 0) {  // (the flat parameter vector keeps the
+            b = *reinterpret_cast<const f32x4*>(a.bias + co);                              // biases behind convPb only 4-byte aligned)
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) b[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
+            for (int e = 0; e < 4; ++e) b[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
+          }
         }
         bias4[mt][q] = b;
       }
@@ -314,45 +386,61 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
       const int nvalid = min(CPT, a.Cout - co0);  // <= 0: none
       constexpr int NPX = OUT_F32 ? 128 : 256;
       constexpr int PSTEP = 256 / TPP;
+      if constexpr (!OUT_F32) {
+        // item k of this thread: pixel row (tid >> 7) + 2 k, column (tid >> 3) & 15 of the tile: one voffset, the row step is a
+        // scalar offset of the buffer store; rows below the image fall off the end of the per-image descriptor
+        const int col = (tid >> 3) & 15, row0 = tid >> 7;
+        const unsigned out_img_bytes = (unsigned)a.H * a.W * a.out_cs * 2u;
+        const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(p_out + (size_t)n * out_img_bytes, 0, out_img_bytes, 0x00020000);
+        const bool col_ok = nvalid > 0 && tx0 + col < a.W;
+        const unsigned vo = col_ok ? (unsigned)((((ty0 + row0) * a.W + tx0 + col) * a.out_cs + a.out_co + co0) * 2) : OOB;
+        const int rstep = 2 * a.W * a.out_cs * 2;
+        const bool full = ty0 + CB_T <= a.H;
+        f32x2 ps[4], pq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ps[e] = f32x2{st_s[2 * e], st_s[2 * e + 1]}; pq[e] = f32x2{st_q[2 * e], st_q[2 * e + 1]}; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int lp = (tid >> 3) + 32 * k;
+          u32x4 v = *reinterpret_cast<const u32x4*>(sO + lp * CB_OS_BF16 + item * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_out, vo, rstep * k, 0);
+          if (do_stats) {
+            const bool ok = col_ok && (full || ty0 + row0 + 2 * k < a.H);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t w = ok ? v[e] : 0u;
+              const f32x2 f = {bf16_lo(w), bf16_hi(w)};
+              ps[e] = pk_add(ps[e], f);
+              pq[e] = pk_fma(f, f, pq[e]);
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st_s[2 * e] = ps[e][0]; st_s[2 * e + 1] = ps[e][1]; st_q[2 * e] = pq[e][0]; st_q[2 * e + 1] = pq[e][1]; }
+      } else {
 #pragma unroll 4
       for (int k = 0; k < NPX / PSTEP; ++k) {
         const int lp = tid / TPP + PSTEP * k;
-        int row, col;
-        if (!OUT_F32) { row = lp >> 4; col = lp & 15; }
-        else {
-          int rr, cc;
-          cb_lane_pixel<HT>(lp & 31, rr, cc);
-          row = 4 * (lp >> 5) + 2 * round + rr; col = cc;
-        }
+        int rr, cc;
+        cb_lane_pixel<HT>(lp & 31, rr, cc);
+        const int row = 4 * (lp >> 5) + 2 * round + rr, col = cc;
         const int oy = ty0 + row, ox = tx0 + col;
         if (nvalid <= 0 || oy >= a.H || ox >= a.W) continue;
         const size_t eo = ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + co0;
-        if (!OUT_F32) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(sO + lp * CB_OS_BF16 + item * 16);
-          *reinterpret_cast<u32x4*>(p_out + eo * 2) = v;   // Cout % 8 == 0 (host-checked)
-          if (do_stats) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float f0 = bf16_lo(v[e]), f1 = bf16_hi(v[e]);
-              st_s[2 * e] += f0; st_q[2 * e] = fmaf(f0, f0, st_q[2 * e]);
-              st_s[2 * e + 1] += f1; st_q[2 * e + 1] = fmaf(f1, f1, st_q[2 * e + 1]);
-            }
-          }
-        } else {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(sO + lp * CB_OS_F32 + item * 16);
-          float* p = reinterpret_cast<float*>(p_out) + eo;
-          if (nvalid == 4) *reinterpret_cast<f32x4*>(p) = v;
-          else {
-            p[0] = v[0];
-            if (nvalid > 1) p[1] = v[1];
-            if (nvalid > 2) p[2] = v[2];
-          }
-          if (do_stats) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (e < nvalid) { st_s[e] += v[e]; st_q[e] = fmaf(v[e], v[e], st_q[e]); }
-          }
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sO + lp * CB_OS_F32 + item * 16);
+        float* p = reinterpret_cast<float*>(p_out) + eo;
+        if (nvalid == 4) *reinterpret_cast<f32x4*>(p) = v;
+        else {
+          p[0] = v[0];
+          if (nvalid > 1) p[1] = v[1];
+          if (nvalid > 2) p[2] = v[2];
         }
+        if (do_stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nvalid) { st_s[e] += v[e]; st_q[e] = fmaf(v[e], v[e], st_q[e]); }
+        }
+      }
       }
       if (!OUT_F32 && a.pool_out[0] != nullptr && nvalid > 0) {
         // raw 2x2-pooled copy: per-channel max (gamma >= 0) or min (gamma < 0) of the window, so that
@@ -386,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
         }
       }
     }
+    if (done) break;
   }
   if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
 }

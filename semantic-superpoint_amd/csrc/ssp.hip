@@ -2848,6 +2848,15 @@ int ssp_debug_occupancy(int which) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WgradWinoGeom<true>::LDS_BYTES);
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 512, WgradWinoGeom<true>::LDS_BYTES);
   }
+  else if (which == 3) {
+    auto k = conv_bf16_kernel<3, 1, false, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ConvBGeom<3>::LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, ConvBGeom<3>::LDS_BYTES);
+  } else if (which == 4) {
+    auto k = wgrad_bf16_kernel<3, 1, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WgradBGeom<3>::LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, WgradBGeom<3>::LDS_BYTES);
+  }
   if (e != hipSuccess) return fail(-2, "occupancy query failed: %s", hipGetErrorString(e));
   return n;
 }

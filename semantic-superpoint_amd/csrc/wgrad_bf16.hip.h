@@ -207,20 +207,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
       }
       __syncthreads();
     }
-    // ---- 16 image rows x taps: K = the 16 pixels of a row ----
+    // ---- 16 image rows x taps: K = the 16 pixels of a row.  The fragments of step s + 1 (the next tap's X, the next row's dY) are
+    // requested before the MFMA of step s is issued (two register sets, pinned with sched_barrier). ----
+    {
+      s16x8 fa[2], fb[2];
+      auto fetch_a = [&](int row) {
+        const unsigned char* pa = sD + baseA + row * 16 * 128;
+        return wb_tr_pair(pa, pa + 4 * 128);
+      };
+      auto fetch_b = [&](int row, int tap) {
+        const int dy = tap / KS, dx = tap % KS;
+        const int rho = (HT & 2) ? ((row + dy) & 1) : 0;   // bit 1 of the slot index flips with the halo row (pitch 18)
+        const unsigned char* pb = sX + (baseB[dx] ^ (rho << 6)) + ((row + dy) * HT + dx) * 128;
+        return wb_tr_pair(pb, pb + 4 * 128);
+      };
+      fa[0] = fetch_a(0);
+      fb[0] = fetch_b(0, 0);
 #pragma unroll 1
-    for (int ry = 0; ry < CB_T; ry += 2) {
+      for (int ry = 0; ry < CB_T; ry += 2) {
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const unsigned char* pa = sD + baseA + (ry + rr) * 16 * 128;
-        const s16x8 fa = wb_tr_pair(pa, pa + 4 * 128);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-          const int dy = tap / KS, dx = tap % KS;
-          const int rho = (HT & 2) ? ((rr + dy) & 1) : 0;   // bit 1 of the slot index flips with the halo row (pitch 18; ry is even)
-          const unsigned char* pb = sX + (baseB[dx] ^ (rho << 6)) + ((ry + rr + dy) * HT + dx) * 128;
-          const s16x8 fb = wb_tr_pair(pb, pb + 4 * 128);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+        for (int st = 0; st < 2 * TAPS; ++st) {   // (row parity, tap); ry is even, so the parities are compile-time
+          const int rr = st / TAPS, tap = st - rr * TAPS;
+          const int nst = st + 1, nrr = (nst / TAPS) & 1, ntap = nst % TAPS;
+          const bool last = st + 1 == 2 * TAPS;     // the next step is row ry + 2 (if any)
+          if (!last || ry + 2 < CB_T) {
+            const int nrow = last ? ry + 2 : ry + nrr;
+            fb[(st + 1) & 1] = fetch_b(nrow, ntap);
+            if (ntap == 0) fa[nrr] = fetch_a(nrow);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rr], fb[st & 1], acc[tap], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
