@@ -31,6 +31,17 @@ static int launch_conv_bf16_t(const ConvBArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
+template <int IN_MODE>
+static int launch_conv_bf16_ws_t(const ConvBArgs& a, int nblocks, hipStream_t st) {
+  static AttrOnce attr_once;
+  auto kern = conv_bf16_ws_kernel<IN_MODE>;
+  if (attr_once.need())
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ConvWsGeom::LDS_BYTES));
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), ConvWsGeom::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   ConvBArgs a;
   for (int k = 0; k < 2; ++k) {
@@ -58,6 +69,14 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   nblocks = std::max(nblocks, 8);
   static const int grid_env = getenv("SSP_CONVB_GRID") ? atoi(getenv("SSP_CONVB_GRID")) : 0;  // (perf-debug)
   if (grid_env > 0) nblocks = grid_env;
+  // the 3x3 layers with bf16 tensors at both ends: wave-specialised kernel, one 8-wave workgroup per CU (SSP_CONVB_WS=0: perf-debug A/B)
+  static const int ws_env = getenv("SSP_CONVB_WS") ? atoi(getenv("SSP_CONVB_WS")) : 1;
+  if (ws_env != 0 && c.ks == 3 && !c.in_f32 && !c.out_f32 && a.nchunks >= 2 && a.nchunks % 2 == 0 && c.cin % CB_KC == 0) {
+    int nb = (int)std::min<long>((long)n_cu, cdiv(units, 8) * 8L) / 8 * 8;
+    nb = std::max(nb, 8);
+    if (grid_env > 0) nb = grid_env;
+    return c.in_mode == 1 ? launch_conv_bf16_ws_t<1>(a, nb, st) : launch_conv_bf16_ws_t<0>(a, nb, st);
+  }
 #define CONVB_CASE(KS_, M_, I_, O_) \
   if (c.ks == KS_ && c.in_mode == M_ && c.in_f32 == I_ && c.out_f32 == O_) return launch_conv_bf16_t<KS_, M_, I_, O_>(a, nblocks, st);
   CONVB_CASE(3, 1, false, false) CONVB_CASE(3, 0, false, false) CONVB_CASE(1, 1, false, true) CONVB_CASE(1, 0, true, false)

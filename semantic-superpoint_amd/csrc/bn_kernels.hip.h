@@ -732,6 +732,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
 // Between the two passes: reduce the NREP replicas of the fp64 sums ONCE (one thread per channel) into
 // k12 = {S1/n, S2/n} for pass 2, and accumulate dgamma += S2, dbeta += S1.  (Letting every pass-2 thread sum the
 // 32 replicas itself cost a fixed ~110 us per launch: 2.6 ms per step in the first profiles.)
+template <typename T = float>  // element type of y / dout (the pool_fix scan is the only place that reads them)
 __global__ void bn_bwd_sums_kernel(const BnBwdArgs a0, const BnBwdArgs a1, int nviews, float* __restrict__ dgamma,
                                    float* __restrict__ dbeta) {
   // 32 lanes per channel (replica r each); lane 0 of the group writes.  grid: ceil(C * 32 / blockDim)
@@ -751,8 +752,14 @@ __global__ void bn_bwd_sums_kernel(const BnBwdArgs a0, const BnBwdArgs a1, int n
         const long npool = (long)a.N * Ho * Wo;
         for (long p = r; p < npool; p += 32) {
           const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((long)Wo * Ho));
-          const float y0 = a.y[((size_t)(n * a.H + 2 * oy) * a.W + 2 * ox) * a.y_cs + a.y_co + c];
-          part += (double)(a.dout[(size_t)p * a.d_cs + a.d_co + c] * ((y0 - a.mean[c]) * a.invstd[c]));
+          const size_t yi = ((size_t)(n * a.H + 2 * oy) * a.W + 2 * ox) * a.y_cs + a.y_co + c, di = (size_t)p * a.d_cs + a.d_co + c;
+          float y0, dv;
+          if constexpr (sizeof(T) == 4) { y0 = a.y[yi]; dv = a.dout[di]; }
+          else {
+            y0 = bf16_lo(reinterpret_cast<const uint16_t*>(a.y)[yi]);
+            dv = bf16_lo(reinterpret_cast<const uint16_t*>(a.dout)[di]);
+          }
+          part += (double)(dv * ((y0 - a.mean[c]) * a.invstd[c]));
         }
       }
 #pragma unroll

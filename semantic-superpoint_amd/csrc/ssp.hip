@@ -24,6 +24,7 @@
 #include "wgrad_wino_fused.hip.h"
 #include "conv_wino_bf16.hip.h"
 #include "conv_bf16.hip.h"
+#include "conv_bf16_ws.hip.h"
 #include "wgrad_bf16.hip.h"
 #include "loss_kernels.hip.h"
 #include "dense_loss.hip.h"
@@ -1127,7 +1128,7 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
   if (nb > 1024) nb = 1024;
   if (!sums_done)  // else: pass 1 was accumulated by the data-gradient conv that produced dOut
     hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(a0.C * 32, 256)), dim3(256), 0, st, a0, a1, nviews, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel<T>, dim3(cdiv(a0.C * 32, 256)), dim3(256), 0, st, a0, a1, nviews, dgamma, dbeta);
   if (!skip_apply)  // else: pass 2 rides the layer's weight gradient (wgrad_wino_fused_kernel)
     hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
   HIPCHK(hipGetLastError());
@@ -1638,7 +1639,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel<float>, h, SS.n, (long)N * H, W);
     if (!fused)  // else: S1 / S2 were accumulated by the data-gradient conv of layer 1 (setup_bnr)
       hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel<float>, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     hipLaunchKernelGGL(bn_bwd_apply_l0_kernel<float>, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                        Gd(h, d.w_off));
   } else if (relu && pool_after && have_pool && d.cout % 4 == 0 && d_cs == d.cout && d_co == 0) {
@@ -1656,7 +1657,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
       }
       hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[1]);
     }
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     // pass 2: inside the layer's weight gradient (it stages dY anyway and writes it for the data gradient) where possible
     // (the pooled layers 1, 3, 5 read the un-pooled activation of layers 0, 2, 4: input mode 1)
     const bool defer = l >= 1 && l < 8 && layer_in_mode(l) == 1 && dy_cs == d.cout && dy_co == 0 && SS.s[0]->y_cs[l] == d.cout &&
@@ -1788,14 +1789,31 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel<uint16_t>, h, SS.n, (long)N * H, W);
       const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel<uint16_t>, h, SS.n, (long)N * H, W);
       hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel<uint16_t>, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
-      hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
+      hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
       hipLaunchKernelGGL(bn_bwd_apply_l0_kernel<uint16_t>, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                          Gd(h, d.w_off));
       HIPCHK(hipGetLastError());
       continue;
     }
-    if (pool_after) CHK((launch_bn_bwd<true, true, uint16_t>(a, SS.n, dg, db, st)));
-    else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st)));
+    if (pool_after) {
+      // pass 1 from the raw pooled copy: the arg-max of z over a window IS that element (max for gamma >= 0, min for gamma < 0), so
+      // the ReLU-layer sums over the quarter-size tensors (Apool, dOut) equal the window-routed sums over Y; channels with
+      // gamma == 0 (xhat not recoverable from the pooled value) are repaired by bn_bwd_sums_kernel's scan over Y (pool_fix)
+      BnBwdArgs r[2];
+      for (int k = 0; k < SS.n; ++k) {
+        r[k] = a[k];
+        r[k].y = SS.s[k]->Apool[l]; r[k].H = lh / 2; r[k].W = lw / 2;
+        a[k].pool_fix = 1;
+      }
+      const BnBwdArgs &a0 = a[0], &a1 = a[SS.n - 1];
+      const long npix = (long)N * (lh / 2) * (lw / 2);
+      const int rows = 256 / (C / 4);
+      const int nb = (int)std::max(1L, std::min<long>(cdiv(npix, rows), 1024));
+      hipLaunchKernelGGL((bn_bwd_kernel<true, false, false, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[SS.n - 1]);
+      hipLaunchKernelGGL(bn_bwd_sums_kernel<uint16_t>, dim3(cdiv(C * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
+      hipLaunchKernelGGL((bn_bwd_kernel<true, true, true, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
+      HIPCHK(hipGetLastError());
+    } else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st)));
     // weight gradient: X = (pooled) raw output of layer l - 1 under its BatchNorm + ReLU, dY = gQ
     const int src = l - 1;
     const bool pooled_in = layer_in_mode(l) == 2;
