@@ -25,7 +25,9 @@ SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs : GRBM_GUI_ACTIVE / 8 XCDs, `traffic` the 
 WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md) - all three from rocprofv3 PMC child runs of this command made BEFORE
 this process touches the GPU (`--traffic live`, the default at N = 1 when rocprofv3 is on PATH; null if that fails).
 `cpu_baseline`: the oracle (oracle/cpu_ref.py, a restatement pinned against the reference) timed on this host's cores,
-rank 0, N = 1 only: batch 32, 1 warm-up + 3 timed steps.  `export`: BASELINE configs[4] beside the headline - 3 timed
+rank 0, N = 1 only: batch 32, 1 warm-up + 3 timed steps.  `bf16` (fp32 line, N = 1): BASELINE configs[3] per GPU - the same step on
+the bf16 path (conv algorithm 12), 5 + 20 steps after the fp32 measurement, with its own `roofline` (bound "hbm": algorithmic bytes
+of the dominant kernel against 8 TB/s, PMC traffic from two more child passes); `--dtype bf16` makes that path the line.  `export`: BASELINE configs[4] beside the headline - 3 timed
 ssp_export_points calls (2 images x 100 views, 480x640) after everything else; never part of `value`.
 """
 import argparse
@@ -48,7 +50,9 @@ PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 (only used for the opt-in --conv-algo 3 line)
 # 3x3 kernels whose PMC counters are reported (name substrings of the rocprofv3 kernel names)
 PMC_KERNELS = ("conv_wino4_kernel", "conv_wino_pipe_kernel", "conv_wino_p2_kernel", "wgrad_wino4_kernel", "wgrad_wino_kernel",
-               "conv_wino_bf16_kernel", "wgrad_wino_bf16_kernel", "conv_mfma_kernel<3", "wgrad_mfma_kernel<3", "conv_wino_kernel")
+               "conv_wino_bf16_kernel", "wgrad_wino_bf16_kernel", "conv_mfma_kernel<3", "wgrad_mfma_kernel<3", "conv_wino_kernel",
+               "conv_bf16_ws_kernel", "conv_bf16_kernel<3", "wgrad_bf16_kernel<3")
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s measured with a float4 copy)
 N_SIMD, N_XCD = 1024, 8  # MI355X: 256 CUs x 4 SIMDs in 8 XCDs
 
 
@@ -71,6 +75,111 @@ def cpu_baseline(arch, H, W, batch=32, steps=3):
     return {"value": round(batch / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
             "sample": "oracle/cpu_ref.py Trainer, %s %dx%d batch %d, 1 warm-up + %d timed steps (%.2f s/step)"
                       % (arch, H, W, batch, steps, dt)}
+
+
+def roofline_block(prof_kernels, pmc, pmc_note, conv_algo, n_prof_steps, steps):
+    """`roofline` of a measured line from the per-kernel HIP-event timings of the library (Engine.profile_read_kernels) and the
+    PMC child runs.  fp32 kernels: bound "mfma" - multiplies EXECUTED on the matrix cores per second against the fp32 MFMA peak.
+    Kernels of the bf16 path (conv_bf16*, wgrad_bf16): bound "hbm" - ALGORITHMIC bytes (each tensor once: bf16 input + output, resp.
+    input + dY) per second against 8 TB/s; their matrix-core rate against the dense bf16 peak rides along as mfma_tflops / mfma_frac."""
+    what = {"conv_wino4_kernel": "3x3 forward + data gradient, Winograd F(4x4,3x3): 1/4 of the direct multiplies",
+            "conv_wino_pipe_kernel": "3x3 forward + data gradient, Winograd F(2x2,3x3): 16/36",
+            "conv_wino_p2_kernel": "3x3 forward + data gradient on the 30x40 maps, Winograd F(2x2,3x3): 16/36",
+            "wgrad_wino_kernel": "3x3 weight gradient, Winograd F(3x3,2x2): 16/36",
+            "wgrad_wino4_kernel": "3x3 weight gradient, Winograd F(3x3,4x4): 1/4",
+            "other": "direct implicit GEMM / bf16-operand Winograd kernels",
+            "conv_bf16_kernel": "3x3 forward + data gradient of the bf16 path: direct implicit GEMM on v_mfma_f32_32x32x16_bf16, bf16 tensors",
+            "wgrad_bf16_kernel": "3x3 weight gradient of the bf16 path: K = pixels through ds_read_b64_tr_b16"}
+    pmc_name = {"conv_bf16_kernel": "conv_bf16_kernel<3", "wgrad_bf16_kernel": "wgrad_bf16_kernel<3"}
+    reduced = conv_algo in (3, 7, 8)
+    mult = {7: 3.0}.get(conv_algo, 1.0)  # the split-bf16 mode 7 issues 3 bf16 MFMAs per product block
+    kernels = {}
+    for name, k in prof_kernels.items():
+        if k["ms"] <= 0:
+            continue
+        sec = k["ms"] * 1e-3
+        c = pmc.get(pmc_name.get(name, name), {})
+        e = {"what": what.get(name, ""), "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 4),
+             "ms_per_step": round(k["ms"] / n_prof_steps, 3), "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]),
+             "traffic": None if c.get("traffic") is None else round(c["traffic"])}
+        if name in ("conv_bf16_kernel", "wgrad_bf16_kernel"):
+            gbs = k["bytes"] / sec / 1e9
+            tf = k["flops"] / sec / 1e12
+            e.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                      "mfma_tflops": round(tf, 1), "mfma_frac": round(tf / PEAK_BF16_MFMA_TF, 4),
+                      "traffic_gbs": None if c.get("traffic") is None else round(c["traffic"] * k["launches"] / sec / 1e9, 1)})
+        else:
+            alg, ex = k["flops"] / sec / 1e12, (mult if name == "other" else 1.0) * k["exec_flops"] / sec / 1e12
+            # per-kernel peak: the fp32 kernel families price against the fp32 MFMA peak under every algorithm (the mixed bf16
+            # mode runs its forward on them); only the bf16-operand bucket of a reduced-precision line uses the bf16 peak
+            kpeak = PEAK_BF16_MFMA_TF if (reduced and name == "other") else PEAK_FP32_MFMA_TF
+            e.update({"bound": "mfma", "peak": kpeak, "unit": "TFLOP/s", "algorithmic_tflops": round(alg, 2),
+                      "algorithmic_frac": round(alg / kpeak, 4), "executed_tflops": round(ex, 2), "executed_frac": round(ex / kpeak, 4),
+                      "achieved": round(ex, 2), "frac": round(ex / kpeak, 4),
+                      "mfma_busy": None if c.get("mfma_busy") is None else round(c["mfma_busy"], 4)})
+        kernels[name] = e
+    if not kernels:
+        return None
+    dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])  # the kernel with the most time per step
+    d = kernels[dom]
+    rl = {"bound": d["bound"], "kernel": "%s (%s)" % (dom, d["what"]), "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+          "frac": d["frac"], "traffic": d["traffic"], "pmc_source": pmc_note,
+          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "launches": d["launches"],
+          "avg_launch_ms": d["avg_launch_ms"], "ms_per_step": d["ms_per_step"],
+          "bracketed_steps": "%d of the %d timed steps" % (n_prof_steps, steps), "kernels": kernels}
+    if d["bound"] == "mfma":
+        rl["note"] = ("achieved / frac = multiplies EXECUTED on the matrix cores per second / fp32 MFMA peak (the hardware fraction); "
+                      "algorithmic_* = direct-convolution FLOPs / time, which Winograd undercuts by 4x resp. 36/16, so that ratio may exceed 1")
+        for f in ("algorithmic_tflops", "algorithmic_frac", "executed_tflops", "executed_frac", "mfma_busy"):
+            rl[f] = d[f]
+    else:
+        rl["note"] = ("achieved = ALGORITHMIC bytes of the launches (bf16 input + output of each 3x3 convolution, once) / their time, "
+                      "against the 8 TB/s HBM3E spec; traffic = HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE); "
+                      "mfma_* = direct-convolution FLOPs / time against the dense bf16 MFMA peak")
+        rl["mfma_tflops"], rl["mfma_frac"], rl["traffic_gbs"] = d["mfma_tflops"], d["mfma_frac"], d["traffic_gbs"]
+    return rl
+
+
+def bf16_block(Engine, arch, B, H, W, dev, sample, args, fp32_pairs_s, pmc16, pmc_note, dense, steps=20, warmup=5):
+    """The pair step of the headline on the bf16 path (one GPU): pairs/s, ratio to the fp32 line of this run, `roofline` with the
+    HBM bound of its dominant kernel (HIP events on every 4th step, PMC traffic from two child passes)."""
+    import torch
+    from semantic_superpoint_amd import synth
+    from semantic_superpoint_amd.lib import layer_table, SCALAR_NAMES
+    eng = Engine(arch, B, H, W, dev, dense_loss=dense is not None)
+    eng.set_conv_algo(12)
+    eng.load_state_dict(synth.default_init_state_dict(layer_table(arch), seed=0))
+
+    def step(it):
+        eng.zero_grad()
+        eng.pair_step(sample, indices=None, seed=(it * 1000003 + 1), train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True, dense=dense)
+        eng.adam_step(args.lr)
+    for it in range(warmup):
+        step(it)
+    torch.cuda.synchronize()
+    eng.profile_enable("conv3x3_every")
+    t0 = time.perf_counter()
+    for it in range(steps):
+        eng.profile_pause(it % 4 != 0)
+        step(warmup + it)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pairs_s = B * steps / dt
+    scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
+    blk = {"metric": "image-pairs/sec, the same pair step on the bf16 path (BASELINE configs[3] per GPU)", "value": round(pairs_s, 2),
+           "unit": "image-pairs/s", "dtype": "bf16", "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
+           "vs_fp32_line": round(pairs_s / fp32_pairs_s, 3), "final_loss": round(scal["loss"], 4),
+           "config": "conv algorithm 12: bf16 NHWC activations / activation gradients in HBM, every convolution (3x3 and 1x1; forward, data and "
+                     "weight gradient) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; first layer fp32 arithmetic; BatchNorm "
+                     "statistics, losses, master weights and Adam fp32"}
+    n_prof = len([i for i in range(steps) if i % 4 == 0])
+    rl = roofline_block(eng.profile_read_kernels(), pmc16, pmc_note, 12, n_prof, steps)
+    if rl is not None:
+        blk["roofline"] = rl
+    eng.profile_enable("none")
+    del eng
+    torch.cuda.empty_cache()
+    return blk
 
 
 def parse_args(argv=None):
@@ -106,9 +215,11 @@ def parse_args(argv=None):
                          "before the timed run; auto = live when N = 1, rocprofv3 is on PATH and the roofline leg is on")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of --traffic live
     ap.add_argument("--no-export", action="store_true", help="skip the `export` block (BASELINE configs[4], 3 calls at 100 x 480x640)")
+    ap.add_argument("--no-bf16", action="store_true",
+                    help="skip the `bf16` block of the fp32 line (BASELINE configs[3] per GPU: the same step on the bf16 path, conv algorithm 12)")
     args = ap.parse_args(argv)
     if args.dtype is not None:
-        args.conv_algo = {"f32": 1, "bf16": 8}[args.dtype]
+        args.conv_algo = {"f32": 1, "bf16": 12}[args.dtype]
     return args
 
 
@@ -170,7 +281,7 @@ def spawn_ranks(args, script=None, argv=None, timeout=None):
 # ------------------------------------------------------------------------------------------------
 # PMC counters measured in this run: rocprofv3 passes over a short child run of the same workload
 # ------------------------------------------------------------------------------------------------
-def live_pmc(args):
+def live_pmc(args, conv_algo=None, counter_sets=(("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))):
     """Per 3x3 kernel: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB -> bytes (separate PMC passes, FETCH doubled:
     gfx950 counts wide coalesced reads at half, MI355X_MICROARCH.md section HBM) and the matrix-pipe occupancy
     SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs : GRBM_GUI_ACTIVE / 8 XCDs (third pass).
@@ -180,13 +291,13 @@ def live_pmc(args):
         return {}, "rocprofv3 not on PATH"
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "1", "--gpus", "1",
              "--arch", args.arch, "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
-             "--conv-algo", str(args.conv_algo), "--desc-loss", args.desc_loss, "--no-cpu-baseline", "--no-roofline",
-             "--traffic", "none", "--no-export"]
+             "--conv-algo", str(args.conv_algo if conv_algo is None else conv_algo), "--desc-loss", args.desc_loss,
+             "--no-cpu-baseline", "--no-roofline", "--traffic", "none", "--no-export", "--no-bf16"]
     tot = {}  # kernel -> counter -> [sum, set(dispatch ids)]
     tmp = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
     notes = []
     try:
-        for ctrs in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")):
+        for ctrs in counter_sets:
             d = os.path.join(tmp, ctrs[0])
             cmd = [rocprof, "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
             try:
@@ -203,7 +314,9 @@ def live_pmc(args):
                 notes.append("no counter_collection.csv for %s" % " ".join(ctrs))
                 continue
             for row in csv.DictReader(open(files[0])):
-                k = next((k for k in PMC_KERNELS if k in row["Kernel_Name"].replace("wgrad_wino_fused_kernel", "wgrad_wino_kernel")), None)
+                kn = row["Kernel_Name"].replace("wgrad_wino_fused_kernel", "wgrad_wino_kernel")
+                kn = kn.replace("conv_bf16_ws_kernel", "conv_bf16_kernel<3")   # (one bucket: the 3x3 forward / data-gradient launches)
+                k = next((k for k in PMC_KERNELS if k in kn), None)
                 if k is None or row["Counter_Name"] not in ctrs:
                     continue
                 e = tot.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, set()])
@@ -246,8 +359,12 @@ def main():
 
     pmc, pmc_note = {}, "not collected"
     want_live = args.traffic == "live" or (args.traffic == "auto" and not args.no_roofline and not args.pmc_child)
+    pmc16 = {}
+    want_bf16_block = (world == 1 and rank == 0 and args.conv_algo == 1 and not args.no_bf16 and not args.pmc_child)
     if want_live and world == 1:
         pmc, pmc_note = live_pmc(args)  # child processes; this process has not touched the GPU yet
+        if want_bf16_block:  # HBM traffic of the bf16 path's kernels: two more passes
+            pmc16, _ = live_pmc(args, conv_algo=12, counter_sets=(("FETCH_SIZE",), ("WRITE_SIZE",)))
 
     import torch
     import torch.distributed as dist
@@ -346,9 +463,9 @@ def main():
         prec = {3: ("bf16", "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)"),
                 7: ("bf16x2", "split-bf16 (hi + lo = 16 significant bits) matrix-core operands, three bf16 MFMAs per product / "
                               "fp32 accumulate + master (NOT the headline precision)"),
-                12: ("bf16", "bf16 path: bf16 NHWC activations / activation gradients in HBM, direct 3x3 convolutions, data and weight "
-                             "gradients on v_mfma_f32_32x32x16_bf16; fp32 accumulate, BatchNorm statistics, losses, master weights, Adam; "
-                             "pointwise heads fp32 (NOT the headline precision)"),
+                12: ("bf16", "bf16 path: bf16 NHWC activations / activation gradients in HBM, every convolution (forward, data and weight "
+                             "gradient) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 BatchNorm statistics, losses, master "
+                             "weights, Adam (BASELINE configs[3] per GPU; NOT the fp32 headline precision)"),
                 8: ("bf16", "mixed bf16: fp32 forward, data / weight gradients of the 3x3 layers with bf16 matrix-core operands; "
                             "fp32 tensors, accumulate, BatchNorm, master weights, Adam (NOT the headline precision)")
                 }.get(args.conv_algo, ("f32", "fp32"))
@@ -367,56 +484,23 @@ def main():
                "rccl_ranks": rccl_ranks,
                "step_tflops": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3, 2),
                "step_frac_of_fp32_mfma_peak": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3 / (PEAK_FP32_MFMA_TF * world), 4),
-               "final_loss": round(scal["loss"], 4)}
+               "final_loss": round(scal["loss"], 4), "build_id": ssp.lib.build_id()[:16]}
         if profiled:
-            peak = PEAK_BF16_MFMA_TF if reduced else PEAK_FP32_MFMA_TF
-            # the split-bf16 mode 7 issues 3 bf16 MFMAs per product block (hi + lo operands); the mixed mode 8 one (its forward is fp32)
-            mult = {7: 3.0}.get(args.conv_algo, 1.0)
-            what = {"conv_wino4_kernel": "3x3 forward + data gradient, Winograd F(4x4,3x3): 1/4 of the direct multiplies",
-                    "conv_wino_pipe_kernel": "3x3 forward + data gradient, Winograd F(2x2,3x3): 16/36",
-                    "conv_wino_p2_kernel": "3x3 forward + data gradient on the 30x40 maps, Winograd F(2x2,3x3): 16/36",
-                    "wgrad_wino_kernel": "3x3 weight gradient, Winograd F(3x3,2x2): 16/36",
-                    "wgrad_wino4_kernel": "3x3 weight gradient, Winograd F(3x3,4x4): 1/4",
-                    "other": "direct implicit GEMM / bf16-operand kernels"}
-            kernels = {}
             n_prof_steps = len([i for i in range(args.steps) if i % PROF_EVERY == 0])  # the bracketed steps of the timed region
-            for name, k in eng.profile_read_kernels().items():
-                if k["ms"] <= 0:
-                    continue
-                sec = k["ms"] * 1e-3
-                alg, ex = k["flops"] / sec / 1e12, (mult if name == "other" else 1.0) * k["exec_flops"] / sec / 1e12
-                c = pmc.get(name, {})
-                # per-kernel peak: the fp32 kernel families price against the fp32 MFMA peak under every algorithm (the mixed bf16
-                # mode runs its forward on them); only the bf16-operand bucket of a reduced-precision line uses the bf16 peak
-                kpeak = PEAK_BF16_MFMA_TF if (reduced and name == "other") else PEAK_FP32_MFMA_TF
-                kernels[name] = {"what": what.get(name, ""), "launches": k["launches"], "peak": kpeak,
-                                 "avg_launch_ms": round(k["ms"] / k["launches"], 4),
-                                 "ms_per_step": round(k["ms"] / n_prof_steps, 3),
-                                 "algorithmic_tflops": round(alg, 2), "algorithmic_frac": round(alg / kpeak, 4),
-                                 "executed_tflops": round(ex, 2), "executed_frac": round(ex / kpeak, 4),
-                                 "frac": round(ex / kpeak, 4),
-                                 "mfma_busy": None if c.get("mfma_busy") is None else round(c["mfma_busy"], 4),
-                                 "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]),
-                                 "traffic": None if c.get("traffic") is None else round(c["traffic"])}
-            if kernels:
-                dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])  # the kernel with the most time per step
-                d = kernels[dom]
-                out["roofline"] = {"bound": "mfma", "kernel": "%s (%s; v_mfma_f32_32x32x2_f32)" % (dom, d["what"]),
-                                   "achieved": d["executed_tflops"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["executed_frac"],
-                                   "note": "achieved / frac = multiplies EXECUTED on the matrix cores per second / fp32 MFMA peak "
-                                           "(the hardware fraction); algorithmic_* = direct-convolution FLOPs / time, which "
-                                           "Winograd undercuts by 4x resp. 36/16, so that ratio may exceed 1",
-                                   "algorithmic_tflops": d["algorithmic_tflops"], "algorithmic_frac": d["algorithmic_frac"],
-                                   "executed_tflops": d["executed_tflops"], "executed_frac": d["executed_frac"],
-                                   "mfma_busy": d["mfma_busy"], "traffic": d["traffic"], "pmc_source": pmc_note,
-                                   "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                                   "launches": d["launches"], "avg_launch_ms": d["avg_launch_ms"],
-                                   "ms_per_step": d["ms_per_step"], "bracketed_steps": "%d of the %d timed steps" % (n_prof_steps, args.steps),
-                                   "kernels": kernels}
+            rl = roofline_block(eng.profile_read_kernels(), pmc, pmc_note, args.conv_algo, n_prof_steps, args.steps)
+            if rl is not None:
+                out["roofline"] = rl
             eng.profile_enable("none")
             profiling[0] = False
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch, H, W, batch=B)
+        if want_bf16_block:
+            # BASELINE configs[3] per GPU beside the fp32 headline (never part of `value`): the same step, same inputs, on the bf16
+            # path (conv algorithm 12: bf16 activations in HBM, bf16 matrix cores, fp32 accumulate / statistics / master / Adam)
+            try:
+                out["bf16"] = bf16_block(Engine, arch, B, H, W, dev, sample, args, pairs_s, pmc16, pmc_note, dense)
+            except Exception as e:  # the headline line must survive a failure of the side measurement
+                out["bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_export and not args.pmc_child:
             # BASELINE configs[4] next to the headline (never part of `value`): the training engine is released first
             try:

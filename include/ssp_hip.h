@@ -105,6 +105,8 @@ enum {
 };
 
 const char* ssp_last_error(void);
+/* sha256 of the library's source files (csrc/*.hip, csrc/*.hip.h, include/ssp_hip.h) at build time: hipbuild.source_id() */
+const char* ssp_build_id(void);
 int ssp_create(const ssp_config* cfg, ssp_handle** out);
 void ssp_destroy(ssp_handle* h);
 size_t ssp_param_count(const ssp_handle* h);       /* net parameters (without eta) */

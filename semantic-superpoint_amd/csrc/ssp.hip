@@ -322,7 +322,7 @@ static size_t carve(ssp_handle* h, void* base) {
     h->wpk_g1_fwd[i] = c.take<float>((size_t)cdiv(d.cin, G1_KC) * cdiv(d.cout, 32) * G1_TILE_FLOATS);
     h->wpk_g1_bwd[i] = c.take<float>((size_t)cdiv(d.cout, G1_KC) * cdiv(d.cin, 32) * G1_TILE_FLOATS);
   }
-  h->g1_partial_slabs = 2 * 512;  // up to 512 CUs
+  h->g1_partial_slabs = 2 * std::max(h->n_cu, 8);  // launch_g1_wgrad uses at most 2 workgroups per CU
   h->g1_partial = c.take<float>((size_t)h->g1_partial_slabs * G1W_SLAB);
   for (int s = 0; s < 2; ++s) {
     Slot& S = h->slot[s];
@@ -1153,12 +1153,24 @@ static int l0_resident_grid(K kern, const ssp_handle* h, int nviews, long rows, 
 
 #include "bf16_host.hip.h"
 
+static int ensure_aux_stream(ssp_handle* h);
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
 const char* ssp_last_error(void) { return g_err.c_str(); }
+
+// sha256 of the library's sources at build time (hipbuild.source_id(): -DSSP_BUILD_ID); the marker prefix lets tools read it
+// from the file without loading it
+#ifndef SSP_BUILD_ID
+#define SSP_BUILD_ID "unknown"
+#endif
+const char* ssp_build_id(void) {
+  static const char marker[] = "SSP_BUILD_ID=" SSP_BUILD_ID;
+  return marker + 13;
+}
 
 int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   if (!cfg || !out) return fail(-1, "null argument");
@@ -1177,13 +1189,9 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   AlgoScope algo(h);
   build_layers(h);
   h->bound = false;
+  h->n_cu = device_cu_count();   // (before carve: the workspace layout depends on it)
   h->ws_bytes = carve(h, nullptr);
   h->prof_family = 0; h->ev_used = 0; h->prof_flops = h->prof_bytes = h->prof_exec_flops = 0; h->prof_launches = 0;
-  h->n_cu = 256;
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    h->n_cu = prop.multiProcessorCount;
   *out = h;
   return 0;
 }
@@ -1213,6 +1221,7 @@ int ssp_bind(ssp_handle* h, const ssp_buffers* b, void* stream) {
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);  // captured pointers are stale after a re-bind
   h->graphs.clear();
   carve(h, b->workspace_dev);
+  CHK(ensure_aux_stream(h));  // (never created lazily inside a stream capture)
   // padding channels (65->80, n_classes->sout_cs) must read as zero forever: clear everything once
   HIPCHK(hipMemsetAsync(b->workspace_dev, 0, h->ws_bytes, (hipStream_t)stream));
   h->bound = true;
@@ -1426,6 +1435,29 @@ static int ensure_aux_stream(ssp_handle* h) {
   return 0;
 }
 
+// Fork / join of the handle's side stream: the destructor records the join event on the side stream and makes `st` wait for it
+// unless join() already did - so an error return between fork and join neither leaves side-stream kernels racing with later
+// work on `st` nor ends a stream capture with an unjoined fork (which would mask the original error).
+struct SideFork {
+  hipStream_t st, side; hipEvent_t ev_join; bool open;
+  SideFork() : st(nullptr), side(nullptr), ev_join(nullptr), open(false) {}
+  int fork(hipStream_t st_, hipStream_t side_, hipEvent_t ev_fork, hipEvent_t ev_join_) {
+    st = st_; side = side_; ev_join = ev_join_;
+    HIPCHK(hipEventRecord(ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
+    open = true;
+    return 0;
+  }
+  int join() {
+    if (!open) return 0;
+    open = false;
+    HIPCHK(hipEventRecord(ev_join, side));
+    HIPCHK(hipStreamWaitEvent(st, ev_join, 0));
+    return 0;
+  }
+  ~SideFork() { (void)join(); }
+};
+
 // One or two activation slots processed together: the two views of a pair are independent problems of identical
 // shape that share the weights, so the MFMA kernels take both in ONE launch (conv: XCDs 0-3 / 4-7; wgrad: one
 // gradient accumulated over both) while the BatchNorm statistics stay per view (Train_model_heatmap_all.py:258,262).
@@ -1529,12 +1561,11 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   // HBM-bound first-layer convolution, which needs none of them; layer 1 waits for the join.
   static const int pack_stream_env = getenv("SSP_PACK_STREAM") ? atoi(getenv("SSP_PACK_STREAM")) : 1;  // (perf-debug: 0 = in line)
   const bool pack_forked = pack_stream_env != 0;
+  SideFork pack_fork;
   if (pack_forked) {
     CHK(ensure_aux_stream(h));
-    HIPCHK(hipEventRecord(h->ev_pack_fork, st));
-    HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_pack_fork, 0));
+    CHK(pack_fork.fork(st, h->aux_stream, h->ev_pack_fork, h->ev_pack_join));
     CHK(pack_all(h, for_backward, SS.n, N, H, W, h->aux_stream));
-    HIPCHK(hipEventRecord(h->ev_pack_join, h->aux_stream));
   } else {
     CHK(pack_all(h, for_backward, SS.n, N, H, W, st));
   }
@@ -1553,7 +1584,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     HIPCHK(hipGetLastError());
     CHK(bn_finalize(h, SS.s, SS.n, 0, (double)N * H * W, train, st));
   }
-  if (pack_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_pack_join, 0));
+  CHK(pack_fork.join());
   for (int l = 1; l < 8; ++l) {
     int lh, lw; layer_res(l, H, W, lh, lw);
     CHK(conv_layer_fwd(h, SS, l, l - 1, N, lh, lw, layer_in_mode(l), train, st));
@@ -1627,6 +1658,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
   }
   const bool fused = h->bsums_fused[l];  // pass 1 already sits in bsums (conv_layer_backward of the layer above)
   h->bsums_fused[l] = false;
+  h->apply_fused[l] = false;             // set below only by the branches that leave pass 2 to the weight gradient
   const bool raw_pool = pool_after && l < 8 && SS.s[0]->pool_raw[l];
   if ((fused || raw_pool) && pool_after)  // S2 of gamma == 0 channels comes from a scan over Y (bn_bwd_sums_kernel)
     for (int k = 0; k < SS.n; ++k) a[k].pool_fix = 1;
@@ -1963,7 +1995,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
     return flush_wgrad_reduce(h, st);  // the pending Winograd weight-gradient slabs -> OIHW gradients, one launch
   };
   if (part == 2) return encoder(EARLY_SPLIT_LAYER - 1, 0);
-  for (int l = 0; l < 16; ++l) h->bsums_fused[l] = false;
+  for (int l = 0; l < 16; ++l) h->bsums_fused[l] = h->apply_fused[l] = false;  // (a failed / aborted pass must not leave a flag behind)
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     // the forward's single memset of the statistics region also cleared the backward sums; clear them again only
@@ -2233,11 +2265,11 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   static const int loss_stream_env = getenv("SSP_LOSS_STREAM") ? atoi(getenv("SSP_LOSS_STREAM")) : 1;  // (perf-debug: 0 = one stream)
   hipStream_t sd = st;
   const bool forked = loss_stream_env != 0 && use_desc && !dense;  // (the dense loss reads the cell mask of the main stream's kernels)
+  SideFork loss_fork;
   if (forked) {
     CHK(ensure_aux_stream(h));
     sd = h->aux_stream;
-    HIPCHK(hipEventRecord(h->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(sd, h->ev_fork, 0));
+    CHK(loss_fork.fork(st, sd, h->ev_fork, h->ev_join));
   }
   if (dense) {  // utils/utils.py:779-893: Gram matrix + loss sums + d total / d dot, then the two backward GEMMs
     Slot &A = h->slot[0], &Bs = h->slot[1];
@@ -2307,10 +2339,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     }
     HIPCHK(hipGetLastError());
   }
-  if (forked) {  // join: the scalars and the backward pass need both loss families
-    HIPCHK(hipEventRecord(h->ev_join, sd));
-    HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
-  }
+  CHK(loss_fork.join());  // the scalars and the backward pass need both loss families
   hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(64), 0, st, h->accum, eta,
                      in->train ? h->buf.grads_dev + h->n_params : (float*)nullptr, scalars_dev, B, h->cfg.n_match,
                      in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train, (int)dense, Hc * Wc);
@@ -2504,7 +2533,7 @@ int ssp_op_conv_wgrad(const float* in_dev, const float* dout_dev, float* dw_oihw
     y.x[0] = in_dev; y.x_cs = cin; y.x_co = 0; y.scale[0] = in_scale_dev; y.shift[0] = in_shift_dev; y.dy[0] = dout_dev;
     y.dy_cs = cout; y.dy_co = 0; y.dw = dw_oihw_dev; y.N = cout;
     return launch_g1_wgrad(&y, 1, 1, (long)n * hh * w, reinterpret_cast<float*>(workspace_dev),
-                           (int)std::min<size_t>(workspace_bytes / (G1W_SLAB * sizeof(float)), 512), 256, (hipStream_t)stream);
+                           (int)std::min<size_t>(workspace_bytes / (G1W_SLAB * sizeof(float)), 512), device_cu_count(), (hipStream_t)stream);
   }
   WgradCall c;
   c.in = in_dev; c.in_cs = cin; c.in_co = 0; c.cin = cin; c.dout = dout_dev; c.dout_cs = cout; c.dout_co = 0; c.cout = cout;

@@ -31,17 +31,45 @@ FIXED_AGPR_KERNELS = {
 }
 
 
+class MissingTool(RuntimeError):
+    """an LLVM binary utility needed by verify_binary is not installed"""
+
+
 def _sources():
     out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") or f.endswith(".hip.h")]
     out.append(os.path.join(HERE, "..", "include", "ssp_hip.h"))
     return out
 
 
+def source_id():
+    """sha256 over the names and contents of every source file of the library (csrc/*.hip, csrc/*.hip.h, include/ssp_hip.h):
+    the BUILD ID.  build() compiles it into the library (-DSSP_BUILD_ID, returned by ssp_build_id()), so a loaded binary can
+    be tied to the checked-out sources by content instead of by modification time."""
+    h = hashlib.sha256()
+    for p in _sources():
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def library_id(lib_path=LIB):
+    """The build id compiled into `lib_path` (read from the file: the marker string SSP_BUILD_ID=<hex>), or None."""
+    try:
+        with open(lib_path, "rb") as f:
+            data = f.read()
+    except OSError:
+        return None
+    m = re.search(rb"SSP_BUILD_ID=([0-9a-f]{64})", data)
+    return m.group(1).decode() if m else None
+
+
 def _stale():
+    """True when there is no library or its compiled-in build id differs from the hash of the checked-out sources."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in _sources())
+    return library_id(LIB) != source_id()
 
 
 def hipcc_path():
@@ -62,7 +90,7 @@ def _sha256(path):
 def _tool(name):
     p = os.path.join(LLVM_BIN, name)
     if not os.path.exists(p):
-        raise RuntimeError("%s not found: cannot verify the accumulation-register contract of %s" % (p, LIB))
+        raise MissingTool("%s not found: cannot verify the accumulation-register contract of %s" % (p, LIB))
     return p
 
 
@@ -115,16 +143,22 @@ def verify_binary(lib_path=LIB, expected=None, require_all=None):
         if n == 0 and require_all:
             raise RuntimeError("no %s instance found in %s" % (fam, lib_path))
     # kernel descriptors: no private segment, no vector-register spills
+    seen_notes = set()
     for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
-        m = re.search(r"\.name:\s+(\S+)", blk)
+        m = re.search(r"\.symbol:\s+(\S+?)\.kd", blk)  # (the kernel's own symbol: `.name:` also occurs in the argument metadata)
         if not m or not any(k in m.group(1) for k in expected):
             continue
+        seen_notes.add(next(k for k in expected if k in m.group(1)))
         seg = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
         agpr = int(re.search(r"^\s*(\d+)", blk).group(1))
         if seg != 0 or spill != 0 or agpr != 256:
             raise RuntimeError("%s: private segment %d B, %d spilled vector registers, %d accumulation registers reserved "
                                "(need 0 / 0 / 256)" % (m.group(1), seg, spill, agpr))
+    for fam, n in found.items():
+        if n > 0 and fam not in seen_notes:
+            raise RuntimeError("%s is in the disassembly of %s but its kernel descriptor was not found in the notes: the "
+                               "spill / private-segment check did not run" % (fam, lib_path))
     return report
 
 
@@ -153,7 +187,7 @@ def build(force=False, verbose=False):
             verify_and_stamp()
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-           "ssp.hip", "-o", "libssp_hip.so"] + os.environ.get("SSP_HIPCC_EXTRA", "").split()
+           "-DSSP_BUILD_ID=\"%s\"" % source_id(), "ssp.hip", "-o", "libssp_hip.so"] + os.environ.get("SSP_HIPCC_EXTRA", "").split()
     r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0 or verbose:
         print(r.stdout)

@@ -71,7 +71,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
-           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16", "ssp_op_bn_bwd_bf16"]
+           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16", "ssp_op_bn_bwd_bf16", "ssp_build_id"]
 
 
 def load_library(path=None):
@@ -89,11 +89,19 @@ def load_library(path=None):
     if os.environ.get("SSP_SKIP_ISA_VERIFY") != "1" and not _build.verified(path):  # the binary about to be loaded (e.g. shipped to the GPU box) keeps the register contract
         try:
             _build.verify_and_stamp(path)
+        except _build.MissingTool as e:
+            raise RuntimeError("%s - cannot check the accumulation-register contract of %s; set SSP_SKIP_ISA_VERIFY=1 to load it "
+                               "unchecked" % (e, path)) from e
         except OSError:  # read-only tree: verified, not stamped
             _build.verify_binary(path)
     lib = C.CDLL(path)
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     lib.ssp_last_error.restype = C.c_char_p
+    try:
+        lib.ssp_build_id.restype = C.c_char_p
+    except AttributeError:
+        if os.environ.get("SSP_HIP_LIB") is None:
+            raise
     lib.ssp_create.argtypes = [C.POINTER(SspConfig), C.POINTER(vp)]
     lib.ssp_destroy.argtypes = [vp]
     lib.ssp_destroy.restype = None
@@ -127,8 +135,12 @@ def load_library(path=None):
     except AttributeError:
         if os.environ.get("SSP_HIP_LIB") is None:
             raise
-    lib.ssp_profile_read_kernel.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
-                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    try:
+        lib.ssp_profile_read_kernel.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                                C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    except AttributeError:
+        if os.environ.get("SSP_HIP_LIB") is None:
+            raise
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
     lib.ssp_op_conv_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, vp, vp, C.c_size_t, vp]
@@ -168,6 +180,11 @@ def load_library(path=None):
     lib.ssp_op_dense_loss.argtypes = [vp, vp, vp, vp, i, i, i, f, f, i, f, vp, C.c_size_t, vp, vp, vp, vp]
     _lib = lib
     return lib
+
+
+def build_id():
+    """Build id of the LOADED library (sha256 of its sources at build time); equals hipbuild.source_id() for the in-tree library."""
+    return load_library().ssp_build_id().decode()
 
 
 def set_conv_algo(algo):
@@ -578,6 +595,8 @@ class Engine:
     def profile_read_kernels(self):
         """Per-kernel split of profile_read(): {kernel name: {ms, launches, flops, exec_flops, bytes}} (launched kernels only)."""
         out = {}
+        if not hasattr(self.lib, "ssp_profile_read_kernel"):  # (an A/B library of an older revision, SSP_HIP_LIB)
+            return out
         for k, name in enumerate(PROF_KERNELS):
             ms, n, fl, ex, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             _check(self.lib.ssp_profile_read_kernel(self.h, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(ex), C.byref(by)))

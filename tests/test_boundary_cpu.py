@@ -28,6 +28,16 @@ def test_library_exports_every_declared_symbol():
     assert sorted(ssp.lib.EXPORTS) == declared
 
 
+def test_library_is_built_from_the_checked_out_sources():
+    """The build id compiled into the in-tree library (sha256 over csrc/*.hip, csrc/*.hip.h, include/ssp_hip.h) equals the hash of
+    the sources as checked out: the binary under test is HEAD's, by content (not by modification time)."""
+    import semantic_superpoint_amd as ssp
+    ssp.build()  # rebuilds iff the ids differ
+    want = ssp.hipbuild.source_id()
+    assert ssp.hipbuild.library_id() == want
+    assert ssp.lib.build_id() == want
+
+
 def test_create_without_gpu_reports_layout():
     """ssp_create / counts need no device memory: parameter and BN layout match the oracle's spec."""
     import ctypes as Ct
@@ -190,13 +200,13 @@ def test_spawn_ranks_watchdog_stops_the_survivors(tmp_path):
 
 
 def test_bench_dtype_flag_selects_the_conv_algorithm():
-    """bench.py --dtype: f32 = the headline Winograd fp32 path, bf16 = the validated mixed mode (BASELINE configs[3])."""
+    """bench.py --dtype: f32 = the headline Winograd fp32 path, bf16 = the bf16 path (conv algorithm 12, BASELINE configs[3])."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     assert b.parse_args([]).conv_algo == 1 and b.parse_args(["--dtype", "f32", "--conv-algo", "0"]).conv_algo == 1
-    assert b.parse_args(["--dtype", "bf16"]).conv_algo == 8
+    assert b.parse_args(["--dtype", "bf16"]).conv_algo == 12
     assert b.parse_args([]).arch == "ssp" and b.parse_args([]).batch == 32  # the north-star workload is the default
 
 

@@ -105,3 +105,10 @@ def test_trainer_plugin_two_steps_vs_oracle(arch, semantic, tmp_path):
     ck = torch.load(p, map_location="cpu")
     assert set(ck) >= {"n_iter", "model_state_dict", "optimizer_state_dict", "loss"}
     assert list(ck["model_state_dict"].keys()) == [k for k, _, _ in C.state_spec(arch)]
+
+
+def test_loaded_library_is_built_from_the_checked_out_sources():
+    """The library the GPU tests run on carries the sha256 of exactly the csrc/ + include/ sources of this checkout
+    (ssp_build_id(), compiled in by hipbuild.build): the tested kernels are HEAD's by content, not by file time."""
+    import semantic_superpoint_amd as ssp
+    assert ssp.lib.build_id() == ssp.hipbuild.source_id()
