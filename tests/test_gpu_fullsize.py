@@ -108,7 +108,9 @@ def test_full_size_step_golden(tag, algo):
                 sl = torch.from_numpy(g["grad_slice/" + k])
                 err = float((mine[:64] - sl).abs().max()) / (float(mine.abs().max()) + 1e-30)
                 worst = max(worst, err)
-                assert err < 2e-2, (k, err)
+                # measured worst slice error (GPU box, round 4): algorithm 1 5.6e-3 (sp) / 4.8e-3 (ssp), algorithm 10 (F(4x4,3x3)
+                # everywhere) 1.5e-2 / 9.1e-3 -> 2x the measured value resp. the former 2e-2 where that is tighter
+                assert err < (1.2e-2 if algo == 1 else 2e-2), (k, err)
             print("G12 %s algo %d: worst 64-element slice error %.2e of max|grad|" % (tag, algo, worst))
             assert (gd["eta"].cpu() - torch.from_numpy(g["grad/eta"])).abs().max() < 2e-4
         e.adam_step(0.001)
@@ -317,6 +319,7 @@ def _compare_step_with_oracle(tag, e, sd, sample, sc, idx, scal_tol, norm_tol, f
     print("%s: flat gradient rel-L2 %.2e (max %.2e), worst tensor %.2e (%s)" % (what, l2, mx, worst[0], worst[1]))
     assert l2 < flat_tol, (what, l2)
     assert (gd["eta"].cpu() - tr.last_grads["eta"]).abs().max() < 1e-5, what
+    _compare_step_with_oracle.last_trainer = tr   # (the oracle's forward outputs of both views: tr.aux)
     return worst
 
 
@@ -338,6 +341,16 @@ def test_bench_size_step_vs_oracle(tag):
     sc = e.pair_step(sample, indices=None, seed=7, train=True).clone()
     torch.cuda.synchronize()
     _compare_step_with_oracle(tag, e, sd, sample, sc, e._last_idx, 2e-4, 2e-3, 3e-3, "B=32 240x320 %s" % tag)
+    # the north star's literal criterion at the benchmark size: detector logits and descriptors of BOTH views, element-wise,
+    # within 1e-3 of the oracle's B = 32 forward (the step above did not move the weights: no optimizer step)
+    tr = _compare_step_with_oracle.last_trainer
+    for view, key in (("image", "out"), ("warped_img", "out_warp")):
+        o = e.forward(sample[view], slot=0, train=True, want=("semi", "desc"))
+        torch.cuda.synchronize()
+        for name in ("semi", "desc"):
+            err = float((o[name].cpu() - tr.aux[key][name].detach()).abs().max())
+            print("B=32 240x320 %s %s %s: max |HIP - oracle| %.2e" % (tag, view, name, err))
+            assert err < 1e-3, (view, name, err)
 
 
 def test_default_predicate_mixes_kernels_below_max_batch():
@@ -374,12 +387,16 @@ def test_backward_refuses_stale_weight_images():
     with pytest.raises(RuntimeError, match="conv algorithm changed"):
         e.backward(0, torch.zeros_like(out["semi"]), torch.zeros_like(out["desc"]), None)
     e.set_conv_algo(1)
-    # forward of ANOTHER shape on the other slot, then the backward of slot 0: the record, not the shape, picks the kernels
+    # forward of ANOTHER shape on the other slot, then the backward of slot 0: the record, not the shape, picks the kernels.
+    # Reference = the oracle evaluated WITH the HIP forward's own ReLU gates and max-pool winners (read back from slot 0): on an
+    # 8x12-cell map one flipped gate is 5 % of a gradient, with the gates forced the comparison is exact to fp32 rounding.
+    e.forward(x, slot=0, train=True)
+    torch.cuda.synchronize()
+    forced = _hip_gates(e, arch, 0, B, H, W)
     tsd = C.to_torch(sd, requires_grad=True)
-    ref = C.forward(tsd, x.cpu(), arch)
+    ref = C.forward(tsd, x.cpu(), arch, forced=forced)
     gs = {k: torch.randn_like(ref[k]) for k in ref}
     sum((ref[k] * gs[k]).sum() for k in ref).backward()
-    e.forward(x, slot=0, train=True)
     e.forward(torch.rand(1, 1, 32, 48, device=_dev()), slot=1, train=True)
     e.zero_grad()
     e.backward(0, gs["semi"].to(_dev()), gs["desc"].to(_dev()), None)
@@ -387,7 +404,7 @@ def test_backward_refuses_stale_weight_images():
     gd = e.grad_dict()
     for k in ("convPa.weight", "down2.mpconv.1.conv.3.weight", "inc.conv.conv.3.weight"):
         l2, _ = _rel(gd[k].cpu(), tsd[k].grad)
-        assert l2 < 5e-2, (k, l2)  # 8x12-cell maps: single gate flips dominate (see tests/test_gpu_model.py::_grad_close)
+        assert l2 < 1e-4, (k, l2)
 
 
 def test_loaded_binary_keeps_the_accumulation_register_contract():

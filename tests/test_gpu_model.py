@@ -218,6 +218,12 @@ def _to_dev(sample):
     return {k: v.to(_dev()).contiguous() for k, v in sample.items()}
 
 
+# 64-element gradient slices of the G6 goldens (the first 64 elements of every gradient tensor against the reference's).  Measured on
+# the GPU box (round 4): 4.8e-6 .. 6.0e-6 of max|grad| under algorithm 1, 2.2e-5 .. 2.5e-5 under algorithm 10 (F(4x4,3x3) carries
+# ~5x the rounding noise) - no ReLU gate of these slices flips.  Bound = 4x the worst measured value (was 2e-2).
+SLICE_TOL = {"sp_64x96": 1e-4, "ssp_64x96": 1e-4, "magicpoint_32x48": 1e-4}
+
+
 def _idx_to_dev(idx, Wc):
     ma = torch.stack([(i["uv_a"][:, 0] + i["uv_a"][:, 1] * Wc) for i in idx]).to(torch.int32)
     mb = torch.stack([(i["uv_b"][:, 0] + i["uv_b"][:, 1] * Wc) for i in idx]).to(torch.int32)
@@ -250,6 +256,7 @@ def test_pair_step_golden(tag, arch, lam, algo):
         assert abs(sc[name] - ref) < TOL * max(1.0, abs(ref)), (name, sc[name], ref)
     gd = e.grad_dict()
     noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+    worst_slice = 0.0
     for k in C.param_keys(arch):
         if k in noisy or ("grad_norm/" + k) not in g:
             continue
@@ -257,7 +264,10 @@ def test_pair_step_golden(tag, arch, lam, algo):
         mine = gd[k].cpu().reshape(-1)
         assert abs(float(mine.norm()) - n_ref) < 5e-3 * n_ref + 1e-6, (k, float(mine.norm()), n_ref)
         sl = torch.from_numpy(g["grad_slice/" + k])
-        assert (mine[:64] - sl).abs().max() < 2e-2 * float(mine.abs().max()) + 1e-6, k
+        err = float((mine[:64] - sl).abs().max()) / (float(mine.abs().max()) + 1e-30)
+        worst_slice = max(worst_slice, err)
+        assert err < SLICE_TOL[tag] + 1e-6, (k, err)
+    print("G6 %s algo %d: worst 64-element slice error %.2e of max|grad|" % (tag, algo, worst_slice))
     assert (gd["eta"].cpu() - torch.from_numpy(g["grad/eta"])).abs().max() < 1e-3
     e.adam_step(0.001)
     torch.cuda.synchronize()
