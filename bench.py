@@ -380,6 +380,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank == 0 and not single_dev and "NCCL_DEBUG" not in os.environ:
+            # rank 0 logs RCCL's init and algorithm / protocol choices to a file that the line quotes (`dp.rccl`)
+            os.environ["SSP_NCCL_LOG"] = os.path.join(tempfile.gettempdir(), "ssp_rccl_rank0_%d.log" % os.getpid())
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,TUNING", NCCL_DEBUG_FILE=os.environ["SSP_NCCL_LOG"])
         if single_dev:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -404,6 +408,7 @@ def main():
         rccl_ranks = int(round(float(t.item())))
         assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
+    dp_diag = parallel.StepDiag(every=4, cuda=True) if world > 1 else None  # N > 1: the line diagnoses its own all-reduce overlap
     stream = torch.cuda.Stream(device=dev) if args.graph else None  # stream capture needs a non-default stream
     profiling = [False]
 
@@ -416,7 +421,7 @@ def main():
                   multi_task=True, dense=dense, graph=args.graph)
         eng.zero_grad()
         if world > 1 and not args.no_overlap:
-            parallel.pair_step_overlapped(eng, sample, args.lr, **kw)
+            parallel.pair_step_overlapped(eng, sample, args.lr, diag=dp_diag if it >= args.warmup else None, **kw)
         else:
             eng.pair_step(sample, **kw)
             if world > 1:  # one blocking all-reduce of the flat fp32 gradient bucket (incl. eta), then the mean
@@ -451,8 +456,13 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [1e3 * dt / args.steps]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [1e3 * float(v.item()) / args.steps for v in allt]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -485,6 +495,14 @@ def main():
                "step_tflops": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3, 2),
                "step_frac_of_fp32_mfma_peak": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3 / (PEAK_FP32_MFMA_TF * world), 4),
                "final_loss": round(scal["loss"], 4), "build_id": ssp.lib.build_id()[:16]}
+        if world > 1:
+            log = None
+            try:
+                with open(os.environ.get("SSP_NCCL_LOG", "")) as f:
+                    log = f.read()
+            except OSError:
+                pass
+            out["dp"] = parallel.dp_diagnostics(dp_diag.summary() if dp_diag is not None else {}, per_rank_ms, log)
         if profiled:
             n_prof_steps = len([i for i in range(args.steps) if i % PROF_EVERY == 0])  # the bracketed steps of the timed region
             rl = roofline_block(eng.profile_read_kernels(), pmc, pmc_note, args.conv_algo, n_prof_steps, args.steps)

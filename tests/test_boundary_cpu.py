@@ -121,6 +121,66 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _FakeEngine:
+    """pair_step_overlapped's view of an Engine, on the CPU: a flat gradient vector with an early / late split."""
+
+    def __init__(self, rank):
+        self.grads = torch.zeros(1000)
+        self.early_offset = 100
+        self.rank = rank
+        self.calls = []
+
+    def pair_step(self, sample, phase=0, **kw):
+        self.calls.append(phase)
+        if phase == 1:
+            self.grads[100:] = float(self.rank + 1)
+        elif phase == 2:
+            self.grads[:100] = 10.0 * (self.rank + 1)
+        return torch.zeros(16)
+
+    def adam_step(self, lr, grad_scale=None):
+        self.scale = grad_scale
+
+
+def _dp_diag_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from semantic_superpoint_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    eng, diag = _FakeEngine(rank), parallel.StepDiag(every=2, cuda=False)
+    for it in range(4):
+        parallel.pair_step_overlapped(eng, None, 0.001, diag=diag)
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(per_rank, torch.tensor([1.0 + rank], dtype=torch.float64))
+    blk = parallel.dp_diagnostics(diag.summary(), [float(v) for v in per_rank],
+                                  "NCCL version 2.22.3\nrank 0 AllReduce: 6537304 Bytes -> Algo 1 proto 2 time 75.0\nConnected all rings")
+    q.put((rank, float(eng.grads[0]), float(eng.grads[999]), eng.calls[:2], eng.scale, blk))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_step_and_its_self_diagnosis_gloo_world2():
+    """parallel.pair_step_overlapped over gloo with 2 CPU processes (a stand-in engine): both buckets are summed over the ranks,
+    Adam gets 1 / world, and the N > 1 bench line's `dp` block carries the keys the first multi-GPU run is read by (exposed all-reduce
+    time, phase-2 time, per-rank step times, RCCL's algorithm / protocol, the expected values of DESIGN.md section 6)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_diag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g_late, g_early, calls, scale, blk in res:
+        assert g_late == 30.0 and g_early == 3.0 and calls == [1, 2] and scale == 0.5
+        assert set(blk) == {"allreduce_exposed_ms", "phase2_ms", "bracketed_steps", "ms_per_step_ranks", "rccl", "expected"}
+        assert blk["bracketed_steps"] == 2 and blk["allreduce_exposed_ms"] >= 0 and blk["phase2_ms"] >= 0
+        assert blk["ms_per_step_ranks"] == {"min": 1.0, "max": 2.0, "all": [1.0, 2.0]}
+        assert blk["rccl"] == {"version": "2.22.3", "choices": {"6537304 B": "Ring/Simple x 1"}, "connected": ["rings"]}
+        assert "allreduce_exposed_ms" in blk["expected"] and "weak_scaling_efficiency_8gpu" in blk["expected"]
+
+
 def test_data_parallel_helpers_gloo_world2():
     """N > 1 path on CPU: gradient bucket mean, replica broadcast and unit sharding with 2 gloo processes."""
     ctx = mp.get_context("spawn")
