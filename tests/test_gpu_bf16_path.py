@@ -235,3 +235,87 @@ def test_bf16_pair_step_vs_bf16_oracle(arch):
     e.adam_step(0.001)
     torch.cuda.synchronize()
     assert (e.eta.cpu() - tr.eta.detach()).abs().max() < 1e-4
+
+
+def test_bf16_path_at_the_benchmark_size():
+    """B = 32, 240x320, SSp - the shape bench.py --dtype bf16 measures, bench.py's inputs and device-sampled indices: the scalars
+    against the bf16 oracle fed with the SAME indices (one oracle step ~ 30 s on the GPU host), the flat gradient's direction, and ten
+    optimizer steps that stay finite and lower the loss like the fp32 path's."""
+    import os
+    from semantic_superpoint_amd import synth
+    from semantic_superpoint_amd.lib import layer_table, SCALAR_NAMES
+    arch = ARCHS[1]
+    B, H, W = 32, 240, 320
+    sd = synth.default_init_state_dict(layer_table(arch), seed=0)
+    sample = synth.make_pair(B, H, W, _dev(), seed=100, semantic=True)
+    e = _engine(arch, B, H, W, sd)
+    e.zero_grad()
+    sc = e.pair_step(sample, indices=None, seed=7, train=True).clone()
+    torch.cuda.synchronize()
+    ma, mb, nm = (t.cpu().long() for t in e._last_idx)
+    Wc = W // 8
+    idx = [{"uv_a": torch.stack((ma[b] % Wc, ma[b] // Wc), 1), "uv_b": torch.stack((mb[b] % Wc, mb[b] // Wc), 1), "nm_b": nm[b]} for b in range(B)]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    tr = C.Trainer(arch, {k: np.asarray(v) for k, v in sd.items()}, lr=0.001, operand_dtype=BF16)
+    tr.real_batch_size = 10 ** 9
+    tr.train_val_sample({k: v.cpu() for k, v in sample.items() if k != "cell_homographies"}, n_iter=0, train=True, indices=idx)
+    sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
+        ref = tr.scalar_dict[name]
+        assert abs(sc[name] - ref) < 2e-3 * max(1.0, abs(ref)), (name, sc[name], ref)
+    gd = e.grad_dict()
+    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+    mine = torch.cat([gd[k].cpu().double().flatten() for k in C.param_keys(arch) if k not in noisy])
+    ref = torch.cat([tr.last_grads[k].double().flatten() for k in C.param_keys(arch) if k not in noisy])
+    cos = float(mine @ ref / (mine.norm() * ref.norm()))
+    rel = float((mine - ref).norm() / ref.norm())
+    print("bf16 path, B = 32 240x320: flat gradient vs the bf16 oracle: rel-L2 %.2e, cosine %.5f" % (rel, cos))
+    assert cos > 0.99 and rel < 0.15, (cos, rel)
+    first = sc["loss"]
+    for it in range(10):
+        e.adam_step(0.001)
+        e.zero_grad()
+        sc2 = e.pair_step(sample, indices=None, seed=8 + it, train=True)
+    torch.cuda.synchronize()
+    last = float(sc2.cpu()[0])
+    assert bool(torch.isfinite(e.params).all()) and last < first, (first, last)
+
+
+@pytest.mark.parametrize("case", ["zero", "negative"])
+def test_bf16_pooled_layers_with_zero_or_negative_gamma(case):
+    """The raw pooled copy takes the per-channel MIN of a window when gamma < 0, and a channel with gamma == 0 gets its BatchNorm-backward
+    sum S2 from the scan over the un-pooled tensor (the pooled value does not determine xhat there): forward and backward of a net
+    whose pooled layers (1, 3, 5) carry such channels against the bf16 oracle."""
+    arch = ARCHS[0]
+    B, H, W = 2, 64, 96
+    sd = C.init_state_dict(arch, seed=13)
+    for bn in ("inc.conv.conv.4", "down1.mpconv.1.conv.4", "down2.mpconv.1.conv.4"):
+        w = sd[bn + ".weight"].copy()
+        if case == "zero":
+            w[[1, 6, 7, 33]] = 0.0
+            sd[bn + ".bias"][[1, 7]] = 0.3   # relu(beta) > 0: the degenerate channel is alive
+        else:
+            w[::3] *= -1.0
+        sd[bn + ".weight"] = w
+    x = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(5))
+    tsd = C.to_torch(sd, requires_grad=True)
+    ref = C.forward(tsd, x, arch, train=True, operand_dtype=BF16)
+    g = torch.Generator().manual_seed(6)
+    gs = {k: torch.randn(ref[k].shape, generator=g) for k in ref}
+    sum((ref[k] * gs[k]).sum() for k in ref).backward()
+    with _Fp64Convs():
+        tsd64 = C.to_torch(sd, requires_grad=True)
+        r64 = C.forward(tsd64, x, arch, train=True, operand_dtype=BF16)
+        sum((r64[k] * gs[k]).sum() for k in r64).backward()
+    e = _engine(arch, B, H, W, sd)
+    out = e.forward(x.to(_dev()), slot=0, train=True, want=("semi", "desc"))
+    e.zero_grad()
+    e.backward(0, gs["semi"].to(_dev()), gs["desc"].to(_dev()), None)
+    torch.cuda.synchronize()
+    for k in ("semi", "desc"):
+        assert _rel_l2(out[k].cpu(), ref[k].detach()) <= 2.0 * _rel_l2(r64[k].detach(), ref[k].detach()) + 1e-3, k
+    gd = e.grad_dict()
+    for k in ("inc.conv.conv.4.weight", "inc.conv.conv.4.bias", "down1.mpconv.1.conv.4.weight", "down2.mpconv.1.conv.4.weight",
+              "inc.conv.conv.3.weight", "down1.mpconv.1.conv.0.weight", "inc.conv.conv.0.weight"):
+        err, floor = _rel_l2(gd[k].cpu(), tsd[k].grad), _rel_l2(tsd64[k].grad, tsd[k].grad)
+        assert err <= 2.5 * floor + 5e-3, (k, err, floor)
