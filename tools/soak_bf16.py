@@ -15,7 +15,7 @@ H, W = 240, 320
 sd = synth.default_init_state_dict(layer_table(arch), seed=0)
 engs = {}
 pair = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "1,8").split(",")]
-NAMES = {1: "fp32", 8: "bf16", 9: "fp32 F(2x2,3x3) only", 10: "fp32 F(4x4,3x3) forced"}
+NAMES = {1: "fp32", 8: "mixed bf16 (algo 8)", 9: "fp32 F(2x2,3x3) only", 10: "fp32 F(4x4,3x3) forced", 12: "bf16 path (algo 12)"}
 for name, algo in ((NAMES.get(pair[0], "algo %d" % pair[0]), pair[0]), (NAMES.get(pair[1], "algo %d" % pair[1]), pair[1])):
     L.set_conv_algo(algo)  # copied into the handle at creation
     engs[name] = Engine(arch, B, H, W, dev)
