@@ -44,7 +44,7 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int nchunks, ncob;
   unsigned in_bytes, out_bytes, wpk_bytes;  // buffer descriptor ranges: in_bytes = bytes of ONE input image
-  int ablate;             // perf-debug only (tools/ablate_conv.py): 1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA
+  int ablate;             // perf-debug only (tools/archive/ablate_conv.py): 1 no global loads, 2 no LDS writes, 4 no stores, 8 no MFMA
   // Data-gradient launches of conv_wino_pipe_kernel: pass 1 of the BatchNorm backward of the layer BELOW (whose activation
   // gradient this launch produces) accumulated in the epilogue into `stats` (= that layer's backward sums, same
   // [NREP][2 C] layout as the forward statistics): S1 = sum dZ, S2 = sum dZ * xhat.

@@ -1,7 +1,7 @@
 // Winograd F(4x4, 3x3) convolution for the large maps (240x320, 120x160): 36 transform components per 6x6 input patch,
 // 4x4 outputs per tile = 2.25 matrix multiplies per output instead of the 4 of F(2x2,3x3) (conv_wino_pipe.hip.h), with
 // about the same transform work per output.  fp32 error against fp64 on a 64 -> 64 layer's data: rel-L2 1.5e-6 (F(2x2):
-// 2.4e-7; tools/wino_error_probe.py).
+// 2.4e-7; tools/archive/wino_error_probe.py).
 //
 //   workgroup = 4 waves (ONE per SIMD) = 32 tiles (32x16 or 16x32 output pixels) x 64 output channels, one per CU;
 //   wave = (I, nt): rows 3I .. 3I+2 of the 6x6 component matrix M (18 components), output-channel half nt:

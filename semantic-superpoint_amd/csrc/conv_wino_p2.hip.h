@@ -32,7 +32,7 @@
 // sets: weight fragments from L2 (the packed weight image [cob][chunk8][component][h][64][4] IS the fragment layout),
 // input fragments from LDS - including the first pair of stage g+1, read from sA[~g&1] during the second half of stage g.
 // A wave therefore never waits for an LDS or L2 round trip between two MFMA groups; the first-generation kernel exposed
-// three LDS round trips per stage (tools/ablate_p2.py: the non-MFMA work of a stage was 2700 cycles long and overlapped
+// three LDS round trips per stage (tools/archive/ablate_p2.py: the non-MFMA work of a stage was 2700 cycles long and overlapped
 // with the 4096 MFMA cycles of the two waves of a SIMD for 700 cycles only).
 // The raw halo lives in LDS as [row][pixel][8 channels] with a row stride of 592 bytes (8x16 tiles; 320 for 16x8): the
 // transform's ds_read_b128 (pixel column 2 tx + j of rows 2 ty + r over the 32 tiles of a wave) is conflict-free with
@@ -41,7 +41,7 @@
 #include "conv_wino_pipe.hip.h"
 
 #ifndef P2_ABL
-#define P2_ABL 0  // compile-time perf ablation (tools/ablate_p2.py): 1 no epilogue, 2 no halo staging / transform, 4 no barriers
+#define P2_ABL 0  // compile-time perf ablation (tools/archive/ablate_p2.py): 1 no epilogue, 2 no halo staging / transform, 4 no barriers
                   // in the stage loop, 8 no MFMA, 16 no weight loads in the stage loop, 32 no fragment reads from LDS
 #endif
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
   // puts a small slice of the staging work behind every single MFMA (fenced with sched_barrier so that the compiler keeps
   // the order): a wave issues in order, so only instructions placed BETWEEN two of its MFMAs run in the shadow of the
   // first one (64 cycles of matrix pipe = room for ~10 VALU / LDS / VMEM issues); work placed between two GROUPS of
-  // back-to-back MFMAs adds its issue time to the stage instead (tools/ablate_p2.py: MFMA-only 0.59 ms + non-MFMA-only
+  // back-to-back MFMAs adds its issue time to the stage instead (tools/archive/ablate_p2.py: MFMA-only 0.59 ms + non-MFMA-only
   // 0.37 ms gave 0.86 ms with group-wise placement, also with two independent workgroups per CU).
 #define P2_MM(I, C, W0, W1, F0, F1)                                                                         \
   if (!(P2_ABL & 8)) {                                                                                      \

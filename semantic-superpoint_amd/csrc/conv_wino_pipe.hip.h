@@ -20,7 +20,7 @@
 #include "conv_wino.hip.h"
 
 #ifndef PIPE_ABL
-#define PIPE_ABL 0  // compile-time perf ablation (tools/ablate_pipe.py): 1 no epilogue, 4 no end-of-stage barrier, 8 no MFMA,
+#define PIPE_ABL 0  // compile-time perf ablation (tools/archive/ablate_pipe.py): 1 no epilogue, 4 no end-of-stage barrier, 8 no MFMA,
                     // 16 no global stores, 512 no halo loads, 1024 cycle-stamp trace, 2048 no weight-fragment loads (B operands
                     // constant), 4096 no LDS fragment reads (A operands constant), 8192 halo loads confined to 64 KB (cache
                     // hits).  CAUTION: variants that make operands constant / zero also lower the power draw - the same
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   acc[(C) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_##C.w, b1_##C[3], acc[(C) + 1], 0, 0, 0); }
 #define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-#if PIPE_ABL & 1024  // cycle stamps of every wave of block 8 -> the stats buffer (tools/ablate_pipe.py trace)
+#if PIPE_ABL & 1024  // cycle stamps of every wave of block 8 -> the stats buffer (tools/archive/ablate_pipe.py trace)
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
   unsigned long long ets[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // epilogue, per round: start, transform done, barrier passed, stores issued
 #define PIPE_TS(V) V = __builtin_amdgcn_s_memtime();

@@ -42,7 +42,7 @@ using namespace sspk;
 #endif
 
 static thread_local std::string g_err;
-static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_kernel (tools/ablate_conv.py)
+static int g_dbg_ablate = 0, g_dbg_grid = 0;  // perf-debug knobs of conv_mfma_kernel (tools/archive/ablate_conv.py)
 // ssp_set_conv_algo: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) where eligible (software-pipelined kernel),
 // 2 = Winograd, un-pipelined kernel (conv_wino_kernel; kept for A/B measurements),
 // 3 = Winograd with bf16 matrix-core operands (conv_wino_bf16_kernel: opt-in reduced precision, BASELINE configs[3])
@@ -290,7 +290,7 @@ struct Carver {
   // Activation / gradient tensors: the k-th one starts at k * 72 KiB past a 4 MiB boundary of the ABSOLUTE address.
   // A kernel that streams two tensors whose addresses are congruent modulo a few MiB (e.g. the 600 MiB layer-0/1
   // activations carved back to back) sends its reads and writes to the same HBM channels at the same time: measured
-  // 0.998 ms vs 0.835 ms for the 64->64 @240x320 convolution (tools/align_probe.py); any skew >= 8 KiB removes it.
+  // 0.998 ms vs 0.835 ms for the 64->64 @240x320 convolution (tools/archive/align_probe.py); any skew >= 8 KiB removes it.
   template <typename T> T* take_skewed(size_t n) {
     constexpr size_t A = (size_t)4 << 20, SK = (size_t)72 << 10;
     const size_t abs0 = reinterpret_cast<size_t>(base) + off;  // base == nullptr (size query): layout relative to 0
@@ -553,7 +553,7 @@ static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
 
 // default algorithm (1): maps with few first-generation work items per CU (the 30x40 layers: 640 items on 256 CUs =
 // 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
-// large maps: tools/conv_probe.py)
+// large maps: tools/archive/conv_probe.py)
 // Winograd F(4x4,3x3) (conv_wino4_kernel): tile blocks of 32x16 / 16x32 pixels, whichever wastes less of the map
 static void w4_geometry(int H, int W, bool& wide, int& tiles_y, int& tiles_x) {
   const long a_w = (long)cdiv(H, 16) * 16 * cdiv(W, 32) * 32, a_t = (long)cdiv(H, 32) * 32 * cdiv(W, 16) * 16;
@@ -627,7 +627,7 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   // everything else: 64 tiles (Winograd) or 256 pixels (direct) = 8x32 / 32x8 per workgroup
   // default algorithm (1): maps with few first-generation work items per CU (the 30x40 layers: 640 items on 256 CUs =
   // 2.5 rounds) run on the finer-grained second-generation kernel (measured 10-15 % faster there, 1-4 % slower on the
-  // large maps: tools/conv_probe.py)
+  // large maps: tools/archive/conv_probe.py)
   const bool p2 = conv_uses_p2(h, c);
   const bool w4 = conv_uses_w4(h, c);
   if (c.pool_out[0] != nullptr) {
@@ -2864,7 +2864,7 @@ int ssp_op_bn_bwd_bf16(const void* y_dev, const void* dout_dev, const float* gam
   return 0;
 }
 
-// perf-debug hook (tools/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
+// perf-debug hook (tools/archive/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
 int ssp_set_conv_algo(int algo) {
   if (algo < 0 || algo > 12 || algo == 4)
     return fail(-1, "conv algo must be 12 (the bf16 path: bf16 activations in HBM, direct bf16 matrix-core convolutions), 0 (direct), 1 (Winograd, pipelined), 2 (Winograd, un-pipelined), 3 (Winograd, bf16 "

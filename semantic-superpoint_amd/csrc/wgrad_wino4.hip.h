@@ -27,7 +27,7 @@
 #include "conv_wino4.hip.h"
 
 #ifndef WG4_ABL
-#define WG4_ABL 0  // compile-time perf ablation (tools/ablate_wgrad4.sh): 1 no MFMAs, 2 no transforms (raw values as operands),
+#define WG4_ABL 0  // compile-time perf ablation (tools/archive/ablate_wgrad4.sh): 1 no MFMAs, 2 no transforms (raw values as operands),
                    // 4 no LDS reads in the K steps, 8 no staging (BatchNorm + LDS writes), 16 no global loads
 #endif
 

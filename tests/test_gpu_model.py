@@ -476,7 +476,7 @@ def test_bf16_operand_mode_tracks_the_fp32_step():
     """ssp_set_conv_algo(3) (opt-in, BASELINE configs[3] "bf16 compute / fp32 master"): same step, bf16 matrix-core
     operands in the 3x3 convolutions and weight gradients.  The losses agree to 1e-4; the GRADIENT is noisy: bf16
     rounding of the Winograd-transformed operands does not cancel where the exact transforms do (non-centred
-    activations), measured 3 % (heads) to 23-34 % (first layers) relative L2 per tensor (tools/bf16_grad_probe.py).
+    activations), measured 3 % (heads) to 23-34 % (first layers) relative L2 per tensor (tools/archive/bf16_grad_probe.py).
     The test pins that envelope: losses within 2 %, flat gradient within 40 % relative L2, cosine similarity > 0.9."""
     from semantic_superpoint_amd import lib as L
     from semantic_superpoint_amd.lib import SCALAR_NAMES
@@ -507,7 +507,7 @@ def test_bf16x2_mode_tracks_the_fp32_step(arch):
     accurate reduced-precision mode (the one-term mode 3 loses the gradient: see the test above).  Losses within 1e-3 of the
     fp32 step; per-tensor gradient relative L2 <= 3e-2 at this small size (measured 1e-2 on one BatchNorm bias: products are
     rounded at ~1e-5, which flips ~1e-5 of the ReLU gates - the same mechanism as fp32 vs oracle, 5x more flips; at B = 32,
-    240x320 the flips average out: tools/bf16_grad_probe.py), flat gradient <= 1.5e-2."""
+    240x320 the flips average out: tools/archive/bf16_grad_probe.py), flat gradient <= 1.5e-2."""
     from semantic_superpoint_amd.lib import SCALAR_NAMES
     B, H, W = 2, 120, 160
     sd = C.init_state_dict(arch, seed=21)

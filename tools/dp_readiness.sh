@@ -31,6 +31,6 @@ for t in ("overlap", "no_overlap", "overlap_traced"):
     except Exception as e:
         print(t, "ERR", e)
 PY
-python3 $R/tools/overlap_timeline.py $O/trace_overlap_traced > $O/timeline.txt 2>&1
+python3 $R/tools/archive/overlap_timeline.py $O/trace_overlap_traced > $O/timeline.txt 2>&1
 cat $O/timeline.txt
 rm -rf $O/trace_overlap_traced
