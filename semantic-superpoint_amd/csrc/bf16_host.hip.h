@@ -31,10 +31,10 @@ static int launch_conv_bf16_t(const ConvBArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
-template <int IN_MODE>
+template <int IN_MODE, bool NC2>
 static int launch_conv_bf16_ws_t(const ConvBArgs& a, int nblocks, hipStream_t st) {
   static AttrOnce attr_once;
-  auto kern = conv_bf16_ws_kernel<IN_MODE>;
+  auto kern = conv_bf16_ws_kernel<IN_MODE, NC2>;
   if (attr_once.need())
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ConvWsGeom::LDS_BYTES));
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), ConvWsGeom::LDS_BYTES, st, a);
@@ -58,6 +58,16 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   a.in_img_bytes = (unsigned)img;
   static const int ablate_env = getenv("SSP_CONVB_ABLATE") ? atoi(getenv("SSP_CONVB_ABLATE")) : 0;  // (perf-debug)
   a.ablate = ablate_env;
+  a.trace = nullptr;
+  static const int trace_env = getenv("SSP_CONVB_TRACE") ? atoi(getenv("SSP_CONVB_TRACE")) : 0;  // (perf-debug: blocking, prints per launch)
+  static unsigned long long* trace_buf = nullptr;
+  static int trace_count = 0;
+  const bool trace_now = trace_env > 0 && c.ks == 3 && !c.in_f32 && !c.out_f32 && (++trace_count % trace_env) == 0;   // every N-th launch
+  if (trace_now) {
+    if (!trace_buf) HIPCHK(hipMalloc(&trace_buf, (64 + 1024) * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(trace_buf, 0, (64 + 1024) * sizeof(unsigned long long), st));
+    a.trace = trace_buf;
+  }
   if (!c.out_f32 && (c.cout % 8 || c.out_cs % 8 || c.out_co % 8)) return fail(-3, "bf16 conv: bf16 output needs channel counts / offsets that are multiples of 8");
   if (!c.in_f32 && (c.in_cs % 8 || c.in_co % 8)) return fail(-3, "bf16 conv: bf16 input needs channel stride / offset that are multiples of 8");
   if (c.in_f32 && (c.in_cs % 4 || c.in_co % 4)) return fail(-3, "bf16 conv: fp32 input needs channel stride / offset that are multiples of 4");
@@ -75,7 +85,31 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
     int nb = (int)std::min<long>((long)n_cu, cdiv(units, 8) * 8L) / 8 * 8;
     nb = std::max(nb, 8);
     if (grid_env > 0) nb = grid_env;
-    return c.in_mode == 1 ? launch_conv_bf16_ws_t<1>(a, nb, st) : launch_conv_bf16_ws_t<0>(a, nb, st);
+    const bool nc2 = a.nchunks == 2;   // a layer of 64 input channels: its affine stays in registers
+    const int rc = c.in_mode == 1 ? (nc2 ? launch_conv_bf16_ws_t<1, true>(a, nb, st) : launch_conv_bf16_ws_t<1, false>(a, nb, st))
+                                  : (nc2 ? launch_conv_bf16_ws_t<0, true>(a, nb, st) : launch_conv_bf16_ws_t<0, false>(a, nb, st));
+    if (trace_now && rc == 0) {
+      static unsigned long long h[64 + 1024];
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpy(h, trace_buf, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[convb trace] %dx%d cin %d cout %d mode %d: %llu stages of workgroup 0; cycles per stage\n", c.H, c.W, c.cin, c.cout, c.in_mode, h[7]);
+      const double ns = (double)std::max<unsigned long long>(h[7], 1);
+      {
+        unsigned long long first = ~0ull, last = 0; double sum = 0, mx = 0, mn = 1e30; int cnt = 0;
+        for (int b = 0; b < std::min(nb, 512); ++b) if (h[65 + 2 * b]) { first = std::min(first, h[64 + 2 * b]); last = std::max(last, h[65 + 2 * b]); }
+        double xs[8] = {0}, xe[8] = {0}; int xn[8] = {0};
+        for (int b = 0; b < std::min(nb, 512); ++b) if (h[65 + 2 * b]) {
+          const double d = (h[65 + 2 * b] - h[64 + 2 * b]) / 100.0; sum += d; mx = std::max(mx, d); mn = std::min(mn, d); ++cnt;
+          xs[b & 7] += (h[64 + 2 * b] - first) / 100.0; xe[b & 7] += (h[65 + 2 * b] - first) / 100.0; ++xn[b & 7];
+        }
+        fprintf(stderr, "  workgroups: %d, loop us min %.1f avg %.1f max %.1f; first start -> last end %.1f us\n", cnt, mn, sum / std::max(cnt, 1), mx, (last - first) / 100.0);
+        for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, "    xcd %d: avg start %.1f  avg end %.1f us\n", x, xs[x] / xn[x], xe[x] / xn[x]);
+      }
+      fprintf(stderr, "  loop: %llu cycles in %.1f us -> shader clock %.0f MHz\n", h[5], h[6] / 100.0, h[6] ? h[5] * 100.0 / h[6] : 0.0);
+      for (int w = 0; w < 4; ++w) fprintf(stderr, "  consumer %d: mfma %.0f  rest %.0f  barrier %.0f\n", w, h[w * 8] / ns, h[w * 8 + 1] / ns, h[w * 8 + 2] / ns);
+      for (int w = 4; w < 8; ++w) fprintf(stderr, "  producer %d: copy-out %.0f  load wait %.0f  staging %.0f  advance %.0f  issue %.0f  barrier %.0f\n", w - 4, h[w * 8] / ns, h[w * 8 + 4] / ns, h[w * 8 + 1] / ns, h[w * 8 + 5] / ns, h[w * 8 + 2] / ns, h[w * 8 + 3] / ns);
+    }
+    return rc;
   }
 #define CONVB_CASE(KS_, M_, I_, O_) \
   if (c.ks == KS_ && c.in_mode == M_ && c.in_f32 == I_ && c.out_f32 == O_) return launch_conv_bf16_t<KS_, M_, I_, O_>(a, nblocks, st);
@@ -94,6 +128,31 @@ static int launch_pack_bf16(const float* w, uint16_t* dst, int cout_w, int cin_w
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+// job table of pack_weights_bf16_multi_kernel: add() queues an image, flush() launches what is queued
+struct PackBQueue {
+  PackBJobs J;
+  int nblocks;
+  PackBQueue() : nblocks(0) { J.n = 0; }
+  int flush(hipStream_t st) {
+    if (J.n == 0) return 0;
+    hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3(nblocks), dim3(256), 0, st, J);
+    HIPCHK(hipGetLastError());
+    J.n = 0; nblocks = 0;
+    return 0;
+  }
+  int add(const float* w, uint16_t* dst, int cout_w, int cin_w, int ks, int tf, int nchunks_total, int chunk_off, hipStream_t st) {
+    if (J.n == PACKB_MAX_JOBS) CHK(flush(st));
+    const int conv_cin = tf ? cout_w : cin_w, conv_cout = tf ? cin_w : cout_w;
+    PackBJob& q = J.j[J.n++];
+    q.w = w; q.dst = dst; q.cout_w = cout_w; q.cin_w = cin_w; q.ks = ks; q.tf = tf;
+    q.nchunks = convb_nchunks(conv_cin); q.ncob = convb_ncob(conv_cout);
+    q.nchunks_total = nchunks_total > 0 ? nchunks_total : q.nchunks; q.chunk_off = chunk_off;
+    q.block0 = nblocks;
+    nblocks += (int)cdiv((long)q.ncob * q.nchunks * ks * ks * 2048, 256);
+    return 0;
+  }
+};
 
 struct WgradBCall {
   const void* x[2] = {nullptr, nullptr}; int x_cs = 0, x_co = 0, cin = 0;

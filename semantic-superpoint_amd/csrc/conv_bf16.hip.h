@@ -55,7 +55,23 @@ struct ConvBArgs {
   int tiles_x, tiles_y, nchunks, ncob;
   unsigned in_img_bytes;     // bytes of ONE input image (buffer descriptor range)
   int ablate;                // perf-debug only (SSP_CONVB_ABLATE): 1 no global loads, 2 no LDS staging writes, 4 no epilogue, 8 no MFMA loop
+  unsigned long long* trace; // perf-debug only (SSP_CONVB_TRACE=1): per-phase cycle sums of workgroup 0 (conv_bf16_ws_kernel), else nullptr
 };
+
+// bias of the 64 output channels of block `cob` in the accumulator layout (bias4[mt][q][e] = channel cob * 64 + mt * 32 + 8 q +
+// 4 lg + e): 32 branch-free dword buffer loads (channels past Cout and a null bias read 0 through the descriptor), ONE wait.  (The
+// first form - a 16-byte load when aligned, else four guarded scalar loads - compiled to eight load / s_waitcnt vmcnt(0) pairs
+// inside exec branches: 8 serial L2 latencies per tile, 0.10 of the 0.52 ms of the 64 -> 64 layer @240x320.)
+__device__ __forceinline__ void cb_load_bias(const float* bias, int Cout, int cob, int lg, f32x4 (&bias4)[2][4]) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias != nullptr ? Cout * 4 : 0, 0x00020000);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bias4[mt][q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (cob * CB_NB + mt * 32 + 8 * q + 4 * lg + e) * 4, 0, 0));
+}
 
 // lane (0..31) of a pixel tile -> (row 0..1, column 0..15).  With RS = halo row pitch (18 for 3x3, 16 for 1x1) the slot index
 // r * RS + c of the 16 lanes of each ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}) is distinct modulo 16.
@@ -332,22 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
 
     // ---- epilogue: bias, rounding, [pixel][channel] tile through LDS, 16-byte stores, statistics of the stored values ----
     f32x4 bias4[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = cob * CB_NB + mt * 32 + 8 * q + 4 * lg;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr) {
-          if (co + 4 <= a.Cout && (reinterpret_cast<uintptr_t>(a.bias + co) & 15) == 0) {  // (the flat parameter vector keeps the
-            b = *reinterpret_cast<const f32x4*>(a.bias + co);                              // biases behind convPb only 4-byte aligned)
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
-          }
-        }
-        bias4[mt][q] = b;
-      }
+    cb_load_bias(a.bias, a.Cout, cob, lg, bias4);
     unsigned char* const p_out = reinterpret_cast<unsigned char*>(a.out[view]);
     const bool do_stats = a.stats[0] != nullptr;
     constexpr int NROUND = OUT_F32 ? 2 : 1;
@@ -508,6 +509,51 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, uint16_t* 
   }
   const uint32_t pk = pack_bf16(v, 0.f);
   dst[((size_t)cob * nchunks_total + chunk + chunk_off) * per_chunk + (idx % per_chunk)] = (uint16_t)(pk & 0xffffu);
+}
+
+// every bf16 operand image of a step in ONE launch (26 images per step for SuperPointNet_gauss2_ssmall: one launch of ~8 us each
+// was 0.2 ms of a 7.1 ms step): a table of jobs by value, blocks -> job by the table's block prefix
+constexpr int PACKB_MAX_JOBS = 40;
+struct PackBJob {
+  const float* w;
+  uint16_t* dst;
+  int cout_w, cin_w, ks, tf, nchunks_total, chunk_off, ncob, nchunks;
+  int block0;   // first block of the job
+};
+struct PackBJobs {
+  int n;
+  PackBJob j[PACKB_MAX_JOBS];
+};
+
+__global__ void pack_weights_bf16_multi_kernel(const PackBJobs J) {
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < J.n; ++i) k = (int)blockIdx.x >= J.j[i].block0 ? i : k;
+  const PackBJob& q = J.j[k];
+  const int KS = q.ks, taps = KS * KS;
+  const int per_chunk = taps * 2 * 2 * 64 * 8;
+  const long total = (long)q.ncob * q.nchunks * per_chunk;
+  const long idx = (long)(blockIdx.x - q.block0) * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  long t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int l = (int)(t & 63); t >>= 6;
+  const int mt = (int)(t & 1); t >>= 1;
+  const int ks = (int)(t & 1); t >>= 1;
+  const int tap = (int)(t % taps); t /= taps;
+  const int chunk = (int)(t % q.nchunks);
+  const int cob = (int)(t / q.nchunks);
+  const int co = cob * 64 + mt * 32 + (l & 31);
+  const int ci = chunk * 32 + ks * 16 + (l >> 5) * 8 + e;
+  const int ky = tap / KS, kx = tap % KS;
+  float v = 0.f;
+  if (!q.tf) {
+    if (co < q.cout_w && ci < q.cin_w) v = q.w[(((size_t)co * q.cin_w + ci) * KS + ky) * KS + kx];
+  } else {
+    if (co < q.cin_w && ci < q.cout_w) v = q.w[(((size_t)ci * q.cin_w + co) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)];
+  }
+  const uint32_t pk = pack_bf16(v, 0.f);
+  q.dst[((size_t)cob * q.nchunks_total + chunk + q.chunk_off) * per_chunk + (idx % per_chunk)] = (uint16_t)(pk & 0xffffu);
 }
 
 }  // namespace sspk

@@ -16,10 +16,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "conv_bf16.hip.h"
 
 namespace sspk {
+
+// packed fp32 arithmetic WITHOUT `volatile` (pk_math.hip.h's forms are volatile: the scheduler treats a side-effecting asm as a
+// barrier for memory operations, which pinned an s_waitcnt lgkmcnt(0) behind every ds_read_b128 of the copy-out) and with in-place
+// accumulators (a fresh output register per operation cost 88 v_mov_b64 per copy-out)
+__device__ __forceinline__ f32x2 ws_pk_fma(f32x2 x, f32x2 y, f32x2 z) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+__device__ __forceinline__ void ws_pk_acc(f32x2& sum, f32x2& sumsq, f32x2 x) {
+  asm("v_pk_add_f32 %0, %0, %1" : "+v"(sum) : "v"(x));
+  asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(sumsq) : "v"(x));
+}
 
 struct ConvWsGeom {
   static constexpr int HT = CB_T + 2;
@@ -29,10 +43,11 @@ struct ConvWsGeom {
   static constexpr int LDS_BYTES = 2 * W_BYTES + 2 * H_BYTES + O_BYTES;
 };
 
-template <int IN_MODE>
+template <int IN_MODE, bool NC2>
 __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a) {
   using G = ConvWsGeom;
   constexpr int HT = G::HT, PAD = 1;
+  constexpr bool DMA = IN_MODE == 0;   // the data gradient stages nothing: its halo goes global -> LDS directly (buffer_load ... lds)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* const sW = smem_b;
   unsigned char* const sH = smem_b + 2 * G::W_BYTES;
@@ -56,18 +71,40 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
 
   if (!producer) {
     // =========================== consumers ===========================
+    if (a.ablate & 64) __builtin_amdgcn_s_setprio(3);
     const int lj = lane & 31, lg = lane >> 5;
     int pr, pc;
     cb_lane_pixel<HT>(lj, pr, pc);
+    // B-operand addresses.  Staged form (IN_MODE 1): halo slots of CB_PS = 80 bytes, one base per pixel tile, taps as immediates.
+    // DMA form (IN_MODE 0): dense 64-byte slots whose four 16-byte items are XOR-swizzled by bits 2..3 of the slot index (the image
+    // buffer_load ... lds can write); the swizzle depends on the slot, so every (tile, tap, k-step) has its own address register -
+    // computed once, they do not depend on the unit.
     int boff[2];
+    int baddr[DMA ? 2 : 1][DMA ? 9 : 1][DMA ? 2 : 1];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) boff[nt] = ((4 * wave + 2 * nt + pr) * HT + pc) * CB_PS + lg * 16;
+    for (int nt = 0; nt < 2; ++nt) {
+      boff[nt] = ((4 * wave + 2 * nt + pr) * HT + pc) * CB_PS + lg * 16;
+      if constexpr (DMA) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int sl = (4 * wave + 2 * nt + pr + tap / 3) * HT + pc + tap % 3;
+            baddr[nt][tap][ks] = sl * 64 + (((ks * 2 + lg) ^ ((sl >> 2) & 3)) << 4);
+          }
+      }
+    }
     const int aoff = lane * 16;
     f32x16 acc[2][2];
     f32x4 bias4[2][4];
-    int chunk = 0, u = u0;
+    int chunk = 0, u = u0, bias_vc = -1;
+    const bool tr = a.trace != nullptr && blockIdx.x == 0;   // (perf-debug: cycle sums of [MFMA loop, rest of the stage, barrier])
+    unsigned long long tc[3] = {0, 0, 0}, t0 = 0, t1 = 0;
+    const unsigned long long tk0 = tr ? __builtin_readcyclecounter() : 0, tr0 = a.trace != nullptr ? __builtin_amdgcn_s_memrealtime() : 0;
     __syncthreads();   // the producers' prologue has staged stage 0
-    for (int s = 0; s < nstages; ++s) {
+    auto stage = [&](auto PAR) __attribute__((always_inline)) {   // PAR = parity of the stage = of its chunk (nchunks is even)
+      constexpr int Q = decltype(PAR)::value;
+      if (tr) t0 = __builtin_readcyclecounter();
       if (chunk == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -75,40 +112,35 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int vc = u / T, cob = vc % a.ncob;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int co = cob * CB_NB + mt * 32 + 8 * q + 4 * lg;
-            f32x4 b = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias != nullptr) {
-              if (co + 4 <= a.Cout && (reinterpret_cast<uintptr_t>(a.bias + co) & 15) == 0) b = *reinterpret_cast<const f32x4*>(a.bias + co);
-              else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) b[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
-              }
-            }
-            bias4[mt][q] = b;
-          }
+        const int vc = u / T;
+        if (vc != bias_vc) { bias_vc = vc; cb_load_bias(a.bias, a.Cout, vc % a.ncob, lg, bias4); }   // (a few times per launch)
       }
-      const unsigned char* const pW = sW + (chunk & 1) * G::W_BYTES + aoff;
-      const unsigned char* const pH = sH + (s & 1) * G::H_BYTES;
-      s16x8 fa[2][2], fb[2][2];
-      auto fetch = [&](int step, s16x8 (&qa)[2], s16x8 (&qb)[2]) {
+      const unsigned char* const pW = sW + Q * G::W_BYTES + aoff;
+      const unsigned char* const pH = sH + Q * G::H_BYTES;
+      // operands run PF k-steps ahead of the MFMAs that use them: with ONE consumer wave per SIMD nothing else hides the
+      // ds_read latency
+      constexpr int PF = 2;
+      s16x8 fa[PF + 1][2], fb[PF + 1][2];
+      auto fetch = [&](int step, s16x8 (&qa)[2], s16x8 (&qb)[2]) __attribute__((always_inline)) {
         const int tap = step >> 1, ks = step & 1;
         const int dy = tap / 3, dx = tap % 3;
         qa[0] = *reinterpret_cast<const s16x8*>(pW + ((tap * 2 + ks) * 2 + 0) * 1024);
         qa[1] = *reinterpret_cast<const s16x8*>(pW + ((tap * 2 + ks) * 2 + 1) * 1024);
-        qb[0] = *reinterpret_cast<const s16x8*>(pH + boff[0] + (dy * HT + dx) * CB_PS + ks * 32);
-        qb[1] = *reinterpret_cast<const s16x8*>(pH + boff[1] + (dy * HT + dx) * CB_PS + ks * 32);
+        if constexpr (DMA) {
+          qb[0] = *reinterpret_cast<const s16x8*>(pH + baddr[0][tap][ks]);
+          qb[1] = *reinterpret_cast<const s16x8*>(pH + baddr[1][tap][ks]);
+        } else {
+          qb[0] = *reinterpret_cast<const s16x8*>(pH + boff[0] + (dy * HT + dx) * CB_PS + ks * 32);
+          qb[1] = *reinterpret_cast<const s16x8*>(pH + boff[1] + (dy * HT + dx) * CB_PS + ks * 32);
+        }
       };
       if (!(a.ablate & 8)) {
-      fetch(0, fa[0], fb[0]);
+#pragma unroll
+      for (int p = 0; p < PF; ++p) fetch(p, fa[p], fb[p]);
 #pragma unroll
       for (int step = 0; step < 18; ++step) {
-        const int cur = step & 1;
-        if (step + 1 < 18) fetch(step + 1, fa[cur ^ 1], fb[cur ^ 1]);
+        const int cur = step % (PF + 1);
+        if (step + PF < 18) fetch(step + PF, fa[(step + PF) % (PF + 1)], fb[(step + PF) % (PF + 1)]);
         __builtin_amdgcn_sched_barrier(0);
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
@@ -117,6 +149,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
         __builtin_amdgcn_sched_barrier(0);
       }
       }
+      if (tr) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; }
       if (chunk + 1 == a.nchunks) {
         // finished unit: bias, rounding, hand the tile to the producers through LDS (they copied the previous one out a stage ago)
 #pragma unroll
@@ -136,7 +169,24 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
       } else {
         ++chunk;
       }
+      if (tr) { t0 = __builtin_readcyclecounter(); tc[1] += t0 - t1; }
       __syncthreads();
+      if (tr) tc[2] += __builtin_readcyclecounter() - t0;
+    };
+    for (int s = 0; s < nstages; s += 2) {   // (nstages is even: nchunks is)
+      stage(std::integral_constant<int, 0>{});
+      stage(std::integral_constant<int, 1>{});
+    }
+    if (a.trace != nullptr && wave == 0 && lane == 0 && blockIdx.x < 512) {   // every workgroup: [start, end] in 100 MHz ticks
+      a.trace[64 + 2 * blockIdx.x] = tr0;
+      a.trace[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (tr && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a.trace[wave * 8 + k] = tc[k];
+      a.trace[wave * 8 + 7] = nstages;
+      a.trace[wave * 8 + 5] = __builtin_readcyclecounter() - tk0;        // shader-clock cycles and 100 MHz ticks of the whole loop
+      a.trace[wave * 8 + 6] = __builtin_amdgcn_s_memrealtime() - tr0;
     }
     return;
   }
@@ -150,104 +200,156 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
   int hs_rel[NHS], hs_yx[NHS];
 #pragma unroll
   for (int i = 0; i < NHS; ++i) {
+    // staged form: thread -> (slot ptid / 4 + 64 i, item ptid % 4).  DMA form: 16-byte unit q = ptid + 256 i of the dense image ->
+    // slot q / 4, whose item at position q % 4 is channel item (q % 4) ^ ((slot / 4) % 4)
     const int sl = (ptid >> 2) + 64 * i;
+    const int cpart = DMA ? (part ^ ((sl >> 2) & 3)) : part;
     const int hy = sl / HT, hx = sl - hy * HT;
     hs_yx[i] = ((sl < HT * HT ? hy - PAD : -30000) << 16) | ((hx - PAD) & 0xffff);
-    hs_rel[i] = (((hy - PAD) * a.W + (hx - PAD)) * a.in_cs + a.in_co + part * 8) * 2;
+    hs_rel[i] = (((hy - PAD) * a.W + (hx - PAD)) * a.in_cs + a.in_co + cpart * 8) * 2;
   }
   __amdgpu_buffer_rsrc_t rsrc_in;
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(a.wpk), 0, (unsigned)(a.ncob * a.nchunks * G::W_BYTES), 0x00020000);
-  // unit descriptors: "ld_" = the unit whose stages are being loaded / staged, "st_" = the finished unit awaiting copy-out
-  int ld_view = 0, ld_cob = 0, ld_n = 0, ld_ty0 = 0, ld_tx0 = 0, ld_vc = 0;
-  auto decode = [&](int uu) {
-    const int vc = uu / T, t = uu - vc * T;
-    ld_vc = vc;
-    ld_view = vc / a.ncob; ld_cob = vc - ld_view * a.ncob;
-    const int txi = t % a.tiles_x, t2 = t / a.tiles_x;
-    const int tyi = t2 % a.tiles_y;
-    ld_n = t2 / a.tiles_y;
-    ld_ty0 = tyi * CB_T; ld_tx0 = txi * CB_T;
+
+  // ---- unit walker: (vc = view * ncob + cob, image, tile row, tile column) of the unit whose stages are being LOADED.  Units of a
+  // workgroup are nslot apart: the step is decomposed once and added with carries (the five integer divisions of a from-scratch
+  // decode were ~1100 cycles per tile on the scalar unit, twice: loads and copy-out).  st1 / st2 = the two units before it: the
+  // copy-out runs one (nchunks > 2) or two (nchunks == 2) units behind the loads. ----
+  int ld_vc, ld_n, ld_ty, ld_tx;
+  {
+    const int vc = u0 / T, t = u0 - vc * T;
+    const int t2 = t / a.tiles_x;
+    ld_vc = vc; ld_tx = t - t2 * a.tiles_x; ld_n = t2 / a.tiles_y; ld_ty = t2 - ld_n * a.tiles_y;
+  }
+  int d_vc, d_n, d_ty, d_tx;
+  {
+    const int r1 = nslot / a.tiles_x, r2 = r1 / a.tiles_y;
+    d_tx = nslot - r1 * a.tiles_x; d_ty = r1 - r2 * a.tiles_y; d_vc = r2 / a.N; d_n = r2 - d_vc * a.N;
+  }
+  int st1_vc = 0, st1_n = 0, st1_yx = 0, st2_vc = 0, st2_n = 0, st2_yx = 0;
+  int ld_view = 0, ld_cob = 0;
+  bool ld_border = false;
+  auto setup_unit = [&]() __attribute__((always_inline)) {   // descriptor + per-slot offsets of the unit (ld_vc, ld_n, ld_ty, ld_tx)
+    ld_view = ld_vc >= a.ncob ? 1 : 0; ld_cob = ld_vc - ld_view * a.ncob;
+    const int ty0 = ld_ty * CB_T, tx0 = ld_tx * CB_T;
     rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.in[ld_view])) + (size_t)ld_n * a.in_img_bytes, 0, a.in_img_bytes, 0x00020000);
-    const int org = (ld_ty0 * a.W + ld_tx0) * a.in_cs * 2;
-    const bool interior = ld_ty0 >= PAD && ld_tx0 >= PAD && ld_ty0 + CB_T + PAD <= a.H && ld_tx0 + CB_T + PAD <= a.W;
-    if (interior) {
+    const int org = (ty0 * a.W + tx0) * a.in_cs * 2;
+    ld_border = !(ty0 >= PAD && tx0 >= PAD && ty0 + CB_T + PAD <= a.H && tx0 + CB_T + PAD <= a.W);
+    if (!ld_border) {
 #pragma unroll
       for (int i = 0; i < NHS; ++i) hs_g[i] = (hs_yx[i] >> 16) > -30000 ? (unsigned)(org + hs_rel[i]) : OOB;
     } else {
 #pragma unroll
       for (int i = 0; i < NHS; ++i) {
-        const int gy = ld_ty0 + (hs_yx[i] >> 16), gx = ld_tx0 + (short)(hs_yx[i] & 0xffff);
+        const int gy = ty0 + (hs_yx[i] >> 16), gx = tx0 + (short)(hs_yx[i] & 0xffff);
         const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         hs_g[i] = ok ? (unsigned)(org + hs_rel[i]) : OOB;
       }
     }
   };
-  u32x4 hv[NHS];
-  unsigned hv_pad = 0;     // bit i: slot i of the loaded stage is padding (outside the image)
-  float sc[8], sh[8];
-  auto issue = [&](int chunk) {   // halo + affine of (ld_ unit, chunk) -> registers
+  int ld_u = u0, ld_chunk = 0;          // the stage whose loads are issued next
+  auto advance = [&]() __attribute__((always_inline)) {                // -> the following stage; false past the end
+    if (ld_chunk + 1 < a.nchunks) { ++ld_chunk; return true; }
+    ld_chunk = 0; ld_u += nslot;
+    st2_vc = st1_vc; st2_n = st1_n; st2_yx = st1_yx;
+    st1_vc = ld_vc; st1_n = ld_n; st1_yx = (ld_ty << 16) | ld_tx;
+    if (ld_u >= u_end) return false;
+    ld_tx += d_tx; int c = ld_tx >= a.tiles_x ? 1 : 0; ld_tx -= c ? a.tiles_x : 0;
+    ld_ty += d_ty + c; c = ld_ty >= a.tiles_y ? 1 : 0; ld_ty -= c ? a.tiles_y : 0;
+    ld_n += d_n + c; c = ld_n >= a.N ? 1 : 0; ld_n -= c ? a.N : 0;
+    ld_vc += d_vc + c;
+    setup_unit();
+    return true;
+  };
+
+  // ---- halo loads: TWO register sets (stage parity), each in flight for two whole stages before it is staged ----
+  u32x4 hv[2][NHS];
+  unsigned hv_pad[2] = {0, 0};   // bit i: slot i of the set is padding (outside the image)
+  int hv_view[2] = {0, 0};       // view of the set's unit (affine of the 64-channel form), border flag in bit 8
+  // affine (IN_MODE 1).  NC2 (a layer of 64 input channels): both chunks' scale / shift stay in registers per view; otherwise they
+  // are loaded with the halo, per set.
+  f32x2 sc2[2][4], sh2[2][4];
+  int aff_view = -1;
+  auto load_affine = [&](int set_or_chunk, int view, int chunk) __attribute__((always_inline)) {
     const int c0 = chunk * CB_KC + part * 8;
-    hv_pad = 0;
+    const float* const p_scale = a.in_scale[view] + c0;
+    const float* const p_shift = a.in_shift[view] + c0;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(p_scale), s1 = *reinterpret_cast<const f32x4*>(p_scale + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(p_shift), h1 = *reinterpret_cast<const f32x4*>(p_shift + 4);
+    sc2[set_or_chunk][0] = f32x2{s0[0], s0[1]}; sc2[set_or_chunk][1] = f32x2{s0[2], s0[3]};
+    sc2[set_or_chunk][2] = f32x2{s1[0], s1[1]}; sc2[set_or_chunk][3] = f32x2{s1[2], s1[3]};
+    sh2[set_or_chunk][0] = f32x2{h0[0], h0[1]}; sh2[set_or_chunk][1] = f32x2{h0[2], h0[3]};
+    sh2[set_or_chunk][2] = f32x2{h1[0], h1[1]}; sh2[set_or_chunk][3] = f32x2{h1[2], h1[3]};
+  };
+  auto issue = [&](auto SET) __attribute__((always_inline)) {   // halo (+ affine) of (ld_ unit, ld_chunk) -> register set SET
+    constexpr int S = decltype(SET)::value;
+    unsigned pad = 0;
 #pragma unroll
     for (int i = 0; i < NHS; ++i) {
-      hv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (a.ablate & 1) ? OOB : hs_g[i], chunk * CB_KC * 2, 0));
-      hv_pad |= (hs_g[i] == OOB ? 1u : 0u) << i;
+      hv[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (a.ablate & 1) ? OOB : hs_g[i], ld_chunk * CB_KC * 2, 0));
+      pad |= (hs_g[i] == OOB ? 1u : 0u) << i;
     }
-    if (IN_MODE == 1) {
-      const float* const p_scale = a.in_scale[ld_view] + c0;
-      const float* const p_shift = a.in_shift[ld_view] + c0;
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(p_scale), s1 = *reinterpret_cast<const f32x4*>(p_scale + 4);
-      const f32x4 h0 = *reinterpret_cast<const f32x4*>(p_shift), h1 = *reinterpret_cast<const f32x4*>(p_shift + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = h0[e]; sh[4 + e] = h1[e]; }
-    }
+    hv_pad[S] = pad;
+    hv_view[S] = ld_view | (ld_border ? 256 : 0);
+    if (IN_MODE == 1 && !NC2) load_affine(S, ld_view, ld_chunk);
   };
-  auto stage_halo = [&](int buf) {   // registers -> activated bf16 operands in halo buffer `buf`
+  auto stage_halo = [&](auto SET) __attribute__((always_inline)) {   // register set SET -> activated bf16 operands in halo buffer SET
+    constexpr int S = decltype(SET)::value;
     if (a.ablate & 2) return;
-    unsigned char* const dst = sH + buf * G::H_BYTES + hs_lds0;
+    unsigned char* const dst = sH + S * G::H_BYTES + hs_lds0;
     // BatchNorm + ReLU + rounding of 8 values in 20 vector instructions: 8 shifts / masks (bf16 -> fp32), 4 packed fmas, 4
     // v_cvt_pk_bf16_f32 and the ReLU on the PACKED result as a 16-bit integer max with 0 (a negative bf16 is a negative int16;
     // rounding is monotonic and odd, so relu(round(z)) == round(relu(z)))
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    f32x2 sc2[4], sh2[4];
-    if (IN_MODE == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { sc2[e] = f32x2{sc[2 * e], sc[2 * e + 1]}; sh2[e] = f32x2{sh[2 * e], sh[2 * e + 1]}; }
+    if (IN_MODE == 1 && NC2 && (hv_view[S] & 255) != aff_view) {   // (once or twice per launch)
+      aff_view = hv_view[S] & 255;
+      load_affine(0, aff_view, 0);
+      load_affine(1, aff_view, 1);
     }
+    const bool border = (hv_view[S] & 256) != 0;   // (uniform) padding is zero in the ACTIVATED domain
 #pragma unroll
     for (int i = 0; i < NHS; ++i) {
       if ((ptid >> 2) + 64 * i >= HT * HT) continue;
       u32x4 o;
-      if (IN_MODE == 1) {
+      if (IN_MODE == 1 && !(a.ablate & 128)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const f32x2 z = pk_fma(f32x2{bf16_lo(hv[i][e]), bf16_hi(hv[i][e])}, sc2[e], sh2[e]);
+          const f32x2 z = ws_pk_fma(f32x2{bf16_lo(hv[S][i][e]), bf16_hi(hv[S][i][e])}, sc2[S][e], sh2[S][e]);
           const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(z[0], z[1])), s16x2{0, 0});
           o[e] = __builtin_bit_cast(uint32_t, r);
         }
-        if (hv_pad != 0) {   // (border tiles only) padding is zero in the ACTIVATED domain
-          const bool pad = (hv_pad >> i) & 1u;
+        if (border) {
+          const bool pad = (hv_pad[S] >> i) & 1u;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pad ? 0u : o[e];
         }
       } else {
-        o = hv[i];
+        o = hv[S][i];
       }
-      *reinterpret_cast<u32x4*>(dst + i * 64 * CB_PS) = o;
+      if (!(a.ablate & 256)) *reinterpret_cast<u32x4*>(dst + i * 64 * CB_PS) = o;
+      else asm volatile("" :: "v"(o));
     }
   };
-  int w_tag[2] = {-1, -1};
-  auto stage_weights = [&](int cob, int chunk) {   // the 36 KB image of (cob, chunk) into slot chunk & 1 unless it is there already
-    const int tag = cob * a.nchunks + chunk, sl = chunk & 1;
-    if (w_tag[sl] == tag) return;
-    w_tag[sl] = tag;
-    u32x4 wv[9];
+  // weights: the 36 KB image of (cob, chunk) lives in slot chunk & 1 (never the slot the consumers read: nchunks is even).  A layer
+  // of 64 input channels loads its two images once; wider layers swap a slot every stage, so the image of stage s + 2 is fetched
+  // into registers an iteration ahead (in flight for a whole stage) and written to LDS one iteration later.
+  int w_tag0 = -1, w_tag1 = -1;     // (two scalars: a dynamically indexed array would live in scratch memory)
+  u32x4 wv[9];
+  int wv_tag = -1;
+  auto fetch_weights = [&](int tag, int par) __attribute__((always_inline)) {
+    if (tag < 0 || (par ? w_tag1 : w_tag0) == tag) return;
+    wv_tag = tag;
 #pragma unroll
     for (int i = 0; i < 9; ++i) wv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, ptid * 16, tag * G::W_BYTES + 4096 * i, 0));
+  };
+  auto commit_weights = [&](int par) __attribute__((always_inline)) {
+    if (wv_tag < 0) return;
+    if (par) w_tag1 = wv_tag; else w_tag0 = wv_tag;
+    wv_tag = -1;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(sW + sl * G::W_BYTES + (ptid + 256 * i) * 16) = wv[i];
+    for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(sW + par * G::W_BYTES + (ptid + 256 * i) * 16) = wv[i];
   };
 
   // statistics of the stored values: per-thread sums of this thread's 8 channels (item = ptid & 7), flushed per (view, cob)
@@ -255,9 +357,10 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
   f32x2 ps[4], pq[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) ps[e] = pq[e] = f32x2{0.f, 0.f};
-  int st_key = -1;
-  auto flush_stats = [&](int key) {
-    const int view = key / a.ncob, cob = key - view * a.ncob;
+  int st_key = -1, pg_key = -1;
+  uint32_t pg_neg[4] = {0u, 0u, 0u, 0u};
+  auto flush_stats = [&](int key) __attribute__((always_inline)) {
+    const int view = key >= a.ncob ? 1 : 0, cob = key - view * a.ncob;
     double* const p_stats = a.stats[view];
     float v[16];
 #pragma unroll
@@ -282,12 +385,10 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
   };
 
   // copy-out of a finished unit from the LDS tile: 16-byte stores, statistics of the stored values, raw pooled copy
-  auto copy_out = [&](int uu) {
+  auto copy_out = [&](int vc, int n, int yx) __attribute__((always_inline)) {
     if (a.ablate & 4) return;
-    const int vc = uu / T, t = uu - vc * T;
-    const int view = vc / a.ncob, cob = vc - view * a.ncob;
-    const int txi = t % a.tiles_x, t2 = t / a.tiles_x;
-    const int n = t2 / a.tiles_y, ty0 = (t2 % a.tiles_y) * CB_T, tx0 = txi * CB_T;
+    const int view = vc >= a.ncob ? 1 : 0, cob = vc - view * a.ncob;
+    const int ty0 = (yx >> 16) * CB_T, tx0 = (yx & 0xffff) * CB_T;
     const bool do_stats = a.stats[0] != nullptr;
     if (do_stats && vc != st_key) {
       if (st_key >= 0) flush_stats(st_key);
@@ -303,81 +404,174 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     const unsigned vo = col_ok ? (unsigned)((((ty0 + row0) * a.W + tx0 + col) * a.out_cs + a.out_co + co0) * 2) : OOB;
     const int rstep = 2 * a.W * a.out_cs * 2;
     const bool full = ty0 + CB_T <= a.H;
+    const bool whole = full && tx0 + CB_T <= a.W && (cob + 1) * CB_NB <= a.Cout;   // (uniform) every element of the tile is stored
+    auto rows = [&](auto WHOLE, auto STATS) __attribute__((always_inline)) {   // (both uniform: straight-line code per variant)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int lp = (ptid >> 3) + 32 * k;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(sO + lp * 128 + ((item ^ (lp & 7)) << 4));
-      __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_out, vo, rstep * k, 0);   // rows below the image fall off the descriptor
-      if (do_stats) {
-        const bool ok = col_ok && (full || ty0 + row0 + 2 * k < a.H);
+      for (int kb = 0; kb < 8; kb += 4) {   // four LDS reads in flight before the first use
+        u32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t w = ok ? v[e] : 0u;
-          const f32x2 f = {bf16_lo(w), bf16_hi(w)};
-          ps[e] = pk_add(ps[e], f);
-          pq[e] = pk_fma(f, f, pq[e]);
+        for (int k = 0; k < 4; ++k) {
+          const int lp = (ptid >> 3) + 32 * (kb + k);
+          v[k] = *reinterpret_cast<const u32x4*>(sO + lp * 128 + ((item ^ (lp & 7)) << 4));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_raw_buffer_store_b128(v[k], rsrc_out, vo, rstep * (kb + k), 0);   // rows below the image fall off the descriptor
+          if (decltype(STATS)::value) {
+            const bool ok = decltype(WHOLE)::value || (col_ok && (full || ty0 + row0 + 2 * (kb + k) < a.H));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t w = ok ? v[k][e] : 0u;
+              ws_pk_acc(ps[e], pq[e], f32x2{bf16_lo(w), bf16_hi(w)});
+            }
+          }
         }
       }
-    }
+    };
+    if (do_stats) { if (whole) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
+    else rows(std::true_type{}, std::false_type{});
     if (a.pool_out[0] != nullptr && ch_ok) {
-      // raw 2x2-pooled copy: per-channel max (gamma >= 0) or min (gamma < 0) of the window (see conv_bf16_kernel)
+      // raw 2x2-pooled copy: per-channel max (gamma >= 0) or min (gamma < 0) of the window (see conv_bf16_kernel).  bf16 pairs are
+      // compared as PACKED HALVES (v_pk_max_f16 / v_pk_min_f16): both formats are sign-magnitude with the exponent above the
+      // mantissa, so the order of two finite bf16 values is the order of the same bits read as fp16 (|x| >= 2^121 would read as an
+      // fp16 NaN, < 2^-119 as a denormal: not activations) - 3 instructions per pair of channels instead of unpack + fp32 max + pack.
+      // The signs of this thread's 8 gammas become a 16-bit-lane mask when the channel block changes.
       uint16_t* const p_pool = a.pool_out[view];
-      float gsign[8];
+      if (vc != pg_key) {
+        pg_key = vc;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) gsign[e] = a.pool_gamma[co0 + e];
+        for (int e = 0; e < 4; ++e)
+          pg_neg[e] = (a.pool_gamma[co0 + 2 * e] < 0.f ? 0x0000ffffu : 0u) | (a.pool_gamma[co0 + 2 * e + 1] < 0.f ? 0xffff0000u : 0u);
+      }
+      const bool any_neg = __builtin_amdgcn_ballot_w64((pg_neg[0] | pg_neg[1] | pg_neg[2] | pg_neg[3]) != 0u) != 0ull;   // (uniform)
       const int Hp = a.H >> 1, Wp = a.W >> 1;
+      auto pkmax = [](uint32_t x, uint32_t y) __attribute__((always_inline)) { uint32_t r; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+      auto pkmin = [](uint32_t x, uint32_t y) __attribute__((always_inline)) { uint32_t r; asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int pp = (ptid >> 3) + 32 * k;
         const int py = pp >> 3, px = pp & 7;
         const int oy = (ty0 >> 1) + py, ox = (tx0 >> 1) + px;
-        if (oy >= Hp || ox >= Wp) continue;
         const int lp = (2 * py) * 16 + 2 * px;
-        auto rd = [&](int q) { return *reinterpret_cast<const u32x4*>(sO + q * 128 + ((item ^ (q & 7)) << 4)); };
+        auto rd = [&](int q) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(sO + q * 128 + ((item ^ (q & 7)) << 4)); };
         const u32x4 v0 = rd(lp), v1 = rd(lp + 1), v2 = rd(lp + 16), v3 = rd(lp + 17);
         u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float l0 = bf16_lo(v0[e]), l1 = bf16_lo(v1[e]), l2 = bf16_lo(v2[e]), l3 = bf16_lo(v3[e]);
-          const float h0 = bf16_hi(v0[e]), h1 = bf16_hi(v1[e]), h2 = bf16_hi(v2[e]), h3 = bf16_hi(v3[e]);
-          const float lo = gsign[2 * e] >= 0.f ? fmaxf(fmaxf(l0, l1), fmaxf(l2, l3)) : fminf(fminf(l0, l1), fminf(l2, l3));
-          const float hi = gsign[2 * e + 1] >= 0.f ? fmaxf(fmaxf(h0, h1), fmaxf(h2, h3)) : fminf(fminf(h0, h1), fminf(h2, h3));
-          o[e] = (__builtin_bit_cast(uint32_t, lo) >> 16) | (__builtin_bit_cast(uint32_t, hi) & 0xffff0000u);
+        for (int e = 0; e < 4; ++e) o[e] = pkmax(pkmax(v0[e], v1[e]), pkmax(v2[e], v3[e]));
+        if (any_neg) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t mn = pkmin(pkmin(v0[e], v1[e]), pkmin(v2[e], v3[e]));
+            o[e] = (mn & pg_neg[e]) | (o[e] & ~pg_neg[e]);
+          }
         }
-        *reinterpret_cast<u32x4*>(p_pool + ((size_t)(n * Hp + oy) * Wp + ox) * a.Cout + co0) = o;
+        if (oy < Hp && ox < Wp) *reinterpret_cast<u32x4*>(p_pool + ((size_t)(n * Hp + oy) * Wp + ox) * a.Cout + co0) = o;
       }
     }
   };
 
-  // ---- prologue: stage 0 (and its weights) synchronously, stage 1's loads in flight ----
-  int ld_u = u0, ld_chunk = 0;          // the stage whose loads are in flight (stage s + 1 inside the loop)
-  auto advance = [&]() {                // -> the following stage (decodes a new unit); false past the end
-    if (ld_chunk + 1 < a.nchunks) { ++ld_chunk; return true; }
-    ld_chunk = 0; ld_u += nslot;
-    if (ld_u >= u_end) return false;
-    decode(ld_u);
-    return true;
-  };
-  decode(ld_u);
-  issue(0);
-  stage_weights(ld_cob, 0);
-  stage_halo(0);
-  bool ld_ok = advance();
-  if (ld_ok) issue(ld_chunk);
-  int cs_u = u0, cs_chunk = 0;          // the stage the consumers compute
-  __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    if (ld_ok) {
-      stage_weights(ld_cob, ld_chunk);   // slot = parity of the chunk: never the slot the consumers read (nchunks is even)
-      stage_halo((s + 1) & 1);
-      ld_ok = advance();
-      if (ld_ok) issue(ld_chunk);        // stage s + 2: in flight across the barrier and the next stage
-    }
-    if (cs_chunk == 0 && s > 0) copy_out(cs_u - nslot);   // the unit that finished with stage s - 1
-    if (++cs_chunk == a.nchunks) { cs_chunk = 0; cs_u += nslot; }
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  const bool tr = a.trace != nullptr && blockIdx.x == 0;   // (perf-debug: cycle sums of [copy-out, staging, issue, barrier, load wait, advance])
+  unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+  int cs_chunk = 0;                     // chunk of the stage the consumers compute
+  if constexpr (DMA) {
+    // ---- data gradient: the halo of stage s + 1 goes global -> LDS while the consumers compute stage s (6 buffer_load ... lds
+    // per producer wave, out-of-image units read as zeros), the weights of a new (cob, chunk) through registers in the same
+    // iteration; the producers' vector work is the copy-out alone ----
+    typedef __attribute__((address_space(3))) void* ldsp;
+    auto issue_dma = [&](auto PAR) __attribute__((always_inline)) {
+      constexpr int Q = decltype(PAR)::value;
+#pragma unroll
+      for (int i = 0; i < NHS; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (ldsp)(sH + Q * G::H_BYTES + (256 * i + 64 * pwave) * 16), 16,
+                                                 (a.ablate & 1) ? OOB : hs_g[i], ld_chunk * CB_KC * 2, 0, 0);
+    };
+    setup_unit();
+    issue_dma(P0{});
+    fetch_weights(ld_cob * a.nchunks, 0);
+    commit_weights(0);
+    bool ld_ok = advance();             // -> stage 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    auto iteration = [&](int s, auto PAR) __attribute__((always_inline)) {   // PAR = parity of stage s + 1
+      constexpr int Q = decltype(PAR)::value;
+      if (tr) t0 = __builtin_readcyclecounter();
+      if (ld_ok) {                       // ld_ = stage s + 1: its buffers were last read in stage s - 1
+        issue_dma(PAR);
+        fetch_weights(ld_cob * a.nchunks + ld_chunk, Q);
+      }
+      if (tr) { t1 = __builtin_readcyclecounter(); tc[2] += t1 - t0; }
+      if (cs_chunk == 0 && s > 0) copy_out(st1_vc, st1_n, st1_yx);   // the unit that finished with stage s - 1
+      if (++cs_chunk == a.nchunks) cs_chunk = 0;
+      if (tr) { t0 = __builtin_readcyclecounter(); tc[0] += t0 - t1; }
+      if (ld_ok) {
+        commit_weights(Q);
+        ld_ok = advance();
+      }
+      if (tr) { t1 = __builtin_readcyclecounter(); tc[5] += t1 - t0; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (and the copy-out's stores have left)
+      if (tr) { t0 = __builtin_readcyclecounter(); tc[4] += t0 - t1; }
+      __syncthreads();
+      if (tr) tc[3] += __builtin_readcyclecounter() - t0;
+    };
+    for (int s = 0; s < nstages; s += 2) {   // (nstages is even: nchunks is)
+      iteration(s, P1{});
+      iteration(s + 1, P0{});
+    }
+  } else {
+  // ---- prologue: stage 0 (and its weights) synchronously; the loads of stages 1 and 2 in flight ----
+  setup_unit();
+  int w_next = -1;                      // weight tag of the stage whose halo was issued last (its image is fetched an iteration later)
+  int w_pend = -1;                      // (NC2) the same tag an iteration later
+  issue(P0{});
+  fetch_weights(ld_cob * a.nchunks, 0);
+  commit_weights(0);
+  stage_halo(P0{});
+  bool ld_ok = advance();               // -> stage 1
+  if (ld_ok) { issue(P1{}); fetch_weights(ld_cob * a.nchunks + ld_chunk, 1); ld_ok = advance(); }
+  if (ld_ok) { issue(P0{}); w_next = ld_cob * a.nchunks + ld_chunk; ld_ok = advance(); } else w_next = -1;   // stage 2; ld_ -> stage 3
+  __syncthreads();
+  // iteration s (the consumers compute stage s): copy-out of the unit that finished with stage s - 1, weights + halo of stage
+  // s + 1 into the buffers of its parity, then the loads of stage s + 3 into the register set that staging freed
+  auto iteration = [&](int s, auto PAR) __attribute__((always_inline)) {   // PAR = parity of stage s + 1
+    constexpr int Q = decltype(PAR)::value;
+    if (tr) t0 = __builtin_readcyclecounter();
+    if (cs_chunk == 0 && s > 0) { if (NC2) copy_out(st2_vc, st2_n, st2_yx); else copy_out(st1_vc, st1_n, st1_yx); }
+    if (++cs_chunk == a.nchunks) cs_chunk = 0;
+    if (tr) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; }
+    if (s + 1 < nstages) {
+      if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t0 = __builtin_readcyclecounter(); tc[4] += t0 - t1; t1 = t0; }
+      if (NC2) { fetch_weights(w_pend, Q); w_pend = -1; }   // (registers of the image live here only)
+      commit_weights(Q);
+      stage_halo(PAR);
+      if (tr) { t0 = __builtin_readcyclecounter(); tc[1] += t0 - t1; }
+      if (NC2) w_pend = w_next;          // a 64-channel layer changes its images with the output block only: fetched in place
+      else fetch_weights(w_next, Q ^ 1); // image of stage s + 2: in flight until the next iteration writes it to LDS
+      w_next = -1;
+      if (ld_ok) {                       // ld_ = stage s + 3
+        issue(PAR);
+        w_next = ld_cob * a.nchunks + ld_chunk;
+        if (tr) { t1 = __builtin_readcyclecounter(); tc[2] += t1 - t0; t0 = t1; }
+        ld_ok = advance();
+        if (tr) { t1 = __builtin_readcyclecounter(); tc[5] += t1 - t0; }
+      }
+    }
+    if (tr) t0 = __builtin_readcyclecounter();
+    __syncthreads();
+    if (tr) tc[3] += __builtin_readcyclecounter() - t0;
+  };
+  for (int s = 0; s < nstages; s += 2) {   // (nstages is even: nchunks is)
+    iteration(s, P1{});
+    iteration(s + 1, P0{});
   }
-  copy_out(cs_u - nslot);
+  }
+  if (tr && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.trace[wave * 8 + k] = tc[k];
+    a.trace[wave * 8 + 7] = nstages;
+  }
+  copy_out(st1_vc, st1_n, st1_yx);
   if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
 }
 

@@ -21,27 +21,27 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // `volatile` keeps the program order of these statements among themselves.
 __device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
   f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
   return d;
 }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
   f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
   return d;
 }
 __device__ __forceinline__ f32x2 pk_nadd(f32x2 x, f32x2 y) {  // -(x + y)
   f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(d) : "v"(x), "v"(y));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(d) : "v"(x), "v"(y));
   return d;
 }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 x, f32x2 y, f32x2 z) {
   f32x2 d;
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
   return d;
 }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 x, f32x2 y) {
   f32x2 d;
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
   return d;
 }
 __device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
@@ -83,8 +83,8 @@ __device__ __forceinline__ float round_bf16(float v) { return bf16_lo(pack_bf16(
 template <bool BCAST_HI>
 __device__ __forceinline__ f32x2 pk_fma_bcast(f32x2 x, f32x2 y, f32x2 z) {
   f32x2 d;
-  if (BCAST_HI) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(y), "v"(z));
-  else asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  if (BCAST_HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "v"(y), "v"(z));
   return d;
 }
 

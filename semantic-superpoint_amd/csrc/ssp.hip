@@ -1348,6 +1348,7 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
   G1PackJobs G;
   G.n = 0;
   int g1_blocks = 0;
+  PackBQueue BQ;   // (bf16 path)
   for (int l = 1; l < h->nlayers; ++l) {
     const LayerDesc& d = h->L[l];
     // the encoder's 3x3 layers at their resolution: the same F(4x4,3x3) predicate as the launches (conv_uses_w4)
@@ -1368,9 +1369,9 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     }
     if (bf16_path()) {  // bf16 operand images of conv_bf16_kernel (forward; mirrored / transposed for the data gradient)
       h->pk_w4_fwd[l] = h->pk_w4_bwd[l] = false; h->pk_g1[l] = false;
-      CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_fwd + d.pk_fwd), d.cout, d.cin, d.ks, 0, 0, 0, st));
+      CHK(BQ.add(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_fwd + d.pk_fwd), d.cout, d.cin, d.ks, 0, 0, 0, st));
       if (with_bwd && (l < 8 || d.ks == 1))  // (the 3x3 heads share ONE concatenated data-gradient image, below)
-        CHK(launch_pack_bf16(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_bwd + d.pk_bwd), d.cout, d.cin, d.ks, 1, 0, 0, st));
+        CHK(BQ.add(P(h, d.w_off), reinterpret_cast<uint16_t*>(h->wpk_bwd + d.pk_bwd), d.cout, d.cin, d.ks, 1, 0, 0, st));
       continue;
     }
     const bool wf = wino_ok(d.ks, d.cin), wb = wino_ok(d.ks, d.cout);
@@ -1389,7 +1390,7 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
   if (with_bwd && bf16_path()) {  // the same concatenation as a bf16 image: 8 chunks of 32 dY channels per head
     const int heads[3] = {L_PA, L_DA, L_DS};
     for (int k = 0; k < h->nheads; ++k)
-      CHK(launch_pack_bf16(P(h, h->L[heads[k]].w_off), reinterpret_cast<uint16_t*>(h->wpk_heads_bwd), 256, 128, 3, 1, 8 * h->nheads, 8 * k, st));
+      CHK(BQ.add(P(h, h->L[heads[k]].w_off), reinterpret_cast<uint16_t*>(h->wpk_heads_bwd), 256, 128, 3, 1, 8 * h->nheads, 8 * k, st));
   } else if (with_bwd) {  // concatenated data-gradient weights of the 3x3 heads: input channels = [Pa | Da | DS] dY
     const int heads[3] = {L_PA, L_DA, L_DS};
     const bool wino = wino_ok(3, 256 * h->nheads);
@@ -1413,6 +1414,7 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     }
     HIPCHK(hipGetLastError());
   }
+  CHK(BQ.flush(st));   // every bf16 operand image of the step: one launch
   if (J.n > 0) {
     hipLaunchKernelGGL(pack_weights_wino8_multi_kernel, dim3(nblocks), dim3(256), 0, st, J);
     HIPCHK(hipGetLastError());

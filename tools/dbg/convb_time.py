@@ -1,6 +1,6 @@
 """Times conv_bf16_kernel / wgrad_bf16_kernel on the layer shapes of the benchmark (operator level)."""
 import sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from semantic_superpoint_amd import lib as L
 dev = torch.device('cuda:0')
 shapes = [(64, 240, 320, 64, 64), (64, 120, 160, 64, 64), (64, 60, 80, 128, 128), (64, 30, 40, 128, 128), (64, 30, 40, 128, 256)]
@@ -14,6 +14,8 @@ for (N, H, W, cin, cout) in shapes:
     def run():
         if which == "conv":
             return L.op_conv_bf16(x, w, None, 3, in_mode=1, in_scale=sc, in_shift=sh)
+        if which == "dgrad":
+            return L.op_conv_bf16(x, w, None, 3, in_mode=0)
         return L.op_conv_wgrad_bf16(x, dy, 3, in_mode=1, in_scale=sc, in_shift=sh)
     for _ in range(3): run()
     torch.cuda.synchronize()
