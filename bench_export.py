@@ -55,12 +55,33 @@ def parse_args(argv=None):
     ap.add_argument("--thresh", type=float, default=0.0155)  # random-init logits: softmax ~ 1/65 = 0.01538
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also time the stages separately (extra, untimed pass)")
+    ap.add_argument("--images-per-step", type=int, default=8,
+                    help="images per timed step (BASELINE configs[4]: batch 64 over 8 GPUs = 8 per GPU; the library call takes 2)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "none"], help="PMC child passes (FETCH_SIZE, WRITE_SIZE) for roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
-def measure_export(dev, arch, n, H, W, thresh, steps, warmup, rank=0, world=1, dist=None, stages=False):
-    """`steps` timed ssp_export_points calls (two images each) on `dev` after `warmup` untimed ones; barriers and the
-    max over ranks when world > 1.  Returns the result fields (rank 0: incl. the roofline of the 3x3 forward launches).
+EXPORT_PMC_KERNELS = ("conv_wino4_kernel", "conv_wino_pipe_kernel", "conv_wino_p2_kernel", "conv0_direct_kernel", "conv1x1_group_kernel")
+
+
+def export_pmc(arch_key, views, H, W):
+    """HBM bytes per launch of the export's convolution kernels: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a
+    1 + 1-step child run of this script (one call, two images), collected and corrected by bench.live_pmc.  {} on failure."""
+    import bench
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "1", "--gpus", "1", "--arch", arch_key,
+             "--views", str(views), "--height", str(H), "--width", str(W), "--no-cpu-baseline", "--traffic", "none"]
+    try:
+        pmc, _ = bench.live_pmc(None, counter_sets=(("FETCH_SIZE",), ("WRITE_SIZE",)), child=child, kernels=EXPORT_PMC_KERNELS)
+    except Exception:
+        return {}
+    return pmc
+
+
+def measure_export(dev, arch, n, H, W, thresh, steps, warmup, rank=0, world=1, dist=None, stages=False, images_per_step=2, pmc=None):
+    """`steps` timed steps of `images_per_step` images (ssp_export_points handles two images per call: a step is
+    images_per_step / 2 calls back to back) on `dev` after `warmup` untimed ones; barriers and the max over ranks when world > 1.
+    `pmc` = {kernel: {"traffic": bytes per launch}} from bench.live_pmc (HBM bytes of the dominant kernel), or None.  Returns the result fields (rank 0: incl. the roofline of the 3x3 forward launches).
     Used by main() below and by bench.py's `export` block (BASELINE configs[4] beside the headline line)."""
     import numpy as np
     import torch
@@ -71,7 +92,10 @@ def measure_export(dev, arch, n, H, W, thresh, steps, warmup, rank=0, world=1, d
     eng.load_state_dict(synth.default_init_state_dict(L.layer_table(arch), seed=0))
     rs = np.random.RandomState(1000 + rank)
     g = torch.Generator().manual_seed(1000 + rank)
-    imgs = [torch.rand(H, W, generator=g).to(dev) for _ in range(2)]
+    if images_per_step < 2 or images_per_step % 2:
+        raise ValueError("images_per_step must be a positive multiple of 2 (the library call takes two images)")
+    calls = images_per_step // 2
+    imgs = [torch.rand(H, W, generator=g).to(dev) for _ in range(images_per_step)]
 
     def homographies():
         hs = np.stack([np.linalg.inv(synth.sample_homography(rs, **synth.WARP_PARAMS)) for _ in range(n)])
@@ -79,14 +103,18 @@ def measure_export(dev, arch, n, H, W, thresh, steps, warmup, rank=0, world=1, d
         hs = torch.from_numpy(hs.astype(np.float32))
         return hs.to(dev), torch.inverse(hs).contiguous().to(dev)
 
-    hom = [homographies() for _ in range(2)]  # host-side sampling stays outside the timed region (as in the loader)
+    hom = [homographies() for _ in range(images_per_step)]  # host-side sampling stays outside the timed region (as in the loader)
     torch.cuda.synchronize()
 
     def step():
-        vm = [L.op_homoadapt_views(imgs[k], hom[k][1]) for k in range(2)]
-        outs = eng.export_points([v for v, _ in vm], [m for _, m in vm], [hom[k][0] for k in range(2)],
-                                 conf_thresh=thresh, nms_dist=4, top_k=600, subpixel=True)
-        return [int(o["count"].item()) for o in outs]  # the host needs the counts to slice the point lists
+        counts = []
+        for c in range(calls):
+            ks = (2 * c, 2 * c + 1)
+            vm = [L.op_homoadapt_views(imgs[k], hom[k][1]) for k in ks]
+            outs = eng.export_points([v for v, _ in vm], [m for _, m in vm], [hom[k][0] for k in ks],
+                                     conf_thresh=thresh, nms_dist=4, top_k=600, subpixel=True)
+            counts += [int(o["count"].item()) for o in outs]  # the host needs the counts to slice the point lists
+        return counts
 
     counts = None
     for _ in range(warmup):
@@ -108,7 +136,8 @@ def measure_export(dev, arch, n, H, W, thresh, steps, warmup, rank=0, world=1, d
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    res = {"images_per_s": world * 2 * steps / dt, "ms_per_step": 1e3 * dt / steps, "points_last_step": counts}
+    res = {"images_per_s": world * images_per_step * steps / dt, "ms_per_step": 1e3 * dt / steps, "points_last_step": counts,
+           "images_per_step": images_per_step}
     if rank == 0:
         pr = eng.profile_read()
         if pr["launches"] > 0 and pr["ms"] > 0:
@@ -124,8 +153,16 @@ def measure_export(dev, arch, n, H, W, thresh, steps, warmup, rank=0, world=1, d
                                        "for F(4x4,3x3), 16/36 for F(2x2,3x3)); algorithmic_* = direct-convolution FLOPs / time",
                                "algorithmic_tflops": round(alg, 2), "algorithmic_frac": round(alg / PEAK_FP32_MFMA_TF, 4),
                                "executed_tflops": round(ex, 2), "executed_frac": round(ex / PEAK_FP32_MFMA_TF, 4),
-                               "traffic": None, "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
+                               "traffic": None, "traffic_kernel": None,
+                               "algorithmic_bytes_per_launch": round(pr["bytes"] / pr["launches"]),
                                "launches": pr["launches"], "avg_launch_ms": round(pr["ms"] / pr["launches"], 4)}
+            if pmc:  # HBM bytes per launch of the kernel that carries the export (PMC child passes of bench.live_pmc)
+                dom = max((k for k in pmc if pmc[k].get("traffic")), key=lambda k: pmc[k]["traffic"] * pmc[k]["launches"], default=None)
+                if dom is not None:
+                    res["roofline"]["traffic"] = round(pmc[dom]["traffic"])
+                    res["roofline"]["traffic_kernel"] = "%s, %d launches in the counted call" % (dom, pmc[dom]["launches"])
+                    res["roofline"]["traffic_all"] = {k: {"bytes_per_launch": round(v["traffic"]), "launches": v["launches"]}
+                                                      for k, v in pmc.items() if v.get("traffic")}
         eng.profile_enable("none")
         if stages:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -155,6 +192,10 @@ def main():
     if int(world_env or "1") != args.gpus:
         raise SystemExit("bench_export.py: --gpus %d does not match WORLD_SIZE=%s of the launcher" % (args.gpus, world_env))
 
+    pmc = None
+    if args.gpus == 1 and args.traffic == "auto" and not args.pmc_child:  # child processes: this one has not touched the GPU yet
+        pmc = export_pmc(args.arch, args.views, args.height, args.width)
+
     import torch
     import torch.distributed as dist
 
@@ -171,7 +212,8 @@ def main():
 
     arch = "SuperPointNet_gauss2" if args.arch == "sp" else "SuperPointNet_gauss2_ssmall"
     n, H, W = args.views, args.height, args.width
-    res = measure_export(dev, arch, n, H, W, args.thresh, args.steps, args.warmup, rank, world, dist, stages=args.stages)
+    res = measure_export(dev, arch, n, H, W, args.thresh, args.steps, args.warmup, rank, world, dist, stages=args.stages,
+                         images_per_step=2 if args.pmc_child else args.images_per_step, pmc=pmc)
 
     if rank == 0:
         ips = res["images_per_s"]
@@ -180,15 +222,16 @@ def main():
                "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(res["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s homography-adaptation export, %d views of %dx%d per image, 2 images per step, "
-                                      "threshold %.4f, nms 4, top-k 600, soft-argmax" % (arch, n, H, W, args.thresh),
+               "config": {"workload": "%s homography-adaptation export, %d views of %dx%d per image, %d images per step "
+                                      "(%d ssp_export_points calls of 2 images), threshold %.4f, nms 4, top-k 600, soft-argmax"
+                                      % (arch, n, H, W, res["images_per_step"], res["images_per_step"] // 2, args.thresh),
                           "parallelism": "images sharded over %d rank(s), no collective" % world},
                "views_per_s": round(ips * n, 1), "forward_tflops": round(ips * gf / 1e3, 2),
                "points_last_step": res["points_last_step"]}
         for k in ("roofline", "stage_ms"):
             if k in res:
                 out[k] = res[k]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.pmc_child:
             out["cpu_baseline"] = cpu_baseline(arch, H, W, n, args.thresh)
         print(json.dumps(out), flush=True)
     if world > 1:
