@@ -107,6 +107,12 @@ enum {
 const char* ssp_last_error(void);
 /* sha256 of the library's source files (csrc/*.hip, csrc/*.hip.h, include/ssp_hip.h) at build time: hipbuild.source_id() */
 const char* ssp_build_id(void);
+/* Bit-reproducible accumulation (process-wide; also SSP_DETERMINISTIC=1 in the environment): floating-point atomics of the path
+ * become order-independent - fp64 accumulators take addends rounded to a fixed quantum (exact sums), fp32 scatter targets go
+ * through 64-bit fixed-point shadows (csrc/det.hip.h).  Switch it BEFORE ssp_bind: the shadows are allocated there.  The
+ * reference has no counterpart (torch.use_deterministic_algorithms is never set: train4.py). */
+int ssp_set_deterministic(int on);
+int ssp_get_deterministic(void);
 int ssp_create(const ssp_config* cfg, ssp_handle** out);
 void ssp_destroy(ssp_handle* h);
 size_t ssp_param_count(const ssp_handle* h);       /* net parameters (without eta) */

@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         double* st = stats + (size_t)(blockIdx.x % NREP) * 128;
-        unsafeAtomicAdd(st + tid * 4 + c, (double)acc[c]);
-        unsafeAtomicAdd(st + 64 + tid * 4 + c, (double)acc[4 + c]);
+        acc_add_stats(st + tid * 4 + c, (double)acc[c]);
+        acc_add_stats(st + 64 + tid * 4 + c, (double)acc[4 + c]);
       }
     }
   }
@@ -472,8 +472,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const B
         if (!cv[i]) continue;
         if (!APPLY) {
           double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 2 * a.C;
-          unsafeAtomicAdd(sm + c0 + i, (double)acc[i]);
-          unsafeAtomicAdd(sm + a.C + c0 + i, (double)acc[4 + i]);
+          acc_add_grad(sm + c0 + i, (double)acc[i]);
+          acc_add_grad(sm + a.C + c0 + i, (double)acc[4 + i]);
         }
       }
     }
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs
     double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 2 * a.C;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      unsafeAtomicAdd(sm + c0 + i, (double)acc[i]);
-      unsafeAtomicAdd(sm + a.C + c0 + i, (double)acc[4 + i]);
+      acc_add_grad(sm + c0 + i, (double)acc[i]);
+      acc_add_grad(sm + a.C + c0 + i, (double)acc[4 + i]);
     }
   }
 }
@@ -624,8 +624,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l0_kernel(const BnBwdArgs a
     double* sm = a.sums + (size_t)(blockIdx.x % NREP) * 128;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      unsafeAtomicAdd(sm + c0 + i, (double)acc[i]);
-      unsafeAtomicAdd(sm + 64 + c0 + i, (double)acc[4 + i]);
+      acc_add_grad(sm + c0 + i, (double)acc[i]);
+      acc_add_grad(sm + 64 + c0 + i, (double)acc[4 + i]);
     }
   }
 }
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += red[(r * 16 + qq) * 10 + t];
-        atomicAdd(dw + (qq * 4 + i) * 9 + t, sum);
+        facc_add(dw + (qq * 4 + i) * 9 + t, sum);
       }
     }
   }

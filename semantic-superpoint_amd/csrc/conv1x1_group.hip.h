@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * G1_WAVES) void conv1x1_group_kernel(const G1Ar
       float tsum = 0.f;
 #pragma unroll
       for (int ww = 0; ww < G1_WAVES; ++ww) tsum += sRed[((ww * G1_NT + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
-      unsafeAtomicAdd(p.stats + (size_t)(blockIdx.x % NREP) * 2 * p.stats_c + which * p.stats_c + ch, (double)tsum);
+      acc_add_stats_or_grad(p.stats + (size_t)(blockIdx.x % NREP) * 2 * p.stats_c + which * p.stats_c + ch, (double)tsum, BNR);
     }
   }
 }

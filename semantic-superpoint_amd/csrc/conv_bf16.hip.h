@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
       for (int k = item; k < 256; k += TPP) t += (double)s_red[k * 17 + which * 8 + e];
       const int co = cob * CB_NB + ch;
       if (co < a.Cout && p_stats != nullptr)
-        unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, t);
+        acc_add_stats(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, t);
     }
   };
 

@@ -377,8 +377,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
       for (int e = 0; e < 8; ++e) {
         const int co = cob * CB_NB + item * 8 + e;
         if (co < a.Cout) {
-          unsafeAtomicAdd(st + co, (double)v[e]);
-          unsafeAtomicAdd(st + a.Cout + co, (double)v[8 + e]);
+          acc_add_stats(st + co, (double)v[e]);
+          acc_add_stats(st + a.Cout + co, (double)v[8 + e]);
         }
       }
     }

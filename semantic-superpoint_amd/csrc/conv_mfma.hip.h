@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int w = 0; w < 4; ++w) t += red[((w * 2 + (ch >> 5)) * 32 + (ch & 31)) * 2 + which];
       const int co = cob * NB + ch;
       if (co < a.Cout)
-        unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
+        acc_add_stats(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
     }
   }
 }

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_kernel(const ConvArgs 
       for (int gq = 0; gq < WINO_THREADS / 16; ++gq) t += red[(gq * 16 + (ch >> 2)) * 8 + which * 4 + (ch & 3)];
       const int co = cob * NB + ch;
       if (co < a.Cout)
-        unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
+        acc_add_stats(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)t);
     }
   }
 }

@@ -708,8 +708,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     const int co = cob * NB + nt * 32 + li;
     if (lh == 0 && co < a.Cout) {
       double* q = p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + co;
-      unsafeAtomicAdd(q, (double)t1);
-      unsafeAtomicAdd(q + a.Cout, (double)t2);
+      // forward: statistics of the output; data gradient with a fused BatchNorm-backward reduction (bnr_mode != 0): S1, S2
+      if (IN_MODE == 0 && a.bnr_mode != 0) { acc_add_grad(q, (double)t1); acc_add_grad(q + a.Cout, (double)t2); }
+      else { acc_add_stats(q, (double)t1); acc_add_stats(q + a.Cout, (double)t2); }
     }
   }
 }

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
     const int which = li >> 4, r = li & 15;
     const int co = cob * NB + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     if (co < a.Cout)
-      unsafeAtomicAdd(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)stat_acc);
+      acc_add_stats_or_grad(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, (double)stat_acc, IN_MODE == 0 && a.bnr_mode != 0);
   }
 }
 

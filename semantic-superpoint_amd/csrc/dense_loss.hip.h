@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256) void dense_dots_kernel(const DenseArgs a) {
   if (tid == 0) {
     // 1024 replicas of each sum (the StepAccum arrays of the sparse loss): same-address atomics stay rare
     const int rep = (blockIdx.x + 19 * blockIdx.y + 7 * blockIdx.z) & 1023;
-    unsafeAtomicAdd(&a.acc->pos_sum[rep], (double)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])));
-    unsafeAtomicAdd(&a.acc->neg_sum[rep], (double)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])));
-    unsafeAtomicAdd(&a.acc->dense_sum[rep], (double)((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])));
+    acc_add_loss(&a.acc->pos_sum[rep], (double)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])));
+    acc_add_loss(&a.acc->neg_sum[rep], (double)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])));
+    acc_add_loss(&a.acc->dense_sum[rep], (double)((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])));
   }
 }
 

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "det.hip.h"
+
 namespace sspk {
 
 // Wave-wide reductions on the DPP data path (cross-lane moves inside the VALU, ~8 cycles each) instead of six
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void detector_loss_kernel(const float* __restr
     }
   }
   const float tot = block_sum_of_waves(lsum_acc, red);
-  if (threadIdx.x == 0) unsafeAtomicAdd(&acc->det_sum[view], (double)tot);
+  if (threadIdx.x == 0) acc_add_loss(&acc->det_sum[view], (double)tot);
 }
 
 // ---- sparse descriptor loss --------------------------------------------------------------------
@@ -193,10 +195,10 @@ __device__ __forceinline__ float4 f4_fma(float w, float4 a, float4 acc) {
   return make_float4(fmaf(w, a.x, acc.x), fmaf(w, a.y, acc.y), fmaf(w, a.z, acc.z), fmaf(w, a.w, acc.w));
 }
 __device__ __forceinline__ void atomic_add4(float* p, float4 v) {
-  atomicAdd(p, v.x);
-  atomicAdd(p + 1, v.y);
-  atomicAdd(p + 2, v.z);
-  atomicAdd(p + 3, v.w);
+  facc_add(p, v.x);
+  facc_add(p + 1, v.y);
+  facc_add(p + 2, v.z);
+  facc_add(p + 3, v.w);
 }
 
 
@@ -242,18 +244,18 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
   const float dot = wave_sum(va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2] + va[3] * vb[3]);
   const float hinge = fmaxf(1.f - dot, 0.f);
   if (!BWD) {
-    if (lane == 0) unsafeAtomicAdd(&acc->pos_sum[img * 16 + ((w >> 2) & 15)], (double)hinge);  // 16 replicas / image
+    if (lane == 0) acc_add_loss(&acc->pos_sum[img * 16 + ((w >> 2) & 15)], (double)hinge);  // 16 replicas / image
   } else if (hinge > 0.f) {
     const float c = -acc->coef_pos / ((float)n_match * (float)B);  // d total / d dot
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (wa[k] != 0.f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(dd_a + base + (size_t)ia[k] * 256 + 64 * j, wa[k] * c * vb[j]);
+        for (int j = 0; j < 4; ++j) facc_add(dd_a + base + (size_t)ia[k] * 256 + 64 * j, wa[k] * c * vb[j]);
       }
       if (wb[k] != 0.f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(dd_b + base + (size_t)ib[k] * 256 + 64 * j, wb[k] * c * va[j]);
+        for (int j = 0; j < 4; ++j) facc_add(dd_b + base + (size_t)ib[k] * 256 + 64 * j, wb[k] * c * va[j]);
       }
     }
   }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __r
   const float c = wave_sum((float)cnt);
   if (lane == 0) {
     const int rep = img * 16 + ((w >> 2) & 15);  // 16 replicas / image: ~60 instead of 1000 atomics per address
-    unsafeAtomicAdd(&acc->neg_sum[rep], (double)hsum);
+    acc_add_loss(&acc->neg_sum[rep], (double)hsum);
     atomicAdd(&acc->nnz[rep], (unsigned)(c + 0.5f));
   }
 }
@@ -347,13 +349,13 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
       for (int i = 0; i < 4; ++i) {
         const float bv = desc_b[ibase + (size_t)bi * 256 + 64 * i];
         ga[i] = fmaf(wgt, bv, ga[i]);
-        atomicAdd(dd_b + ibase + (size_t)bi * 256 + 64 * i, wgt * a[i]);
+        facc_add(dd_b + ibase + (size_t)bi * 256 + 64 * i, wgt * a[i]);
       }
     }
   }
   if (have_a) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(dd_a + ibase + (size_t)ma * 256 + 64 * i, ga[i]);
+    for (int i = 0; i < 4; ++i) facc_add(dd_a + ibase + (size_t)ma * 256 + 64 * i, ga[i]);
   }
 }
 

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "det.hip.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace sspk {

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float v = ((dacc[k][j][0] + dacc[k][j][1]) + hist[k * SEM_MAX_C + lane + 64 * j]) * LN2;
-            if (v != 0.f) atomicAdd(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + lane + 64 * j, v);
+            if (v != 0.f) facc_add(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + lane + 64 * j, v);
           }
         }
       __builtin_amdgcn_wave_barrier();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
   }
   if (FWD) {
     const float tot = block_sum_of_waves(wave_sum(nll_acc), red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(&acc->sem_sum[view], (double)tot);
+    if (threadIdx.x == 0) acc_add_loss(&acc->sem_sum[view], (double)tot);
   }
 }
 
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m
                           (a.w + b.w) + (c.w + d.w)};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (q * 4 + e < C) atomicAdd(out + q * 4 + e, t[e]);
+        if (q * 4 + e < C) facc_add(out + q * 4 + e, t[e]);
     }
 }
 

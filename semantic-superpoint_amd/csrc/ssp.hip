@@ -1158,6 +1158,57 @@ static int ensure_aux_stream(ssp_handle* h);
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// ---- bit-reproducible accumulation (csrc/det.hip.h): process-wide switch, fp32 scatter targets with fixed-point shadows ----
+struct DetHostRegion { float* lo; size_t n; long long* shadow; const ssp_handle* owner; };
+static std::vector<DetHostRegion> g_det_regions;
+static int g_det_mode = -1;   // -1: not read yet (SSP_DETERMINISTIC), 0 / 1
+static bool det_mode() {
+  if (g_det_mode < 0) { const char* e = getenv("SSP_DETERMINISTIC"); g_det_mode = (e != nullptr && atoi(e) != 0) ? 1 : 0; }
+  return g_det_mode == 1;
+}
+static int det_upload() {
+  DetRegion tab[DET_MAX_REGIONS];
+  int n = 0;
+  for (const DetHostRegion& r : g_det_regions) {
+    if (n == DET_MAX_REGIONS) return fail(-3, "deterministic mode: more than %d fp32 scatter targets are bound in this process", DET_MAX_REGIONS);
+    tab[n].lo = r.lo; tab[n].hi = r.lo + r.n; tab[n].shadow = r.shadow; ++n;
+  }
+  for (int i = n; i < DET_MAX_REGIONS; ++i) { tab[i].lo = tab[i].hi = nullptr; tab[i].shadow = nullptr; }
+  const int flag = det_mode() ? 1 : 0;
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_det_region), tab, sizeof(tab)));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_det_nregion), &n, sizeof(n)));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_det), &flag, sizeof(flag)));
+  return 0;
+}
+static void det_release(const ssp_handle* h) {
+  bool any = false;
+  for (size_t i = 0; i < g_det_regions.size();) {
+    if (g_det_regions[i].owner == h) { (void)hipFree(g_det_regions[i].shadow); g_det_regions.erase(g_det_regions.begin() + i); any = true; }
+    else ++i;
+  }
+  if (any) (void)det_upload();
+}
+static int det_register(const ssp_handle* h, float* lo, size_t n) {
+  if (lo == nullptr || n == 0) return 0;
+  DetHostRegion r;
+  r.lo = lo; r.n = n; r.owner = h; r.shadow = nullptr;
+  HIPCHK(hipMalloc(&r.shadow, n * sizeof(long long)));
+  HIPCHK(hipMemset(r.shadow, 0, n * sizeof(long long)));
+  g_det_regions.push_back(r);
+  return 0;
+}
+// shadow of the region that starts at `base` -> the tensor (dst += shadow 2^-40; shadow = 0); a no-op outside deterministic mode
+static int det_fold(float* base, hipStream_t st) {
+  if (!det_mode() || base == nullptr) return 0;
+  for (const DetHostRegion& r : g_det_regions)
+    if (r.lo == base) {
+      hipLaunchKernelGGL(det_fold_kernel, dim3((unsigned)std::min<long>(cdiv((long)r.n, 256), 2048)), dim3(256), 0, st, r.shadow, r.lo, (long)r.n);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
+  return 0;
+}
+
 extern "C" {
 
 const char* ssp_last_error(void) { return g_err.c_str(); }
@@ -1171,6 +1222,12 @@ const char* ssp_build_id(void) {
   static const char marker[] = "SSP_BUILD_ID=" SSP_BUILD_ID;
   return marker + 13;
 }
+
+int ssp_set_deterministic(int on) {
+  g_det_mode = on ? 1 : 0;
+  return det_upload();   // (handles bound before the switch keep their plain fp32 scatters until they are bound again)
+}
+int ssp_get_deterministic(void) { return det_mode() ? 1 : 0; }
 
 int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   if (!cfg || !out) return fail(-1, "null argument");
@@ -1198,6 +1255,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
 
 void ssp_destroy(ssp_handle* h) {
   if (!h) return;
+  det_release(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1224,6 +1282,16 @@ int ssp_bind(ssp_handle* h, const ssp_buffers* b, void* stream) {
   CHK(ensure_aux_stream(h));  // (never created lazily inside a stream capture)
   // padding channels (65->80, n_classes->sout_cs) must read as zero forever: clear everything once
   HIPCHK(hipMemsetAsync(b->workspace_dev, 0, h->ws_bytes, (hipStream_t)stream));
+  det_release(h);
+  if (det_mode()) {   // fixed-point shadows of the tensors that fp32 atomics scatter into
+    const size_t cells = (size_t)h->cfg.max_batch * (h->cfg.height / 8) * (h->cfg.width / 8);
+    CHK(det_register(h, b->grads_dev, b->grads_dev ? h->n_params + 3 : 0));
+    for (int v = 0; v < 2; ++v) {
+      CHK(det_register(h, h->slot[v].ddesc, cells * 256));
+      CHK(det_register(h, h->slot[v].dsout, h->slot[v].dsout ? cells * h->sout_cs : 0));
+    }
+    CHK(det_upload());
+  }
   h->bound = true;
   return 0;
 }
@@ -1971,8 +2039,15 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
 // reduced, so every gradient from layer EARLY_SPLIT_LAYER's conv weight to the end of the flat vector is FINAL (the
 // early all-reduce bucket, ssp_grad_early_offset); 2 = the remaining layers EARLY_SPLIT_LAYER-1..0 (their dOut sits in gP).
 enum { EARLY_SPLIT_LAYER = 2 };
+static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
+                             float* const* dsout, hipStream_t st, int part);
 static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
                         float* const* dsout, hipStream_t st, int part = 0) {
+  CHK(run_backward_impl(h, SS, dsemi, draw_desc, dsout, st, part));
+  return det_fold(h->buf.grads_dev, st);   // (deterministic mode) bias / first-layer gradients scattered by fp32 atomics
+}
+static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
+                             float* const* dsout, hipStream_t st, int part) {
   Slot& S0 = *SS.s[0];
   if (!h->packed_bwd || h->packed_algo != g_conv_algo)
     return fail(-3, "backward: the packed weight images do not belong to this pass (%s) - run the forward of the step again",
@@ -2310,6 +2385,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
                          h->cfg.n_non);
       for (int v = 0; v < 2; ++v) {
         Slot& S = h->slot[v];
+        CHK(det_fold(S.ddesc, sd));   // (deterministic mode) the scattered gradient: fixed-point shadow -> tensor
         hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, sd, S.desc, S.inv_norm, S.ddesc, ncells);
       }
     }
@@ -2334,6 +2410,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
         CHK(dev_zero(S.dsout, (size_t)ncells * h->sout_cs * sizeof(float), st));
         hipLaunchKernelGGL((sem_ce_kernel<3>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
                            h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
+        CHK(det_fold(S.dsout, st));
       } else {
         hipLaunchKernelGGL((sem_ce_kernel<1>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], (float*)nullptr,
                            h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);

@@ -71,7 +71,8 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_op_sample_homographies", "ssp_op_warp_labels_full", "ssp_op_sem_finalize", "ssp_adam_step_scaled",
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
-           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16", "ssp_op_bn_bwd_bf16", "ssp_build_id"]
+           "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16", "ssp_op_bn_bwd_bf16", "ssp_build_id",
+           "ssp_set_deterministic", "ssp_get_deterministic"]
 
 
 def load_library(path=None):
@@ -99,6 +100,8 @@ def load_library(path=None):
     lib.ssp_last_error.restype = C.c_char_p
     try:
         lib.ssp_build_id.restype = C.c_char_p
+        lib.ssp_set_deterministic.argtypes = [C.c_int]
+        lib.ssp_get_deterministic.restype = C.c_int
     except AttributeError:
         if os.environ.get("SSP_HIP_LIB") is None:
             raise
@@ -180,6 +183,18 @@ def load_library(path=None):
     lib.ssp_op_dense_loss.argtypes = [vp, vp, vp, vp, i, i, i, f, f, i, f, vp, C.c_size_t, vp, vp, vp, vp]
     _lib = lib
     return lib
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible accumulation for Engines created AFTER the call (also SSP_DETERMINISTIC=1): the fp64 accumulators take
+    addends rounded to a fixed quantum, the fp32 scatter targets (descriptor / segmentation gradients, bias and first-layer weight
+    gradients) go through 64-bit fixed-point shadows.  Two runs from the same state then agree bit for bit; the default mode keeps
+    the plain floating-point atomics (run-to-run differences ~1e-6)."""
+    _check(load_library().ssp_set_deterministic(1 if on else 0))
+
+
+def get_deterministic():
+    return bool(load_library().ssp_get_deterministic())
 
 
 def build_id():
