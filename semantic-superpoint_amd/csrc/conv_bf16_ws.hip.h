@@ -197,7 +197,9 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
   constexpr int NHS = (HT * HT * 4 + 255) / 256;   // 6 (the last round is partly empty)
   const int hs_lds0 = (ptid >> 2) * CB_PS + part * 16;
   unsigned hs_g[NHS];
-  int hs_rel[NHS], hs_yx[NHS];
+  int hs_rel[NHS];
+  int hs_yx0 = 0;   // halo (row, column) of this thread's first slot; slot i is 64 = 3 x 18 + 10 further (kept as ONE register: six
+                    // spilled the staging loop into scratch)
 #pragma unroll
   for (int i = 0; i < NHS; ++i) {
     // staged form: thread -> (slot ptid / 4 + 64 i, item ptid % 4).  DMA form: 16-byte unit q = ptid + 256 i of the dense image ->
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     const int sl = (ptid >> 2) + 64 * i;
     const int cpart = DMA ? (part ^ ((sl >> 2) & 3)) : part;
     const int hy = sl / HT, hx = sl - hy * HT;
-    hs_yx[i] = ((sl < HT * HT ? hy - PAD : -30000) << 16) | ((hx - PAD) & 0xffff);
+    if (i == 0) hs_yx0 = (hy << 16) | hx;
     hs_rel[i] = (((hy - PAD) * a.W + (hx - PAD)) * a.in_cs + a.in_co + cpart * 8) * 2;
   }
   __amdgpu_buffer_rsrc_t rsrc_in;
@@ -239,12 +241,16 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     ld_border = !(ty0 >= PAD && tx0 >= PAD && ty0 + CB_T + PAD <= a.H && tx0 + CB_T + PAD <= a.W);
     if (!ld_border) {
 #pragma unroll
-      for (int i = 0; i < NHS; ++i) hs_g[i] = (hs_yx[i] >> 16) > -30000 ? (unsigned)(org + hs_rel[i]) : OOB;
+      for (int i = 0; i < NHS; ++i) hs_g[i] = (ptid >> 2) + 64 * i < HT * HT ? (unsigned)(org + hs_rel[i]) : OOB;
     } else {
 #pragma unroll
       for (int i = 0; i < NHS; ++i) {
-        const int gy = ty0 + (hs_yx[i] >> 16), gx = tx0 + (short)(hs_yx[i] & 0xffff);
-        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        int yx = hs_yx0;
+        asm volatile("" : "+v"(yx));   // (opaque: hipcc would hoist the six coordinate pairs out of the tile loop and keep them alive)
+        int hy = (yx >> 16) + 3 * i, hx = (yx & 0xffff) + 10 * i;   // + 64 slots per round
+        hy += hx / HT; hx %= HT;                                              // (constants: hx < 18 + 50)
+        const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+        const bool ok = (ptid >> 2) + 64 * i < HT * HT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         hs_g[i] = ok ? (unsigned)(org + hs_rel[i]) : OOB;
       }
     }
@@ -308,29 +314,31 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
       load_affine(0, aff_view, 0);
       load_affine(1, aff_view, 1);
     }
-    const bool border = (hv_view[S] & 256) != 0;   // (uniform) padding is zero in the ACTIVATED domain
+    auto run = [&](auto BORDER) __attribute__((always_inline)) {   // (one straight-line body per variant: a uniform test inside the
+#pragma unroll                                                      //  slot loop became a branch per slot)
+      for (int i = 0; i < NHS; ++i) {
+        if ((ptid >> 2) + 64 * i >= HT * HT) continue;
+        u32x4 o;
+        if (IN_MODE == 1 && !(a.ablate & 128)) {
 #pragma unroll
-    for (int i = 0; i < NHS; ++i) {
-      if ((ptid >> 2) + 64 * i >= HT * HT) continue;
-      u32x4 o;
-      if (IN_MODE == 1 && !(a.ablate & 128)) {
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 z = ws_pk_fma(f32x2{bf16_lo(hv[S][i][e]), bf16_hi(hv[S][i][e])}, sc2[S][e], sh2[S][e]);
+            const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(z[0], z[1])), s16x2{0, 0});
+            o[e] = __builtin_bit_cast(uint32_t, r);
+          }
+          if (decltype(BORDER)::value) {   // padding is zero in the ACTIVATED domain
+            const bool pad = (hv_pad[S] >> i) & 1u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f32x2 z = ws_pk_fma(f32x2{bf16_lo(hv[S][i][e]), bf16_hi(hv[S][i][e])}, sc2[S][e], sh2[S][e]);
-          const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(z[0], z[1])), s16x2{0, 0});
-          o[e] = __builtin_bit_cast(uint32_t, r);
+            for (int e = 0; e < 4; ++e) o[e] = pad ? 0u : o[e];
+          }
+        } else {
+          o = hv[S][i];
         }
-        if (border) {
-          const bool pad = (hv_pad[S] >> i) & 1u;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pad ? 0u : o[e];
-        }
-      } else {
-        o = hv[S][i];
+        if (!(a.ablate & 256)) *reinterpret_cast<u32x4*>(dst + i * 64 * CB_PS) = o;
+        else asm volatile("" :: "v"(o));
       }
-      if (!(a.ablate & 256)) *reinterpret_cast<u32x4*>(dst + i * 64 * CB_PS) = o;
-      else asm volatile("" :: "v"(o));
-    }
+    };
+    if ((hv_view[S] & 256) != 0) run(std::true_type{}); else run(std::false_type{});   // (uniform) border tile of the image?
   };
   // weights: the 36 KB image of (cob, chunk) lives in slot chunk & 1 (never the slot the consumers read: nchunks is even).  A layer
   // of 64 input channels loads its two images once; wider layers swap a slot every stage, so the image of stage s + 2 is fetched
