@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -80,7 +81,33 @@ static void run(const char* name, int grid) {
   printf("%-38s grid %4d: %.3f ms, %.1f TF/s, %.1f wave-clock cycles per MFMA per wave\n", name, grid, ms, mfma * 32768.0 / ms / 1e9, (double)c / (iters * 72.0));
 }
 
-int main() {
+// sustained form: `mfma_lds_loop <variant 0|1|2> <seconds>` keeps launching one variant (grid 256) so that rocm-smi can sample the
+// socket power / shader clock of "MFMAs alone" against "MFMAs + their LDS operand reads" (tools/dbg/power_ubench.sh)
+template <int VAR>
+static void sustain(double seconds) {
+  float* out; unsigned long long* cyc;
+  hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&cyc, 8);
+  auto k = loop_kernel<VAR>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 62784);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double total_ms = 0; long launches = 0;
+  while (total_ms < seconds * 1e3) {
+    hipEventRecord(e0);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(256), 62784, 0, out, 2000, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    total_ms += ms; launches += 50;
+  }
+  const double mfma = 256.0 * 4 * 2000 * 72 * launches;
+  printf("variant %d sustained %.1f s: %.1f TF/s\n", VAR, total_ms / 1e3, mfma * 32768.0 / total_ms / 1e9);
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 3) {
+    const int v = atoi(argv[1]); const double sec = atof(argv[2]);
+    if (v == 0) sustain<0>(sec); else if (v == 1) sustain<1>(sec); else sustain<2>(sec);
+    return 0;
+  }
   run<0>("MFMAs only (register operands)", 256);
   run<0>("MFMAs only (register operands)", 512);
   run<1>("+ 4 linear ds_read_b128 per step", 256);
