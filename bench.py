@@ -136,6 +136,9 @@ def roofline_block(prof_kernels, pmc, pmc_note, conv_algo, n_prof_steps, steps):
         rl["note"] = ("achieved = ALGORITHMIC bytes of the launches (bf16 input + output of each 3x3 convolution, once) / their time, "
                       "against the 8 TB/s HBM3E spec; traffic = HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE); "
                       "mfma_* = direct-convolution FLOPs / time against the dense bf16 MFMA peak")
+        rl["limiter"] = ("neither roof: the launches run at the socket's 1400 W power cap (shader clock 1.6-2.1 GHz of 2.4 during them; "
+                         "profiles/r04_bf16_conv_sustained_ablation_power.txt, r04_bf16_instep_phase_trace.txt) and a SIMD issues matrix OR "
+                         "vector instructions (profiles/r04_ubench_mfma_valu_share.txt): DESIGN.md section 8")
         rl["mfma_tflops"], rl["mfma_frac"], rl["traffic_gbs"] = d["mfma_tflops"], d["mfma_frac"], d["traffic_gbs"]
     return rl
 

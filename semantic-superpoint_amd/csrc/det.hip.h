@@ -18,7 +18,7 @@ namespace sspk {
 
 __device__ int g_det;   // 0 = plain atomics (default)
 
-constexpr int DET_MAX_REGIONS = 8;
+constexpr int DET_MAX_REGIONS = 16;   // (five per bound handle with gradients)
 struct DetRegion {
   const float* lo;
   const float* hi;
