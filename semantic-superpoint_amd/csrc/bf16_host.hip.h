@@ -175,8 +175,27 @@ static int launch_wgrad_bf16_t(const WgradBArgs& a, int nblocks, hipStream_t st)
   return 0;
 }
 
-// partial slabs [pairs * nsplit][taps][64][64] in `partial`, summed into c.dw by wgrad_reduce_kernel
-static int launch_wgrad_bf16(const WgradBCall& c, float* partial, size_t partial_floats, int n_cu, hipStream_t st) {
+// Deferred slab reductions of a backward pass (the engine's launches): every weight gradient keeps its own slice of the partial
+// buffer until flush() sums them all in ONE launch (wgrad_reduce_multi_kernel).  Two jobs never write the same gradient.
+struct WredBQueue {
+  WredBJobs J;
+  size_t used;   // floats of the partial buffer taken by the queued jobs
+  WredBQueue() : used(0) { J.n = 0; }
+  int flush(hipStream_t st) {
+    if (J.n == 0) { used = 0; return 0; }
+    const WredBJob& last = J.j[J.n - 1];
+    const int nblocks = last.block0 + cdiv(last.cout * last.cin * last.ks * last.ks, 64);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, J);
+    HIPCHK(hipGetLastError());
+    J.n = 0; used = 0;
+    return 0;
+  }
+};
+
+// partial slabs [pairs * nsplit][taps][64][64] in `partial`, summed into c.dw by wgrad_reduce_kernel (at once, or - with a queue -
+// by the queue's flush)
+static int launch_wgrad_bf16(const WgradBCall& c, float* partial, size_t partial_floats, int n_cu, hipStream_t st,
+                             WredBQueue* queue = nullptr) {
   WgradBArgs a;
   for (int k = 0; k < 2; ++k) { a.x[k] = c.x[k]; a.dy[k] = c.dy[k]; a.x_scale[k] = c.x_scale[k]; a.x_shift[k] = c.x_shift[k]; }
   a.partial = partial; a.nviews = c.nviews; a.N = c.N; a.H = c.H; a.W = c.W;
@@ -191,16 +210,29 @@ static int launch_wgrad_bf16(const WgradBCall& c, float* partial, size_t partial
   if (c.in_mode == 1 && (!c.x_scale[0] || !c.x_shift[0])) return fail(-1, "bf16 wgrad: in_mode 1 needs scale / shift");
   const int pairs = a.ncib * a.ncob, taps = c.ks * c.ks;
   const long ntiles = (long)c.nviews * c.N * a.tiles_x * a.tiles_y;
-  long nsplit = std::max(1L, std::min<long>(ntiles, (2L * n_cu) / pairs));
+  static const int wg_per_cu = getenv("SSP_WGB_PER_CU") ? std::max(1, atoi(getenv("SSP_WGB_PER_CU"))) : 2;  // (perf-debug: slabs per CU)
+  long nsplit = std::max(1L, std::min<long>(ntiles, ((long)wg_per_cu * n_cu) / pairs));
   while (nsplit > 1 && (size_t)pairs * nsplit * taps * 4096 > partial_floats) --nsplit;
   if ((size_t)pairs * nsplit * taps * 4096 > partial_floats) return fail(-4, "bf16 wgrad: scratch too small");
   a.nsplit = (int)nsplit;
+  if (queue != nullptr) {   // own slice of the buffer; the reduction waits for the flush
+    const size_t need = (size_t)pairs * nsplit * taps * 4096;
+    if (queue->used + need > partial_floats || queue->J.n == WREDB_MAX_JOBS) CHK(queue->flush(st));
+    a.partial = partial + queue->used;
+    WredBJob& q = queue->J.j[queue->J.n];
+    q.partial = a.partial; q.dw = c.dw; q.cin = c.cin; q.cout = c.cout; q.ks = c.ks; q.ncob = a.ncob; q.nsplit = (int)nsplit;
+    q.block0 = queue->J.n ? queue->J.j[queue->J.n - 1].block0 + cdiv(queue->J.j[queue->J.n - 1].cout * queue->J.j[queue->J.n - 1].cin *
+                                                                     queue->J.j[queue->J.n - 1].ks * queue->J.j[queue->J.n - 1].ks, 64) : 0;
+    ++queue->J.n;
+    queue->used += need;
+  }
   const int nblocks = pairs * (int)nsplit;
 #define WGB_CASE(KS_, M_, F_) \
   if (c.ks == KS_ && c.in_mode == M_ && c.dy_f32 == F_) { CHK((launch_wgrad_bf16_t<KS_, M_, F_>(a, nblocks, st))); } else
   WGB_CASE(3, 1, false) WGB_CASE(3, 0, false) WGB_CASE(1, 1, true)
   return fail(-3, "bf16 wgrad: unsupported variant ks=%d in_mode=%d dy_f32=%d", c.ks, c.in_mode, (int)c.dy_f32);
 #undef WGB_CASE
+  if (queue != nullptr) return 0;
   const int total = c.cout * c.cin * taps;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, c.dw, c.cin, c.cout, c.ks, a.ncob, a.nsplit);
   HIPCHK(hipGetLastError());

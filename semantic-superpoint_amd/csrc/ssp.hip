@@ -165,6 +165,7 @@ struct ssp_handle {
   float* partial;    // wgrad partial slabs: every Winograd wgrad launch of a backward pass gets its own slice ...
   size_t partial_floats;
   size_t partial_used = 0;  // ... and the slices are reduced into the gradients by ONE launch (flush_wgrad_reduce)
+  struct WredBQueue* rq_bf16 = nullptr;  // the same for the bf16 path's weight gradients (bf16_host.hip.h)
   WredJobs rjobs{};
   bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
   bool apply_fused[16] = {};  // pass 2 (APPLY) of layer l was left to the layer's weight gradient (wgrad_wino_fused_kernel)
@@ -969,7 +970,9 @@ static bool wgrad_can_fuse_apply(int ks, int in_mode, int H, int W, int cout) {
 }
 
 // sums the pending partial slabs of the deferred Winograd weight-gradient launches into the OIHW gradients
+static int flush_wgrad_reduce_bf16(ssp_handle* h, hipStream_t st);
 static int flush_wgrad_reduce(ssp_handle* h, hipStream_t st) {
+  if (h != nullptr) CHK(flush_wgrad_reduce_bf16(h, st));
   if (h == nullptr || h->rjobs.n == 0) { if (h) h->partial_used = 0; return 0; }
   const WredJob& last = h->rjobs.j[h->rjobs.n - 1];
   const int nblocks = last.block0 + last.ncob * last.cin;
@@ -1153,6 +1156,8 @@ static int l0_resident_grid(K kern, const ssp_handle* h, int nviews, long rows, 
 
 #include "bf16_host.hip.h"
 
+static int flush_wgrad_reduce_bf16(ssp_handle* h, hipStream_t st) { return h->rq_bf16 != nullptr ? h->rq_bf16->flush(st) : 0; }
+
 static int ensure_aux_stream(ssp_handle* h);
 
 // ------------------------------------------------------------------------------------------------
@@ -1243,6 +1248,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
   if (h->cfg.n_match <= 0) h->cfg.n_match = 1000;
   if (h->cfg.n_non <= 0) h->cfg.n_non = 100;
   h->conv_algo = g_default_conv_algo;
+  h->rq_bf16 = new WredBQueue();
   AlgoScope algo(h);
   build_layers(h);
   h->bound = false;
@@ -1256,6 +1262,7 @@ int ssp_create(const ssp_config* cfg, ssp_handle** out) {
 void ssp_destroy(ssp_handle* h) {
   if (!h) return;
   det_release(h);
+  delete h->rq_bf16;
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1930,7 +1937,7 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       }
       const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
       ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_WGRAD_BF16);
-      CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
+      CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st, h->rq_bf16));
     }
     {
       ConvBCall c;
@@ -1972,7 +1979,7 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
       w.x[k] = S.Y[src]; w.dy[k] = dy[k]; w.x_scale[k] = S.bn[src].scale; w.x_shift[k] = S.bn[src].shift;
       c.in[k] = dy[k]; c.out[k] = S.gP;
     }
-    CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
+    CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st, h->rq_bf16));
     return launch_conv_bf16(c, h->n_cu, st);
   };
   if (has_semi) {
@@ -2020,7 +2027,7 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     }
     const double flops = 2.0 * SS.n * ncells * 128.0 * 256 * 9;
     ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * ncells * (128.0 + 256.0), flops, SSP_PROF_K_WGRAD_BF16);
-    CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st));
+    CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st, h->rq_bf16));
   }
   ConvBCall c;
   c.nviews = SS.n; c.N = N; c.H = Hc; c.W = Wc; c.ks = 3; c.in_mode = 0;
@@ -2049,6 +2056,7 @@ static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* ds
 static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
                              float* const* dsout, hipStream_t st, int part) {
   Slot& S0 = *SS.s[0];
+  if (h->rq_bf16 != nullptr) { h->rq_bf16->J.n = 0; h->rq_bf16->used = 0; }   // (a failed pass must not leave slab reductions queued)
   if (!h->packed_bwd || h->packed_algo != g_conv_algo)
     return fail(-3, "backward: the packed weight images do not belong to this pass (%s) - run the forward of the step again",
                 !h->packed_bwd ? "the last forward packed no data-gradient weights" : "the conv algorithm changed since the forward");
@@ -2061,7 +2069,10 @@ static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* cons
   float *gP[2] = {nullptr, nullptr}, *gQ[2] = {nullptr, nullptr};
   for (int k = 0; k < SS.n; ++k) { gP[k] = SS.s[k]->gP; gQ[k] = SS.s[k]->gQ; }
   auto encoder = [&](int l_hi, int l_lo) -> int {  // dOut (gP) -> dY (gQ) -> weight gradient + data gradient (gP)
-    if (bf16_path()) return encoder_backward_bf16(h, SS, l_hi, l_lo, st);
+    if (bf16_path()) {
+      CHK(encoder_backward_bf16(h, SS, l_hi, l_lo, st));
+      return flush_wgrad_reduce(h, st);   // the queued slab reductions of this part (heads included): one launch
+    }
     for (int l = l_hi; l >= l_lo; --l) {
       int lh, lw; layer_res(l, H, W, lh, lw);
       const bool pool_after = (l == 1 || l == 3 || l == 5);
