@@ -22,12 +22,14 @@ run2() {  # $1 = tag, $2 = extra args, $3 = port, $4 = profile rank 0 (0/1)
 run2 overlap "" 29611 0
 run2 no_overlap "--no-overlap" 29612 0
 run2 overlap_traced "" 29613 1
+run2 overlap_bf16 "--dtype bf16" 29614 0
 python3 - <<PY
 import json
-for t in ("overlap", "no_overlap", "overlap_traced"):
+for t in ("overlap", "no_overlap", "overlap_traced", "overlap_bf16"):
     try:
         d = json.loads(open("$O/%s.json" % t).read().strip().splitlines()[-1])
         print(t, d["value"], "pairs/s", d["ms_per_step"], "ms/step", d["config"]["allreduce"])
+        print("   dp:", json.dumps(d.get("dp"))[:1200])
     except Exception as e:
         print(t, "ERR", e)
 PY
