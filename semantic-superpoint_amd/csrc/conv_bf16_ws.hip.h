@@ -360,6 +360,20 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(sW + par * G::W_BYTES + (ptid + 256 * i) * 16) = wv[i];
   };
 
+  // wide layers (more than 64 input channels: a new image every stage) of the staged form: the image of stage s + 1 goes global ->
+  // LDS (9 buffer_load ... lds per wave, no registers, no ds_write) at the start of iteration s, lands under the staging arithmetic
+  // and is waited for BEFORE the next halo loads are issued (so the wait never touches the prefetch)
+  typedef __attribute__((address_space(3))) void* w_ldsp;
+  auto dma_weights = [&](int tag, int par) __attribute__((always_inline)) {
+    if (tag < 0 || (par ? w_tag1 : w_tag0) == tag) return false;
+    if (par) w_tag1 = tag; else w_tag0 = tag;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (w_ldsp)(sW + par * G::W_BYTES + (256 * i + 64 * pwave) * 16), 16, ptid * 16,
+                                               tag * G::W_BYTES + 4096 * i, 0, 0);
+    return true;
+  };
+
   // statistics of the stored values: per-thread sums of this thread's 8 channels (item = ptid & 7), flushed per (view, cob)
   const int item = ptid & 7;
   f32x2 ps[4], pq[4];
@@ -530,14 +544,19 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
   } else {
   // ---- prologue: stage 0 (and its weights) synchronously; the loads of stages 1 and 2 in flight ----
   setup_unit();
-  int w_next = -1;                      // weight tag of the stage whose halo was issued last (its image is fetched an iteration later)
-  int w_pend = -1;                      // (NC2) the same tag an iteration later
+  int w_next = -1;                      // weight tag of the stage whose halo was issued last
+  int w_pend = -1;                      // ... and of the stage before it (= stage s + 1 at the start of iteration s)
   issue(P0{});
   fetch_weights(ld_cob * a.nchunks, 0);
   commit_weights(0);
   stage_halo(P0{});
   bool ld_ok = advance();               // -> stage 1
-  if (ld_ok) { issue(P1{}); fetch_weights(ld_cob * a.nchunks + ld_chunk, 1); ld_ok = advance(); }
+  if (ld_ok) {
+    issue(P1{});
+    if (NC2) fetch_weights(ld_cob * a.nchunks + ld_chunk, 1);   // (committed by iteration 0)
+    else w_pend = ld_cob * a.nchunks + ld_chunk;
+    ld_ok = advance();
+  }
   if (ld_ok) { issue(P0{}); w_next = ld_cob * a.nchunks + ld_chunk; ld_ok = advance(); } else w_next = -1;   // stage 2; ld_ -> stage 3
   __syncthreads();
   // iteration s (the consumers compute stage s): copy-out of the unit that finished with stage s - 1, weights + halo of stage
@@ -550,12 +569,17 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     if (tr) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; }
     if (s + 1 < nstages) {
       if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t0 = __builtin_readcyclecounter(); tc[4] += t0 - t1; t1 = t0; }
-      if (NC2) { fetch_weights(w_pend, Q); w_pend = -1; }   // (registers of the image live here only)
-      commit_weights(Q);
+      bool dma = false;
+      if (NC2) {   // a 64-channel layer changes its images with the output block only: through registers, in place
+        fetch_weights(w_pend, Q);
+        commit_weights(Q);
+      } else {
+        dma = dma_weights(w_pend, Q);
+      }
       stage_halo(PAR);
+      if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the image has landed (nothing else is in flight here)
       if (tr) { t0 = __builtin_readcyclecounter(); tc[1] += t0 - t1; }
-      if (NC2) w_pend = w_next;          // a 64-channel layer changes its images with the output block only: fetched in place
-      else fetch_weights(w_next, Q ^ 1); // image of stage s + 2: in flight until the next iteration writes it to LDS
+      w_pend = w_next;
       w_next = -1;
       if (ld_ok) {                       // ld_ = stage s + 3
         issue(PAR);
