@@ -556,4 +556,37 @@ __global__ void pack_weights_bf16_multi_kernel(const PackBJobs J) {
   q.dst[((size_t)cob * q.nchunks_total + chunk + q.chunk_off) * per_chunk + (idx % per_chunk)] = (uint16_t)(pk & 0xffffu);
 }
 
+// a = bf16(relu(bn(y))) of a dense bf16 NHWC tensor, materialised ONCE for an input that many convolution units read: the three 3x3
+// heads take the 30x40 output of encoder layer 7 through 12 (view, 64-channel block) units per tile, each of which would load,
+// activate and write the same halo.  Same arithmetic as the on-load transform (one fp32 fma, round to nearest even, ReLU on the
+// rounded value), so the heads see identical operands; their launches then run the staging-free form (IN_MODE 0).
+__global__ __launch_bounds__(256) void bn_relu_bf16_kernel(const uint16_t* __restrict__ y0, const uint16_t* __restrict__ y1,
+                                                           const float* __restrict__ sc0, const float* __restrict__ sh0,
+                                                           const float* __restrict__ sc1, const float* __restrict__ sh1,
+                                                           uint16_t* __restrict__ o0, uint16_t* __restrict__ o1, long nitems, int C) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const uint16_t* const y = blockIdx.y ? y1 : y0;
+  const float* const sc = blockIdx.y ? sc1 : sc0;
+  const float* const sh = blockIdx.y ? sh1 : sh0;
+  uint16_t* const o = blockIdx.y ? o1 : o0;
+  const int ipp = C >> 3;   // 16-byte items per pixel
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nitems; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % ipp) * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(y + i * 8);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + c0), s1 = *reinterpret_cast<const f32x4*>(sc + c0 + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + c0), h1 = *reinterpret_cast<const f32x4*>(sh + c0 + 4);
+    const float scv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    const float shv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float zl = __builtin_fmaf(bf16_lo(v[e]), scv[2 * e], shv[2 * e]);
+      const float zh = __builtin_fmaf(bf16_hi(v[e]), scv[2 * e + 1], shv[2 * e + 1]);
+      const s16x2 m = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(zl, zh)), s16x2{0, 0});
+      r[e] = __builtin_bit_cast(uint32_t, m);
+    }
+    *reinterpret_cast<u32x4*>(o + i * 8) = r;
+  }
+}
+
 }  // namespace sspk

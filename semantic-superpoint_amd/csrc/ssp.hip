@@ -144,6 +144,10 @@ struct Slot {
   float* Apool[8];  // pooled output of layers l = 1, 3, 5 (inputs of layers 2, 4, 6), else nullptr: the RAW pooled conv output
                     // written by layer l's conv (pool_raw[l], BatchNorm + ReLU applied on load) or maxpool(relu(bn(Y_l)))
   bool pool_raw[8] = {false, false, false, false, false, false, false, false};  // set by this slot's last forward
+  // bf16 path: act[l] = bf16(relu(bn(.))) of layer l's (pooled) output at 30x40, l = 5, 6, 7 - the materialised input of the layers
+  // whose units would each activate the same halo (layers 6, 7: two 64-channel blocks; the three 3x3 heads: twelve)
+  float* act[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool act_valid[8] = {false, false, false, false, false, false, false, false};  // written by this slot's last forward
   const float* x;   // input image of the last forward (caller-owned)
   void* stats_region;
   size_t stats_bytes;
@@ -351,6 +355,7 @@ static size_t carve(ssp_handle* h, void* base) {
       S.dsout = nullptr;
     }
     S.desc = c.take_skewed<float>(cells * 256);
+    for (int l = 5; l <= 7; ++l) S.act[l] = c.take_skewed<float>(cells * 64);   // (bf16 [cells][128])
     S.inv_norm = c.take<float>(cells);
     S.cellmask = c.take<float>(cells);
     S.dsemi = c.take<float>(cells * 80);
@@ -1557,10 +1562,29 @@ static int conv_layer_fwd_bf16(ssp_handle* h, const SlotSet& SS, int l, int src,
   c.out_cs = SS.s[0]->y_cs[l]; c.out_co = SS.s[0]->y_co[l]; c.cout = d.cout;
   c.out_f32 = d.ks == 1;
   const bool pool_out = l < 8 && SS.s[0]->Apool[l] != nullptr && d.bn;
+  // 3x3 layers on the 30x40 maps (layers 6, 7 and the three heads): the input is activated once into act[src]
+  // (bn_relu_bf16_kernel: 20 MB, 9 us) and read without staging arithmetic by every unit and by the weight gradient
+  static const int act_env = getenv("SSP_ACT7") ? atoi(getenv("SSP_ACT7")) : 1;   // (perf-debug A/B: 0 off, 1 heads only, 2 also layers 6, 7)
+  const bool from_act = d.ks == 3 && d.cin == 128 && src >= 5 && src <= 7 && (src == 7 ? act_env != 0 : act_env >= 2) &&
+                        SS.s[0]->act[src] != nullptr && (pooled ? SS.s[0]->pool_raw[src] : (SS.s[0]->y_cs[src] == 128 && SS.s[0]->y_co[src] == 0));
+  if (from_act && !SS.s[0]->act_valid[src]) {
+    Slot &S0 = *SS.s[0], &S1 = *SS.s[SS.n - 1];
+    const long nitems = (long)N * H * W * 16;
+    const float* y0 = pooled ? S0.Apool[src] : S0.Y[src];
+    const float* y1 = pooled ? S1.Apool[src] : S1.Y[src];
+    hipLaunchKernelGGL(bn_relu_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(nitems, 256), 4096), SS.n), dim3(256), 0, st,
+                       reinterpret_cast<const uint16_t*>(y0), reinterpret_cast<const uint16_t*>(y1), S0.bn[src].scale, S0.bn[src].shift,
+                       S1.bn[src].scale, S1.bn[src].shift, reinterpret_cast<uint16_t*>(S0.act[src]), reinterpret_cast<uint16_t*>(S1.act[src]),
+                       nitems, 128);
+    HIPCHK(hipGetLastError());
+    for (int k = 0; k < SS.n; ++k) SS.s[k]->act_valid[src] = true;
+  }
+  const bool from_act7 = from_act;
+  if (from_act) c.in_mode = 0;
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     if (pooled && !S.pool_raw[src]) return fail(-3, "bf16 path: layer %d has no raw pooled output", src);
-    c.in[k] = pooled ? S.Apool[src] : S.Y[src];
+    c.in[k] = from_act7 ? S.act[src] : pooled ? S.Apool[src] : S.Y[src];
     c.out[k] = S.Y[l];
     c.in_scale[k] = S.bn[src].scale; c.in_shift[k] = S.bn[src].shift;
     c.stats[k] = (d.bn && train) ? S.bn[l].stats : nullptr;
@@ -1631,6 +1655,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     S.N = N; S.H = H; S.W = W; S.x = xs[k];
+    for (int l = 0; l < 8; ++l) S.act_valid[l] = false;   // (rewritten by this forward where a layer uses it)
     CHK(dev_zero(S.stats_region, S.stats_bytes, st));
     S.bsums_dirty = false;
   }
@@ -1935,6 +1960,10 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
         if (pooled_in && !S.pool_raw[src]) return fail(-3, "bf16 path: layer %d has no raw pooled output", src);
         w.x[k] = pooled_in ? S.Apool[src] : S.Y[src]; w.dy[k] = S.gQ; w.x_scale[k] = S.bn[src].scale; w.x_shift[k] = S.bn[src].shift;
       }
+      if (src >= 5 && S0.act_valid[src] && SS.s[SS.n - 1]->act_valid[src]) {   // the forward materialised this layer's activated input
+        w.in_mode = 0;
+        for (int k = 0; k < SS.n; ++k) w.x[k] = SS.s[k]->act[src];
+      }
       const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
       ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_WGRAD_BF16);
       CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st, h->rq_bf16));
@@ -2021,9 +2050,11 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     WgradBCall w;
     w.nviews = SS.n; w.N = N; w.H = Hc; w.W = Wc; w.ks = 3; w.in_mode = 1;
     w.x_cs = 128; w.x_co = 0; w.cin = 128; w.dy_cs = hcs; w.dy_co = 256 * hk; w.cout = 256; w.dw = Gd(h, d.w_off);
+    const bool from_act7 = S0.act_valid[7] && SS.s[SS.n - 1]->act_valid[7];   // the forward materialised the activated input
+    if (from_act7) w.in_mode = 0;
     for (int k = 0; k < SS.n; ++k) {
       Slot& S = *SS.s[k];
-      w.x[k] = S.Y[7]; w.dy[k] = S.gQ; w.x_scale[k] = S.bn[7].scale; w.x_shift[k] = S.bn[7].shift;
+      w.x[k] = from_act7 ? S.act[7] : S.Y[7]; w.dy[k] = S.gQ; w.x_scale[k] = S.bn[7].scale; w.x_shift[k] = S.bn[7].shift;
     }
     const double flops = 2.0 * SS.n * ncells * 128.0 * 256 * 9;
     ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * ncells * (128.0 + 256.0), flops, SSP_PROF_K_WGRAD_BF16);
