@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
                                                          const int32_t* __restrict__ match_b, float* __restrict__ dd_a,
                                                          float* __restrict__ dd_b, StepAccum* __restrict__ acc, int B,
                                                          int Hc, int Wc, int n_match) {
+  const DetTarget t_a = det_resolve(dd_a), t_b = det_resolve(dd_b);   // (deterministic mode: fixed-point shadows)
   int img;
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
@@ -251,11 +252,11 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
     for (int k = 0; k < 4; ++k) {
       if (wa[k] != 0.f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) facc_add(dd_a + base + (size_t)ia[k] * 256 + 64 * j, wa[k] * c * vb[j]);
+        for (int j = 0; j < 4; ++j) facc_add(t_a, dd_a + base + (size_t)ia[k] * 256 + 64 * j, wa[k] * c * vb[j]);
       }
       if (wb[k] != 0.f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) facc_add(dd_b + base + (size_t)ib[k] * 256 + 64 * j, wb[k] * c * va[j]);
+        for (int j = 0; j < 4; ++j) facc_add(t_b, dd_b + base + (size_t)ib[k] * 256 + 64 * j, wb[k] * c * va[j]);
       }
     }
   }
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
                                                                 const float* __restrict__ dots, float* __restrict__ dd_a,
                                                                 float* __restrict__ dd_b, const StepAccum* __restrict__ acc,
                                                                 int B, int Hc, int Wc, int n_match, int n_non) {
+  const DetTarget t_a = det_resolve(dd_a), t_b = det_resolve(dd_b);   // (deterministic mode: fixed-point shadows)
   int img;
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
@@ -349,13 +351,13 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
       for (int i = 0; i < 4; ++i) {
         const float bv = desc_b[ibase + (size_t)bi * 256 + 64 * i];
         ga[i] = fmaf(wgt, bv, ga[i]);
-        facc_add(dd_b + ibase + (size_t)bi * 256 + 64 * i, wgt * a[i]);
+        facc_add(t_b, dd_b + ibase + (size_t)bi * 256 + 64 * i, wgt * a[i]);
       }
     }
   }
   if (have_a) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) facc_add(dd_a + ibase + (size_t)ma * 256 + 64 * i, ga[i]);
+    for (int i = 0; i < 4; ++i) facc_add(t_a, dd_a + ibase + (size_t)ma * 256 + 64 * i, ga[i]);
   }
 }
 

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
   constexpr bool FWD = (MODE & 1) != 0, BWD = (MODE & 2) != 0;
   float nll_acc = 0.f;  // per lane (= per pixel slot of the tiles this wave visits)
   const float g = BWD ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
+  const DetTarget t_ds = det_resolve(dsout);   // (deterministic mode: fixed-point shadow of d(convSout))
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   if (BWD) {
 #pragma unroll
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float v = ((dacc[k][j][0] + dacc[k][j][1]) + hist[k * SEM_MAX_C + lane + 64 * j]) * LN2;
-            if (v != 0.f) facc_add(dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + lane + 64 * j, v);
+            if (v != 0.f) facc_add(t_ds, dsout + ((size_t)n * Hc * Wc + cidx[k]) * cs + lane + 64 * j, v);
           }
         }
       __builtin_amdgcn_wave_barrier();
