@@ -152,19 +152,24 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
       if (tr) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; }
       if (chunk + 1 == a.nchunks) {
         // finished unit: bias, rounding, hand the tile to the producers through LDS (they copied the previous one out a stage ago)
+        auto hand_over = [&](auto BIAS) __attribute__((always_inline)) {   // (the data gradient has no bias: 64 additions per tile less)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int lp = (4 * wave + 2 * nt + pr) * 16 + pc;
+          for (int nt = 0; nt < 2; ++nt) {
+            const int lp = (4 * wave + 2 * nt + pr) * 16 + pc;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              u32x2 o;
-              o[0] = pack_bf16(acc[mt][nt][4 * q] + bias4[mt][q][0], acc[mt][nt][4 * q + 1] + bias4[mt][q][1]);
-              o[1] = pack_bf16(acc[mt][nt][4 * q + 2] + bias4[mt][q][2], acc[mt][nt][4 * q + 3] + bias4[mt][q][3]);
-              *reinterpret_cast<u32x2*>(sO + lp * 128 + (((mt * 4 + q) ^ (lp & 7)) << 4) + lg * 8) = o;
-            }
-        }
+              for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                if (decltype(BIAS)::value) v += bias4[mt][q];
+                u32x2 o;
+                o[0] = pack_bf16(v[0], v[1]);
+                o[1] = pack_bf16(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(sO + lp * 128 + (((mt * 4 + q) ^ (lp & 7)) << 4) + lg * 8) = o;
+              }
+          }
+        };
+        if (a.bias != nullptr) hand_over(std::true_type{}); else hand_over(std::false_type{});
         chunk = 0; u += nslot;
       } else {
         ++chunk;
