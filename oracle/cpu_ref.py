@@ -428,10 +428,15 @@ def multi_task_loss(eta, det, pos, neg, sem=None):
 # --------------------------------------------------------------------------------------
 def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lambda_loss=1.0, lamda_d=1.0,
                 multi_task=True, gaussian=True, n_match=1000, n_non=100, np_rng=np.random, torch_gen=None,
-                train=True, dense=None, forced=None, operand_dtype=None):
+                train=True, dense=None, forced=None, operand_dtype=None, warped_pair=True):
     """Forward of both views + all losses.  Returns (loss, scalars dict, aux dict).
-    dense: None (sparse descriptor loss) or the dict of model.dense_loss.params (Train_model_heatmap_all.py:131-137)."""
+    dense: None (sparse descriptor loss) or the dict of model.dense_loss.params (Train_model_heatmap_all.py:131-137).
+    warped_pair=False: the single-view branch (`data.warped_pair.enable: false`, :207; the shipped
+    configs/magicpoint_shapes_pair.yaml:50-51): ONE forward, detector (+ semantic) loss of the image only; the warped
+    terms are the constants 0 of :330-332 and lambda_loss must be 0 (:343 asserts "need a pair of images")."""
     semantic = arch.endswith("ssmall")
+    if not warped_pair:
+        return _single_view_losses(sd, eta, sample, arch, lambda_loss, multi_task, gaussian, train, forced, operand_dtype)
     out = forward(sd, sample["image"], arch, train=train, forced=None if forced is None else forced[0], operand_dtype=operand_dtype)
     out_w = forward(sd, sample["warped_img"], arch, train=train,  # separate BN statistics (:258,262)
                     forced=None if forced is None else forced[1], operand_dtype=operand_dtype)
@@ -469,6 +474,26 @@ def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lamb
     if semantic:
         scal["eta_sem"] = eta[2]
     return loss, scal, {"out": out, "out_warp": out_w, "indices": used}
+
+
+def _single_view_losses(sd, eta, sample, arch, lambda_loss, multi_task, gaussian, train, forced, operand_dtype):
+    """Train_model_heatmap_all.py:237-262,296-332,346-365 with if_warp == False."""
+    semantic = arch.endswith("ssmall")
+    assert not lambda_loss > 0, "need a pair of images"  # :343
+    out = forward(sd, sample["image"], arch, train=train, forced=None if forced is None else forced[0], operand_dtype=operand_dtype)
+    lab = sample["labels_2D_gaussian"] if gaussian else sample["labels_2D"]
+    loss_det = detector_loss(out["semi"], labels2Dto3D(lab).float(), get_masks(sample["valid_mask"]))
+    zero = torch.zeros(())
+    loss_sem = sem_loss(out["sem"], sample["semantic"]) if semantic else zero
+    if multi_task:  # pos = neg = 0: the descriptor weight eta[1] still receives its constant 1/2 gradient
+        loss = multi_task_loss(eta, loss_det + zero, zero, zero, (loss_sem + zero) if semantic else None)
+    else:
+        loss = loss_det + zero + loss_sem + zero
+    scal = {"loss": loss, "loss_det": loss_det, "loss_det_warp": zero, "loss_desc": zero, "loss_sem": loss_sem,
+            "loss_sem_warp": zero, "eta_det": eta[0], "eta_desc": eta[1], "positive_dist": zero, "negative_dist": zero}
+    if semantic:
+        scal["eta_sem"] = eta[2]
+    return loss, scal, {"out": out, "out_warp": None, "indices": None}
 
 
 class AdamState:

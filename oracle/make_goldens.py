@@ -20,7 +20,7 @@ ARCHS = ("SuperPointNet_gauss2", "SuperPointNet_gauss2_ssmall")
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # a copy: fixtures are written at the end of a generator, the tensors live on
 
 
 def close(a, b, tol, what):
@@ -240,7 +240,7 @@ def g6_train_step():
     """G6: full train_val_sample (2 forwards + losses + backward + Adam) on the reference vs oracle."""
     cases = [("sp_64x96", "SuperPointNet_gauss2", 64, 96, dict()),
              ("ssp_64x96", "SuperPointNet_gauss2_ssmall", 64, 96, dict()),
-             ("magicpoint_32x48", "SuperPointNet_gauss2", 32, 48, dict(lambda_loss=0, warp_only_det=True)),
+             ("pair_lambda0_32x48", "SuperPointNet_gauss2", 32, 48, dict(lambda_loss=0)),  # PAIR step, descriptor loss off
              ("sp_dense_64x96", "SuperPointNet_gauss2", 64, 96, dict(dense=True)),
              ("sp_dense_uniform_64x96", "SuperPointNet_gauss2", 64, 96, dict(dense=True, multi_task=False))]
     only = os.environ.get("SSP_G6_ONLY")
@@ -587,12 +587,118 @@ def g12_full_size_step():
         print("G12", tag, "ok;", os.path.getsize(os.path.join(OUT, "g12_step_%s_240x320.npz" % tag)), "bytes")
 
 
+def magicpoint_config(multi_task, batch=2):
+    """configs/magicpoint_shapes_pair.yaml as SHIPPED (read from the reference at generation time) plus the keys it lacks and
+    the trainer reads (SURVEY.md section 5 'Shipped-config defects'): model.real_batch_size (:108), data.semantic (:221),
+    model.multi_task_loss (:355), an importable front_end_model; batch 64 -> BASELINE configs[0]'s 2."""
+    import yaml
+    with open(os.path.join(R.REF_ROOT, "configs", "magicpoint_shapes_pair.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    assert cfg["data"]["warped_pair"]["enable"] is False and cfg["model"]["lambda_loss"] == 0
+    assert cfg["data"]["preprocessing"]["resize"] == [120, 160] and cfg["data"]["gaussian_label"]["enable"] is False
+    cfg["front_end_model"] = "Train_model_heatmap_all"
+    cfg["model"].update({"batch_size": batch, "real_batch_size": batch, "eval_batch_size": batch, "multi_task_loss": bool(multi_task)})
+    cfg["data"]["semantic"] = False
+    cfg["pretrained"] = None
+    return cfg
+
+
+def g13_single_view_step():
+    """G13: BASELINE configs[0] - the SINGLE-VIEW step (`data.warped_pair.enable: false`, Train_model_heatmap_all.py:207,
+    237-262, 330-332, 346-353) of the shipped configs/magicpoint_shapes_pair.yaml at 120x160, B = 2, on the real reference:
+    scalars of two optimizer steps, gradient norms + slices, post-Adam eta / parameter slices, one validation call
+    (train=False: no_grad forward in train-mode BatchNorm + the logging branch's precision / recall).  Both values of the
+    key the yaml lacks (model.multi_task_loss).  Also records that `detector_loss.loss_type: l2` RAISES in the reference for
+    these models (65 logits against the 64-channel target of add_dustbin=False, :170-172,302-304)."""
+    arch, H, W = "SuperPointNet_gauss2", 120, 160
+    for tag, mt in (("uniform", False), ("kendall", True)):
+        cfg = magicpoint_config(mt)
+        sd = C.init_state_dict(arch, seed=37)
+        full = C.make_synthetic_pair(2, H, W, seed=43, kp_prob=0.004)
+        sample = {k: full[k] for k in ("image", "labels_2D", "valid_mask")}
+        sample["valid_mask"] = sample["valid_mask"].clone()
+        sample["valid_mask"][0, :, 16:40, 24:56] = 0  # some invalid cells (augmentation border), exercises mask.sum()
+        kw = dict(lambda_loss=0.0, multi_task=mt, gaussian=False, warped_pair=False)
+        agent = R.make_trainer(cfg, sd)
+        tr = C.Trainer(arch, sd, lr=0.001, **kw)
+        save = {"in/image_u8": np.round(npy(sample["image"]) * 255).astype(np.uint8),
+                "in/labels_2D": np.packbits(npy(sample["labels_2D"]).astype(np.uint8)),
+                "in/valid_mask": np.packbits(npy(sample["valid_mask"]).astype(np.uint8))}
+        sample["image"] = torch.from_numpy(save["in/image_u8"].astype(np.float32) / 255.0)  # what the test decodes
+        for it in range(2):
+            agent.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=it + 1, train=True)
+            sc_ref = {k: float(v) for k, v in agent.scalar_dict.items()}
+            tr.train_val_sample(sample, n_iter=it + 1, train=True)
+            for k in sc_ref:
+                close(sc_ref[k], tr.scalar_dict[k], 2e-5 * max(1.0, abs(sc_ref[k])), "G13 %s scalar %s it%d" % (tag, k, it))
+                save["step%d/%s" % (it, k)] = np.float32(sc_ref[k])
+        noisy = {conv + ".bias" for conv, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+        named = dict(agent.net.named_parameters())
+        for k, p in named.items():
+            if k not in noisy and not k.startswith(("convD", "bnD")):  # the descriptor head is not in the graph: untouched
+                close_adam(p, tr.sd[k], 0.001, "G13 %s post-step %s" % (tag, k))
+        for k in ("convDa.weight", "bnDb.weight"):
+            assert torch.equal(named[k].detach(), torch.as_tensor(np.array(sd[k]))), "descriptor head moved"
+        close(agent.multi_task_loss.eta, tr.eta, 1e-5, "G13 eta")
+        save["post/eta"] = npy(agent.multi_task_loss.eta)
+        for k in ("inc.conv.conv.3.weight", "down3.mpconv.1.conv.4.weight", "convPb.weight", "bnPb.bias"):
+            save["post_slice/" + k] = npy(named[k].reshape(-1)[:64])
+        rsd = agent.net.state_dict()
+        for k in rsd:
+            if "running_var" in k:
+                save["post_state/" + k] = npy(rsd[k])
+        # validation call (Train_model_frontend_all.py:340-349): forward under no_grad, BatchNorm still in train mode
+        agent.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=7, train=False)
+        tr.train_val_sample(sample, n_iter=7, train=False)
+        for k in ("loss", "loss_det", "loss_det_warp"):
+            close(float(agent.scalar_dict[k]), tr.scalar_dict[k], 2e-5 * max(1.0, abs(float(agent.scalar_dict[k]))), "G13 val " + k)
+        for k, v in agent.scalar_dict.items():
+            save["val/" + k] = np.float32(float(v))
+        # gradients of the first step, no optimizer step
+        agent2 = R.make_trainer(cfg, sd)
+        agent2.real_batch_size = 10 ** 9
+        agent2.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=1, train=True)
+        tr2 = C.Trainer(arch, sd, lr=0.001, **kw)
+        tr2.real_batch_size = 10 ** 9
+        tr2.train_val_sample(sample, n_iter=1, train=True)
+        for k, p in agent2.net.named_parameters():
+            g, go = p.grad, tr2.last_grads[k]
+            if g is None:
+                assert go is None and k.startswith(("convD", "bnD")), k
+                continue
+            scale = max(1e-6, float(g.abs().max()))
+            if k not in noisy:
+                close(g, go, 5e-4 * scale + 1e-6, "G13 %s grad %s" % (tag, k))
+            save["grad_norm/" + k] = np.float32(g.norm().item())
+            save["grad_slice/" + k] = npy(g.reshape(-1)[:64])
+        eg = agent2.multi_task_loss.eta.grad
+        if mt:
+            close(eg, tr2.last_grads["eta"], 1e-5, "G13 eta grad")
+            save["grad/eta"] = npy(eg)
+        else:
+            assert eg is None and tr2.last_grads["eta"] is None
+        # loss_type l2: the reference itself raises (MSELoss of [B,65,Hc,Wc] logits against the [B,64,Hc,Wc] target)
+        cfg_l2 = magicpoint_config(mt)
+        cfg_l2["model"]["detector_loss"]["loss_type"] = "l2"
+        a3 = R.make_trainer(cfg_l2, sd)
+        try:
+            a3.train_val_sample({k: v.clone() for k, v in sample.items()}, n_iter=1, train=True)
+            raised = ""
+        except RuntimeError as e:
+            raised = str(e)
+        assert "must match the size" in raised, raised
+        save["l2_raises"] = np.array(raised)
+        path = os.path.join(OUT, "g13_single_view_%s_120x160.npz" % tag)
+        np.savez_compressed(path, **save)
+        print("G13", tag, "ok;", os.path.getsize(path), "bytes; loss", float(save["step0/loss"]), "->", float(save["step1/loss"]))
+
+
 def main():
     assert R.available(), "reference not mounted"
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     only = os.environ.get("SSP_GOLDEN_ONLY")  # e.g. SSP_GOLDEN_ONLY=g12 regenerates one family
-    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss, g11_pair_labels, g12_full_size_step):
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss, g11_pair_labels, g12_full_size_step, g13_single_view_step):
         if only and not fn.__name__.startswith(only):
             continue
         fn()

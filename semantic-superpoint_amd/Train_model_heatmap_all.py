@@ -198,14 +198,23 @@ class Train_model_heatmap_all(object):
     def train_val_sample(self, sample, n_iter=0, train=False):
         task = "train" if train else "val"
         cfg, m = self.config, self.config["model"]
-        if not cfg["data"]["warped_pair"]["enable"]:
-            raise NotImplementedError("the accelerated step is the PAIR step (data.warped_pair.enable: true)")
+        if_warp = bool(cfg["data"]["warped_pair"]["enable"])  # :207; false = the single-view step (magicpoint_shapes_pair.yaml)
+        det_loss_type = m["detector_loss"]["loss_type"]
+        if det_loss_type == "l2":
+            # The reference builds a 64-channel target (add_dustbin=False, :296-304) and hands it to MSELoss with the models'
+            # 65 logits (:170-172): torch raises this RuntimeError on every model of the path (pinned: G13 `l2_raises`).
+            raise RuntimeError("The size of tensor a (65) must match the size of tensor b (64) at non-singleton dimension 1 "
+                               "(model.detector_loss.loss_type 'l2' is not usable with the 65-logit detector head)")
+        if det_loss_type != "softmax":  # :168-178: `loss` is never assigned
+            raise UnboundLocalError("local variable 'loss' referenced before assignment (detector_loss.loss_type %r)" % (det_loss_type,))
         img = sample["image"]
         B, _, H, W = img.shape
         self.batch_size = B
         eng = self._engine_for(B, H, W)
+        if not if_warp:  # the warped keys of a pair loader are never read (:226-251)
+            sample = {k: v for k, v in sample.items() if not k.startswith(("warped_", "homographies", "inv_homographies", "cell_homographies"))}
         dev = {k: (v.to(self.device, non_blocking=True).contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
-        if "cell_homographies" not in dev and not sample["homographies"].is_cuda:
+        if if_warp and "cell_homographies" not in dev and not sample["homographies"].is_cuda:
             # the loader's homographies are host tensors: scale them to cell coordinates with the reference's own op
             # sequence here, so that the device sampler's matches round exactly like descriptor_loss_sparse's
             dev["cell_homographies"] = L.scaled_homographies(sample["homographies"], H // 8, W // 8).to(self.device)
@@ -214,6 +223,7 @@ class Train_model_heatmap_all(object):
             if k in dev:
                 dev[k] = dev[k].float()
         lam = float(m["lambda_loss"])
+        assert if_warp or not lam > 0, "need a pair of images"  # :343
         idx = None
         dense = None
         if self.desc_loss_type == "dense":

@@ -396,7 +396,7 @@ __global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta,
 
 __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ eta, float* __restrict__ deta,
                                 float* __restrict__ scal, int B, int n_match, int multi_task, float lambda_loss,
-                                float lamda_d, int semantic, int train, int dense, int cells) {
+                                float lamda_d, int semantic, int train, int dense, int cells, int nviews) {
   // one wave (launched with 64 threads): lane i reduces the replicas of image i (sparse loss) or a slice of the 1024
   // replica slots (dense loss); thread 0 then combines in the order of the former single-thread loop
   if (blockIdx.x != 0) return;
@@ -423,7 +423,8 @@ __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ 
   __syncthreads();
   if (threadIdx.x != 0) return;
   const float det0 = (float)acc->det_sum[0] / ((float)acc->mask_cnt[0] + 1e-5f);
-  const float det1 = (float)acc->det_sum[1] / ((float)acc->mask_cnt[1] + 1e-5f);
+  // single-view step (nviews == 1): the warped terms are the constants 0 of Train_model_heatmap_all.py:330-332
+  const float det1 = nviews > 1 ? (float)acc->det_sum[1] / ((float)acc->mask_cnt[1] + 1e-5f) : 0.f;
   float pos = 0.f, neg = 0.f, ldesc = 0.f;
   if (lambda_loss > 0.f && dense) {  // utils/utils.py:884-890
     double ps = 0, ns = 0, ls = 0;
@@ -450,7 +451,7 @@ __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ 
   float sem0 = 0.f, sem1 = 0.f;
   if (semantic) {
     sem0 = (float)(acc->sem_sum[0] / acc->sem_cnt[0]);
-    sem1 = (float)(acc->sem_sum[1] / acc->sem_cnt[1]);
+    if (nviews > 1) sem1 = (float)(acc->sem_sum[1] / acc->sem_cnt[1]);
   }
   float loss;
   if (multi_task) {

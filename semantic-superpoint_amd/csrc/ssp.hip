@@ -2346,9 +2346,13 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   if (!in || !scalars_dev) return fail(-1, "null argument");
   if (phase < 0 || phase > 2) return fail(-1, "pair-step phase must be 0, 1 or 2");
   AlgoScope algo(h);
+  // Single-view step (`data.warped_pair.enable: false`, Train_model_heatmap_all.py:207,237-262,330-332 - the branch the shipped
+  // configs/magicpoint_shapes_pair.yaml takes): warped_image_dev == NULL.  One forward, detector (+ segmentation) loss of the
+  // image only, loss_det_warp = loss_sem_warp = 0; the descriptor loss needs a pair (:343 asserts).
+  const int nv = in && in->warped_image_dev ? 2 : 1;
   if (phase == 2) {
     if (!in->train) return 0;
-    SlotSet SS2{2, {&h->slot[0], &h->slot[1]}};
+    SlotSet SS2{nv, {&h->slot[0], nv == 2 ? &h->slot[1] : nullptr}};
     const float* none[2] = {nullptr, nullptr};
     float* nonef[2] = {nullptr, nullptr};
     return run_backward(h, SS2, none, none, nonef, (hipStream_t)stream, 2);
@@ -2358,8 +2362,11 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   if (B < 1 || B > h->cfg.max_batch || B > 64)
     return fail(-1, "pair-step batch %d out of range (1..min(max_batch, 64))", B);
   const bool semantic = h->nheads == 3;
-  if (semantic && (!in->semantic_dev || !in->warped_semantic_dev)) return fail(-1, "semantic labels required for the ssmall model");
+  if (semantic && (!in->semantic_dev || (nv == 2 && !in->warped_semantic_dev))) return fail(-1, "semantic labels required for the ssmall model");
   const bool use_desc = in->lambda_loss > 0.f;
+  if (use_desc && nv == 1) return fail(-1, "need a pair of images: lambda_loss > 0 with warped_image_dev == NULL");
+  if (!in->image_dev || !in->labels_dev || !in->valid_mask_dev || (nv == 2 && (!in->warped_labels_dev || !in->warped_valid_mask_dev)))
+    return fail(-1, "pair step: image / labels / valid mask pointers of every view are required");
   const bool dense = use_desc && in->dense_loss != 0;
   if (dense && !h->dense_coef) return fail(-1, "dense descriptor loss needs a handle created with ssp_config.dense_loss = 1");
   if (use_desc && !dense && (!in->match_a_dev || !in->match_b_dev || !in->nonmatch_b_dev))
@@ -2369,13 +2376,13 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   const int ncells = B * Hc * Wc;
   hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
                      in->lamda_d, (int)semantic);
-  SlotSet SS{2, {&h->slot[0], &h->slot[1]}};
+  SlotSet SS{nv, {&h->slot[0], nv == 2 ? &h->slot[1] : nullptr}};
   {
     const float* xs[2] = {in->image_dev, in->warped_image_dev};
     CHK(run_forward(h, SS, xs, B, H, W, 1, in->train != 0, st));
   }
   const float* masks[2] = {in->valid_mask_dev, in->warped_valid_mask_dev};
-  for (int v = 0; v < 2; ++v) {
+  for (int v = 0; v < nv; ++v) {
     Slot& S = h->slot[v];
     hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, st, masks[v], S.cellmask,
                        &h->accum->mask_cnt[v], B, H, W);
@@ -2435,7 +2442,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   }
   const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
   const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
-  for (int v = 0; v < 2; ++v) {
+  for (int v = 0; v < nv; ++v) {
     Slot& S = h->slot[v];
     hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
                        S.bn[L_PB].shift, labels[v], S.cellmask, in->train ? S.dsemi : nullptr, h->accum, v, B, H, W, 80);
@@ -2445,8 +2452,8 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     const long npx = (long)B * H * W;
     const long ntile = (long)B * (Hc + 1) * (Wc + 1);
     const int grid = (int)std::min<long>((ntile + 3) / 4, 4096);
-    hipLaunchKernelGGL(sem_count_kernel, dim3(512, 2), dim3(256), 0, st, sems[0], sems[1], npx, h->cfg.n_classes, h->accum);
-    for (int v = 0; v < 2; ++v) {
+    hipLaunchKernelGGL(sem_count_kernel, dim3(512, nv), dim3(256), 0, st, sems[0], sems[1], npx, h->cfg.n_classes, h->accum);
+    for (int v = 0; v < nv; ++v) {
       Slot& S = h->slot[v];
       if (in->train) {  // loss sum and d(convSout) in one pass (coef_sem: step_begin_kernel, sem_cnt: sem_count_kernel)
         CHK(dev_zero(S.dsout, (size_t)ncells * h->sout_cs * sizeof(float), st));
@@ -2463,12 +2470,12 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   CHK(loss_fork.join());  // the scalars and the backward pass need both loss families
   hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(64), 0, st, h->accum, eta,
                      in->train ? h->buf.grads_dev + h->n_params : (float*)nullptr, scalars_dev, B, h->cfg.n_match,
-                     in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train, (int)dense, Hc * Wc);
+                     in->multi_task, in->lambda_loss, in->lamda_d, (int)semantic, in->train, (int)dense, Hc * Wc, nv);
   HIPCHK(hipGetLastError());
   if (in->train) {
-    const float* dss[2] = {h->slot[0].dsemi, h->slot[1].dsemi};
+    const float* dss[2] = {h->slot[0].dsemi, nv == 2 ? h->slot[1].dsemi : nullptr};
     const float* dds[2] = {use_desc ? h->slot[0].ddesc : nullptr, use_desc ? h->slot[1].ddesc : nullptr};
-    float* dsos[2] = {semantic ? h->slot[0].dsout : nullptr, semantic ? h->slot[1].dsout : nullptr};
+    float* dsos[2] = {semantic ? h->slot[0].dsout : nullptr, semantic && nv == 2 ? h->slot[1].dsout : nullptr};
     CHK(run_backward(h, SS, dss, dds, dsos, st, phase));
   }
   return 0;

@@ -462,12 +462,23 @@ class Engine:
         phase: 0 whole step; 1 / 2 = the two halves of ssp_pair_step_phase (data-parallel overlap; call 2 with the
         same arguments).  graph=True replays the step as a hipGraph (ssp_pair_step_graph; needs a non-default
         current stream; the device sampler then fills persistent index buffers inside the graph).
+        A sample WITHOUT "warped_img" is the single-view step of `data.warped_pair.enable: false`
+        (Train_model_heatmap_all.py:207,237-262,330-332; configs/magicpoint_shapes_pair.yaml): one forward, detector
+        (+ segmentation) loss of the image only; lambda_loss must be 0 (the reference asserts "need a pair of images").
         Returns the device tensor of SSP_N_SCALARS floats (no host sync)."""
         img = sample["image"]
         B, c1, H, W = img.shape
+        single = sample.get("warped_img") is None
+        if single and lambda_loss > 0:
+            raise AssertionError("need a pair of images")  # Train_model_heatmap_all.py:343
         lab = sample["labels_2D_gaussian"] if gaussian else sample["labels_2D"]
-        labw = sample["warped_labels_gaussian"] if gaussian else sample["warped_labels"]
-        req = [img, sample["warped_img"], lab, labw, sample["valid_mask"], sample["warped_valid_mask"]]
+        if single:
+            imgw = labw = maskw = None
+            req = [img, lab, sample["valid_mask"]]
+        else:
+            imgw, maskw = sample["warped_img"], sample["warped_valid_mask"]
+            labw = sample["warped_labels_gaussian"] if gaussian else sample["warped_labels"]
+            req = [img, imgw, lab, labw, sample["valid_mask"], maskw]
         for t in req:
             _need_gpu(t, "sample tensor")
             if t.dtype != torch.float32 or tuple(t.shape) != (B, 1, H, W):
@@ -476,12 +487,14 @@ class Engine:
         if (H, W) != (self.height, self.width) or B > self.max_batch:
             raise ValueError("pair step [%d,1,%d,%d] does not match the engine (%d x %dx%d)"
                              % (B, H, W, self.max_batch, self.height, self.width))
-        Hm = sample["homographies"].to(torch.float32)
-        if not Hm.is_contiguous():
-            Hm = Hm.contiguous()
-        _need_gpu(Hm, "homographies")
-        if tuple(Hm.shape) != (B, 3, 3):
-            raise ValueError("homographies must be [B,3,3]")
+        Hm = None
+        if not single:
+            Hm = sample["homographies"].to(torch.float32)
+            if not Hm.is_contiguous():
+                Hm = Hm.contiguous()
+            _need_gpu(Hm, "homographies")
+            if tuple(Hm.shape) != (B, 3, 3):
+                raise ValueError("homographies must be [B,3,3]")
         if dense is not None and not self.dense_loss:
             raise RuntimeError("create the Engine with dense_loss=True to use the dense descriptor loss")
         sample_in_graph = False
@@ -507,8 +520,8 @@ class Engine:
             ma = mb = nm = None
         sem = semw = None
         if self.arch.endswith("ssmall"):
-            sem, semw = sample.get("semantic"), sample.get("warped_sem")
-            for t in (sem, semw):
+            sem, semw = sample.get("semantic"), (None if single else sample.get("warped_sem"))
+            for t in ((sem,) if single else (sem, semw)):
                 if t is None:
                     raise KeyError("the ssmall model needs sample['semantic'] and sample['warped_sem']")
                 _need_gpu(t, "semantic labels")
@@ -516,11 +529,11 @@ class Engine:
                     raise ValueError("semantic labels must be int64 [B,H,W] = %s, got %s %s"
                                      % ((B, H, W), t.dtype, tuple(t.shape)))
             if getattr(self, "check_label_range", False):  # one host sync: off by default (torch raises here too)
-                for t in (sem, semw):
+                for t in ((sem,) if single else (sem, semw)):
                     if int(t.min()) < 0 or int(t.max()) > self.n_classes:
                         raise ValueError("semantic label outside [0, %d]" % self.n_classes)
-        inp = SspPairInputs(B, _ptr(img), _ptr(sample["warped_img"]), _ptr(lab), _ptr(labw), _ptr(sample["valid_mask"]),
-                            _ptr(sample["warped_valid_mask"]), _ptr(Hm), _ptr(sem), _ptr(semw), _ptr(ma), _ptr(mb),
+        inp = SspPairInputs(B, _ptr(img), _ptr(imgw), _ptr(lab), _ptr(labw), _ptr(sample["valid_mask"]),
+                            _ptr(maskw), _ptr(Hm), _ptr(sem), _ptr(semw), _ptr(ma), _ptr(mb),
                             _ptr(nm), int(seed) & 0xFFFFFFFFFFFFFFFF, float(lambda_loss), float(lamda_d),
                             int(bool(multi_task)), int(bool(train)), int(dense is not None),
                             float((dense or {}).get("lamda_d", 250.0)), float((dense or {}).get("descriptor_dist", 4.0)),

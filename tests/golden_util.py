@@ -47,3 +47,11 @@ def g10_inputs(seed, B, Hc, Wc):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     dw /= np.linalg.norm(dw, axis=1, keepdims=True)
     return d, dw
+
+
+def g13_sample(g, H=120, W=160, B=2):
+    """Decodes the single-view inputs of g13_single_view_*.npz (8-bit image, bit-packed labels / valid mask)."""
+    n = B * H * W
+    return {"image": torch.from_numpy(g["in/image_u8"].astype(np.float32) / 255.0),
+            "labels_2D": torch.from_numpy(np.unpackbits(g["in/labels_2D"])[:n].reshape(B, 1, H, W).astype(np.float32)),
+            "valid_mask": torch.from_numpy(np.unpackbits(g["in/valid_mask"])[:n].reshape(B, 1, H, W).astype(np.float32))}

@@ -149,11 +149,54 @@ def _hip_gates(e, arch, slot, B, H, W):
     return {"relu": relu, "pool": pool}
 
 
+def _gate_flip_case(arch, B, H, W, sd, sample, used, algo, loss_kw, plain_grads, forced_tol=1e-4, plain_tol=5e-3):
+    """(a) HIP vs the plain oracle gradients `plain_grads`: statistical agreement (gate flips of activations within rounding
+    distance of 0 perturb the gradient).  (b) HIP vs the oracle evaluated WITH THE HIP PATH'S ReLU gates and max-pool
+    winners: agreement to `forced_tol` relative L2 per tensor (and 10 x that per element of max|ref|) -> the flips are the
+    whole difference.  Returns (worst plain, worst forced, worst 64-element slice error against the forced oracle)."""
+    single = "warped_img" not in sample
+    nv = 1 if single else 2
+    e = _engine(arch, B, H, W, sd)
+    if algo is not None:
+        e.set_conv_algo(algo)
+    e.zero_grad()
+    e.pair_step(_to_dev(sample), indices=None if used is None else _idx_to_dev(used, W // 8), train=True, **loss_kw)
+    torch.cuda.synchronize()
+    gd = {k: v.cpu().clone() for k, v in e.grad_dict().items()}
+    forced = tuple(_hip_gates(e, arch, v, B, H, W) for v in range(nv))
+    nflip = ngates = 0
+    for v in range(nv):
+        for k, z in _oracle_preacts(sd, sample, arch, v).items():
+            nflip += int((forced[v]["relu"][k] != (z > 0)).sum())
+            ngates += z.numel()
+    tsd = C.to_torch(sd, requires_grad=True)
+    eta = torch.tensor([1.0, 2.0, 1.0], requires_grad=True)
+    okw = {k: v for k, v in loss_kw.items() if k in ("lambda_loss", "lamda_d", "multi_task", "gaussian")}
+    loss, _, _ = C.pair_losses(tsd, eta, sample, arch, indices=used, forced=forced, warped_pair=not single, **okw)
+    loss.backward()
+    worst_plain, worst_forced, worst_slice = (0.0, ""), (0.0, ""), (0.0, "")
+    for k in C.param_keys(arch):
+        if k in _noisy(arch) or tsd[k].grad is None:
+            continue
+        l2p, _ = _rel(gd[k], plain_grads[k])
+        l2f, mxf = _rel(gd[k], tsd[k].grad)
+        sl = float((gd[k].reshape(-1)[:64] - tsd[k].grad.reshape(-1)[:64]).abs().max() / (tsd[k].grad.abs().max() + 1e-30))
+        worst_plain, worst_forced = max(worst_plain, (l2p, k)), max(worst_forced, (max(l2f, 0.1 * mxf), k))
+        worst_slice = max(worst_slice, (sl, k))
+    print("%s %dx%d algo %s%s: gate flips %d of %d; worst rel-L2: plain %.2e (%s), gates forced %.2e (%s); worst 64-element "
+          "slice vs the forced oracle %.2e of max|grad| (%s)"
+          % (arch, H, W, algo, " single view" if single else "", nflip, ngates, worst_plain[0], worst_plain[1], worst_forced[0],
+             worst_forced[1], worst_slice[0], worst_slice[1]))
+    assert worst_plain[0] <= plain_tol, ("plain oracle", worst_plain, "flipped gates: %d" % nflip)
+    assert worst_forced[0] <= forced_tol, ("gates forced", worst_forced, "flipped gates: %d" % nflip)
+    if eta.grad is not None:
+        assert (gd["eta"] - eta.grad).abs().max() < 1e-5
+    return worst_plain, worst_forced, worst_slice
+
+
 @pytest.mark.parametrize("tag", ["sp", "ssp"])
 def test_gradient_differences_are_gate_flips_only(tag):
-    """120x160, B = 2.  (a) HIP vs the plain oracle: statistical agreement (gate flips of activations within rounding
-    distance of 0 perturb the gradient).  (b) HIP vs the oracle evaluated WITH THE HIP PATH'S ReLU gates and max-pool
-    winners: agreement to 1e-4 relative L2 per tensor -> the flips are the whole difference."""
+    """120x160, B = 2, default kernels (every 3x3 layer on F(2x2,3x3) at this size)."""
     arch = ARCHS[tag]
     B, H, W = 2, 120, 160
     sd = C.init_state_dict(arch, seed=9)
@@ -163,34 +206,35 @@ def test_gradient_differences_are_gate_flips_only(tag):
     np.random.seed(50)
     torch.manual_seed(60)
     tr.train_val_sample(sample, n_iter=0, train=True)
-    used = tr.aux["indices"]
-    e = _engine(arch, B, H, W, sd)
-    e.zero_grad()
-    e.pair_step(_to_dev(sample), indices=_idx_to_dev(used, W // 8), train=True)
-    torch.cuda.synchronize()
-    gd = {k: v.cpu().clone() for k, v in e.grad_dict().items()}
-    forced = (_hip_gates(e, arch, 0, B, H, W), _hip_gates(e, arch, 1, B, H, W))
-    nflip = ngates = 0
-    for v in range(2):
-        for k, z in _oracle_preacts(sd, sample, arch, v).items():
-            nflip += int((forced[v]["relu"][k] != (z > 0)).sum())
-            ngates += z.numel()
-    tsd = C.to_torch(sd, requires_grad=True)
-    eta = torch.tensor([1.0, 2.0, 1.0], requires_grad=True)
-    loss, _, _ = C.pair_losses(tsd, eta, sample, arch, indices=used, forced=forced)
-    loss.backward()
-    worst_plain, worst_forced = (0.0, ""), (0.0, "")
-    for k in C.param_keys(arch):
-        if k in _noisy(arch):
-            continue
-        l2p, _ = _rel(gd[k], tr.last_grads[k])
-        l2f, mxf = _rel(gd[k], tsd[k].grad)
-        worst_plain, worst_forced = max(worst_plain, (l2p, k)), max(worst_forced, (max(l2f, 0.1 * mxf), k))
-    print("gate flips %d of %d; worst rel-L2: plain %.2e (%s), gates forced %.2e (%s)"
-          % (nflip, ngates, worst_plain[0], worst_plain[1], worst_forced[0], worst_forced[1]))
-    assert worst_plain[0] <= 5e-3, ("plain oracle", worst_plain, "flipped gates: %d" % nflip)
-    assert worst_forced[0] <= 1e-4, ("gates forced", worst_forced, "flipped gates: %d" % nflip)
-    assert (gd["eta"] - eta.grad).abs().max() < 1e-5
+    _gate_flip_case(arch, B, H, W, sd, sample, tr.aux["indices"], None, {}, tr.last_grads)
+
+
+@pytest.mark.parametrize("tag", ["sp", "ssp"])
+def test_gate_flips_only_under_the_benchmarked_kernels_240x320(tag):
+    """The same proof where conv_wino4_kernel (Winograd F(4x4,3x3), 36 % of the fp32 step) really runs: algorithm 10 on the
+    G12 inputs (240x320, B = 2, the reference's own sampled indices).  The G12 slice differences against the REAL reference
+    (test_full_size_step_golden: up to 1.5e-2 of max|grad|) are thereby gate flips, not kernel error: against the oracle
+    evaluated with the HIP path's gates every tensor agrees to 1e-4 and every 64-element slice to 2 x the measured residual."""
+    arch = ARCHS[tag]
+    g = G.load("g12_step_%s_240x320.npz" % tag)
+    sample = C.compact_from_npz(g)
+    B, _, H, W = sample["image"].shape
+    sd = C.init_state_dict(arch, seed=29)
+    used = G.indices_from(g, "idx/", B)
+    tr = C.Trainer(arch, sd, lr=0.001, lambda_loss=1.0, multi_task=True)
+    tr.real_batch_size = 10 ** 9
+    tr.train_val_sample(sample, n_iter=1, train=True, indices=used)
+    for k in C.param_keys(arch):  # the oracle's plain gradients ARE the reference's (fixture slices)
+        if k not in _noisy(arch):
+            r = torch.from_numpy(g["grad_slice/" + k])
+            assert (tr.last_grads[k].reshape(-1)[:64] - r).abs().max() <= 1e-3 * float(tr.last_grads[k].abs().max()) + 1e-7, k
+    _, _, ws = _gate_flip_case(arch, B, H, W, sd, sample, used, 10, dict(lambda_loss=1.0, lamda_d=1.0, multi_task=True),
+                               tr.last_grads, forced_tol=5e-5, plain_tol=2e-2)
+    assert ws[0] <= FORCED_SLICE_TOL_W4, ws
+
+
+# 64-element slices of the algorithm-10 gradients against the forced-gate oracle at 240x320: 2 x the residual measured on the GPU box
+FORCED_SLICE_TOL_W4 = 3e-5  # measured 1.44e-5 (sp), 1.18e-5 (ssp); per-tensor rel-L2 2.34e-5
 
 
 def _oracle_preacts(sd, sample, arch, view):

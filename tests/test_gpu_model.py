@@ -221,7 +221,7 @@ def _to_dev(sample):
 # 64-element gradient slices of the G6 goldens (the first 64 elements of every gradient tensor against the reference's).  Measured on
 # the GPU box (round 4): 4.8e-6 .. 6.0e-6 of max|grad| under algorithm 1, 2.2e-5 .. 2.5e-5 under algorithm 10 (F(4x4,3x3) carries
 # ~5x the rounding noise) - no ReLU gate of these slices flips.  Bound = 4x the worst measured value (was 2e-2).
-SLICE_TOL = {"sp_64x96": 1e-4, "ssp_64x96": 1e-4, "magicpoint_32x48": 1e-4}
+SLICE_TOL = {"sp_64x96": 1e-4, "ssp_64x96": 1e-4, "pair_lambda0_32x48": 1e-4}
 
 
 def _idx_to_dev(idx, Wc):
@@ -232,7 +232,7 @@ def _idx_to_dev(idx, Wc):
 
 
 @pytest.mark.parametrize("tag,arch,lam", [("sp_64x96", ARCHS[0], 1.0), ("ssp_64x96", ARCHS[1], 1.0),
-                                          ("magicpoint_32x48", ARCHS[0], 0.0)])
+                                          ("pair_lambda0_32x48", ARCHS[0], 0.0)])
 @pytest.mark.parametrize("algo", [1, 10])
 def test_pair_step_golden(tag, arch, lam, algo):
     """G6: the full step (2 forwards + losses + backward + Adam) against the reference's scalars,

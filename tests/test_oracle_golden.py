@@ -121,7 +121,7 @@ DENSE = {"descriptor_dist": 4, "lambda_d": 800}  # the shipped spelling; descrip
 
 
 @pytest.mark.parametrize("tag,arch,lam", [("sp_64x96", ARCHS[0], 1.0), ("ssp_64x96", ARCHS[1], 1.0),
-                                          ("magicpoint_32x48", ARCHS[0], 0.0), ("sp_dense_64x96", ARCHS[0], 1.0),
+                                          ("pair_lambda0_32x48", ARCHS[0], 0.0), ("sp_dense_64x96", ARCHS[0], 1.0),
                                           ("sp_dense_uniform_64x96", ARCHS[0], 1.0)])
 def test_g6_train_step(tag, arch, lam):
     g = G.load("g6_step_%s.npz" % tag)
@@ -149,6 +149,41 @@ def test_g6_train_step(tag, arch, lam):
             n = float(g["grad_norm/" + k])
             assert abs(float(gr.norm()) - n) < 1e-3 * n + 1e-7, k
             assert (gr.reshape(-1)[:64] - t(g["grad_slice/" + k])).abs().max() < 1e-3 * float(gr.abs().max()) + 1e-7, k
+
+
+@pytest.mark.parametrize("tag", ["uniform", "kendall"])
+def test_g13_single_view_step(tag):
+    """BASELINE configs[0]: the shipped magicpoint yaml's `warped_pair.enable: false` branch (one forward, detector loss
+    only; Train_model_heatmap_all.py:207,237-262,330-332) - oracle leg against the real reference's two optimizer steps."""
+    g = G.load("g13_single_view_%s_120x160.npz" % tag)
+    sample = G.g13_sample(g)
+    arch = ARCHS[0]
+    sd = C.init_state_dict(arch, seed=37)
+    tr = C.Trainer(arch, sd, lr=0.001, lambda_loss=0.0, multi_task=tag == "kendall", gaussian=False, warped_pair=False)
+    for it in range(2):
+        tr.train_val_sample(sample, n_iter=it + 1, train=True)
+        for k, v in g.items():
+            if k.startswith("step%d/" % it):
+                ref = float(v)
+                assert abs(tr.scalar_dict[k[6:]] - ref) < 3e-5 * max(1.0, abs(ref)), (k, tr.scalar_dict[k[6:]], ref)
+        if it == 0:
+            noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
+            for k, gr in tr.last_grads.items():
+                if k == "eta":
+                    assert (gr is None) == ("grad/eta" not in g)
+                    if gr is not None:
+                        assert (gr - t(g["grad/eta"])).abs().max() < 1e-5
+                elif gr is None:  # the descriptor head is not in the graph of a single-view step
+                    assert k.startswith(("convD", "bnD")) and "grad_norm/" + k not in g
+                elif k not in noisy:
+                    n = float(g["grad_norm/" + k])
+                    assert abs(float(gr.norm()) - n) < 1e-3 * n + 1e-7, k
+                    assert (gr.reshape(-1)[:64] - t(g["grad_slice/" + k])).abs().max() < 1e-3 * float(gr.abs().max()) + 1e-7, k
+    assert (tr.eta.detach() - t(g["post/eta"])).abs().max() < 1e-5
+    assert float(g["step0/loss_det_warp"]) == 0.0 and float(g["step0/loss_desc"]) == 0.0
+    assert "must match the size" in str(g["l2_raises"])  # loss_type l2 raises in the reference itself
+    with pytest.raises(AssertionError):  # :343 "need a pair of images"
+        C.pair_losses(tr.sd, tr.eta, sample, arch, lambda_loss=1.0, warped_pair=False)
 
 
 def test_erode_ellipse_shape():
