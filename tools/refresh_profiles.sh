@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --traffic none --no-export"
+Q="--no-cpu-baseline --traffic none --no-export --no-bf16"   # (--no-bf16: the fp32 passes must not trace the in-process bf16 block)
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_ssp.json 2> $O/bench_ssp.err
 python3 $R/bench.py --arch sp --steps 20 --warmup 5 --no-cpu-baseline --no-export > $O/bench_sp.json 2>/dev/null
 python3 $R/bench.py --steps 20 --warmup 5 $Q --no-roofline --graph > $O/bench_ssp_graph.json 2>/dev/null
