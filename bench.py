@@ -143,14 +143,36 @@ def roofline_block(prof_kernels, pmc, pmc_note, conv_algo, n_prof_steps, steps):
     return rl
 
 
-def bf16_block(Engine, arch, B, H, W, dev, sample, args, fp32_pairs_s, pmc16, pmc_note, dense, steps=20, warmup=5):
-    """The pair step of the headline on the bf16 path (one GPU): pairs/s, ratio to the fp32 line of this run, `roofline` with the
-    HBM bound of its dominant kernel (HIP events on every 4th step, PMC traffic from two child passes)."""
+PRECISION = {
+    3: ("bf16", "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)"),
+    7: ("bf16x2", "split-bf16 (hi + lo = 16 significant bits) matrix-core operands, three bf16 MFMAs per product / "
+                  "fp32 accumulate + master (NOT the headline precision)"),
+    12: ("bf16", "bf16 path: bf16 NHWC activations / activation gradients in HBM, every convolution (forward, data and weight "
+                 "gradient) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 BatchNorm statistics, losses, master "
+                 "weights, Adam (BASELINE configs[3] per GPU; NOT the fp32 headline precision)"),
+    8: ("bf16", "mixed bf16: fp32 forward, data / weight gradients of the 3x3 layers with bf16 matrix-core operands; "
+                "fp32 tensors, accumulate, BatchNorm, master weights, Adam (NOT the headline precision)"),
+}
+
+
+def workload_name(arch, H, W, B, conv_algo, dense, graph=False):
+    return "%s pair step %dx%d, batch %d per GPU, %s, %s, Adam%s" % (
+        arch, H, W, B, PRECISION.get(conv_algo, ("f32", "fp32"))[1],
+        "sparse loss 1000x100" if dense is None else "dense descriptor loss (1200x1200 per image)", ", hipGraph replay" if graph else "")
+
+
+def side_block(Engine, what, arch, conv_algo, B, H, W, dev, sample, args, headline_pairs_s, pmc_side, pmc_note, dense, cpu_ref_line=None,
+               steps=20, warmup=5):
+    """Another single-GPU configuration of BASELINE.json measured beside the headline in the same process (never part of `value`):
+    the same pair step, same inputs and device-sampled indices, on another architecture / conv algorithm.  Carries the headline's
+    fields: metric, value, unit, dtype, steps, warmup, ms_per_step, config.workload, roofline (HIP events on every 4th step; PMC
+    traffic / matrix-pipe occupancy from child passes of that configuration), cpu_baseline (a reference to the one measured here:
+    the oracle is fp32, it is not timed twice)."""
     import torch
     from semantic_superpoint_amd import synth
     from semantic_superpoint_amd.lib import layer_table, SCALAR_NAMES
     eng = Engine(arch, B, H, W, dev, dense_loss=dense is not None)
-    eng.set_conv_algo(12)
+    eng.set_conv_algo(conv_algo)
     eng.load_state_dict(synth.default_init_state_dict(layer_table(arch), seed=0))
 
     def step(it):
@@ -169,16 +191,19 @@ def bf16_block(Engine, arch, B, H, W, dev, sample, args, fp32_pairs_s, pmc16, pm
     dt = time.perf_counter() - t0
     pairs_s = B * steps / dt
     scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
-    blk = {"metric": "image-pairs/sec, the same pair step on the bf16 path (BASELINE configs[3] per GPU)", "value": round(pairs_s, 2),
-           "unit": "image-pairs/s", "dtype": "bf16", "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
-           "vs_fp32_line": round(pairs_s / fp32_pairs_s, 3), "final_loss": round(scal["loss"], 4),
-           "config": "conv algorithm 12: bf16 NHWC activations / activation gradients in HBM, every convolution (3x3 and 1x1; forward, data and "
-                     "weight gradient) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; first layer fp32 arithmetic; BatchNorm "
-                     "statistics, losses, master weights and Adam fp32"}
+    blk = {"metric": "image-pairs/sec at %dx%d bs%d (pair training step), %s" % (H, W, B, what), "value": round(pairs_s, 2),
+           "unit": "image-pairs/s", "n_gpus": 1, "dtype": PRECISION.get(conv_algo, ("f32", "fp32"))[0], "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * dt / steps, 3), "vs_headline": round(pairs_s / headline_pairs_s, 3), "data": "synthetic",
+           "config": {"workload": workload_name(arch, H, W, B, conv_algo, dense), "parallelism": "dp1", "global_batch": B},
+           "step_tflops": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3, 2), "final_loss": round(scal["loss"], 4)}
+    if conv_algo == 12:
+        blk["vs_fp32_line"] = blk["vs_headline"]
     n_prof = len([i for i in range(steps) if i % 4 == 0])
-    rl = roofline_block(eng.profile_read_kernels(), pmc16, pmc_note, 12, n_prof, steps)
+    rl = roofline_block(eng.profile_read_kernels(), pmc_side, pmc_note, conv_algo, n_prof, steps)
     if rl is not None:
         blk["roofline"] = rl
+    if cpu_ref_line is not None:
+        blk["cpu_baseline"] = cpu_ref_line
     eng.profile_enable("none")
     del eng
     torch.cuda.empty_cache()
@@ -203,11 +228,11 @@ def parse_args(argv=None):
                          "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
                          "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
                          "workgroups per CU, 7 = Winograd with split-bf16 (hi + lo, 16 significant bits) operands: reported "
-                         "as dtype bf16x2")
+                         "as dtype bf16x2, 8 = mixed (fp32 forward, bf16-operand gradients), 9 = F(2x2,3x3) only, 10 = F(4x4,3x3) "
+                         "wherever legal, 11 = algorithm 1 with the F(3x3,4x4) weight gradient, 12 = the bf16 path (--dtype bf16)")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
-                    help="f32 = --conv-algo 1 (the headline); bf16 = --conv-algo 8, the validated mixed bf16 mode of BASELINE "
-                         "configs[3] (fp32 forward, data / weight gradients of the 3x3 layers with bf16 matrix-core operands, everything "
-                         "else fp32)")
+                    help="f32 = --conv-algo 1 (the headline); bf16 = --conv-algo 12, the bf16 path of BASELINE configs[3] (bf16 NHWC "
+                         "activations in HBM, every convolution on the bf16 matrix cores, fp32 accumulate / statistics / master weights)")
     ap.add_argument("--desc-loss", default="sparse", choices=["sparse", "dense"],
                     help="descriptor loss of the step: sparse (shipped configs, the headline) or dense (model.dense_loss)")
     ap.add_argument("--graph", action="store_true", help="replay the pair step as a hipGraph (ssp_pair_step_graph)")
@@ -218,6 +243,9 @@ def parse_args(argv=None):
                          "before the timed run; auto = live when N = 1, rocprofv3 is on PATH and the roofline leg is on")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of --traffic live
     ap.add_argument("--no-export", action="store_true", help="skip the `export` block (BASELINE configs[4], 3 calls at 100 x 480x640)")
+    ap.add_argument("--no-sp", action="store_true",
+                    help="skip the `sp` block of the SSp fp32 line (BASELINE configs[1]: SuperPointNet_gauss2, the same step without the "
+                         "segmentation head)")
     ap.add_argument("--no-bf16", action="store_true",
                     help="skip the `bf16` block of the fp32 line (BASELINE configs[3] per GPU: the same step on the bf16 path, conv algorithm 12)")
     args = ap.parse_args(argv)
@@ -298,7 +326,7 @@ def live_pmc(args, conv_algo=None, counter_sets=(("FETCH_SIZE",), ("WRITE_SIZE",
         child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "1", "--gpus", "1",
              "--arch", args.arch, "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
              "--conv-algo", str(args.conv_algo if conv_algo is None else conv_algo), "--desc-loss", args.desc_loss,
-             "--no-cpu-baseline", "--no-roofline", "--traffic", "none", "--no-export", "--no-bf16"]
+             "--no-cpu-baseline", "--no-roofline", "--traffic", "none", "--no-export", "--no-bf16", "--no-sp"]
     tot = {}  # kernel -> counter -> [sum, set(dispatch ids)]
     tmp = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
     notes = []
@@ -368,10 +396,16 @@ def main():
     pmc16 = {}
     pmc_export = None
     want_bf16_block = (world == 1 and rank == 0 and args.conv_algo == 1 and not args.no_bf16 and not args.pmc_child)
+    # BASELINE configs[1] (SuperPointNet_gauss2, no semantic head) beside the configs[2] headline
+    want_sp_block = (world == 1 and rank == 0 and args.conv_algo == 1 and args.arch == "ssp" and not args.no_sp and not args.pmc_child)
+    pmc_sp = {}
     if want_live and world == 1:
         pmc, pmc_note = live_pmc(args)  # child processes; this process has not touched the GPU yet
         if want_bf16_block:  # HBM traffic of the bf16 path's kernels: two more passes
             pmc16, _ = live_pmc(args, conv_algo=12, counter_sets=(("FETCH_SIZE",), ("WRITE_SIZE",)))
+        if want_sp_block:    # the SP step's own counters (same kernels, one 3x3 head less per launch group)
+            sp_args = argparse.Namespace(**dict(vars(args), arch="sp"))
+            pmc_sp, _ = live_pmc(sp_args)
         if not args.no_export and rank == 0:  # ... and of the export block's convolutions (one call, two images)
             import bench_export
             pmc_export = bench_export.export_pmc("sp", 100, 480, 640)
@@ -479,31 +513,20 @@ def main():
     if rank == 0:
         scal = dict(zip(SCALAR_NAMES, eng.scalars.cpu().tolist()))
         pairs_s = world * B * args.steps / dt
-        reduced = args.conv_algo in (3, 7, 8, 12)
-        prec = {3: ("bf16", "bf16 matrix-core operands / fp32 accumulate + master (NOT the headline precision)"),
-                7: ("bf16x2", "split-bf16 (hi + lo = 16 significant bits) matrix-core operands, three bf16 MFMAs per product / "
-                              "fp32 accumulate + master (NOT the headline precision)"),
-                12: ("bf16", "bf16 path: bf16 NHWC activations / activation gradients in HBM, every convolution (forward, data and weight "
-                             "gradient) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 BatchNorm statistics, losses, master "
-                             "weights, Adam (BASELINE configs[3] per GPU; NOT the fp32 headline precision)"),
-                8: ("bf16", "mixed bf16: fp32 forward, data / weight gradients of the 3x3 layers with bf16 matrix-core operands; "
-                            "fp32 tensors, accumulate, BatchNorm, master weights, Adam (NOT the headline precision)")
-                }.get(args.conv_algo, ("f32", "fp32"))
+        prec = PRECISION.get(args.conv_algo, ("f32", "fp32"))
         out = {"metric": "image-pairs/sec at %dx%d bs%d (pair training step)" % (H, W, B), "value": round(pairs_s, 2),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": prec[0], "data": "synthetic",
-               "config": {"workload": "%s pair step %dx%d, batch %d per GPU, %s, %s, Adam%s"
-                                      % (arch, H, W, B, prec[1],
-                                         "sparse loss 1000x100" if dense is None else
-                                         "dense descriptor loss (1200x1200 per image)",
-                                         ", hipGraph replay" if args.graph else ""),
+               "config": {"workload": workload_name(arch, H, W, B, args.conv_algo, dense, args.graph),
                           "parallelism": "dp%d" % world, "global_batch": world * B,
                           "allreduce": ("none" if world == 1 else "one bucket after backward" if args.no_overlap else
                                         "split bucket, early part overlapped with the backward of the 240x320 layers")},
                "rccl_ranks": rccl_ranks,
                "step_tflops": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3, 2),
-               "step_frac_of_fp32_mfma_peak": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3 / (PEAK_FP32_MFMA_TF * world), 4),
+               # direct-convolution (algorithmic) FLOPs of the whole step against the fp32 MFMA peak: an ALGORITHMIC ratio (Winograd
+               # executes 1/4 resp. 16/36 of these multiplies, so it may exceed 1); the hardware fraction is roofline.frac
+               "step_algorithmic_tflops_vs_fp32_mfma_peak": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3 / (PEAK_FP32_MFMA_TF * world), 4),
                "final_loss": round(scal["loss"], 4), "build_id": ssp.lib.build_id()[:16]}
         if world > 1:
             log = None
@@ -522,11 +545,23 @@ def main():
             profiling[0] = False
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch, H, W, batch=B)
+        cpu_line = None
+        if "cpu_baseline" in out:
+            cpu_line = dict(out["cpu_baseline"], note="the fp32 oracle step timed once in this run (top-level cpu_baseline)")
+        if want_sp_block:
+            # BASELINE configs[1] beside the headline (never part of `value`): SuperPointNet_gauss2, the same step without the
+            # segmentation head, fp32 default kernels, same inputs
+            try:
+                out["sp"] = side_block(Engine, "SuperPointNet_gauss2 (BASELINE configs[1])", "SuperPointNet_gauss2", 1, B, H, W, dev,
+                                       sample, args, pairs_s, pmc_sp, pmc_note, dense)
+            except Exception as e:  # the headline line must survive a failure of the side measurement
+                out["sp"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if want_bf16_block:
             # BASELINE configs[3] per GPU beside the fp32 headline (never part of `value`): the same step, same inputs, on the bf16
             # path (conv algorithm 12: bf16 activations in HBM, bf16 matrix cores, fp32 accumulate / statistics / master / Adam)
             try:
-                out["bf16"] = bf16_block(Engine, arch, B, H, W, dev, sample, args, pairs_s, pmc16, pmc_note, dense)
+                out["bf16"] = side_block(Engine, "bf16 path (BASELINE configs[3] per GPU)", arch, 12, B, H, W, dev, sample, args,
+                                         pairs_s, pmc16, pmc_note, dense, cpu_ref_line=cpu_line)
             except Exception as e:  # the headline line must survive a failure of the side measurement
                 out["bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_export and not args.pmc_child:

@@ -95,7 +95,10 @@ class StepDiag:
 # what the first 8-GPU run should show: the early bucket (6.39 MB) needs 0.15-0.25 ms on a ring over xGMI and has
 # the whole of phase 2 to hide under; exposed per step: the late 151 KB bucket (one latency-bound all-reduce) and RCCL's CUs
 DP_EXPECTED = {"allreduce_exposed_ms": "0.03-0.1 (the late 151 KB bucket; the early 6.4 MB bucket hides under phase 2)",
-               "phase2_ms": "fp32: ~3.5 of a 13.7 ms step; bf16 path: ~1.7 of 7.2 ms",
+               # per-GPU batch 32 (the bench configuration), from the single-GPU step timelines (tools/timeline_step.sh): fp32 = weight
+               # gradient 1.70 + data gradient 1.40 of the 64 -> 64 layer at 240x320 + first-layer kernels 0.41; phase 2 scales with
+               # the per-rank batch: the two-ranks-on-one-device trace profiles/r04_dp_readiness.txt ran 16 pairs per rank (2.07 / 0.85)
+               "phase2_ms": "batch 32 per GPU: fp32 ~3.5 of a 13.7 ms step, bf16 path ~1.5-1.7 of 7.2 ms (batch 16 per rank: 2.1 / 0.85)",
                "weak_scaling_efficiency_8gpu": "0.97-0.99",
                "rccl": "ring or tree, Simple / LL128 protocol for the 6.4 MB bucket; LL for the 151 KB bucket"}
 

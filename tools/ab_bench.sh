@@ -4,8 +4,8 @@
 T=$1; shift
 mkdir -p gpurun_out/$T
 for i in 1 2; do
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-export "$@" > gpurun_out/$T/new$i.json 2> gpurun_out/$T/new$i.err
-  SSP_SKIP_ISA_VERIFY=1 SSP_HIP_LIB=$PWD/ab/libssp_base.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-export "$@" > gpurun_out/$T/base$i.json 2> gpurun_out/$T/base$i.err
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-export --no-sp "$@" > gpurun_out/$T/new$i.json 2> gpurun_out/$T/new$i.err
+  SSP_SKIP_ISA_VERIFY=1 SSP_HIP_LIB=$PWD/ab/libssp_base.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-export --no-sp "$@" > gpurun_out/$T/base$i.json 2> gpurun_out/$T/base$i.err
 done
 python - <<PY
 import json,glob

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pf32
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --traffic none --no-export --no-roofline --no-bf16 $*"
+Q="--no-cpu-baseline --traffic none --no-export --no-roofline --no-bf16 --no-sp $*"
 rocprofv3 --kernel-trace --stats -d $O/kt -o k -- python3 $R/bench.py $Q --steps 6 --warmup 1 > $O/bench_line.txt 2>/dev/null
 if [ "${PMC:-0}" = "1" ]; then
   rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o s -- python3 $R/bench.py $Q --steps 1 --warmup 1 > /dev/null 2>&1

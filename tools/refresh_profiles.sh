@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --traffic none --no-export --no-bf16"   # (--no-bf16: the fp32 passes must not trace the in-process bf16 block)
+Q="--no-cpu-baseline --traffic none --no-export --no-bf16 --no-sp"   # (--no-bf16 --no-sp: the fp32 passes must not trace the in-process bf16 block)
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_ssp.json 2> $O/bench_ssp.err
 python3 $R/bench.py --arch sp --steps 20 --warmup 5 --no-cpu-baseline --no-export > $O/bench_sp.json 2>/dev/null
 python3 $R/bench.py --steps 20 --warmup 5 $Q --no-roofline --graph > $O/bench_ssp_graph.json 2>/dev/null
@@ -31,7 +31,7 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS
 python3 $R/bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-export > $O/bench_ssp_bf16.json 2>/dev/null
 python3 $R/bench.py --arch sp --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-export > $O/bench_sp_bf16.json 2>/dev/null
 SSP_CONVB_WS=0 python3 $R/bench.py --dtype bf16 --steps 20 --warmup 5 $Q > $O/bench_ssp_bf16_generic_3x3_kernels.json 2>/dev/null
-SSP_DETERMINISTIC=1 python3 $R/bench.py --steps 20 --warmup 5 $Q --no-roofline --no-bf16 > $O/bench_ssp_deterministic.json 2>/dev/null
+SSP_DETERMINISTIC=1 python3 $R/bench.py --steps 20 --warmup 5 $Q --no-roofline --no-bf16 --no-sp > $O/bench_ssp_deterministic.json 2>/dev/null
 SSP_DETERMINISTIC=1 python3 $R/bench.py --dtype bf16 --steps 20 --warmup 5 $Q --no-roofline > $O/bench_ssp_bf16_deterministic.json 2>/dev/null
 cd $R
 bash tools/prof_bf16.sh > /dev/null 2>&1
