@@ -223,13 +223,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12],
-                    help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct, 2 = fp32 Winograd "
-                         "un-pipelined, 5 = fp32 Winograd pipelined with LDS-staged weights, 3 = Winograd with bf16 "
-                         "matrix-core operands (reduced precision: reported as dtype bf16), 6 = fp32 Winograd, two 4-wave "
-                         "workgroups per CU, 7 = Winograd with split-bf16 (hi + lo, 16 significant bits) operands: reported "
-                         "as dtype bf16x2, 8 = mixed (fp32 forward, bf16-operand gradients), 9 = F(2x2,3x3) only, 10 = F(4x4,3x3) "
-                         "wherever legal, 11 = algorithm 1 with the F(3x3,4x4) weight gradient, 12 = the bf16 path (--dtype bf16)")
+    ap.add_argument("--conv-algo", type=int, default=1, choices=[0, 1, 6, 9, 10, 11, 12],
+                    help="ssp_set_conv_algo: 1 = fp32 Winograd (default, the headline), 0 = fp32 direct implicit GEMM, 6 = fp32 "
+                         "Winograd F(2x2,3x3), two 4-wave workgroups per CU, 9 = F(2x2,3x3) only, 10 = F(4x4,3x3) wherever legal, 11 = "
+                         "algorithm 1 with the F(3x3,4x4) weight gradient, 12 = the bf16 path (--dtype bf16).  (2 / 3 / 5 / 7 / 8: "
+                         "experiments of rounds 1-3, compiled out of the shipped library - SSP_LEGACY_ALGOS)")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="f32 = --conv-algo 1 (the headline); bf16 = --conv-algo 12, the bf16 path of BASELINE configs[3] (bf16 NHWC "
                          "activations in HBM, every convolution on the bf16 matrix cores, fp32 accumulate / statistics / master weights)")

@@ -37,8 +37,8 @@ enum { SSP_NREP = 32 }; /* replicas of each fp64 statistics accumulator (spreads
 typedef struct {
   int arch;      /* SSP_ARCH_* */
   int n_classes; /* 133 for the ssmall seg head; ignored for gauss2 */
-  int max_batch; /* largest N of any forward (1..1024); ssp_pair_step additionally requires batch <= 64
-                    (fixed per-image accumulator arrays of the sparse / dense descriptor loss) */
+  int max_batch; /* largest N of any forward (1..1024); ssp_pair_step additionally requires batch <= 256
+                    (per-image accumulator arrays of the sparse descriptor loss, SSP_MAX_PAIRS) */
   int height;    /* H, multiple of 8 */
   int width;     /* W, multiple of 8 */
   int n_match;   /* num_matching_attempts (1000) */
@@ -63,11 +63,15 @@ typedef struct {
   size_t workspace_bytes;
 } ssp_buffers;
 
-/* One micro-batch of pairs (Train_model_heatmap_all.py:212-251 `sample`). NCHW with C==1. */
+/* One micro-batch of pairs (Train_model_heatmap_all.py:212-251 `sample`). NCHW with C==1.
+ * warped_image_dev == NULL selects the SINGLE-VIEW step of `data.warped_pair.enable: false` (Train_model_heatmap_all.py:207,
+ * 237-262, 330-332; configs/magicpoint_shapes_pair.yaml): one forward, detector (+ segmentation) loss of the image only,
+ * loss_det_warp = loss_sem_warp = 0; the other warped_* pointers and homographies_dev are then ignored and lambda_loss must
+ * be 0 (the reference asserts "need a pair of images"). */
 typedef struct {
   int batch;
   const float* image_dev;             /* [B,1,H,W] */
-  const float* warped_image_dev;      /* [B,1,H,W] */
+  const float* warped_image_dev;      /* [B,1,H,W], or NULL: single-view step */
   const float* labels_dev;            /* [B,1,H,W] labels_2D(_gaussian) */
   const float* warped_labels_dev;     /* [B,1,H,W] */
   const float* valid_mask_dev;        /* [B,1,H,W] */

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void dense_dots_kernel(const DenseArgs a) {
   __syncthreads();
   if (tid == 0) {
     // 1024 replicas of each sum (the StepAccum arrays of the sparse loss): same-address atomics stay rare
-    const int rep = (blockIdx.x + 19 * blockIdx.y + 7 * blockIdx.z) & 1023;
+    const int rep = (blockIdx.x + 19 * blockIdx.y + 7 * blockIdx.z) & (SSP_DENSE_REPS - 1);
     acc_add_loss(&a.acc->pos_sum[rep], (double)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])));
     acc_add_loss(&a.acc->neg_sum[rep], (double)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])));
     acc_add_loss(&a.acc->dense_sum[rep], (double)((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])));
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void dense_op_prep_kernel(StepAccum* acc, cons
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) s += valid[i];
   red[threadIdx.x] = s;
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) acc->pos_sum[i] = acc->neg_sum[i] = acc->dense_sum[i] = 0.0;
+  for (int i = threadIdx.x; i < SSP_DENSE_REPS; i += 256) acc->pos_sum[i] = acc->neg_sum[i] = acc->dense_sum[i] = 0.0;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void dense_op_prep_kernel(StepAccum* acc, cons
 __global__ void dense_op_finish_kernel(const StepAccum* acc, float* __restrict__ out3, int B, int cells) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double ps = 0, ns = 0, ls = 0;
-  for (int i = 0; i < 64 * 16; ++i) {
+  for (int i = 0; i < SSP_DENSE_REPS; ++i) {
     ps += acc->pos_sum[i];
     ns += acc->neg_sum[i];
     ls += acc->dense_sum[i];

@@ -53,8 +53,13 @@ __device__ __forceinline__ void facc_add(float* p, float v) {
     for (int i = 0; i < n; ++i) {
       const DetRegion r = g_det_region[i];
       if (p >= r.lo && p < r.hi) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(r.shadow + (p - r.lo)), (unsigned long long)__double2ll_rn((double)v * DET_K_SHADOW));
-        return;
+        // (a non-finite contribution has no fixed-point image - __double2ll_rn would turn it into 0 or a saturated value and hide
+        // a diverged gradient: it goes to the tensor itself, where the fold's addition keeps it)
+        if (isfinite(v)) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(r.shadow + (p - r.lo)), (unsigned long long)__double2ll_rn((double)v * DET_K_SHADOW));
+          return;
+        }
+        break;
       }
     }
   }
@@ -79,7 +84,7 @@ __device__ __forceinline__ DetTarget det_resolve(float* base) {
   return t;
 }
 __device__ __forceinline__ void facc_add(const DetTarget& t, float* p, float v) {
-  if (t.shadow != nullptr)
+  if (t.shadow != nullptr && isfinite(v))   // (non-finite: see facc_add above)
     atomicAdd(reinterpret_cast<unsigned long long*>(t.shadow + (p - t.lo)), (unsigned long long)__double2ll_rn((double)v * DET_K_SHADOW));
   else
     atomicAdd(p, v);

@@ -58,17 +58,21 @@ __device__ __forceinline__ float block_sum_of_waves(float v, float* smem4) {
   return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
+// Pairs per ssp_pair_step call (per-image accumulators of the sparse descriptor loss below; ssp_config.max_batch bounds a forward)
+constexpr int SSP_MAX_PAIRS = 256;
+constexpr int SSP_DENSE_REPS = 1024;   // replica slots the dense descriptor loss spreads its three sums over (<= SSP_MAX_PAIRS * 16)
 // Device-side accumulators / coefficients of one pair step (doubles for order-insensitive sums).
 struct StepAccum {
   double det_sum[2];    // sum over cells of mask * sum_c BCE, per view
   double mask_cnt[2];   // mask.sum() per view
   double sem_sum[2];    // sum of NLL over non-ignored pixels
   double sem_cnt[2];    // number of non-ignored pixels
-  double pos_sum[64 * 16];   // per image x 16 replicas: sum_k max(0, 1 - <a,b>)
-  double neg_sum[64 * 16];   // per image x 16 replicas: sum max(0, <a,b> - 0.2)
-  unsigned int nnz[64 * 16]; // per image x 16 replicas: number of non-zero non-match hinges
-  unsigned int nnz_img[64];  // per image totals (desc_counts_kernel), read by the backward kernels
-  double dense_sum[64 * 16]; // dense descriptor loss: replicas of sum (pos + neg) * valid (pos_sum / neg_sum hold the rest)
+  double pos_sum[SSP_MAX_PAIRS * 16];   // per image x 16 replicas: sum_k max(0, 1 - <a,b>)
+  double neg_sum[SSP_MAX_PAIRS * 16];   // per image x 16 replicas: sum max(0, <a,b> - 0.2)
+  unsigned int nnz[SSP_MAX_PAIRS * 16]; // per image x 16 replicas: number of non-zero non-match hinges
+  unsigned int nnz_img[SSP_MAX_PAIRS];  // per image totals (desc_counts_kernel), read by the backward kernels
+  double dense_sum[SSP_DENSE_REPS];     // dense descriptor loss: replicas of sum (pos + neg) * valid (the first SSP_DENSE_REPS
+                                        // slots of pos_sum / neg_sum hold the rest)
   float coef_det, coef_pos, coef_neg, coef_sem;  // d total / d (loss_det sum), d/d pos mean, d/d neg mean, d/d sem sum
 };
 
@@ -363,20 +367,23 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
 
 // per-image totals of the non-zero hinge counts (between the forward and backward descriptor kernels)
 __global__ void desc_counts_kernel(StepAccum* acc, int B) {
-  const int i = threadIdx.x;
-  if (i >= B) return;
-  unsigned nz = 0;
-  for (int r = 0; r < 16; ++r) nz += acc->nnz[i * 16 + r];
-  acc->nnz_img[i] = nz;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    unsigned nz = 0;
+    for (int r = 0; r < 16; ++r) nz += acc->nnz[i * 16 + r];
+    acc->nnz_img[i] = nz;
+  }
 }
 
 // ---- MultiTaskLoss coefficients (before the loss kernels) and scalars / eta gradient (after) ----
 __global__ void step_begin_kernel(StepAccum* acc, const float* __restrict__ eta, int multi_task, float lambda_loss,
-                                  float lamda_d, int semantic) {
-  // one wave (launched with 64 threads): the 4 x 1024 replica slots are cleared in parallel (a single thread took 17 us)
+                                  float lamda_d, int semantic, int B) {
+  // one wave (launched with 64 threads): the replica slots in use (16 per image, at least the dense loss's 1024) are cleared in
+  // parallel (a single thread took 17 us)
   if (blockIdx.x != 0) return;
-  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
-    acc->pos_sum[i] = acc->neg_sum[i] = acc->dense_sum[i] = 0.0;
+  const int nclear = max(B * 16, SSP_DENSE_REPS);
+  for (int i = threadIdx.x; i < nclear; i += blockDim.x) {
+    acc->pos_sum[i] = acc->neg_sum[i] = 0.0;
+    if (i < SSP_DENSE_REPS) acc->dense_sum[i] = 0.0;
     acc->nnz[i] = 0u;
   }
   if (threadIdx.x != 0) return;
@@ -400,25 +407,27 @@ __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ 
   // one wave (launched with 64 threads): lane i reduces the replicas of image i (sparse loss) or a slice of the 1024
   // replica slots (dense loss); thread 0 then combines in the order of the former single-thread loop
   if (blockIdx.x != 0) return;
-  __shared__ float s_p[64], s_q[64];
+  __shared__ float s_p[SSP_MAX_PAIRS], s_q[SSP_MAX_PAIRS];
   __shared__ double s_d[3][64];
   const int li = threadIdx.x;
   if (lambda_loss > 0.f && dense) {
     double ps = 0, ns = 0, ls = 0;
-    for (int i = li; i < 64 * 16; i += 64) {
+    for (int i = li; i < SSP_DENSE_REPS; i += 64) {
       ps += acc->pos_sum[i];
       ns += acc->neg_sum[i];
       ls += acc->dense_sum[i];
     }
     s_d[0][li] = ps; s_d[1][li] = ns; s_d[2][li] = ls;
-  } else if (lambda_loss > 0.f && li < B) {
-    double ps = 0, ns = 0;
-    for (int r = 0; r < 16; ++r) {
-      ps += acc->pos_sum[li * 16 + r];
-      ns += acc->neg_sum[li * 16 + r];
+  } else if (lambda_loss > 0.f) {
+    for (int img = li; img < B; img += 64) {
+      double ps = 0, ns = 0;
+      for (int r = 0; r < 16; ++r) {
+        ps += acc->pos_sum[img * 16 + r];
+        ns += acc->neg_sum[img * 16 + r];
+      }
+      s_p[img] = (float)ps / (float)n_match;
+      s_q[img] = (float)ns / ((float)acc->nnz_img[img] + 1.f);
     }
-    s_p[li] = (float)ps / (float)n_match;
-    s_q[li] = (float)ns / ((float)acc->nnz_img[li] + 1.f);
   }
   __syncthreads();
   if (threadIdx.x != 0) return;

@@ -22,7 +22,12 @@
 #include "conv_wino4.hip.h"
 #include "wgrad_wino4.hip.h"
 #include "wgrad_wino_fused.hip.h"
+#ifndef SSP_LEGACY_ALGOS
+#define SSP_LEGACY_ALGOS 0
+#endif
+#if SSP_LEGACY_ALGOS
 #include "conv_wino_bf16.hip.h"
+#endif
 #include "conv_bf16.hip.h"
 #include "conv_bf16_ws.hip.h"
 #include "wgrad_bf16.hip.h"
@@ -34,9 +39,11 @@
 
 using namespace sspk;
 
-// A/B-only convolution algorithms of rounds 1-2 that no shipped configuration selects: 2 (conv_wino_kernel, the un-pipelined
-// F(2x2,3x3) convolution) and 5 (conv_wino_pipe_kernel with the weights staged through LDS).  Compiled out by default
-// (8 kernel instances, ~10 s of build time); -DSSP_LEGACY_ALGOS=1 (SSP_HIPCC_EXTRA) brings them back.
+// Convolution algorithms of rounds 1-3 that no shipped configuration selects: 2 (conv_wino_kernel, the un-pipelined F(2x2,3x3)
+// convolution), 5 (conv_wino_pipe_kernel with the weights staged through LDS) and the bf16-OPERAND experiments inside the fp32
+// Winograd kernels that the bf16 path (algorithm 12) superseded: 3 (one bf16 part), 7 (hi + lo parts), 8 (mixed: fp32 forward,
+// bf16-operand gradients) - conv_wino_bf16.hip.h.  Compiled out of the shipped library (28 kernel instances); their results are
+// PERF_LOG.md section 10 and profiles/r0[2-4]_*mixed_bf16*; -DSSP_LEGACY_ALGOS=1 (SSP_HIPCC_EXTRA) brings them back.
 #ifndef SSP_LEGACY_ALGOS
 #define SSP_LEGACY_ALGOS 0
 #endif
@@ -58,7 +65,7 @@ static inline bool wino_ok(int ks, int conv_cin) { return g_conv_algo != 0 && ks
 // only (the default of rounds 1-2), 10 = F(4x4,3x3) wherever legal
 // 11 = algorithm 1 with the Winograd F(3x3,4x4) weight gradient (wgrad_wino4_kernel: opt-in, measured not faster)
 static inline bool pipe_algo() { return g_conv_algo == 1 || g_conv_algo == 9 || g_conv_algo == 10 || g_conv_algo == 11; }
-static inline bool bf16_algo() { return g_conv_algo == 3 || g_conv_algo == 7 || g_conv_algo == 8; }
+static inline bool bf16_algo() { return SSP_LEGACY_ALGOS && (g_conv_algo == 3 || g_conv_algo == 7 || g_conv_algo == 8); }
 // 12 = the bf16 PATH (BASELINE configs[3]): bf16 NHWC activations / activation gradients in HBM, direct implicit-GEMM 3x3 convolutions,
 // data and weight gradients on v_mfma_f32_32x32x16_bf16 (conv_bf16.hip.h, wgrad_bf16.hip.h); fp32 master weights, BatchNorm
 // statistics, losses and Adam; the pointwise heads and everything behind them stay on the fp32 kernels
@@ -530,6 +537,7 @@ static int launch_wino4_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
+#if SSP_LEGACY_ALGOS
 template <int IN_MODE, bool WIDE, int NT = 1>
 static int launch_wino_bf16_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   static AttrOnce attr_once;
@@ -543,7 +551,6 @@ static int launch_wino_bf16_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
-#if SSP_LEGACY_ALGOS
 template <int IN_MODE, bool WIDE>
 static int launch_wino_t(const ConvArgs& a, int nblocks, hipStream_t st) {
   static AttrOnce attr_once;
@@ -669,6 +676,7 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     if (c.in_mode == 0) return wide4 ? launch_wino4_t<0, true>(a, nblocks, st) : launch_wino4_t<0, false>(a, nblocks, st);
     return wide4 ? launch_wino4_t<1, true>(a, nblocks, st) : launch_wino4_t<1, false>(a, nblocks, st);
   }
+#if SSP_LEGACY_ALGOS
   if (c.wino && bf16_algo()) {
     if (bf16_parts(c.backward) == 1) {
       a.wpk_bytes /= 2;  // one bf16 part: half the bytes of the fp32 image
@@ -679,6 +687,7 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
     if (c.in_mode == 0) return wide ? launch_wino_bf16_t<0, true, 2>(a, nblocks, st) : launch_wino_bf16_t<0, false, 2>(a, nblocks, st);
     return wide ? launch_wino_bf16_t<1, true, 2>(a, nblocks, st) : launch_wino_bf16_t<1, false, 2>(a, nblocks, st);
   }
+#endif
   if (p2) {  // second-generation pipelined Winograd: two independent 4-wave workgroups per CU
     if (c.in_mode == 0) return wide ? launch_wino_p2_t<0, true>(a, nblocks, st) : launch_wino_p2_t<0, false>(a, nblocks, st);
     return wide ? launch_wino_p2_t<1, true>(a, nblocks, st) : launch_wino_p2_t<1, false>(a, nblocks, st);
@@ -932,6 +941,7 @@ static int launch_wgrad_wino4_t(const WgradArgs& a, int nblocks, hipStream_t st)
   return 0;
 }
 
+#if SSP_LEGACY_ALGOS
 template <int IN_MODE, bool WIDE, int NT = 1>
 static int launch_wgrad_wino_bf16_t(const WgradArgs& a, int nblocks, hipStream_t st) {
   using G = WgradWinoGeom<WIDE>;
@@ -944,6 +954,7 @@ static int launch_wgrad_wino_bf16_t(const WgradArgs& a, int nblocks, hipStream_t
   HIPCHK(hipGetLastError());
   return 0;
 }
+#endif
 
 struct WgradCall {
   const float* in; int in_cs, in_co, cin;
@@ -1051,20 +1062,27 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
       const bool b16 = bf16_algo();
       if (!wino || wino4 || (b16 && bf16_parts(true) != 1))
         return fail(-3, "fused BatchNorm apply needs the F(3x3,2x2) weight gradient (fp32, or bf16 operands in one part)");
+#if SSP_LEGACY_ALGOS
 #define WGF_CASE(M_, P_) \
       if (c.in_mode == M_ && c.fuse_pool == P_ && !b16) CHK((wide ? launch_wgrad_wino_fused_t<M_, true, P_>(a, nblocks, st) : launch_wgrad_wino_fused_t<M_, false, P_>(a, nblocks, st))); \
       if (c.in_mode == M_ && c.fuse_pool == P_ && b16) CHK((wide ? launch_wgrad_wino_fused_t<M_, true, P_, true>(a, nblocks, st) : launch_wgrad_wino_fused_t<M_, false, P_, true>(a, nblocks, st)));
+#else
+#define WGF_CASE(M_, P_) \
+      if (c.in_mode == M_ && c.fuse_pool == P_) CHK((wide ? launch_wgrad_wino_fused_t<M_, true, P_>(a, nblocks, st) : launch_wgrad_wino_fused_t<M_, false, P_>(a, nblocks, st)));
+#endif
       WGF_CASE(0, false) WGF_CASE(0, true) WGF_CASE(1, false) WGF_CASE(1, true)
 #undef WGF_CASE
     } else if (wino4) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino4_t<0, true>(a, nblocks, st) : launch_wgrad_wino4_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino4_t<1, true>(a, nblocks, st) : launch_wgrad_wino4_t<1, false>(a, nblocks, st)));
+#if SSP_LEGACY_ALGOS
     } else if (wino && bf16_algo() && bf16_parts(true) == 1) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_bf16_t<1, true>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false>(a, nblocks, st)));
     } else if (wino && bf16_algo()) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_bf16_t<0, true, 2>(a, nblocks, st) : launch_wgrad_wino_bf16_t<0, false, 2>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_bf16_t<1, true, 2>(a, nblocks, st) : launch_wgrad_wino_bf16_t<1, false, 2>(a, nblocks, st)));
+#endif
     } else if (wino) {
       if (c.in_mode == 0) CHK((wide ? launch_wgrad_wino_t<0, true>(a, nblocks, st) : launch_wgrad_wino_t<0, false>(a, nblocks, st)));
       else CHK((wide ? launch_wgrad_wino_t<1, true>(a, nblocks, st) : launch_wgrad_wino_t<1, false>(a, nblocks, st)));
@@ -1103,10 +1121,12 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
     if (w4)  // F(4x4,3x3) image of conv_wino4_kernel: 8-channel chunks of 36 components
       hipLaunchKernelGGL(pack_weights_wino4_kernel, dim3(cdiv(ncob * 2 * nchunks * W4_B_FLOATS, 256)), dim3(256), 0, st, w, dst,
                          cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks);
+#if SSP_LEGACY_ALGOS
     else if (bf16_algo())
       hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w,
                          reinterpret_cast<__bf16*>(dst), cout_w, cin_w, tf, 2 * nchunks, 0, 0, ncob, 2 * nchunks,
                          bf16_parts(tf != 0));
+#endif
     else if (pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6)  // 8-channel stages of the pipelined kernels: twice as many chunks of half the size
       hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, dst, cout_w, cin_w, tf,
                          2 * nchunks, 0, 0, ncob, 2 * nchunks);
@@ -1172,6 +1192,7 @@ static int ensure_aux_stream(ssp_handle* h);
 struct DetHostRegion { float* lo; size_t n; long long* shadow; const ssp_handle* owner; };
 static std::vector<DetHostRegion> g_det_regions;
 static int g_det_mode = -1;   // -1: not read yet (SSP_DETERMINISTIC), 0 / 1
+static int g_det_device = -1; // device of the registered regions
 static bool det_mode() {
   if (g_det_mode < 0) { const char* e = getenv("SSP_DETERMINISTIC"); g_det_mode = (e != nullptr && atoi(e) != 0) ? 1 : 0; }
   return g_det_mode == 1;
@@ -1196,7 +1217,9 @@ static void det_release(const ssp_handle* h) {
     if (g_det_regions[i].owner == h) { (void)hipFree(g_det_regions[i].shadow); g_det_regions.erase(g_det_regions.begin() + i); any = true; }
     else ++i;
   }
-  if (any) (void)det_upload();
+  // (an upload that fails here leaves the device table pointing at freed shadows only for regions nobody scatters into any more:
+  // their owner is being re-bound or destroyed; the next successful upload replaces the table)
+  if (any && det_upload() != 0) fprintf(stderr, "libssp_hip: deterministic-mode region table upload failed on release: %s\n", g_err.c_str());
 }
 static int det_register(const ssp_handle* h, float* lo, size_t n) {
   if (lo == nullptr || n == 0) return 0;
@@ -1296,13 +1319,26 @@ int ssp_bind(ssp_handle* h, const ssp_buffers* b, void* stream) {
   HIPCHK(hipMemsetAsync(b->workspace_dev, 0, h->ws_bytes, (hipStream_t)stream));
   det_release(h);
   if (det_mode()) {   // fixed-point shadows of the tensors that fp32 atomics scatter into
+    // The region table is ONE __device__ array per device while the host list is per process, and neither is locked: the mode
+    // supports handles of one device, bound from one thread.  Capacity is checked BEFORE anything is registered, and a failure
+    // half-way rolls this handle's regions back (a stale entry would fail every later bind of the process).
+    int dev_now = -1;
+    HIPCHK(hipGetDevice(&dev_now));
+    if (g_det_device >= 0 && g_det_device != dev_now && !g_det_regions.empty())
+      return fail(-3, "deterministic mode: handles of ONE device per process (regions of device %d are bound, this bind is on device %d)", g_det_device, dev_now);
+    const int need = (b->grads_dev ? 1 : 0) + 2 + (h->slot[0].dsout ? 2 : 0);
+    if ((int)g_det_regions.size() + need > DET_MAX_REGIONS)
+      return fail(-3, "deterministic mode: %d fp32 scatter targets are bound in this process, this handle needs %d more (limit %d)",
+                  (int)g_det_regions.size(), need, DET_MAX_REGIONS);
+    g_det_device = dev_now;
     const size_t cells = (size_t)h->cfg.max_batch * (h->cfg.height / 8) * (h->cfg.width / 8);
-    CHK(det_register(h, b->grads_dev, b->grads_dev ? h->n_params + 3 : 0));
-    for (int v = 0; v < 2; ++v) {
-      CHK(det_register(h, h->slot[v].ddesc, cells * 256));
-      CHK(det_register(h, h->slot[v].dsout, h->slot[v].dsout ? cells * h->sout_cs : 0));
+    int rc = det_register(h, b->grads_dev, b->grads_dev ? h->n_params + 3 : 0);
+    for (int v = 0; v < 2 && rc == 0; ++v) {
+      rc = det_register(h, h->slot[v].ddesc, cells * 256);
+      if (rc == 0) rc = det_register(h, h->slot[v].dsout, h->slot[v].dsout ? cells * h->sout_cs : 0);
     }
-    CHK(det_upload());
+    if (rc == 0) rc = det_upload();
+    if (rc != 0) { det_release(h); return rc; }
   }
   h->bound = true;
   return 0;
@@ -1476,11 +1512,14 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
     const bool wino = wino_ok(3, 256 * h->nheads);
     const int total = 2 * 16 * (wino ? WC : 9) * CK * NB;
     for (int k = 0; k < h->nheads; ++k) {
+#if SSP_LEGACY_ALGOS
       if (wino && bf16_algo())
         hipLaunchKernelGGL(pack_weights_wino8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            P(h, h->L[heads[k]].w_off), reinterpret_cast<__bf16*>(h->wpk_heads_bwd), 256, 128, 1,
                            32 * h->nheads, 32 * k, 0, 2, 32, bf16_parts(true));
-      else if (wino && multi && J.n < PACK_MAX_JOBS)
+      else
+#endif
+      if (wino && multi && J.n < PACK_MAX_JOBS)
         add_job(P(h, h->L[heads[k]].w_off), h->wpk_heads_bwd, 256, 128, 1, 32 * h->nheads, 32 * k, 0, 2, 32);
       else if (wino && multi)
         hipLaunchKernelGGL(pack_weights_wino8_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
@@ -2359,8 +2398,8 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   }
   if (in->train && !h->buf.grads_dev) return fail(-1, "train step needs a gradient buffer");
   const int B = in->batch, H = h->cfg.height, W = h->cfg.width, Hc = H / 8, Wc = W / 8;
-  if (B < 1 || B > h->cfg.max_batch || B > 64)
-    return fail(-1, "pair-step batch %d out of range (1..min(max_batch, 64))", B);
+  if (B < 1 || B > h->cfg.max_batch || B > SSP_MAX_PAIRS)
+    return fail(-1, "pair-step batch %d out of range (1..min(max_batch, %d))", B, SSP_MAX_PAIRS);
   const bool semantic = h->nheads == 3;
   if (semantic && (!in->semantic_dev || (nv == 2 && !in->warped_semantic_dev))) return fail(-1, "semantic labels required for the ssmall model");
   const bool use_desc = in->lambda_loss > 0.f;
@@ -2375,7 +2414,7 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   const float* eta = h->buf.params_dev + h->n_params;
   const int ncells = B * Hc * Wc;
   hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
-                     in->lamda_d, (int)semantic);
+                     in->lamda_d, (int)semantic, B);
   SlotSet SS{nv, {&h->slot[0], nv == 2 ? &h->slot[1] : nullptr}};
   {
     const float* xs[2] = {in->image_dev, in->warped_image_dev};
@@ -2486,7 +2525,7 @@ static int sample_indices_impl(ssp_handle* h, const float* homographies_dev, con
                                hipStream_t st) {
   if (!h) return fail(-1, "null handle");
   if (!homographies_dev && !hcell_dev) return fail(-1, "sample_indices: homographies required");
-  if (batch < 1 || batch > 64) return fail(-1, "batch out of range");
+  if (batch < 1 || batch > SSP_MAX_PAIRS) return fail(-1, "batch out of range (1..%d)", SSP_MAX_PAIRS);
   const int Hc = h->cfg.height / 8, Wc = h->cfg.width / 8;
   if (Hc * Wc > SAMPLER_MAX_CELLS) return fail(-1, "sampler supports at most %d cells", SAMPLER_MAX_CELLS);
   if (h->cfg.n_match > SAMPLER_MAX_CELLS) return fail(-1, "n_match too large for the device sampler");
@@ -2526,7 +2565,8 @@ int ssp_adam_step_scaled(ssp_handle* h, float lr, int step, float grad_scale, vo
 int ssp_handle_set_conv_algo(ssp_handle* h, int algo) {
   if (!h) return fail(-1, "null handle");
   if (algo < 0 || algo > 12 || algo == 4) return fail(-1, "conv algo must be 0..3 or 5..12 (see ssp_set_conv_algo)");
-  if (!SSP_LEGACY_ALGOS && (algo == 2 || algo == 5)) return fail(-1, "conv algo %d is compiled out (-DSSP_LEGACY_ALGOS=1)", algo);
+  if (!SSP_LEGACY_ALGOS && (algo == 2 || algo == 3 || algo == 5 || algo == 7 || algo == 8))
+    return fail(-1, "conv algo %d is compiled out of the shipped library (-DSSP_LEGACY_ALGOS=1)", algo);
   h->conv_algo = algo;
   return 0;
 }
@@ -2975,6 +3015,7 @@ int ssp_op_bn_bwd_bf16(const void* y_dev, const void* dout_dev, const float* gam
                        float* dgamma_dev, float* dbeta_dev, float* dbias_dev, double* sums_dev, int n, int hh, int w, int c, int cs,
                        int relu, int pool, void* stream) {
   if (cs < c || (cs & 3)) return fail(-1, "ssp_op_bn_bwd_bf16: the channel stride must be a multiple of 4 and >= C");
+  if (!relu) return fail(-3, "ssp_op_bn_bwd_bf16: only the ReLU layers run on bf16 tensors");   // (before anything is allocated)
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(sums_dev, 0, 2 * (size_t)c * NREP * sizeof(double), st));
   BnBwdArgs a;
@@ -2985,11 +3026,10 @@ int ssp_op_bn_bwd_bf16(const void* y_dev, const void* dout_dev, const float* gam
   float* k12 = nullptr;
   HIPCHK(hipMallocAsync((void**)&k12, 2 * c * sizeof(float), st));
   a.k12 = k12; a.x = nullptr; a.apool = nullptr; a.beta = nullptr; a.pool_fix = 0;
-  if (relu && pool) CHK((launch_bn_bwd<true, true, uint16_t>(&a, 1, dgamma_dev, dbeta_dev, st)));
-  else if (relu) CHK((launch_bn_bwd<true, false, uint16_t>(&a, 1, dgamma_dev, dbeta_dev, st)));
-  else return fail(-3, "ssp_op_bn_bwd_bf16: only the ReLU layers run on bf16 tensors");
-  HIPCHK(hipFreeAsync(k12, st));
-  return 0;
+  const int rc = pool ? launch_bn_bwd<true, true, uint16_t>(&a, 1, dgamma_dev, dbeta_dev, st)
+                      : launch_bn_bwd<true, false, uint16_t>(&a, 1, dgamma_dev, dbeta_dev, st);
+  HIPCHK(hipFreeAsync(k12, st));   // (on the failure path too)
+  return rc;
 }
 
 // perf-debug hook (tools/archive/ablate_conv.py): disable parts of conv_mfma_kernel / override its grid; 0,0 = product
@@ -3000,7 +3040,8 @@ int ssp_set_conv_algo(int algo) {
                     ", 7 (Winograd, split-bf16 hi + lo operands), 8 (forward split-bf16, backward bf16), 9 (Winograd "
                     "F(2x2,3x3) only: algorithm 1 without F(4x4,3x3) on the large maps), 10 (F(4x4,3x3) wherever legal) or 11 (algorithm 1 "
                     "with the F(3x3,4x4) weight gradient)");
-  if (!SSP_LEGACY_ALGOS && (algo == 2 || algo == 5)) return fail(-1, "conv algo %d is compiled out (-DSSP_LEGACY_ALGOS=1)", algo);
+  if (!SSP_LEGACY_ALGOS && (algo == 2 || algo == 3 || algo == 5 || algo == 7 || algo == 8))
+    return fail(-1, "conv algo %d is compiled out of the shipped library (-DSSP_LEGACY_ALGOS=1)", algo);
   g_default_conv_algo = algo;
   return 0;
 }
@@ -3094,7 +3135,7 @@ int ssp_op_dense_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev
 int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,
                        const int32_t* match_b_dev, const int32_t* nonmatch_b_dev, int b, int hc, int wc, int n_match,
                        int n_non, float* out2_dev, void* stream) {
-  if (b < 1 || b > 64) return fail(-1, "batch out of range");
+  if (b < 1 || b > SSP_MAX_PAIRS) return fail(-1, "batch out of range (1..%d)", SSP_MAX_PAIRS);
   hipStream_t st = (hipStream_t)stream;
   StepAccum* acc = nullptr;
   HIPCHK(hipMallocAsync((void**)&acc, sizeof(StepAccum), st));

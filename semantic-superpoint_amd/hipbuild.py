@@ -53,6 +53,9 @@ def source_id():
         with open(p, "rb") as f:
             h.update(f.read())
         h.update(b"\0")
+    extra = os.environ.get("SSP_HIPCC_EXTRA", "").strip()
+    if extra:  # a library built with extra compiler flags (ablation macros) is NOT the build of the checked-out sources
+        h.update(b"SSP_HIPCC_EXTRA\0" + extra.encode() + b"\0")
     return h.hexdigest()
 
 

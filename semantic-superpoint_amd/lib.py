@@ -146,8 +146,13 @@ def load_library(path=None):
             raise
     lib.ssp_op_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, vp, C.c_size_t, vp]
     lib.ssp_op_conv_wgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, C.c_size_t, vp]
-    lib.ssp_op_conv_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, vp, vp, C.c_size_t, vp]
-    lib.ssp_op_conv_wgrad_bf16.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, i, vp, C.c_size_t, vp]
+    try:  # (the bf16 operators are newer than an A/B library of an older revision, SSP_HIP_LIB)
+        lib.ssp_op_conv_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, vp, vp, C.c_size_t, vp]
+        lib.ssp_op_conv_wgrad_bf16.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp, vp, i, vp, C.c_size_t, vp]
+        lib.ssp_op_bn_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
+    except AttributeError:
+        if os.environ.get("SSP_HIP_LIB") is None:
+            raise
     lib.ssp_debug_buffer.argtypes = [vp, i, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.ssp_debug_conv_knobs.argtypes = [i, i]
     lib.ssp_debug_occupancy.argtypes = [i]
@@ -157,7 +162,6 @@ def load_library(path=None):
     lib.ssp_op_warp_labels.argtypes = [vp, vp, vp, i, i, i, vp]
     lib.ssp_op_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
     lib.ssp_op_bn_bwd_strided.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
-    lib.ssp_op_bn_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
     ep = C.POINTER(SspExportParams)

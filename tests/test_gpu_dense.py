@@ -102,7 +102,7 @@ def test_trainer_plugin_with_dense_loss_config():
     cfg = {"data": {"dataset": "Coco", "semantic": False, "gaussian_label": {"enable": False},
                     "warped_pair": {"enable": True}},
            "model": {"name": "SuperPointNet_gauss2", "params": {}, "batch_size": B, "real_batch_size": B,
-                     "learning_rate": 1e-3, "lambda_loss": 1, "multi_task_loss": True,
+                     "learning_rate": 1e-3, "lambda_loss": 1, "multi_task_loss": True, "detector_loss": {"loss_type": "softmax"},
                      "dense_loss": {"enable": True, "params": {"descriptor_dist": 4, "lambda_d": 800}},
                      "sparse_loss": {"enable": True, "params": {"lamda_d": 1, "dist": "cos", "method": "2d"}}},
            "retrain": True, "reset_iter": True, "train_iter": 10, "validation_interval": 5, "tensorboard_interval": 100,

@@ -280,7 +280,7 @@ def test_trainer_logs_precision_recall():
     cfg = {"data": {"dataset": "Coco", "semantic": False, "gaussian_label": {"enable": False},
                     "warped_pair": {"enable": True}},
            "model": {"name": "SuperPointNet_gauss2", "params": {}, "batch_size": B, "real_batch_size": B,
-                     "learning_rate": 1e-3, "lambda_loss": 1, "multi_task_loss": True,
+                     "learning_rate": 1e-3, "lambda_loss": 1, "multi_task_loss": True, "detector_loss": {"loss_type": "softmax"},
                      "sparse_loss": {"enable": True, "params": {"num_matching_attempts": 1000,
                                                                 "num_masked_non_matches_per_match": 100,
                                                                 "lamda_d": 1, "dist": "cos", "method": "2d"}}},

@@ -472,151 +472,9 @@ def test_conv_algorithms_agree_on_a_training_step(algo):
     _grad_close(out[algo][1], out[1][1], "flat gradient, algo %d vs 1" % algo, **SMALL)  # 64x96
 
 
-def test_bf16_operand_mode_tracks_the_fp32_step():
-    """ssp_set_conv_algo(3) (opt-in, BASELINE configs[3] "bf16 compute / fp32 master"): same step, bf16 matrix-core
-    operands in the 3x3 convolutions and weight gradients.  The losses agree to 1e-4; the GRADIENT is noisy: bf16
-    rounding of the Winograd-transformed operands does not cancel where the exact transforms do (non-centred
-    activations), measured 3 % (heads) to 23-34 % (first layers) relative L2 per tensor (tools/archive/bf16_grad_probe.py).
-    The test pins that envelope: losses within 2 %, flat gradient within 40 % relative L2, cosine similarity > 0.9."""
-    from semantic_superpoint_amd import lib as L
-    from semantic_superpoint_amd.lib import SCALAR_NAMES
-    arch, B, H, W = "SuperPointNet_gauss2", 2, 64, 96
-    sd = C.init_state_dict(arch, seed=21)
-    sample = _to_dev(C.make_synthetic_pair(B, H, W, seed=6, kp_prob=0.005))
-    out = {}
-    try:
-        for a in (1, 3):
-            L.set_conv_algo(a)
-            e = _engine(arch, B, H, W, sd)
-            e.zero_grad()
-            sc = e.pair_step(sample, indices=None, seed=3, train=True)
-            torch.cuda.synchronize()
-            out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), e.grads.clone().cpu().double())
-    finally:
-        L.set_conv_algo(1)
-    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist"):
-        assert abs(out[1][0][name] - out[3][0][name]) < 2e-2 * max(1.0, abs(out[1][0][name])), name
-    g1, g3 = out[1][1], out[3][1]
-    assert float((g1 - g3).norm() / g1.norm()) < 0.4
-    assert float((g1 * g3).sum() / (g1.norm() * g3.norm())) > 0.9
-
-
-@pytest.mark.parametrize("arch", ARCHS)
-def test_bf16x2_mode_tracks_the_fp32_step(arch):
-    """ssp_set_conv_algo(7): split-bf16 (hi + lo) matrix-core operands in the 3x3 convolutions and weight gradients - the
-    accurate reduced-precision mode (the one-term mode 3 loses the gradient: see the test above).  Losses within 1e-3 of the
-    fp32 step; per-tensor gradient relative L2 <= 3e-2 at this small size (measured 1e-2 on one BatchNorm bias: products are
-    rounded at ~1e-5, which flips ~1e-5 of the ReLU gates - the same mechanism as fp32 vs oracle, 5x more flips; at B = 32,
-    240x320 the flips average out: tools/archive/bf16_grad_probe.py), flat gradient <= 1.5e-2."""
-    from semantic_superpoint_amd.lib import SCALAR_NAMES
-    B, H, W = 2, 120, 160
-    sd = C.init_state_dict(arch, seed=21)
-    sample = _to_dev(C.make_synthetic_pair(B, H, W, seed=6, semantic=arch.endswith("ssmall"), kp_prob=0.005))
-    out = {}
-    for a in (1, 7):
-        e = _engine(arch, B, H, W, sd)
-        e.set_conv_algo(a)
-        e.zero_grad()
-        sc = e.pair_step(sample, indices=None, seed=3, train=True)
-        torch.cuda.synchronize()
-        out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), {k: v.clone().cpu().double() for k, v in e.grad_dict().items()},
-                  e.grads.clone().cpu().double())
-    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
-        assert abs(out[1][0][name] - out[7][0][name]) < 1e-3 * max(1.0, abs(out[1][0][name])), name
-    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
-    worst = 0.0
-    for k, g1 in out[1][1].items():
-        if k in noisy or k == "eta":
-            continue
-        rel = float((g1 - out[7][1][k]).norm() / (g1.norm() + 1e-30))
-        worst = max(worst, rel)
-        assert rel <= 3e-2, (k, rel)
-    g1, g7 = out[1][2], out[7][2]
-    assert float((g1 - g7).norm() / g1.norm()) < 1.5e-2  # (measured 0.9e-2 .. 1.1e-2 depending on the sampled pair)
-    print("bf16x2 vs fp32: worst per-tensor gradient rel-L2 %.2e" % worst)
-
-
-@pytest.mark.parametrize("arch", ARCHS)
-def test_mixed_bf16_mode_tracks_the_fp32_step(arch):
-    """ssp_set_conv_algo(8) = `bench.py --dtype bf16`, the BASELINE configs[3] candidate ("bf16 compute / fp32 master"):
-    fp32 forward (the default algorithm's kernels, so every loss equals the fp32 step's), data / weight gradients of the 3x3
-    layers with bf16 matrix-core operands (one part), fp32 storage, accumulation, BatchNorm, master weights and Adam.
-    Against the fp32 step at 120x160, B = 2: losses within 1e-5 (identical forward; the summation order of the atomics
-    differs), every gradient tensor within 2e-2 relative L2 (unbiased 2^-9 operand noise accumulated down the backward chain:
-    measured 1.4e-2 on the first layer's BatchNorm bias; 2.2e-2 while the forward still ran on split-bf16 operands and
-    moved ReLU gates), flat gradient within 1e-2 (measured 6.6e-3 - 7.6e-3), cosine > 0.9999."""
-    from semantic_superpoint_amd.lib import SCALAR_NAMES
-    B, H, W = 2, 120, 160
-    sd = C.init_state_dict(arch, seed=21)
-    sample = _to_dev(C.make_synthetic_pair(B, H, W, seed=6, semantic=arch.endswith("ssmall"), kp_prob=0.005))
-    out = {}
-    for a in (1, 8):
-        e = _engine(arch, B, H, W, sd)
-        e.set_conv_algo(a)
-        e.zero_grad()
-        sc = e.pair_step(sample, indices=None, seed=3, train=True)
-        torch.cuda.synchronize()
-        out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), {k: v.clone().cpu().double() for k, v in e.grad_dict().items()},
-                  e.grads.clone().cpu().double())
-    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
-        assert abs(out[1][0][name] - out[8][0][name]) < 1e-5 * max(1.0, abs(out[1][0][name])), name
-    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
-    worst = (0.0, "")
-    for k, g1 in out[1][1].items():
-        if k in noisy or k == "eta":
-            continue
-        rel = float((g1 - out[8][1][k]).norm() / (g1.norm() + 1e-30))
-        worst = max(worst, (rel, k))
-        assert rel <= 2e-2, (k, rel)
-    g1, g8 = out[1][2], out[8][2]
-    flat = float((g1 - g8).norm() / g1.norm())
-    print("mixed bf16 vs fp32 (%s, 120x160): worst per-tensor rel-L2 %.2e (%s), flat %.2e" % (arch, worst[0], worst[1], flat))
-    assert flat < 1e-2
-    assert float((g1 * g8).sum() / (g1.norm() * g8.norm())) > 0.9999
-
-
-def test_mixed_bf16_mode_at_the_benchmark_size():
-    """The same comparison at B = 32, 240x320 (SSp, configs[3]'s per-GPU shape; measured 1.1e-2 worst per tensor, 2.0e-3
-    flat - 1.4e-2 / 3.7e-3 before the forward went back to fp32): per-tensor <= 1.5e-2, flat <= 3e-3, every scalar within
-    1e-5; then 10 optimizer steps in mode 8 stay finite and lower the loss."""
-    from semantic_superpoint_amd import synth
-    from semantic_superpoint_amd.lib import SCALAR_NAMES, layer_table
-    arch = ARCHS[1]
-    B, H, W = 32, 240, 320
-    sd = synth.default_init_state_dict(layer_table(arch), seed=0)
-    sample = synth.make_pair(B, H, W, _dev(), seed=100, semantic=True)
-    e = _engine(arch, B, H, W, sd)
-    out = {}
-    for a in (1, 8):
-        e.set_conv_algo(a)
-        e.load_state_dict(sd)
-        e.zero_grad()
-        sc = e.pair_step(sample, indices=None, seed=7, train=True)
-        torch.cuda.synchronize()
-        out[a] = (dict(zip(SCALAR_NAMES, sc.cpu().tolist())), {k: v.clone().double() for k, v in e.grad_dict().items()},
-                  e.grads.clone().double())
-    for name in ("loss", "loss_det", "loss_det_warp", "positive_dist", "negative_dist", "loss_sem", "loss_sem_warp"):
-        assert abs(out[1][0][name] - out[8][0][name]) < 1e-5 * max(1.0, abs(out[1][0][name])), name
-    noisy = {c + ".bias" for c, bn, _, _, _ in C.layer_table(arch) if bn is not None}
-    worst = (0.0, "")
-    for k, g1 in out[1][1].items():
-        if k in noisy or k == "eta":
-            continue
-        worst = max(worst, (float((g1 - out[8][1][k]).norm() / (g1.norm() + 1e-30)), k))
-    flat = float((out[1][2] - out[8][2]).norm() / out[1][2].norm())
-    print("mixed bf16 vs fp32 (B = 32, 240x320): worst per-tensor rel-L2 %.2e (%s), flat %.2e" % (worst[0], worst[1], flat))
-    assert worst[0] <= 1.5e-2 and flat <= 3e-3, (worst, flat)
-    e.load_state_dict(sd)
-    first = last = None
-    for it in range(10):
-        e.zero_grad()
-        sc = e.pair_step(sample, indices=None, seed=1000 + it, train=True)
-        e.adam_step(0.001)
-        if it in (0, 9):
-            v = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
-            assert all(np.isfinite(x) for x in v.values()), v
-            first, last = (v, last) if it == 0 else (first, v)
-    assert last["loss"] < first["loss"], (first["loss"], last["loss"])
+# (The bf16-OPERAND experiments inside the fp32 Winograd kernels - conv algorithms 3 / 7 / 8 of rounds 2-3 - were superseded by the bf16
+# path (algorithm 12, tests/test_gpu_bf16_path.py) and are compiled out of the shipped library (-DSSP_LEGACY_ALGOS=1 brings them back);
+# their tests left with them: git history of this file at round 4, results in PERF_LOG.md section 10.)
 
 
 @pytest.mark.parametrize("n_classes", [21, 150])
@@ -644,3 +502,30 @@ def test_segmentation_head_with_another_class_count(n_classes):
     for k in ("convSout.weight", "convSout.bias", "convDS.weight", "bnS1.weight", "convPb.weight", "convDb.weight",
               "down3.mpconv.1.conv.3.weight"):
         _grad_close(gd[k].cpu(), tsd[k].grad, k, **SMALL)
+
+
+def test_pair_step_with_more_than_64_pairs():
+    """B = 80 pairs in ONE ssp_pair_step call (the per-image accumulators of the sparse descriptor loss were fixed 64-entry arrays
+    up to round 4; SSP_MAX_PAIRS = 256 now): the scalars against the oracle fed with the device-sampled indices."""
+    from semantic_superpoint_amd.lib import SCALAR_NAMES
+    arch, B, H, W = ARCHS[0], 80, 32, 48
+    sd = C.init_state_dict(arch, seed=2)
+    sample = C.make_synthetic_pair(B, H, W, seed=3, kp_prob=0.02)
+    e = _engine(arch, B, H, W, sd, n_match=200, n_non=20)
+    e.zero_grad()
+    sc = e.pair_step(_to_dev(sample), indices=None, seed=11, train=True).clone()
+    torch.cuda.synchronize()
+    ma, mb, nm = (t.cpu().long() for t in e._last_idx)
+    Wc = W // 8
+    idx = [{"uv_a": torch.stack((ma[b] % Wc, ma[b] // Wc), 1).float(), "uv_b": torch.stack((mb[b] % Wc, mb[b] // Wc), 1).float(),
+            "nm_b": nm[b]} for b in range(B)]
+    tr = C.Trainer(arch, sd, lr=1e-3, n_match=200, n_non=20)
+    tr.real_batch_size = 10 ** 9
+    tr.train_val_sample(sample, n_iter=0, train=True, indices=idx)
+    sc = dict(zip(SCALAR_NAMES, sc.cpu().tolist()))
+    for k in ("loss", "loss_det", "loss_det_warp", "loss_desc", "positive_dist", "negative_dist"):
+        ref = tr.scalar_dict[k]
+        assert abs(sc[k] - ref) < TOL * max(1.0, abs(ref)), (k, sc[k], ref)
+    gd = e.grad_dict()
+    for k in ("convDb.weight", "convPb.weight", "bnDa.weight"):
+        _grad_close(gd[k].cpu(), tr.last_grads[k], k, **TINY)

@@ -11,8 +11,6 @@ python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_ssp.json 2> $O/bench_ssp.er
 python3 $R/bench.py --arch sp --steps 20 --warmup 5 --no-cpu-baseline --no-export > $O/bench_sp.json 2>/dev/null
 python3 $R/bench.py --steps 20 --warmup 5 $Q --no-roofline --graph > $O/bench_ssp_graph.json 2>/dev/null
 python3 $R/bench.py --steps 20 --warmup 5 $Q --no-roofline > $O/bench_ssp_eager.json 2>/dev/null
-python3 $R/bench.py --conv-algo 8 --steps 20 --warmup 5 $Q > $O/bench_ssp_mixed_bf16.json 2>/dev/null
-python3 $R/bench.py --arch sp --conv-algo 8 --steps 20 --warmup 5 $Q > $O/bench_sp_mixed_bf16.json 2>/dev/null
 python3 $R/bench.py --conv-algo 0 --steps 10 --warmup 3 $Q > $O/bench_ssp_direct.json 2>/dev/null
 python3 $R/bench.py --conv-algo 9 --steps 20 --warmup 5 $Q > $O/bench_ssp_f2x2_only.json 2>/dev/null
 python3 $R/bench.py --conv-algo 11 --steps 20 --warmup 5 $Q > $O/bench_ssp_wgrad_f3x3_4x4.json 2>/dev/null
