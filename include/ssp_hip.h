@@ -37,7 +37,7 @@ enum { SSP_NREP = 32 }; /* replicas of each fp64 statistics accumulator (spreads
 typedef struct {
   int arch;      /* SSP_ARCH_* */
   int n_classes; /* 133 for the ssmall seg head; ignored for gauss2 */
-  int max_batch; /* largest N of any forward (1..1024); ssp_pair_step additionally requires batch <= 256
+  int max_batch; /* largest N of any forward (1..1024); ssp_pair_step additionally requires batch <= 128
                     (per-image accumulator arrays of the sparse descriptor loss, SSP_MAX_PAIRS) */
   int height;    /* H, multiple of 8 */
   int width;     /* W, multiple of 8 */

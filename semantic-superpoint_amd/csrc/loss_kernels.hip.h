@@ -59,7 +59,7 @@ __device__ __forceinline__ float block_sum_of_waves(float v, float* smem4) {
 }
 
 // Pairs per ssp_pair_step call (per-image accumulators of the sparse descriptor loss below; ssp_config.max_batch bounds a forward)
-constexpr int SSP_MAX_PAIRS = 256;
+constexpr int SSP_MAX_PAIRS = 128;   // (StepAccum stays below the 64 KiB scratch contract of the ssp_op_* loss operators)
 constexpr int SSP_DENSE_REPS = 1024;   // replica slots the dense descriptor loss spreads its three sums over (<= SSP_MAX_PAIRS * 16)
 // Device-side accumulators / coefficients of one pair step (doubles for order-insensitive sums).
 struct StepAccum {
@@ -75,6 +75,8 @@ struct StepAccum {
                                         // slots of pos_sum / neg_sum hold the rest)
   float coef_det, coef_pos, coef_neg, coef_sem;  // d total / d (loss_det sum), d/d pos mean, d/d neg mean, d/d sem sum
 };
+
+static_assert(sizeof(StepAccum) <= 65536, "the ssp_op_* loss operators carve a StepAccum out of a 64 KiB scratch");
 
 // ---- cell masks: one wave per cell; lane = dy*8+dx --------------------------------------------
 __global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict__ mask2d, float* __restrict__ cellmask,

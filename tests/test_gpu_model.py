@@ -506,7 +506,7 @@ def test_segmentation_head_with_another_class_count(n_classes):
 
 def test_pair_step_with_more_than_64_pairs():
     """B = 80 pairs in ONE ssp_pair_step call (the per-image accumulators of the sparse descriptor loss were fixed 64-entry arrays
-    up to round 4; SSP_MAX_PAIRS = 256 now): the scalars against the oracle fed with the device-sampled indices."""
+    up to round 4; SSP_MAX_PAIRS = 128 now): the scalars against the oracle fed with the device-sampled indices."""
     from semantic_superpoint_amd.lib import SCALAR_NAMES
     arch, B, H, W = ARCHS[0], 80, 32, 48
     sd = C.init_state_dict(arch, seed=2)
