@@ -37,7 +37,7 @@ static int launch_conv_bf16_ws_t(const ConvBArgs& a, int nblocks, hipStream_t st
   auto kern = conv_bf16_ws_kernel<IN_MODE, NC2>;
   if (attr_once.need())
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ConvWsGeom::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), ConvWsGeom::LDS_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(conv_ws_threads<IN_MODE>()), ConvWsGeom::LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }

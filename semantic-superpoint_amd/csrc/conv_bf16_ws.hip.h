@@ -20,6 +20,13 @@
 
 #include "conv_bf16.hip.h"
 
+#ifndef CONVB_WS_ABL
+#define CONVB_WS_ABL 0   // compile-time perf ablations of the INNER loops (SSP_HIPCC_EXTRA=-DCONVB_WS_ABL=n): 1 halo loads out of bounds
+                         // (zeros, no HBM reads), 128 no staging arithmetic, 256 no LDS writes of the staging.  The whole-phase knobs
+                         // 2 (no staging), 4 (no copy-out), 8 (no MFMA loop) stay runtime bits of SSP_CONVB_ABLATE: a uniform test per
+                         // slot in the staging loop cost a branch per slot (round 5)
+#endif
+
 namespace sspk {
 
 // packed fp32 arithmetic WITHOUT `volatile` (pk_math.hip.h's forms are volatile: the scheduler treats a side-effecting asm as a
@@ -43,11 +50,20 @@ struct ConvWsGeom {
   static constexpr int LDS_BYTES = 2 * W_BYTES + 2 * H_BYTES + O_BYTES;
 };
 
+// Threads per workgroup.  The data gradient (IN_MODE 0) runs 4 consumer + 4 producer waves.  The forward (IN_MODE 1) runs THREE
+// roles, 4 + 4 + 4 waves: its producers were a single latency-bound instruction stream per SIMD (measured WITHOUT the MFMA loop:
+// 4300-4760 cycles per stage for ~320 instructions - loads, LDS round trips and stores of the halo staging and of the copy-out wait
+// for each other; profiles/r05_bf16_ws_role_split.txt), so the copy-out / statistics / pooled copy of a finished unit moved to a
+// third wave per SIMD that runs beside the staging wave.
+template <int IN_MODE>
+constexpr int conv_ws_threads() { return IN_MODE == 1 ? 768 : 512; }
+
 template <int IN_MODE, bool NC2>
-__global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a) {
+__global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_kernel(const ConvBArgs a) {
   using G = ConvWsGeom;
   constexpr int HT = G::HT, PAD = 1;
   constexpr bool DMA = IN_MODE == 0;   // the data gradient stages nothing: its halo goes global -> LDS directly (buffer_load ... lds)
+  constexpr bool SPLIT = IN_MODE == 1; // waves 4-7 stage, waves 8-11 copy out
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* const sW = smem_b;
   unsigned char* const sH = smem_b + 2 * G::W_BYTES;
@@ -197,7 +213,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
   }
 
   // =========================== producers ===========================
-  const int ptid = tid - 256, pwave = wave - 4;
+  const bool copier = SPLIT && wave >= 8;                 // (scalar) the copy-out role of the three-role form
+  const int ptid = (tid - 256) & 255, pwave = (wave - 4) & 3;
   const int part = ptid & 3;
   constexpr int NHS = (HT * HT * 4 + 255) / 256;   // 6 (the last round is partly empty)
   const int hs_lds0 = (ptid >> 2) * CB_PS + part * 16;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     unsigned pad = 0;
 #pragma unroll
     for (int i = 0; i < NHS; ++i) {
-      hv[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (a.ablate & 1) ? OOB : hs_g[i], ld_chunk * CB_KC * 2, 0));
+      hv[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (CONVB_WS_ABL & 1) ? OOB : hs_g[i], ld_chunk * CB_KC * 2, 0));
       pad |= (hs_g[i] == OOB ? 1u : 0u) << i;
     }
     hv_pad[S] = pad;
@@ -320,27 +337,38 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
       load_affine(1, aff_view, 1);
     }
     auto run = [&](auto BORDER) __attribute__((always_inline)) {   // (one straight-line body per variant: a uniform test inside the
-#pragma unroll                                                      //  slot loop became a branch per slot)
-      for (int i = 0; i < NHS; ++i) {
-        if ((ptid >> 2) + 64 * i >= HT * HT) continue;
-        u32x4 o;
-        if (IN_MODE == 1 && !(a.ablate & 128)) {
+      // slot loop became a branch per slot - the inner-loop ablations are compile-time for the same reason).  Two slots' values
+      // are computed before their LDS writes: 8 independent 5-instruction chains for the scheduler instead of one chain per slot
+      // (three or six at once spilled registers in the 64-channel form)
+      constexpr int GS = 2;
+      static_assert(NHS % GS == 0, "whole groups of slots");
+#pragma unroll
+      for (int g3 = 0; g3 < NHS; g3 += GS) {
+      u32x4 o[NHS];
+#pragma unroll
+      for (int i = g3; i < g3 + GS; ++i) {
+        if (IN_MODE == 1 && !(CONVB_WS_ABL & 128)) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const f32x2 z = ws_pk_fma(f32x2{bf16_lo(hv[S][i][e]), bf16_hi(hv[S][i][e])}, sc2[S][e], sh2[S][e]);
             const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(z[0], z[1])), s16x2{0, 0});
-            o[e] = __builtin_bit_cast(uint32_t, r);
+            o[i][e] = __builtin_bit_cast(uint32_t, r);
           }
           if (decltype(BORDER)::value) {   // padding is zero in the ACTIVATED domain
             const bool pad = (hv_pad[S] >> i) & 1u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pad ? 0u : o[e];
+            for (int e = 0; e < 4; ++e) o[i][e] = pad ? 0u : o[i][e];
           }
         } else {
-          o = hv[S][i];
+          o[i] = hv[S][i];
         }
-        if (!(a.ablate & 256)) *reinterpret_cast<u32x4*>(dst + i * 64 * CB_PS) = o;
-        else asm volatile("" :: "v"(o));
+      }
+#pragma unroll
+      for (int i = g3; i < g3 + GS; ++i) {
+        if (i == NHS - 1 && (ptid >> 2) + 64 * i >= HT * HT) continue;   // (only the last round is partly empty: 6 x 64 slots >= 324)
+        if (!(CONVB_WS_ABL & 256)) *reinterpret_cast<u32x4*>(dst + i * 64 * CB_PS) = o[i];
+        else asm volatile("" :: "v"(o[i]));
+      }
       }
     };
     if ((hv_view[S] & 256) != 0) run(std::true_type{}); else run(std::false_type{});   // (uniform) border tile of the image?
@@ -497,6 +525,29 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     }
   };
 
+  if constexpr (SPLIT) {
+    if (copier) {
+      // ---- copy-out role (waves 8-11 of the forward): its own unit walker, one barrier per stage like everybody else; the unit
+      // that finished with stage s - 1 leaves the LDS tile during stage s ----
+      int co_vc = ld_vc, co_n = ld_n, co_ty = ld_ty, co_tx = ld_tx;
+      __syncthreads();   // (the stagers' prologue)
+      int cs = 0;
+      for (int s = 0; s < nstages; ++s) {
+        if (cs == 0 && s > 0) {
+          copy_out(co_vc, co_n, (co_ty << 16) | co_tx);
+          co_tx += d_tx; int c = co_tx >= a.tiles_x ? 1 : 0; co_tx -= c ? a.tiles_x : 0;
+          co_ty += d_ty + c; c = co_ty >= a.tiles_y ? 1 : 0; co_ty -= c ? a.tiles_y : 0;
+          co_n += d_n + c; c = co_n >= a.N ? 1 : 0; co_n -= c ? a.N : 0;
+          co_vc += d_vc + c;
+        }
+        if (++cs == a.nchunks) cs = 0;
+        __syncthreads();
+      }
+      copy_out(co_vc, co_n, (co_ty << 16) | co_tx);
+      if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
+      return;
+    }
+  }
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   const bool tr = a.trace != nullptr && blockIdx.x == 0;   // (perf-debug: cycle sums of [copy-out, staging, issue, barrier, load wait, advance])
@@ -512,7 +563,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
 #pragma unroll
       for (int i = 0; i < NHS; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (ldsp)(sH + Q * G::H_BYTES + (256 * i + 64 * pwave) * 16), 16,
-                                                 (a.ablate & 1) ? OOB : hs_g[i], ld_chunk * CB_KC * 2, 0, 0);
+                                                 (CONVB_WS_ABL & 1) ? OOB : hs_g[i], ld_chunk * CB_KC * 2, 0, 0);
     };
     setup_unit();
     issue_dma(P0{});
@@ -569,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
   auto iteration = [&](int s, auto PAR) __attribute__((always_inline)) {   // PAR = parity of stage s + 1
     constexpr int Q = decltype(PAR)::value;
     if (tr) t0 = __builtin_readcyclecounter();
-    if (cs_chunk == 0 && s > 0) { if (NC2) copy_out(st2_vc, st2_n, st2_yx); else copy_out(st1_vc, st1_n, st1_yx); }
+    if (!SPLIT && cs_chunk == 0 && s > 0) { if (NC2) copy_out(st2_vc, st2_n, st2_yx); else copy_out(st1_vc, st1_n, st1_yx); }
     if (++cs_chunk == a.nchunks) cs_chunk = 0;
     if (tr) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; }
     if (s + 1 < nstages) {
@@ -608,8 +659,10 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_ws_kernel(const ConvBArgs a)
     for (int k = 0; k < 6; ++k) a.trace[wave * 8 + k] = tc[k];
     a.trace[wave * 8 + 7] = nstages;
   }
-  copy_out(st1_vc, st1_n, st1_yx);
-  if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
+  if constexpr (!SPLIT) {
+    copy_out(st1_vc, st1_n, st1_yx);
+    if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
+  }
 }
 
 }  // namespace sspk
