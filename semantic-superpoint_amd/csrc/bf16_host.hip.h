@@ -9,6 +9,10 @@ struct ConvBCall {
   const float* in_scale[2] = {nullptr, nullptr}; const float* in_shift[2] = {nullptr, nullptr};
   double* stats[2] = {nullptr, nullptr};
   uint16_t* pool_out[2] = {nullptr, nullptr}; const float* pool_gamma = nullptr;
+  const uint16_t* bnr_t[2] = {nullptr, nullptr};   // fused BatchNorm-backward sums of the layer below (ConvBArgs::bnr_*)
+  const float* bnr_scale[2] = {nullptr, nullptr}; const float* bnr_shift[2] = {nullptr, nullptr};
+  const float* bnr_mean[2] = {nullptr, nullptr}; const float* bnr_invstd[2] = {nullptr, nullptr};
+  double* bnr_sums[2] = {nullptr, nullptr};
   int nviews = 1, N = 0, H = 0, W = 0, ks = 3, in_mode = 0;
   bool in_f32 = false, out_f32 = false;
 };
@@ -42,11 +46,21 @@ static int launch_conv_bf16_ws_t(const ConvBArgs& a, int nblocks, hipStream_t st
   return 0;
 }
 
+// whether launch_conv_bf16 runs this call on the wave-specialised kernel (the form that can carry the fused BatchNorm-backward sums)
+static bool launch_conv_bf16_is_ws(const ConvBCall& c) {
+  static const int ws_env = getenv("SSP_CONVB_WS") ? atoi(getenv("SSP_CONVB_WS")) : 1;
+  const int nchunks = convb_nchunks(c.cin);
+  return ws_env != 0 && c.ks == 3 && !c.in_f32 && !c.out_f32 && nchunks >= 2 && nchunks % 2 == 0 && c.cin % CB_KC == 0 &&
+         c.in_mode == 0 && c.bias == nullptr && c.out_co == 0 && c.out_cs == c.cout && !c.stats[0];
+}
+
 static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   ConvBArgs a;
   for (int k = 0; k < 2; ++k) {
     a.in[k] = c.in[k]; a.out[k] = c.out[k]; a.in_scale[k] = c.in_scale[k]; a.in_shift[k] = c.in_shift[k];
     a.stats[k] = c.stats[k]; a.pool_out[k] = c.pool_out[k];
+    a.bnr_t[k] = c.bnr_t[k]; a.bnr_scale[k] = c.bnr_scale[k]; a.bnr_shift[k] = c.bnr_shift[k]; a.bnr_mean[k] = c.bnr_mean[k];
+    a.bnr_invstd[k] = c.bnr_invstd[k]; a.bnr_sums[k] = c.bnr_sums[k];
   }
   a.wpk = c.wpk; a.bias = c.bias; a.pool_gamma = c.pool_gamma;
   a.nviews = c.nviews; a.N = c.N; a.H = c.H; a.W = c.W;
@@ -81,7 +95,11 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   if (grid_env > 0) nblocks = grid_env;
   // the 3x3 layers with bf16 tensors at both ends: wave-specialised kernel, one 8-wave workgroup per CU (SSP_CONVB_WS=0: perf-debug A/B)
   static const int ws_env = getenv("SSP_CONVB_WS") ? atoi(getenv("SSP_CONVB_WS")) : 1;
-  if (ws_env != 0 && c.ks == 3 && !c.in_f32 && !c.out_f32 && a.nchunks >= 2 && a.nchunks % 2 == 0 && c.cin % CB_KC == 0) {
+  const bool ws_ok = ws_env != 0 && c.ks == 3 && !c.in_f32 && !c.out_f32 && a.nchunks >= 2 && a.nchunks % 2 == 0 && c.cin % CB_KC == 0 &&
+                     !(c.in_mode == 0 && c.bias != nullptr);   // (the staging-free form is the data gradient: no bias path)
+  if (c.bnr_t[0] != nullptr && !(ws_ok && c.in_mode == 0 && c.out_co == 0 && c.out_cs == c.cout && !c.stats[0]))
+    return fail(-3, "bf16 conv: the fused BatchNorm-backward sums ride the wave-specialised data-gradient form with a dense output only");
+  if (ws_ok) {
     int nb = (int)std::min<long>((long)n_cu, cdiv(units, 8) * 8L) / 8 * 8;
     nb = std::max(nb, 8);
     if (grid_env > 0) nb = grid_env;

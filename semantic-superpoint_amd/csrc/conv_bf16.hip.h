@@ -49,6 +49,13 @@ struct ConvBArgs {
   double* stats[2];          // [NREP][2 Cout] sum, sum of squares of the stored output, or nullptr
   uint16_t* pool_out[2];     // [N,H/2,W/2,Cout] raw pooled copy (per-channel max for gamma >= 0, min for gamma < 0) or nullptr
   const float* pool_gamma;
+  // Fused BatchNorm-backward reduction (conv_bf16_ws_kernel as a DATA GRADIENT only): the output of this launch is dOut of the layer
+  // below, whose raw (pooled) bf16 output t sits at the same pixels.  The copy-out accumulates that layer's pass-1 sums of the
+  // STORED values, S1 = sum dz, S2 = sum dz xhat with dz = [t scale + shift > 0] dOut, xhat = (t - mean) invstd, into bnr_sums
+  // ([NREP][2 Cout] doubles) - the work of bn_bwd_kernel<RELU, false, false, bf16> without its launch and its read of dOut.
+  const uint16_t* bnr_t[2];  // [N,H,W,Cout] or nullptr (no fusion)
+  const float* bnr_scale[2]; const float* bnr_shift[2]; const float* bnr_mean[2]; const float* bnr_invstd[2];
+  double* bnr_sums[2];
   int nviews, N, H, W;
   int Cin, in_cs, in_co;
   int Cout, out_cs, out_co;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
         for (int k = 0; k < 8; ++k) {
           const int lp = (tid >> 3) + 32 * k;
           u32x4 v = *reinterpret_cast<const u32x4*>(sO + lp * CB_OS_BF16 + item * 16);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_out, vo, rstep * k, 0);
+          ssp_store_b128(v, rsrc_out, vo, rstep * k);
           if (do_stats) {
             const bool ok = col_ok && (full || ty0 + row0 + 2 * k < a.H);
 #pragma unroll

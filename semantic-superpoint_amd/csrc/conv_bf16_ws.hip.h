@@ -37,6 +37,16 @@ __device__ __forceinline__ f32x2 ws_pk_fma(f32x2 x, f32x2 y, f32x2 z) {
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
   return d;
 }
+__device__ __forceinline__ f32x2 ws_pk_mul(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 ws_pk_sub(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
 __device__ __forceinline__ void ws_pk_acc(f32x2& sum, f32x2& sumsq, f32x2 x) {
   asm("v_pk_add_f32 %0, %0, %1" : "+v"(sum) : "v"(x));
   asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(sumsq) : "v"(x));
@@ -56,14 +66,14 @@ struct ConvWsGeom {
 // for each other; profiles/r05_bf16_ws_role_split.txt), so the copy-out / statistics / pooled copy of a finished unit moved to a
 // third wave per SIMD that runs beside the staging wave.
 template <int IN_MODE>
-constexpr int conv_ws_threads() { return IN_MODE == 1 ? 768 : 512; }
+constexpr int conv_ws_threads() { return 768; }
 
 template <int IN_MODE, bool NC2>
 __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_kernel(const ConvBArgs a) {
   using G = ConvWsGeom;
   constexpr int HT = G::HT, PAD = 1;
   constexpr bool DMA = IN_MODE == 0;   // the data gradient stages nothing: its halo goes global -> LDS directly (buffer_load ... lds)
-  constexpr bool SPLIT = IN_MODE == 1; // waves 4-7 stage, waves 8-11 copy out
+  constexpr bool SPLIT = true;         // waves 4-7 stage / issue the LDS-DMA, waves 8-11 copy out
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* const sW = smem_b;
   unsigned char* const sH = smem_b + 2 * G::W_BYTES;
@@ -96,17 +106,17 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
     // buffer_load ... lds can write); the swizzle depends on the slot, so every (tile, tap, k-step) has its own address register -
     // computed once, they do not depend on the unit.
     int boff[2];
-    int baddr[DMA ? 2 : 1][DMA ? 9 : 1][DMA ? 2 : 1];
+    int baddr[DMA ? 2 : 1][DMA ? 9 : 1];   // k-step 0; k-step 1 = the same slot's item ^ 2, i.e. address ^ 32 (one v_xor per read instead
+                                          // of 18 more address registers: the three-role form lives on 168 registers)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       boff[nt] = ((4 * wave + 2 * nt + pr) * HT + pc) * CB_PS + lg * 16;
       if constexpr (DMA) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
+          {
             const int sl = (4 * wave + 2 * nt + pr + tap / 3) * HT + pc + tap % 3;
-            baddr[nt][tap][ks] = sl * 64 + (((ks * 2 + lg) ^ ((sl >> 2) & 3)) << 4);
+            baddr[nt][tap] = sl * 64 + ((lg ^ ((sl >> 2) & 3)) << 4);
           }
       }
     }
@@ -128,14 +138,17 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int vc = u / T;
-        if (vc != bias_vc) { bias_vc = vc; cb_load_bias(a.bias, a.Cout, vc % a.ncob, lg, bias4); }   // (a few times per launch)
+        if constexpr (!DMA) {   // (the data-gradient form carries no bias: launch_conv_bf16 sends a biased in_mode-0 call to the generic kernel)
+          const int vc = u / T;
+          if (vc != bias_vc) { bias_vc = vc; cb_load_bias(a.bias, a.Cout, vc % a.ncob, lg, bias4); }   // (a few times per launch)
+        }
       }
       const unsigned char* const pW = sW + Q * G::W_BYTES + aoff;
       const unsigned char* const pH = sH + Q * G::H_BYTES;
       // operands run PF k-steps ahead of the MFMAs that use them: with ONE consumer wave per SIMD nothing else hides the
       // ds_read latency
-      constexpr int PF = 2;
+      constexpr int PF = DMA ? 1 : 2;   // (the staging-free form carries 18 operand address registers: one set less keeps it at 168; round 4
+                                        //  measured no difference between 1, 2 and 3 k-steps of prefetch)
       s16x8 fa[PF + 1][2], fb[PF + 1][2];
       auto fetch = [&](int step, s16x8 (&qa)[2], s16x8 (&qb)[2]) __attribute__((always_inline)) {
         const int tap = step >> 1, ks = step & 1;
@@ -143,8 +156,8 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
         qa[0] = *reinterpret_cast<const s16x8*>(pW + ((tap * 2 + ks) * 2 + 0) * 1024);
         qa[1] = *reinterpret_cast<const s16x8*>(pW + ((tap * 2 + ks) * 2 + 1) * 1024);
         if constexpr (DMA) {
-          qb[0] = *reinterpret_cast<const s16x8*>(pH + baddr[0][tap][ks]);
-          qb[1] = *reinterpret_cast<const s16x8*>(pH + baddr[1][tap][ks]);
+          qb[0] = *reinterpret_cast<const s16x8*>(pH + (baddr[0][tap] ^ (ks << 5)));
+          qb[1] = *reinterpret_cast<const s16x8*>(pH + (baddr[1][tap] ^ (ks << 5)));
         } else {
           qb[0] = *reinterpret_cast<const s16x8*>(pH + boff[0] + (dy * HT + dx) * CB_PS + ks * 32);
           qb[1] = *reinterpret_cast<const s16x8*>(pH + boff[1] + (dy * HT + dx) * CB_PS + ks * 32);
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
               }
           }
         };
-        if (a.bias != nullptr) hand_over(std::true_type{}); else hand_over(std::false_type{});
+        if (!DMA && a.bias != nullptr) hand_over(std::true_type{}); else hand_over(std::false_type{});
         chunk = 0; u += nslot;
       } else {
         ++chunk;
@@ -410,13 +423,15 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
   // statistics of the stored values: per-thread sums of this thread's 8 channels (item = ptid & 7), flushed per (view, cob)
   const int item = ptid & 7;
   f32x2 ps[4], pq[4];
+  f32x2 b_sc[4], b_sh[4], b_mu[4], b_is[4];   // (fused BatchNorm-backward sums: parameters of this thread's 8 channels)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) ps[e] = pq[e] = f32x2{0.f, 0.f};
+  for (int e = 0; e < 4; ++e) ps[e] = pq[e] = b_sc[e] = b_sh[e] = b_mu[e] = b_is[e] = f32x2{0.f, 0.f};
   int st_key = -1, pg_key = -1;
   uint32_t pg_neg[4] = {0u, 0u, 0u, 0u};
+  const bool do_bnr = DMA && a.bnr_t[0] != nullptr;   // (uniform) fused BatchNorm-backward sums of the layer below (data gradient)
   auto flush_stats = [&](int key) __attribute__((always_inline)) {
     const int view = key >= a.ncob ? 1 : 0, cob = key - view * a.ncob;
-    double* const p_stats = a.stats[view];
+    double* const p_stats = do_bnr ? a.bnr_sums[view] : a.stats[view];
     float v[16];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[2 * e] = ps[e][0]; v[2 * e + 1] = ps[e][1]; v[8 + 2 * e] = pq[e][0]; v[9 + 2 * e] = pq[e][1]; ps[e] = pq[e] = f32x2{0.f, 0.f}; }
@@ -432,8 +447,8 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
       for (int e = 0; e < 8; ++e) {
         const int co = cob * CB_NB + item * 8 + e;
         if (co < a.Cout) {
-          acc_add_stats(st + co, (double)v[e]);
-          acc_add_stats(st + a.Cout + co, (double)v[8 + e]);
+          acc_add_stats_or_grad(st + co, (double)v[e], do_bnr);
+          acc_add_stats_or_grad(st + a.Cout + co, (double)v[8 + e], do_bnr);
         }
       }
     }
@@ -445,11 +460,22 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
     const int view = vc >= a.ncob ? 1 : 0, cob = vc - view * a.ncob;
     const int ty0 = (yx >> 16) * CB_T, tx0 = (yx & 0xffff) * CB_T;
     const bool do_stats = a.stats[0] != nullptr;
-    if (do_stats && vc != st_key) {
+    const int co0 = cob * CB_NB + item * 8;
+    if ((do_stats || do_bnr) && vc != st_key) {
       if (st_key >= 0) flush_stats(st_key);
       st_key = vc;
+      if (do_bnr) {   // the layer-below parameters of this thread's 8 channels (a few times per launch)
+        const bool okc = co0 < a.Cout;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = okc ? co0 + 2 * e : 0;
+          b_sc[e] = f32x2{a.bnr_scale[view][c], a.bnr_scale[view][c + 1]};
+          b_sh[e] = f32x2{a.bnr_shift[view][c], a.bnr_shift[view][c + 1]};
+          b_mu[e] = f32x2{a.bnr_mean[view][c], a.bnr_mean[view][c + 1]};
+          b_is[e] = f32x2{a.bnr_invstd[view][c], a.bnr_invstd[view][c + 1]};
+        }
+      }
     }
-    const int co0 = cob * CB_NB + item * 8;
     const bool ch_ok = co0 < a.Cout;   // (Cout % 8 == 0: host-checked)
     const int col = (ptid >> 3) & 15, row0 = ptid >> 7;
     unsigned char* const p_out = reinterpret_cast<unsigned char*>(a.out[view]);
@@ -460,10 +486,20 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
     const int rstep = 2 * a.W * a.out_cs * 2;
     const bool full = ty0 + CB_T <= a.H;
     const bool whole = full && tx0 + CB_T <= a.W && (cob + 1) * CB_NB <= a.Cout;   // (uniform) every element of the tile is stored
-    auto rows = [&](auto WHOLE, auto STATS) __attribute__((always_inline)) {   // (both uniform: straight-line code per variant)
+    // fused BatchNorm-backward sums: the layer-below tensor t at this thread's pixels (same channel block, dense [N,H,W,Cout])
+    __amdgpu_buffer_rsrc_t rsrc_t = rsrc_out;
+    if (do_bnr) rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.bnr_t[view]) + (size_t)n * a.H * a.W * a.Cout, 0,
+                                                            (unsigned)a.H * a.W * a.Cout * 2u, 0x00020000);
+    const unsigned vo_t = col_ok ? (unsigned)((((ty0 + row0) * a.W + tx0 + col) * a.Cout + co0) * 2) : OOB;
+    const int rstep_t = 2 * a.W * a.Cout * 2;
+    auto rows = [&](auto WHOLE, auto STATS, auto BNR) __attribute__((always_inline)) {   // (all uniform: straight-line code per variant)
 #pragma unroll
       for (int kb = 0; kb < 8; kb += 4) {   // four LDS reads in flight before the first use
-        u32x4 v[4];
+        u32x4 v[4], tv[4];
+        if (decltype(BNR)::value) {   // (issued first: an L2 / HBM round trip)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, vo_t, rstep_t * (kb + k), 0));
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int lp = (ptid >> 3) + 32 * (kb + k);
@@ -471,7 +507,20 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          __builtin_amdgcn_raw_buffer_store_b128(v[k], rsrc_out, vo, rstep * (kb + k), 0);   // rows below the image fall off the descriptor
+          ssp_store_b128(v[k], rsrc_out, vo, rstep * (kb + k));   // rows below the image fall off the descriptor
+          if (decltype(BNR)::value) {
+            const bool ok = decltype(WHOLE)::value || (col_ok && (full || ty0 + row0 + 2 * (kb + k) < a.H));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t w = ok ? v[k][e] : 0u, yb = tv[k][e];
+              const f32x2 d2 = {bf16_lo(w), bf16_hi(w)}, y2 = {bf16_lo(yb), bf16_hi(yb)};
+              const f32x2 z2 = ws_pk_fma(y2, b_sc[e], b_sh[e]);
+              const f32x2 dz = {z2[0] > 0.f ? d2[0] : 0.f, z2[1] > 0.f ? d2[1] : 0.f};
+              const f32x2 xh = ws_pk_mul(ws_pk_sub(y2, b_mu[e]), b_is[e]);
+              asm("v_pk_add_f32 %0, %0, %1" : "+v"(ps[e]) : "v"(dz));
+              asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pq[e]) : "v"(dz), "v"(xh));
+            }
+          }
           if (decltype(STATS)::value) {
             const bool ok = decltype(WHOLE)::value || (col_ok && (full || ty0 + row0 + 2 * (kb + k) < a.H));
 #pragma unroll
@@ -483,8 +532,11 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
         }
       }
     };
-    if (do_stats) { if (whole) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
-    else rows(std::true_type{}, std::false_type{});
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (do_stats) { if (whole) rows(T_{}, T_{}, F_{}); else rows(F_{}, T_{}, F_{}); }
+    else if (do_bnr) { if (whole) rows(T_{}, F_{}, T_{}); else rows(F_{}, F_{}, T_{}); }
+    else rows(T_{}, F_{}, F_{});
     if (a.pool_out[0] != nullptr && ch_ok) {
       // raw 2x2-pooled copy: per-channel max (gamma >= 0) or min (gamma < 0) of the window (see conv_bf16_kernel).  bf16 pairs are
       // compared as PACKED HALVES (v_pk_max_f16 / v_pk_min_f16): both formats are sign-magnitude with the exponent above the
@@ -544,7 +596,7 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
         __syncthreads();
       }
       copy_out(co_vc, co_n, (co_ty << 16) | co_tx);
-      if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
+      if ((a.stats[0] != nullptr || do_bnr) && st_key >= 0) flush_stats(st_key);
       return;
     }
   }
@@ -580,7 +632,7 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
         fetch_weights(ld_cob * a.nchunks + ld_chunk, Q);
       }
       if (tr) { t1 = __builtin_readcyclecounter(); tc[2] += t1 - t0; }
-      if (cs_chunk == 0 && s > 0) copy_out(st1_vc, st1_n, st1_yx);   // the unit that finished with stage s - 1
+      if (!SPLIT && cs_chunk == 0 && s > 0) copy_out(st1_vc, st1_n, st1_yx);   // the unit that finished with stage s - 1
       if (++cs_chunk == a.nchunks) cs_chunk = 0;
       if (tr) { t0 = __builtin_readcyclecounter(); tc[0] += t0 - t1; }
       if (ld_ok) {
@@ -661,7 +713,7 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
   }
   if constexpr (!SPLIT) {
     copy_out(st1_vc, st1_n, st1_yx);
-    if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
+    if ((a.stats[0] != nullptr || do_bnr) && st_key >= 0) flush_stats(st_key);
   }
 }
 

@@ -1957,11 +1957,16 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       v.count = (double)N * lh * lw; v.k12 = S.bn[l].k12;
     }
     float *dg = Gd(h, d.g_off), *db = Gd(h, d.be_off);
+    // pass 1 of this layer's BatchNorm backward already sits in bsums: the data-gradient launch of the layer above accumulated it
+    // in its copy-out (ConvBArgs::bnr_*)
+    const bool sums_fused = h->bsums_fused[l];
+    h->bsums_fused[l] = false;
     if (l == 0) {
       const BnBwdArgs &a0 = a[0], &a1 = a[SS.n - 1];
       const int nb1 = l0_resident_grid(bn_bwd_reduce_l0_kernel<uint16_t>, h, SS.n, (long)N * H, W);
       const int nb2 = l0_resident_grid(bn_bwd_apply_l0_kernel<uint16_t>, h, SS.n, (long)N * H, W);
-      hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel<uint16_t>, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
+      if (!sums_fused)
+        hipLaunchKernelGGL(bn_bwd_reduce_l0_kernel<uint16_t>, dim3(nb1, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off));
       hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(cdiv(64 * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
       hipLaunchKernelGGL(bn_bwd_apply_l0_kernel<uint16_t>, dim3(nb2, SS.n), dim3(256), l0_lds_bytes(W), st, a0, a1, P(h, d.w_off), P(h, d.b_off),
                          Gd(h, d.w_off));
@@ -1982,11 +1987,12 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       const long npix = (long)N * (lh / 2) * (lw / 2);
       const int rows = 256 / (C / 4);
       const int nb = (int)std::max(1L, std::min<long>(cdiv(npix, rows), 1024));
-      hipLaunchKernelGGL((bn_bwd_kernel<true, false, false, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[SS.n - 1]);
+      if (!sums_fused)
+        hipLaunchKernelGGL((bn_bwd_kernel<true, false, false, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[SS.n - 1]);
       hipLaunchKernelGGL(bn_bwd_sums_kernel<uint16_t>, dim3(cdiv(C * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
       hipLaunchKernelGGL((bn_bwd_kernel<true, true, true, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
       HIPCHK(hipGetLastError());
-    } else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st)));
+    } else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st, sums_fused)));
     // weight gradient: X = (pooled) raw output of layer l - 1 under its BatchNorm + ReLU, dY = gQ
     const int src = l - 1;
     const bool pooled_in = layer_in_mode(l) == 2;
@@ -2013,9 +2019,22 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       c.in_cs = C; c.in_co = 0; c.cin = C; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_bwd + d.pk_bwd);
       c.out_cs = d.cin; c.out_co = 0; c.cout = d.cin;
       for (int k = 0; k < SS.n; ++k) { c.in[k] = SS.s[k]->gQ; c.out[k] = SS.s[k]->gP; }
+      // pass 1 of layer src's BatchNorm backward in this launch's copy-out: its output IS dOut of layer src, at the resolution of
+      // src's (pooled) raw output - the tensor the separate pass would read beside it (Apool for the pooled layers, see above)
+      static const int bnr_env = getenv("SSP_BF16_BNR") ? atoi(getenv("SSP_BF16_BNR")) : 1;   // (perf-debug: 0 = separate pass 1)
+      const bool bnr = bnr_env != 0 && launch_conv_bf16_is_ws(c);
+      if (bnr) {
+        for (int k = 0; k < SS.n; ++k) {
+          Slot& S = *SS.s[k];
+          c.bnr_t[k] = reinterpret_cast<const uint16_t*>(pooled_in ? S.Apool[src] : S.Y[src]);
+          c.bnr_scale[k] = S.bn[src].scale; c.bnr_shift[k] = S.bn[src].shift; c.bnr_mean[k] = S.bn[src].mean;
+          c.bnr_invstd[k] = S.bn[src].invstd; c.bnr_sums[k] = S.bn[src].bsums;
+        }
+      }
       const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
       ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_CONV_BF16);
       CHK(launch_conv_bf16(c, h->n_cu, st));
+      if (bnr) h->bsums_fused[src] = true;
     }
   }
   return 0;

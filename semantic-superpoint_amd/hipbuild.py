@@ -111,9 +111,39 @@ def disassemble(lib_path, workdir):
     return dis, notes
 
 
+_STORE_RE = re.compile(r"(?:buffer|global|flat|scratch)_store_dwordx[34]\s+(?:v\d+,\s+|v\[\d+:\d+\],\s+)?v\[(\d+):(\d+)\]")
+_BUF_STORE_RE = re.compile(r"buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\]")
+_VALU_DST_RE = re.compile(r"(v_\S+)\s+(?:v\[(\d+):(\d+)\]|v(\d+))\b")
+
+
+def store_data_hazards(dis):
+    """[(kernel, store, clobbering instruction)]: every 12 / 16-byte store of the disassembly `dis` whose NEXT instruction is a
+    vector-ALU instruction writing one of the store's data registers.  The hardware reads the data of such a store for a few cycles
+    after issue (one wait state), and hipcc for gfx950 (ROCm 7.2) does not keep the slot free: round 5 found conv_bf16_ws_kernel
+    storing v7 << 16 in the last four lanes of every 16-lane row behind `buffer_store_dwordx4 v[6:9]; v_lshlrev_b32 v6, 16, v7`."""
+    out = []
+    parts = re.split(r"^[0-9a-f]{16} <([^>]+)>:\n", dis, flags=re.M)
+    for i in range(1, len(parts), 2):
+        name = parts[i]
+        lines = [l.strip() for l in parts[i + 1].splitlines() if l.strip()]
+        for k in range(len(lines) - 1):
+            m = _BUF_STORE_RE.match(lines[k]) or _STORE_RE.match(lines[k])
+            if not m:
+                continue
+            a, b = int(m.group(1)), int(m.group(2))
+            mm = _VALU_DST_RE.match(lines[k + 1])
+            if not mm or mm.group(1).startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                continue
+            lo, hi = (int(mm.group(2)), int(mm.group(3))) if mm.group(2) else (int(mm.group(4)), int(mm.group(4)))
+            if lo <= b and hi >= a:
+                out.append((name, lines[k].split("//")[0].strip(), lines[k + 1].split("//")[0].strip()))
+    return out
+
+
 def verify_binary(lib_path=LIB, expected=None, require_all=None):
     """Raises RuntimeError if a fixed-accumulation-register kernel of `lib_path` contains any accumulation-register
-    instruction beyond its inline asm, touches scratch, or spills vector registers.  Returns {kernel symbol: counts}.
+    instruction beyond its inline asm, touches scratch, or spills vector registers, or if ANY kernel of the library overwrites
+    the data of a wide store in the slot behind it (store_data_hazards).  Returns {kernel symbol: counts}.
     require_all (default: only for the in-tree library): every kernel family of the contract must be present - an A/B
     build of an older revision (SSP_HIP_LIB) may lack the newer kernels."""
     expected = expected if expected is not None else FIXED_AGPR_KERNELS
@@ -147,6 +177,11 @@ def verify_binary(lib_path=LIB, expected=None, require_all=None):
     for fam, n in found.items():
         if n == 0 and require_all:
             raise RuntimeError("no %s instance found in %s" % (fam, lib_path))
+    hazards = store_data_hazards(dis)
+    if hazards:
+        raise RuntimeError("store-data hazard (a vector instruction overwrites a data register of a 12 / 16-byte store in the next "
+                           "slot; gfx950 needs one wait state, hipcc does not insert it - use ssp_store_b128, csrc/pk_math.hip.h): "
+                           + "; ".join("%s: %s -> %s" % h for h in hazards[:8]) + (" ... %d in all" % len(hazards) if len(hazards) > 8 else ""))
     # kernel descriptors: no private segment, no vector-register spills
     seen_notes = set()
     for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
