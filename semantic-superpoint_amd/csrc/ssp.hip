@@ -43,7 +43,7 @@ using namespace sspk;
 // convolution), 5 (conv_wino_pipe_kernel with the weights staged through LDS) and the bf16-OPERAND experiments inside the fp32
 // Winograd kernels that the bf16 path (algorithm 12) superseded: 3 (one bf16 part), 7 (hi + lo parts), 8 (mixed: fp32 forward,
 // bf16-operand gradients) - conv_wino_bf16.hip.h.  Compiled out of the shipped library (28 kernel instances); their results are
-// PERF_LOG.md section 10 and profiles/r0[2-4]_*mixed_bf16*; -DSSP_LEGACY_ALGOS=1 (SSP_HIPCC_EXTRA) brings them back.
+// profiles/PERF_LOG_rounds_1-4.md section 10 and profiles/r0[2-4]_*mixed_bf16*; -DSSP_LEGACY_ALGOS=1 (SSP_HIPCC_EXTRA) brings them back.
 #ifndef SSP_LEGACY_ALGOS
 #define SSP_LEGACY_ALGOS 0
 #endif

@@ -474,7 +474,7 @@ def test_conv_algorithms_agree_on_a_training_step(algo):
 
 # (The bf16-OPERAND experiments inside the fp32 Winograd kernels - conv algorithms 3 / 7 / 8 of rounds 2-3 - were superseded by the bf16
 # path (algorithm 12, tests/test_gpu_bf16_path.py) and are compiled out of the shipped library (-DSSP_LEGACY_ALGOS=1 brings them back);
-# their tests left with them: git history of this file at round 4, results in PERF_LOG.md section 10.)
+# their tests left with them: git history of this file at round 4, results in profiles/PERF_LOG_rounds_1-4.md section 10.)
 
 
 @pytest.mark.parametrize("n_classes", [21, 150])
