@@ -113,7 +113,7 @@ def disassemble(lib_path, workdir):
 
 _STORE_RE = re.compile(r"(?:buffer|global|flat|scratch)_store_dwordx[34]\s+(?:v\d+,\s+|v\[\d+:\d+\],\s+)?v\[(\d+):(\d+)\]")
 _BUF_STORE_RE = re.compile(r"buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\]")
-_VALU_DST_RE = re.compile(r"(v_\S+)\s+(?:v\[(\d+):(\d+)\]|v(\d+))\b")
+_VALU_DST_RE = re.compile(r"(v_\S+)\s+(?:v\[(\d+):(\d+)\]|v(\d+))(?=[,\s]|$)")
 
 
 def store_data_hazards(dis):

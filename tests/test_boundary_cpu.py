@@ -38,6 +38,39 @@ def test_library_is_built_from_the_checked_out_sources():
     assert ssp.lib.build_id() == want
 
 
+def test_store_data_hazard_lint():
+    """hipbuild.store_data_hazards: the ISA lint behind verify_binary (round 5: hipcc for gfx950 leaves no wait state between a 12 /
+    16-byte store and a vector instruction that overwrites one of its data registers; the hardware needs one).  A synthetic
+    disassembly with the pattern that corrupted conv_bf16_ws_kernel, its harmless neighbours, and the in-tree library (clean)."""
+    import tempfile
+    import semantic_superpoint_amd as ssp
+    hb = ssp.hipbuild
+    dis = (
+        "0000000000001000 <kernel_a>:\n"
+        "\tbuffer_store_dwordx4 v[6:9], v55, s[36:39], s62 offen      // 000000001000: E07C1000\n"
+        "\tv_lshlrev_b32_e32 v6, 16, v7                               // 000000001008: 240C0E90\n"      # the round-5 bug
+        "\tglobal_store_dwordx3 v[2:3], v[10:12], off                  // 000000001010: DC7C8000\n"
+        "\tv_pk_add_f32 v[12:13], v[20:21], v[22:23]                  // 000000001018: D3B2400C\n"      # overlaps v12
+        "\tbuffer_store_dwordx4 v[14:17], v55, s[36:39], s20 offen    // 000000001020: E07C1000\n"
+        "\ts_nop 0                                                    // 000000001028: BF800000\n"      # padded: fine
+        "\tv_lshlrev_b32_e32 v14, 16, v15                             // 00000000102C: 241C1E90\n"
+        "\tbuffer_store_dwordx4 v[18:21], v55, s[36:39], s20 offen    // 000000001030: E07C1000\n"
+        "\tv_add_f32_e32 v30, v18, v19                                // 000000001038: 023C2712\n"      # reads only: fine
+        "\tbuffer_store_dwordx2 v[40:41], v55, s[36:39], s20 offen    // 000000001040: E0741000\n"
+        "\tv_mov_b32_e32 v40, 0                                       // 000000001048: 7E500280\n"      # 8-byte store: no hazard
+        "0000000000002000 <kernel_b>:\n"
+        "\tbuffer_store_dwordx4 v[6:9], v55, s[36:39], s62 offen      // 000000002000: E07C1000\n"
+        "\tv_cmp_gt_f32_e32 vcc, v6, v7                               // 000000002008: 7C880F06\n"      # writes no vector register
+    )
+    found = hb.store_data_hazards(dis)
+    assert [(k, c.split()[0], c.split()[1].rstrip(",")) for k, _, c in found] == [("kernel_a", "v_lshlrev_b32_e32", "v6"),
+                                                                                ("kernel_a", "v_pk_add_f32", "v[12:13]")], found
+    ssp.build()
+    with tempfile.TemporaryDirectory(prefix="ssp_isa_", dir="/tmp") as tmp:
+        real, _ = hb.disassemble(hb.LIB, tmp)
+    assert len(real) > 1_000_000 and hb.store_data_hazards(real) == []
+
+
 def test_create_without_gpu_reports_layout():
     """ssp_create / counts need no device memory: parameter and BN layout match the oracle's spec."""
     import ctypes as Ct
