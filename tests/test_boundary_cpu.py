@@ -89,6 +89,32 @@ def test_create_without_gpu_reports_layout():
     assert lib.ssp_create(Ct.byref(bad), Ct.byref(h)) != 0 and b"multiples of 8" in lib.ssp_last_error()
 
 
+def test_retired_conv_algorithms_are_refused_and_the_bench_flags_follow():
+    """Conv algorithms 2 / 3 / 5 / 7 / 8 (experiments of rounds 1-3) are compiled out of the shipped library: the per-handle and the
+    process-wide selectors refuse them with a message, the shipped ones are accepted; bench.py offers only what the library runs and
+    its side blocks (`sp`, `bf16`) can be switched off."""
+    import ctypes as Ct
+    import semantic_superpoint_amd as ssp
+    lib = ssp.load_library()
+    cfg = ssp.lib.SspConfig(1, 133, 2, 64, 96, 1000, 100)
+    h = Ct.c_void_p()
+    assert lib.ssp_create(Ct.byref(cfg), Ct.byref(h)) == 0
+    for algo in (2, 3, 5, 7, 8):
+        assert lib.ssp_handle_set_conv_algo(h, algo) != 0 and b"compiled out" in lib.ssp_last_error(), algo
+        assert lib.ssp_set_conv_algo(algo) != 0 and b"compiled out" in lib.ssp_last_error(), algo
+    for algo in (0, 1, 6, 9, 10, 11, 12):
+        assert lib.ssp_handle_set_conv_algo(h, algo) == 0, (algo, lib.ssp_last_error())
+    assert lib.ssp_handle_set_conv_algo(h, 4) != 0 and lib.ssp_handle_set_conv_algo(h, 13) != 0
+    assert lib.ssp_set_conv_algo(1) == 0
+    lib.ssp_destroy(h)
+    b = _load_bench()
+    for algo in ("2", "3", "5", "7", "8"):
+        with pytest.raises(SystemExit):
+            b.parse_args(["--conv-algo", algo])
+    a = b.parse_args(["--no-sp", "--no-bf16", "--conv-algo", "10"])
+    assert a.no_sp and a.no_bf16 and a.conv_algo == 10 and not b.parse_args([]).no_sp
+
+
 @pytest.mark.parametrize("arch", ["SuperPointNet_gauss2", "SuperPointNet_gauss2_ssmall"])
 def test_module_state_dict_is_the_reference_wire_format(arch):
     from semantic_superpoint_amd import models
