@@ -67,6 +67,9 @@ struct ConvArgs {
   // BatchNorm + ReLU on load to a quarter-size tensor and the separate pooled-activation pass disappears.
   float* pool_out[2] = {nullptr, nullptr};
   const float* pool_gamma = nullptr;
+  // perf-debug only (a build with SSP_HIPCC_EXTRA=-DW4_TRACE=1 and SSP_W4_TRACE=N in the environment): per-phase cycle sums of the four
+  // waves of workgroup 0 of conv_wino4_kernel, else nullptr
+  unsigned long long* trace = nullptr;
 };
 
 // lane/row index m (0..31) of an MFMA M-tile -> pixel (r,c) inside the SH x SW sub-rectangle.

@@ -45,6 +45,12 @@
 #define W4_NT 2  // cache-policy bits of the output stores and of the fused BatchNorm-backward tensor loads: 2 = nt (streamed once:
                  // they should not push the halo lines out of the XCD's L2; 0.65 instead of 0.68 ms per 64 -> 64 launch at 240x320)
 #endif
+#ifndef W4_TRACE
+#define W4_TRACE 0  // compile-time perf trace (never in the shipped library): s_memtime stamps around the phases of a stage and the tile
+                  // epilogue, summed per wave of workgroup 0 into ConvArgs::trace[wave * 8 + k]: k = 0 first half (pairs 0..4 beside
+                  // the transform), 1 wait at barrier A, 2 second half (pairs 5..8 beside the halo staging), 3 wait at barrier B,
+                  // 4 tile epilogue, 5 whole loop, 6 stages; tools/dbg/w4_trace.sh
+#endif
 #ifndef W4_ABL
 #define W4_ABL 0  // compile-time perf ablation: 1 no tile epilogue, 2 no transform, 4 no halo staging, 16 no output stores,
                   // 32 no barrier in the epilogue rounds, 64 accumulators not cleared, 128 no barriers in the stage loop, 256 no
@@ -454,7 +460,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_FETCH(2, cA, 5, chunk)                                                                                         \
     W4_FENCE();                                                                                                       \
     W4_MM8(4, 1)                                                                                                      \
+    W4_T(0)                                                                                                           \
     if (!(W4_ABL & 128)) __syncthreads();                                                                             \
+    W4_T(1)                                                                                                           \
     W4_FETCH(0, cA, 6, chunk)                                                                                         \
     W4_FENCE();                                                                                                       \
     W4_MM(5, 0, 2) W4_HALO_PAR(SET) W4_HALO_BN(0, SET) W4_FENCE();                                                    \
@@ -482,8 +490,17 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     if (nchunk != 0) W4_FETCH_F(0, nA, 0)                                                                             \
     W4_FENCE();                                                                                                       \
     W4_MM8(8, 2)                                                                                                      \
-    if (!(W4_ABL & 128)) __syncthreads();
+    W4_T(2)                                                                                                           \
+    if (!(W4_ABL & 128)) __syncthreads();                                                                             \
+    W4_T(3)
 
+#if W4_TRACE
+  unsigned long long tc_[5] = {0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter();
+  const unsigned long long tk0_ = tp_;
+#define W4_T(K) { const unsigned long long tn_ = __builtin_readcyclecounter(); tc_[K] += tn_ - tp_; tp_ = tn_; }
+#else
+#define W4_T(K)
+#endif
   static_assert(PK == 8, "stage = 8 input channels");
   int tile = tile0, chunk = 0;
   for (g = 0; g < nstages; g += 2) {  // nst = Cin / 8 is even (Cin % 16 == 0): a tile ends behind an odd stage
@@ -676,11 +693,21 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
       if (!(W4_ABL & 64)) w4_acc_clear(c11);
       W4_CLEAR_V()
 #endif
+      W4_T(4)
       chunk = 0;
       tile += per_cob;
       W4_FETCH_F(0, nA, 0)
     }
   }
+#if W4_TRACE
+  if (a.trace != nullptr && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a.trace[wave * 8 + k] = tc_[k];
+    a.trace[wave * 8 + 5] = __builtin_readcyclecounter() - tk0_;
+    a.trace[wave * 8 + 6] = (unsigned long long)nstages;
+  }
+#endif
+#undef W4_T
 #undef W4_ISSUE_HALO
 #undef W4_STAGE
 #undef W4_CLEAR_V

@@ -526,14 +526,41 @@ static int launch_wino_p2_t(const ConvArgs& a, int nblocks, hipStream_t st) {
 }
 
 template <int IN_MODE, bool WIDE>
-static int launch_wino4_t(const ConvArgs& a, int nblocks, hipStream_t st) {
+static int launch_wino4_t(const ConvArgs& a_in, int nblocks, hipStream_t st) {
   static AttrOnce attr_once;
   auto kern = conv_wino4_kernel<IN_MODE, WIDE>;
   if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
   }
+#if W4_TRACE
+  // perf-debug build only: every SSP_W4_TRACE-th launch carries a trace buffer, is waited for and printed (cycles per stage)
+  ConvArgs a = a_in;
+  static const int trace_env = getenv("SSP_W4_TRACE") ? atoi(getenv("SSP_W4_TRACE")) : 0;
+  static unsigned long long* trace_buf = nullptr;
+  static int trace_count = 0;
+  const bool trace_now = trace_env > 0 && (++trace_count % trace_env) == 0;
+  if (trace_now) {
+    if (!trace_buf) HIPCHK(hipMalloc(&trace_buf, 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(trace_buf, 0, 64 * sizeof(unsigned long long), st));
+    a.trace = trace_buf;
+  }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(W4_THREADS), W4_LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
+  if (trace_now) {
+    unsigned long long hbuf[64];
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(hbuf, trace_buf, sizeof(hbuf), hipMemcpyDeviceToHost));
+    const double ns = (double)std::max<unsigned long long>(hbuf[6], 1);
+    fprintf(stderr, "[w4 trace] %dx%d cin %d cout %d mode %d bnr %d nprob %d: %llu stages of workgroup 0; cycles per stage (MFMA floor 4608)\n",
+            a.H, a.W, a.Cin, a.Cout, IN_MODE, a.bnr_mode, a.nprob, hbuf[6]);
+    for (int w = 0; w < 4; ++w)
+      fprintf(stderr, "  wave %d: first half %.0f  barrier A %.0f  second half %.0f  barrier B %.0f  epilogue %.0f  | loop %.0f\n", w,
+              hbuf[w * 8] / ns, hbuf[w * 8 + 1] / ns, hbuf[w * 8 + 2] / ns, hbuf[w * 8 + 3] / ns, hbuf[w * 8 + 4] / ns, hbuf[w * 8 + 5] / ns);
+  }
+#else
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(W4_THREADS), W4_LDS_BYTES, st, a_in);
+  HIPCHK(hipGetLastError());
+#endif
   return 0;
 }
 
