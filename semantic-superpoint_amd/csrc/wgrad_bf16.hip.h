@@ -72,17 +72,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
     baseB[dx] = (8 * lg + lt) * 128 + ((nh ^ beta) << 6) + (16 * sub + 4 * (li & 3)) * 2;
   }
 
-  // staging: 16-byte item = 8 channels; chunk = tid & 7 is fixed per thread, slot = (tid >> 3) + 32 k
+  int baseB2[2][3];   // by the parity of the halo row (3x3: pitch 18, bit 1 of the slot index flips with the row)
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) { baseB2[0][dx] = baseB[dx]; baseB2[1][dx] = baseB[dx] ^ 64; }
+
+  // staging: 16-byte item = 8 channels; chunk = tid & 7 is fixed per thread, slot = (tid >> 3) + 32 k.  Bit 1 of the slot index is
+  // (tid >> 4) & 1 in every round, so the half swap of a slot is a per-thread constant: position c8 of this thread's slots holds
+  // channel item cs8, and this thread's own item c8 lives at byte qswz of the slot.
   const int c8 = tid & 7;
-  float sc[8], sh[8];
-  if (IN_MODE == 1) {
+  const int cs8 = ((((c8 >> 2) ^ (tid >> 4)) & 1) << 2) | (c8 & 3);
+  const int qswz = ((((c8 >> 2) ^ (tid >> 4)) & 1) << 6) + (c8 & 3) * 16;
+  const int cxx2 = (cib * 64 + cs8 * 8) * 2, cdd = cob * 64 + cs8 * 8;
+  const unsigned lane_d = (unsigned)((((tid >> 7) * a.W + ((tid >> 3) & 15)) * a.dy_cs + cdd) * 2);
+  // BatchNorm affine of this thread's 8 input channels as packed pairs; ZERO beyond Cin: max(0 x + 0, 0) = 0 is the padding value,
+  // so the activation needs no per-channel mask
+  f32x2 sc2[4], sh2[4];
+  auto load_affine = [&](int view) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = min(cib * 64 + c8 * 8 + e, a.Cin - 1);
-      sc[e] = a.x_scale[0][c];  // (re-read per view below when the views differ)
-      sh[e] = a.x_shift[0][c];
+      const int c = cib * 64 + c8 * 8 + e;
+      const bool in = c < a.Cin;
+      sc2[e >> 1][e & 1] = in ? a.x_scale[view][min(c, a.Cin - 1)] : 0.f;
+      sh2[e >> 1][e & 1] = in ? a.x_shift[view][min(c, a.Cin - 1)] : 0.f;
     }
-  }
+  };
+  if (IN_MODE == 1) load_affine(0);  // (re-read per view below when the views differ)
   int sc_view = 0;
 
   f32x16 acc[TAPS];
@@ -102,12 +116,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
     const int ty0 = tyi * CB_T, tx0 = txi * CB_T;
     if (IN_MODE == 1 && view != sc_view) {
       sc_view = view;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = min(cib * 64 + c8 * 8 + e, a.Cin - 1);
-        sc[e] = a.x_scale[view][c];
-        sh[e] = a.x_shift[view][c];
-      }
+      load_affine(view);
     }
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x[view])) + (size_t)n * a.x_img_bytes, 0, a.x_img_bytes, 0x00020000);
@@ -130,30 +139,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
         dv2[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_d, vo, 16, 0));
       }
     }
+    // tiles whose halo lies inside the map, for a layer of whole 64-channel blocks: no per-slot coordinates or bounds on either side
+    const bool inside = ty0 >= PAD && tx0 >= PAD && ty0 + CB_T + PAD <= a.H && tx0 + CB_T + PAD <= a.W;
+    const bool fastx = inside && (a.Cin & 63) == 0, fastd = inside && (a.Cout & 63) == 0;
+    unsigned okmask = 0;  // bit k: X slot (tid >> 3) + 32 k is a pixel of the map (general path; the activation zeroes the others)
     __syncthreads();  // every wave has finished the transposing reads of the previous tile
+    if (fastx) {
+      const int sbx = (((ty0 - PAD) * a.W + tx0 - PAD) * a.x_cs + a.x_co) * 2;   // (wave-uniform: the scalar offset of the load)
 #pragma unroll
-    for (int k = 0; k < NXS; ++k) {
-      int s = (tid >> 3) + 32 * k;   // (slots >= HT * HT of the last round land in the padding of the X region)
-      asm volatile("" : "+v"(s));    // (opaque: hipcc otherwise hoists the slot coordinates of all rounds out of the tile loop
-                                     // and keeps ~30 registers alive beside the 144 accumulators)
-      const int cs8 = ((((c8 >> 2) ^ (s >> 1)) & 1) << 2) | (c8 & 3);   // channel item that lives at position c8 of slot s
-      const int cxx = cib * 64 + cs8 * 8;
-      const int hy = s / HT, hx = s - hy * HT;
-      const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
-      const bool ok = s < HT * HT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && cxx < a.Cin;
-      const unsigned vo = ok ? (unsigned)(((gy * a.W + gx) * a.x_cs + a.x_co + cxx) * 2) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (ldsp)(sX + (32 * k + 8 * wave) * 128), 16, vo, 0, 0, 0);
+      for (int k = 0; k < NXS; ++k) {
+        unsigned s = (tid >> 3) + 32 * k;   // (slots >= HT * HT of the last round land in the padding of the X region: whatever
+        asm volatile("" : "+v"(s));         //  they load - rows below the tile, or 0 beyond the image - is never read)
+        const unsigned hy = HT == 16 ? s >> 4 : __umul24(s, 3641u) >> 16;   // s / 18 for s < 352
+        const unsigned hx = s - __umul24(hy, (unsigned)HT);
+        const unsigned vo = __umul24(__umul24(hy, (unsigned)a.W) + hx, (unsigned)(a.x_cs * 2)) + cxx2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (ldsp)(sX + (32 * k + 8 * wave) * 128), 16, vo, sbx, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NXS; ++k) {
+        int s = (tid >> 3) + 32 * k;
+        asm volatile("" : "+v"(s));    // (opaque: hipcc otherwise hoists the slot coordinates of all rounds out of the tile loop
+                                       // and keeps ~30 registers alive beside the 144 accumulators)
+        const int hy = HT == 16 ? s >> 4 : (int)(__umul24((unsigned)s, 3641u) >> 16), hx = s - hy * HT;
+        const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+        const bool in_map = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const bool ok = s < HT * HT && in_map && cxx2 < a.Cin * 2;
+        okmask |= (in_map ? 1u : 0u) << k;
+        const unsigned vo = ok ? (unsigned)(((gy * a.W + gx) * a.x_cs + a.x_co) * 2 + cxx2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (ldsp)(sX + (32 * k + 8 * wave) * 128), 16, vo, 0, 0, 0);
+      }
     }
     if constexpr (!DY_F32) {
+      if (fastd) {
+        // slot (tid >> 3) + 32 k = pixel row (tid >> 7) + 2 k, column (tid >> 3) & 15: the round advances two image rows
+        const int sbd = ((ty0 * a.W + tx0) * a.dy_cs + a.dy_co) * 2, rows2 = a.W * a.dy_cs * 4;
 #pragma unroll
-      for (int k = 0; k < NDS; ++k) {
-        const int s = (tid >> 3) + 32 * k;
-        const int cs8 = ((((c8 >> 2) ^ (s >> 1)) & 1) << 2) | (c8 & 3);
-        const int cdd = cob * 64 + cs8 * 8;
-        const int gy = ty0 + (s >> 4), gx = tx0 + (s & 15);
-        const bool ok = gy < a.H && gx < a.W && cdd < a.Cout;
-        const unsigned vo = ok ? (unsigned)(((gy * a.W + gx) * a.dy_cs + a.dy_co + cdd) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (ldsp)(sD + (32 * k + 8 * wave) * 128), 16, vo, 0, 0, 0);
+        for (int k = 0; k < NDS; ++k)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (ldsp)(sD + (32 * k + 8 * wave) * 128), 16, lane_d, sbd + k * rows2, 0, 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NDS; ++k) {
+          const int s = (tid >> 3) + 32 * k;
+          const int gy = ty0 + (s >> 4), gx = tx0 + (s & 15);
+          const bool ok = gy < a.H && gx < a.W && cdd < a.Cout;
+          const unsigned vo = ok ? (unsigned)(((gy * a.W + gx) * a.dy_cs + a.dy_co + cdd) * 2) : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (ldsp)(sD + (32 * k + 8 * wave) * 128), 16, vo, 0, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -172,76 +204,109 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
             else if (cd + 2 * e + 1 >= a.Cout) o[e] &= 0xffffu;
           }
         }
-        *reinterpret_cast<u32x4*>(sD + s * 128 + ((((c8 >> 2) ^ (s >> 1)) & 1) << 6) + (c8 & 3) * 16) = o;
+        *reinterpret_cast<u32x4*>(sD + s * 128 + qswz) = o;
       }
     }
     __syncthreads();  // (the DMA has landed: hipcc drains vmcnt before the barrier)
-    if (IN_MODE == 1 || (a.Cin & 63) != 0) {
-      // activate the raw bf16 halo in place: this thread owns channel item c8 of slots (tid >> 3) + 32 k
+    if constexpr (IN_MODE == 1) {
+      // BatchNorm + ReLU + rounding of the raw bf16 halo IN PLACE: this thread owns channel item c8 of slots (tid >> 3) + 32 k, i.e.
+      // one 16-byte address + 4096 k.  The forward kernel's arithmetic (conv_bf16_ws_kernel, stage_halo): packed fma, round, ReLU
+      // on the packed result as a 16-bit integer max with 0 - 20 vector instructions per 8 values.
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int k = 0; k < NXS; ++k) {
-        int s = (tid >> 3) + 32 * k;
-        asm volatile("" : "+v"(s));
-        if (s >= HT * HT) continue;
-        const int hy = s / HT, hx = s - hy * HT;
-        const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
-        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && cx < a.Cin;
-        u32x4* const q = reinterpret_cast<u32x4*>(sX + s * 128 + ((((c8 >> 2) ^ (s >> 1)) & 1) << 6) + (c8 & 3) * 16);
-        u32x4 o = {0u, 0u, 0u, 0u};
-        if (ok) {
-          const u32x4 v = *q;
-          float f[8];
+        if (32 * k + 32 > HT * HT && (tid >> 3) + 32 * k >= HT * HT) continue;   // (the last round is partly padding)
+        u32x4* const q = reinterpret_cast<u32x4*>(sX + (tid >> 3) * 128 + qswz + k * 4096);
+        const u32x4 v = *q;
+        u32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(v[e]); f[2 * e + 1] = bf16_hi(v[e]); }
-          if (IN_MODE == 1) {
+        for (int e = 0; e < 4; ++e) {
+          const f32x2 z = pk_fma(f32x2{bf16_lo(v[e]), bf16_hi(v[e])}, sc2[e], sh2[e]);
+          const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(z[0], z[1])), s16x2{0, 0});
+          o[e] = __builtin_bit_cast(uint32_t, r);
+        }
+        if (!fastx) {   // padding is zero in the ACTIVATED domain
+          const bool pad = !((okmask >> k) & 1u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
-          }
+          for (int e = 0; e < 4; ++e) o[e] = pad ? 0u : o[e];
+        }
+        *q = o;
+      }
+      __syncthreads();
+    } else if ((a.Cin & 63) != 0) {
+      // (no activation, a ragged last channel block: the channels beyond Cin of a loaded item are zeroed)
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (cx + e >= a.Cin) f[e] = 0.f;
+      for (int k = 0; k < NXS; ++k) {
+        if (32 * k + 32 > HT * HT && (tid >> 3) + 32 * k >= HT * HT) continue;
+        u32x4* const q = reinterpret_cast<u32x4*>(sX + (tid >> 3) * 128 + qswz + k * 4096);
+        u32x4 o = *q;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) {
+          if (cx + 2 * e >= a.Cin) o[e] = 0u;
+          else if (cx + 2 * e + 1 >= a.Cin) o[e] &= 0xffffu;
         }
         *q = o;
       }
       __syncthreads();
     }
-    // ---- 16 image rows x taps: K = the 16 pixels of a row.  The fragments of step s + 1 (the next tap's X, the next row's dY) are
-    // requested before the MFMA of step s is issued (two register sets, pinned with sched_barrier). ----
-    {
-      s16x8 fa[2], fb[2];
-      auto fetch_a = [&](int row) {
+    if constexpr (KS == 3) {
+      // ---- halo-row major: the X fragment of (halo row r, column shift dx) feeds the three taps (dy, dx) with the dY rows r - dy
+      // (K = the 16 pixels of an image row): 54 X + 16 dY fragment fetches per tile for 144 MFMAs (tap major: 144 + 16).  X
+      // fragments are requested two steps (2 - 6 MFMAs) ahead into three rotating registers, dY rows one halo row ahead into four;
+      // every address is a lane constant + an immediate. ----
+      s16x8 fa[4], fb[3];
+      auto fetch_a = [&](int row) __attribute__((always_inline)) {
         const unsigned char* pa = sD + baseA + row * 16 * 128;
         return wb_tr_pair(pa, pa + 4 * 128);
       };
-      auto fetch_b = [&](int row, int tap) {
-        const int dy = tap / KS, dx = tap % KS;
-        const int rho = (HT & 2) ? ((row + dy) & 1) : 0;   // bit 1 of the slot index flips with the halo row (pitch 18)
-        const unsigned char* pb = sX + (baseB[dx] ^ (rho << 6)) + ((row + dy) * HT + dx) * 128;
+      auto fetch_b = [&](int st) __attribute__((always_inline)) {   // step st = 3 r + dx
+        const int r = st / 3, dx = st - 3 * r;
+        const unsigned char* pb = sX + baseB2[r & 1][dx] + (r * HT + dx) * 128;   // (bit 1 of the slot index flips with the halo row)
+        return wb_tr_pair(pb, pb + 4 * 128);
+      };
+      fb[0] = fetch_b(0);
+      fa[0] = fetch_a(0);
+      fb[1] = fetch_b(1);
+#pragma unroll
+      for (int st = 0; st < 3 * HT; ++st) {
+        const int r = st / 3, dx = st - 3 * r;
+        if (st + 2 < 3 * HT) fb[(st + 2) % 3] = fetch_b(st + 2);
+        if (dx == 0 && r + 1 < CB_T) fa[(r + 1) & 3] = fetch_a(r + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int row = r - dy;
+          if (row >= 0 && row < CB_T)
+            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[row & 3], fb[st % 3], acc[dy * 3 + dx], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // ---- pointwise: 16 image rows, K = the 16 pixels of a row; the fragments of row s + 1 are requested before the MFMA of row s ----
+      s16x8 fa[2], fb[2];
+      auto fetch_a = [&](int row) __attribute__((always_inline)) {
+        const unsigned char* pa = sD + baseA + row * 16 * 128;
+        return wb_tr_pair(pa, pa + 4 * 128);
+      };
+      auto fetch_b = [&](int row) __attribute__((always_inline)) {
+        const unsigned char* pb = sX + baseB[0] + row * HT * 128;
         return wb_tr_pair(pb, pb + 4 * 128);
       };
       fa[0] = fetch_a(0);
-      fb[0] = fetch_b(0, 0);
-#pragma unroll 1
-      for (int ry = 0; ry < CB_T; ry += 2) {
+      fb[0] = fetch_b(0);
 #pragma unroll
-        for (int st = 0; st < 2 * TAPS; ++st) {   // (row parity, tap); ry is even, so the parities are compile-time
-          const int rr = st / TAPS, tap = st - rr * TAPS;
-          const int nst = st + 1, nrr = (nst / TAPS) & 1, ntap = nst % TAPS;
-          const bool last = st + 1 == 2 * TAPS;     // the next step is row ry + 2 (if any)
-          if (!last || ry + 2 < CB_T) {
-            const int nrow = last ? ry + 2 : ry + nrr;
-            fb[(st + 1) & 1] = fetch_b(nrow, ntap);
-            if (ntap == 0) fa[nrr] = fetch_a(nrow);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rr], fb[st & 1], acc[tap], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+      for (int ry = 0; ry < CB_T; ++ry) {
+        if (ry + 1 < CB_T) {
+          fa[(ry + 1) & 1] = fetch_a(ry + 1);
+          fb[(ry + 1) & 1] = fetch_b(ry + 1);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ry & 1], fb[ry & 1], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+
 
   // ---- partial slab [tap][ci][co] ----
   float* const slab = a.partial + (size_t)blockIdx.x * TAPS * 4096;
