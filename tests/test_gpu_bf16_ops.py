@@ -113,6 +113,11 @@ WGRAD_CASES = [
     (1, 30, 40, 128, 128, 3, 1, "bf16"),   # ragged tiles, 2 x 2 slabs
     (2, 24, 48, 64, 128, 3, 0, "bf16"),    # plain input
     (1, 14, 18, 256, 136, 1, 1, "f32"),    # pointwise head, ragged output channels (133 + 3 zero)
+    # maps with INTERIOR 16x16 tiles (halo inside the map): the staging path without per-slot coordinates / padding masks
+    (1, 64, 80, 64, 64, 3, 1, "bf16"),     # 4 x 5 tiles, 2 x 3 of them interior
+    (1, 56, 72, 128, 64, 3, 1, "bf16"),    # interior tiles beside ragged ones (56 = 3.5, 72 = 4.5 tiles), two input-channel blocks
+    (1, 48, 48, 64, 64, 3, 0, "bf16"),     # plain input: interior tile without the activation pass
+    (1, 48, 64, 256, 256, 1, 1, "f32"),    # pointwise, whole channel blocks: every tile is interior
 ]
 
 
