@@ -466,6 +466,7 @@ struct WgradArgs {
   const float* f_k12[2] = {nullptr, nullptr};
   const float* f_gamma = nullptr;
   int f_ycs = 0;
+  unsigned long long* trace = nullptr;  // WGF_TRACE builds only (wgrad_wino_fused.hip.h): phase cycle sums of workgroup 0
 };
 
 template <int KS, int SH, int SW>

@@ -943,15 +943,43 @@ static int launch_wgrad_wino_t(const WgradArgs& a, int nblocks, hipStream_t st) 
 }
 
 template <int IN_MODE, bool WIDE, bool POOL, bool BF16 = false>
-static int launch_wgrad_wino_fused_t(const WgradArgs& a, int nblocks, hipStream_t st) {
+static int launch_wgrad_wino_fused_t(const WgradArgs& a_in, int nblocks, hipStream_t st) {
   using GF = WgradFusedGeom<WIDE>;
   static AttrOnce attr_once;
   auto kern = wgrad_wino_fused_kernel<IN_MODE, WIDE, POOL, BF16>;
   if (attr_once.need()) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GF::LDS_BYTES));
   }
+#if WGF_TRACE
+  // perf-debug build only: every SSP_WGF_TRACE-th launch carries a trace buffer, is waited for and printed (cycles per tile)
+  WgradArgs a = a_in;
+  static const int trace_env = getenv("SSP_WGF_TRACE") ? atoi(getenv("SSP_WGF_TRACE")) : 0;
+  static unsigned long long* trace_buf = nullptr;
+  static int trace_count = 0;
+  const bool trace_now = trace_env > 0 && (++trace_count % trace_env) == 0;
+  if (trace_now) {
+    if (!trace_buf) HIPCHK(hipMalloc(&trace_buf, 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(trace_buf, 0, 64 * sizeof(unsigned long long), st));
+    a.trace = trace_buf;
+  }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), GF::LDS_BYTES, st, a);
   HIPCHK(hipGetLastError());
+  if (trace_now) {
+    unsigned long long hbuf[64];
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(hbuf, trace_buf, sizeof(hbuf), hipMemcpyDeviceToHost));
+    const double nt = (double)std::max<unsigned long long>(hbuf[6], 1);
+    fprintf(stderr, "[wgf trace] %dx%d cin %d cout %d mode %d pool %d nprob %d: %llu tiles of workgroup 0 at %.0f MHz; cycles per tile (MFMA floor 2 x 8192 per SIMD)\n",
+            a.H, a.W, a.Cin, a.Cout, IN_MODE, (int)POOL, a.nprob, hbuf[6], 100.0 * (double)hbuf[5] / (double)std::max<unsigned long long>(hbuf[7], 1));
+    for (int w = 0; w < 8; ++w)
+      fprintf(stderr, "  wave %d: top barrier %.0f  staging %.0f  barrier %.0f  issue %.0f  mfma %.0f  | loop %.0f\n", w, hbuf[w * 8] / nt,
+              hbuf[w * 8 + 1] / nt, hbuf[w * 8 + 2] / nt, hbuf[w * 8 + 3] / nt, hbuf[w * 8 + 4] / nt, hbuf[w * 8 + 5] / nt);
+  }
+#else
+  const WgradArgs& a = a_in;
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), GF::LDS_BYTES, st, a);
+  HIPCHK(hipGetLastError());
+#endif
   return 0;
 }
 

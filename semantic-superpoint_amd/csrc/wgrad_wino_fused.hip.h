@@ -21,6 +21,13 @@
 #include "conv_wino.hip.h"
 #include "conv_wino_bf16.hip.h"
 
+#ifndef WGF_TRACE
+#define WGF_TRACE 0  // compile-time perf trace (never in the shipped library): s_memtime stamps around the phases of a tile, summed per
+                   // wave of workgroup 0 into WgradArgs::trace[wave * 8 + k]: k = 0 wait at the top barrier, 1 staging (halo LDS
+                   // writes + the fused APPLY + dY stores), 2 wait at the second barrier, 3 issue of the next tile's loads, 4 MFMA
+                   // phase, 5 whole loop, 6 tiles, 7 the loop in 100 MHz ticks (-> the shader clock the launch ran at); tools/dbg/wgf_trace.sh
+#endif
+
 namespace sspk {
 
 template <bool WIDE>
@@ -134,26 +141,57 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
     sO[(2 * NX + 8) * 512] = xmask_in;
   }
   bool nxt_inside = false;  // wave-uniform: the prefetched tile is an interior tile
-#define WGF_ISSUE(TILE)                                                                                       \
+  // Tile walker (wave-uniform scalars; every per-tile instruction of this loop is issue time: two waves per SIMD share one issue
+  // port and the CU's eight waves ONE scalar unit, and no MFMA runs while they stage / issue): the coordinates of the tile whose
+  // loads are in flight advance incrementally (no divisions per tile), the three buffer descriptors are rebuilt only when the
+  // image changes, and the staging below reuses them for the dY stores of the tile it consumes.
+  int w_tile = t_begin, w_prob = 0, w_n = 0, w_ty0 = 0, w_tx0 = 0;
+  {
+    w_prob = t_begin >= a.ntiles ? 1 : 0;
+    const int tl_ = t_begin - w_prob * a.ntiles;
+    const int tx_ = tl_ % a.tiles_x, t2_ = tl_ / a.tiles_x;
+    w_ty0 = (t2_ % a.tiles_y) * G::TH; w_tx0 = tx_ * G::TW; w_n = t2_ / a.tiles_y;
+  }
+  const int w_xend = a.tiles_x * G::TW, w_yend = a.tiles_y * G::TH;
+  auto walk = [&]() __attribute__((always_inline)) {   // -> the next tile (the caller stops at t_end - 1)
+    ++w_tile;
+    w_tx0 += G::TW;
+    if (w_tx0 >= w_xend) {
+      w_tx0 = 0; w_ty0 += G::TH;
+      if (w_ty0 >= w_yend) {
+        w_ty0 = 0; ++w_n;
+        if (w_tile == a.ntiles) { w_n = 0; w_prob = 1; }
+      }
+    }
+  };
+  __amdgpu_buffer_rsrc_t rx_, ry_, rp_;
+  int r_key = -1;   // (problem, image) the descriptors were built for
+#define WGF_ISSUE()                                                                                           \
   {                                                                                                           \
-    const int pr_ = (TILE) >= a.ntiles ? 1 : 0;                                                               \
-    const int tl_ = (TILE) - pr_ * a.ntiles;                                                                  \
-    const int tx_ = tl_ % a.tiles_x, t2_ = tl_ / a.tiles_x;                                                   \
-    const int ty0_ = (t2_ % a.tiles_y) * G::TH, tx0_ = tx_ * G::TW, n_ = t2_ / a.tiles_y;                     \
-    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
-        const_cast<float*>(pr_ ? a.in2 : a.in) + (size_t)n_ * a.H * a.W * a.in_cs, 0, a.H * xrow, 0x00020000); \
-    const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
-        const_cast<float*>(a.f_y[pr_]) + (size_t)n_ * a.H * a.W * a.f_ycs, 0, a.H * yrow, 0x00020000);        \
-    const __amdgpu_buffer_rsrc_t rp_ = __builtin_amdgcn_make_buffer_rsrc(                                     \
-        const_cast<float*>(pr_ ? a.dout2 : a.dout) + (size_t)n_ * (POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.dout_cs, 0, \
-        (POOL ? (a.H >> 1) : a.H) * prow, 0x00020000);                                                        \
+    const int pr_ = w_prob, n_ = w_n;                                                                         \
+    const int ty0_ = __builtin_amdgcn_readfirstlane(w_ty0), tx0_ = __builtin_amdgcn_readfirstlane(w_tx0);     \
+    if (r_key != pr_ * 65536 + n_) {                                                                          \
+      r_key = pr_ * 65536 + n_;                                                                               \
+      rx_ = __builtin_amdgcn_make_buffer_rsrc(                                                                \
+          const_cast<float*>(pr_ ? a.in2 : a.in) + (size_t)n_ * a.H * a.W * a.in_cs, 0, a.H * xrow, 0x00020000); \
+      ry_ = __builtin_amdgcn_make_buffer_rsrc(                                                                \
+          const_cast<float*>(a.f_y[pr_]) + (size_t)n_ * a.H * a.W * a.f_ycs, 0, a.H * yrow, 0x00020000);      \
+      rp_ = __builtin_amdgcn_make_buffer_rsrc(                                                                \
+          const_cast<float*>(pr_ ? a.dout2 : a.dout) + (size_t)n_ * (POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.dout_cs, 0, \
+          (POOL ? (a.H >> 1) : a.H) * prow, 0x00020000);                                                      \
+    }                                                                                                         \
     nxt_inside = ty0_ >= 1 && ty0_ + G::TH + 1 <= a.H && tx0_ >= 1 && tx0_ + G::TW + 1 <= a.W;               \
-    const int yb_ = ty0_ * yrow + tx0_ * ypix;                                                                \
-    const int pb_ = POOL ? (ty0_ >> 1) * prow + (tx0_ >> 1) * ppix : ty0_ * prow + tx0_ * ppix + a.dout_co * 4; \
+    /* (scalar offsets through readfirstlane: mixed into the per-lane validity tests below they became vector values and every   */ \
+    /* y load a waterfall loop)                                                                                                */ \
+    const int yb_ = __builtin_amdgcn_readfirstlane(ty0_ * yrow + tx0_ * ypix);                                \
+    const int pb_ = __builtin_amdgcn_readfirstlane(POOL ? (ty0_ >> 1) * prow + (tx0_ >> 1) * ppix : ty0_ * prow + tx0_ * ppix + a.dout_co * 4); \
+    /* ONE set of load instructions for interior and border tiles (the branches only pick the offsets): with the loads inside  */ \
+    /* the branches hipcc guards the interior block's first register writes with vmcnt waits for the OTHER block's loads        */ \
+    unsigned xvo_[NX];                                                                                        \
+    int xso_ = 0;                                                                                             \
     if (nxt_inside) {                                                                                         \
-      const int xb_ = (ty0_ - 1) * xrow + (tx0_ - 1) * xpix;                                                  \
-      _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                          \
-        xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, sO[i * 512], xb_, 0)); \
+      xso_ = __builtin_amdgcn_readfirstlane((ty0_ - 1) * xrow + (tx0_ - 1) * xpix);                           \
+      _Pragma("unroll") for (int i = 0; i < NX; ++i) xvo_[i] = sO[i * 512];                                   \
       xmask = sO[(2 * NX + 8) * 512];                                                                         \
     } else {                                                                                                  \
       xmask = 0;                                                                                              \
@@ -161,11 +199,12 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
         const unsigned rc_ = sO[(NX + i) * 512];                                                              \
         const int gy = ty0_ - 1 + (int)(rc_ >> 16), gx = tx0_ - 1 + (int)(rc_ & 0xFFFFu);                     \
         const bool ok = rc_ != 0xFFFFFFFFu && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   \
-        xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                            \
-            rx_, ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB, 0, 0));                                   \
+        xvo_[i] = ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB;                                          \
         xmask |= (ok ? 1u : 0u) << i;                                                                         \
       }                                                                                                       \
     }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                            \
+      xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, xvo_[i], xso_, 0));      \
     if (POOL) {                                                                                               \
       unsigned yo_ = sO[(2 * NX) * 512], po_ = sO[(2 * NX + 1) * 512];                                        \
       /* H and W are even: a window is inside the map or outside as a whole */                               \
@@ -198,11 +237,21 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
   const float c1 = irow == 0 ? 0.f : irow == 1 ? 1.f : -1.f;
 
   __syncthreads();  // sF / sS
-  if (t_begin < t_end) WGF_ISSUE(t_begin)
+  if (t_begin < t_end) WGF_ISSUE()
+#if WGF_TRACE
+  unsigned long long tc_[5] = {0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter();
+  const unsigned long long tk0_ = tp_, tr0_ = __builtin_amdgcn_s_memrealtime();   // (s_memrealtime: the constant 100 MHz counter)
+#define WGF_T(K) { const unsigned long long tn_ = __builtin_readcyclecounter(); tc_[K] += tn_ - tp_; tp_ = tn_; }
+#else
+#define WGF_T(K)
+#endif
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // all waves finished reading the previous tile's LDS image
+    WGF_T(0)
+    // the walker stands on this tile (its loads were issued one iteration ago); the dY stores below use its coordinates and the
+    // y descriptor's image (ry_ belongs to the same image: dY shares y's geometry)
+    const int cur_prob = w_prob, cur_n = w_n, cur_ty0 = w_ty0, cur_tx0 = w_tx0;
     {
-      const int cur_prob = tile >= a.ntiles ? 1 : 0;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (IN_MODE != 0) {
         sc = *reinterpret_cast<const f32x4*>(sS + cur_prob * 128 + q16 * 4);
@@ -264,9 +313,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
       }
       // dY for the data-gradient convolution of this layer (every tile exactly once: the blocks of input-channel block 0)
       if (cib == 0) {
-        const int tl = tile - cur_prob * a.ntiles;
-        const int tx_i = tl % a.tiles_x, t2 = tl / a.tiles_x;
-        const int ty0 = (t2 % a.tiles_y) * G::TH, tx0 = tx_i * G::TW, n = t2 / a.tiles_y;
+        const int ty0 = cur_ty0, tx0 = cur_tx0, n = cur_n;
         const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
             a.f_dy[cur_prob] + (size_t)n * a.H * a.W * a.f_ycs, 0, a.H * yrow, 0x00020000);
         const int yb = ty0 * yrow + tx0 * ypix;
@@ -284,12 +331,17 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
         }
       }
     }
+    WGF_T(1)
     __syncthreads();
+    WGF_T(2)
     {
-      const int nxt = min(tile + 1, t_end - 1);  // unconditional prefetch (redundant on the last tile)
-      WGF_ISSUE(nxt)
+      // (sliced between the MFMA steps instead - tile state behind step 0, the loads behind steps 1 - 7 - the MFMA phase grew by more
+      // than this phase is long: 27.1 k instead of 25.0 k cycles per tile, profiles/r05_wgf_phase_trace.txt)
+      if (tile + 1 < t_end) walk();  // unconditional prefetch (the last tile loads itself again)
+      WGF_ISSUE()
       __builtin_amdgcn_sched_barrier(0);
     }
+    WGF_T(3)
     {
       // lane bases: channel pair 2 li of the raw rows ra / rb, tile column offset of the lane half; dY column of this lane
       const float* xa0 = sX + (ra * G::WT + 2 * lh) * 64 + 2 * li;
@@ -356,7 +408,18 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
         }
       }
     }
+    WGF_T(4)
   }
+#if WGF_TRACE
+  if (a.trace != nullptr && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a.trace[wave * 8 + k] = tc_[k];
+    a.trace[wave * 8 + 5] = __builtin_readcyclecounter() - tk0_;
+    a.trace[wave * 8 + 6] = (unsigned long long)(t_end - t_begin);
+    a.trace[wave * 8 + 7] = __builtin_amdgcn_s_memrealtime() - tr0_;   // loop cycles / this = shader clock / 100 MHz
+  }
+#endif
+#undef WGF_T
 #undef WGF_ISSUE
   // partial slab: [blk][component][ci 64][co 64]; M-tile e, row m <-> input channel 2 m + e
   float* dst = a.partial + (size_t)blockIdx.x * WC * 4096;
