@@ -8,6 +8,11 @@
 // tiles of both views, writes ONE fp32 partial slab; wgrad_reduce_kernel sums the slabs into the OIHW gradient.
 // LDS: X halo 18 x 18 pixels x 128 B + dY tile 256 x 128 B; the two 64-byte halves of a pixel slot are swapped when bit 1
 // of the slot index is set, which makes the four pixel rows of a transposing read hit four distinct bank quarters.
+// Two workgroups per CU (78 KB each): one's staging / activation runs under the other's MFMA phase.  The kernel is bound by
+// instruction issue (round 5: 2155 -> ~870 instructions per tile and wave for the same 144 MFMAs, PERF_LOG 5c): the 3x3 MFMA loop
+// walks the HALO rows - one X fragment per (halo row, column shift) feeds the three taps above each other - , the activation
+// runs at constant addresses in the forward kernel's 20 vector instructions per 8 values, and tiles whose halo lies inside the
+// map are staged without per-slot coordinates or bounds.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
