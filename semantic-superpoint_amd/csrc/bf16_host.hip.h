@@ -179,16 +179,25 @@ struct WgradBCall {
   float* dw = nullptr;  // OIHW gradient, accumulated
   int nviews = 1, N = 0, H = 0, W = 0, ks = 3, in_mode = 0;
   bool dy_f32 = false;
+  // fuse 1 / 2: the APPLY pass of this layer's BatchNorm + ReLU (+ MaxPool) backward rides the dY staging (WgradBArgs::f_*); dy = the
+  // tensor the kernel WRITES dY to (for the data gradient), f_y / f_dout what it reads
+  int fuse = 0;
+  const void* f_y[2] = {nullptr, nullptr}; const void* f_dout[2] = {nullptr, nullptr};
+  const float* f_scale[2] = {nullptr, nullptr}; const float* f_shift[2] = {nullptr, nullptr}; const float* f_mean[2] = {nullptr, nullptr};
+  const float* f_invstd[2] = {nullptr, nullptr}; const float* f_k12[2] = {nullptr, nullptr}; const float* f_gamma = nullptr;
+  int f_dcs = 0, f_dco = 0;
 };
 
-template <int KS, int IN_MODE, bool DY_F32>
+template <int KS, int IN_MODE, bool DY_F32, int FUSE = 0>
 static int launch_wgrad_bf16_t(const WgradBArgs& a, int nblocks, hipStream_t st) {
   using G = WgradBGeom<KS>;
   static AttrOnce attr_once;
-  auto kern = wgrad_bf16_kernel<KS, IN_MODE, DY_F32>;
+  auto kern = wgrad_bf16_kernel<KS, IN_MODE, DY_F32, FUSE>;
+  constexpr int lds = G::LDS_BYTES + (FUSE != 0 ? G::P_BYTES : 0);
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   if (attr_once.need())
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS_BYTES, st, a);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -245,11 +254,26 @@ static int launch_wgrad_bf16(const WgradBCall& c, float* partial, size_t partial
     queue->used += need;
   }
   const int nblocks = pairs * (int)nsplit;
+  if (c.fuse != 0) {
+    if (c.ks != 3 || c.dy_f32 || (c.fuse != 1 && c.fuse != 2) || !c.f_y[0] || !c.f_dout[0] || !c.f_gamma || !c.f_k12[0])
+      return fail(-3, "bf16 wgrad: the fused BatchNorm-backward APPLY needs a 3x3 layer with bf16 dY and its y / dOut / parameters");
+    if (c.fuse == 2 && ((c.H | c.W) & 1)) return fail(-3, "bf16 wgrad: fused pooled APPLY on an odd map");
+    if (c.f_dcs % 8 || c.f_dco % 8) return fail(-3, "bf16 wgrad: dOut channel stride / offset must be multiples of 8");
+    for (int k = 0; k < 2; ++k) {
+      a.f_y[k] = c.f_y[k]; a.f_dout[k] = c.f_dout[k]; a.f_dy[k] = const_cast<void*>(c.dy[k]); a.f_scale[k] = c.f_scale[k];
+      a.f_shift[k] = c.f_shift[k]; a.f_mean[k] = c.f_mean[k]; a.f_invstd[k] = c.f_invstd[k]; a.f_k12[k] = c.f_k12[k];
+    }
+    a.f_gamma = c.f_gamma; a.f_dcs = c.f_dcs; a.f_dco = c.f_dco;
+  }
 #define WGB_CASE(KS_, M_, F_) \
-  if (c.ks == KS_ && c.in_mode == M_ && c.dy_f32 == F_) { CHK((launch_wgrad_bf16_t<KS_, M_, F_>(a, nblocks, st))); } else
+  if (c.ks == KS_ && c.in_mode == M_ && c.dy_f32 == F_ && c.fuse == 0) { CHK((launch_wgrad_bf16_t<KS_, M_, F_>(a, nblocks, st))); } else
+#define WGB_FCASE(M_, FU_) \
+  if (c.ks == 3 && c.in_mode == M_ && !c.dy_f32 && c.fuse == FU_) { CHK((launch_wgrad_bf16_t<3, M_, false, FU_>(a, nblocks, st))); } else
+  WGB_FCASE(1, 1) WGB_FCASE(1, 2) WGB_FCASE(0, 1) WGB_FCASE(0, 2)
   WGB_CASE(3, 1, false) WGB_CASE(3, 0, false) WGB_CASE(1, 1, true)
   return fail(-3, "bf16 wgrad: unsupported variant ks=%d in_mode=%d dy_f32=%d", c.ks, c.in_mode, (int)c.dy_f32);
 #undef WGB_CASE
+#undef WGB_FCASE
   if (queue != nullptr) return 0;
   const int total = c.cout * c.cin * taps;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, c.dw, c.cin, c.cout, c.ks, a.ncob, a.nsplit);

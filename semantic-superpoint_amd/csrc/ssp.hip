@@ -2028,6 +2028,10 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       HIPCHK(hipGetLastError());
       continue;
     }
+    // pass 2 (APPLY) rides the layer's weight gradient (wgrad_bf16_kernel<.., FUSE>; SSP_BF16_FUSE_APPLY=0: the separate pass)
+    const char* const fuse_s = getenv("SSP_BF16_FUSE_APPLY");   // (read per call: tests switch it between two steps of one process)
+    const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
+    const bool fuse_apply = fuse_env != 0 && C % 8 == 0 && (!pool_after || ((lh | lw) & 1) == 0);
     if (pool_after) {
       // pass 1 from the raw pooled copy: the arg-max of z over a window IS that element (max for gamma >= 0, min for gamma < 0), so
       // the ReLU-layer sums over the quarter-size tensors (Apool, dOut) equal the window-routed sums over Y; channels with
@@ -2045,9 +2049,9 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       if (!sums_fused)
         hipLaunchKernelGGL((bn_bwd_kernel<true, false, false, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[SS.n - 1]);
       hipLaunchKernelGGL(bn_bwd_sums_kernel<uint16_t>, dim3(cdiv(C * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
-      hipLaunchKernelGGL((bn_bwd_kernel<true, true, true, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
+      if (!fuse_apply) hipLaunchKernelGGL((bn_bwd_kernel<true, true, true, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
       HIPCHK(hipGetLastError());
-    } else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st, sums_fused)));
+    } else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st, sums_fused, fuse_apply)));
     // weight gradient: X = (pooled) raw output of layer l - 1 under its BatchNorm + ReLU, dY = gQ
     const int src = l - 1;
     const bool pooled_in = layer_in_mode(l) == 2;
@@ -2063,6 +2067,14 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       if (src >= 5 && S0.act_valid[src] && SS.s[SS.n - 1]->act_valid[src]) {   // the forward materialised this layer's activated input
         w.in_mode = 0;
         for (int k = 0; k < SS.n; ++k) w.x[k] = SS.s[k]->act[src];
+      }
+      if (fuse_apply) {
+        w.fuse = pool_after ? 2 : 1; w.f_gamma = P(h, d.g_off); w.f_dcs = C; w.f_dco = 0;
+        for (int k = 0; k < SS.n; ++k) {
+          Slot& S = *SS.s[k];
+          w.f_y[k] = S.Y[l]; w.f_dout[k] = S.gP; w.f_scale[k] = S.bn[l].scale; w.f_shift[k] = S.bn[l].shift; w.f_mean[k] = S.bn[l].mean;
+          w.f_invstd[k] = S.bn[l].invstd; w.f_k12[k] = S.bn[l].k12;
+        }
       }
       const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
       ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_WGRAD_BF16);

@@ -237,6 +237,53 @@ def test_bf16_pair_step_vs_bf16_oracle(arch):
     assert (e.eta.cpu() - tr.eta.detach()).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("arch,B,H,W", [("SuperPointNet_gauss2_ssmall", 2, 120, 160), ("SuperPointNet_gauss2", 2, 240, 320),
+                                        ("SuperPointNet_gauss2", 1, 72, 104)])
+def test_bf16_apply_pass_fused_into_the_weight_gradient_equals_the_separate_pass(arch, B, H, W, monkeypatch):
+    """Pass 2 (APPLY) of every encoder layer's BatchNorm + ReLU (+ MaxPool) backward rides the layer's weight gradient
+    (wgrad_bf16_kernel<.., FUSE>, SSP_BF16_FUSE_APPLY, default on); bn_bwd_kernel<true, POOL, true, uint16_t> is the separate pass.
+    Same inputs, same engine, the switch toggled between steps, under the bit-reproducible accumulation (so that two steps of ONE
+    form are bit-identical - asserted - and the comparison sees the forms, not the order of the atomics).  dY = gs (dZ - S1/n -
+    xhat S2/n) is evaluated as gs dZ + (P y + Q) in the fused form: single bf16 values of dY round to the other neighbour, and
+    every layer below re-quantises what it inherits - a relative difference eps in a gradient tensor flips eps / ulp of its elements
+    by one ulp when it is stored as bf16, i.e. leaves sqrt(eps ulp) behind, which converges to the ulp (4e-3) within a few layers however
+    small it starts.  Bound per gradient tensor: 2e-2 rel-L2 and cosine >= 0.9999 (measured 9e-4 .. 8e-3 on the first layers; the
+    path's own accumulation-order floor is 1e-2, module docstring); the scalars are identical (forward and losses do not depend on the switch).  72x104: ragged tiles
+    (4.5 x 6.5), odd 9x13 maps under the plain form; 240x320: interior tiles of the staging path without bounds."""
+    from semantic_superpoint_amd import lib as L
+    semantic = arch.endswith("ssmall")
+    sd = C.init_state_dict(arch, seed=12)
+    sample = C.make_synthetic_pair(B, H, W, seed=6, semantic=semantic, kp_prob=0.005)
+    L.set_deterministic(True)
+    try:
+        e = _engine(arch, B, H, W, sd)
+        idx = e.sample_indices(_to_dev(sample)["homographies"], seed=5)
+        out = []
+        for mode in ("1", "0", "1"):
+            monkeypatch.setenv("SSP_BF16_FUSE_APPLY", mode)
+            e.zero_grad()
+            sc = e.pair_step(_to_dev(sample), indices=idx, train=True)
+            torch.cuda.synchronize()
+            out.append((sc.cpu().clone(), {k: v.cpu().clone() for k, v in e.grad_dict().items()}))
+        del e
+    finally:
+        L.set_deterministic(False)
+    assert torch.equal(out[0][0], out[1][0])
+    for k, g in out[0][1].items():
+        assert torch.equal(g, out[2][1][k]), k   # the fused form twice: bit-identical
+    worst = (0.0, None)
+    for k, g in out[0][1].items():
+        r = out[1][1][k]
+        if float(r.abs().max()) < 1e-6 and float(g.abs().max()) < 1e-6:   # conv bias under BatchNorm: 0 + noise
+            continue
+        err = _rel_l2(g, r)
+        cos = float((g.double().flatten() @ r.double().flatten()) / (g.double().norm() * r.double().norm() + 1e-30))
+        if err > worst[0]:
+            worst = (err, k)
+        assert err < 2e-2 and cos >= 0.9999, (k, err, cos)
+    print("fused vs separate APPLY pass, %s %dx%d: worst per-tensor gradient rel-L2 %.2e (%s)" % (arch, H, W, worst[0], worst[1]))
+
+
 def test_bf16_path_at_the_benchmark_size():
     """B = 32, 240x320, SSp - the shape bench.py --dtype bf16 measures, bench.py's inputs and device-sampled indices: the scalars
     against the bf16 oracle fed with the SAME indices (one oracle step ~ 30 s on the GPU host), the flat gradient's direction, and ten
