@@ -2155,6 +2155,10 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
   }
   // ---- 3x3 heads ----
   const int heads[3] = {L_PA, L_DA, L_DS};
+  // pass 2 (APPLY) of their BatchNorm + ReLU backward rides their weight gradients (as in encoder_backward_bf16): y, dOut and dY are
+  // the head's 256-channel slice of [cells][256 heads] tensors
+  const char* const heads_fuse_s = getenv("SSP_BF16_FUSE_APPLY");
+  const bool heads_fuse = heads_fuse_s ? atoi(heads_fuse_s) != 0 : true;
   for (int hk = 0; hk < h->nheads; ++hk) {
     const LayerDesc& d = h->L[heads[hk]];
     BnBwdArgs a[2];
@@ -2168,7 +2172,7 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
       v.N = N; v.H = Hc; v.W = Wc; v.C = 256; v.y_cs = hcs; v.y_co = 256 * hk; v.d_cs = hcs; v.d_co = 256 * hk;
       v.dy_cs = hcs; v.dy_co = 256 * hk; v.count = (double)ncells; v.k12 = S.bn[l].k12;
     }
-    CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, Gd(h, d.g_off), Gd(h, d.be_off), st)));
+    CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, Gd(h, d.g_off), Gd(h, d.be_off), st, false, heads_fuse)));
   }
   for (int hk = 0; hk < h->nheads; ++hk) {
     const LayerDesc& d = h->L[heads[hk]];
@@ -2180,6 +2184,15 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     for (int k = 0; k < SS.n; ++k) {
       Slot& S = *SS.s[k];
       w.x[k] = from_act7 ? S.act[7] : S.Y[7]; w.dy[k] = S.gQ; w.x_scale[k] = S.bn[7].scale; w.x_shift[k] = S.bn[7].shift;
+    }
+    if (heads_fuse) {
+      const int l = heads[hk];
+      w.fuse = 1; w.f_gamma = P(h, d.g_off); w.f_dcs = hcs; w.f_dco = 256 * hk;
+      for (int k = 0; k < SS.n; ++k) {
+        Slot& S = *SS.s[k];
+        w.f_y[k] = S.Y[l]; w.f_dout[k] = S.gP; w.f_scale[k] = S.bn[l].scale; w.f_shift[k] = S.bn[l].shift; w.f_mean[k] = S.bn[l].mean;
+        w.f_invstd[k] = S.bn[l].invstd; w.f_k12[k] = S.bn[l].k12;
+      }
     }
     const double flops = 2.0 * SS.n * ncells * 128.0 * 256 * 9;
     ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * ncells * (128.0 + 256.0), flops, SSP_PROF_K_WGRAD_BF16);
