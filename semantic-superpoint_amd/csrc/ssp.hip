@@ -2203,9 +2203,22 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
   c.in_cs = hcs; c.in_co = 0; c.cin = hcs; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_heads_bwd);
   c.out_cs = 128; c.out_co = 0; c.cout = 128;
   for (int k = 0; k < SS.n; ++k) { c.in[k] = SS.s[k]->gQ; c.out[k] = SS.s[k]->gP; }
+  // pass 1 of layer 7's BatchNorm backward in this launch's copy-out (its output IS dOut of layer 7), as between the encoder layers
+  static const int bnr_env = getenv("SSP_BF16_BNR") ? atoi(getenv("SSP_BF16_BNR")) : 1;
+  const bool bnr = bnr_env != 0 && launch_conv_bf16_is_ws(c);
+  if (bnr) {
+    for (int k = 0; k < SS.n; ++k) {
+      Slot& S = *SS.s[k];
+      c.bnr_t[k] = reinterpret_cast<const uint16_t*>(S.Y[7]);
+      c.bnr_scale[k] = S.bn[7].scale; c.bnr_shift[k] = S.bn[7].shift; c.bnr_mean[k] = S.bn[7].mean;
+      c.bnr_invstd[k] = S.bn[7].invstd; c.bnr_sums[k] = S.bn[7].bsums;
+    }
+  }
   const double flops = 2.0 * SS.n * ncells * (double)hcs * 128 * 9;
   ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, 2.0 * SS.n * ncells * (hcs + 128.0), flops, SSP_PROF_K_CONV_BF16);
-  return launch_conv_bf16(c, h->n_cu, st);
+  CHK(launch_conv_bf16(c, h->n_cu, st));
+  if (bnr) h->bsums_fused[7] = true;
+  return 0;
 }
 
 // dsemi[k]: [cells][80] grad wrt semi (post bnPb); draw_desc[k]: [cells][256] grad wrt bnDb output (pre-normalisation);
