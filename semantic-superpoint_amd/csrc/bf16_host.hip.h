@@ -97,8 +97,10 @@ static int launch_conv_bf16(const ConvBCall& c, int n_cu, hipStream_t st) {
   static const int ws_env = getenv("SSP_CONVB_WS") ? atoi(getenv("SSP_CONVB_WS")) : 1;
   const bool ws_ok = ws_env != 0 && c.ks == 3 && !c.in_f32 && !c.out_f32 && a.nchunks >= 2 && a.nchunks % 2 == 0 && c.cin % CB_KC == 0 &&
                      !(c.in_mode == 0 && c.bias != nullptr);   // (the staging-free form is the data gradient: no bias path)
-  if (c.bnr_t[0] != nullptr && !(ws_ok && c.in_mode == 0 && c.out_co == 0 && c.out_cs == c.cout && !c.stats[0]))
-    return fail(-3, "bf16 conv: the fused BatchNorm-backward sums ride the wave-specialised data-gradient form with a dense output only");
+  // fused BatchNorm-backward sums: the wave-specialised data-gradient form with a dense output, or the generic kernel with a bf16 output
+  // (there the tensor of the layer below has the geometry of the output: out_cs, out_co) - never beside forward statistics
+  if (c.bnr_t[0] != nullptr && (c.stats[0] || c.out_f32 || (ws_ok && !(c.in_mode == 0 && c.out_co == 0 && c.out_cs == c.cout))))
+    return fail(-3, "bf16 conv: the fused BatchNorm-backward sums need a bf16 output without forward statistics (wave-specialised form: dense output)");
   if (ws_ok) {
     int nb = (int)std::min<long>((long)n_cu, cdiv(units, 8) * 8L) / 8 * 8;
     nb = std::max(nb, 8);

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
   auto flush_stats = [&](int key) {
     // block reduction of the per-thread sums over the threads with the same channel item, then fp64 atomics
     const int view = key / a.ncob, cob = key - view * a.ncob;
-    double* const p_stats = a.stats[view];
+    const bool grad = a.bnr_t[0] != nullptr;   // fused BatchNorm-backward sums (below): S1, S2 of the layer below instead of statistics
+    double* const p_stats = grad ? a.bnr_sums[view] : a.stats[view];
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < CPT; ++e) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
       for (int k = item; k < 256; k += TPP) t += (double)s_red[k * 17 + which * 8 + e];
       const int co = cob * CB_NB + ch;
       if (co < a.Cout && p_stats != nullptr)
-        acc_add_stats(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, t);
+        acc_add_stats_or_grad(p_stats + (size_t)(blockIdx.x % NREP) * 2 * a.Cout + which * a.Cout + co, t, grad);
     }
   };
 
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
     // the stage being staged and computed now: unit u, `chunk`
     const int view = ld_view, cob = ld_cob, n = ld_n, ty0 = ld_ty0, tx0 = ld_tx0;
     if (chunk == 0) {
-      if (a.stats[0] != nullptr && ld_vc != st_key) {
+      if ((a.stats[0] != nullptr || a.bnr_t[0] != nullptr) && ld_vc != st_key) {
         if (st_key >= 0) flush_stats(st_key);
         st_key = ld_vc;
       }
@@ -407,12 +408,45 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
         f32x2 ps[4], pq[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ps[e] = f32x2{st_s[2 * e], st_s[2 * e + 1]}; pq[e] = f32x2{st_q[2 * e], st_q[2 * e + 1]}; }
+        // Fused BatchNorm-backward reduction (ConvBArgs::bnr_*, as in conv_bf16_ws_kernel: this launch is a data gradient, its output
+        // is dOut of the layer below, whose raw bf16 output t has the geometry of the output tensor): S1 += dz, S2 += dz xhat of the
+        // STORED values, dz = [t scale + shift > 0] dOut, xhat = (t - mean) invstd.  t in two batches of four rows.
+        const bool do_bnr = a.bnr_t[0] != nullptr;
+        f32x2 b_sc[4], b_sh[4], b_mu[4], b_is[4];
+        u32x4 tv[4];
+        __amdgpu_buffer_rsrc_t rsrc_t = rsrc_out;
+        if (do_bnr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = min(co0 + e, a.Cout - 1);
+            b_sc[e >> 1][e & 1] = a.bnr_scale[view][c]; b_sh[e >> 1][e & 1] = a.bnr_shift[view][c];
+            b_mu[e >> 1][e & 1] = a.bnr_mean[view][c]; b_is[e >> 1][e & 1] = a.bnr_invstd[view][c];
+          }
+          rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.bnr_t[view])) + (size_t)n * out_img_bytes, 0, out_img_bytes, 0x00020000);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int lp = (tid >> 3) + 32 * k;
+          if (do_bnr && (k & 3) == 0) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) tv[kk] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, vo, rstep * (k + kk), 0));
+          }
           u32x4 v = *reinterpret_cast<const u32x4*>(sO + lp * CB_OS_BF16 + item * 16);
           ssp_store_b128(v, rsrc_out, vo, rstep * k);
-          if (do_stats) {
+          if (do_bnr) {
+            const bool ok = col_ok && (full || ty0 + row0 + 2 * k < a.H);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t w = ok ? v[e] : 0u, yb = tv[k & 3][e];
+              const f32x2 d2 = {bf16_lo(w), bf16_hi(w)}, y2 = {bf16_lo(yb), bf16_hi(yb)};
+              const f32x2 z2 = pk_fma(y2, b_sc[e], b_sh[e]);
+              const f32x2 dz = {z2[0] > 0.f ? d2[0] : 0.f, z2[1] > 0.f ? d2[1] : 0.f};
+              const f32x2 xh = pk_mul(pk_sub(y2, b_mu[e]), b_is[e]);
+              ps[e] = pk_add(ps[e], dz);
+              pq[e] = pk_fma(dz, xh, pq[e]);
+            }
+          } else if (do_stats) {
             const bool ok = col_ok && (full || ty0 + row0 + 2 * k < a.H);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -484,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBArgs a) {
     }
     if (done) break;
   }
-  if (a.stats[0] != nullptr && st_key >= 0) flush_stats(st_key);
+  if ((a.stats[0] != nullptr || a.bnr_t[0] != nullptr) && st_key >= 0) flush_stats(st_key);
 }
 
 // OIHW fp32 weights -> bf16 operand image of conv_bf16_kernel: [cob][chunk32][tap][kstep 2][mtile 2][lane 64][8]:

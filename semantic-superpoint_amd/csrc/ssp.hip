@@ -2128,13 +2128,23 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     c.nviews = SS.n; c.N = N; c.H = Hc; c.W = Wc; c.ks = 1; c.in_mode = 0; c.in_f32 = true;
     c.in_cs = dy_cs; c.in_co = 0; c.cin = d.cout; c.wpk = reinterpret_cast<const uint16_t*>(h->wpk_bwd + d.pk_bwd);
     c.out_cs = hcs; c.out_co = co; c.cout = 256;
+    // pass 1 of the 3x3 head's BatchNorm backward in this data gradient's copy-out (its output is dOut of that head; the head's raw
+    // output has the output's geometry: its 256-channel slice of [cells][256 heads])
+    static const int bnr_env = getenv("SSP_BF16_BNR") ? atoi(getenv("SSP_BF16_BNR")) : 1;
     for (int k = 0; k < SS.n; ++k) {
       Slot& S = *SS.s[k];
       w.x[k] = S.Y[src]; w.dy[k] = dy[k]; w.x_scale[k] = S.bn[src].scale; w.x_shift[k] = S.bn[src].shift;
       c.in[k] = dy[k]; c.out[k] = S.gP;
+      if (bnr_env != 0) {
+        c.bnr_t[k] = reinterpret_cast<const uint16_t*>(S.Y[src]);
+        c.bnr_scale[k] = S.bn[src].scale; c.bnr_shift[k] = S.bn[src].shift; c.bnr_mean[k] = S.bn[src].mean;
+        c.bnr_invstd[k] = S.bn[src].invstd; c.bnr_sums[k] = S.bn[src].bsums;
+      }
     }
     CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st, h->rq_bf16));
-    return launch_conv_bf16(c, h->n_cu, st);
+    CHK(launch_conv_bf16(c, h->n_cu, st));
+    if (bnr_env != 0) h->bsums_fused[src] = true;
+    return 0;
   };
   if (has_semi) {
     CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQs, 80, 0, N, Hc, Wc, st));
@@ -2172,7 +2182,9 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
       v.N = N; v.H = Hc; v.W = Wc; v.C = 256; v.y_cs = hcs; v.y_co = 256 * hk; v.d_cs = hcs; v.d_co = 256 * hk;
       v.dy_cs = hcs; v.dy_co = 256 * hk; v.count = (double)ncells; v.k12 = S.bn[l].k12;
     }
-    CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, Gd(h, d.g_off), Gd(h, d.be_off), st, false, heads_fuse)));
+    const bool sums_fused = h->bsums_fused[heads[hk]];
+    h->bsums_fused[heads[hk]] = false;
+    CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, Gd(h, d.g_off), Gd(h, d.be_off), st, sums_fused, heads_fuse)));
   }
   for (int hk = 0; hk < h->nheads; ++hk) {
     const LayerDesc& d = h->L[heads[hk]];
