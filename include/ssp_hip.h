@@ -117,6 +117,10 @@ const char* ssp_build_id(void);
  * reference has no counterpart (torch.use_deterministic_algorithms is never set: train4.py). */
 int ssp_set_deterministic(int on);
 int ssp_get_deterministic(void);
+/* Measurement aid (no counterpart in the reference): the shader clock in MHz that the device sustains while every CU runs
+ * fp32 matrix-core instructions for ~`ms` milliseconds on `stream` (blocking).  bench.py reports it before and after the timed
+ * region: the boxes of a pool differ in the clock their power controller grants. */
+int ssp_clock_probe(float ms, double* mhz_out, void* stream);
 int ssp_create(const ssp_config* cfg, ssp_handle** out);
 void ssp_destroy(ssp_handle* h);
 size_t ssp_param_count(const ssp_handle* h);       /* net parameters (without eta) */

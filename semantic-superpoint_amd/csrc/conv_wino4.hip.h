@@ -249,31 +249,31 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #define W4_HALO_BN(K, SET) if (IN_MODE != 0 && !(W4_ABL & 4)) hreg##SET[K] = bn_relu_quad(hreg##SET[K], psc, psh, (h_pad##SET >> (K)) & 1u);
 #define W4_HALO_WR(K, SET) if (!(W4_ABL & 4) && ((K) < NH - 1 || r4)) *reinterpret_cast<f32x4*>(sR + r_lds[K]) = hreg##SET[K];
 
-  // ---- transform roles: wave w computes row w (and, waves 0 / 1, row w + 4) of V = B^T d B for (tile, channel quad) =
-  // (tid >> 1) & 31, tid & 1:   T[c] = k0 d[r0][c] + k1 d[r0+1][c] + k2 d[r0+2][c] + d[rl][c]
-  //   row 0: r0 0, rl 4, k ( 4,  0, -5)   row 1: r0 1, rl 4, k (-4, -4,  1)   row 2: r0 1, rl 4, k ( 4, -4, -1)
-  //   row 3: r0 1, rl 4, k (-2, -1,  2)   row 4: r0 1, rl 4, k ( 2, -1, -2)   row 5: r0 1, rl 5, k ( 4,  0, -5)
-  // second row: waves 2 and 3 recompute rows 4 and 5 as well (identical values, benign double writes): they would wait at
-  // the stage barrier anyway, and twelve wave-uniform branches per stage around the slices cost the waves that do need
-  // the row more (~16 cycles each) than the duplicated LDS traffic costs anybody
+  // ---- transform roles (round 6): V = B^T d B per (tile, channel quad) = (tid >> 1) & 31, tid & 1; the six rows of V are shared by
+  // the four waves as TASKS with common subexpressions instead of one row + a duplicated second row per wave (8 row transforms for
+  // 6 rows, 3 fma per raw column and row):
+  //   wave 0: rows 1 & 2     p = d4 - 4 d2, q = d3 - 4 d1:   T1 = p + q,   T2 = p - q      (4 packed quad operations per column
+  //   wave 1: rows 3 & 4     p = d4 -   d2, q = d3 -   d1:   T3 = p + 2 q, T4 = p - 2 q     for two rows: raw rows 1..4)
+  //   wave 2: row 0          T0 = 4 d0 - 5 d2 + d4                                          (2 per column: raw rows 0, 2, 4)
+  //   wave 3: row 5          T5 = 4 d1 - 5 d3 + d5                                          (raw rows 1, 3, 5)
+  // followed by the row pass V[r][.] = T[r][.] B per row (12 quad operations).  Critical wave: 96 packed instructions + 24 LDS
+  // reads per stage instead of 130 + 48; waves 2, 3 (48 + 18) wait at barrier A.
   constexpr bool twB = !(W4_ABL & 2);
   const int t_tile = (tid >> 1) & 31;
   int t_ty, t_tx;
   w4_tile_xy<WIDE>(t_tile, t_ty, t_tx);
-  const int t_r0 = wave == 0 ? 0 : 1;
+  const bool t_pair = wave < 2;                       // wave-uniform task kind
+  const int t_r0 = wave == 2 ? 0 : 1;                 // first raw row read
+  const int t_row = wave == 0 ? 1 : wave == 1 ? 3 : wave == 2 ? 0 : 5;   // (first) V row written
   // (readfirstlane: the coefficients must reach the packed fmas in scalar register pairs, not in per-lane selects)
 #define W4_UNI(X) __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (X))))
-  const float ka0 = W4_UNI(wave == 1 ? -4.f : wave == 3 ? -2.f : 4.f);
-  const float ka1 = W4_UNI(wave == 0 ? 0.f : wave == 3 ? -1.f : -4.f);
-  const float ka2 = W4_UNI(wave == 0 ? -5.f : wave == 1 ? 1.f : wave == 2 ? -1.f : 2.f);
-  const float kb0 = W4_UNI((wave & 1) == 0 ? 2.f : 4.f);   // row 4 (even waves) / row 5 (odd waves)
-  const float kb1 = W4_UNI((wave & 1) == 0 ? -1.f : 0.f);
-  const float kb2 = W4_UNI((wave & 1) == 0 ? -2.f : -5.f);
+  const float kp_ = W4_UNI(wave == 0 ? -4.f : wave == 1 ? -1.f : -5.f);   // pair: p = d4 + kp d2 (= kq); single: -5
+  const float ks_ = W4_UNI(wave == 1 ? 2.f : 1.f);                        // pair: T = p +- ks q
+  const float kn_ = W4_UNI(wave == 1 ? -2.f : -1.f);
 #undef W4_UNI
-  const f32x2 tka0 = {ka0, ka0}, tka1 = {ka1, ka1}, tka2 = {ka2, ka2}, tkb0 = {kb0, kb0}, tkb1 = {kb1, kb1}, tkb2 = {kb2, kb2};
-  // second row: byte offsets of its first / last raw row against the first row's (wave 0: rows 1.. / 4; wave 1: rows 1.. / 5)
-  const int dAb = wave == 0 ? ROWF * 4 : 0, dLb = (wave & 1) ? ROWF * 4 : 0;
-  int t_ab[6];  // byte addresses of the first raw row read | of the last raw row read << 16
+  const f32x2 tkp = {kp_, kp_}, tks = {ks_, ks_}, tkn = {kn_, kn_};
+  const int dLb = wave == 3 ? ROWF * 4 : 0;           // row 5: its last raw row is row 5, not row 4
+  int t_ab[6];  // byte addresses of the first raw row read | of raw row 4 << 16
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     const int C = 4 * t_tx + c, Ra = 4 * t_ty + t_r0, Rb = 4 * t_ty + 4;
@@ -281,36 +281,78 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     const int tb_ = (Rb * PITCH + (C & ~7) + ((C + ((Rb >> 2) & 3)) & 7)) * PK + q2 * 4;
     t_ab[c] = (ta_ * 4) | ((tb_ * 4) << 16);
   }
-  const int t_dst = (wave * 6 * W4_TILES + t_tile) * PK + ((q2 ^ ((t_tile >> 3) & 1)) << 2);
-  const int DST_B = (4 + (wave & 1) - wave) * 6 * W4_TILES * PK;  // row 4 + (w & 1) against row w
+  const int t_dst = (t_row * 6 * W4_TILES + t_tile) * PK + ((q2 ^ ((t_tile >> 3) & 1)) << 2);
+  constexpr int DST_B = 6 * W4_TILES * PK;            // the pair's second row
 #define W4_LD(P) (*reinterpret_cast<const f32x4*>(P))
-  // raw pixels of column C into register set X, one MFMA slot ahead of their use (a second set, two slots ahead, and operands
-  // fetched two component pairs ahead instead of one measured the same: 0.745 vs 0.745 ms on one box)
-#define W4_TR_RD(X, C, DA, DL)                                                                              \
+  // raw pixels of column C, one MFMA slot ahead of their use: pair task rx0..3 = raw rows 1..4; single task rx0, rx1 = the two
+  // rows at distance 2 from the first one, rx3 = the last row (4 or 5)
+#define W4_TR_RD(C)                                                                                         \
   {                                                                                                         \
-    const char* pa_ = reinterpret_cast<const char*>(smem) + ((t_ab[C] & 0xffff) + (DA));                    \
-    X##0 = W4_LD(pa_); X##1 = W4_LD(pa_ + ROWF * 4); X##2 = W4_LD(pa_ + 2 * ROWF * 4);                      \
-    X##3 = W4_LD(reinterpret_cast<const char*>(smem) + (((unsigned)t_ab[C] >> 16) + (DL)));                 \
+    const char* pa_ = reinterpret_cast<const char*>(smem) + (t_ab[C] & 0xffff);                             \
+    rx0 = W4_LD(pa_); rx1 = W4_LD(pa_ + ROWF * 4); rx2 = W4_LD(pa_ + 2 * ROWF * 4);                         \
+    rx3 = W4_LD(reinterpret_cast<const char*>(smem) + ((unsigned)t_ab[C] >> 16));                           \
   }
-#define W4_TR_T(DST, X, K0, K1, K2) DST = pk4_fma_k(K2, X##2, pk4_fma_k(K1, X##1, pk4_fma_k(K0, X##0, X##3)));
-#define W4_TR_WR(DSTBUF, J, V) *reinterpret_cast<f32x4*>((DSTBUF) + t_dst + (J) * W4_TILES * PK) = (V);
-  // one V row, unsliced (prologue)
-#define W4_TRANSFORM_ROW(DSTBUF, DA, DL, K0, K1, K2)                                                        \
+#define W4_TR_RD3(C)                                                                                        \
   {                                                                                                         \
-    f32x4 T_[6];                                                                                            \
-    _Pragma("unroll") for (int c = 0; c < 6; ++c) {                                                         \
-      f32x4 x_0, x_1, x_2, x_3;                                                                             \
-      W4_TR_RD(x_, c, DA, DL)                                                                               \
-      W4_TR_T(T_[c], x_, K0, K1, K2)                                                                        \
+    const char* pa_ = reinterpret_cast<const char*>(smem) + (t_ab[C] & 0xffff);                             \
+    rx0 = W4_LD(pa_); rx1 = W4_LD(pa_ + 2 * ROWF * 4);                                                      \
+    rx3 = W4_LD(reinterpret_cast<const char*>(smem) + (((unsigned)t_ab[C] >> 16) + dLb));                   \
+  }
+  // column pass: pair -> TA##C, TB##C; single -> TA##C
+#define W4_PC(C) { const f32x4 p_ = pk4_fma_k(tkp, rx1, rx3), q_ = pk4_fma_k(tkp, rx0, rx2); TA##C = pk4_fma_k(tks, q_, p_); TB##C = pk4_fma_k(tkn, q_, p_); }
+#define W4_SC(C) TA##C = pk_fma_p44(rx0, pk4_fma_k(tkp, rx1, rx3));
+#define W4_TR_WR(DSTBUF, J, V) *reinterpret_cast<f32x4*>((DSTBUF) + t_dst + (J) * W4_TILES * PK) = (V);
+  // row pass of one V row from its six column-pass values T##0..T##5 (in four slices; a, c / b, e: even / odd columns)
+#define W4_RP_A(T, DSTBUF, TA_, TC_) { TC_ = pk4_sub(T##4, T##2); TA_ = pk_fma_m44(T##2, T##4); W4_TR_WR(DSTBUF, 0, pk_fma_p44(pk4_sub(T##0, T##2), TC_)) }
+#define W4_RP_B(T, DSTBUF) { te = pk4_sub(T##3, T##1); tb = pk_fma_m44(T##1, T##3); W4_TR_WR(DSTBUF, 5, pk_fma_m44(te, pk4_sub(T##5, T##3))) }
+#define W4_RP_C(TA_, TB_, DSTBUF) { W4_TR_WR(DSTBUF, 1, pk4_add(TA_, TB_)) W4_TR_WR(DSTBUF, 2, pk4_sub(TA_, TB_)) }
+#define W4_RP_D(TC_, TE_, DSTBUF) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(TE_, TC_)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(TE_, TC_)) }
+  // the slices of the two task kinds (S = slice number; the stage body puts one slice behind one MFMA, the prologue runs them
+  // back to back); row A's even-column values (ta, tc) stay live across the odd columns, row B's go through ta2, tc2
+#define W4_PSL(S, DSTBUF)                                                                                   \
+  if (twB) {                                                                                                \
+    if constexpr ((S) == 0) W4_TR_RD(0)                                                                     \
+    else if constexpr ((S) == 1) { W4_PC(0) W4_TR_RD(2) }                                                   \
+    else if constexpr ((S) == 2) { W4_PC(2) W4_TR_RD(4) }                                                   \
+    else if constexpr ((S) == 3) { W4_PC(4) W4_TR_RD(1) }                                                   \
+    else if constexpr ((S) == 4) W4_RP_A(TA, DSTBUF, ta, tc)                                                \
+    else if constexpr ((S) == 5) W4_RP_A(TB, (DSTBUF) + DST_B, ta2, tc2)                                    \
+    else if constexpr ((S) == 6) { W4_PC(1) W4_TR_RD(3) }                                                   \
+    else if constexpr ((S) == 7) { W4_PC(3) W4_TR_RD(5) }                                                   \
+    else if constexpr ((S) == 8) W4_PC(5)                                                                   \
+    else if constexpr ((S) == 9) W4_RP_B(TA, DSTBUF)                                                        \
+    else if constexpr ((S) == 10) W4_RP_C(ta, tb, DSTBUF)                                                   \
+    else if constexpr ((S) == 11) W4_RP_D(tc, te, DSTBUF)                                                   \
+    else if constexpr ((S) == 12) W4_RP_B(TB, (DSTBUF) + DST_B)                                             \
+    else if constexpr ((S) == 13) W4_RP_C(ta2, tb, (DSTBUF) + DST_B)                                        \
+    else if constexpr ((S) == 14) W4_RP_D(tc2, te, (DSTBUF) + DST_B)                                        \
+  }
+#define W4_SSL(S, DSTBUF)                                                                                   \
+  if (twB) {                                                                                                \
+    if constexpr ((S) == 0) W4_TR_RD3(0)                                                                    \
+    else if constexpr ((S) == 1) { W4_SC(0) W4_TR_RD3(2) }                                                  \
+    else if constexpr ((S) == 2) { W4_SC(2) W4_TR_RD3(4) }                                                  \
+    else if constexpr ((S) == 3) { W4_SC(4) W4_TR_RD3(1) }                                                  \
+    else if constexpr ((S) == 4) W4_RP_A(TA, DSTBUF, ta, tc)                                                \
+    else if constexpr ((S) == 5) { W4_SC(1) W4_TR_RD3(3) }                                                  \
+    else if constexpr ((S) == 6) { W4_SC(3) W4_TR_RD3(5) }                                                  \
+    else if constexpr ((S) == 7) W4_SC(5)                                                                   \
+    else if constexpr ((S) == 8) W4_RP_B(TA, DSTBUF)                                                        \
+    else if constexpr ((S) == 9) W4_RP_C(ta, tb, DSTBUF)                                                    \
+    else if constexpr ((S) == 10) W4_RP_D(tc, te, DSTBUF)                                                   \
+  }
+#define W4_XF_REGS f32x4 rx0, rx1, rx2, rx3, TA0, TA1, TA2, TA3, TA4, TA5, TB0, TB1, TB2, TB3, TB4, TB5, ta, tb, tc, te, ta2, tc2;
+  // the whole task, unsliced (prologue)
+#define W4_TRANSFORM_ALL(DSTBUF)                                                                            \
+  {                                                                                                         \
+    W4_XF_REGS                                                                                              \
+    if (t_pair) {                                                                                           \
+      W4_PSL(0, DSTBUF) W4_PSL(1, DSTBUF) W4_PSL(2, DSTBUF) W4_PSL(3, DSTBUF) W4_PSL(4, DSTBUF) W4_PSL(5, DSTBUF) W4_PSL(6, DSTBUF) W4_PSL(7, DSTBUF) \
+      W4_PSL(8, DSTBUF) W4_PSL(9, DSTBUF) W4_PSL(10, DSTBUF) W4_PSL(11, DSTBUF) W4_PSL(12, DSTBUF) W4_PSL(13, DSTBUF) W4_PSL(14, DSTBUF) \
+    } else {                                                                                                \
+      W4_SSL(0, DSTBUF) W4_SSL(1, DSTBUF) W4_SSL(2, DSTBUF) W4_SSL(3, DSTBUF) W4_SSL(4, DSTBUF) W4_SSL(5, DSTBUF) W4_SSL(6, DSTBUF) W4_SSL(7, DSTBUF) \
+      W4_SSL(8, DSTBUF) W4_SSL(9, DSTBUF) W4_SSL(10, DSTBUF)                                                \
     }                                                                                                       \
-    const f32x4 ta_ = pk_fma_m44(T_[2], T_[4]), tb_ = pk_fma_m44(T_[1], T_[3]);                             \
-    const f32x4 tc_ = pk4_sub(T_[4], T_[2]), te_ = pk4_sub(T_[3], T_[1]);                                   \
-    W4_TR_WR(DSTBUF, 0, pk_fma_p44(pk4_sub(T_[0], T_[2]), tc_))       /* 4 T0 - 5 T2 + T4 */                \
-    W4_TR_WR(DSTBUF, 1, pk4_add(ta_, tb_))                                                                  \
-    W4_TR_WR(DSTBUF, 2, pk4_sub(ta_, tb_))                                                                  \
-    W4_TR_WR(DSTBUF, 3, pk_fma_p24(te_, tc_))                                                               \
-    W4_TR_WR(DSTBUF, 4, pk_fma_m24(te_, tc_))                                                               \
-    W4_TR_WR(DSTBUF, 5, pk_fma_m44(te_, pk4_sub(T_[5], T_[3])))       /* 4 T1 - 5 T3 + T5 */                \
   }
 
   // ---- per-block parameters in LDS ----
@@ -352,8 +394,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   W4_ISSUE_HALO(B)     // stage 1
   W4_HALO_ALL(A)
   __syncthreads();
-  W4_TRANSFORM_ROW(sA, 0, 0, tka0, tka1, tka2)
-  W4_TRANSFORM_ROW(sA + DST_B, dAb, dLb, tkb0, tkb1, tkb2)
+  W4_TRANSFORM_ALL(sA)
   W4_ISSUE_HALO(A)     // stage 2: consumed by stage 0 of the loop (even stages use set A)
   __syncthreads();
   W4_HALO_ALL(B)
@@ -417,20 +458,35 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   W4_FETCH_W(4, 1, 0)
   if (W4_ABL & (256 | 512)) { W4_FETCH(0, sA, 0, 0) W4_FETCH(1, sA, 1, 0) W4_FETCH(2, sA, 2, 0) }
 
-  // eleven transform slices of one V row behind MFMAs N .. N + 10 of pairs P0, P0 + 1 (column order 0, 2, 4, 1, 3, 5)
-#define W4_ROW_SLICES(COND, DSTBUF, DA, DL, K0, K1, K2, M0, M1, M2, M3, M4, M5, M6, M7, M8, M9, M10, M11)   \
-  M0  if (COND) W4_TR_RD(rx, 0, DA, DL) W4_FENCE();                                                         \
-  M1  if (COND) { W4_TR_T(T0, rx, K0, K1, K2) W4_TR_RD(rx, 2, DA, DL) } W4_FENCE();                         \
-  M2  if (COND) { W4_TR_T(T2, rx, K0, K1, K2) W4_TR_RD(rx, 4, DA, DL) } W4_FENCE();                         \
-  M3  if (COND) { W4_TR_T(T4, rx, K0, K1, K2) W4_TR_RD(rx, 1, DA, DL) } W4_FENCE();                         \
-  M4  if (COND) { tc = pk4_sub(T4, T2); ta = pk_fma_m44(T2, T4); W4_TR_WR(DSTBUF, 0, pk_fma_p44(pk4_sub(T0, T2), tc)) } W4_FENCE(); \
-  M5  if (COND) { W4_TR_T(T1, rx, K0, K1, K2) W4_TR_RD(rx, 3, DA, DL) } W4_FENCE();                         \
-  M6  if (COND) { W4_TR_T(T3, rx, K0, K1, K2) W4_TR_RD(rx, 5, DA, DL) } W4_FENCE();                         \
-  M7  if (COND) { W4_TR_T(T5, rx, K0, K1, K2) } W4_FENCE();                                                 \
-  M8  if (COND) { te = pk4_sub(T3, T1); tb = pk_fma_m44(T1, T3); W4_TR_WR(DSTBUF, 5, pk_fma_m44(te, pk4_sub(T5, T3))) } W4_FENCE(); \
-  M9  if (COND) { W4_TR_WR(DSTBUF, 1, pk4_add(ta, tb)) W4_TR_WR(DSTBUF, 2, pk4_sub(ta, tb)) } W4_FENCE();   \
-  M10 if (COND) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(te, tc)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(te, tc)) } W4_FENCE(); \
-  M11 W4_FENCE();
+  // first half of a stage: pairs 0..4 (40 MFMAs); transform slice k of the wave's task behind MFMA slot k (slots = the MFMAs of
+  // pairs 0, 2 and the first four of pairs 1, 3; the pair task has 15 slices, the single-row task 11)
+#define W4_PSLN(S) W4_PSL(S, nA)
+#define W4_SSLN(S) W4_SSL(S, nA)
+#define W4_HALF1(SL)                                                                                                  \
+    W4_MMX(0, 0, 0, 3) SL(0) W4_FENCE();                                                                              \
+    W4_MMX(0, 1, 0, 3) SL(1) W4_FENCE();                                                                              \
+    W4_MMX(0, 2, 0, 3) SL(2) W4_FENCE();                                                                              \
+    W4_MMX(0, 3, 0, 3) SL(3) W4_FENCE();                                                                              \
+    W4_MMX(0, 4, 0, 3) SL(4) W4_FENCE();                                                                              \
+    W4_MMX(0, 5, 0, 3) SL(5) W4_FENCE();                                                                              \
+    W4_MMX(0, 6, 0, 3) SL(6) W4_FENCE();                                                                              \
+    W4_MMX(0, 7, 0, 3) W4_FETCH(2, cA, 2, chunk) W4_FENCE(); SL(7) W4_FENCE();                                        \
+    W4_MMX(1, 0, 1, 4) SL(8) W4_FENCE();                                                                              \
+    W4_MMX(1, 1, 1, 4) SL(9) W4_FENCE();                                                                              \
+    W4_MMX(1, 2, 1, 4) SL(10) W4_FENCE();                                                                             \
+    W4_MMX(1, 3, 1, 4) SL(11) W4_FENCE();                                                                             \
+    W4_MMX(1, 4, 1, 4) W4_MMX(1, 5, 1, 4) W4_MMX(1, 6, 1, 4) W4_MMX(1, 7, 1, 4)                                       \
+    W4_FETCH(0, cA, 3, chunk)                                                                                         \
+    W4_FENCE();                                                                                                       \
+    W4_MM(2, 0, 2) SL(12) W4_FENCE();                                                                                 \
+    W4_MM(2, 1, 2) SL(13) W4_FENCE();                                                                                 \
+    W4_MM(2, 2, 2) SL(14) W4_FENCE();                                                                                 \
+    W4_MM(2, 3, 2) W4_MM(2, 4, 2) W4_MM(2, 5, 2) W4_MM(2, 6, 2)                                                       \
+    W4_MM(2, 7, 2) W4_FETCH(1, cA, 4, chunk) W4_FENCE();                                                              \
+    W4_MM8(3, 0)                                                                                                      \
+    W4_FETCH(2, cA, 5, chunk)                                                                                         \
+    W4_FENCE();                                                                                                       \
+    W4_MM8(4, 1)
 
   // One stage (8 input channels, 72 MFMAs per wave) of the pipeline; SET = the halo register set of the stage's parity, BUFV
   // = the transformed-input buffer it consumes (both = the stage parity: the stage loop is unrolled by two, nst is even).
@@ -443,23 +499,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     const float* const cA = sA + buf * W4_A_FLOATS;                                                                   \
     float* const nA = sA + (buf ^ 1) * W4_A_FLOATS;                                                                   \
     const int nchunk = chunk + 1 == nst ? 0 : chunk + 1;                                                              \
-    f32x4 rx0, rx1, rx2, rx3, T0, T1, T2, T3, T4, T5, ta, tb, tc, te;                                                 \
+    W4_XF_REGS                                                                                                        \
     W4_FETCH_F(1, cA, 1)                                                                                              \
     W4_FENCE();                                                                                                       \
-    W4_ROW_SLICES(!(W4_ABL & 2), nA, 0, 0, tka0, tka1, tka2,                                                          \
-                  W4_MMX(0, 0, 0, 3), W4_MMX(0, 1, 0, 3), W4_MMX(0, 2, 0, 3), W4_MMX(0, 3, 0, 3), W4_MMX(0, 4, 0, 3), W4_MMX(0, 5, 0, 3),\
-                  W4_MMX(0, 6, 0, 3), W4_MMX(0, 7, 0, 3) W4_FETCH(2, cA, 2, chunk) W4_FENCE();, W4_MMX(1, 0, 1, 4), W4_MMX(1, 1, 1, 4),\
-                  W4_MMX(1, 2, 1, 4), W4_MMX(1, 3, 1, 4))                                                             \
-    W4_MMX(1, 4, 1, 4) W4_MMX(1, 5, 1, 4) W4_MMX(1, 6, 1, 4) W4_MMX(1, 7, 1, 4)                                       \
-    W4_FETCH(0, cA, 3, chunk)                                                                                         \
-    W4_FENCE();                                                                                                       \
-    W4_ROW_SLICES(twB, nA + DST_B, dAb, dLb, tkb0, tkb1, tkb2,                                                        \
-                  W4_MM(2, 0, 2), W4_MM(2, 1, 2), W4_MM(2, 2, 2), W4_MM(2, 3, 2), W4_MM(2, 4, 2), W4_MM(2, 5, 2), W4_MM(2, 6, 2),\
-                  W4_MM(2, 7, 2) W4_FETCH(1, cA, 4, chunk) W4_FENCE();, W4_MM(3, 0, 0), W4_MM(3, 1, 0), W4_MM(3, 2, 0), W4_MM(3, 3, 0))\
-    W4_MM(3, 4, 0) W4_MM(3, 5, 0) W4_MM(3, 6, 0) W4_MM(3, 7, 0)                                                       \
-    W4_FETCH(2, cA, 5, chunk)                                                                                         \
-    W4_FENCE();                                                                                                       \
-    W4_MM8(4, 1)                                                                                                      \
+    if (t_pair) { W4_HALF1(W4_PSLN) } else { W4_HALF1(W4_SSLN) }                                                      \
     W4_T(0)                                                                                                           \
     if (!(W4_ABL & 128)) __syncthreads();                                                                             \
     W4_T(1)                                                                                                           \
@@ -543,6 +586,17 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
         bq0 = sS[nt * 32 + li]; bq1 = sS[NB + nt * 32 + li]; bq2 = sS[2 * NB + nt * 32 + li]; bq3 = sS[3 * NB + nt * 32 + li];
       }
       const float sg = (IN_MODE != 0 && p_pool != nullptr) ? sG[nt * 32 + li] : 1.f;
+      // raw pooled copy [N, H/2, W/2, Cout]: buffer stores like the output's (lane part: channel + the lh tile column's two
+      // windows; pooled row / column of the quad in the scalar offset) - as plain pointer stores every one of the 32 stores of a
+      // tile cost ~17 instructions of 64-bit address arithmetic and an exec-mask branch (round 6)
+      __amdgpu_buffer_rsrc_t rsrc_pool = rsrc_out;
+      unsigned lane_pl[2] = {OOB, OOB};
+      if (IN_MODE != 0 && p_pool != nullptr) {
+        const unsigned pimg = (unsigned)((a.H >> 1) * (a.W >> 1) * a.Cout) * 4u;
+        rsrc_pool = __builtin_amdgcn_make_buffer_rsrc(p_pool + (size_t)n * (a.H >> 1) * (a.W >> 1) * a.Cout, 0, pimg, 0x00020000);
+#pragma unroll
+        for (int wnd = 0; wnd < 2; ++wnd) lane_pl[wnd] = co_ok ? (unsigned)(((2 * lh + wnd) * a.Cout + co) * 4) : OOB;
+      }
       // row exchange [wave][8 values][lane][4], partner = the other row half (wave ^ 2); even register quads through the
       // consumed sA image, odd ones through sX: one barrier per quad
       float* const sAc = sA + buf * W4_A_FLOATS;
@@ -661,13 +715,16 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
             }
           }
           if (IN_MODE != 0 && p_pool != nullptr) {
+            // pooled pixel (py, px) = ((row_u + g_row) / 2 + 2 e, (col_u + g_col) / 2 + 2 lh + wnd): row and quad column are scalar
+            const unsigned so_p = (unsigned)((((row_u + g_row) >> 1) * (a.W >> 1) + ((col_u + g_col) >> 1)) * a.Cout) * 4u;
+            const unsigned sr_p = (unsigned)((a.W >> 1) * a.Cout) * 8u;
 #pragma unroll
             for (int wnd = 0; wnd < 2; ++wnd)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const int py = (row_u + g_row + 4 * e) >> 1, px = ((col_u + g_col + 4 * lh) >> 1) + wnd;
-                if (co_ok && 2 * py < a.H && 2 * px < a.W)
-                  p_pool[((size_t)(n * (a.H >> 1) + py) * (a.W >> 1) + px) * a.Cout + co] = pm[wnd][e] * sg;
+                const unsigned vo = (FULL || (4 * e < lim_y && 2 * wnd < lim_x)) ? lane_pl[wnd] : OOB;
+                const float pv = pm[wnd][e] * sg;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), rsrc_pool, vo, so_p + (unsigned)e * sr_p, 0);
               }
           }
         };
@@ -715,10 +772,21 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #undef W4_HALO_BN
 #undef W4_HALO_WR
 #undef W4_TR_RD
-#undef W4_TR_T
 #undef W4_TR_WR
-#undef W4_TRANSFORM_ROW
-#undef W4_ROW_SLICES
+#undef W4_TRANSFORM_ALL
+#undef W4_HALF1
+#undef W4_PSLN
+#undef W4_SSLN
+#undef W4_PSL
+#undef W4_SSL
+#undef W4_PC
+#undef W4_SC
+#undef W4_RP_A
+#undef W4_RP_B
+#undef W4_RP_C
+#undef W4_RP_D
+#undef W4_TR_RD3
+#undef W4_XF_REGS
 #undef W4_FETCH
 #undef W4_FETCH_F
 #undef W4_FETCH_W

@@ -40,12 +40,21 @@ constexpr int PIPE_LDS_BYTES = (2 * (PA_FLOATS + PB_FLOATS) + PR_FLOATS + PS_FLO
 // raw halo pixel p (raster index), quad q (0/1) -> float offset in sR.  ds_read_b128 is serviced in four groups of 16
 // NON-contiguous lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) on 64 banks (256 B): the stride-2 pixel reads
 // of the transform (lane = (tile, quad)) are conflict-free when the 8 pixels of a lane group fall on 8 different 32-byte
-// positions of the 256-byte bank row.  The pixels are rotated inside aligned groups of 8 by a function of the group
-// index found by exhaustive search over the lane-group model (tools/lds_conflicts.py): 8 -> 4 LDS cycles per read for
-// the 8x32 tiles, 10 -> 6.5 for the 32x8 tiles (whose lane groups span four halo rows).  The 16-byte writes (8
-// contiguous lanes = 4 consecutive pixels, 32 banks) stay conflict-free under any rotation.
+// positions of the 256-byte bank row.  8x32 tiles (34-pixel halo rows): the pixels are rotated inside aligned groups of 8 by a
+// function of the group index found by exhaustive search over the lane-group model (tools/lds_conflicts.py): 8 -> 4 LDS cycles
+// per read.  32x8 tiles (10-pixel halo rows, a lane group spans four of them): the same family only reached 6.5 cycles
+// (`SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS` 0.77, profiles/r05_ssp_pmc_sq_summary.txt); round 6: plain raster order with the pixel
+// column XOR-ed by bit 1 of the halo row (as conv_wino_p2_kernel) is conflict-free: 4 cycles.  The 16-byte writes (8 contiguous
+// lanes = 4 consecutive raster pixels = 128 contiguous bytes either way, 32 banks) stay conflict-free.
+#ifndef PIPE_XOR
+#define PIPE_XOR 1
+#endif
 template <bool WIDE>
 __device__ __forceinline__ int pipe_raw_off(int p, int q) {
+  if (!WIDE && PIPE_XOR) {
+    const int r = p / 10, c = p - r * 10;
+    return (r * 10 + (c ^ ((r >> 1) & 1))) * PK + q * 4;
+  }
   const int b = p >> 3;
   const int g = WIDE ? (b + 6 * (b >> 1)) : ((b >> 1) + 6 * (b >> 2));
   return ((p & ~7) + ((p + g) & 7)) * PK + q * 4;

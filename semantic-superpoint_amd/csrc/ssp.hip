@@ -1311,6 +1311,61 @@ const char* ssp_build_id(void) {
   return marker + 13;
 }
 
+// Shader clock under matrix-core load (round 6: the benchmark line reports the clock its box sustains - boxes of the pool differ by
+// +-3 % in pairs/s, mostly through the clock the power controller grants).  One workgroup of 4 waves per CU runs back-to-back
+// v_mfma_f32_32x32x2_f32 on pseudo-random operands for ~`ms` milliseconds; workgroup 0 counts shader cycles (s_memtime) against the
+// constant 100 MHz counter (s_memrealtime).
+__global__ __launch_bounds__(256) void clock_probe_kernel(float* sink, unsigned long long* out, int iters) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a[4], b[4];
+  unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s = s * 1664525u + 1013904223u; a[i] = ((int)(s >> 8) - (1 << 23)) * (1.f / (1 << 23));
+    s = s * 1664525u + 1013904223u; b[i] = ((int)(s >> 8) - (1 << 23)) * (0.05f / (1 << 23));
+  }
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[(m + u) & 3], acc[m], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][9];
+  sink[blockIdx.x * 256 + threadIdx.x] = r;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
+int ssp_clock_probe(float ms, double* mhz_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!mhz_out || !(ms > 0.f) || ms > 1000.f) return fail(-1, "ssp_clock_probe: bad argument");
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return fail(-2, "ssp_clock_probe: no device");
+  float* sink = nullptr;
+  unsigned long long* out = nullptr;
+  if (hipMalloc(&sink, (size_t)ncu * 256 * 4) != hipSuccess) return fail(-2, "ssp_clock_probe: hipMalloc");
+  if (hipMalloc(&out, 16) != hipSuccess) { (void)hipFree(sink); return fail(-2, "ssp_clock_probe: hipMalloc"); }
+  // 16 MFMAs of 64 cycles per iteration and wave, one wave per SIMD: 1024 cycles per iteration; 2.4 GHz upper bound for the count
+  const int iters = (int)(ms * 2.4e6f / 1024.f) + 1;
+  unsigned long long h[2] = {0, 0};
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(ncu), dim3(256), 0, stream, sink, out, iters);
+  hipError_t e = hipMemcpyAsync(h, out, 16, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(sink);
+  (void)hipFree(out);
+  if (e != hipSuccess || h[1] == 0) return fail(-2, "ssp_clock_probe: %s", hipGetErrorString(e));
+  *mhz_out = 100.0 * (double)h[0] / (double)h[1];
+  return 0;
+}
+
 int ssp_set_deterministic(int on) {
   g_det_mode = on ? 1 : 0;
   return det_upload();   // (handles bound before the switch keep their plain fp32 scatters until they are bound again)

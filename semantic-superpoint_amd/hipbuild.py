@@ -21,10 +21,11 @@ LIB = os.path.join(CSRC, "libssp_hip.so")
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 
 # kernels with inline-asm-private accumulation registers -> the exact count of every instruction that may touch a0..a255:
-# conv_wino4_kernel: 16 accumulators x 4 k-pairs x 2 stage instances (the stage loop is unrolled by two) = 128 MFMAs on a[..]; two
+# conv_wino4_kernel: per stage instance the first half (pairs 0..4 = 10 accumulators x 4 k-pairs) exists once per transform task kind
+# (2 x 40) + pairs 5..7 (24) = 104; x 2 stage instances (the stage loop is unrolled by two) = 208 MFMAs on a[..]; two
 # clear sites x 256 writes; the epilogue reads each of the 256 registers once in either wave role (2 x 256)
 FIXED_AGPR_KERNELS = {
-    "conv_wino4_kernel": {"v_mfma_f32_32x32x2_f32": 128, "v_accvgpr_write_b32": 512, "v_accvgpr_read_b32": 512},
+    "conv_wino4_kernel": {"v_mfma_f32_32x32x2_f32": 208, "v_accvgpr_write_b32": 512, "v_accvgpr_read_b32": 512},
     # wgrad_wino4_kernel: 16 accumulators x 4 K steps x 4 wave roles = 256 MFMAs on a[..] (the 2 x 4 x 4 = 32 of the two
     # vector-register accumulators carry no a-operand); one clear (256 writes); the epilogue reads every register once
     "wgrad_wino4_kernel": {"v_mfma_f32_32x32x2_f32": 256, "v_accvgpr_write_b32": 256, "v_accvgpr_read_b32": 256},

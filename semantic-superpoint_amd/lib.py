@@ -72,7 +72,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
            "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16", "ssp_op_bn_bwd_bf16", "ssp_build_id",
-           "ssp_set_deterministic", "ssp_get_deterministic"]
+           "ssp_set_deterministic", "ssp_get_deterministic", "ssp_clock_probe"]
 
 
 def load_library(path=None):
@@ -199,6 +199,19 @@ def set_deterministic(on=True):
 
 def get_deterministic():
     return bool(load_library().ssp_get_deterministic())
+
+
+def clock_probe(ms=5.0):
+    """Shader clock (MHz) the current device sustains under fp32 matrix-core load for ~`ms` milliseconds (ssp_clock_probe; blocking).
+    None for an A/B library of an older revision that lacks the entry point."""
+    import torch
+    lib = load_library()
+    if not hasattr(lib, "ssp_clock_probe"):
+        return None
+    lib.ssp_clock_probe.argtypes = [C.c_float, C.POINTER(C.c_double), C.c_void_p]
+    out = C.c_double(0.0)
+    _check(lib.ssp_clock_probe(float(ms), C.byref(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return float(out.value)
 
 
 def build_id():

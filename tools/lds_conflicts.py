@@ -31,7 +31,35 @@ def transform(wide, wave, j, ra, rot=raw_off):
         ty, tx = t_tile // TTX, t_tile % TTX
         out.append(4 * rot((2 * ty + ra) * HC + 2 * tx + j, q2))
     return out
+def pipe_rot(wide):
+    """conv_wino_pipe.hip.h pipe_raw_off<WIDE>: 8x32 tiles: rotation inside aligned 8-pixel groups of the raster index; 32x8 tiles
+    (round 6): raster order, pixel column XOR bit 1 of the halo row"""
+    def f(p, q):
+        if not wide:
+            r, c = divmod(p, 10)
+            return (r * 10 + (c ^ ((r >> 1) & 1))) * PK + q * 4
+        b = p >> 3
+        return ((p & ~7) + ((p + b + 6 * (b >> 1)) & 7)) * PK + q * 4
+    return f
+def p2_transform(wide, j, r, xor=True):
+    """conv_wino_p2.hip.h: ds_read_b128 of pixel column 2 tx + j of halo row 2 ty + r, lane = (tile, quad) of ONE wave (32 tiles);
+    row stride 148 floats (8x16 tiles) / 80 (16x8 tiles, column XOR (row >> 1) & 1: p2_raw_col)"""
+    TTX, srow = (8, 148) if wide else (4, 80)
+    out = []
+    for lane in range(64):
+        q2, t = lane & 1, (lane >> 1) & 31
+        ty, tx = t // TTX, t % TTX
+        row, col = 2 * ty + r, 2 * tx + j
+        if xor and not wide: col ^= (row >> 1) & 1
+        out.append(4 * (row * srow + col * PK + q2 * 4))
+    return out
 if __name__ == "__main__":
+    for wide in (True, False):
+        for xor in (False, True):
+            c = [cycles(p2_transform(wide, j, r, xor)) for j in range(4) for r in range(4)]
+            print("conv_wino_p2 transform reads (%s, column xor %d): min %d max %d" % ("8x16" if wide else "16x8", xor, min(c), max(c)))
+        c = [cycles(transform(wide, w, j, ra, pipe_rot(wide))) for w in range(2) for j in range(4) for ra in range(4)]
+        print("conv_wino_pipe transform reads (%s): min %d max %d" % ("8x32" if wide else "32x8", min(c), max(c)))
     for sh in (2, 4):
         print("A fragments, swizzle bit (tile >> %d) & 1: %s cycles" % (sh, [cycles(a_frag(sh, mt)) for mt in (0, 1)]))
     for wide in (True, False):
