@@ -21,6 +21,7 @@
 // the BatchNorm partial sums are taken from the summed values.  Persistent XCD-aware grid and dual-problem launches
 // as in conv_mfma_kernel.
 #pragma once
+#include <type_traits>
 #include "conv_mfma.hip.h"
 
 namespace sspk {
@@ -362,10 +363,15 @@ struct WgradWinoGeom {
 // 8 MFMAs instead of ~34.  On this chip every VALU instruction beside a v_mfma_f32_32x32x2_f32 costs matrix-pipe time one
 // for one (the fp32 MFMA executes on the vector ALUs: DESIGN.md section 8, tools/ubench/mfma_overlap.hip).
 //   T[c] = d[ra][c] + sg d[rb][c];   (r0, r1) = c0 dy[0][0..1] + c1 dy[1][0..1]
-template <typename G>
+struct WgsNoHook {
+  template <typename S> __device__ __forceinline__ void operator()(S) const {}
+};
+// `hook(std::integral_constant<int, S>)` runs between the LDS reads and the MFMAs of step S (wgrad_wino_fused_kernel issues the
+// next tile's global loads there, two per step)
+template <typename G, typename HOOK = WgsNoHook>
 __device__ __forceinline__ void wgrad_wino_steps(f32x16 (&acc)[4][2], const float* __restrict__ xa0,
                                                  const float* __restrict__ xb0, const float* __restrict__ db0,
-                                                 const f32x2 sg, const f32x2 c0, const f32x2 c1) {
+                                                 const f32x2 sg, const f32x2 c0, const f32x2 c1, HOOK&& hook = HOOK()) {
   f32x2 U[4], Wv[4], T[4], top, bot, r;
 #define WGS_LOAD(S)                                                                                          \
   {                                                                                                          \
@@ -406,6 +412,7 @@ __device__ __forceinline__ void wgrad_wino_steps(f32x16 (&acc)[4][2], const floa
   WGS_HEAD()                                                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                                         \
   if ((S) + 1 < 16) WGS_LOAD(((S) + 1 < 16 ? (S) + 1 : 0))                                                   \
+  hook(std::integral_constant<int, (S)>{});                                                                  \
   __builtin_amdgcn_sched_barrier(0);                                                                         \
   WGS_TAIL()                                                                                                 \
   __builtin_amdgcn_sched_barrier(0);

@@ -19,6 +19,7 @@
 // PARKED IN LDS here (hipcc otherwise hoists every pp / WT, pp % WT out of the tile loop: wgrad_wino4.hip.h).
 #pragma once
 #include "conv_wino.hip.h"
+#include <type_traits>
 #include "conv_wino_bf16.hip.h"
 
 #ifndef WGF_TRACE
@@ -166,7 +167,14 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
   };
   __amdgpu_buffer_rsrc_t rx_, ry_, rp_;
   int r_key = -1;   // (problem, image) the descriptors were built for
-#define WGF_ISSUE()                                                                                           \
+  // Offsets of the next tile's loads (WGF_PREP) - the loads themselves are ISSUED IN SLICES BETWEEN THE MFMA STEPS of the current
+  // tile (wgf_load_slice, round 6).  As one block behind the staging barrier they cost 3100 (older waves of a SIMD) to 6900 cycles
+  // (younger ones) per tile, with ~60 instructions on the interior path: eight waves push 96 KB of 16-byte loads into the CU's
+  // memory pipeline at once and every wave stalls on the full queue before it can start its MFMA phase
+  // (profiles/r05_wgf_phase_trace.txt: "issue"); spread over the first steps of a 12-16 k cycle MFMA phase they never queue.
+  unsigned xvo[NX], yo[4] = {0u, 0u, 0u, 0u}, po1 = 0u;
+  int xso = 0, yb = 0, pb = 0;
+#define WGF_PREP()                                                                                            \
   {                                                                                                           \
     const int pr_ = w_prob, n_ = w_n;                                                                         \
     const int ty0_ = __builtin_amdgcn_readfirstlane(w_ty0), tx0_ = __builtin_amdgcn_readfirstlane(w_tx0);     \
@@ -183,15 +191,13 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
     nxt_inside = ty0_ >= 1 && ty0_ + G::TH + 1 <= a.H && tx0_ >= 1 && tx0_ + G::TW + 1 <= a.W;               \
     /* (scalar offsets through readfirstlane: mixed into the per-lane validity tests below they became vector values and every   */ \
     /* y load a waterfall loop)                                                                                                */ \
-    const int yb_ = __builtin_amdgcn_readfirstlane(ty0_ * yrow + tx0_ * ypix);                                \
-    const int pb_ = __builtin_amdgcn_readfirstlane(POOL ? (ty0_ >> 1) * prow + (tx0_ >> 1) * ppix : ty0_ * prow + tx0_ * ppix + a.dout_co * 4); \
-    /* ONE set of load instructions for interior and border tiles (the branches only pick the offsets): with the loads inside  */ \
-    /* the branches hipcc guards the interior block's first register writes with vmcnt waits for the OTHER block's loads        */ \
-    unsigned xvo_[NX];                                                                                        \
-    int xso_ = 0;                                                                                             \
+    yb = __builtin_amdgcn_readfirstlane(ty0_ * yrow + tx0_ * ypix);                                           \
+    pb = __builtin_amdgcn_readfirstlane(POOL ? (ty0_ >> 1) * prow + (tx0_ >> 1) * ppix : ty0_ * prow + tx0_ * ppix + a.dout_co * 4); \
+    /* ONE set of load instructions for interior and border tiles (the branches only pick the offsets)                         */ \
+    xso = 0;                                                                                                  \
     if (nxt_inside) {                                                                                         \
-      xso_ = __builtin_amdgcn_readfirstlane((ty0_ - 1) * xrow + (tx0_ - 1) * xpix);                           \
-      _Pragma("unroll") for (int i = 0; i < NX; ++i) xvo_[i] = sO[i * 512];                                   \
+      xso = __builtin_amdgcn_readfirstlane((ty0_ - 1) * xrow + (tx0_ - 1) * xpix);                            \
+      _Pragma("unroll") for (int i = 0; i < NX; ++i) xvo[i] = sO[i * 512];                                    \
       xmask = sO[(2 * NX + 8) * 512];                                                                         \
     } else {                                                                                                  \
       xmask = 0;                                                                                              \
@@ -199,20 +205,16 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
         const unsigned rc_ = sO[(NX + i) * 512];                                                              \
         const int gy = ty0_ - 1 + (int)(rc_ >> 16), gx = tx0_ - 1 + (int)(rc_ & 0xFFFFu);                     \
         const bool ok = rc_ != 0xFFFFFFFFu && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   \
-        xvo_[i] = ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB;                                          \
+        xvo[i] = ok ? (unsigned)(gy * xrow + gx * xpix + xq) : OOB;                                           \
         xmask |= (ok ? 1u : 0u) << i;                                                                         \
       }                                                                                                       \
     }                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                            \
-      xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, xvo_[i], xso_, 0));      \
     if (POOL) {                                                                                               \
       unsigned yo_ = sO[(2 * NX) * 512], po_ = sO[(2 * NX + 1) * 512];                                        \
       /* H and W are even: a window is inside the map or outside as a whole */                               \
       wvalid = (yo_ != OOB && (nxt_inside || (ty0_ + 2 * wy < a.H && tx0_ + 2 * wx < a.W))) ? 1u : 0u;       \
       if (!wvalid) { yo_ = OOB; po_ = OOB; }                                                                  \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                           \
-        yreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry_, yo_, yb_ + (k >> 1) * yrow + (k & 1) * ypix, 0)); \
-      preg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp_, po_, pb_, 0));           \
+      yo[0] = yo_; po1 = po_;                                                                                 \
     } else {                                                                                                  \
       wvalid = 0;                                                                                             \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
@@ -222,12 +224,50 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
           if (!(rc_ != 0xFFFFFFFFu && ty0_ + (int)(rc_ >> 16) < a.H && tx0_ + (int)(rc_ & 0xFFFFu) < a.W)) yo_ = OOB; \
         }                                                                                                     \
         wvalid |= (yo_ != OOB ? 1u : 0u) << i;                                                                \
-        yreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry_, yo_, yb_, 0));         \
-        /* y and the gradient share the pixel geometry; their channel strides may differ only by the scalar part */ \
-        preg[POOL ? 0 : i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp_, yo_, pb_, 0)); \
+        yo[i] = yo_;                                                                                          \
       }                                                                                                       \
     }                                                                                                         \
   }
+  // load number IDX of the prepared tile: the X halo quads, then the four y quads, then the gradient quad(s)
+  auto wgf_load = [&](auto IDX_) __attribute__((always_inline)) {
+    constexpr int IDX = decltype(IDX_)::value;
+    if constexpr (IDX < NX) {
+      xreg[IDX] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, xvo[IDX], xso, 0));
+    } else if constexpr (IDX < NX + 4) {
+      constexpr int k = IDX - NX;
+      if (POOL) yreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry_, yo[0], yb + (k >> 1) * yrow + (k & 1) * ypix, 0));
+      else yreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry_, yo[k], yb, 0));
+    } else if constexpr (IDX < NX + 4 + NP) {
+      constexpr int k = IDX - NX - 4;
+      // y and the gradient share the pixel geometry; their channel strides may differ only by the scalar part
+      if (POOL) preg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp_, po1, pb, 0));
+      else preg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp_, yo[k], pb, 0));
+    }
+  };
+  constexpr int NLOAD = NX + 4 + NP;
+  // the two loads behind MFMA step S (all issued within the first (NLOAD + 1) / 2 <= 8 of the 16 steps)
+  bool w_more = false;  // the tile in the MFMA phase is not this block's last one
+  auto wgf_load_slice = [&](auto S_) __attribute__((always_inline)) {
+    constexpr int S = decltype(S_)::value;
+    // step 0 also moves the walker and prepares the offsets: as a phase of its own between the staging barrier and the MFMA
+    // phase that cost 1.0 (interior tiles) to 2.3 k cycles (border tiles) of LDS / scalar latency per tile with no MFMA in flight
+    if constexpr (S == 0) {
+      if (!BF16) {
+        if (w_more) walk();  // unconditional prefetch (the last tile loads itself again)
+        WGF_PREP()
+      }
+    }
+    if constexpr (2 * S < NLOAD) wgf_load(std::integral_constant<int, (2 * S < NLOAD ? 2 * S : 0)>{});
+    if constexpr (2 * S + 1 < NLOAD) wgf_load(std::integral_constant<int, (2 * S + 1 < NLOAD ? 2 * S + 1 : 0)>{});
+  };
+#define WGF_LOAD_ALL()                                                                                        \
+  {                                                                                                           \
+    wgf_load_slice(std::integral_constant<int, 0>{}); wgf_load_slice(std::integral_constant<int, 1>{});       \
+    wgf_load_slice(std::integral_constant<int, 2>{}); wgf_load_slice(std::integral_constant<int, 3>{});       \
+    wgf_load_slice(std::integral_constant<int, 4>{}); wgf_load_slice(std::integral_constant<int, 5>{});       \
+    wgf_load_slice(std::integral_constant<int, 6>{}); wgf_load_slice(std::integral_constant<int, 7>{});       \
+  }
+  static_assert(NLOAD <= 16, "eight load slices");
 
   // per-wave constants of component row i:  T[i][c] = d[ra][c] + sg d[rb][c];  R[q] = c0 dy[0][q] + c1 dy[1][q]
   const int ra = irow == 0 ? 0 : irow == 2 ? 2 : 1;
@@ -237,7 +277,10 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
   const float c1 = irow == 0 ? 0.f : irow == 1 ? 1.f : -1.f;
 
   __syncthreads();  // sF / sS
-  if (t_begin < t_end) WGF_ISSUE()
+  if (t_begin < t_end) {  // the first tile: slice 0 prepares it (w_more = false: the walker stays)
+    if (BF16) WGF_PREP()
+    WGF_LOAD_ALL()
+  }
 #if WGF_TRACE
   unsigned long long tc_[5] = {0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter();
   const unsigned long long tk0_ = tp_, tr0_ = __builtin_amdgcn_s_memrealtime();   // (s_memrealtime: the constant 100 MHz counter)
@@ -337,8 +380,12 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
     {
       // (sliced between the MFMA steps instead - tile state behind step 0, the loads behind steps 1 - 7 - the MFMA phase grew by more
       // than this phase is long: 27.1 k instead of 25.0 k cycles per tile, profiles/r05_wgf_phase_trace.txt)
-      if (tile + 1 < t_end) walk();  // unconditional prefetch (the last tile loads itself again)
-      WGF_ISSUE()
+      w_more = tile + 1 < t_end;
+      if (BF16) {
+        if (w_more) walk();
+        WGF_PREP()
+        WGF_LOAD_ALL()
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     WGF_T(3)
@@ -347,7 +394,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
       const float* xa0 = sX + (ra * G::WT + 2 * lh) * 64 + 2 * li;
       const float* xb0 = sX + (rb * G::WT + 2 * lh) * 64 + 2 * li;
       const float* db0 = sD + (2 * lh) * 64 + coh * 32 + li;
-      if (!BF16) wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1});
+      if (!BF16) wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1}, wgf_load_slice);
     }
     if (BF16) {
       // (pinned: hipcc converts each value on its own as soon as it exists and merges the halves with v_perm_b32)
@@ -420,7 +467,8 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
   }
 #endif
 #undef WGF_T
-#undef WGF_ISSUE
+#undef WGF_PREP
+#undef WGF_LOAD_ALL
   // partial slab: [blk][component][ci 64][co 64]; M-tile e, row m <-> input channel 2 m + e
   float* dst = a.partial + (size_t)blockIdx.x * WC * 4096;
 #pragma unroll
