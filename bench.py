@@ -77,6 +77,36 @@ def cpu_baseline(arch, H, W, batch=32, steps=3):
                       % (arch, H, W, batch, steps, dt)}
 
 
+def power_state():
+    """Socket power cap / current draw of GPU 0 as rocm-smi reports them (a child process, run BEFORE this process touches the GPU;
+    None where the tool or the field is missing): the boxes of a pool differ in the clock their power controller grants."""
+    exe = shutil.which("rocm-smi")
+    if exe is None:
+        return None
+    try:
+        r = subprocess.run([exe, "-d", "0", "--showmaxpower", "--showpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+    except Exception:
+        return None
+    out = {}
+    for k, v in card.items():
+        kl = k.lower()
+        try:
+            if "max" in kl and "power" in kl:
+                out["power_cap_w"] = float(v)
+            elif "power" in kl and ("socket" in kl or "average" in kl or "current" in kl):
+                out["power_idle_w"] = float(v)
+        except (TypeError, ValueError):
+            pass
+    return out or None
+
+
+# BASELINE.md section 2: the REAL reference (Train_model_heatmap_all.train_val_sample imported with stub modules) timed in the
+# survey container (8 host threads, PyTorch CPU): SSp / SP pair step at 240x320, batch 32
+REFERENCE_CPU_CONTAINER = {"SuperPointNet_gauss2_ssmall": {"value": 0.62, "s_per_step": 51.8}, "SuperPointNet_gauss2": {"value": 0.90, "s_per_step": 35.7}}
+
+
 def roofline_block(prof_kernels, pmc, pmc_note, conv_algo, n_prof_steps, steps):
     """`roofline` of a measured line from the per-kernel HIP-event timings of the library (Engine.profile_read_kernels) and the
     PMC child runs.  fp32 kernels: bound "mfma" - multiplies EXECUTED on the matrix cores per second against the fp32 MFMA peak.
@@ -136,9 +166,6 @@ def roofline_block(prof_kernels, pmc, pmc_note, conv_algo, n_prof_steps, steps):
         rl["note"] = ("achieved = ALGORITHMIC bytes of the launches (bf16 input + output of each 3x3 convolution, once) / their time, "
                       "against the 8 TB/s HBM3E spec; traffic = HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE); "
                       "mfma_* = direct-convolution FLOPs / time against the dense bf16 MFMA peak")
-        rl["limiter"] = ("neither roof: the launches run at the socket's 1400 W power cap (shader clock 1.6-2.1 GHz of 2.4 during them; "
-                         "profiles/r04_bf16_conv_sustained_ablation_power.txt, r04_bf16_instep_phase_trace.txt) and a SIMD issues matrix OR "
-                         "vector instructions (profiles/r04_ubench_mfma_valu_share.txt): DESIGN.md section 8")
         rl["mfma_tflops"], rl["mfma_frac"], rl["traffic_gbs"] = d["mfma_tflops"], d["mfma_frac"], d["traffic_gbs"]
     return rl
 
@@ -389,6 +416,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    power = power_state() if (rank == 0 and not args.pmc_child) else None   # (a child process: nothing here has touched the GPU)
     pmc, pmc_note = {}, "not collected"
     want_live = args.traffic == "live" or (args.traffic == "auto" and not args.no_roofline and not args.pmc_child)
     pmc16 = {}
@@ -492,12 +520,17 @@ def main():
         eng.profile_enable("conv3x3_every")  # every 3x3 forward / data-gradient / weight-gradient launch, split by kernel
         profiling[0] = True
     torch.cuda.synchronize()
+    clock_before = ssp.lib.clock_probe(5.0) if rank == 0 else None   # (outside the timed region; ~5 ms of fp32 MFMAs on every CU)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     run(args.steps, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    clock_after = ssp.lib.clock_probe(5.0) if rank == 0 else None
     per_rank_ms = [1e3 * dt / args.steps]
     if world > 1:
         mine = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -526,6 +559,14 @@ def main():
                # executes 1/4 resp. 16/36 of these multiplies, so it may exceed 1); the hardware fraction is roofline.frac
                "step_algorithmic_tflops_vs_fp32_mfma_peak": round(pairs_s * GFLOP_PER_PAIR[arch] / 1e3 / (PEAK_FP32_MFMA_TF * world), 4),
                "final_loss": round(scal["loss"], 4), "build_id": ssp.lib.build_id()[:16]}
+        # what explains this box (boxes of one pool differ by +-3 % in pairs/s): the shader clock the device sustains under fp32
+        # matrix-core load right before and right after the timed region (ssp_clock_probe: 5 ms on every CU, 2400 MHz is the part's
+        # maximum) and the socket's power cap / draw at start as rocm-smi reports them
+        if clock_before is not None and clock_after is not None:
+            out["gpu_clock_mhz"] = {"before": round(clock_before, 1), "after": round(clock_after, 1), "max": 2400.0,
+                                    "pairs_per_s_per_ghz": round(pairs_s / (0.5e-3 * (clock_before + clock_after)), 2)}
+        if power is not None:
+            out["power"] = power
         if world > 1:
             log = None
             try:
@@ -543,6 +584,12 @@ def main():
             profiling[0] = False
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch, H, W, batch=B)
+            if (H, W, B) == (240, 320, 32) and arch in REFERENCE_CPU_CONTAINER:
+                ref = REFERENCE_CPU_CONTAINER[arch]
+                out["cpu_baseline"]["reference_cpu_container"] = {
+                    "value": ref["value"], "unit": "image-pairs/s", "cores": 8, "kind": "reference",
+                    "sample": "BASELINE.md section 2: the reference's own train_val_sample (stub modules for absent packages) in the build "
+                              "container, 8 threads, %.1f s per step - measured there once, NOT in this run" % ref["s_per_step"]}
         cpu_line = None
         if "cpu_baseline" in out:
             cpu_line = dict(out["cpu_baseline"], note="the fp32 oracle step timed once in this run (top-level cpu_baseline)")

@@ -690,7 +690,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   if (g_dbg_grid > 0) nblocks = g_dbg_grid;  // perf-debug only (ssp_debug_conv_knobs)
   if ((nblocks / 8) < c.ncob) return fail(-3, "too many output-channel blocks (%d) for the persistent grid", c.ncob);
   const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
-  const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
+  // algorithmic bytes: input + output once, plus what the FUSED passes of the launch move (round 6): the layer-below tensor of the
+  // BatchNorm-backward sums (data gradient), the quarter-size raw pooled copy (forward)
+  const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout +
+                                                          (c.bnr_mode != 0 ? (double)c.cout : 0.0) + (c.pool_out[0] != nullptr ? 0.25 * c.cout : 0.0));
   int fam = prof_family;
   if (prof_family == SSP_PROF_CONV3X3_FWD && h && h->prof_family == SSP_PROF_CONV_BIG_FWD && c.H * c.W >= 240 * 320 &&
       c.cin == 64)
@@ -1110,7 +1113,10 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   }
   {
     const double flops = 2.0 * c.nprob * c.N * c.H * c.W * (double)c.cin * c.cout * c.ks * c.ks;
-    const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) + c.cout);
+    // algorithmic bytes: X + dY once; a launch that carries the layer's BatchNorm-backward APPLY reads y and the gradient wrt the
+    // (pooled) activation INSTEAD of dY and writes dY for the data gradient (round 6: counted)
+    const double bytes = 4.0 * c.nprob * c.N * c.H * c.W * ((double)c.cin * (c.in_mode == 2 ? 4 : 1) +
+                                                            (c.fuse_apply ? (2.0 + (c.fuse_pool ? 0.25 : 1.0)) * c.cout : (double)c.cout));
     ProfScope ps(h, c.ks == 3 ? SSP_PROF_CONV3X3_WGRAD : -1, st, flops, bytes, flops * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0),
                  wino4 ? SSP_PROF_K_WGRAD_WINO4 : wino && !bf16_algo() ? SSP_PROF_K_WGRAD_WINO : SSP_PROF_K_OTHER);
     if (c.fuse_apply) {
@@ -1743,7 +1749,7 @@ static int conv_layer_fwd_bf16(ssp_handle* h, const SlotSet& SS, int l, int src,
   if (pool_out) c.pool_gamma = P(h, d.g_off);
   {
     const double flops = 2.0 * SS.n * N * H * W * (double)d.cin * d.cout * d.ks * d.ks;
-    const double bytes = SS.n * (double)N * H * W * (2.0 * d.cin + (c.out_f32 ? 4.0 : 2.0) * d.cout);
+    const double bytes = SS.n * (double)N * H * W * (2.0 * d.cin + (c.out_f32 ? 4.0 : 2.0) * d.cout + (pool_out ? 0.5 * d.cout : 0.0));  // (+ the raw pooled copy)
     ProfScope ps(h, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : -1, st, flops, bytes, flops, SSP_PROF_K_CONV_BF16);
     CHK(launch_conv_bf16(c, h->n_cu, st));
   }
@@ -2132,7 +2138,9 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
         }
       }
       const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
-      ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_WGRAD_BF16);
+      // (bytes: X + dY once; with the fused APPLY: y + the gradient wrt the (pooled) activation in, dY out - counted since round 6)
+      const double wbytes = 2.0 * SS.n * N * lh * lw * ((double)d.cin + (fuse_apply ? (2.0 + (pool_after ? 0.25 : 1.0)) * C : (double)C));
+      ProfScope ps(h, SSP_PROF_CONV3X3_WGRAD, st, flops, wbytes, flops, SSP_PROF_K_WGRAD_BF16);
       CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st, h->rq_bf16));
     }
     {
@@ -2154,7 +2162,8 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
         }
       }
       const double flops = 2.0 * SS.n * N * lh * lw * (double)d.cin * C * 9;
-      ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin + C), flops, SSP_PROF_K_CONV_BF16);
+      // (bytes: dY in, dOut of the layer below out, + the layer-below raw (pooled) output the fused BatchNorm-backward sums read)
+      ProfScope ps(h, SSP_PROF_CONV3X3_DGRAD, st, flops, 2.0 * SS.n * N * lh * lw * ((double)d.cin * (bnr ? 2.0 : 1.0) + C), flops, SSP_PROF_K_CONV_BF16);
       CHK(launch_conv_bf16(c, h->n_cu, st));
       if (bnr) h->bsums_fused[src] = true;
     }
