@@ -60,11 +60,12 @@ struct ConvWsGeom {
   static constexpr int LDS_BYTES = 2 * W_BYTES + 2 * H_BYTES + O_BYTES;
 };
 
-// Threads per workgroup.  The data gradient (IN_MODE 0) runs 4 consumer + 4 producer waves.  The forward (IN_MODE 1) runs THREE
-// roles, 4 + 4 + 4 waves: its producers were a single latency-bound instruction stream per SIMD (measured WITHOUT the MFMA loop:
-// 4300-4760 cycles per stage for ~320 instructions - loads, LDS round trips and stores of the halo staging and of the copy-out wait
-// for each other; profiles/r05_bf16_ws_role_split.txt), so the copy-out / statistics / pooled copy of a finished unit moved to a
-// third wave per SIMD that runs beside the staging wave.
+// Threads per workgroup: BOTH modes run THREE roles, 4 + 4 + 4 waves (consumers / stagers or LDS-DMA issuers / copy-out).  With two
+// roles the producers were a single latency-bound instruction stream per SIMD (measured WITHOUT the MFMA loop: 4300-4760 cycles per
+// stage for ~320 instructions - loads, LDS round trips and stores of the halo staging and of the copy-out wait for each other;
+// profiles/r05_bf16_ws_role_split.txt), so the copy-out / statistics / pooled copy (forward) resp. the copy-out with the fused
+// BatchNorm-backward sums (data gradient) of a finished unit runs on a third wave per SIMD beside the staging wave.  (The two-role
+// form of round 4 - copy-out on the producer waves, 512 threads - is gone: 168 registers per wave is the budget of every role.)
 template <int IN_MODE>
 constexpr int conv_ws_threads() { return 768; }
 
@@ -73,7 +74,6 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
   using G = ConvWsGeom;
   constexpr int HT = G::HT, PAD = 1;
   constexpr bool DMA = IN_MODE == 0;   // the data gradient stages nothing: its halo goes global -> LDS directly (buffer_load ... lds)
-  constexpr bool SPLIT = true;         // waves 4-7 stage / issue the LDS-DMA, waves 8-11 copy out
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* const sW = smem_b;
   unsigned char* const sH = smem_b + 2 * G::W_BYTES;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
   }
 
   // =========================== producers ===========================
-  const bool copier = SPLIT && wave >= 8;                 // (scalar) the copy-out role of the three-role form
+  const bool copier = wave >= 8;                          // (scalar) the copy-out role: waves 4-7 stage / issue the LDS-DMA, waves 8-11 copy out
   const int ptid = (tid - 256) & 255, pwave = (wave - 4) & 3;
   const int part = ptid & 3;
   constexpr int NHS = (HT * HT * 4 + 255) / 256;   // 6 (the last round is partly empty)
@@ -264,7 +264,6 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
     const int r1 = nslot / a.tiles_x, r2 = r1 / a.tiles_y;
     d_tx = nslot - r1 * a.tiles_x; d_ty = r1 - r2 * a.tiles_y; d_vc = r2 / a.N; d_n = r2 - d_vc * a.N;
   }
-  int st1_vc = 0, st1_n = 0, st1_yx = 0, st2_vc = 0, st2_n = 0, st2_yx = 0;
   int ld_view = 0, ld_cob = 0;
   bool ld_border = false;
   auto setup_unit = [&]() __attribute__((always_inline)) {   // descriptor + per-slot offsets of the unit (ld_vc, ld_n, ld_ty, ld_tx)
@@ -294,8 +293,6 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
   auto advance = [&]() __attribute__((always_inline)) {                // -> the following stage; false past the end
     if (ld_chunk + 1 < a.nchunks) { ++ld_chunk; return true; }
     ld_chunk = 0; ld_u += nslot;
-    st2_vc = st1_vc; st2_n = st1_n; st2_yx = st1_yx;
-    st1_vc = ld_vc; st1_n = ld_n; st1_yx = (ld_ty << 16) | ld_tx;
     if (ld_u >= u_end) return false;
     ld_tx += d_tx; int c = ld_tx >= a.tiles_x ? 1 : 0; ld_tx -= c ? a.tiles_x : 0;
     ld_ty += d_ty + c; c = ld_ty >= a.tiles_y ? 1 : 0; ld_ty -= c ? a.tiles_y : 0;
@@ -577,7 +574,7 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
     }
   };
 
-  if constexpr (SPLIT) {
+  {
     if (copier) {
       // ---- copy-out role (waves 8-11 of the forward): its own unit walker, one barrier per stage like everybody else; the unit
       // that finished with stage s - 1 leaves the LDS tile during stage s ----
@@ -632,7 +629,6 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
         fetch_weights(ld_cob * a.nchunks + ld_chunk, Q);
       }
       if (tr) { t1 = __builtin_readcyclecounter(); tc[2] += t1 - t0; }
-      if (!SPLIT && cs_chunk == 0 && s > 0) copy_out(st1_vc, st1_n, st1_yx);   // the unit that finished with stage s - 1
       if (++cs_chunk == a.nchunks) cs_chunk = 0;
       if (tr) { t0 = __builtin_readcyclecounter(); tc[0] += t0 - t1; }
       if (ld_ok) {
@@ -672,7 +668,6 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
   auto iteration = [&](int s, auto PAR) __attribute__((always_inline)) {   // PAR = parity of stage s + 1
     constexpr int Q = decltype(PAR)::value;
     if (tr) t0 = __builtin_readcyclecounter();
-    if (!SPLIT && cs_chunk == 0 && s > 0) { if (NC2) copy_out(st2_vc, st2_n, st2_yx); else copy_out(st1_vc, st1_n, st1_yx); }
     if (++cs_chunk == a.nchunks) cs_chunk = 0;
     if (tr) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; }
     if (s + 1 < nstages) {
@@ -710,10 +705,6 @@ __global__ __launch_bounds__(conv_ws_threads<IN_MODE>(), 1) void conv_bf16_ws_ke
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.trace[wave * 8 + k] = tc[k];
     a.trace[wave * 8 + 7] = nstages;
-  }
-  if constexpr (!SPLIT) {
-    copy_out(st1_vc, st1_n, st1_yx);
-    if ((a.stats[0] != nullptr || do_bnr) && st_key >= 0) flush_stats(st_key);
   }
 }
 

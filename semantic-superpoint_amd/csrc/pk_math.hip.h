@@ -12,9 +12,11 @@ typedef unsigned int ssp_u32x4 __attribute__((ext_vector_type(4)));
 // 16-byte buffer store whose data registers stay untouched for one more wait state.  gfx950 reads the data of a store of more than
 // 8 bytes from the register file for a few cycles after issue; a vector instruction that overwrites one of those registers in the
 // NEXT slot corrupts the last lanes of each 16-lane row of the stored value (found in round 5: v_lshlrev_b32 v6, 16, v7 straight
-// behind buffer_store_dwordx4 v[6:9] stored v7 << 16 in lanes 12-15 / 28-31 / 44-47 / 60-63).  hipcc (ROCm 7.2) does not insert
-// the wait state on this target; the asm keeps the value alive across an s_nop, and hipbuild.verify_binary scans every kernel of
-// the library for the pattern.
+// behind buffer_store_dwordx4 v[6:9] stored v7 << 16 in lanes 12-15 / 28-31 / 44-47 / 60-63).  LLVM pads this hazard for the
+// vector instructions the COMPILER emits; it cannot see a vector write inside INLINE ASM - the exposure of this code base, whose
+// packed arithmetic below is asm throughout (the shift of the round-5 bug came from such a helper).  The asm here keeps the value
+// alive across an s_nop, and hipbuild.verify_binary scans every kernel of the library for the pattern (store_data_hazards): a new
+// asm helper that may overwrite a register a wide store has just read needs the same treatment.
 __device__ __forceinline__ void ssp_store_b128(ssp_u32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
   asm volatile("s_nop 0" : : "v"(v) : "memory");

@@ -180,6 +180,8 @@ struct ssp_handle {
   WredJobs rjobs{};
   bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
   bool apply_fused[16] = {};  // pass 2 (APPLY) of layer l was left to the layer's weight gradient (wgrad_wino_fused_kernel)
+  bool bf16_fuse_apply = true;  // bf16 path: the same for wgrad_bf16_kernel<.., FUSE>; SSP_BF16_FUSE_APPLY, read ONCE per backward pass
+                                // (bf16_fuse_apply_env: tests switch it between two steps of one process) and part of the graph key
   StepAccum* accum;
   float* dots;       // [B * n_match * n_non] non-match dot products of the current step
   float* dense_coef; // [B * cells * cells] d total / d dot of the dense descriptor loss (cfg.dense_loss), else nullptr
@@ -2090,9 +2092,7 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       continue;
     }
     // pass 2 (APPLY) rides the layer's weight gradient (wgrad_bf16_kernel<.., FUSE>; SSP_BF16_FUSE_APPLY=0: the separate pass)
-    const char* const fuse_s = getenv("SSP_BF16_FUSE_APPLY");   // (read per call: tests switch it between two steps of one process)
-    const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
-    const bool fuse_apply = fuse_env != 0 && C % 8 == 0 && (!pool_after || ((lh | lw) & 1) == 0);
+    const bool fuse_apply = h->bf16_fuse_apply && C % 8 == 0 && (!pool_after || ((lh | lw) & 1) == 0);
     if (pool_after) {
       // pass 1 from the raw pooled copy: the arg-max of z over a window IS that element (max for gamma >= 0, min for gamma < 0), so
       // the ReLU-layer sums over the quarter-size tensors (Apool, dOut) equal the window-routed sums over Y; channels with
@@ -2195,11 +2195,14 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     // pass 1 of the 3x3 head's BatchNorm backward in this data gradient's copy-out (its output is dOut of that head; the head's raw
     // output has the output's geometry: its 256-channel slice of [cells][256 heads])
     static const int bnr_env = getenv("SSP_BF16_BNR") ? atoi(getenv("SSP_BF16_BNR")) : 1;
+    // (the same geometry predicate as the fp32 path's add_dgrad: the generic kernel reads S.Y[src] with the OUTPUT's stride / offset /
+    // channel count - a layer table in which the head's raw output sits elsewhere falls back to the separate pass 1)
+    const bool bnr = bnr_env != 0 && h->L[src].bn && S0.y_cs[src] == hcs && S0.y_co[src] == co && h->L[src].cout == c.cout;
     for (int k = 0; k < SS.n; ++k) {
       Slot& S = *SS.s[k];
       w.x[k] = S.Y[src]; w.dy[k] = dy[k]; w.x_scale[k] = S.bn[src].scale; w.x_shift[k] = S.bn[src].shift;
       c.in[k] = dy[k]; c.out[k] = S.gP;
-      if (bnr_env != 0) {
+      if (bnr) {
         c.bnr_t[k] = reinterpret_cast<const uint16_t*>(S.Y[src]);
         c.bnr_scale[k] = S.bn[src].scale; c.bnr_shift[k] = S.bn[src].shift; c.bnr_mean[k] = S.bn[src].mean;
         c.bnr_invstd[k] = S.bn[src].invstd; c.bnr_sums[k] = S.bn[src].bsums;
@@ -2207,7 +2210,7 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     }
     CHK(launch_wgrad_bf16(w, h->partial, h->partial_floats, h->n_cu, st, h->rq_bf16));
     CHK(launch_conv_bf16(c, h->n_cu, st));
-    if (bnr_env != 0) h->bsums_fused[src] = true;
+    if (bnr) h->bsums_fused[src] = true;
     return 0;
   };
   if (has_semi) {
@@ -2231,8 +2234,7 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
   const int heads[3] = {L_PA, L_DA, L_DS};
   // pass 2 (APPLY) of their BatchNorm + ReLU backward rides their weight gradients (as in encoder_backward_bf16): y, dOut and dY are
   // the head's 256-channel slice of [cells][256 heads] tensors
-  const char* const heads_fuse_s = getenv("SSP_BF16_FUSE_APPLY");
-  const bool heads_fuse = heads_fuse_s ? atoi(heads_fuse_s) != 0 : true;
+  const bool heads_fuse = h->bf16_fuse_apply;
   for (int hk = 0; hk < h->nheads; ++hk) {
     const LayerDesc& d = h->L[heads[hk]];
     BnBwdArgs a[2];
@@ -2306,8 +2308,13 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
 enum { EARLY_SPLIT_LAYER = 2 };
 static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
                              float* const* dsout, hipStream_t st, int part);
+static bool bf16_fuse_apply_env() {
+  const char* const e = getenv("SSP_BF16_FUSE_APPLY");
+  return e ? atoi(e) != 0 : true;
+}
 static int run_backward(ssp_handle* h, const SlotSet& SS, const float* const* dsemi, const float* const* draw_desc,
                         float* const* dsout, hipStream_t st, int part = 0) {
+  if (part != 2) h->bf16_fuse_apply = bf16_fuse_apply_env();   // (one value for the heads and the encoder of a step, both phases)
   CHK(run_backward_impl(h, SS, dsemi, draw_desc, dsout, st, part));
   return det_fold(h->buf.grads_dev, st);   // (deterministic mode) bias / first-layer gradients scattered by fp32 atomics
 }
@@ -2779,14 +2786,14 @@ int ssp_pair_step_graph(ssp_handle* h, const ssp_pair_inputs* in, float* scalars
   hipStream_t st = (hipStream_t)stream;
   if (st == nullptr) return fail(-1, "ssp_pair_step_graph needs a non-default stream (stream capture)");
   // key = everything a captured launch depends on except the seed (kept in device memory)
-  std::vector<unsigned char> key(sizeof(ssp_pair_inputs) + sizeof(void*) + 3 * sizeof(int));
+  std::vector<unsigned char> key(sizeof(ssp_pair_inputs) + sizeof(void*) + 4 * sizeof(int));
   {
     ssp_pair_inputs k;
     memcpy(&k, in, sizeof(k));  // bytewise (padding included: the caller's struct is the key)
     k.seed = 0;
     memcpy(key.data(), &k, sizeof(k));
     memcpy(key.data() + sizeof(k), &scalars_dev, sizeof(void*));
-    const int extra[3] = {phase, sample_indices, h->conv_algo};
+    const int extra[4] = {phase, sample_indices, h->conv_algo, bf16_fuse_apply_env() ? 1 : 0};   // (a captured backward freezes the switch)
     memcpy(key.data() + sizeof(k) + sizeof(void*), extra, sizeof(extra));
   }
   hipGraphExec_t exec = nullptr;

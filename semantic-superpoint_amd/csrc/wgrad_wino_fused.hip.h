@@ -20,7 +20,12 @@
 #pragma once
 #include "conv_wino.hip.h"
 #include <type_traits>
-#include "conv_wino_bf16.hip.h"
+#ifndef SSP_LEGACY_ALGOS
+#define SSP_LEGACY_ALGOS 0
+#endif
+#if SSP_LEGACY_ALGOS
+#include "conv_wino_bf16.hip.h"   // (the bf16-operand MFMA phase of the retired mixed mode 8: BF16 = true below)
+#endif
 
 #ifndef WGF_TRACE
 #define WGF_TRACE 0  // compile-time perf trace (never in the shipped library): s_memtime stamps around the phases of a tile, summed per
@@ -44,6 +49,7 @@ struct WgradFusedGeom {
 // v_mfma_f32_32x32x8_bf16 per 8 tiles; the mixed bf16 mode 8) on the same fp32 LDS tile images.
 template <int IN_MODE, bool WIDE, bool POOL, bool BF16 = false>
 __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a) {
+  static_assert(!BF16 || SSP_LEGACY_ALGOS, "the bf16-operand form belongs to the retired conv algorithms (-DSSP_LEGACY_ALGOS=1)");
   using G = WgradWinoGeom<WIDE>;
   using GF = WgradFusedGeom<WIDE>;
   constexpr int NX = GF::NX;
@@ -396,6 +402,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
       const float* db0 = sD + (2 * lh) * 64 + coh * 32 + li;
       if (!BF16) wgrad_wino_steps<G>(acc, xa0, xb0, db0, f32x2{sg, sg}, f32x2{c0, c0}, f32x2{c1, c1}, wgf_load_slice);
     }
+#if SSP_LEGACY_ALGOS
     if (BF16) {
       // (pinned: hipcc converts each value on its own as soon as it exists and merges the halves with v_perm_b32)
       auto cvt2 = [](float lo, float hi) -> unsigned {
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
         }
       }
     }
+#endif
     WGF_T(4)
   }
 #if WGF_TRACE

@@ -112,32 +112,43 @@ def disassemble(lib_path, workdir):
     return dis, notes
 
 
-_STORE_RE = re.compile(r"(?:buffer|global|flat|scratch)_store_dwordx[34]\s+(?:v\d+,\s+|v\[\d+:\d+\],\s+)?v\[(\d+):(\d+)\]")
-_BUF_STORE_RE = re.compile(r"buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\]")
-_VALU_DST_RE = re.compile(r"(v_\S+)\s+(?:v\[(\d+):(\d+)\]|v(\d+))(?=[,\s]|$)")
+_STORE_RE = re.compile(r"(?:buffer|global|flat|scratch)_store_dwordx[34]\s+(?:off,\s+|v\d+,\s+|v\[\d+:\d+\],\s+)?([va])\[(\d+):(\d+)\]")
+_VALU_DST_RE = re.compile(r"(v_\S+)\s+(?:([va])\[(\d+):(\d+)\]|([va])(\d+))(?=[,\s]|$)")
+_INSN_RE = re.compile(r"^[a-z][a-z0-9_]*(\s|$)")
 
 
 def store_data_hazards(dis):
-    """[(kernel, store, clobbering instruction)]: every 12 / 16-byte store of the disassembly `dis` whose NEXT instruction is a
-    vector-ALU instruction writing one of the store's data registers.  The hardware reads the data of such a store for a few cycles
-    after issue (one wait state), and hipcc for gfx950 (ROCm 7.2) does not keep the slot free: round 5 found conv_bf16_ws_kernel
-    storing v7 << 16 in the last four lanes of every 16-lane row behind `buffer_store_dwordx4 v[6:9]; v_lshlrev_b32 v6, 16, v7`."""
+    """[(kernel, store, clobbering instruction)]: every 12 / 16-byte store of the disassembly `dis` whose NEXT INSTRUCTION is a
+    vector-ALU instruction writing one of the store's data registers (vector or accumulation registers; the `off,` scratch form
+    included; labels and other non-instruction lines between the two are skipped: a branch target does not hide a fall-through).
+    The hardware reads the data of such a store for a few cycles after issue (one wait state).  LLVM's hazard recognizer pads this for
+    the VALU instructions the COMPILER emits; what it cannot see is a VALU write inside INLINE ASM, which this code base uses
+    everywhere (pk_math.hip.h): round 5 found conv_bf16_ws_kernel storing v7 << 16 in the last four lanes of every 16-lane row
+    behind `buffer_store_dwordx4 v[6:9]; v_lshlrev_b32 v6, 16, v7` (the shift came from an asm helper).  New asm helpers that
+    write a register a wide store has just read must keep the value alive across an s_nop (ssp_store_b128)."""
     out = []
     parts = re.split(r"^[0-9a-f]{16} <([^>]+)>:\n", dis, flags=re.M)
     for i in range(1, len(parts), 2):
         name = parts[i]
-        lines = [l.strip() for l in parts[i + 1].splitlines() if l.strip()]
+        # instruction lines only (llvm-objdump prints "<label>:" lines for branch targets inside a kernel)
+        lines = [l.strip().split("//")[0].strip() for l in parts[i + 1].splitlines()]
+        lines = [l for l in lines if l and _INSN_RE.match(l)]
         for k in range(len(lines) - 1):
-            m = _BUF_STORE_RE.match(lines[k]) or _STORE_RE.match(lines[k])
+            m = _STORE_RE.match(lines[k])
             if not m:
                 continue
-            a, b = int(m.group(1)), int(m.group(2))
+            bank, a, b = m.group(1), int(m.group(2)), int(m.group(3))
             mm = _VALU_DST_RE.match(lines[k + 1])
             if not mm or mm.group(1).startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
                 continue
-            lo, hi = (int(mm.group(2)), int(mm.group(3))) if mm.group(2) else (int(mm.group(4)), int(mm.group(4)))
-            if lo <= b and hi >= a:
-                out.append((name, lines[k].split("//")[0].strip(), lines[k + 1].split("//")[0].strip()))
+            if mm.group(2):
+                dbank, lo, hi = mm.group(2), int(mm.group(3)), int(mm.group(4))
+            else:
+                dbank, lo, hi = mm.group(5), int(mm.group(6)), int(mm.group(6))
+            if mm.group(1).startswith("v_accvgpr_write"):
+                dbank = "a"
+            if dbank == bank and lo <= b and hi >= a:
+                out.append((name, lines[k], lines[k + 1]))
     return out
 
 

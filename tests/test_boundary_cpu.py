@@ -58,13 +58,20 @@ def test_store_data_hazard_lint():
         "\tv_add_f32_e32 v30, v18, v19                                // 000000001038: 023C2712\n"      # reads only: fine
         "\tbuffer_store_dwordx2 v[40:41], v55, s[36:39], s20 offen    // 000000001040: E0741000\n"
         "\tv_mov_b32_e32 v40, 0                                       // 000000001048: 7E500280\n"      # 8-byte store: no hazard
+        "\tscratch_store_dwordx4 off, v[50:53], off offset:16         // 000000001050: DC7C0010\n"      # the `off,` scratch form ...
+        "<L7>:\n"                                                                                        # ... across a branch-target label
+        "\tv_mov_b32_e32 v52, 0                                       // 000000001058: 7E680280\n"
+        "\tglobal_store_dwordx4 v[2:3], a[4:7], off                   // 000000001060: DC7C8000\n"      # accumulation-register data
+        "\tv_accvgpr_write_b32 a5, v3                                 // 000000001068: D3D94005\n"
         "0000000000002000 <kernel_b>:\n"
         "\tbuffer_store_dwordx4 v[6:9], v55, s[36:39], s62 offen      // 000000002000: E07C1000\n"
         "\tv_cmp_gt_f32_e32 vcc, v6, v7                               // 000000002008: 7C880F06\n"      # writes no vector register
     )
     found = hb.store_data_hazards(dis)
     assert [(k, c.split()[0], c.split()[1].rstrip(",")) for k, _, c in found] == [("kernel_a", "v_lshlrev_b32_e32", "v6"),
-                                                                                ("kernel_a", "v_pk_add_f32", "v[12:13]")], found
+                                                                                ("kernel_a", "v_pk_add_f32", "v[12:13]"),
+                                                                                ("kernel_a", "v_mov_b32_e32", "v52"),
+                                                                                ("kernel_a", "v_accvgpr_write_b32", "a5")], found
     ssp.build()
     with tempfile.TemporaryDirectory(prefix="ssp_isa_", dir="/tmp") as tmp:
         real, _ = hb.disassemble(hb.LIB, tmp)

@@ -10,7 +10,13 @@ from semantic_superpoint_amd import lib as L
 dev = torch.device("cuda:0")
 import socket
 pr = torch.cuda.get_device_properties(0)
-print("box %s: %s, %d CUs, %.0f GB" % (socket.gethostname(), pr.name, pr.multi_processor_count, pr.total_memory / 2**30), flush=True)
+import subprocess
+try:
+    uid = subprocess.run(["rocm-smi", "--showuniqueid"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
+    uid = " ".join(l.split(":")[-1].strip() for l in uid.splitlines() if "Unique ID" in l)
+except Exception as ex:
+    uid = "?"
+print("box %s gpu %s: %s, %d CUs, %.0f GB" % (socket.gethostname(), uid, pr.name, pr.multi_processor_count, pr.total_memory / 2**30), flush=True)
 def to_dev(s): return {k: v.to(dev).contiguous() for k, v in s.items()}
 for (arch, B, H, W) in [("SuperPointNet_gauss2_ssmall", 2, 120, 160), ("SuperPointNet_gauss2", 2, 240, 320), ("SuperPointNet_gauss2", 1, 72, 104)]:
     sd = C.init_state_dict(arch, seed=12)
