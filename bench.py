@@ -77,11 +77,17 @@ def cpu_baseline(arch, H, W, batch=32, steps=3):
                       % (arch, H, W, batch, steps, dt)}
 
 
+def under_profiler():
+    """True when this process runs under rocprofv3 (its tool library is preloaded and has initialised the GPU before main()): no
+    child processes may be started from here, and the clock-probe launches would only pollute the kernel statistics."""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
+
+
 def power_state():
     """Socket power cap / current draw of GPU 0 as rocm-smi reports them (a child process, run BEFORE this process touches the GPU;
     None where the tool or the field is missing): the boxes of a pool differ in the clock their power controller grants."""
     exe = shutil.which("rocm-smi")
-    if exe is None:
+    if exe is None or under_profiler():
         return None
     try:
         r = subprocess.run([exe, "-d", "0", "--showmaxpower", "--showpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
@@ -520,7 +526,8 @@ def main():
         eng.profile_enable("conv3x3_every")  # every 3x3 forward / data-gradient / weight-gradient launch, split by kernel
         profiling[0] = True
     torch.cuda.synchronize()
-    clock_before = ssp.lib.clock_probe(5.0) if rank == 0 else None   # (outside the timed region; ~5 ms of fp32 MFMAs on every CU)
+    probe_clock = rank == 0 and not under_profiler() and not args.pmc_child
+    clock_before = ssp.lib.clock_probe(5.0) if probe_clock else None   # (outside the timed region; ~5 ms of fp32 MFMAs on every CU)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -530,7 +537,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    clock_after = ssp.lib.clock_probe(5.0) if rank == 0 else None
+    clock_after = ssp.lib.clock_probe(5.0) if probe_clock else None
     per_rank_ms = [1e3 * dt / args.steps]
     if world > 1:
         mine = torch.tensor([dt], dtype=torch.float64, device=dev)

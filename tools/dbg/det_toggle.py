@@ -4,18 +4,19 @@
 import os, sys, gc
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
-import torch
-from oracle import cpu_ref as C
-from semantic_superpoint_amd import lib as L
-dev = torch.device("cuda:0")
-import socket
-pr = torch.cuda.get_device_properties(0)
+# (the GPU's unique id BEFORE anything initialises the GPU: no child processes afterwards)
 import subprocess
 try:
     uid = subprocess.run(["rocm-smi", "--showuniqueid"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
     uid = " ".join(l.split(":")[-1].strip() for l in uid.splitlines() if "Unique ID" in l)
 except Exception as ex:
     uid = "?"
+import torch
+from oracle import cpu_ref as C
+from semantic_superpoint_amd import lib as L
+dev = torch.device("cuda:0")
+import socket
+pr = torch.cuda.get_device_properties(0)
 print("box %s gpu %s: %s, %d CUs, %.0f GB" % (socket.gethostname(), uid, pr.name, pr.multi_processor_count, pr.total_memory / 2**30), flush=True)
 def to_dev(s): return {k: v.to(dev).contiguous() for k, v in s.items()}
 for (arch, B, H, W) in [("SuperPointNet_gauss2_ssmall", 2, 120, 160), ("SuperPointNet_gauss2", 2, 240, 320), ("SuperPointNet_gauss2", 1, 72, 104)]:
