@@ -284,6 +284,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   const int t_dst = (t_row * 6 * W4_TILES + t_tile) * PK + ((q2 ^ ((t_tile >> 3) & 1)) << 2);
   constexpr int DST_B = 6 * W4_TILES * PK;            // the pair's second row
 #define W4_LD(P) (*reinterpret_cast<const f32x4*>(P))
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
   // raw pixels of column C, one MFMA slot ahead of their use: pair task rx0..3 = raw rows 1..4; single task rx0, rx1 = the two
   // rows at distance 2 from the first one, rx3 = the last row (4 or 5)
 #define W4_TR_RD(C)                                                                                         \
@@ -292,6 +293,17 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     rx0 = W4_LD(pa_); rx1 = W4_LD(pa_ + ROWF * 4); rx2 = W4_LD(pa_ + 2 * ROWF * 4);                         \
     rx3 = W4_LD(reinterpret_cast<const char*>(smem) + ((unsigned)t_ab[C] >> 16));                           \
   }
+// pair task, round 6b: two raw-pixel register sets (X = rxa / rxb) so that the reads of the NEXT column are the first instructions
+// behind an MFMA (they issue in its shadow; behind the column arithmetic they each took an issue slot of their own), with the two
+// byte addresses (pa_n, pb_n) unpacked at the end of the previous slice
+#define W4_TR_ADDR(C) { pa_n = t_ab[C] & 0xffff; pb_n = (int)((unsigned)t_ab[C] >> 16); }
+#define W4_TR_RDX(X)                                                                                        \
+  {                                                                                                         \
+    const char* pa_ = reinterpret_cast<const char*>(smem) + pa_n;                                           \
+    X##0 = W4_LD(pa_); X##1 = W4_LD(pa_ + ROWF * 4); X##2 = W4_LD(pa_ + 2 * ROWF * 4);                      \
+    X##3 = W4_LD(reinterpret_cast<const char*>(smem) + pb_n);                                               \
+  }
+#define W4_PCX(C, X) { const f32x4 p_ = pk4_fma_k(tkp, X##1, X##3), q_ = pk4_fma_k(tkp, X##0, X##2); TA##C = pk4_fma_k(tks, q_, p_); TB##C = pk4_fma_k(tkn, q_, p_); }
 #define W4_TR_RD3(C)                                                                                        \
   {                                                                                                         \
     const char* pa_ = reinterpret_cast<const char*>(smem) + (t_ab[C] & 0xffff);                             \
@@ -309,23 +321,30 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #define W4_RP_D(TC_, TE_, DSTBUF) { W4_TR_WR(DSTBUF, 3, pk_fma_p24(TE_, TC_)) W4_TR_WR(DSTBUF, 4, pk_fma_m24(TE_, TC_)) }
   // the slices of the two task kinds (S = slice number; the stage body puts one slice behind one MFMA, the prologue runs them
   // back to back); row A's even-column values (ta, tc) stay live across the odd columns, row B's go through ta2, tc2
+// (the row-pass outputs of a slice are written at the START of the next slice - pw0 / pw1 -: a ds_write_b128 right behind an MFMA
+// issues in its shadow, behind the arithmetic that produced its data it took ~10 cycles of its own)
+#define W4_RPX_A(T, TA_, TC_) { TC_ = pk4_sub(T##4, T##2); TA_ = pk_fma_m44(T##2, T##4); pw0 = pk_fma_p44(pk4_sub(T##0, T##2), TC_); }
+#define W4_RPX_B(T) { te = pk4_sub(T##3, T##1); tb = pk_fma_m44(T##1, T##3); pw0 = pk_fma_m44(te, pk4_sub(T##5, T##3)); }
+#define W4_RPX_C(TA_) { pw0 = pk4_add(TA_, tb); pw1 = pk4_sub(TA_, tb); }
+#define W4_RPX_D(TC_) { pw0 = pk_fma_p24(te, TC_); pw1 = pk_fma_m24(te, TC_); }
 #define W4_PSL(S, DSTBUF)                                                                                   \
   if (twB) {                                                                                                \
-    if constexpr ((S) == 0) W4_TR_RD(0)                                                                     \
-    else if constexpr ((S) == 1) { W4_PC(0) W4_TR_RD(2) }                                                   \
-    else if constexpr ((S) == 2) { W4_PC(2) W4_TR_RD(4) }                                                   \
-    else if constexpr ((S) == 3) { W4_PC(4) W4_TR_RD(1) }                                                   \
-    else if constexpr ((S) == 4) W4_RP_A(TA, DSTBUF, ta, tc)                                                \
-    else if constexpr ((S) == 5) W4_RP_A(TB, (DSTBUF) + DST_B, ta2, tc2)                                    \
-    else if constexpr ((S) == 6) { W4_PC(1) W4_TR_RD(3) }                                                   \
-    else if constexpr ((S) == 7) { W4_PC(3) W4_TR_RD(5) }                                                   \
-    else if constexpr ((S) == 8) W4_PC(5)                                                                   \
-    else if constexpr ((S) == 9) W4_RP_B(TA, DSTBUF)                                                        \
-    else if constexpr ((S) == 10) W4_RP_C(ta, tb, DSTBUF)                                                   \
-    else if constexpr ((S) == 11) W4_RP_D(tc, te, DSTBUF)                                                   \
-    else if constexpr ((S) == 12) W4_RP_B(TB, (DSTBUF) + DST_B)                                             \
-    else if constexpr ((S) == 13) W4_RP_C(ta2, tb, (DSTBUF) + DST_B)                                        \
-    else if constexpr ((S) == 14) W4_RP_D(tc2, te, (DSTBUF) + DST_B)                                        \
+    if constexpr ((S) == 0) { W4_TR_ADDR(0) W4_TR_RDX(rxa) W4_TR_ADDR(2) }                                  \
+    else if constexpr ((S) == 1) { W4_TR_RDX(rxb) W4_FENCE(); W4_PCX(0, rxa) W4_TR_ADDR(4) }                \
+    else if constexpr ((S) == 2) { W4_TR_RDX(rxa) W4_FENCE(); W4_PCX(2, rxb) W4_TR_ADDR(1) }                \
+    else if constexpr ((S) == 3) { W4_TR_RDX(rxb) W4_FENCE(); W4_PCX(4, rxa) W4_TR_ADDR(3) }                \
+    else if constexpr ((S) == 4) { W4_TR_RDX(rxa) W4_FENCE(); W4_RPX_A(TA, ta, tc) }                        \
+    else if constexpr ((S) == 5) { W4_TR_WR(DSTBUF, 0, pw0) W4_FENCE(); W4_RPX_A(TB, ta2, tc2) }            \
+    else if constexpr ((S) == 6) { W4_TR_WR((DSTBUF) + DST_B, 0, pw0) W4_FENCE(); W4_PCX(1, rxb) W4_TR_ADDR(5) } \
+    else if constexpr ((S) == 7) { W4_TR_RDX(rxb) W4_FENCE(); W4_PCX(3, rxa) }                              \
+    else if constexpr ((S) == 8) W4_PCX(5, rxb)                                                             \
+    else if constexpr ((S) == 9) W4_RPX_B(TA)                                                               \
+    else if constexpr ((S) == 10) { W4_TR_WR(DSTBUF, 5, pw0) W4_FENCE(); W4_RPX_C(ta) }                     \
+    else if constexpr ((S) == 11) { W4_TR_WR(DSTBUF, 1, pw0) W4_TR_WR(DSTBUF, 2, pw1) W4_FENCE(); W4_RPX_D(tc) } \
+    else if constexpr ((S) == 12) { W4_TR_WR(DSTBUF, 3, pw0) W4_TR_WR(DSTBUF, 4, pw1) W4_FENCE(); W4_RPX_B(TB) } \
+    else if constexpr ((S) == 13) { W4_TR_WR((DSTBUF) + DST_B, 5, pw0) W4_FENCE(); W4_RPX_C(ta2) }          \
+    else if constexpr ((S) == 14) { W4_TR_WR((DSTBUF) + DST_B, 1, pw0) W4_TR_WR((DSTBUF) + DST_B, 2, pw1) W4_FENCE(); W4_RPX_D(tc2) } \
+    else if constexpr ((S) == 15) { W4_TR_WR((DSTBUF) + DST_B, 3, pw0) W4_TR_WR((DSTBUF) + DST_B, 4, pw1) } \
   }
 #define W4_SSL(S, DSTBUF)                                                                                   \
   if (twB) {                                                                                                \
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     else if constexpr ((S) == 9) W4_RP_C(ta, tb, DSTBUF)                                                    \
     else if constexpr ((S) == 10) W4_RP_D(tc, te, DSTBUF)                                                   \
   }
-#define W4_XF_REGS f32x4 rx0, rx1, rx2, rx3, TA0, TA1, TA2, TA3, TA4, TA5, TB0, TB1, TB2, TB3, TB4, TB5, ta, tb, tc, te, ta2, tc2;
+#define W4_XF_REGS f32x4 rx0, rx1, rx2, rx3, rxa0, rxa1, rxa2, rxa3, rxb0, rxb1, rxb2, rxb3; int pa_n, pb_n; f32x4 pw0, pw1, TA0, TA1, TA2, TA3, TA4, TA5, TB0, TB1, TB2, TB3, TB4, TB5, ta, tb, tc, te, ta2, tc2;
   // the whole task, unsliced (prologue)
 #define W4_TRANSFORM_ALL(DSTBUF)                                                                            \
   {                                                                                                         \
@@ -349,6 +368,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     if (t_pair) {                                                                                           \
       W4_PSL(0, DSTBUF) W4_PSL(1, DSTBUF) W4_PSL(2, DSTBUF) W4_PSL(3, DSTBUF) W4_PSL(4, DSTBUF) W4_PSL(5, DSTBUF) W4_PSL(6, DSTBUF) W4_PSL(7, DSTBUF) \
       W4_PSL(8, DSTBUF) W4_PSL(9, DSTBUF) W4_PSL(10, DSTBUF) W4_PSL(11, DSTBUF) W4_PSL(12, DSTBUF) W4_PSL(13, DSTBUF) W4_PSL(14, DSTBUF) \
+      W4_PSL(15, DSTBUF)                                                                                    \
     } else {                                                                                                \
       W4_SSL(0, DSTBUF) W4_SSL(1, DSTBUF) W4_SSL(2, DSTBUF) W4_SSL(3, DSTBUF) W4_SSL(4, DSTBUF) W4_SSL(5, DSTBUF) W4_SSL(6, DSTBUF) W4_SSL(7, DSTBUF) \
       W4_SSL(8, DSTBUF) W4_SSL(9, DSTBUF) W4_SSL(10, DSTBUF)                                                \
@@ -449,7 +469,6 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   else w4_mfma_a<((P) < 8 ? 2 * (P) + 1 : 0)>(Fb##S[(I) >> 1], Wb##SW[(I) >> 1]);                            \
   __builtin_amdgcn_sched_barrier(0);
 #define W4_MM(P, I, S) W4_MMX(P, I, S, S)
-#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define W4_MM8(P, S) W4_MM(P, 0, S) W4_MM(P, 1, S) W4_MM(P, 2, S) W4_MM(P, 3, S) W4_MM(P, 4, S) W4_MM(P, 5, S) W4_MM(P, 6, S) W4_MM(P, 7, S)
 
   int g = -1;  // (the ablation macros test g < 0 = prologue)
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   if (W4_ABL & (256 | 512)) { W4_FETCH(0, sA, 0, 0) W4_FETCH(1, sA, 1, 0) W4_FETCH(2, sA, 2, 0) }
 
   // first half of a stage: pairs 0..4 (40 MFMAs); transform slice k of the wave's task behind MFMA slot k (slots = the MFMAs of
-  // pairs 0, 2 and the first four of pairs 1, 3; the pair task has 15 slices, the single-row task 11)
+  // pairs 0, 2 and the first four of pairs 1, 3; the pair task has 16 slices, the single-row task 11)
 #define W4_PSLN(S) W4_PSL(S, nA)
 #define W4_SSLN(S) W4_SSL(S, nA)
 #define W4_HALF1(SL)                                                                                                  \
@@ -481,7 +500,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_MM(2, 0, 2) SL(12) W4_FENCE();                                                                                 \
     W4_MM(2, 1, 2) SL(13) W4_FENCE();                                                                                 \
     W4_MM(2, 2, 2) SL(14) W4_FENCE();                                                                                 \
-    W4_MM(2, 3, 2) W4_MM(2, 4, 2) W4_MM(2, 5, 2) W4_MM(2, 6, 2)                                                       \
+    W4_MM(2, 3, 2) SL(15) W4_FENCE();                                                                                 \
+    W4_MM(2, 4, 2) W4_MM(2, 5, 2) W4_MM(2, 6, 2)                                                                      \
     W4_MM(2, 7, 2) W4_FETCH(1, cA, 4, chunk) W4_FENCE();                                                              \
     W4_MM8(3, 0)                                                                                                      \
     W4_FETCH(2, cA, 5, chunk)                                                                                         \
@@ -503,12 +523,14 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_FETCH_F(1, cA, 1)                                                                                              \
     W4_FENCE();                                                                                                       \
     if (t_pair) { W4_HALF1(W4_PSLN) } else { W4_HALF1(W4_SSLN) }                                                      \
+    W4_HALO_PAR(SET)   /* (in front of the barrier: the LDS round trip of the BN parameters was exposed in front of the first BN slice) */ \
+    W4_FENCE();                                                                                                       \
     W4_T(0)                                                                                                           \
     if (!(W4_ABL & 128)) __syncthreads();                                                                             \
     W4_T(1)                                                                                                           \
     W4_FETCH(0, cA, 6, chunk)                                                                                         \
     W4_FENCE();                                                                                                       \
-    W4_MM(5, 0, 2) W4_HALO_PAR(SET) W4_HALO_BN(0, SET) W4_FENCE();                                                    \
+    W4_MM(5, 0, 2) W4_HALO_BN(0, SET) W4_FENCE();                                                                     \
     W4_MM(5, 1, 2) W4_HALO_WR(0, SET) W4_FENCE();                                                                     \
     W4_MM(5, 2, 2) W4_HALO_BN(1, SET) W4_FENCE();                                                                     \
     W4_MM(5, 3, 2) W4_HALO_WR(1, SET) W4_FENCE();                                                                     \
@@ -786,6 +808,13 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #undef W4_RP_C
 #undef W4_RP_D
 #undef W4_TR_RD3
+#undef W4_TR_RDX
+#undef W4_TR_ADDR
+#undef W4_PCX
+#undef W4_RPX_A
+#undef W4_RPX_B
+#undef W4_RPX_C
+#undef W4_RPX_D
 #undef W4_XF_REGS
 #undef W4_FETCH
 #undef W4_FETCH_F
