@@ -346,19 +346,27 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     else if constexpr ((S) == 14) { W4_TR_WR((DSTBUF) + DST_B, 1, pw0) W4_TR_WR((DSTBUF) + DST_B, 2, pw1) W4_FENCE(); W4_RPX_D(tc2) } \
     else if constexpr ((S) == 15) { W4_TR_WR((DSTBUF) + DST_B, 3, pw0) W4_TR_WR((DSTBUF) + DST_B, 4, pw1) } \
   }
+#define W4_TR_RD3X(X)                                                                                       \
+  {                                                                                                         \
+    const char* pa_ = reinterpret_cast<const char*>(smem) + pa_n;                                           \
+    X##0 = W4_LD(pa_); X##1 = W4_LD(pa_ + 2 * ROWF * 4);                                                    \
+    X##3 = W4_LD(reinterpret_cast<const char*>(smem) + (pb_n + dLb));                                       \
+  }
+#define W4_SCX(C, X) TA##C = pk_fma_p44(X##0, pk4_fma_k(tkp, X##1, X##3));
 #define W4_SSL(S, DSTBUF)                                                                                   \
   if (twB) {                                                                                                \
-    if constexpr ((S) == 0) W4_TR_RD3(0)                                                                    \
-    else if constexpr ((S) == 1) { W4_SC(0) W4_TR_RD3(2) }                                                  \
-    else if constexpr ((S) == 2) { W4_SC(2) W4_TR_RD3(4) }                                                  \
-    else if constexpr ((S) == 3) { W4_SC(4) W4_TR_RD3(1) }                                                  \
-    else if constexpr ((S) == 4) W4_RP_A(TA, DSTBUF, ta, tc)                                                \
-    else if constexpr ((S) == 5) { W4_SC(1) W4_TR_RD3(3) }                                                  \
-    else if constexpr ((S) == 6) { W4_SC(3) W4_TR_RD3(5) }                                                  \
-    else if constexpr ((S) == 7) W4_SC(5)                                                                   \
-    else if constexpr ((S) == 8) W4_RP_B(TA, DSTBUF)                                                        \
-    else if constexpr ((S) == 9) W4_RP_C(ta, tb, DSTBUF)                                                    \
-    else if constexpr ((S) == 10) W4_RP_D(tc, te, DSTBUF)                                                   \
+    if constexpr ((S) == 0) { W4_TR_ADDR(0) W4_TR_RD3X(rxa) W4_TR_ADDR(2) }                                 \
+    else if constexpr ((S) == 1) { W4_TR_RD3X(rxb) W4_FENCE(); W4_SCX(0, rxa) W4_TR_ADDR(4) }               \
+    else if constexpr ((S) == 2) { W4_TR_RD3X(rxa) W4_FENCE(); W4_SCX(2, rxb) W4_TR_ADDR(1) }               \
+    else if constexpr ((S) == 3) { W4_TR_RD3X(rxb) W4_FENCE(); W4_SCX(4, rxa) W4_TR_ADDR(3) }               \
+    else if constexpr ((S) == 4) { W4_TR_RD3X(rxa) W4_FENCE(); W4_RPX_A(TA, ta, tc) }                       \
+    else if constexpr ((S) == 5) { W4_TR_WR(DSTBUF, 0, pw0) W4_FENCE(); W4_SCX(1, rxb) W4_TR_ADDR(5) }      \
+    else if constexpr ((S) == 6) { W4_TR_RD3X(rxb) W4_FENCE(); W4_SCX(3, rxa) }                             \
+    else if constexpr ((S) == 7) W4_SCX(5, rxb)                                                             \
+    else if constexpr ((S) == 8) W4_RPX_B(TA)                                                               \
+    else if constexpr ((S) == 9) { W4_TR_WR(DSTBUF, 5, pw0) W4_FENCE(); W4_RPX_C(ta) }                      \
+    else if constexpr ((S) == 10) { W4_TR_WR(DSTBUF, 1, pw0) W4_TR_WR(DSTBUF, 2, pw1) W4_FENCE(); W4_RPX_D(tc) } \
+    else if constexpr ((S) == 11) { W4_TR_WR(DSTBUF, 3, pw0) W4_TR_WR(DSTBUF, 4, pw1) }                     \
   }
 #define W4_XF_REGS f32x4 rx0, rx1, rx2, rx3, rxa0, rxa1, rxa2, rxa3, rxb0, rxb1, rxb2, rxb3; int pa_n, pb_n; f32x4 pw0, pw1, TA0, TA1, TA2, TA3, TA4, TA5, TB0, TB1, TB2, TB3, TB4, TB5, ta, tb, tc, te, ta2, tc2;
   // the whole task, unsliced (prologue)
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
       W4_PSL(15, DSTBUF)                                                                                    \
     } else {                                                                                                \
       W4_SSL(0, DSTBUF) W4_SSL(1, DSTBUF) W4_SSL(2, DSTBUF) W4_SSL(3, DSTBUF) W4_SSL(4, DSTBUF) W4_SSL(5, DSTBUF) W4_SSL(6, DSTBUF) W4_SSL(7, DSTBUF) \
-      W4_SSL(8, DSTBUF) W4_SSL(9, DSTBUF) W4_SSL(10, DSTBUF)                                                \
+      W4_SSL(8, DSTBUF) W4_SSL(9, DSTBUF) W4_SSL(10, DSTBUF) W4_SSL(11, DSTBUF)                             \
     }                                                                                                       \
   }
 
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   if (W4_ABL & (256 | 512)) { W4_FETCH(0, sA, 0, 0) W4_FETCH(1, sA, 1, 0) W4_FETCH(2, sA, 2, 0) }
 
   // first half of a stage: pairs 0..4 (40 MFMAs); transform slice k of the wave's task behind MFMA slot k (slots = the MFMAs of
-  // pairs 0, 2 and the first four of pairs 1, 3; the pair task has 16 slices, the single-row task 11)
+  // pairs 0, 2 and the first four of pairs 1, 3; the pair task has 16 slices, the single-row task 12)
 #define W4_PSLN(S) W4_PSL(S, nA)
 #define W4_SSLN(S) W4_SSL(S, nA)
 #define W4_HALF1(SL)                                                                                                  \
@@ -811,6 +819,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #undef W4_TR_RDX
 #undef W4_TR_ADDR
 #undef W4_PCX
+#undef W4_TR_RD3X
+#undef W4_SCX
 #undef W4_RPX_A
 #undef W4_RPX_B
 #undef W4_RPX_C
