@@ -19,10 +19,9 @@
 // Stage pipeline (8 input channels per stage = 72 MFMAs per wave in 9 component pairs, the two accumulators of a pair
 // alternating; transformed input double-buffered, ONE raw-halo buffer):
 //
-//   first half : pairs 0..4  ||  transform raw(g+1): sR -> sA[~g&1]  (wave w: row w of V = B^T d B, waves 0, 1 also row w + 4)
-//   barrier A
-//   second half: pairs 5..8  ||  halo (g+2): registers -> sR (BatchNorm + ReLU of the producer), halo loads (g+3)
-//   barrier B
+//   first half : pairs 0..4  ||  transform raw(g+1): sR[~g&1] -> sA[~g&1]  (the wave's transform task, below)
+//   second half: pairs 5..8  ||  halo (g+2): registers -> sR[g&1] (BatchNorm + ReLU of the producer), halo loads (g+4)
+//   barrier    (ONE per stage since round 6: raw halo and transformed input are both double-buffered)
 //
 // Three rotating operand sets (9 = 3 x 3 pairs per stage: the same rotation in every stage; two of them live at a time):
 // weights from L2 (the packed
@@ -68,11 +67,14 @@ constexpr int W4_A_FLOATS = W4C * W4_TILES * PK;       // 9216 floats = 36 KB tr
 constexpr int W4_B_FLOATS = W4C * PK * NB;             // 18432 floats: packed weights per (cob, 8-channel chunk)
 constexpr int W4_R_FLOATS = 34 * 24 * PK;              // raw halo: 34 rows x 24 pixels (16x32 tiles) >= 18 x 40 (32x16)
 constexpr int W4_X_FLOATS = 4 * 8 * 256;               // row exchange: [wave][8 values][lane][4] = 32 KB
-constexpr int W4_S_FLOATS = 2048 + 2 * NB;             // BatchNorm scale | shift (or 4 x 64 bnr parameters), bias, pool sign
-constexpr int W4_LDS_BYTES = (2 * W4_A_FLOATS + W4_R_FLOATS + W4_X_FLOATS + W4_S_FLOATS) * 4;  // 141312
+constexpr int W4_MAX_CIN = 256;                        // (scale | shift of the producer's BatchNorm in LDS; w4_eligible)
+constexpr int W4_S_FLOATS = 2 * W4_MAX_CIN + 2 * NB;   // BatchNorm scale | shift (or 4 x 64 bnr parameters), bias, pool sign
+// TWO raw-halo buffers (round 6): halo (g+2) goes into the buffer whose transform finished a stage ago while transform (g+1) reads
+// the other one - ONE barrier per stage instead of two
+constexpr int W4_LDS_BYTES = (2 * W4_A_FLOATS + 2 * W4_R_FLOATS + W4_X_FLOATS + W4_S_FLOATS) * 4;  // 161280
 static_assert(W4_X_FLOATS <= W4_A_FLOATS, "the consumed transformed-input buffer is the second exchange buffer");
 static_assert(W4_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-static_assert(W4_R_FLOATS * 4 < 65536, "16-bit raw-halo byte addresses");
+static_assert(2 * W4_R_FLOATS * 4 < 65536, "16-bit raw-halo byte addresses (+ the buffer offset in the instruction)");
 static_assert(W4_B_FLOATS == W4_PACK_FLOATS, "pack_wino4_element");
 
 // k (wave-uniform, in a scalar register pair) * y + z
@@ -154,12 +156,12 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   constexpr int NH = 5;                                // halo items (pixel, channel quad) per thread: 1224 / 256
   static_assert(HR * PITCH * PK <= W4_R_FLOATS, "raw halo buffer");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // [sR][sA0][sA1][sX][sS]: the raw halo sits at LDS offset 0, so that two of its byte addresses fit one register
+  // [sR0][sR1][sA0][sA1][sX][sS]: the raw halo sits at LDS offset 0, so that two of its byte addresses fit one register
   float* const sR = smem;
-  float* const sA = smem + W4_R_FLOATS;
+  float* const sA = smem + 2 * W4_R_FLOATS;
   float* const sX = sA + 2 * W4_A_FLOATS;
   float* const sS = sX + W4_X_FLOATS;                  // IN_MODE 1: scale[Cin] | shift[Cin]; bnr: 4 x 64 parameters
-  float* const sBias = sS + 2048;
+  float* const sBias = sS + 2 * W4_MAX_CIN;
   float* const sG = sBias + NB;                        // +-1: sign of gamma (pooled raw output)
 
   const int tid = threadIdx.x;
@@ -244,10 +246,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 #define W4_HALO_PAR(SET)                                                                                    \
   if (IN_MODE != 0) {                                                                                       \
     psc = *reinterpret_cast<const f32x4*>(sS + h_chunk##SET * PK + q2 * 4);                                 \
-    psh = *reinterpret_cast<const f32x4*>(sS + 1024 + h_chunk##SET * PK + q2 * 4);                          \
+    psh = *reinterpret_cast<const f32x4*>(sS + W4_MAX_CIN + h_chunk##SET * PK + q2 * 4);                    \
   }
 #define W4_HALO_BN(K, SET) if (IN_MODE != 0 && !(W4_ABL & 4)) hreg##SET[K] = bn_relu_quad(hreg##SET[K], psc, psh, (h_pad##SET >> (K)) & 1u);
-#define W4_HALO_WR(K, SET) if (!(W4_ABL & 4) && ((K) < NH - 1 || r4)) *reinterpret_cast<f32x4*>(sR + r_lds[K]) = hreg##SET[K];
+#define W4_HALO_WR(K, SET) if (!(W4_ABL & 4) && ((K) < NH - 1 || r4)) *reinterpret_cast<f32x4*>(sR + rw_off + r_lds[K]) = hreg##SET[K];
 
   // ---- transform roles (round 6): V = B^T d B per (tile, channel quad) = (tid >> 1) & 31, tid & 1; the six rows of V are shared by
   // the four waves as TASKS with common subexpressions instead of one row + a duplicated second row per wave (8 row transforms for
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
 // pair task, round 6b: two raw-pixel register sets (X = rxa / rxb) so that the reads of the NEXT column are the first instructions
 // behind an MFMA (they issue in its shadow; behind the column arithmetic they each took an issue slot of their own), with the two
 // byte addresses (pa_n, pb_n) unpacked at the end of the previous slice
-#define W4_TR_ADDR(C) { pa_n = t_ab[C] & 0xffff; pb_n = (int)((unsigned)t_ab[C] >> 16); }
+#define W4_TR_ADDR(C) { pa_n = (t_ab[C] & 0xffff) + tr_off; pb_n = (int)((unsigned)t_ab[C] >> 16) + tr_off; }
 #define W4_TR_RDX(X)                                                                                        \
   {                                                                                                         \
     const char* pa_ = reinterpret_cast<const char*>(smem) + pa_n;                                           \
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   if (IN_MODE != 0) {
     for (int c = tid; c < a.Cin; c += W4_THREADS) {
       sS[c] = p_scale[c];
-      sS[1024 + c] = p_shift[c];
+      sS[W4_MAX_CIN + c] = p_shift[c];
     }
   } else if (a.bnr_mode != 0) {
     // fused BatchNorm-backward sums (ConvArgs::bnr_*): the four per-channel parameters of this block's 64 output channels.
@@ -420,12 +422,11 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
   W4_HALO_WR(0, SET) W4_HALO_WR(1, SET) W4_HALO_WR(2, SET) W4_HALO_WR(3, SET) W4_HALO_WR(4, SET)
   W4_ISSUE_HALO(A)     // stage 0
   W4_ISSUE_HALO(B)     // stage 1
-  W4_HALO_ALL(A)
+  { const int rw_off = 0; W4_HALO_ALL(A) }                 // raw(0) -> sR[0]
   __syncthreads();
-  W4_TRANSFORM_ALL(sA)
+  { const int tr_off = 0; W4_TRANSFORM_ALL(sA) }
   W4_ISSUE_HALO(A)     // stage 2: consumed by stage 0 of the loop (even stages use set A)
-  __syncthreads();
-  W4_HALO_ALL(B)
+  { const int rw_off = W4_R_FLOATS; W4_HALO_ALL(B) }       // raw(1) -> sR[1]
   W4_ISSUE_HALO(B)     // stage 3: consumed by stage 1 of the loop
   __syncthreads();
 #undef W4_HALO_ALL
@@ -527,6 +528,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     const float* const cA = sA + buf * W4_A_FLOATS;                                                                   \
     float* const nA = sA + (buf ^ 1) * W4_A_FLOATS;                                                                   \
     const int nchunk = chunk + 1 == nst ? 0 : chunk + 1;                                                              \
+    const int rw_off = buf * W4_R_FLOATS;            /* halo (g+2) -> sR[g & 1] (floats) */                             \
+    const int tr_off = (buf ^ 1) * W4_R_FLOATS * 4;  /* transform (g+1) <- sR[(g+1) & 1] (bytes) */                      \
     W4_XF_REGS                                                                                                        \
     W4_FETCH_F(1, cA, 1)                                                                                              \
     W4_FENCE();                                                                                                       \
@@ -534,8 +537,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_HALO_PAR(SET)   /* (in front of the barrier: the LDS round trip of the BN parameters was exposed in front of the first BN slice) */ \
     W4_FENCE();                                                                                                       \
     W4_T(0)                                                                                                           \
-    if (!(W4_ABL & 128)) __syncthreads();                                                                             \
-    W4_T(1)                                                                                                           \
+    W4_T(1)   /* (no barrier here since round 6: the raw halo is double-buffered) */                                    \
     W4_FETCH(0, cA, 6, chunk)                                                                                         \
     W4_FENCE();                                                                                                       \
     W4_MM(5, 0, 2) W4_HALO_BN(0, SET) W4_FENCE();                                                                     \
@@ -560,12 +562,14 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_FETCH_F(2, cA, 8)                                                                                              \
     W4_FENCE();                                                                                                       \
     W4_MM8(7, 1)                                                                                                      \
-    if (nchunk != 0) W4_FETCH_F(0, nA, 0)                                                                             \
-    W4_FENCE();                                                                                                       \
-    W4_MM8(8, 2)                                                                                                      \
     W4_T(2)                                                                                                           \
     if (!(W4_ABL & 128)) __syncthreads();                                                                             \
-    W4_T(3)
+    W4_T(3)                                                                                                           \
+    /* the first fragments of the next stage (other waves wrote them during THIS stage: behind the stage's one barrier), */ \
+    /* then pair 8 from operands fetched in front of the barrier: its 8 MFMAs cover the LDS round trip                   */ \
+    if (nchunk != 0) W4_FETCH_F(0, nA, 0)                                                                             \
+    W4_FENCE();                                                                                                       \
+    W4_MM8(8, 2)
 
 #if W4_TRACE
   unsigned long long tc_[5] = {0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter();

@@ -608,7 +608,7 @@ static void w4_geometry(int H, int W, bool& wide, int& tiles_y, int& tiles_x) {
 // 32-pair step gain 0.7 % of the step, the 30x40 ones nothing).
 static bool w4_eligible(const ssp_handle* h, int nprob, int N, int H, int W, int cin, int cout) {
   if (g_conv_algo != 1 && g_conv_algo != 10 && g_conv_algo != 11) return false;
-  if (cin % 8 != 0) return false;
+  if (cin % 8 != 0 || cin > W4_MAX_CIN) return false;   // (the producer's BatchNorm scale | shift of <= W4_MAX_CIN channels sit in LDS)
   if (g_conv_algo == 10) return true;
   bool wide; int ty, tx;
   w4_geometry(H, W, wide, ty, tx);
