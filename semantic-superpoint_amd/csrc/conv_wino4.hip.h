@@ -550,10 +550,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     W4_MM(5, 7, 2) W4_HALO_WR(3, SET) W4_FENCE();                                                                     \
     W4_FETCH(1, cA, 7, chunk)                                                                                         \
     W4_FETCH_W(2, 8, chunk)                                                                                           \
-    W4_FETCH_W(3, 0, nchunk)                                                                                          \
-    W4_FETCH_W(4, 1, nchunk)                                                                                          \
     W4_FENCE();                                                                                                       \
-    W4_MM(6, 0, 0) W4_HALO_BN(4, SET) W4_FENCE();                                                                     \
+    /* (the weight window of the next stage behind the NEXT MFMA: ~26 scalar / memory instructions do not fit one shadow) */ \
+    W4_MM(6, 0, 0) W4_FETCH_W(3, 0, nchunk) W4_FETCH_W(4, 1, nchunk) W4_FENCE(); W4_HALO_BN(4, SET) W4_FENCE();       \
     W4_MM(6, 1, 0) W4_HALO_WR(4, SET) W4_FENCE();                                                                     \
     W4_MM(6, 2, 0)                                                                                                    \
     W4_ISSUE_HALO(SET)                                                                                                \
