@@ -243,6 +243,15 @@ int ssp_op_labels(const float* labels2d_dev, const float* mask2d_dev, float* tar
 int ssp_op_detector_loss(const float* semi_nhwc_dev, int cs, const float* labels2d_dev, const float* mask2d_dev, int b, int h,
                          int w, void* scratch_dev, size_t scratch_bytes, float* loss_dev, float* dsemi_nhwc_dev, void* stream);
 
+/* sem_loss (Train_model_heatmap_all.py:181-193: CrossEntropyLoss(ignore_index = n_classes) of the bilinear upsample,
+ * align_corners=False, models/SuperPointNet_gauss2_ssmall.py:87-91) as an operator, without the [b,n_classes,h,w] logits: convSout NHWC
+ * [b][h/8*w/8][cs] (n_classes logits, channel stride cs >= n_classes), labels int64 [b,h,w] (values outside [0, n_classes) are
+ * ignored) -> loss_dev[0] = mean NLL over the counted pixels and (optional, OVERWRITTEN) d loss / d convSout in the same layout.
+ * algo: 0 = the kernel the training step would take, 1 = pixels-then-classes lanes (any h, w; <= 192 classes), 2 = (x, class) lanes
+ * (<= 144 classes).  scratch: 64 KiB. */
+int ssp_op_sem_loss(const float* sout_nhwc_dev, int cs, const int64_t* labels_dev, int b, int h, int w, int n_classes, int algo,
+                    void* scratch_dev, size_t scratch_bytes, float* loss_dev, float* dsout_nhwc_dev, void* stream);
+
 /* ---- pair construction on the device (dataset side of the reference, datasets/Coco.py:341-392) ----
  * ssp_op_warp_image : inv_warp_image_batch (utils/utils.py:347-385): out[p] = sample(img, inv_h * p), p on the
  *                     linspace(-1,1) grid, zeros padding, align_corners=True; nearest != 0 selects mode="nearest".

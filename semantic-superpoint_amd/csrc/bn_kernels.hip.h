@@ -813,10 +813,13 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
 // (models/SuperPointNet_gauss2.py:64-65, no epsilon).
 __global__ __launch_bounds__(256) void desc_normalize_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ desc,
-                                                             float* __restrict__ inv_norm, int ncells, int cs, int co) {
+                                                             float* __restrict__ inv_norm, float* __restrict__ zero_out, int ncells,
+                                                             int cs, int co) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= ncells) return;
+  // (training step with the sparse descriptor loss: d(desc) [cells][256], the scatter target of the loss kernels, starts at zero)
+  if (zero_out != nullptr) *reinterpret_cast<float4*>(zero_out + (size_t)wave * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 v = *reinterpret_cast<const float4*>(y + (size_t)wave * cs + co + lane * 4);
   const float4 sc = *reinterpret_cast<const float4*>(scale + lane * 4);
   const float4 sh = *reinterpret_cast<const float4*>(shift + lane * 4);

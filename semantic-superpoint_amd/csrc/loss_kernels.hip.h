@@ -70,13 +70,23 @@ struct StepAccum {
   double pos_sum[SSP_MAX_PAIRS * 16];   // per image x 16 replicas: sum_k max(0, 1 - <a,b>)
   double neg_sum[SSP_MAX_PAIRS * 16];   // per image x 16 replicas: sum max(0, <a,b> - 0.2)
   unsigned int nnz[SSP_MAX_PAIRS * 16]; // per image x 16 replicas: number of non-zero non-match hinges
-  unsigned int nnz_img[SSP_MAX_PAIRS];  // per image totals (desc_counts_kernel), read by the backward kernels
+  unsigned int nnz_img[SSP_MAX_PAIRS];  // (unused since the readers sum the 16 replicas themselves: nnz_of_image; kept for the layout)
   double dense_sum[SSP_DENSE_REPS];     // dense descriptor loss: replicas of sum (pos + neg) * valid (the first SSP_DENSE_REPS
                                         // slots of pos_sum / neg_sum hold the rest)
   float coef_det, coef_pos, coef_neg, coef_sem;  // d total / d (loss_det sum), d/d pos mean, d/d neg mean, d/d sem sum
 };
 
 static_assert(sizeof(StepAccum) <= 65536, "the ssp_op_* loss operators carve a StepAccum out of a 64 KiB scratch");
+
+// Number of non-zero non-match hinges of an image: the sum of its 16 replica counters.  The readers (non-match backward, step end)
+// add them up themselves - a one-block kernel between the forward and the backward descriptor kernels did it before and waited
+// ~0.1 ms for a free slot beside the persistent segmentation-loss kernel of the other stream.
+__device__ __forceinline__ unsigned nnz_of_image(const StepAccum* acc, int img) {
+  unsigned nz = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) nz += acc->nnz[img * 16 + r];
+  return nz;
+}
 
 // ---- cell masks: one wave per cell; lane = dy*8+dx --------------------------------------------
 __global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict__ mask2d, float* __restrict__ cellmask,
@@ -250,9 +260,10 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
     }
   const float dot = wave_sum(va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2] + va[3] * vb[3]);
   const float hinge = fmaxf(1.f - dot, 0.f);
-  if (!BWD) {
-    if (lane == 0) acc_add_loss(&acc->pos_sum[img * 16 + ((w >> 2) & 15)], (double)hinge);  // 16 replicas / image
-  } else if (hinge > 0.f) {
+  // (the gradient of the match term does not depend on any sum over the batch - coef_pos is set by step_begin_kernel - so a training
+  // step runs the BWD instantiation alone: loss sum and scatter from one gather of the eight corner rows)
+  if (lane == 0) acc_add_loss(&acc->pos_sum[img * 16 + ((w >> 2) & 15)], (double)hinge);  // 16 replicas / image
+  if (BWD && hinge > 0.f) {
     const float c = -acc->coef_pos / ((float)n_match * (float)B);  // d total / d dot
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
   const int lane = threadIdx.x & 63;
   if (w < 0) return;
   const size_t ibase = (size_t)img * Hc * Wc * 256 + lane;
-  const float wgt = acc->coef_neg / (((float)acc->nnz_img[img] + 1.f) * (float)B);
+  const float wgt = acc->coef_neg / (((float)nnz_of_image(acc, img) + 1.f) * (float)B);
   const int32_t* nm = nonmatch_b + (size_t)w * n_non;
   const float* dk = dots + (size_t)w * n_non;
   const int ma = match_a[w];
@@ -364,15 +375,6 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
   if (have_a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) facc_add(t_a, dd_a + ibase + (size_t)ma * 256 + 64 * i, ga[i]);
-  }
-}
-
-// per-image totals of the non-zero hinge counts (between the forward and backward descriptor kernels)
-__global__ void desc_counts_kernel(StepAccum* acc, int B) {
-  for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    unsigned nz = 0;
-    for (int r = 0; r < 16; ++r) nz += acc->nnz[i * 16 + r];
-    acc->nnz_img[i] = nz;
   }
 }
 
@@ -428,7 +430,7 @@ __global__ void step_end_kernel(const StepAccum* acc, const float* __restrict__ 
         ns += acc->neg_sum[img * 16 + r];
       }
       s_p[img] = (float)ps / (float)n_match;
-      s_q[img] = (float)ns / ((float)acc->nnz_img[img] + 1.f);
+      s_q[img] = (float)ns / ((float)nnz_of_image(acc, img) + 1.f);
     }
   }
   __syncthreads();
@@ -495,6 +497,17 @@ __global__ void fill_affine_identity_kernel(float* p, int c) {  // p[0..c) = 1 (
 __global__ void detector_op_finish_kernel(const StepAccum* acc, float* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   out[0] = (float)acc->det_sum[0] / ((float)acc->mask_cnt[0] + 1e-5f);
+}
+
+// operator form of the segmentation loss (ssp_op_sem_loss)
+__global__ void sem_op_prep_kernel(StepAccum* acc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  acc->sem_sum[0] = acc->sem_cnt[0] = 0.0;
+  acc->coef_sem = 1.f;
+}
+__global__ void sem_op_finish_kernel(const StepAccum* acc, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out[0] = (float)(acc->sem_sum[0] / acc->sem_cnt[0]);
 }
 
 __global__ void sparse_loss_means_kernel(const StepAccum* acc, float* out, int B, int n_match) {

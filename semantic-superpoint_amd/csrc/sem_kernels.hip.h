@@ -25,11 +25,19 @@ __device__ __forceinline__ void up_src(int dst, int in_size, int out_size, int& 
 // Number of non-ignored labels (CrossEntropyLoss(ignore_index=C) averages over them): sem_cnt[view] += count, both views in
 // one launch (blockIdx.y).  Two labels per 16-byte load, four loads in flight per thread: the kernel sits on the critical path
 // in front of sem_ce_kernel and was latency-bound (40 us per view for 20 MB with one 8-byte load per thread and trip).
+// zero0 / zero1 (optional): nzero floats per view set to 0 on the way - d(convSout), the scatter target of the loss kernel (16-byte
+// aligned, nzero % 4 == 0: [cells][channel stride], stride % 4 == 0).
 __global__ __launch_bounds__(256) void sem_count_kernel(const int64_t* __restrict__ labels0, const int64_t* __restrict__ labels1,
-                                                        long n, int C, StepAccum* __restrict__ acc) {
+                                                        long n, int C, StepAccum* __restrict__ acc, float* __restrict__ zero0 = nullptr,
+                                                        float* __restrict__ zero1 = nullptr, long nzero = 0) {
   __shared__ float red[4];
   const int view = blockIdx.y;
   const int64_t* __restrict__ labels = view ? labels1 : labels0;
+  if (float* const z = view ? zero1 : zero0) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < nzero; q += (long)gridDim.x * blockDim.x)
+      *reinterpret_cast<f32x4*>(z + q * 4) = zero4;
+  }
   typedef long long ll2 __attribute__((ext_vector_type(2)));
   float cnt = 0.f;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -273,6 +281,401 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int i = 0; i < 4 * SEM_MAX_C / 256; ++i) *reinterpret_cast<f32x4*>(hist + (i * 64 + lane) * 4) = zero4;
+    }
+  }
+  if (FWD) {
+    const float tot = block_sum_of_waves(wave_sum(nll_acc), red);
+    if (threadIdx.x == 0) acc_add_loss(&acc->sem_sum[view], (double)tot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same loss with lanes = (x, class) - the form the training step runs for H = 8 Hc, W = 8 Wc, C <= 144 (133 here).
+//
+// sem_ce_kernel above pays for the two lane layouts it needs (pixels for the sum over the classes, classes for the sum over
+// the pixels) by interpolating and exponentiating every (pixel, class) TWICE, the second time with 133 classes in 3 x 64 lane
+// slots (69 % of the lanes): 9 + 13 vector instructions per (pixel, class) pair = 27 ns of SIMD issue per element
+// (tools/ubench/valu_rate.hip: v_pk_* 2.1 ns, v_exp_f32 3.45 ns, plain fp32 1.3-1.4 ns per wave instruction at >= 2 waves per SIMD).
+// Here a lane owns the column x = xl + 4 xr (xl = lane & 3, xr = 0, 1) and the classes c = 16 blk + cl (cl = lane >> 2,
+// blk < 9: 133 of 144 slots = 92 %) of the shifted 8x8 tile, all 8 rows y in registers:
+//   * every tile has the SAME interpolation weights ((2 y + 1) / 16, (2 x + 1) / 16 - the tile is shifted by (4,4), so its 64
+//     pixels lie between the same four cells; at the image border the four cells coincide pairwise and any convex weights
+//     give the clamped value), so they are compile-time constants per lane and exact;
+//   * the shift of the log-sum-exp goes into the OPERAND: c''_k[c] = (corner_k[c] - M_k) log2 e with M_k = max_c corner_k[c];
+//     the interpolation of c'' is (l_c - m) log2 e with m = sum_k w_k M_k >= max_c l_c, the same bound as above, for free;
+//   * in a lane, l'(y) = T0 + (2 y + 1) / 16 (T1 - T0) is LINEAR in y (T_a = the column interpolation of corner row a), so the
+//     eight exponentials are two geometric progressions: e(0) = exp2(l'(0)), e(y + 1) = e(y) r and e(7) = exp2(l'(7)),
+//     e(y - 1) = e(y) / r with r = exp2((T1 - T0) / 8) - 4 v_exp_f32 and 6 multiplies for 8 values.  Both ends are anchored
+//     (the larger end is one of them, l' <= 0, and a progression runs three steps): a value that underflows on the way was
+//     below 2^-72 of the largest term anyway, and the exponent of r is clamped to +-126 so that 0 * inf cannot appear;
+//   * the exponentials stay in registers (144 per lane) for the gradient: sum over y in the lane (2 fma per element), over the
+//     two columns with the x weights, over the four x lanes of a quad on the DPP path (9 instructions per 16 classes), one
+//     atomic per lane and block (9 per lane and tile; 12 above);
+//   * sum over the classes: 16 partial sums per lane (its 8 rows x 2 columns), transposed through LDS - lane (xl, cl) receives
+//     the total of pixel j = cl (row j & 7, column xl + 4 (j >> 3)) and plays that pixel for the label logit, the NLL, g / sum
+//     and the -g [c == label] histogram; g / sum goes back through LDS (16 values per lane).
+// ~100 plain + 8 transcendental instructions per 16 classes and lane = 7-8 ns per element instead of 27.
+// Numerics: same bound m, same base-2 domain; three chained multiplies add <= 2 ulp to an exponential.
+#ifndef SEMX_WGS
+#define SEMX_WGS 2  // workgroups per CU = waves per SIMD the register allocation aims at
+#endif
+#ifndef SEMX_ABL
+#define SEMX_ABL 0  // compile-time perf ablation (tools/ubench/sem_ce_bench.hip -DSEMX_ABL=n): 1 no global atomics, 2 no LDS label
+                    // histogram, 4 no gradient sweep, 8 no next-tile requests ahead (the loads sit in front of their use),
+                    // 16 no group reduction in front of the label histogram
+#endif
+constexpr int SEMX_NB = 9;                 // 16-class blocks per lane
+constexpr int SEMX_TP = 16 * 16 + 16;      // floats per x-lane plane of the transposition (+16: every lane of a read on its own bank)
+constexpr int SEMX_HS = SEMX_NB * 16;      // label histogram: floats per corner
+// Every exponential carries the factor 2^K (added to the operand, taken out of log(sum) and, in the gradient, with the x weights).
+// The bound m may sit far above the largest logit of a pixel (neighbouring cells that disagree: up to the logit range), and a
+// progression that starts from an underflowed end loses the terms up to 2^(-4/7 (126 + K)) of 2^0 = the bound: with K = 116
+// the loss of a pixel stays exact to fp32 while its largest term is above 2^-114 of the bound = 79 in natural units (the direct
+// evaluation above, without K: 2^-102, 70).  144 classes x 2^116 < 2^124: the sums cannot overflow.
+constexpr float SEMX_K = 116.f, SEMX_2K = 0x1p116f, SEMX_2MK = 0x1p-116f;
+// "Logit" of the class slots past C: below every real logit, and so large that subtracting a maximum or adding K does not change
+// it - the operand is the SAME in the four corners (ratio 1, no inf - inf) and its exponential is 0.
+constexpr float SEMX_NOCLASS = -1e30f;
+
+// every lane has a source with the controls used here (quad_perm, row_ror).  dpp_f: operand of an addition / maximum (the compiler
+// folds it into v_add_f32_dpp when the old value is 0); dpp_mov: a value of its own (no initialisation of the destination)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+// reduction over the 16 lanes that share lane & 3, result in all of them: rotations by 4 and 8 inside the 16-lane rows, then
+// v_permlane16_swap / v_permlane32_swap of the value with itself (tools/ubench/permlane_probe.hip: [0] = rows a0 b0 a2 b2 /
+// a0 a1 b0 b1, [1] = a1 b1 a3 b3 / a2 a3 b2 b3)
+template <typename Op>
+__device__ __forceinline__ float xlane_allreduce16(float v, Op op) {
+  v = op(v, dpp_f<0x124>(v));  // row_ror:4
+  v = op(v, dpp_f<0x128>(v));  // row_ror:8
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  return v;
+}
+
+// Launch geometry: one workgroup = four waves on four CONSECUTIVE TILE ROWS of one image, walking the same range of tile columns in
+// lockstep (one barrier per step).  A cell's gradient has four contributing tiles; instead of four atomics per (cell, class)
+//   * the two right corners of a tile stay in registers and join the left corners of the next tile of the walk (a quad shift), and
+//   * the bottom-left total of a wave goes to the wave below through LDS and joins its top-left total,
+// so that a step of four tiles issues five cell vectors of atomics instead of sixteen (the L2 retires roughly one fp32 atomic per
+// channel and clock: 576 per tile were 105 of the kernel's 238 us).  Everything that leaves the workgroup is still an atomic add -
+// seams between workgroups, image borders (where corner cells coincide) and complete cells alike need no case distinction.
+struct SemXcGeom {
+  int row_groups;   // ceil((Hc + 1) / 4)
+  int x_splits;     // column ranges per tile row
+  int x_per_split;  // ceil((Wc + 1) / x_splits)
+};
+__host__ __device__ inline SemXcGeom sem_xc_geom(int B, int Hc, int Wc, int target_workgroups) {
+  SemXcGeom g;
+  g.row_groups = (Hc + 1 + 3) / 4;
+  const int per = B * g.row_groups;
+  int xs = (target_workgroups + per - 1) / per;
+  xs = xs < 1 ? 1 : (xs > Wc + 1 ? Wc + 1 : xs);
+  g.x_per_split = (Wc + 1 + xs - 1) / xs;
+  g.x_splits = (Wc + 1 + g.x_per_split - 1) / g.x_per_split;
+  return g;
+}
+
+// NB: 16-class blocks per lane (3, 6 or 9: the smallest that holds C; class slots past C run along as zeros - no branch per block)
+template <int MODE, int NB>
+__global__ __launch_bounds__(256, SEMX_WGS) void sem_ce_xc_kernel(const float* __restrict__ sout, const int64_t* __restrict__ labels,
+                                                           float* __restrict__ dsout, StepAccum* __restrict__ acc, int view,
+                                                           int B, int Hc, int Wc, int C, int cs, SemXcGeom geom) {
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  constexpr bool FWD = (MODE & 1) != 0, BWD = (MODE & 2) != 0;
+  __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float s_tr[4][4 * SEMX_TP];
+  __shared__ __attribute__((aligned(16))) float s_gi[4][64];
+  __shared__ __attribute__((aligned(16))) float s_hist[4][4 * SEMX_HS];
+  __shared__ float s_carry[4][2 * SEMX_HS];  // right corners of the previous tile of each wave: [top, bottom][class]
+  __shared__ float s_down[4][2][SEMX_HS];  // bottom-left totals on their way to the wave below, double-buffered over the steps
+  const int wave_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* const tr = s_tr[wave_in_blk];
+  float* const gis = s_gi[wave_in_blk];
+  float* const hist = s_hist[wave_in_blk];
+  const int H = 8 * Hc, W = 8 * Wc;
+  const int TX = Wc + 1, TY = Hc + 1;
+  const int xl = lane & 3, cl = lane >> 2;
+  // this workgroup: image n, tile rows 4 rg .. 4 rg + 3 (one per wave), tile columns x_begin .. x_end
+  const int xs = blockIdx.x % geom.x_splits, rg = (blockIdx.x / geom.x_splits) % geom.row_groups;
+  const int n = blockIdx.x / (geom.x_splits * geom.row_groups);
+  const int tyi = rg * 4 + wave_in_blk;  // tile row index 0 .. TY - 1 (a wave past the last row only keeps the barriers company)
+  const bool row_ok = tyi < TY;
+  const int ty = tyi - 1;
+  const int x_begin = xs * geom.x_per_split, x_end = min(TX, x_begin + geom.x_per_split);
+  const int cy0 = max(ty, 0), cy1 = min(ty + 1, Hc - 1);
+  const size_t cell0 = (size_t)n * Hc * Wc;
+  // Rows live in PAIRS (i, 7 - i), i < 4: the two geometric progressions of a column advance together in one packed multiply.
+  // Slot j = 8 xr + 2 i + h of a lane is the pixel (row h ? 7 - i : i, column xl + 4 xr).
+  // interpolation weights of this lane's two columns (class role) and of its pixel (pixel role: slot pj = cl)
+  const float wx1[2] = {(float)(2 * xl + 1) * 0.0625f, (float)(2 * xl + 9) * 0.0625f};
+  const float wx0[2] = {1.f - wx1[0], 1.f - wx1[1]};
+  const int pj = cl, pi = (pj >> 1) & 3, py = (pj & 1) ? 7 - pi : pi, px = xl + 4 * (pj >> 3);
+  const float pwy1 = (float)(2 * py + 1) * 0.0625f, pwx1 = (float)(2 * px + 1) * 0.0625f;
+  const float pw[4] = {(1.f - pwy1) * (1.f - pwx1), (1.f - pwy1) * pwx1, pwy1 * (1.f - pwx1), pwy1 * pwx1};
+  const int y = 8 * ty + 4 + py;  // this lane's pixel row (pixel role)
+  const bool y_ok = row_ok && y >= 0 && y < H;
+  float nll_acc = 0.f;
+  const float g = BWD ? acc->coef_sem / (float)acc->sem_cnt[view] : 0.f;
+  const float gK = g * SEMX_2K;  // the sums carry 2^K
+  const float wxs0[2] = {wx0[0] * SEMX_2MK, wx0[1] * SEMX_2MK}, wxs1[2] = {wx1[0] * SEMX_2MK, wx1[1] * SEMX_2MK};  // 2^-K: exact
+  const DetTarget t_ds = det_resolve(dsout);   // (deterministic mode: fixed-point shadow of d(convSout))
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < 4 * SEMX_HS / 256 + 1; ++i)
+      if ((i * 64 + lane) * 4 < 4 * SEMX_HS) *reinterpret_cast<f32x4*>(hist + (i * 64 + lane) * 4) = zero4;
+  }
+  // One tile ahead: the label of this lane's pixel and the logits of its corner (k = xl, classes 16 blk + cl) are requested
+  // between the two sweeps of the tile in front of them - two waves per SIMD do not hide a trip to memory by themselves.
+  int64_t lab_n = C;
+  float cc_n[NB];
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) cc_n[blk] = SEMX_NOCLASS;
+  auto request = [&](int txi) {
+    const int tx = txi - 1;
+    const int cx0 = max(tx, 0), cx1 = min(tx + 1, Wc - 1);
+    const int x = 8 * tx + 4 + px;
+    lab_n = C;
+    if (y_ok && x >= 0 && x < W) lab_n = labels[((size_t)n * H + y) * W + x];
+    const int ck = ((xl & 2) ? cy1 : cy0) * Wc + ((xl & 1) ? cx1 : cx0);
+    const float* const cpk = sout + (cell0 + ck) * cs;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      cc_n[blk] = SEMX_NOCLASS;
+      if (blk * 16 + cl < C) cc_n[blk] = cpk[blk * 16 + cl];
+    }
+  };
+  if (row_ok && x_begin < x_end) request(x_begin);
+  // the previous tile's right corners (lanes xl = 1, 3) are this tile's left corners: they wait in LDS (registers are short)
+  float* const carry = s_carry[wave_in_blk] + (xl >> 1) * SEMX_HS + cl;
+  if (BWD && (xl & 1)) {
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) carry[blk * 16] = 0.f;
+  }
+  // x_end - x_begin tiles, then one more step that only hands on the right corners of the last tile
+  for (int txi = x_begin; txi <= x_end; ++txi) {
+    const int tx = txi - 1;
+    const int cx0 = max(tx, 0), cx1 = min(tx + 1, Wc - 1);
+    const int cidx[4] = {cy0 * Wc + cx0, cy0 * Wc + cx1, cy1 * Wc + cx0, cy1 * Wc + cx1};
+    // ---- pixel role: label of slot pj (a pixel outside the image holds C) ----
+    const int label_l = (txi < x_end && (uint64_t)lab_n < (uint64_t)C) ? (int)lab_n : C;  // (the test of sem_count_kernel, on 64 bits)
+    const bool counted = label_l < C;
+    const bool work = __ballot(counted) != 0ull;  // wave-uniform: ignored / outside pixels contribute nothing
+    float dres[NB];  // corner k = xl, classes 16 blk + cl: d(convSout) of this tile
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) dres[blk] = 0.f;
+    if (work) {
+      float cc[NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) cc[blk] = cc_n[blk];
+      // the label logits of the four corners (pixel role), consumed after the forward sweep
+      float lc[4] = {0.f, 0.f, 0.f, 0.f};
+      if (FWD && counted) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lc[k] = sout[(cell0 + cidx[k]) * cs + label_l];
+      }
+      // ---- class role: maximum over the classes of corner k = xl ----
+      float mx = -INFINITY;
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+        mx = fmaxf(mx, cc[blk]);
+      const float Mk = xlane_allreduce16(mx, [](float a, float b) { return fmaxf(a, b); });
+      // ---- forward: exponentials of the tile in registers, partial sums over this lane's classes ----
+      f32x2 E[NB][2][2];  // rows (0, 7) and the ratios (r, 1 / r) of each column: the gradient sweep runs the progressions again
+      f32x2 SE[2][4];
+#pragma unroll
+      for (int xr = 0; xr < 2; ++xr)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) SE[xr][i] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        {
+          const float c2 = fmaf(cc[blk] - Mk, LOG2E, SEMX_K);  // (class slots past C: SEMX_NOCLASS)
+          const float c00 = dpp_mov<0x00>(c2), c01 = dpp_mov<0x55>(c2), c10 = dpp_mov<0xAA>(c2), c11 = dpp_mov<0xFF>(c2);
+          const float d0 = c01 - c00, d1 = c11 - c10;
+#pragma unroll
+          for (int xr = 0; xr < 2; ++xr) {
+            const float T0 = fmaf(wx1[xr], d0, c00), T1 = fmaf(wx1[xr], d1, c10);
+            const float D = T1 - T0;
+            const float s = __builtin_amdgcn_fmed3f(D * 0.125f, -126.f, 126.f);
+            const f32x2 R = {__builtin_amdgcn_exp2f(s), __builtin_amdgcn_exp2f(-s)};
+            const f32x2 P0 = {__builtin_amdgcn_exp2f(fmaf(D, 0.0625f, T0)), __builtin_amdgcn_exp2f(fmaf(D, 0.9375f, T0))};  // rows 0, 7
+            const f32x2 P1 = P0 * R, P2 = P1 * R, P3 = P2 * R;                                                              // 1, 6 ...
+            E[blk][xr][0] = P0; E[blk][xr][1] = R;
+            SE[xr][0] += P0; SE[xr][1] += P1; SE[xr][2] += P2; SE[xr][3] += P3;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one class block at a time: interleaved blocks cost registers
+      }
+      if (!(SEMX_ABL & 8) && txi + 1 < x_end) request(txi + 1);
+      // ---- sum over the classes: transpose the 16 partial sums of each lane through LDS; lane (xl, cl) gets slot pj = cl ----
+#pragma unroll
+      for (int xr = 0; xr < 2; ++xr)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          *reinterpret_cast<f32x4*>(tr + xl * SEMX_TP + cl * 16 + xr * 8 + h * 4) =
+              f32x4{SE[xr][2 * h][0], SE[xr][2 * h][1], SE[xr][2 * h + 1][0], SE[xr][2 * h + 1][1]};
+      __builtin_amdgcn_wave_barrier();  // LDS executes one wave's instructions in order; this only pins the compiler
+      float sp = 0.f;
+#pragma unroll
+      for (int src = 0; src < 16; ++src) sp += tr[xl * SEMX_TP + src * 16 + cl];
+      __builtin_amdgcn_wave_barrier();
+      // ---- pixel role: NLL, g / sum, label histogram ----
+      // (cross-lane reads stay outside divergent code: a DPP source lane that is switched off delivers 0)
+      const float Ms[4] = {dpp_mov<0x00>(Mk), dpp_mov<0x55>(Mk), dpp_mov<0xAA>(Mk), dpp_mov<0xFF>(Mk)};
+      if (FWD && counted) {  // the label logit relative to the shift: sum_k w_k (corner_k[label] - M_k)
+        float ll = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ll = fmaf(pw[k], lc[k] - Ms[k], ll);
+        nll_acc += (logf(sp) - SEMX_K * LN2) - ll;
+      }
+      if (BWD) {
+        gis[xl * 16 + pj] = counted ? gK / sp : 0.f;  // g / sum; uncounted pixels: e is finite, d = 0
+        // -g [c == label] w_k, summed per (corner, label) in the LDS histogram.  A segmentation map has one or two labels in most
+        // 8x8 tiles, and 64 LDS atomics on one address are slow (~40 us of the launch): while the first pixel still to be done
+        // shares its label with >= 8 pixels, the group is reduced on the DPP path instead (sums of w_y, w_x, w_y w_x over the
+        // group give the four corner weights) and lands in the histogram as one 4-lane atomic.  The rest takes the atomics.
+        unsigned long long todo = __ballot(counted);
+        if (!(SEMX_ABL & 16)) {
+          while (todo != 0ull) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int lab = __builtin_amdgcn_readlane(label_l, lead);
+            const bool mine = counted && label_l == lab;
+            const unsigned long long grp = __ballot(mine) & todo;
+            if (__popcll(grp) < 8) break;
+            todo &= ~grp;
+            const float sy = wave_sum(mine ? pwy1 : 0.f), sx = wave_sum(mine ? pwx1 : 0.f), sxy = wave_sum(mine ? pwy1 * pwx1 : 0.f);
+            const float cnt = (float)__popcll(grp);
+            // corner k = 2 a + b: sum of wy_a wx_b, wy_0 = 1 - wy_1, wx_0 = 1 - wx_1
+            const float sk = lane == 0 ? (cnt - sy) - (sx - sxy) : lane == 1 ? sx - sxy : lane == 2 ? sy - sxy : sxy;
+            if (lane < 4 && !(SEMX_ABL & 2)) atomicAdd(hist + lane * SEMX_HS + lab, -g * sk);
+          }
+        }
+        if (counted && ((todo >> lane) & 1ull)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (!(SEMX_ABL & 2)) atomicAdd(hist + k * SEMX_HS + label_l, -g * pw[k]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // Q_a[xr][i] = wy_a(rows i, 7 - i) g / sum of this lane's columns;  wy_1(i) = (2 i + 1) / 16 = wy_0(7 - i)
+        f32x2 Q0[2][4], Q1[2][4];
+#pragma unroll
+        for (int xr = 0; xr < 2; ++xr)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gis + xl * 16 + xr * 8 + h * 4);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int i = 2 * h + u;
+              const float wa = (float)(2 * i + 1) * 0.0625f;   // wy_1(i) = wy_0(7 - i)
+              const f32x2 gp = {v[2 * u], v[2 * u + 1]};
+              Q1[xr][i] = gp * f32x2{wa, 1.f - wa};
+              Q0[xr][i] = gp * f32x2{1.f - wa, wa};
+            }
+          }
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          if (!(SEMX_ABL & 4)) {
+            float V[2][2];  // [corner row a][column xr]
+#pragma unroll
+            for (int xr = 0; xr < 2; ++xr) {
+              f32x2 P = E[blk][xr][0];
+              const f32x2 R = E[blk][xr][1];
+              f32x2 S0 = Q0[xr][0] * P, S1 = Q1[xr][0] * P;
+#pragma unroll
+              for (int i = 1; i < 4; ++i) {
+                P = P * R;
+                S0 = __builtin_elementwise_fma(Q0[xr][i], P, S0);
+                S1 = __builtin_elementwise_fma(Q1[xr][i], P, S1);
+              }
+              V[0][xr] = S0[0] + S0[1];
+              V[1][xr] = S1[0] + S1[1];
+            }
+            // the two columns with the x weights, then the four x lanes of the quad; lane xl keeps corner xl = 2 a + b
+            float R[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              float w0 = fmaf(wxs0[1], V[a][1], wxs0[0] * V[a][0]), w1 = fmaf(wxs1[1], V[a][1], wxs1[0] * V[a][0]);
+              w0 += dpp_f<0xB1>(w0);  // quad_perm [1,0,3,2]
+              w1 += dpp_f<0xB1>(w1);
+              R[a] = (xl & 1) ? w1 : w0;
+            }
+            R[0] += dpp_f<0x4E>(R[0]);  // quad_perm [2,3,0,1]
+            R[1] += dpp_f<0x4E>(R[1]);
+            dres[blk] = (xl & 2) ? R[1] : R[0];
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one class block at a time: interleaved blocks cost registers (spills at 256)
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+          dres[blk] += hist[xl * SEMX_HS + blk * 16 + cl];  // (class slots past C: untouched zeros)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4 * SEMX_HS / 256 + 1; ++i)
+          if ((i * 64 + lane) * 4 < 4 * SEMX_HS) *reinterpret_cast<f32x4*>(hist + (i * 64 + lane) * 4) = zero4;
+      }
+    } else if (!(SEMX_ABL & 8) && row_ok && txi + 1 < x_end) {
+      request(txi + 1);
+    }
+    if ((SEMX_ABL & 8) && row_ok && txi + 1 < x_end) request(txi + 1);
+    if (BWD) {
+      // ---- left corners = this tile's (xl = 0, 2) + the previous tile's right corners (xl = 1, 3): complete along x ----
+      float tl[NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) tl[blk] = dres[blk];
+      __builtin_amdgcn_wave_barrier();
+      if (!(xl & 1)) {  // (reads first: LDS executes the wave's instructions in order)
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) tl[blk] += carry[blk * 16];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (xl & 1) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) carry[blk * 16] = dres[blk];
+      }
+      __builtin_amdgcn_wave_barrier();
+      // bottom-left (xl = 2): to the wave below, or out (last wave of the workgroup)
+      const int par = (txi - x_begin) & 1;
+      float* const dn = s_down[wave_in_blk][par];
+      // cell of this lane's left corner (the step behind the last tile column: the right corners of that column)
+      const int ckl = ((xl & 2) ? cy1 : cy0) * Wc + min(cx0, Wc - 1);
+      float* const dk = dsout + (cell0 + ckl) * cs + cl;
+      if (xl == 2) {
+        if (wave_in_blk < 3 && tyi + 1 < TY) {  // (the wave below works on a tile row)
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk)
+            dn[blk * 16 + cl] = tl[blk];
+        } else if (row_ok && !(SEMX_ABL & 1)) {  // last wave of the workgroup / last tile row of the image
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk)
+            if (blk * 16 + cl < C && tl[blk] != 0.f) facc_add(t_ds, dk + blk * 16, tl[blk]);
+        }
+      }
+      __syncthreads();
+      // top-left (xl = 0) + the bottom-left of the wave above: out
+      if (xl == 0 && row_ok) {
+        const float* const up = s_down[(wave_in_blk + 3) & 3][par];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+          if (blk * 16 + cl < C) {
+            const float v = tl[blk] + (wave_in_blk > 0 ? up[blk * 16 + cl] : 0.f);
+            if (v != 0.f && !(SEMX_ABL & 1)) facc_add(t_ds, dk + blk * 16, v);
+          }
+      }
     }
   }
   if (FWD) {

@@ -208,8 +208,10 @@ struct ssp_handle {
   // the detector / segmentation-loss kernels (vector-ALU-bound) of the caller's stream; fork / join by events (captured as a
   // fork-join into the hipGraph form).  Created at the first pair step, per device of the handle.
   hipStream_t aux_stream = nullptr;
+  hipStream_t aux2_stream = nullptr;   // label-only kernels of the loss phase, beside the first-layer convolution and the weight packing
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_pack_fork = nullptr, ev_pack_join = nullptr;  // the weight images are packed beside the first-layer conv
+  hipEvent_t ev_early_fork = nullptr, ev_early_join = nullptr;  // label-only work of the loss phase beside the forward pass
   // profiling
   int prof_family;
   bool prof_paused = false;  // ssp_profile_pause: launches are not bracketed while set (bench.py samples every n-th step)
@@ -1415,7 +1417,10 @@ void ssp_destroy(ssp_handle* h) {
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_pack_fork) (void)hipEventDestroy(h->ev_pack_fork);
   if (h->ev_pack_join) (void)hipEventDestroy(h->ev_pack_join);
+  if (h->ev_early_fork) (void)hipEventDestroy(h->ev_early_fork);
+  if (h->ev_early_join) (void)hipEventDestroy(h->ev_early_join);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  if (h->aux2_stream) (void)hipStreamDestroy(h->aux2_stream);
   delete h;
 }
 
@@ -1667,10 +1672,13 @@ static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W
 static int ensure_aux_stream(ssp_handle* h) {
   if (h->aux_stream != nullptr) return 0;
   HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->aux2_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_pack_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_pack_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_early_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_early_join, hipEventDisableTiming));
   return 0;
 }
 
@@ -1808,7 +1816,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
 }
 
 static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs, int N, int H, int W, int train,
-                       bool for_backward, hipStream_t st, bool detector_only = false) {
+                       bool for_backward, hipStream_t st, bool detector_only = false, bool zero_ddesc = false) {
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     S.N = N; S.H = H; S.W = W; S.x = xs[k];
@@ -1891,7 +1899,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   for (int k = 0; k < SS.n; ++k) {
     Slot& S = *SS.s[k];
     hipLaunchKernelGGL(desc_normalize_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_DB], S.bn[L_DB].scale,
-                       S.bn[L_DB].shift, S.desc, S.inv_norm, ncells, S.y_cs[L_DB], S.y_co[L_DB]);
+                       S.bn[L_DB].shift, S.desc, S.inv_norm, zero_ddesc ? S.ddesc : (float*)nullptr, ncells, S.y_cs[L_DB], S.y_co[L_DB]);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -2574,6 +2582,37 @@ int ssp_adam_step(ssp_handle* h, float lr, int step, void* stream) {
 
 // phase 0: the whole step; 1: everything up to the point where the early gradient bucket is final; 2: the rest of the
 // backward pass (encoder layers below EARLY_SPLIT_LAYER)
+// Segmentation loss of one view.  algo 0: the step's choice - the (x, class) lane form (sem_ce_xc_kernel) when the label map is exactly
+// 8x the logit map and the classes fit its 9 x 16 slots, the pixels-then-classes form (sem_ce_kernel) otherwise; SSP_SEM_XC=0 keeps
+// the latter everywhere (same-box A/B).  1 / 2 force a form (2 fails on shapes it does not cover).
+static int sem_xc_env() {
+  static const int v = [] { const char* e = getenv("SSP_SEM_XC"); return e ? atoi(e) : 1; }();
+  return v;
+}
+static int launch_sem_ce(int algo, bool train, const float* sout, const int64_t* labels, float* dsout, StepAccum* acc, int view, int B,
+                         int Hc, int Wc, int H, int W, int C, int cs, hipStream_t st) {
+  const bool xc_ok = H == 8 * Hc && W == 8 * Wc && C <= 16 * SEMX_NB;
+  if (algo == 2 && !xc_ok) return fail(-1, "sem_ce: the (x, class) form needs H = 8 Hc, W = 8 Wc and <= %d classes", 16 * SEMX_NB);
+  if (C > SEM_MAX_C) return fail(-1, "sem_ce: at most %d classes", SEM_MAX_C);
+  const bool xc = algo == 2 || (algo == 0 && xc_ok && sem_xc_env() != 0);
+  const long ntile = (long)B * (Hc + 1) * (Wc + 1);
+  if (xc) {
+    static const int wgs_per_cu = [] { const char* e = getenv("SSP_SEM_XC_WGS"); return e ? atoi(e) : 2; }();
+    const SemXcGeom geom = sem_xc_geom(B, Hc, Wc, wgs_per_cu * device_cu_count());   // two 4-wave workgroups per CU, all resident
+    const int grid = B * geom.row_groups * geom.x_splits;
+#define SSP_SEM_XC(MODE, NB) \
+  hipLaunchKernelGGL((sem_ce_xc_kernel<MODE, NB>), dim3(grid), dim3(256), 0, st, sout, labels, dsout, acc, view, B, Hc, Wc, C, cs, geom)
+    if (train) { if (C <= 48) SSP_SEM_XC(3, 3); else if (C <= 96) SSP_SEM_XC(3, 6); else SSP_SEM_XC(3, 9); }
+    else { if (C <= 48) SSP_SEM_XC(1, 3); else if (C <= 96) SSP_SEM_XC(1, 6); else SSP_SEM_XC(1, 9); }
+#undef SSP_SEM_XC
+  } else {
+    const int grid = (int)std::min<long>((ntile + 3) / 4, 4096);
+    if (train) hipLaunchKernelGGL((sem_ce_kernel<3>), dim3(grid), dim3(256), 0, st, sout, labels, dsout, acc, view, B, Hc, Wc, H, W, C, cs);
+    else hipLaunchKernelGGL((sem_ce_kernel<1>), dim3(grid), dim3(256), 0, st, sout, labels, dsout, acc, view, B, Hc, Wc, H, W, C, cs);
+  }
+  return 0;
+}
+
 static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scalars_dev, int phase, hipStream_t st_in) {
   void* stream = st_in;
   if (!h || !h->bound) return fail(-1, "handle not bound");
@@ -2611,16 +2650,42 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, st, h->accum, eta, in->multi_task, in->lambda_loss,
                      in->lamda_d, (int)semantic, B);
   SlotSet SS{nv, {&h->slot[0], nv == 2 ? &h->slot[1] : nullptr}};
+  // The part of the loss phase that needs the LABELS only - cell masks, the count of the segmentation labels - runs on a third
+  // stream beside the first-layer convolution and the weight packing (both leave the chip room; a launch beside the later,
+  // CU-filling convolutions would delay their workgroups), and the scatter targets are zeroed by kernels that run anyway:
+  // d(convSout) by the label count, d(desc) by the descriptor normalisation at the end of the forward pass.  ~0.15 ms of small
+  // memory-bound launches off the serial part of the step.  SSP_EARLY_LABELS=0: in place, in front of the loss kernels.
+  static const int early_env = getenv("SSP_EARLY_LABELS") ? atoi(getenv("SSP_EARLY_LABELS")) : 1;
+  const bool early = early_env != 0;
+  const float* masks[2] = {in->valid_mask_dev, in->warped_valid_mask_dev};
+  const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
+  const bool zero_dsout = semantic && in->train;
+  auto label_kernels = [&](hipStream_t se) -> int {
+    for (int v = 0; v < nv; ++v) {
+      Slot& S = h->slot[v];
+      hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, se, masks[v], S.cellmask,
+                         &h->accum->mask_cnt[v], B, H, W);
+    }
+    if (semantic)
+      hipLaunchKernelGGL(sem_count_kernel, dim3(512, nv), dim3(256), 0, se, sems[0], sems[1], (long)B * H * W, h->cfg.n_classes, h->accum,
+                         zero_dsout ? h->slot[0].dsout : (float*)nullptr, zero_dsout && nv == 2 ? h->slot[1].dsout : (float*)nullptr,
+                         (long)ncells * h->sout_cs);
+    HIPCHK(hipGetLastError());
+    return 0;
+  };
+  if (early) {
+    CHK(ensure_aux_stream(h));
+    HIPCHK(hipEventRecord(h->ev_early_fork, st));   // (behind step_begin_kernel: the accumulators are zero, the last step is done)
+    HIPCHK(hipStreamWaitEvent(h->aux2_stream, h->ev_early_fork, 0));
+    CHK(label_kernels(h->aux2_stream));
+    HIPCHK(hipEventRecord(h->ev_early_join, h->aux2_stream));
+  }
   {
     const float* xs[2] = {in->image_dev, in->warped_image_dev};
-    CHK(run_forward(h, SS, xs, B, H, W, 1, in->train != 0, st));
+    CHK(run_forward(h, SS, xs, B, H, W, 1, in->train != 0, st, false, early && in->train && use_desc && !dense));
   }
-  const float* masks[2] = {in->valid_mask_dev, in->warped_valid_mask_dev};
-  for (int v = 0; v < nv; ++v) {
-    Slot& S = h->slot[v];
-    hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, st, masks[v], S.cellmask,
-                       &h->accum->mask_cnt[v], B, H, W);
-  }
+  if (early) HIPCHK(hipStreamWaitEvent(st, h->ev_early_join, 0));
+  else CHK(label_kernels(st));
   // ---- descriptor loss on the side stream (fork) ----
   static const int loss_stream_env = getenv("SSP_LOSS_STREAM") ? atoi(getenv("SSP_LOSS_STREAM")) : 1;  // (perf-debug: 0 = one stream)
   hipStream_t sd = st;
@@ -2652,15 +2717,17 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     HIPCHK(hipGetLastError());
   } else if (use_desc) {
     Slot &A = h->slot[0], &Bs = h->slot[1];
-    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
-                       in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
+    if (!in->train)   // (training: desc_match_kernel<true> below accumulates the loss sum as well)
+      hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
+                         in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
     hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
                        in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match,
                        h->cfg.n_non);
-    hipLaunchKernelGGL(desc_counts_kernel, dim3(1), dim3(64), 0, sd, h->accum, B);
     if (in->train) {
-      CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
-      CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
+      if (!early) {
+        CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
+        CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
+      }
       hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
                          in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
       hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
@@ -2675,7 +2742,6 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     HIPCHK(hipGetLastError());
   }
   const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
-  const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
   for (int v = 0; v < nv; ++v) {
     Slot& S = h->slot[v];
     hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
@@ -2683,20 +2749,13 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   }
   HIPCHK(hipGetLastError());
   if (semantic) {
-    const long npx = (long)B * H * W;
-    const long ntile = (long)B * (Hc + 1) * (Wc + 1);
-    const int grid = (int)std::min<long>((ntile + 3) / 4, 4096);
-    hipLaunchKernelGGL(sem_count_kernel, dim3(512, nv), dim3(256), 0, st, sems[0], sems[1], npx, h->cfg.n_classes, h->accum);
     for (int v = 0; v < nv; ++v) {
       Slot& S = h->slot[v];
       if (in->train) {  // loss sum and d(convSout) in one pass (coef_sem: step_begin_kernel, sem_cnt: sem_count_kernel)
-        CHK(dev_zero(S.dsout, (size_t)ncells * h->sout_cs * sizeof(float), st));
-        hipLaunchKernelGGL((sem_ce_kernel<3>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], S.dsout,
-                           h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
+        CHK(launch_sem_ce(0, true, S.Y[L_SOUT], sems[v], S.dsout, h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs, st));
         CHK(det_fold(S.dsout, st));
       } else {
-        hipLaunchKernelGGL((sem_ce_kernel<1>), dim3(grid), dim3(256), 0, st, S.Y[L_SOUT], sems[v], (float*)nullptr,
-                           h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs);
+        CHK(launch_sem_ce(0, false, S.Y[L_SOUT], sems[v], nullptr, h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs, st));
       }
     }
     HIPCHK(hipGetLastError());
@@ -3362,6 +3421,23 @@ int ssp_op_detector_loss(const float* semi_nhwc_dev, int cs, const float* labels
   hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024)), dim3(256), 0, st, semi_nhwc_dev, ones,
                      ones + 65, labels2d_dev, cellmask, dsemi_nhwc_dev, acc, 0, b, hh, w, cs);
   hipLaunchKernelGGL(detector_op_finish_kernel, dim3(1), dim3(64), 0, st, acc, loss_dev);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp_op_sem_loss(const float* sout_nhwc_dev, int cs, const int64_t* labels_dev, int b, int hh, int w, int n_classes, int algo,
+                    void* scratch_dev, size_t scratch_bytes, float* loss_dev, float* dsout_nhwc_dev, void* stream) {
+  if (hh % 8 || w % 8 || cs < n_classes || n_classes < 1) return fail(-1, "sem_loss: H, W multiples of 8 and channel stride >= n_classes required");
+  if (algo < 0 || algo > 2) return fail(-1, "sem_loss: algo 0 (the step's choice), 1 or 2");
+  if (scratch_bytes < sizeof(StepAccum)) return fail(-4, "ssp_op_sem_loss scratch too small (%zu < %zu)", scratch_bytes, sizeof(StepAccum));
+  hipStream_t st = (hipStream_t)stream;
+  StepAccum* acc = reinterpret_cast<StepAccum*>(scratch_dev);
+  const int hc = hh / 8, wc = w / 8;
+  hipLaunchKernelGGL(sem_op_prep_kernel, dim3(1), dim3(64), 0, st, acc);
+  hipLaunchKernelGGL(sem_count_kernel, dim3(512, 1), dim3(256), 0, st, labels_dev, labels_dev, (long)b * hh * w, n_classes, acc);
+  if (dsout_nhwc_dev != nullptr) CHK(dev_zero(dsout_nhwc_dev, (size_t)b * hc * wc * cs * sizeof(float), st));
+  CHK(launch_sem_ce(algo, dsout_nhwc_dev != nullptr, sout_nhwc_dev, labels_dev, dsout_nhwc_dev, acc, 0, b, hc, wc, hh, w, n_classes, cs, st));
+  hipLaunchKernelGGL(sem_op_finish_kernel, dim3(1), dim3(64), 0, st, acc, loss_dev);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -72,7 +72,7 @@ EXPORTS = ["ssp_last_error", "ssp_create", "ssp_destroy", "ssp_param_count", "ss
            "ssp_pair_step_phase", "ssp_grad_early_offset", "ssp_pair_step_graph", "ssp_handle_set_conv_algo",
            "ssp_op_detector_loss", "ssp_debug_occupancy", "ssp_sample_indices_cell", "ssp_op_warp_labels_px",
            "ssp_op_warp_labels_full_px", "ssp_profile_read_kernel", "ssp_op_label_quantize", "ssp_profile_pause", "ssp_op_conv_bf16", "ssp_op_conv_wgrad_bf16", "ssp_op_bn_bwd_bf16", "ssp_build_id",
-           "ssp_set_deterministic", "ssp_get_deterministic", "ssp_clock_probe"]
+           "ssp_set_deterministic", "ssp_get_deterministic", "ssp_clock_probe", "ssp_op_sem_loss"]
 
 
 def load_library(path=None):
@@ -125,6 +125,11 @@ def load_library(path=None):
     lib.ssp_grad_early_offset.restype = C.c_size_t
     lib.ssp_handle_set_conv_algo.argtypes = [vp, i]
     lib.ssp_op_detector_loss.argtypes = [vp, i, vp, vp, i, i, i, vp, C.c_size_t, vp, vp, vp]
+    try:  # (newer than an A/B library of an older revision, SSP_HIP_LIB)
+        lib.ssp_op_sem_loss.argtypes = [vp, i, vp, i, i, i, i, i, vp, C.c_size_t, vp, vp, vp]
+    except AttributeError:
+        if os.environ.get("SSP_HIP_LIB") is None:
+            raise
     lib.ssp_sample_indices.argtypes = [vp, vp, i, C.c_uint64, vp, vp, vp, vp]
     lib.ssp_sample_indices_cell.argtypes = [vp, vp, i, C.c_uint64, vp, vp, vp, vp]
     lib.ssp_op_warp_labels_px.argtypes = [vp, vp, vp, i, i, i, vp]
@@ -777,6 +782,27 @@ def op_labels(labels2d=None, mask2d=None):
     with torch.cuda.device(ref.device):
         _check(lib.ssp_op_labels(_ptr(labels2d), _ptr(mask2d), _ptr(tgt), _ptr(cm), B, H, W, _stream()))
     return tgt, cm
+
+
+def op_sem_loss(sout_nchw, labels, grad=True, algo=0, cs=None):
+    """sem_loss of public NCHW logits [B,C,Hc,Wc] at 1/8 resolution against int64 labels [B,8Hc,8Wc] (C = ignore index): the fused
+    bilinear upsample + cross entropy of the training step; returns (loss, d loss / d logits NCHW or None).  algo: see ssp_op_sem_loss."""
+    lib = load_library()
+    _need_gpu(sout_nchw, "sout")
+    B, c, Hc, Wc = sout_nchw.shape
+    cs = cs or (c + 7) // 8 * 8
+    dev = sout_nchw.device
+    x = torch.zeros(B, Hc, Wc, cs, dtype=torch.float32, device=dev)
+    x[..., :c] = sout_nchw.permute(0, 2, 3, 1)
+    d = torch.full_like(x, float("nan")) if grad else None   # (the operator overwrites it)
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    scratch = torch.empty(65536, dtype=torch.uint8, device=dev)
+    lab = labels.to(device=dev, dtype=torch.int64).contiguous()
+    assert tuple(lab.shape) == (B, Hc * 8, Wc * 8)
+    with torch.cuda.device(dev):
+        _check(lib.ssp_op_sem_loss(_ptr(x), cs, _ptr(lab), B, Hc * 8, Wc * 8, c, algo, _ptr(scratch), scratch.numel(), _ptr(out), _ptr(d),
+                                   _stream()))
+    return float(out.item()), (d[..., :c].permute(0, 3, 1, 2).contiguous() if grad else None)
 
 
 def op_detector_loss(semi_nchw, labels2d, mask2d, grad=True):

@@ -218,3 +218,71 @@ def test_pair_construction_kernels_golden(golden_dir):
         out = L.op_warp_labels(lab.to(dev), Hs[i:i + 1], exact=False).cpu()
         assert float((out != ref).float().sum()) <= 2, i  # rounding ties of the analytic T^-1 H T
 
+
+
+# ------------------------------------------------------------------------------------------------
+# segmentation loss as an operator (ssp_op_sem_loss): both lane layouts against autograd of F.interpolate + cross_entropy in fp64
+# ------------------------------------------------------------------------------------------------
+def _sem_ref(logits, labels, C):
+    x = logits.double().requires_grad_(True)
+    up = F.interpolate(x, scale_factor=8, mode="bilinear", align_corners=False)
+    lab = labels.clone()
+    lab[(lab < 0) | (lab > C)] = C     # the kernels ignore every value outside [0, C)
+    loss = F.cross_entropy(up, lab, ignore_index=C)
+    loss.backward()
+    return float(loss.detach()), x.grad.float()
+
+
+def _sem_labels(B, H, W, C, kind, gen):
+    if kind == "noise":      # every pixel its own class: worst case of the label histogram
+        lab = torch.randint(0, C, (B, H, W), generator=gen)
+    else:                    # segments: a few classes per 8x8 tile, like a segmentation map
+        coarse = torch.randint(0, C, (B, 1, (H + 23) // 24, (W + 23) // 24), generator=gen).float()
+        lab = F.interpolate(coarse, size=(H, W), mode="nearest")[:, 0].long()
+    lab[0, :9, :] = C                    # ignored rows: the first tile row of image 0 has no counted pixel at all
+    lab[-1, H // 2:H // 2 + 3, 5:40] = C
+    lab[-1, -1, -1] = 255                # values a dataset may hold for "void": ignored like C
+    lab[-1, -2, -1] = -1
+    return lab
+
+
+SEM_CASES = [
+    # B, Hc, Wc, C, scale of the logits, labels
+    (2, 8, 12, 133, 3.0, "segments"),
+    (2, 8, 12, 133, 3.0, "noise"),
+    (1, 5, 7, 133, 40.0, "segments"),     # sharp softmax: the shift bound matters
+    (1, 4, 4, 133, 25.0, "noise"),
+    (3, 3, 9, 21, 2.0, "segments"),       # two class blocks
+    (1, 6, 5, 144, 2.0, "noise"),         # every class slot of the (x, class) form in use
+    (1, 6, 5, 1, 2.0, "segments"),
+]
+
+
+@pytest.mark.parametrize("algo", [1, 2], ids=["pixels_then_classes", "x_class_lanes"])
+@pytest.mark.parametrize("B,Hc,Wc,C,scale,kind", SEM_CASES)
+def test_sem_loss_operator_vs_autograd(B, Hc, Wc, C, scale, kind, algo):
+    from semantic_superpoint_amd import lib as L
+    gen = torch.Generator().manual_seed(1000 * C + Hc)
+    logits = torch.randn(B, C, Hc, Wc, generator=gen) * scale
+    labels = _sem_labels(B, 8 * Hc, 8 * Wc, C, kind, gen)
+    ref_loss, ref_grad = _sem_ref(logits, labels, C)
+    loss, grad = L.op_sem_loss(logits.to(_dev()), labels, algo=algo)
+    assert abs(loss - ref_loss) < 2e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    assert (grad.cpu() - ref_grad).abs().max() < 1e-7 + 2e-5 * float(ref_grad.abs().max())
+    fwd_only, none = L.op_sem_loss(logits.to(_dev()), labels, grad=False, algo=algo)
+    assert none is None and abs(fwd_only - loss) < 1e-6 * max(1.0, abs(loss))
+
+
+def test_sem_loss_operator_dispatch_and_limits():
+    """algo 0 is what the step runs: the (x, class) form up to 144 classes, the other form above; 2 refuses what it cannot do."""
+    from semantic_superpoint_amd import lib as L
+    gen = torch.Generator().manual_seed(7)
+    for C in (133, 150):
+        logits = torch.randn(1, C, 4, 6, generator=gen) * 2
+        labels = _sem_labels(1, 32, 48, C, "segments", gen)
+        ref_loss, ref_grad = _sem_ref(logits, labels, C)
+        loss, grad = L.op_sem_loss(logits.to(_dev()), labels, algo=0)
+        assert abs(loss - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+        assert (grad.cpu() - ref_grad).abs().max() < 1e-7 + 2e-5 * float(ref_grad.abs().max())
+    with pytest.raises(RuntimeError):
+        L.op_sem_loss(torch.randn(1, 150, 4, 6).to(_dev()), torch.zeros(1, 32, 48, dtype=torch.long), algo=2)
