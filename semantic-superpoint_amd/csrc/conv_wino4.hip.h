@@ -17,7 +17,7 @@
 // >> 2) + 4 (lane >> 5)), so four consecutive channels sit in four consecutive registers (16-byte LDS / global accesses).
 //
 // Stage pipeline (8 input channels per stage = 72 MFMAs per wave in 9 component pairs, the two accumulators of a pair
-// alternating; transformed input double-buffered, ONE raw-halo buffer):
+// alternating; transformed input and raw halo double-buffered, ONE barrier per stage):
 //
 //   first half : pairs 0..4  ||  transform raw(g+1): sR[~g&1] -> sA[~g&1]  (the wave's transform task, below)
 //   second half: pairs 5..8  ||  halo (g+2): registers -> sR[g&1] (BatchNorm + ReLU of the producer), halo loads (g+4)

@@ -255,6 +255,7 @@ SEM_CASES = [
     (3, 3, 9, 21, 2.0, "segments"),       # two class blocks
     (1, 6, 5, 144, 2.0, "noise"),         # every class slot of the (x, class) form in use
     (1, 6, 5, 1, 2.0, "segments"),
+    (1, 30, 40, 133, 3.0, "segments"),    # one image of the training shape: 8 row groups, the column range split over workgroups
 ]
 
 
