@@ -366,8 +366,8 @@ struct WgradWinoGeom {
 struct WgsNoHook {
   template <typename S> __device__ __forceinline__ void operator()(S) const {}
 };
-// `hook(std::integral_constant<int, S>)` runs between the LDS reads and the MFMAs of step S (wgrad_wino_fused_kernel issues the
-// next tile's global loads there, two per step)
+// `hook(std::integral_constant<int, S>)` runs behind the LDS reads of step S, in the shadow of its first MFMA (wgrad_wino_fused_kernel
+// issues the next tile's global loads there, two per step)
 template <typename G, typename HOOK = WgsNoHook>
 __device__ __forceinline__ void wgrad_wino_steps(f32x16 (&acc)[4][2], const float* __restrict__ xa0,
                                                  const float* __restrict__ xb0, const float* __restrict__ db0,
@@ -391,7 +391,12 @@ __device__ __forceinline__ void wgrad_wino_steps(f32x16 (&acc)[4][2], const floa
     _Pragma("unroll") for (int c = 0; c < 4; ++c) T[c] = pk_fma(sg, Wv[c], U[c]);                   \
     r = pk_fma(c1, bot, pk_mul(c0, top));                                                                   \
   }
-#define WGS_TAIL()                                                                                           \
+  // second half: the operands of the 8 MFMAs, the first MFMA, then - in ITS shadow - the LDS reads of step s + 1 and the hook's
+  // global loads (a non-VALU instruction directly behind an MFMA issues for free while the matrix pipe is busy; in front of the
+  // group, where they stood until round 6, each of the 8 cost ~5 cycles: PERF_LOG round 6 section 0), then the other 7 MFMAs.
+  // The reads land under those 7 (448 cycles).
+#define WGS_STEP(S)                                                                                          \
+  WGS_HEAD()                                                                                                 \
   {                                                                                                          \
     const f32x2 V0 = pk_sub(T[0], T[2]), V1 = pk_add(T[1], T[2]), V2 = pk_sub(T[2], T[1]), V3 = pk_sub(T[1], T[3]); \
     const float D0 = r[0], D1 = r[0] + r[1], D2 = r[0] - r[1], D3 = -r[1];                                   \
@@ -399,6 +404,10 @@ __device__ __forceinline__ void wgrad_wino_steps(f32x16 (&acc)[4][2], const floa
     /* all operands are complete before the fence, the first MFMA reads V0, written >= 3 instructions earlier */ \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[0], D0, acc[0][0], 0, 0, 0);                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if ((S) + 1 < 16) WGS_LOAD(((S) + 1 < 16 ? (S) + 1 : 0))                                                 \
+    hook(std::integral_constant<int, (S)>{});                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[1], D0, acc[0][1], 0, 0, 0);                         \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[0], D1, acc[1][0], 0, 0, 0);                         \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[1], D1, acc[1][1], 0, 0, 0);                         \
@@ -406,22 +415,13 @@ __device__ __forceinline__ void wgrad_wino_steps(f32x16 (&acc)[4][2], const floa
     acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[1], D2, acc[2][1], 0, 0, 0);                         \
     acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[0], D3, acc[3][0], 0, 0, 0);                         \
     acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[1], D3, acc[3][1], 0, 0, 0);                         \
-  }
-  // the LDS reads of step s + 1 are issued between the two halves of step s and land under its 8 MFMAs
-#define WGS_STEP(S)                                                                                          \
-  WGS_HEAD()                                                                                                 \
-  __builtin_amdgcn_sched_barrier(0);                                                                         \
-  if ((S) + 1 < 16) WGS_LOAD(((S) + 1 < 16 ? (S) + 1 : 0))                                                   \
-  hook(std::integral_constant<int, (S)>{});                                                                  \
-  __builtin_amdgcn_sched_barrier(0);                                                                         \
-  WGS_TAIL()                                                                                                 \
+  }                                                                                                          \
   __builtin_amdgcn_sched_barrier(0);
   WGS_LOAD(0)
   WGS_STEP(0) WGS_STEP(1) WGS_STEP(2) WGS_STEP(3) WGS_STEP(4) WGS_STEP(5) WGS_STEP(6) WGS_STEP(7)
   WGS_STEP(8) WGS_STEP(9) WGS_STEP(10) WGS_STEP(11) WGS_STEP(12) WGS_STEP(13) WGS_STEP(14) WGS_STEP(15)
 #undef WGS_LOAD
 #undef WGS_HEAD
-#undef WGS_TAIL
 #undef WGS_STEP
 }
 
