@@ -1,6 +1,6 @@
-"""Soak of the mixed bf16 mode (conv algo 8, BASELINE configs[3]) against fp32: two engines, identical initial weights,
+"""Soak of the bf16 path (conv algo 12, BASELINE configs[3]) against fp32: two engines, identical initial weights,
 identical batches and sampler seeds, N optimizer steps each; prints both loss curves (mean over 10-step windows) and
-their relative deviation.  usage: soak_bf16.py [ssp|sp] [steps] [batch] [algo_a,algo_b]   (default 1,8; "9,1" soaks the default
+their relative deviation.  usage: soak_bf16.py [ssp|sp] [steps] [batch] [algo_a,algo_b]   (default 1,12; "9,1" soaks the default
 algorithm - Winograd F(4x4,3x3) on the large maps - against F(2x2,3x3) only)"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 H, W = 240, 320
 sd = synth.default_init_state_dict(layer_table(arch), seed=0)
 engs = {}
-pair = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "1,8").split(",")]
+pair = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "1,12").split(",")]
 NAMES = {1: "fp32", 8: "mixed bf16 (algo 8)", 9: "fp32 F(2x2,3x3) only", 10: "fp32 F(4x4,3x3) forced", 12: "bf16 path (algo 12)"}
 for name, algo in ((NAMES.get(pair[0], "algo %d" % pair[0]), pair[0]), (NAMES.get(pair[1], "algo %d" % pair[1]), pair[1])):
     L.set_conv_algo(algo)  # copied into the handle at creation
