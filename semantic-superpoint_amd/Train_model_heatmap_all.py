@@ -256,6 +256,7 @@ class Train_model_heatmap_all(object):
             self.scalar_dict["eta_sem"] = eta[2]
         if n_iter % cfg["tensorboard_interval"] == 0 or task == "val":
             self.log_precision_recall(eng, dev, B, H, W)
+            self.tb_hist_dict(task, self.hist_dict)   # (:568; `images_dict` stays unwritten like the reference's commented-out :567)
         self.tb_scalar_dict(self.scalar_dict, task)
         return float(s["loss"])
 
@@ -295,6 +296,38 @@ class Train_model_heatmap_all(object):
             return
         for element in list(losses):
             self._writer.add_scalar(task + "-" + element, losses[element], self.n_iter // self.r)
+
+    def tb_images_dict(self, task, tb_imgs, max_img=5):
+        """Train_model_frontend_all.py:535-566: the first `max_img` entries of every [N,C,H,W] array of the dict as images; with
+        `config["semantic"]` the class maps `sem_pred` / `warp_sem_pred` are reduced to their argmax first.  (The reference's
+        heat-map trainer leaves its own call commented out, :567; the method is here for callers that want the overlays of
+        `images_dict` in their event file.)"""
+        if self._writer is None:
+            return
+        if self.config.get("semantic", False) and "sem_pred" in tb_imgs:
+            for key in ("sem_pred", "warp_sem_pred"):
+                if key in tb_imgs:
+                    a = np.asarray(tb_imgs[key])
+                    out = np.zeros((a.shape[0], 1) + a.shape[2:])
+                    out[:, 0] = np.argmax(a, axis=1)
+                    tb_imgs[key] = out
+        for element in list(tb_imgs):
+            for idx in range(tb_imgs[element].shape[0]):
+                if idx >= max_img:
+                    break
+                self._writer.add_image(task + "-" + element + "/%d" % idx, tb_imgs[element][idx, ...], self.n_iter // self.r)
+
+    def tb_hist_dict(self, task, tb_dict):
+        """Train_model_frontend_all.py:568-571."""
+        if self._writer is None:
+            return
+        for element in list(tb_dict):
+            self._writer.add_histogram(task + "-" + element, tb_dict[element], self.n_iter // self.r)
+
+    def printLosses(self, losses, task="training"):
+        """Train_model_frontend_all.py:573-582 (the scalars are Python floats here: no .item())."""
+        for element in list(losses):
+            print(task, "-", element, ": ", float(losses[element]))
 
     # ---- outer loop / checkpoints (Train_model_frontend_all.py:315-359, 422-439) ----
     def train(self, **options):

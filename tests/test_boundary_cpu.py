@@ -145,6 +145,31 @@ def test_trainer_refuses_cpu_and_unsupported_configs():
         T(cfg, device="cpu")
 
 
+def test_trainer_tensorboard_helpers_follow_the_reference_names():
+    """tb_images_dict / tb_hist_dict / printLosses of the base class (Train_model_frontend_all.py:535-582): tags
+    "<task>-<element>/<idx>", at most max_img images per element, semantic class maps reduced to their argmax, step n_iter // r."""
+    import types
+    from semantic_superpoint_amd.Train_model_heatmap_all import Train_model_heatmap_all as T
+    calls = []
+    writer = types.SimpleNamespace(add_image=lambda tag, img, step: calls.append(("image", tag, np.asarray(img).shape, step)),
+                                   add_histogram=lambda tag, v, step: calls.append(("hist", tag, step)))
+    me = types.SimpleNamespace(_writer=writer, config={"semantic": True}, n_iter=12, r=4)
+    imgs = {"heat": np.zeros((3, 1, 8, 8)), "sem_pred": np.random.rand(2, 5, 8, 8), "warp_sem_pred": np.random.rand(2, 5, 8, 8)}
+    expect = np.argmax(imgs["sem_pred"], axis=1)
+    T.tb_images_dict(me, "training", imgs, max_img=2)
+    tags = [c[1] for c in calls]
+    assert tags == ["training-heat/0", "training-heat/1", "training-sem_pred/0", "training-sem_pred/1",
+                    "training-warp_sem_pred/0", "training-warp_sem_pred/1"]
+    assert all(c[3] == 3 for c in calls) and calls[2][2] == (1, 8, 8)
+    assert np.array_equal(imgs["sem_pred"][:, 0], expect)
+    calls.clear()
+    T.tb_hist_dict(me, "val", {"a": np.arange(4.0)})
+    assert calls == [("hist", "val-a", 3)]
+    me._writer = None   # no writer: silently nothing, like tb_scalar_dict
+    T.tb_images_dict(me, "val", {"x": np.zeros((1, 1, 2, 2))})
+    T.tb_hist_dict(me, "val", {"a": np.arange(4.0)})
+
+
 def test_host_sampler_reproduces_reference_indices():
     """`ssp_sampler: reference` consumes numpy/torch RNG like the reference: same seeds => G4's indices."""
     from semantic_superpoint_amd.Train_model_heatmap_all import sample_sparse_indices_host
