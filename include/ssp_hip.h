@@ -98,6 +98,11 @@ typedef struct {
    * computed by the caller on the host with the reference's own fp32 op sequence; used by the captured device sampler
    * (ssp_pair_step_graph) - see ssp_sample_indices_cell */
   const float* cell_homographies_dev;
+  /* sparse_loss.params.method / dist (sparse_loss.py:76-77, pixelwise_contrastive_loss.py:140): 0 / 0 = "2d" / "cos", what every
+   * shipped config selects; method 1 = "1d" (matches by index_select at the cell), dist 1 = "euclidean" (squared distance of the
+   * matches, (max(0, ||a - b|| - 0.2))^2 of the non-matches - nearly every non-match of unit descriptors is then a hard one) */
+  int sparse_method;
+  int sparse_dist;
 } ssp_pair_inputs;
 
 /* indices into the float scalars[SSP_N_SCALARS] array filled by ssp_pair_step (the reference's
@@ -389,11 +394,14 @@ int ssp_debug_occupancy(int which);
  * "scale<l>","shift<l>","mean<l>","invstd<l>"); under the bf16 path Y<l> / A<l> of the 3x3 layers, gP and gQ hold bf16 elements */
 int ssp_debug_buffer(ssp_handle* h, int slot, const char* name, float** ptr, size_t* nfloats);
 
-/* forward of batch_descriptor_loss_sparse (utils/loss_functions/sparse_loss.py:267-284) on NHWC descriptor
- * maps [B][hc*wc][256] with explicit indices; out2_dev = {mean positive_dist, mean negative_dist}. */
+/* batch_descriptor_loss_sparse (utils/loss_functions/sparse_loss.py:267-284) on NHWC descriptor maps [B][hc*wc][256] with explicit
+ * indices; out2_dev = {mean positive_dist, mean negative_dist}.  method: 0 = "2d" (bilinear grid_sample at normPts), 1 = "1d"
+ * (index_select at the cell); dist: 0 = "cos", 1 = "euclidean" (pixelwise_contrastive_loss.py:140,185-210,247-258).  With dd_a /
+ * dd_b (both or none; same layout, OVERWRITTEN) also the gradient of coef_pos * positive_dist + coef_neg * negative_dist. */
 int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,
                        const int32_t* match_b_dev, const int32_t* nonmatch_b_dev, int b, int hc, int wc, int n_match,
-                       int n_non, float* out2_dev, void* stream);
+                       int n_non, int method, int dist, float coef_pos, float coef_neg, float* dd_a_nhwc_dev, float* dd_b_nhwc_dev,
+                       float* out2_dev, void* stream);
 
 /* Dense descriptor loss as an operator (utils/utils.py:779-893) on NHWC descriptor maps [B][hc*wc][256]:
  * out3_dev = {loss_desc, pos_sum, neg_sum}; with dda_dev / ddb_dev (both or none) also the gradients of

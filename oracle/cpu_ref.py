@@ -381,36 +381,48 @@ def norm_pts(pts, shape_wh):
     return pts / torch.as_tensor(shape_wh).float() * 2 - 1
 
 
-def descriptor_loss_sparse_given(desc_a, desc_b, idx, lamda_d=1.0, n_non=100):
+def descriptor_loss_sparse_given(desc_a, desc_b, idx, lamda_d=1.0, n_non=100, dist="cos", method="2d"):
     """Deterministic half of descriptor_loss_sparse (sparse_loss.py:219-254) for one image given
-    the sampled indices.  desc_* [D,Hc,Wc].  Returns (loss, pos, neg)."""
+    the sampled indices.  desc_* [D,Hc,Wc].  Returns (loss, pos, neg).
+    method: "2d" = bilinear grid_sample at normPts (pixelwise_contrastive_loss.py:160-184), anything else ("1d") =
+    index_select at the integer cell (:185-188).  dist: "cos" = hinge on the dot product (:200-204, :247-256), anything else
+    ("euclidean") = squared distance of the matches (:205-206) and (max(0, ||a - b|| - M))^2 of the non-matches (:249-258)."""
     D, Hc, Wc = desc_a.shape
     wh = (Wc, Hc)
-    ga = norm_pts(idx["uv_a"], wh).view(1, -1, 1, 2)
-    gb = norm_pts(idx["uv_b"], wh).view(1, -1, 1, 2)
-    # match_loss(method="2d"): pixelwise_contrastive_loss.py:160-206
-    da = F.grid_sample(desc_a.unsqueeze(0), ga, mode="bilinear", align_corners=True).squeeze(0).squeeze(-1).t()
-    db = F.grid_sample(desc_b.unsqueeze(0), gb, mode="bilinear", align_corners=True).squeeze(0).squeeze(-1).t()
-    pos = torch.clamp(1.0 - (da * db).sum(-1), min=0).sum() / da.shape[0]
-    # non matches: sparse_loss.py:96-100,245-246 ; pixelwise_contrastive_loss.py:238-263
     flat_a = desc_a.reshape(D, Hc * Wc).t()
     flat_b = desc_b.reshape(D, Hc * Wc).t()
+    if method == "2d":
+        ga = norm_pts(idx["uv_a"], wh).view(1, -1, 1, 2)
+        gb = norm_pts(idx["uv_b"], wh).view(1, -1, 1, 2)
+        da = F.grid_sample(desc_a.unsqueeze(0), ga, mode="bilinear", align_corners=True).squeeze(0).squeeze(-1).t()
+        db = F.grid_sample(desc_b.unsqueeze(0), gb, mode="bilinear", align_corners=True).squeeze(0).squeeze(-1).t()
+    else:  # sparse_loss.py:224-226,234-236: uv_to_1d, index_select
+        da = flat_a[(idx["uv_a"][:, 0] + idx["uv_a"][:, 1] * Wc).long()]
+        db = flat_b[(idx["uv_b"][:, 0] + idx["uv_b"][:, 1] * Wc).long()]
+    if dist == "cos":
+        pos = torch.clamp(1.0 - (da * db).sum(-1), min=0).sum() / da.shape[0]
+    else:
+        pos = (da - db).pow(2).sum() / da.shape[0]
+    # non matches: sparse_loss.py:96-100,245-246 ; pixelwise_contrastive_loss.py:238-263 (M = 0.2, invert=True)
     ia = (idx["uv_a"][:, 0] + idx["uv_a"][:, 1] * Wc).long().repeat_interleave(n_non)
     ib = idx["nm_b"].long()
-    nm = torch.clamp((flat_a[ia] * flat_b[ib]).sum(-1) - 0.2, min=0)
+    if dist == "cos":
+        nm = torch.clamp((flat_a[ia] * flat_b[ib]).sum(-1) - 0.2, min=0)
+    else:
+        nm = torch.clamp((flat_a[ia] - flat_b[ib]).norm(2, 1) - 0.2, min=0).pow(2)
     nnz = int((nm != 0).sum())
     neg = nm.sum() / (nnz + 1)  # sparse_loss.py:154
     return lamda_d * pos + neg, pos, neg
 
 
 def batch_descriptor_loss_sparse(desc, desc_w, homographies, indices=None, lamda_d=1.0, n_match=1000,
-                                 n_non=100, np_rng=np.random, torch_gen=None):
+                                 n_non=100, np_rng=np.random, torch_gen=None, dist="cos", method="2d"):
     """sparse_loss.py:267-284.  `indices` (list per image) overrides sampling."""
     ls, ps, ns, used = [], [], [], []
     for i in range(desc.shape[0]):
         idx = indices[i] if indices is not None else sample_sparse_indices(
             homographies[i].float(), desc.shape[2], desc.shape[3], n_match, n_non, np_rng, torch_gen)
-        l, p, n = descriptor_loss_sparse_given(desc[i], desc_w[i], idx, lamda_d, n_non)
+        l, p, n = descriptor_loss_sparse_given(desc[i], desc_w[i], idx, lamda_d, n_non, dist, method)
         ls.append(l), ps.append(p), ns.append(n), used.append(idx)
     return torch.stack(ls).mean(), torch.stack(ps).mean(), torch.stack(ns).mean(), used
 
@@ -428,8 +440,9 @@ def multi_task_loss(eta, det, pos, neg, sem=None):
 # --------------------------------------------------------------------------------------
 def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lambda_loss=1.0, lamda_d=1.0,
                 multi_task=True, gaussian=True, n_match=1000, n_non=100, np_rng=np.random, torch_gen=None,
-                train=True, dense=None, forced=None, operand_dtype=None, warped_pair=True):
+                train=True, dense=None, forced=None, operand_dtype=None, warped_pair=True, sparse_dist="cos", sparse_method="2d"):
     """Forward of both views + all losses.  Returns (loss, scalars dict, aux dict).
+    sparse_dist / sparse_method: model.sparse_loss.params.dist / method (sparse_loss.py:76-77; every shipped config: cos / 2d).
     dense: None (sparse descriptor loss) or the dict of model.dense_loss.params (Train_model_heatmap_all.py:131-137).
     warped_pair=False: the single-view branch (`data.warped_pair.enable: false`, :207; the shipped
     configs/magicpoint_shapes_pair.yaml:50-51): ONE forward, detector (+ semantic) loss of the image only; the warped
@@ -459,7 +472,8 @@ def pair_losses(sd, eta, sample, arch="SuperPointNet_gauss2", indices=None, lamb
         used = None
     elif lambda_loss > 0:
         loss_desc, pos, neg, used = batch_descriptor_loss_sparse(
-            out["desc"], out_w["desc"], sample["homographies"], indices, lamda_d, n_match, n_non, np_rng, torch_gen)
+            out["desc"], out_w["desc"], sample["homographies"], indices, lamda_d, n_match, n_non, np_rng, torch_gen,
+            sparse_dist, sparse_method)
     else:
         loss_desc, pos, neg, used = zero, zero, zero, None
     if multi_task:

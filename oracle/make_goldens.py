@@ -232,6 +232,45 @@ def g4_sparse_loss():
     assert float(p2) > 0.01 and abs(float(p2) - float(po)) < 1e-6
 
 
+def g14_sparse_loss_variants():
+    """G14: descriptor_loss_sparse with the parameter values no shipped config selects but the function accepts
+    (sparse_loss.py:76-77, pixelwise_contrastive_loss.py:140): method "1d" (index_select at the cell instead of the bilinear
+    grid_sample) and dist "euclidean" (squared distance / (max(0, ||a - b|| - 0.2))^2 instead of the hinges on the dot product)."""
+    for tag, (Hc, Wc) in (("small", (4, 6)), ("mid", (9, 12))):
+        for method, dist in (("1d", "cos"), ("2d", "euclidean"), ("1d", "euclidean")):
+            params = {"num_matching_attempts": 200, "num_masked_non_matches_per_match": 20, "lamda_d": 1, "dist": dist, "method": method}
+            rs = np.random.RandomState(23)
+            B = 2
+            d = rs.randn(B, 256, Hc, Wc).astype(np.float32)
+            dw = (0.9 * d + 0.45 * rs.randn(B, 256, Hc, Wc)).astype(np.float32)  # close pairs: hard negatives in both metrics
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            dw /= np.linalg.norm(dw, axis=1, keepdims=True)
+            Hs = torch.from_numpy(np.stack([np.linalg.inv(C.sample_homography(rs)) for _ in range(B)]).astype(np.float32))
+            desc = torch.from_numpy(d).requires_grad_(True)
+            desc_w = torch.from_numpy(dw).requires_grad_(True)
+            R.install()
+            import utils.loss_functions.sparse_loss as SL
+            np.random.seed(77); torch.manual_seed(78)
+            loss, _, pos, neg = SL.batch_descriptor_loss_sparse(desc, desc_w, Hs, device="cpu", **params)
+            g_d, g_dw = torch.autograd.grad(loss + 0.5 * pos + 0.25 * neg, (desc, desc_w))
+            np.random.seed(77); torch.manual_seed(78)
+            d2 = desc.detach().clone().requires_grad_(True)
+            dw2 = desc_w.detach().clone().requires_grad_(True)
+            lo, po, no, used = C.batch_descriptor_loss_sparse(d2, dw2, Hs, None, 1.0, 200, 20, np.random, None, dist, method)
+            close(loss, lo, 1e-6, "G14 loss"); close(pos, po, 1e-6, "G14 pos"); close(neg, no, 1e-6, "G14 neg")
+            go_d, go_dw = torch.autograd.grad(lo + 0.5 * po + 0.25 * no, (d2, dw2))
+            close(g_d, go_d, 1e-7, "G14 d desc"); close(g_dw, go_dw, 1e-7, "G14 d desc_w")
+            assert float(neg) > 0 and float(pos) > 0, (tag, method, dist, float(pos), float(neg))
+            save = {"H": npy(Hs), "loss": npy(loss), "pos": npy(pos), "neg": npy(neg), "seed": 23, "n_match": 200, "n_non": 20,
+                    "grad_weights": np.array([1.0, 0.5, 0.25], np.float32), "desc": d, "desc_w": dw, "ddesc": npy(g_d),
+                    "ddesc_w": npy(g_dw)}
+            for i in range(B):
+                save["uv_a%d" % i] = npy(used[i]["uv_a"]).astype(np.int16)
+                save["uv_b%d" % i] = npy(used[i]["uv_b"]).astype(np.int16)
+                save["nm_b%d" % i] = npy(used[i]["nm_b"]).astype(np.int16)
+            np.savez_compressed(os.path.join(OUT, "g14_sparse_loss_%s_%s_%s.npz" % (method, dist, tag)), **save)
+
+
 def _sample_to_npz(s):
     return {("in/" + k): npy(v) for k, v in s.items()}
 
@@ -698,7 +737,7 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     only = os.environ.get("SSP_GOLDEN_ONLY")  # e.g. SSP_GOLDEN_ONLY=g12 regenerates one family
-    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss, g11_pair_labels, g12_full_size_step, g13_single_view_step):
+    for fn in (g1_forward, g2_labels, g3_detector_loss, g5_sem_loss, g4_sparse_loss, g7_warps, g6_train_step, g8_export, g9_logging, g10_dense_loss, g11_pair_labels, g12_full_size_step, g13_single_view_step, g14_sparse_loss_variants):
         if only and not fn.__name__.startswith(only):
             continue
         fn()

@@ -97,9 +97,7 @@ class Train_model_heatmap_all(object):
             self.desc_params = m["dense_loss"].get("params") or {}
             self.desc_loss_type = "dense"
         elif m.get("sparse_loss", {}).get("enable", False):
-            self.desc_params = m["sparse_loss"]["params"]
-            if self.desc_params.get("method", "2d") != "2d" or self.desc_params.get("dist", "cos") != "cos":
-                raise NotImplementedError("only sparse_loss method='2d', dist='cos' (all shipped configs) is accelerated")
+            self.desc_params = m["sparse_loss"]["params"]   # method / dist: descriptor_loss_sparse's own defaults (sparse_loss.py:76-77)
             self.desc_loss_type = "sparse"
         else:
             raise KeyError("model.dense_loss.enable or model.sparse_loss.enable must be true")
@@ -238,6 +236,8 @@ class Train_model_heatmap_all(object):
         seed = (int(cfg.get("ssp_seed", 0)) * 1000003 + n_iter) * 64 + parallel.rank()
         kw = dict(indices=idx, seed=seed, train=train, lambda_loss=lam, lamda_d=float(self.desc_params.get("lamda_d", 250)),
                   multi_task=bool(m["multi_task_loss"]), gaussian=self.gaussian, dense=dense)
+        if self.desc_loss_type == "sparse":  # descriptor_loss_sparse's own defaults: dist="cos", method="1d" (sparse_loss.py:76-77)
+            kw.update(sparse_method=str(self.desc_params.get("method", "1d")), sparse_dist=str(self.desc_params.get("dist", "cos")))
         opt_step = train and ((n_iter + 1) * B) % self.real_batch_size == 0
         if opt_step:  # all-reduce (world > 1) overlapped with the tail of the backward pass, then fused Adam
             sc = parallel.pair_step_overlapped(eng, dev, self.learning_rate, **kw)

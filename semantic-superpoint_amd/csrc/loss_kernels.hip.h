@@ -207,6 +207,16 @@ __device__ __forceinline__ Bilin bilin_setup(int cell, int Hc, int Wc) {
   b.w11 = (vx1 && vy1) ? ax * ay : 0.f;
   return b;
 }
+// method "1d" of match_loss (pixelwise_contrastive_loss.py:185-188): index_select at the cell itself - one corner, weight 1
+__device__ __forceinline__ Bilin bilin_cell(int cell) {
+  Bilin b;
+  b.i00 = b.i01 = b.i10 = b.i11 = cell;
+  b.w00 = 1.f; b.w01 = b.w10 = b.w11 = 0.f;
+  return b;
+}
+// variants of the sparse descriptor loss (sparse_loss.py:76-77; every shipped config: method "2d", dist "cos" = flags 0)
+constexpr int DESC_METHOD_1D = 1;   // matches sampled by index_select instead of the bilinear grid_sample
+constexpr int DESC_EUCLIDEAN = 2;   // squared distance / (max(0, ||a - b|| - 0.2))^2 instead of the hinges on the dot product
 __device__ __forceinline__ float4 f4_fma(float w, float4 a, float4 acc) {
   return make_float4(fmaf(w, a.x, acc.x), fmaf(w, a.y, acc.y), fmaf(w, a.z, acc.z), fmaf(w, a.w, acc.w));
 }
@@ -239,41 +249,59 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
                                                          const int32_t* __restrict__ match_a,
                                                          const int32_t* __restrict__ match_b, float* __restrict__ dd_a,
                                                          float* __restrict__ dd_b, StepAccum* __restrict__ acc, int B,
-                                                         int Hc, int Wc, int n_match) {
+                                                         int Hc, int Wc, int n_match, int flags) {
   const DetTarget t_a = det_resolve(dd_a), t_b = det_resolve(dd_b);   // (deterministic mode: fixed-point shadows)
   int img;
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
   if (w < 0) return;
+  const bool m1d = (flags & DESC_METHOD_1D) != 0, euc = (flags & DESC_EUCLIDEAN) != 0;   // wave-uniform
   const size_t base = (size_t)img * Hc * Wc * 256 + lane;
-  const Bilin ba = bilin_setup(match_a[w], Hc, Wc), bb = bilin_setup(match_b[w], Hc, Wc);
+  const Bilin ba = m1d ? bilin_cell(match_a[w]) : bilin_setup(match_a[w], Hc, Wc);
+  const Bilin bb = m1d ? bilin_cell(match_b[w]) : bilin_setup(match_b[w], Hc, Wc);
   float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
   // torch accumulates nw, ne, sw, se in this order
   const int ia[4] = {ba.i00, ba.i01, ba.i10, ba.i11}, ib[4] = {bb.i00, bb.i01, bb.i10, bb.i11};
   const float wa[4] = {ba.w00, ba.w01, ba.w10, ba.w11}, wb[4] = {bb.w00, bb.w01, bb.w10, bb.w11};
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
+  if (m1d) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      va[j] = fmaf(wa[k], desc_a[base + (size_t)ia[k] * 256 + 64 * j], va[j]);
-      vb[j] = fmaf(wb[k], desc_b[base + (size_t)ib[k] * 256 + 64 * j], vb[j]);
+      va[j] = desc_a[base + (size_t)ia[0] * 256 + 64 * j];
+      vb[j] = desc_b[base + (size_t)ib[0] * 256 + 64 * j];
     }
-  const float dot = wave_sum(va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2] + va[3] * vb[3]);
-  const float hinge = fmaxf(1.f - dot, 0.f);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)   // (all 32 row loads of a wave in flight)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        va[j] = fmaf(wa[k], desc_a[base + (size_t)ia[k] * 256 + 64 * j], va[j]);
+        vb[j] = fmaf(wb[k], desc_b[base + (size_t)ib[k] * 256 + 64 * j], vb[j]);
+      }
+  }
+  // cos: max(0, 1 - <a, b>) (pixelwise_contrastive_loss.py:200-204);  euclidean: |a - b|^2 (:205-206)
+  float term;
+  if (!euc) {
+    term = fmaxf(1.f - wave_sum(va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2] + va[3] * vb[3]), 0.f);
+  } else {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q = fmaf(va[j] - vb[j], va[j] - vb[j], q);
+    term = wave_sum(q);
+  }
   // (the gradient of the match term does not depend on any sum over the batch - coef_pos is set by step_begin_kernel - so a training
   // step runs the BWD instantiation alone: loss sum and scatter from one gather of the eight corner rows)
-  if (lane == 0) acc_add_loss(&acc->pos_sum[img * 16 + ((w >> 2) & 15)], (double)hinge);  // 16 replicas / image
-  if (BWD && hinge > 0.f) {
-    const float c = -acc->coef_pos / ((float)n_match * (float)B);  // d total / d dot
+  if (lane == 0) acc_add_loss(&acc->pos_sum[img * 16 + ((w >> 2) & 15)], (double)term);  // 16 replicas / image
+  if (BWD && (euc || term > 0.f)) {
+    const float c = acc->coef_pos / ((float)n_match * (float)B) * (euc ? 2.f : -1.f);  // d total / d <a, b>  resp.  d total / d (a - b) / (a - b)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 4; ++k) {   // (method "1d": the weights of corners 1 - 3 are 0)
       if (wa[k] != 0.f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) facc_add(t_a, dd_a + base + (size_t)ia[k] * 256 + 64 * j, wa[k] * c * vb[j]);
+        for (int j = 0; j < 4; ++j) facc_add(t_a, dd_a + base + (size_t)ia[k] * 256 + 64 * j, wa[k] * c * (euc ? va[j] - vb[j] : vb[j]));
       }
       if (wb[k] != 0.f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) facc_add(t_b, dd_b + base + (size_t)ib[k] * 256 + 64 * j, wb[k] * c * va[j]);
+        for (int j = 0; j < 4; ++j) facc_add(t_b, dd_b + base + (size_t)ib[k] * 256 + 64 * j, wb[k] * c * (euc ? vb[j] - va[j] : va[j]));
       }
     }
   }
@@ -287,11 +315,12 @@ __global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __r
                                                                 const int32_t* __restrict__ match_a,
                                                                 const int32_t* __restrict__ nonmatch_b,
                                                                 float* __restrict__ dots, StepAccum* __restrict__ acc,
-                                                                int B, int Hc, int Wc, int n_match, int n_non) {
+                                                                int B, int Hc, int Wc, int n_match, int n_non, int flags) {
   int img;
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
   if (w < 0) return;
+  const bool euc = (flags & DESC_EUCLIDEAN) != 0;  // wave-uniform: `dots` then holds ||a - b|| and the term is (max(0, d - 0.2))^2
   const int grp = lane >> 4, l16 = lane & 15;
   const size_t ibase = (size_t)img * Hc * Wc * 256;
   const float* ap = desc_a + ibase + (size_t)match_a[w] * 256 + l16 * 4;
@@ -310,13 +339,20 @@ __global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 b = *reinterpret_cast<const float4*>(bp + i * 64);
-      d += a[i].x * b.x + a[i].y * b.y + a[i].z * b.z + a[i].w * b.w;
+      if (!euc) {
+        d += a[i].x * b.x + a[i].y * b.y + a[i].z * b.z + a[i].w * b.w;
+      } else {
+        const float ex = a[i].x - b.x, ey = a[i].y - b.y, ez = a[i].z - b.z, ew = a[i].w - b.w;
+        d += ex * ex + ey * ey + ez * ez + ew * ew;
+      }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if (euc) d = sqrtf(d);   // (a - b).norm(2, 1): pixelwise_contrastive_loss.py:249
     if (l16 == 0 && valid) {
       if (dots != nullptr) dots[(size_t)w * n_non + j] = d;
-      const float h = fmaxf(d - 0.2f, 0.f);
+      float h = fmaxf(d - 0.2f, 0.f);
+      if (euc) h *= h;
       hsum += h;
       cnt += (h != 0.f) ? 1u : 0u;
     }
@@ -338,7 +374,8 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
                                                                 const int32_t* __restrict__ nonmatch_b,
                                                                 const float* __restrict__ dots, float* __restrict__ dd_a,
                                                                 float* __restrict__ dd_b, const StepAccum* __restrict__ acc,
-                                                                int B, int Hc, int Wc, int n_match, int n_non) {
+                                                                int B, int Hc, int Wc, int n_match, int n_non, int flags) {
+  const bool euc = (flags & DESC_EUCLIDEAN) != 0;  // d term / d a = 2 (d - 0.2) (a - b) / d instead of b
   const DetTarget t_a = det_resolve(dd_a), t_b = det_resolve(dd_b);   // (deterministic mode: fixed-point shadows)
   int img;
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
@@ -364,11 +401,22 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
       const int bit = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       const int bi = nm[j0 + bit];  // wave-uniform
+      if (!euc) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float bv = desc_b[ibase + (size_t)bi * 256 + 64 * i];
-        ga[i] = fmaf(wgt, bv, ga[i]);
-        facc_add(t_b, dd_b + ibase + (size_t)bi * 256 + 64 * i, wgt * a[i]);
+        for (int i = 0; i < 4; ++i) {
+          const float bv = desc_b[ibase + (size_t)bi * 256 + 64 * i];
+          ga[i] = fmaf(wgt, bv, ga[i]);
+          facc_add(t_b, dd_b + ibase + (size_t)bi * 256 + 64 * i, wgt * a[i]);
+        }
+      } else {
+        const float dn = dk[j0 + bit];  // wave-uniform, > 0.2
+        const float sgrad = wgt * 2.f * (dn - 0.2f) / dn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float e = a[i] - desc_b[ibase + (size_t)bi * 256 + 64 * i];
+          ga[i] = fmaf(sgrad, e, ga[i]);
+          facc_add(t_b, dd_b + ibase + (size_t)bi * 256 + 64 * i, -sgrad * e);
+        }
       }
     }
   }
@@ -510,6 +558,11 @@ __global__ void sem_op_finish_kernel(const StepAccum* acc, float* out) {
   out[0] = (float)(acc->sem_sum[0] / acc->sem_cnt[0]);
 }
 
+// operator form of the sparse descriptor loss (ssp_op_sparse_loss): d total / d (mean positive term), d total / d (mean negative term)
+__global__ void sparse_op_prep_kernel(StepAccum* acc, float coef_pos, float coef_neg) {
+  acc->coef_pos = coef_pos;
+  acc->coef_neg = coef_neg;
+}
 __global__ void sparse_loss_means_kernel(const StepAccum* acc, float* out, int B, int n_match) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float pos = 0.f, neg = 0.f;

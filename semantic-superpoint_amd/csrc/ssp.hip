@@ -2717,22 +2717,23 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
     HIPCHK(hipGetLastError());
   } else if (use_desc) {
     Slot &A = h->slot[0], &Bs = h->slot[1];
+    const int dflags = (in->sparse_method != 0 ? DESC_METHOD_1D : 0) | (in->sparse_dist != 0 ? DESC_EUCLIDEAN : 0);
     if (!in->train)   // (training: desc_match_kernel<true> below accumulates the loss sum as well)
       hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
-                         in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match);
+                         in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match, dflags);
     hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
                        in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match,
-                       h->cfg.n_non);
+                       h->cfg.n_non, dflags);
     if (in->train) {
       if (!early) {
         CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
         CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
       }
       hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
-                         in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match);
+                         in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match, dflags);
       hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
                          in->nonmatch_b_dev, h->dots, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
-                         h->cfg.n_non);
+                         h->cfg.n_non, dflags);
       for (int v = 0; v < 2; ++v) {
         Slot& S = h->slot[v];
         CHK(det_fold(S.ddesc, sd));   // (deterministic mode) the scattered gradient: fixed-point shadow -> tensor
@@ -3388,18 +3389,37 @@ int ssp_op_dense_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev
 
 int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_dev, const int32_t* match_a_dev,
                        const int32_t* match_b_dev, const int32_t* nonmatch_b_dev, int b, int hc, int wc, int n_match,
-                       int n_non, float* out2_dev, void* stream) {
+                       int n_non, int method, int dist, float coef_pos, float coef_neg, float* dd_a_nhwc_dev, float* dd_b_nhwc_dev,
+                       float* out2_dev, void* stream) {
   if (b < 1 || b > SSP_MAX_PAIRS) return fail(-1, "batch out of range (1..%d)", SSP_MAX_PAIRS);
+  if ((dd_a_nhwc_dev == nullptr) != (dd_b_nhwc_dev == nullptr)) return fail(-1, "sparse_loss: both gradient pointers or none");
   hipStream_t st = (hipStream_t)stream;
+  const bool grad = dd_a_nhwc_dev != nullptr;
+  const int dflags = (method != 0 ? DESC_METHOD_1D : 0) | (dist != 0 ? DESC_EUCLIDEAN : 0);
   StepAccum* acc = nullptr;
+  float* dots = nullptr;
   HIPCHK(hipMallocAsync((void**)&acc, sizeof(StepAccum), st));
   HIPCHK(hipMemsetAsync(acc, 0, sizeof(StepAccum), st));
-  hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
-                     match_a_dev, match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match);
+  hipLaunchKernelGGL(sparse_op_prep_kernel, dim3(1), dim3(1), 0, st, acc, coef_pos, coef_neg);
+  const size_t ncell_floats = (size_t)b * hc * wc * 256;
+  if (grad) {
+    HIPCHK(hipMallocAsync((void**)&dots, (size_t)b * n_match * n_non * sizeof(float), st));
+    CHK(dev_zero(dd_a_nhwc_dev, ncell_floats * sizeof(float), st));
+    CHK(dev_zero(dd_b_nhwc_dev, ncell_floats * sizeof(float), st));
+    hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
+                       match_a_dev, match_b_dev, dd_a_nhwc_dev, dd_b_nhwc_dev, acc, b, hc, wc, n_match, dflags);
+  } else {
+    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
+                       match_a_dev, match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match, dflags);
+  }
   hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
-                     match_a_dev, nonmatch_b_dev, (float*)nullptr, acc, b, hc, wc, n_match, n_non);
+                     match_a_dev, nonmatch_b_dev, dots, acc, b, hc, wc, n_match, n_non, dflags);
+  if (grad)
+    hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
+                       match_a_dev, nonmatch_b_dev, dots, dd_a_nhwc_dev, dd_b_nhwc_dev, acc, b, hc, wc, n_match, n_non, dflags);
   hipLaunchKernelGGL(sparse_loss_means_kernel, dim3(1), dim3(1), 0, st, acc, out2_dev, b, n_match);
   HIPCHK(hipGetLastError());
+  if (dots != nullptr) HIPCHK(hipFreeAsync(dots, st));
   HIPCHK(hipFreeAsync(acc, st));
   return 0;
 }

@@ -43,7 +43,8 @@ class SspPairInputs(C.Structure):
                 ("warped_semantic_dev", C.c_void_p), ("match_a_dev", C.c_void_p), ("match_b_dev", C.c_void_p),
                 ("nonmatch_b_dev", C.c_void_p), ("seed", C.c_uint64), ("lambda_loss", C.c_float),
                 ("lamda_d", C.c_float), ("multi_task", C.c_int), ("train", C.c_int), ("dense_loss", C.c_int),
-                ("dense_lamda_d", C.c_float), ("descriptor_dist", C.c_float), ("cell_homographies_dev", C.c_void_p)]
+                ("dense_lamda_d", C.c_float), ("descriptor_dist", C.c_float), ("cell_homographies_dev", C.c_void_p),
+                ("sparse_method", C.c_int), ("sparse_dist", C.c_int)]
 
 
 class SspHomographyParams(C.Structure):
@@ -168,7 +169,7 @@ def load_library(path=None):
     lib.ssp_op_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
     lib.ssp_op_bn_bwd_strided.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.ssp_op_labels.argtypes = [vp, vp, vp, vp, i, i, i, vp]
-    lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp]
+    lib.ssp_op_sparse_loss.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, C.c_float, C.c_float, vp, vp, vp, vp]
     ep = C.POINTER(SspExportParams)
     lib.ssp_export_workspace_bytes.argtypes = [ep]
     lib.ssp_export_workspace_bytes.restype = C.c_size_t
@@ -475,9 +476,12 @@ class Engine:
         return ma, mb, nm
 
     def pair_step(self, sample, indices=None, seed=0, train=True, lambda_loss=1.0, lamda_d=1.0, multi_task=True,
-                  gaussian=True, dense=None, phase=0, graph=False):
+                  gaussian=True, dense=None, phase=0, graph=False, sparse_method="2d", sparse_dist="cos"):
         """`sample`: dict of device tensors with the reference's keys (Train_model_heatmap_all.py:212-251).
         indices: (match_a, match_b, nonmatch_b) int32 device tensors or None (device sampler with `seed`).
+        sparse_method / sparse_dist: model.sparse_loss.params.method / dist (sparse_loss.py:76-77): "2d" = bilinear grid_sample of the
+        matches (every shipped config), anything else = index_select at the cell; "cos" = hinges on the dot product, anything else =
+        the euclidean forms (pixelwise_contrastive_loss.py:140,185-210,247-258).
         dense: None (sparse descriptor loss) or the model.dense_loss.params dict (dense descriptor loss,
         utils/utils.py:779-893; keys lamda_d (default 250: the shipped `lambda_d` spelling is ignored by the reference
         too) and descriptor_dist (4)); needs an Engine created with dense_loss=True.
@@ -559,7 +563,7 @@ class Engine:
                             _ptr(nm), int(seed) & 0xFFFFFFFFFFFFFFFF, float(lambda_loss), float(lamda_d),
                             int(bool(multi_task)), int(bool(train)), int(dense is not None),
                             float((dense or {}).get("lamda_d", 250.0)), float((dense or {}).get("descriptor_dist", 4.0)),
-                            None)
+                            None, int(sparse_method != "2d"), int(sparse_dist != "cos"))
         hcell = sample.get("cell_homographies")
         if hcell is not None:  # the reference's own cell-space matrices (scaled_homographies): exact match indices
             _need_gpu(hcell, "cell_homographies")
@@ -823,19 +827,27 @@ def op_detector_loss(semi_nchw, labels2d, mask2d, grad=True):
     return float(out.item()), (d[..., :65].permute(0, 3, 1, 2).contiguous() if grad else None)
 
 
-def op_sparse_loss(desc_a_nchw, desc_b_nchw, match_a, match_b, nonmatch_b):
-    """(positive_dist, negative_dist) of the sparse descriptor loss for NCHW descriptor maps and explicit indices."""
+def op_sparse_loss(desc_a_nchw, desc_b_nchw, match_a, match_b, nonmatch_b, method="2d", dist="cos", grad=None):
+    """(positive_dist, negative_dist) of the sparse descriptor loss for NCHW descriptor maps and explicit indices; with
+    grad = (coef_pos, coef_neg) also the gradients of coef_pos * positive_dist + coef_neg * negative_dist wrt both maps (NCHW).
+    method / dist: sparse_loss.params ("2d" / "cos" in every shipped config; see Engine.pair_step)."""
     lib = load_library()
     _need_gpu(desc_a_nchw, "desc")
     B, D, Hc, Wc = desc_a_nchw.shape
     a = desc_a_nchw.permute(0, 2, 3, 1).contiguous()
     b = desc_b_nchw.permute(0, 2, 3, 1).contiguous()
     out = torch.zeros(2, dtype=torch.float32, device=a.device)
+    da = torch.full_like(a, float("nan")) if grad is not None else None   # (the operator overwrites them)
+    db = torch.full_like(b, float("nan")) if grad is not None else None
+    cp, cn = grad if grad is not None else (0.0, 0.0)
     with torch.cuda.device(a.device):
         _check(lib.ssp_op_sparse_loss(_ptr(a), _ptr(b), _ptr(match_a), _ptr(match_b), _ptr(nonmatch_b), B, Hc, Wc,
-                                      match_a.shape[1], nonmatch_b.shape[1] // match_a.shape[1], _ptr(out), _stream()))
+                                      match_a.shape[1], nonmatch_b.shape[1] // match_a.shape[1], int(method != "2d"), int(dist != "cos"),
+                                      float(cp), float(cn), _ptr(da), _ptr(db), _ptr(out), _stream()))
     torch.cuda.synchronize()
-    return float(out[0]), float(out[1])
+    if grad is None:
+        return float(out[0]), float(out[1])
+    return float(out[0]), float(out[1]), da.permute(0, 3, 1, 2).contiguous(), db.permute(0, 3, 1, 2).contiguous()
 
 
 def op_dense_loss(desc_a_nchw, desc_b_nchw, homographies, mask_valid, lamda_d=250.0, descriptor_dist=4.0, grad=None):

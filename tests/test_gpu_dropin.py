@@ -60,8 +60,11 @@ def test_module_forward_backward_autograd(arch):
     assert oe["semi"].shape == (2, 65, 8, 12)
 
 
-@pytest.mark.parametrize("arch,semantic", [("SuperPointNet_gauss2", False), ("SuperPointNet_gauss2_ssmall", True)])
-def test_trainer_plugin_two_steps_vs_oracle(arch, semantic, tmp_path):
+@pytest.mark.parametrize("arch,semantic,method,dist", [
+    ("SuperPointNet_gauss2", False, "2d", "cos"), ("SuperPointNet_gauss2_ssmall", True, "2d", "cos"),
+    ("SuperPointNet_gauss2", False, "1d", "euclidean"),   # the other values descriptor_loss_sparse accepts (sparse_loss.py:76-77)
+    ("SuperPointNet_gauss2", False, None, None)])          # keys absent from the config: the function's own defaults ("1d", "cos")
+def test_trainer_plugin_two_steps_vs_oracle(arch, semantic, method, dist, tmp_path):
     """Train_model_heatmap_all.train_val_sample with the reference-faithful host sampler and the same numpy/torch
     seeds as the oracle trainer: scalar_dict (incl. post-step eta) after two optimizer steps."""
     from semantic_superpoint_amd.Train_model_heatmap_all import Train_model_heatmap_all as T
@@ -71,9 +74,10 @@ def test_trainer_plugin_two_steps_vs_oracle(arch, semantic, tmp_path):
                      "lambda_loss": 1, "multi_task_loss": True, "dense_loss": {"enable": False},
                      "detector_loss": {"loss_type": "softmax"},
                      "sparse_loss": {"enable": True, "params": {"num_matching_attempts": 1000,
-                                                                "num_masked_non_matches_per_match": 100, "lamda_d": 1,
-                                                                "dist": "cos", "method": "2d"}}},
+                                                                "num_masked_non_matches_per_match": 100, "lamda_d": 1}}},
            "validation_interval": 1000, "retrain": True, "reset_iter": True, "ssp_sampler": "reference"}
+    if method is not None:
+        cfg["model"]["sparse_loss"]["params"].update({"dist": dist, "method": method})
 
     class W_:
         def __init__(self):
@@ -89,7 +93,7 @@ def test_trainer_plugin_two_steps_vs_oracle(arch, semantic, tmp_path):
     agent.net.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in sd.items()})
     agent.dataParallel()
     sample = C.make_synthetic_pair(B, H, W, seed=8, semantic=semantic, kp_prob=0.01)
-    tr = C.Trainer(arch, sd, lr=1e-3)
+    tr = C.Trainer(arch, sd, lr=1e-3, sparse_method=method or "1d", sparse_dist=dist or "cos")
     for it in range(2):
         np.random.seed(10 + it); torch.manual_seed(20 + it)
         tr.train_val_sample(sample, n_iter=it, train=True)

@@ -330,6 +330,33 @@ def test_sparse_loss_golden_full():
     assert abs(pos - float(g["pos"])) < 1e-4 and abs(neg - float(g["neg"])) < 1e-4
 
 
+@pytest.mark.parametrize("tag", ["small", "mid"])
+@pytest.mark.parametrize("method,dist", [("2d", "cos"), ("1d", "cos"), ("2d", "euclidean"), ("1d", "euclidean")])
+def test_sparse_loss_variants_golden(method, dist, tag):
+    """G14 (and G4 for the shipped pair of values): loss terms AND gradients of the sparse descriptor loss kernels against the REAL
+    reference for every (method, dist) descriptor_loss_sparse accepts (sparse_loss.py:76-77), through ssp_op_sparse_loss."""
+    from semantic_superpoint_amd import lib as L
+    if (method, dist) == ("2d", "cos"):
+        if tag != "small":
+            pytest.skip("G4 stores the full gradients at the small size only")
+        g = G.load("g4_sparse_loss_small.npz")
+    else:
+        g = G.load("g14_sparse_loss_%s_%s_%s.npz" % (method, dist, tag))
+    d, dw = torch.from_numpy(g["desc"]), torch.from_numpy(g["desc_w"])
+    B, _, Hc, Wc = d.shape
+    idx = G.indices_from(g, "", B)
+    w = g["grad_weights"]   # d (w0 loss + w1 pos + w2 neg), loss = lamda_d pos + neg, lamda_d = 1
+    pos, neg, ga, gb = L.op_sparse_loss(d.to(_dev()), dw.to(_dev()), *_idx_to_dev(idx, Wc), method=method, dist=dist,
+                                        grad=(float(w[0] + w[1]), float(w[0] + w[2])))
+    assert abs(pos - float(g["pos"])) < 2e-5 * max(1.0, abs(float(g["pos"])))
+    assert abs(neg - float(g["neg"])) < 2e-5 * max(1.0, abs(float(g["neg"])))
+    for mine, ref in ((ga, g["ddesc"]), (gb, g["ddesc_w"])):
+        ref = torch.from_numpy(ref)
+        assert (mine.cpu() - ref).abs().max() < 1e-7 + 2e-5 * float(ref.abs().max())
+    p2, n2 = L.op_sparse_loss(d.to(_dev()), dw.to(_dev()), *_idx_to_dev(idx, Wc), method=method, dist=dist)   # forward only
+    assert abs(p2 - pos) < 1e-6 and abs(n2 - neg) < 1e-6
+
+
 @pytest.mark.parametrize("B,H,W", [(4, 240, 320), (2, 480, 640)])
 def test_device_sampler_distribution(B, H, W):
     """ssp_sample_indices: every sampled match is a valid correspondence of the oracle, matches are distinct

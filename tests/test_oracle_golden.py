@@ -90,6 +90,24 @@ def test_g4_sparse_loss(tag):
         assert abs(float(gb.norm()) - float(g["ddesc_w_norm"])) < 1e-4 * float(g["ddesc_w_norm"])
 
 
+@pytest.mark.parametrize("tag", ["small", "mid"])
+@pytest.mark.parametrize("method,dist", [("1d", "cos"), ("2d", "euclidean"), ("1d", "euclidean")])
+def test_g14_sparse_loss_variants(method, dist, tag):
+    """descriptor_loss_sparse's other parameter values (method "1d", dist "euclidean": sparse_loss.py:76-77) - the oracle against the
+    reference's loss terms and gradients (oracle/make_goldens.py: g14)."""
+    g = G.load("g14_sparse_loss_%s_%s_%s.npz" % (method, dist, tag))
+    B = g["desc"].shape[0]
+    idx = G.indices_from(g, "", B)
+    da, db = t(g["desc"]).requires_grad_(True), t(g["desc_w"]).requires_grad_(True)
+    loss, pos, neg, _ = C.batch_descriptor_loss_sparse(da, db, t(g["H"]), idx, 1.0, int(g["n_match"]), int(g["n_non"]), dist=dist,
+                                                       method=method)
+    for a, k in ((loss, "loss"), (pos, "pos"), (neg, "neg")):
+        assert abs(float(a) - float(g[k])) < 2e-6 * max(1, abs(float(g[k]))), k
+    w = g["grad_weights"]
+    ga, gb = torch.autograd.grad(float(w[0]) * loss + float(w[1]) * pos + float(w[2]) * neg, (da, db))
+    assert (ga - t(g["ddesc"])).abs().max() < 1e-6 and (gb - t(g["ddesc_w"])).abs().max() < 1e-6
+
+
 def test_g4_sampler_reproduces_reference_indices():
     """Same numpy/torch RNG streams => the oracle's sampler yields the reference's indices bit-exactly."""
     g = G.load("g4_sparse_loss_small.npz")
