@@ -244,7 +244,8 @@ __device__ __forceinline__ int desc_wave_of_block(int B, int n_match, int& img) 
 }
 // Channel mapping: lane l holds channels l, l+64, l+128, l+192, so every load AND every atomic instruction of a wave
 // covers 256 contiguous bytes (with 4 consecutive channels per lane the scatter hit each cache line 4 times).
-template <bool BWD>
+// EUC (compile time: the shipped form keeps its instruction stream): dist "euclidean"; flags & DESC_METHOD_1D (run time): method "1d"
+template <bool BWD, bool EUC = false>
 __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict__ desc_a, const float* __restrict__ desc_b,
                                                          const int32_t* __restrict__ match_a,
                                                          const int32_t* __restrict__ match_b, float* __restrict__ dd_a,
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
   if (w < 0) return;
-  const bool m1d = (flags & DESC_METHOD_1D) != 0, euc = (flags & DESC_EUCLIDEAN) != 0;   // wave-uniform
+  const bool m1d = (flags & DESC_METHOD_1D) != 0;   // wave-uniform
+  constexpr bool euc = EUC;
   const size_t base = (size_t)img * Hc * Wc * 256 + lane;
   const Bilin ba = m1d ? bilin_cell(match_a[w]) : bilin_setup(match_a[w], Hc, Wc);
   const Bilin bb = m1d ? bilin_cell(match_b[w]) : bilin_setup(match_b[w], Hc, Wc);
@@ -308,8 +310,10 @@ __global__ __launch_bounds__(256) void desc_match_kernel(const float* __restrict
 }
 
 // non-match term, forward: one wave per match k; 4 non-matches per iteration (16 lanes each, 16 channels per lane).
+// EUC: dist "euclidean" - `dots` holds ||a - b|| and the term is (max(0, d - 0.2))^2 (pixelwise_contrastive_loss.py:249-258).
 // a-side = integer-cell gather of image a at match_a[k] (sparse_loss.py:55-58,245), b-side = nonmatch_b.
 // The dot products are kept (12.8 MB at B = 32) so that the backward only touches the hard negatives.
+template <bool EUC = false>
 __global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __restrict__ desc_a,
                                                                 const float* __restrict__ desc_b,
                                                                 const int32_t* __restrict__ match_a,
@@ -320,7 +324,8 @@ __global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __r
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs
   const int lane = threadIdx.x & 63;
   if (w < 0) return;
-  const bool euc = (flags & DESC_EUCLIDEAN) != 0;  // wave-uniform: `dots` then holds ||a - b|| and the term is (max(0, d - 0.2))^2
+  constexpr bool euc = EUC;
+  (void)flags;
   const int grp = lane >> 4, l16 = lane & 15;
   const size_t ibase = (size_t)img * Hc * Wc * 256;
   const float* ap = desc_a + ibase + (size_t)match_a[w] * 256 + l16 * 4;
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(256) void desc_nonmatch_fwd_kernel(const float* __r
 
 // non-match term, backward: one wave per match k reads its stored dot products and walks only the hard negatives
 // (dot > 0.2).  Lane l holds channels l, l+64, l+128, l+192: loads and atomics are 256 contiguous bytes per wave.
+template <bool EUC = false>
 __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __restrict__ desc_a,
                                                                 const float* __restrict__ desc_b,
                                                                 const int32_t* __restrict__ match_a,
@@ -375,7 +381,8 @@ __global__ __launch_bounds__(256) void desc_nonmatch_bwd_kernel(const float* __r
                                                                 const float* __restrict__ dots, float* __restrict__ dd_a,
                                                                 float* __restrict__ dd_b, const StepAccum* __restrict__ acc,
                                                                 int B, int Hc, int Wc, int n_match, int n_non, int flags) {
-  const bool euc = (flags & DESC_EUCLIDEAN) != 0;  // d term / d a = 2 (d - 0.2) (a - b) / d instead of b
+  constexpr bool euc = EUC;  // d term / d a = 2 (d - 0.2) (a - b) / d instead of b
+  (void)flags;
   const DetTarget t_a = det_resolve(dd_a), t_b = det_resolve(dd_b);   // (deterministic mode: fixed-point shadows)
   int img;
   const int w = desc_wave_of_block(B, n_match, img);  // one wave per match, images pinned to XCDs

@@ -2718,22 +2718,33 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   } else if (use_desc) {
     Slot &A = h->slot[0], &Bs = h->slot[1];
     const int dflags = (in->sparse_method != 0 ? DESC_METHOD_1D : 0) | (in->sparse_dist != 0 ? DESC_EUCLIDEAN : 0);
+    const bool euc = (dflags & DESC_EUCLIDEAN) != 0;
+    const dim3 dgrid(desc_grid(B, h->cfg.n_match));
+#define SSP_DESC(KERNEL, ...)                                                                 \
+    {                                                                                         \
+      if (euc) hipLaunchKernelGGL((KERNEL<true>), dgrid, dim3(256), 0, sd, __VA_ARGS__);      \
+      else hipLaunchKernelGGL((KERNEL<false>), dgrid, dim3(256), 0, sd, __VA_ARGS__);         \
+    }
+#define SSP_DESC_MATCH(BWD, ...)                                                                        \
+    {                                                                                                   \
+      if (euc) hipLaunchKernelGGL((desc_match_kernel<BWD, true>), dgrid, dim3(256), 0, sd, __VA_ARGS__); \
+      else hipLaunchKernelGGL((desc_match_kernel<BWD, false>), dgrid, dim3(256), 0, sd, __VA_ARGS__);   \
+    }
     if (!in->train)   // (training: desc_match_kernel<true> below accumulates the loss sum as well)
-      hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
-                         in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match, dflags);
-    hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
-                       in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum, B, Hc, Wc, h->cfg.n_match,
-                       h->cfg.n_non, dflags);
+      SSP_DESC_MATCH(false, A.desc, Bs.desc, in->match_a_dev, in->match_b_dev, (float*)nullptr, (float*)nullptr, h->accum, B, Hc, Wc,
+                     h->cfg.n_match, dflags)
+    SSP_DESC(desc_nonmatch_fwd_kernel, A.desc, Bs.desc, in->match_a_dev, in->nonmatch_b_dev, in->train ? h->dots : (float*)nullptr, h->accum,
+             B, Hc, Wc, h->cfg.n_match, h->cfg.n_non, dflags)
     if (in->train) {
       if (!early) {
         CHK(dev_zero(A.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
         CHK(dev_zero(Bs.ddesc, (size_t)ncells * 256 * sizeof(float), sd));
       }
-      hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
-                         in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match, dflags);
-      hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(B, h->cfg.n_match)), dim3(256), 0, sd, A.desc, Bs.desc, in->match_a_dev,
-                         in->nonmatch_b_dev, h->dots, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match,
-                         h->cfg.n_non, dflags);
+      SSP_DESC_MATCH(true, A.desc, Bs.desc, in->match_a_dev, in->match_b_dev, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc, h->cfg.n_match, dflags)
+      SSP_DESC(desc_nonmatch_bwd_kernel, A.desc, Bs.desc, in->match_a_dev, in->nonmatch_b_dev, h->dots, A.ddesc, Bs.ddesc, h->accum, B, Hc, Wc,
+               h->cfg.n_match, h->cfg.n_non, dflags)
+#undef SSP_DESC
+#undef SSP_DESC_MATCH
       for (int v = 0; v < 2; ++v) {
         Slot& S = h->slot[v];
         CHK(det_fold(S.ddesc, sd));   // (deterministic mode) the scattered gradient: fixed-point shadow -> tensor
@@ -3402,21 +3413,34 @@ int ssp_op_sparse_loss(const float* desc_a_nhwc_dev, const float* desc_b_nhwc_de
   HIPCHK(hipMemsetAsync(acc, 0, sizeof(StepAccum), st));
   hipLaunchKernelGGL(sparse_op_prep_kernel, dim3(1), dim3(1), 0, st, acc, coef_pos, coef_neg);
   const size_t ncell_floats = (size_t)b * hc * wc * 256;
+  const bool euc = (dflags & DESC_EUCLIDEAN) != 0;
+  const dim3 dgrid(desc_grid(b, n_match));
   if (grad) {
     HIPCHK(hipMallocAsync((void**)&dots, (size_t)b * n_match * n_non * sizeof(float), st));
     CHK(dev_zero(dd_a_nhwc_dev, ncell_floats * sizeof(float), st));
     CHK(dev_zero(dd_b_nhwc_dev, ncell_floats * sizeof(float), st));
-    hipLaunchKernelGGL((desc_match_kernel<true>), dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
-                       match_a_dev, match_b_dev, dd_a_nhwc_dev, dd_b_nhwc_dev, acc, b, hc, wc, n_match, dflags);
-  } else {
-    hipLaunchKernelGGL((desc_match_kernel<false>), dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
-                       match_a_dev, match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match, dflags);
   }
-  hipLaunchKernelGGL(desc_nonmatch_fwd_kernel, dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
-                     match_a_dev, nonmatch_b_dev, dots, acc, b, hc, wc, n_match, n_non, dflags);
+#define SSP_OPD(KERNEL, ...)                                                                  \
+  {                                                                                           \
+    if (euc) hipLaunchKernelGGL((KERNEL<true>), dgrid, dim3(256), 0, st, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((KERNEL<false>), dgrid, dim3(256), 0, st, __VA_ARGS__);           \
+  }
+  if (grad) {
+    if (euc) hipLaunchKernelGGL((desc_match_kernel<true, true>), dgrid, dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev, match_a_dev,
+                                match_b_dev, dd_a_nhwc_dev, dd_b_nhwc_dev, acc, b, hc, wc, n_match, dflags);
+    else hipLaunchKernelGGL((desc_match_kernel<true, false>), dgrid, dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev, match_a_dev,
+                            match_b_dev, dd_a_nhwc_dev, dd_b_nhwc_dev, acc, b, hc, wc, n_match, dflags);
+  } else {
+    if (euc) hipLaunchKernelGGL((desc_match_kernel<false, true>), dgrid, dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev, match_a_dev,
+                                match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match, dflags);
+    else hipLaunchKernelGGL((desc_match_kernel<false, false>), dgrid, dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev, match_a_dev,
+                            match_b_dev, (float*)nullptr, (float*)nullptr, acc, b, hc, wc, n_match, dflags);
+  }
+  SSP_OPD(desc_nonmatch_fwd_kernel, desc_a_nhwc_dev, desc_b_nhwc_dev, match_a_dev, nonmatch_b_dev, dots, acc, b, hc, wc, n_match, n_non, dflags)
   if (grad)
-    hipLaunchKernelGGL(desc_nonmatch_bwd_kernel, dim3(desc_grid(b, n_match)), dim3(256), 0, st, desc_a_nhwc_dev, desc_b_nhwc_dev,
-                       match_a_dev, nonmatch_b_dev, dots, dd_a_nhwc_dev, dd_b_nhwc_dev, acc, b, hc, wc, n_match, n_non, dflags);
+    SSP_OPD(desc_nonmatch_bwd_kernel, desc_a_nhwc_dev, desc_b_nhwc_dev, match_a_dev, nonmatch_b_dev, dots, dd_a_nhwc_dev, dd_b_nhwc_dev, acc, b,
+            hc, wc, n_match, n_non, dflags)
+#undef SSP_OPD
   hipLaunchKernelGGL(sparse_loss_means_kernel, dim3(1), dim3(1), 0, st, acc, out2_dev, b, n_match);
   HIPCHK(hipGetLastError());
   if (dots != nullptr) HIPCHK(hipFreeAsync(dots, st));
