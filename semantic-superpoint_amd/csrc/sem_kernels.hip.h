@@ -306,15 +306,16 @@ __global__ __launch_bounds__(256) void sem_ce_kernel(const float* __restrict__ s
 //   * in a lane, l'(y) = T0 + (2 y + 1) / 16 (T1 - T0) is LINEAR in y (T_a = the column interpolation of corner row a), so the
 //     eight exponentials are two geometric progressions: e(0) = exp2(l'(0)), e(y + 1) = e(y) r and e(7) = exp2(l'(7)),
 //     e(y - 1) = e(y) / r with r = exp2((T1 - T0) / 8) - 4 v_exp_f32 and 6 multiplies for 8 values.  Both ends are anchored
-//     (the larger end is one of them, l' <= 0, and a progression runs three steps): a value that underflows on the way was
-//     below 2^-72 of the largest term anyway, and the exponent of r is clamped to +-126 so that 0 * inf cannot appear;
-//   * the exponentials stay in registers (144 per lane) for the gradient: sum over y in the lane (2 fma per element), over the
-//     two columns with the x weights, over the four x lanes of a quad on the DPP path (9 instructions per 16 classes), one
-//     atomic per lane and block (9 per lane and tile; 12 above);
+//     (the larger end is one of them, l' <= 0, and a progression runs three steps; the two progressions advance as ONE packed
+//     multiply by (r, 1 / r)); the exponent of r is clamped to +-126 so that 0 * inf cannot appear, underflow: SEMX_K below;
+//   * the ANCHORS AND RATIOS stay in registers (4 per column and class block, 72 per lane) for the gradient, whose sweep runs the
+//     progressions again (3 packed multiplies) under 2 packed fma per row pair: sum over y in the lane, over the two columns with
+//     the x weights, over the four x lanes of a quad on the DPP path (9 instructions per 16 classes); lane xl keeps corner xl;
 //   * sum over the classes: 16 partial sums per lane (its 8 rows x 2 columns), transposed through LDS - lane (xl, cl) receives
-//     the total of pixel j = cl (row j & 7, column xl + 4 (j >> 3)) and plays that pixel for the label logit, the NLL, g / sum
-//     and the -g [c == label] histogram; g / sum goes back through LDS (16 values per lane).
-// ~100 plain + 8 transcendental instructions per 16 classes and lane = 7-8 ns per element instead of 27.
+//     the total of pixel slot j = cl and plays that pixel for the label logit, the NLL, g / sum and the -g [c == label]
+//     histogram; g / sum goes back through LDS (16 values per lane);
+//   * atomics: see the launch geometry in front of the kernel (5 cell vectors per step of four tiles instead of 16).
+// ~90 vector + 8 transcendental instructions per 16 classes and lane = 7-8 ns per element instead of 27.
 // Numerics: same bound m, same base-2 domain; three chained multiplies add <= 2 ulp to an exponential.
 #ifndef SEMX_WGS
 #define SEMX_WGS 2  // workgroups per CU = waves per SIMD the register allocation aims at
