@@ -1376,6 +1376,14 @@ int ssp_clock_probe(float ms, double* mhz_out, void* stream_) {
   return 0;
 }
 
+// perf-debug (SSP_DBG_IDLE_US=n): one wave that sleeps for n microseconds of the constant 100 MHz counter - an idle stretch in front of
+// the loss phase of the pair step, to see how much of it the power / clock management gives back to the kernels around it
+// (PERF_LOG round 6 section 9).
+__global__ void idle_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+
 int ssp_set_deterministic(int on) {
   g_det_mode = on ? 1 : 0;
   return det_upload();   // (handles bound before the switch keep their plain fp32 scatters until they are bound again)
@@ -2686,6 +2694,10 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   }
   if (early) HIPCHK(hipStreamWaitEvent(st, h->ev_early_join, 0));
   else CHK(label_kernels(st));
+  {
+    static const int idle_us = getenv("SSP_DBG_IDLE_US") ? atoi(getenv("SSP_DBG_IDLE_US")) : 0;
+    if (idle_us > 0) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)idle_us * 100ull);
+  }
   // ---- descriptor loss on the side stream (fork) ----
   static const int loss_stream_env = getenv("SSP_LOSS_STREAM") ? atoi(getenv("SSP_LOSS_STREAM")) : 1;  // (perf-debug: 0 = one stream)
   hipStream_t sd = st;
