@@ -811,10 +811,22 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
 
 // desc: raw YDb [cells][cs] -> normalised desc [cells][256] and 1/norm [cells]
 // (models/SuperPointNet_gauss2.py:64-65, no epsilon).
-__global__ __launch_bounds__(256) void desc_normalize_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, float* __restrict__ desc,
-                                                             float* __restrict__ inv_norm, float* __restrict__ zero_out, int ncells,
-                                                             int cs, int co) {
+// blockIdx.y = view of the pair (one launch for both: a small launch costs ~13 us of the step whatever it does, PERF_LOG round 6
+// section 4); the second pointer set may be omitted (gridDim.y == 1).
+__global__ __launch_bounds__(256) void desc_normalize_kernel(const float* __restrict__ y0, const float* __restrict__ scale0,
+                                                             const float* __restrict__ shift0, float* __restrict__ desc0,
+                                                             float* __restrict__ inv_norm0, float* __restrict__ zero_out0, int ncells,
+                                                             int cs, int co, const float* __restrict__ y1 = nullptr,
+                                                             const float* __restrict__ scale1 = nullptr,
+                                                             const float* __restrict__ shift1 = nullptr, float* __restrict__ desc1 = nullptr,
+                                                             float* __restrict__ inv_norm1 = nullptr, float* __restrict__ zero_out1 = nullptr) {
+  const bool v1 = blockIdx.y != 0;
+  const float* __restrict__ y = v1 ? y1 : y0;
+  const float* __restrict__ scale = v1 ? scale1 : scale0;
+  const float* __restrict__ shift = v1 ? shift1 : shift0;
+  float* __restrict__ desc = v1 ? desc1 : desc0;
+  float* __restrict__ inv_norm = v1 ? inv_norm1 : inv_norm0;
+  float* __restrict__ zero_out = v1 ? zero_out1 : zero_out0;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= ncells) return;
@@ -833,9 +845,16 @@ __global__ __launch_bounds__(256) void desc_normalize_kernel(const float* __rest
 }
 
 // backward of the L2 normalisation: d_raw = (d - desc * <desc, d>) * inv_norm   (in place on d)
-__global__ __launch_bounds__(256) void desc_normalize_bwd_kernel(const float* __restrict__ desc,
-                                                                 const float* __restrict__ inv_norm,
-                                                                 float* __restrict__ d, int ncells) {
+__global__ __launch_bounds__(256) void desc_normalize_bwd_kernel(const float* __restrict__ desc0,
+                                                                 const float* __restrict__ inv_norm0,
+                                                                 float* __restrict__ d0, int ncells,
+                                                                 const float* __restrict__ desc1 = nullptr,
+                                                                 const float* __restrict__ inv_norm1 = nullptr,
+                                                                 float* __restrict__ d1 = nullptr) {   // (blockIdx.y = view)
+  const bool v1 = blockIdx.y != 0;
+  const float* __restrict__ desc = v1 ? desc1 : desc0;
+  const float* __restrict__ inv_norm = v1 ? inv_norm1 : inv_norm0;
+  float* __restrict__ d = v1 ? d1 : d0;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= ncells) return;

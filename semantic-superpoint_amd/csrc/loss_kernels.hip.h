@@ -89,8 +89,14 @@ __device__ __forceinline__ unsigned nnz_of_image(const StepAccum* acc, int img) 
 }
 
 // ---- cell masks: one wave per cell; lane = dy*8+dx --------------------------------------------
-__global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict__ mask2d, float* __restrict__ cellmask,
-                                                        double* __restrict__ mask_cnt, int B, int H, int W) {
+// blockIdx.y = view of the pair (second pointer set optional)
+__global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict__ mask2d0, float* __restrict__ cellmask0,
+                                                        double* __restrict__ mask_cnt0, int B, int H, int W,
+                                                        const float* __restrict__ mask2d1 = nullptr, float* __restrict__ cellmask1 = nullptr,
+                                                        double* __restrict__ mask_cnt1 = nullptr) {
+  const float* __restrict__ mask2d = blockIdx.y ? mask2d1 : mask2d0;
+  float* __restrict__ cellmask = blockIdx.y ? cellmask1 : cellmask0;
+  double* __restrict__ mask_cnt = blockIdx.y ? mask_cnt1 : mask_cnt0;
   __shared__ float red[4];
   const int Hc = H / 8, Wc = W / 8;
   const int lane = threadIdx.x & 63;
@@ -128,12 +134,26 @@ __global__ __launch_bounds__(256) void labels2dto3d_kernel(const float* __restri
 // ---- detector loss fwd+bwd: one wave per cell --------------------------------------------------
 // ypb: raw convPb output NHWC [cells][cs] (65 channels), BN affine applied here.
 // dsemi (may be nullptr): d total / d semi, NHWC [cells][cs] (pads written 0).
-__global__ __launch_bounds__(256) void detector_loss_kernel(const float* __restrict__ ypb, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift,
-                                                            const float* __restrict__ labels2d,
-                                                            const float* __restrict__ cellmask, float* __restrict__ dsemi,
-                                                            StepAccum* __restrict__ acc, int view, int B, int H, int W,
-                                                            int cs) {
+// blockIdx.y != 0: the second pointer set, view + 1 (both views of the pair in one launch)
+__global__ __launch_bounds__(256) void detector_loss_kernel(const float* __restrict__ ypb0, const float* __restrict__ scale0,
+                                                            const float* __restrict__ shift0,
+                                                            const float* __restrict__ labels2d0,
+                                                            const float* __restrict__ cellmask0, float* __restrict__ dsemi0,
+                                                            StepAccum* __restrict__ acc, int view0, int B, int H, int W,
+                                                            int cs, const float* __restrict__ ypb1 = nullptr,
+                                                            const float* __restrict__ scale1 = nullptr,
+                                                            const float* __restrict__ shift1 = nullptr,
+                                                            const float* __restrict__ labels2d1 = nullptr,
+                                                            const float* __restrict__ cellmask1 = nullptr,
+                                                            float* __restrict__ dsemi1 = nullptr) {
+  const bool v1 = blockIdx.y != 0;
+  const float* __restrict__ ypb = v1 ? ypb1 : ypb0;
+  const float* __restrict__ scale = v1 ? scale1 : scale0;
+  const float* __restrict__ shift = v1 ? shift1 : shift0;
+  const float* __restrict__ labels2d = v1 ? labels2d1 : labels2d0;
+  const float* __restrict__ cellmask = v1 ? cellmask1 : cellmask0;
+  float* __restrict__ dsemi = v1 ? dsemi1 : dsemi0;
+  const int view = view0 + (v1 ? 1 : 0);
   __shared__ float red[4];
   const int Hc = H / 8, Wc = W / 8;
   const int lane = threadIdx.x & 63;

@@ -391,9 +391,20 @@ __host__ __device__ inline SemXcGeom sem_xc_geom(int B, int Hc, int Wc, int targ
 
 // NB: 16-class blocks per lane (3, 6 or 9: the smallest that holds C; class slots past C run along as zeros - no branch per block)
 template <int MODE, int NB>
-__global__ __launch_bounds__(256, SEMX_WGS) void sem_ce_xc_kernel(const float* __restrict__ sout, const int64_t* __restrict__ labels,
-                                                           float* __restrict__ dsout, StepAccum* __restrict__ acc, int view,
-                                                           int B, int Hc, int Wc, int C, int cs, SemXcGeom geom) {
+__global__ __launch_bounds__(256, SEMX_WGS) void sem_ce_xc_kernel(const float* __restrict__ sout0, const int64_t* __restrict__ labels0,
+                                                           float* __restrict__ dsout0, StepAccum* __restrict__ acc, int view0,
+                                                           int B, int Hc, int Wc, int C, int cs, SemXcGeom geom,
+                                                           const float* __restrict__ sout1 = nullptr,
+                                                           const int64_t* __restrict__ labels1 = nullptr,
+                                                           float* __restrict__ dsout1 = nullptr) {
+  // both views of the pair in one launch: the workgroups past B x row groups x column ranges belong to the second pointer set, view0 + 1
+  const int wg_per_view = B * geom.row_groups * geom.x_splits;
+  const bool second = (int)blockIdx.x >= wg_per_view;
+  const float* __restrict__ sout = second ? sout1 : sout0;
+  const int64_t* __restrict__ labels = second ? labels1 : labels0;
+  float* __restrict__ dsout = second ? dsout1 : dsout0;
+  const int view = view0 + (second ? 1 : 0);
+  const int wg = (int)blockIdx.x - (second ? wg_per_view : 0);
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   constexpr bool FWD = (MODE & 1) != 0, BWD = (MODE & 2) != 0;
   __shared__ float red[4];
@@ -410,8 +421,8 @@ __global__ __launch_bounds__(256, SEMX_WGS) void sem_ce_xc_kernel(const float* _
   const int TX = Wc + 1, TY = Hc + 1;
   const int xl = lane & 3, cl = lane >> 2;
   // this workgroup: image n, tile rows 4 rg .. 4 rg + 3 (one per wave), tile columns x_begin .. x_end
-  const int xs = blockIdx.x % geom.x_splits, rg = (blockIdx.x / geom.x_splits) % geom.row_groups;
-  const int n = blockIdx.x / (geom.x_splits * geom.row_groups);
+  const int xs = wg % geom.x_splits, rg = (wg / geom.x_splits) % geom.row_groups;
+  const int n = wg / (geom.x_splits * geom.row_groups);
   const int tyi = rg * 4 + wave_in_blk;  // tile row index 0 .. TY - 1 (a wave past the last row only keeps the barriers company)
   const bool row_ok = tyi < TY;
   const int ty = tyi - 1;
@@ -734,8 +745,9 @@ __global__ void sem_upsample_bwd_nchw_kernel(const float* __restrict__ dsem, flo
 // block = 256 threads = 64 float4 column quads x 4 row lanes (rows are read as contiguous float4 runs); a block owns
 // COLSUM_ROWS rows; the row lanes meet in LDS, one atomic per column and block.  cs % 4 == 0, cs <= 256.
 constexpr int COLSUM_ROWS = 512;
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m, float* __restrict__ out, int rows, int C,
-                                                     int cs) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m0, float* __restrict__ out, int rows, int C,
+                                                     int cs, const float* __restrict__ m1 = nullptr) {   // (blockIdx.y: matrix 0 / 1)
+  const float* __restrict__ m = blockIdx.y ? m1 : m0;
   __shared__ float4 red[4][64];
   const int rl = threadIdx.x >> 6;
   const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(r0 + COLSUM_ROWS, rows);

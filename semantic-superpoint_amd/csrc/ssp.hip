@@ -437,7 +437,8 @@ struct ProfScope {
 // segmentation-gradient buffers kept their previous contents and the atomically accumulated gradients blew up), while
 // kernel nodes replay reliably.  Grid-stride 16-byte stores: the few-hundred-KB buffers of the step are latency-bound.
 // ------------------------------------------------------------------------------------------------
-__global__ void zero_fill_kernel(uint32_t* __restrict__ p, size_t nwords) {
+__global__ void zero_fill_kernel(uint32_t* __restrict__ p0, size_t nwords, uint32_t* __restrict__ p1 = nullptr) {  // (blockIdx.y: range 0 / 1)
+  uint32_t* __restrict__ p = blockIdx.y ? p1 : p0;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
   if ((reinterpret_cast<size_t>(p) & 15) == 0) {
     uint4* q = reinterpret_cast<uint4*>(p);
@@ -454,6 +455,17 @@ static int dev_zero(void* p, size_t bytes, hipStream_t st) {
   const size_t nwords = bytes / 4;
   const int nb = (int)std::min<size_t>((nwords / 4 + 255) / 256 + 1, 2048);
   hipLaunchKernelGGL(zero_fill_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), nwords);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// two ranges of the same size in one launch (the statistics of the two views)
+static int dev_zero2(void* p0, void* p1, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if (p1 == nullptr || p1 == p0) return dev_zero(p0, bytes, st);
+  if (bytes % 4 != 0 || ((reinterpret_cast<size_t>(p0) | reinterpret_cast<size_t>(p1)) & 3) != 0) return fail(-1, "dev_zero2: unaligned range");
+  const size_t nwords = bytes / 4;
+  const int nb = (int)std::min<size_t>((nwords / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(nb, 2), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p0), nwords, reinterpret_cast<uint32_t*>(p1));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1829,9 +1841,10 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     Slot& S = *SS.s[k];
     S.N = N; S.H = H; S.W = W; S.x = xs[k];
     for (int l = 0; l < 8; ++l) S.act_valid[l] = false;   // (rewritten by this forward where a layer uses it)
-    CHK(dev_zero(S.stats_region, S.stats_bytes, st));
     S.bsums_dirty = false;
   }
+  if (SS.n == 2 && SS.s[0]->stats_bytes == SS.s[1]->stats_bytes) CHK(dev_zero2(SS.s[0]->stats_region, SS.s[1]->stats_region, SS.s[0]->stats_bytes, st));
+  else for (int k = 0; k < SS.n; ++k) CHK(dev_zero(SS.s[k]->stats_region, SS.s[k]->stats_bytes, st));
   // The Winograd weight images (a ~95 us latency-bound launch over 2.6 M floats) are packed on the side stream beside the
   // HBM-bound first-layer convolution, which needs none of them; layer 1 waits for the join.
   static const int pack_stream_env = getenv("SSP_PACK_STREAM") ? atoi(getenv("SSP_PACK_STREAM")) : 1;  // (perf-debug: 0 = in line)
@@ -1904,10 +1917,11 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     CHK(pointwise(pw2, 2));
   }
   const int ncells = N * Hc * Wc;
-  for (int k = 0; k < SS.n; ++k) {
-    Slot& S = *SS.s[k];
-    hipLaunchKernelGGL(desc_normalize_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, st, S.Y[L_DB], S.bn[L_DB].scale,
-                       S.bn[L_DB].shift, S.desc, S.inv_norm, zero_ddesc ? S.ddesc : (float*)nullptr, ncells, S.y_cs[L_DB], S.y_co[L_DB]);
+  {
+    Slot &S = *SS.s[0], &T = *SS.s[SS.n - 1];   // both views in one launch (blockIdx.y)
+    hipLaunchKernelGGL(desc_normalize_kernel, dim3(cdiv(ncells, 4), SS.n), dim3(256), 0, st, S.Y[L_DB], S.bn[L_DB].scale,
+                       S.bn[L_DB].shift, S.desc, S.inv_norm, zero_ddesc ? S.ddesc : (float*)nullptr, ncells, S.y_cs[L_DB], S.y_co[L_DB],
+                       T.Y[L_DB], T.bn[L_DB].scale, T.bn[L_DB].shift, T.desc, T.inv_norm, zero_ddesc ? T.ddesc : (float*)nullptr);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -2240,9 +2254,8 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
   if (has_sem) {
     const LayerDesc& d = h->L[L_SOUT];
     if (h->sout_cs > 256) return fail(-3, "segmentation head: more than 256 classes are not supported by colsum_kernel");
-    for (int k = 0; k < SS.n; ++k)
-      hipLaunchKernelGGL(colsum_kernel, dim3(cdiv((long)ncells, COLSUM_ROWS)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), (int)ncells, d.cout,
-                         h->sout_cs);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv((long)ncells, COLSUM_ROWS), SS.n), dim3(256), 0, st, dsout[0], Gd(h, d.b_off), (int)ncells, d.cout,
+                       h->sout_cs, dsout[SS.n - 1]);
     HIPCHK(hipGetLastError());
     CHK(pointwise(L_SOUT, L_DS, dsout, h->sout_cs, 512));
   }
@@ -2443,9 +2456,8 @@ static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* cons
     const LayerDesc& d = h->L[L_SOUT];
     const int ncells = N * Hc * Wc;
     if (h->sout_cs > 256) return fail(-3, "segmentation head: more than 256 classes are not supported by colsum_kernel");
-    for (int k = 0; k < SS.n; ++k)
-      hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, COLSUM_ROWS)), dim3(256), 0, st, dsout[k], Gd(h, d.b_off), ncells, d.cout,
-                         h->sout_cs);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, COLSUM_ROWS), SS.n), dim3(256), 0, st, dsout[0], Gd(h, d.b_off), ncells, d.cout,
+                       h->sout_cs, dsout[SS.n - 1]);
     HIPCHK(hipGetLastError());
     CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st, grouped, gw));
     if (grouped) add_dgrad(L_SOUT, dsout, h->sout_cs, 512);
@@ -2598,25 +2610,32 @@ static int sem_xc_env() {
   return v;
 }
 static int launch_sem_ce(int algo, bool train, const float* sout, const int64_t* labels, float* dsout, StepAccum* acc, int view, int B,
-                         int Hc, int Wc, int H, int W, int C, int cs, hipStream_t st) {
+                         int Hc, int Wc, int H, int W, int C, int cs, hipStream_t st, const float* sout1 = nullptr,
+                         const int64_t* labels1 = nullptr, float* dsout1 = nullptr) {
+  // (sout1 / labels1 / dsout1: the other view of the pair, view + 1, in the same launch where the kernel can)
   const bool xc_ok = H == 8 * Hc && W == 8 * Wc && C <= 16 * SEMX_NB;
   if (algo == 2 && !xc_ok) return fail(-1, "sem_ce: the (x, class) form needs H = 8 Hc, W = 8 Wc and <= %d classes", 16 * SEMX_NB);
   if (C > SEM_MAX_C) return fail(-1, "sem_ce: at most %d classes", SEM_MAX_C);
   const bool xc = algo == 2 || (algo == 0 && xc_ok && sem_xc_env() != 0);
   const long ntile = (long)B * (Hc + 1) * (Wc + 1);
+  const int nviews = sout1 != nullptr ? 2 : 1;
   if (xc) {
     static const int wgs_per_cu = [] { const char* e = getenv("SSP_SEM_XC_WGS"); return e ? atoi(e) : 2; }();
-    const SemXcGeom geom = sem_xc_geom(B, Hc, Wc, wgs_per_cu * device_cu_count());   // two 4-wave workgroups per CU, all resident
-    const int grid = B * geom.row_groups * geom.x_splits;
+    const SemXcGeom geom = sem_xc_geom(B, Hc, Wc, wgs_per_cu * device_cu_count());   // two 4-wave workgroups per CU and view, all resident
+    const int grid = B * geom.row_groups * geom.x_splits * nviews;
 #define SSP_SEM_XC(MODE, NB) \
-  hipLaunchKernelGGL((sem_ce_xc_kernel<MODE, NB>), dim3(grid), dim3(256), 0, st, sout, labels, dsout, acc, view, B, Hc, Wc, C, cs, geom)
+  hipLaunchKernelGGL((sem_ce_xc_kernel<MODE, NB>), dim3(grid), dim3(256), 0, st, sout, labels, dsout, acc, view, B, Hc, Wc, C, cs, geom, sout1, \
+                     labels1, dsout1)
     if (train) { if (C <= 48) SSP_SEM_XC(3, 3); else if (C <= 96) SSP_SEM_XC(3, 6); else SSP_SEM_XC(3, 9); }
     else { if (C <= 48) SSP_SEM_XC(1, 3); else if (C <= 96) SSP_SEM_XC(1, 6); else SSP_SEM_XC(1, 9); }
 #undef SSP_SEM_XC
   } else {
     const int grid = (int)std::min<long>((ntile + 3) / 4, 4096);
-    if (train) hipLaunchKernelGGL((sem_ce_kernel<3>), dim3(grid), dim3(256), 0, st, sout, labels, dsout, acc, view, B, Hc, Wc, H, W, C, cs);
-    else hipLaunchKernelGGL((sem_ce_kernel<1>), dim3(grid), dim3(256), 0, st, sout, labels, dsout, acc, view, B, Hc, Wc, H, W, C, cs);
+    for (int v = 0; v < nviews; ++v) {
+      const float* so = v ? sout1 : sout; const int64_t* la = v ? labels1 : labels; float* ds = v ? dsout1 : dsout;
+      if (train) hipLaunchKernelGGL((sem_ce_kernel<3>), dim3(grid), dim3(256), 0, st, so, la, ds, acc, view + v, B, Hc, Wc, H, W, C, cs);
+      else hipLaunchKernelGGL((sem_ce_kernel<1>), dim3(grid), dim3(256), 0, st, so, la, ds, acc, view + v, B, Hc, Wc, H, W, C, cs);
+    }
   }
   return 0;
 }
@@ -2669,11 +2688,8 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
   const int64_t* sems[2] = {in->semantic_dev, in->warped_semantic_dev};
   const bool zero_dsout = semantic && in->train;
   auto label_kernels = [&](hipStream_t se) -> int {
-    for (int v = 0; v < nv; ++v) {
-      Slot& S = h->slot[v];
-      hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512)), dim3(256), 0, se, masks[v], S.cellmask,
-                         &h->accum->mask_cnt[v], B, H, W);
-    }
+    hipLaunchKernelGGL(cell_mask_kernel, dim3(std::min(cdiv(ncells, 4), 512), nv), dim3(256), 0, se, masks[0], h->slot[0].cellmask,
+                       &h->accum->mask_cnt[0], B, H, W, masks[nv - 1], h->slot[nv - 1].cellmask, &h->accum->mask_cnt[nv - 1]);
     if (semantic)
       hipLaunchKernelGGL(sem_count_kernel, dim3(512, nv), dim3(256), 0, se, sems[0], sems[1], (long)B * H * W, h->cfg.n_classes, h->accum,
                          zero_dsout ? h->slot[0].dsout : (float*)nullptr, zero_dsout && nv == 2 ? h->slot[1].dsout : (float*)nullptr,
@@ -2721,10 +2737,8 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
                          A.ddesc, pc);
       hipLaunchKernelGGL((dense_grad_kernel<true>), dim3(4, cdiv(pc, 64), B), dim3(256), 0, sd, h->dense_coef, A.desc,
                          Bs.ddesc, pc);
-      for (int v = 0; v < 2; ++v) {
-        Slot& S = h->slot[v];
-        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, sd, S.desc, S.inv_norm, S.ddesc, ncells);
-      }
+      hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4), 2), dim3(256), 0, sd, A.desc, A.inv_norm, A.ddesc, ncells,
+                         Bs.desc, Bs.inv_norm, Bs.ddesc);
     }
     HIPCHK(hipGetLastError());
   } else if (use_desc) {
@@ -2757,31 +2771,27 @@ static int pair_step_impl(ssp_handle* h, const ssp_pair_inputs* in, float* scala
                h->cfg.n_match, h->cfg.n_non, dflags)
 #undef SSP_DESC
 #undef SSP_DESC_MATCH
-      for (int v = 0; v < 2; ++v) {
-        Slot& S = h->slot[v];
-        CHK(det_fold(S.ddesc, sd));   // (deterministic mode) the scattered gradient: fixed-point shadow -> tensor
-        hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4)), dim3(256), 0, sd, S.desc, S.inv_norm, S.ddesc, ncells);
-      }
+      CHK(det_fold(A.ddesc, sd));   // (deterministic mode) the scattered gradients: fixed-point shadow -> tensor
+      CHK(det_fold(Bs.ddesc, sd));
+      hipLaunchKernelGGL(desc_normalize_bwd_kernel, dim3(cdiv(ncells, 4), 2), dim3(256), 0, sd, A.desc, A.inv_norm, A.ddesc, ncells,
+                         Bs.desc, Bs.inv_norm, Bs.ddesc);
     }
     HIPCHK(hipGetLastError());
   }
   const float* labels[2] = {in->labels_dev, in->warped_labels_dev};
-  for (int v = 0; v < nv; ++v) {
-    Slot& S = h->slot[v];
-    hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024)), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
-                       S.bn[L_PB].shift, labels[v], S.cellmask, in->train ? S.dsemi : nullptr, h->accum, v, B, H, W, 80);
+  {
+    Slot &S = h->slot[0], &T = h->slot[nv - 1];   // both views in one launch (blockIdx.y)
+    hipLaunchKernelGGL(detector_loss_kernel, dim3(std::min(cdiv(ncells, 4), 1024), nv), dim3(256), 0, st, S.Y[L_PB], S.bn[L_PB].scale,
+                       S.bn[L_PB].shift, labels[0], S.cellmask, in->train ? S.dsemi : nullptr, h->accum, 0, B, H, W, 80,
+                       T.Y[L_PB], T.bn[L_PB].scale, T.bn[L_PB].shift, labels[nv - 1], T.cellmask, in->train ? T.dsemi : nullptr);
   }
   HIPCHK(hipGetLastError());
-  if (semantic) {
-    for (int v = 0; v < nv; ++v) {
-      Slot& S = h->slot[v];
-      if (in->train) {  // loss sum and d(convSout) in one pass (coef_sem: step_begin_kernel, sem_cnt: sem_count_kernel)
-        CHK(launch_sem_ce(0, true, S.Y[L_SOUT], sems[v], S.dsout, h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs, st));
-        CHK(det_fold(S.dsout, st));
-      } else {
-        CHK(launch_sem_ce(0, false, S.Y[L_SOUT], sems[v], nullptr, h->accum, v, B, Hc, Wc, H, W, h->cfg.n_classes, h->sout_cs, st));
-      }
-    }
+  if (semantic) {   // loss sum and d(convSout) in one pass, both views in one launch (coef_sem: step_begin_kernel, sem_cnt: sem_count_kernel)
+    Slot &S = h->slot[0], &T = h->slot[nv - 1];
+    CHK(launch_sem_ce(0, in->train != 0, S.Y[L_SOUT], sems[0], in->train ? S.dsout : nullptr, h->accum, 0, B, Hc, Wc, H, W, h->cfg.n_classes,
+                      h->sout_cs, st, nv == 2 ? T.Y[L_SOUT] : nullptr, nv == 2 ? sems[1] : nullptr, nv == 2 && in->train ? T.dsout : nullptr));
+    if (in->train)
+      for (int v = 0; v < nv; ++v) CHK(det_fold(h->slot[v].dsout, st));
     HIPCHK(hipGetLastError());
   }
   CHK(loss_fork.join());  // the scalars and the backward pass need both loss families
