@@ -235,9 +235,10 @@ __device__ __forceinline__ void replica_sums(const double* __restrict__ sums, in
   }
 }
 
-__global__ void bn_finalize_kernel(const BnLayer L0, const BnLayer L1, int nviews, int train, int64_t* nbt) {
+__device__ __forceinline__ void bn_finalize_body(const BnLayer& L0, const BnLayer& L1, int nviews, int train, int64_t* nbt) {
   // 32 lanes per channel (replica r each); lane 0 of the group writes.  grid: ceil(C * 32 / blockDim)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((t >> 5) >= ((L0.C + 7) & ~7)) return;   // (whole 256-thread workgroups past the layer: a launch shared with a wider layer)
   const int c = min(t >> 5, L0.C - 1), r = t & 31;  // clamped: every lane takes part in the shuffles
   const bool writer = r == 0 && (t >> 5) < L0.C;
   for (int v = 0; v < nviews; ++v) {  // view 0 then view 1: the running statistics are updated in the reference's order
@@ -268,6 +269,15 @@ __global__ void bn_finalize_kernel(const BnLayer L0, const BnLayer L1, int nview
       L.shift[c] = L.beta[c] - (float)mean * sc;
     }
   }
+}
+__global__ void bn_finalize_kernel(const BnLayer L0, const BnLayer L1, int nviews, int train, int64_t* nbt) {
+  bn_finalize_body(L0, L1, nviews, train, nbt);
+}
+// two layers whose statistics come out of ONE launch (the pointwise heads): blockIdx.y = layer
+__global__ void bn_finalize2_kernel(const BnLayer A0, const BnLayer A1, int64_t* nbt_a, const BnLayer B0, const BnLayer B1, int64_t* nbt_b,
+                                    int nviews, int train) {
+  if (blockIdx.y == 0) bn_finalize_body(A0, A1, nviews, train, nbt_a);
+  else bn_finalize_body(B0, B1, nviews, train, nbt_b);
 }
 
 // MaxPool2d(2)(ReLU(BN(y))) materialised once per pooled layer boundary (layers 1, 3, 5): the three consumers
@@ -733,10 +743,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l0_kernel(const BnBwdArgs a0
 // k12 = {S1/n, S2/n} for pass 2, and accumulate dgamma += S2, dbeta += S1.  (Letting every pass-2 thread sum the
 // 32 replicas itself cost a fixed ~110 us per launch: 2.6 ms per step in the first profiles.)
 template <typename T = float>  // element type of y / dout (the pool_fix scan is the only place that reads them)
-__global__ void bn_bwd_sums_kernel(const BnBwdArgs a0, const BnBwdArgs a1, int nviews, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta) {
+__device__ __forceinline__ void bn_bwd_sums_body(const BnBwdArgs& a0, const BnBwdArgs& a1, int nviews, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta) {
   // 32 lanes per channel (replica r each); lane 0 of the group writes.  grid: ceil(C * 32 / blockDim)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((t >> 5) >= ((a0.C + 7) & ~7)) return;   // (whole 256-thread workgroups past the layer: a launch shared with a wider layer)
   const int c = min(t >> 5, a0.C - 1), r = t & 31;
   const bool writer = r == 0 && (t >> 5) < a0.C;
   for (int v = 0; v < nviews; ++v) {  // the views accumulate into the same gradients: one after the other in this thread
@@ -779,6 +790,23 @@ __global__ void bn_bwd_sums_kernel(const BnBwdArgs a0, const BnBwdArgs a1, int n
     // and block in pass 2, which cost ~110 us per launch through same-address contention.
     if (a.dbias != nullptr) a.dbias[c] += a.gamma[c] * a.invstd[c] * (float)(s1 - a.count * (double)k1);
   }
+}
+template <typename T = float>
+__global__ void bn_bwd_sums_kernel(const BnBwdArgs a0, const BnBwdArgs a1, int nviews, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta) {
+  bn_bwd_sums_body<T>(a0, a1, nviews, dgamma, dbeta);
+}
+// up to three layers whose pass 1 is complete at the same point of the backward pass (the 3x3 heads): blockIdx.y = layer
+struct BnSumsJobs {
+  BnBwdArgs a0[3], a1[3];
+  float* dgamma[3];
+  float* dbeta[3];
+  int n;
+};
+template <typename T = float>
+__global__ void bn_bwd_sums_multi_kernel(const BnSumsJobs J, int nviews) {
+  const int j = blockIdx.y;
+  bn_bwd_sums_body<T>(J.a0[j], J.a1[j], nviews, J.dgamma[j], J.dbeta[j]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1220,10 +1220,32 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   return 0;
 }
 
+// Replica reductions of several layers whose pass 1 is complete at the same point of the backward pass (the 3x3 heads: pass 1 in the
+// pointwise heads' data gradient, pass 2 in their weight gradients) collected for ONE launch - each small launch is ~13 us of the step.
+struct BnSumsQueue {
+  BnSumsJobs J;
+  int maxC = 0;
+  BnSumsQueue() { J.n = 0; }
+};
+static int flush_bn_sums(BnSumsQueue& q, int nviews, hipStream_t st) {
+  if (q.J.n == 0) return 0;
+  if (q.J.n == 1) hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(cdiv(q.maxC * 32, 256)), dim3(256), 0, st, q.J.a0[0], q.J.a1[0], nviews,
+                                     q.J.dgamma[0], q.J.dbeta[0]);
+  else hipLaunchKernelGGL(bn_bwd_sums_multi_kernel<float>, dim3(cdiv(q.maxC * 32, 256), q.J.n), dim3(256), 0, st, q.J, nviews);
+  HIPCHK(hipGetLastError());
+  q.J.n = 0; q.maxC = 0;
+  return 0;
+}
 // pass 1 (sums) -> replica reduction + dgamma/dbeta -> pass 2 (apply); a[0 .. nviews-1] ride the same launches
 template <bool RELU, bool POOL, typename T = float>
 static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* dbeta, hipStream_t st,
-                         bool sums_done = false, bool skip_apply = false) {
+                         bool sums_done = false, bool skip_apply = false, BnSumsQueue* queue = nullptr) {
+  if (queue != nullptr && sums_done && skip_apply && sizeof(T) == 4 && queue->J.n < 3) {  // only the reduction is left: the caller flushes
+    const int j = queue->J.n++;
+    queue->J.a0[j] = a[0]; queue->J.a1[j] = a[nviews - 1]; queue->J.dgamma[j] = dgamma; queue->J.dbeta[j] = dbeta;
+    queue->maxC = std::max(queue->maxC, a[0].C);
+    return 0;
+  }
   // a.dbias (conv bias gradient, may be null) is produced by bn_bwd_sums_kernel
   const BnBwdArgs& a0 = a[0];
   const BnBwdArgs& a1 = a[nviews - 1];
@@ -1564,9 +1586,8 @@ static const float* P(const ssp_handle* h, size_t off) { return h->buf.params_de
 static float* Gd(const ssp_handle* h, size_t off) { return h->buf.grads_dev + off; }
 
 // BatchNorm statistics -> affine of layer l for every view of the set, ONE launch (view 0 then view 1 in the same thread)
-static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, double count, int train, hipStream_t st) {
+static void bn_layer_args(ssp_handle* h, Slot* const* slots, int nviews, int l, double count, BnLayer* b) {
   const LayerDesc& d = h->L[l];
-  BnLayer b[2];
   for (int k = 0; k < nviews; ++k) {
     Slot& S = *slots[k];
     b[k].stats = S.bn[l].stats; b[k].gamma = P(h, d.g_off); b[k].beta = P(h, d.be_off);
@@ -1575,8 +1596,25 @@ static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, dou
     b[k].scale = S.bn[l].scale; b[k].shift = S.bn[l].shift; b[k].mean = S.bn[l].mean; b[k].invstd = S.bn[l].invstd;
     b[k].C = d.cout; b[k].count = count;
   }
-  int64_t* nbt = h->buf.num_batches_tracked_dev ? h->buf.num_batches_tracked_dev + d.bn_index : nullptr;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, b[0], b[nviews - 1], nviews, train, nbt);
+  if (nviews == 1) b[1] = b[0];
+}
+static int64_t* bn_nbt(ssp_handle* h, int l) {
+  return h->buf.num_batches_tracked_dev ? h->buf.num_batches_tracked_dev + h->L[l].bn_index : nullptr;
+}
+static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, double count, int train, hipStream_t st) {
+  BnLayer b[2];
+  bn_layer_args(h, slots, nviews, l, count, b);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(h->L[l].cout * 32, 256)), dim3(256), 0, st, b[0], b[1], nviews, train, bn_nbt(h, l));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// two layers of one count whose statistics come out of the same launch: one finalize launch (blockIdx.y = layer)
+static int bn_finalize2(ssp_handle* h, Slot* const* slots, int nviews, int la, int lb, double count, int train, hipStream_t st) {
+  BnLayer a[2], b[2];
+  bn_layer_args(h, slots, nviews, la, count, a);
+  bn_layer_args(h, slots, nviews, lb, count, b);
+  const int nb = cdiv(std::max(h->L[la].cout, h->L[lb].cout) * 32, 256);
+  hipLaunchKernelGGL(bn_finalize2_kernel, dim3(nb, 2), dim3(256), 0, st, a[0], a[1], bn_nbt(h, la), b[0], b[1], bn_nbt(h, lb), nviews, train);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1901,8 +1939,11 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
       }
     }
     CHK(launch_g1(Lg, n, SS.n, (long)N * Hc * Wc, 1, h->n_cu, st));
+    int bl[3], nbl = 0;
     for (int i = 0; i < n; ++i)
-      if (h->L[layers[i]].bn) CHK(bn_finalize(h, SS.s, SS.n, layers[i], (double)N * Hc * Wc, train, st));
+      if (h->L[layers[i]].bn) bl[nbl++] = layers[i];
+    if (nbl == 2) return bn_finalize2(h, SS.s, SS.n, bl[0], bl[1], (double)N * Hc * Wc, train, st);   // convDb + convPb: one launch
+    for (int i = 0; i < nbl; ++i) CHK(bn_finalize(h, SS.s, SS.n, bl[i], (double)N * Hc * Wc, train, st));
     return 0;
   };
   const int pw[3] = {L_DB, L_SOUT, L_PB};
@@ -1930,7 +1971,8 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
 // BatchNorm(+ReLU(+pool)) backward of layer l for every view of the set in the same launches: dout[k] -> dy[k]
 // (+ dgamma, dbeta, conv-bias gradient, accumulated over the views)
 static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const float* const* dout, int d_cs, int d_co, bool relu,
-                             bool pool_after, float* const* dy, int dy_cs, int dy_co, int N, int H, int W, hipStream_t st) {
+                             bool pool_after, float* const* dy, int dy_cs, int dy_co, int N, int H, int W, hipStream_t st,
+                             BnSumsQueue* queue = nullptr) {
   const LayerDesc& d = h->L[l];
   BnBwdArgs a[2];
   bool have_pool = true;
@@ -1992,7 +2034,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const bool defer = l >= 1 && d_cs == SS.s[0]->y_cs[l] && d_co == SS.s[0]->y_co[l] && dy_cs == d_cs && dy_co == d_co &&
                        wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout);
     h->apply_fused[l] = defer;
-    CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused, defer)));
+    CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused, defer, queue)));
   }
   else CHK((launch_bn_bwd<false, false>(a, SS.n, dg, db, st)));
   HIPCHK(hipGetLastError());
@@ -2469,8 +2511,10 @@ static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* cons
   // concatenated dY channels (sums the heads' contributions) gQ -> gP [cells][128] ----
   {
     const int heads[3] = {L_PA, L_DA, L_DS};
+    BnSumsQueue sums_queue;   // the heads' replica reductions in one launch where nothing else is left of their BatchNorm backward
     for (int hk = 0; hk < h->nheads; ++hk)
-      CHK(bn_layer_backward(h, SS, heads[hk], gP, hcs, 256 * hk, true, false, gQ, hcs, 256 * hk, N, Hc, Wc, st));
+      CHK(bn_layer_backward(h, SS, heads[hk], gP, hcs, 256 * hk, true, false, gQ, hcs, 256 * hk, N, Hc, Wc, st, &sums_queue));
+    CHK(flush_bn_sums(sums_queue, SS.n, st));
     for (int hk = 0; hk < h->nheads; ++hk) {
       const LayerDesc& d = h->L[heads[hk]];
       WgradCall w;
