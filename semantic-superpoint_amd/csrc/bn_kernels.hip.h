@@ -344,8 +344,10 @@ struct BnBwdArgs {
 
 // T = float, or uint16_t for the bf16 path (y, dout and dy are bf16 tensors behind the float* fields; offsets in elements)
 template <bool RELU, bool POOL, bool APPLY, typename T = float>
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const BnBwdArgs a1) {
-  const BnBwdArgs& a = blockIdx.y ? a1 : a0;  // the two views of a pair ride one launch
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a0, const BnBwdArgs a1, const BnBwdArgs b0, const BnBwdArgs b1) {
+  // the two views of a pair ride one launch (blockIdx.y 0, 1), and so may a second layer of the same template form (2, 3: the two
+  // pointwise heads' BatchNorm - a small launch costs ~13 us of the step whatever it does); callers with one layer pass it twice
+  const BnBwdArgs& a = blockIdx.y == 0 ? a0 : blockIdx.y == 1 ? a1 : blockIdx.y == 2 ? b0 : b1;
   const T* const t_y = reinterpret_cast<const T*>(a.y);
   const T* const t_dout = reinterpret_cast<const T*>(a.dout);
   T* const t_dy = reinterpret_cast<T*>(a.dy);

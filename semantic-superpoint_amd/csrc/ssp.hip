@@ -1220,6 +1220,12 @@ static int launch_pack(const float* w, float* dst, int cout_w, int cin_w, int ks
   return 0;
 }
 
+struct BnPlainJob {   // arguments of one plain (no ReLU) BatchNorm backward, collected instead of launched (launch_bn_bwd_pair)
+  BnBwdArgs a[2];
+  float* dg = nullptr;
+  float* db = nullptr;
+  bool filled = false;
+};
 // Replica reductions of several layers whose pass 1 is complete at the same point of the backward pass (the 3x3 heads: pass 1 in the
 // pointwise heads' data gradient, pass 2 in their weight gradients) collected for ONE launch - each small launch is ~13 us of the step.
 struct BnSumsQueue {
@@ -1254,10 +1260,10 @@ static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* d
   int nb = cdiv(npix, rows);
   if (nb > 1024) nb = 1024;
   if (!sums_done)  // else: pass 1 was accumulated by the data-gradient conv that produced dOut
-    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
+    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, false, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1, a0, a1);
   hipLaunchKernelGGL(bn_bwd_sums_kernel<T>, dim3(cdiv(a0.C * 32, 256)), dim3(256), 0, st, a0, a1, nviews, dgamma, dbeta);
   if (!skip_apply)  // else: pass 2 rides the layer's weight gradient (wgrad_wino_fused_kernel)
-    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1);
+    hipLaunchKernelGGL((bn_bwd_kernel<RELU, POOL, true, T>), dim3(nb, nviews), dim3(256), 0, st, a0, a1, a0, a1);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1972,7 +1978,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
 // (+ dgamma, dbeta, conv-bias gradient, accumulated over the views)
 static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const float* const* dout, int d_cs, int d_co, bool relu,
                              bool pool_after, float* const* dy, int dy_cs, int dy_co, int N, int H, int W, hipStream_t st,
-                             BnSumsQueue* queue = nullptr) {
+                             BnSumsQueue* queue = nullptr, BnPlainJob* collect = nullptr) {
   const LayerDesc& d = h->L[l];
   BnBwdArgs a[2];
   bool have_pool = true;
@@ -2018,7 +2024,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
       for (int k = 0; k < 2; ++k) {
         r[k].y = r[k].apool; r[k].y_cs = d.cout; r[k].y_co = 0; r[k].H = H / 2; r[k].W = W / 2;
       }
-      hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[1]);
+      hipLaunchKernelGGL((bn_bwd_kernel<true, false, false>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[1], r[0], r[1]);
     }
     hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(cdiv(d.cout * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
     // pass 2: inside the layer's weight gradient (it stages dY anyway and writes it for the data gradient) where possible
@@ -2026,7 +2032,7 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const bool defer = l >= 1 && l < 8 && layer_in_mode(l) == 1 && dy_cs == d.cout && dy_co == 0 && SS.s[0]->y_cs[l] == d.cout &&
                        SS.s[0]->y_co[l] == 0 && wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout);
     h->apply_fused[l] = defer;
-    if (!defer) hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
+    if (!defer) hipLaunchKernelGGL((bn_bwd_kernel<true, true, true>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1, a0, a1);
   } else if (relu && pool_after) CHK((launch_bn_bwd<true, true>(a, SS.n, dg, db, st, fused)));
   else if (relu) {
     // encoder layers 2, 4, 6, 7 (dense [N,H,W,C] tensors) and the 3x3 heads (slices of [cells][256 heads] tensors: y, the
@@ -2036,7 +2042,28 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     h->apply_fused[l] = defer;
     CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused, defer, queue)));
   }
+  else if (collect != nullptr) {   // BatchNorm without ReLU (the pointwise heads): the caller launches two layers together
+    collect->a[0] = a0; collect->a[1] = a1; collect->dg = dg; collect->db = db; collect->filled = true;
+    return 0;
+  }
   else CHK((launch_bn_bwd<false, false>(a, SS.n, dg, db, st)));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// BatchNorm backward of TWO plain layers (no ReLU, no pooling: convPb and convDb) in three launches instead of six
+static int launch_bn_bwd_pair(const BnPlainJob& p, const BnPlainJob& q, int nviews, hipStream_t st) {
+  auto blocks = [](const BnBwdArgs& a) {
+    const int nq = (a.C + 3) / 4, rows = 256 / nq;
+    return std::min(cdiv((long)a.N * a.H * a.W, rows), 1024);
+  };
+  const int nb = std::max(blocks(p.a[0]), blocks(q.a[0]));
+  hipLaunchKernelGGL((bn_bwd_kernel<false, false, false, float>), dim3(nb, 4), dim3(256), 0, st, p.a[0], p.a[1], q.a[0], q.a[1]);
+  BnSumsQueue sq;
+  sq.J.n = 2; sq.maxC = std::max(p.a[0].C, q.a[0].C);
+  sq.J.a0[0] = p.a[0]; sq.J.a1[0] = p.a[1]; sq.J.dgamma[0] = p.dg; sq.J.dbeta[0] = p.db;
+  sq.J.a0[1] = q.a[0]; sq.J.a1[1] = q.a[1]; sq.J.dgamma[1] = q.dg; sq.J.dbeta[1] = q.db;
+  CHK(flush_bn_sums(sq, nviews, st));
+  hipLaunchKernelGGL((bn_bwd_kernel<false, false, true, float>), dim3(nb, 4), dim3(256), 0, st, p.a[0], p.a[1], q.a[0], q.a[1]);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2180,9 +2207,9 @@ static int encoder_backward_bf16(ssp_handle* h, const SlotSet& SS, int l_hi, int
       const int rows = 256 / (C / 4);
       const int nb = (int)std::max(1L, std::min<long>(cdiv(npix, rows), 1024));
       if (!sums_fused)
-        hipLaunchKernelGGL((bn_bwd_kernel<true, false, false, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[SS.n - 1]);
+        hipLaunchKernelGGL((bn_bwd_kernel<true, false, false, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, r[0], r[SS.n - 1], r[0], r[SS.n - 1]);
       hipLaunchKernelGGL(bn_bwd_sums_kernel<uint16_t>, dim3(cdiv(C * 32, 256)), dim3(256), 0, st, a0, a1, SS.n, dg, db);
-      if (!fuse_apply) hipLaunchKernelGGL((bn_bwd_kernel<true, true, true, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1);
+      if (!fuse_apply) hipLaunchKernelGGL((bn_bwd_kernel<true, true, true, uint16_t>), dim3(nb, SS.n), dim3(256), 0, st, a0, a1, a0, a1);
       HIPCHK(hipGetLastError());
     } else CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, dg, db, st, sums_fused, fuse_apply)));
     // weight gradient: X = (pooled) raw output of layer l - 1 under its BatchNorm + ReLU, dY = gQ
@@ -2482,14 +2509,24 @@ static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* cons
     }
     if (bnr) h->bsums_fused[src] = true;
   };
+  // the two pointwise heads' BatchNorm backward (pass 1, replica reduction, pass 2) in three launches for both where both run and
+  // the convolutions behind them are deferred to the grouped launches anyway
+  BnPlainJob job_pb, job_db;
+  const bool pair = has_semi && has_desc && grouped && gw && SS.n == 2;
+  if (pair) {
+    CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQ, 80, 0, N, Hc, Wc, st, nullptr, &job_pb));
+    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st, nullptr, &job_db));
+    if (!job_pb.filled || !job_db.filled) return fail(-3, "pointwise heads: BatchNorm backward not in the plain form");
+    CHK(launch_bn_bwd_pair(job_pb, job_db, SS.n, st));
+  }
   if (has_semi) {
-    CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQ, 80, 0, N, Hc, Wc, st));
+    if (!pair) CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQ, 80, 0, N, Hc, Wc, st));
     CHK(conv_layer_backward(h, SS, L_PB, L_PA, gQ, 80, 0, dact, hcs, 0, N, Hc, Wc, 1, st, grouped, gw));
     if (grouped) add_dgrad(L_PB, gQ, 80, 0);
     if (gw) add_wgrad(L_PB, gQ, 80);
   }
   if (has_desc) {
-    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st));
+    if (!pair) CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st));
     CHK(conv_layer_backward(h, SS, L_DB, L_DA, gQd, 256, 0, dact, hcs, 256, N, Hc, Wc, 1, st, grouped, gw));
     if (grouped) add_dgrad(L_DB, gQd, 256, 256);
     if (gw) add_wgrad(L_DB, gQd, 256);
