@@ -1246,7 +1246,8 @@ static int flush_bn_sums(BnSumsQueue& q, int nviews, hipStream_t st) {
 template <bool RELU, bool POOL, typename T = float>
 static int launch_bn_bwd(const BnBwdArgs* a, int nviews, float* dgamma, float* dbeta, hipStream_t st,
                          bool sums_done = false, bool skip_apply = false, BnSumsQueue* queue = nullptr) {
-  if (queue != nullptr && sums_done && skip_apply && sizeof(T) == 4 && queue->J.n < 3) {  // only the reduction is left: the caller flushes
+  // (the reduction reads the tensors - as T - only for the pool_fix scan: without it the fp32 instantiation serves the bf16 path too)
+  if (queue != nullptr && sums_done && skip_apply && (sizeof(T) == 4 || a[0].pool_fix == 0) && queue->J.n < 3) {  // only the reduction is left: the caller flushes
     const int j = queue->J.n++;
     queue->J.a0[j] = a[0]; queue->J.a1[j] = a[nviews - 1]; queue->J.dgamma[j] = dgamma; queue->J.dbeta[j] = dbeta;
     queue->maxC = std::max(queue->maxC, a[0].C);
@@ -2312,12 +2313,21 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     if (bnr) h->bsums_fused[src] = true;
     return 0;
   };
+  // (the two fp32 BatchNorm backward passes of the pointwise heads in three launches for both, like the fp32 path)
+  BnPlainJob job_pb, job_db;
+  const bool pair = has_semi && has_desc && SS.n == 2;
+  if (pair) {
+    CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQs, 80, 0, N, Hc, Wc, st, nullptr, &job_pb));
+    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st, nullptr, &job_db));
+    if (!job_pb.filled || !job_db.filled) return fail(-3, "pointwise heads: BatchNorm backward not in the plain form");
+    CHK(launch_bn_bwd_pair(job_pb, job_db, SS.n, st));
+  }
   if (has_semi) {
-    CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQs, 80, 0, N, Hc, Wc, st));
+    if (!pair) CHK(bn_layer_backward(h, SS, L_PB, dsemi, 80, 0, false, false, gQs, 80, 0, N, Hc, Wc, st));
     CHK(pointwise(L_PB, L_PA, gQs, 80, 0));
   }
   if (has_desc) {
-    CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st));
+    if (!pair) CHK(bn_layer_backward(h, SS, L_DB, draw_desc, 256, 0, false, false, gQd, 256, 0, N, Hc, Wc, st));
     CHK(pointwise(L_DB, L_DA, gQd, 256, 256));
   }
   if (has_sem) {
@@ -2333,6 +2343,7 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
   // pass 2 (APPLY) of their BatchNorm + ReLU backward rides their weight gradients (as in encoder_backward_bf16): y, dOut and dY are
   // the head's 256-channel slice of [cells][256 heads] tensors
   const bool heads_fuse = h->bf16_fuse_apply;
+  BnSumsQueue sums_queue;   // the heads' replica reductions in one launch where nothing else is left of their BatchNorm backward
   for (int hk = 0; hk < h->nheads; ++hk) {
     const LayerDesc& d = h->L[heads[hk]];
     BnBwdArgs a[2];
@@ -2348,8 +2359,9 @@ static int heads_backward_bf16(ssp_handle* h, const SlotSet& SS, const float* co
     }
     const bool sums_fused = h->bsums_fused[heads[hk]];
     h->bsums_fused[heads[hk]] = false;
-    CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, Gd(h, d.g_off), Gd(h, d.be_off), st, sums_fused, heads_fuse)));
+    CHK((launch_bn_bwd<true, false, uint16_t>(a, SS.n, Gd(h, d.g_off), Gd(h, d.be_off), st, sums_fused, heads_fuse, &sums_queue)));
   }
+  CHK(flush_bn_sums(sums_queue, SS.n, st));
   for (int hk = 0; hk < h->nheads; ++hk) {
     const LayerDesc& d = h->L[heads[hk]];
     WgradBCall w;
