@@ -273,11 +273,16 @@ __device__ __forceinline__ void bn_finalize_body(const BnLayer& L0, const BnLaye
 __global__ void bn_finalize_kernel(const BnLayer L0, const BnLayer L1, int nviews, int train, int64_t* nbt) {
   bn_finalize_body(L0, L1, nviews, train, nbt);
 }
-// two layers whose statistics come out of ONE launch (the pointwise heads): blockIdx.y = layer
-__global__ void bn_finalize2_kernel(const BnLayer A0, const BnLayer A1, int64_t* nbt_a, const BnLayer B0, const BnLayer B1, int64_t* nbt_b,
-                                    int nviews, int train) {
-  if (blockIdx.y == 0) bn_finalize_body(A0, A1, nviews, train, nbt_a);
-  else bn_finalize_body(B0, B1, nviews, train, nbt_b);
+// up to three layers whose statistics are complete at the same point of the forward pass (the pointwise heads of one grouped launch;
+// the three 3x3 heads, which all read layer 7): blockIdx.y = layer
+struct BnFinJobs {
+  BnLayer L0[3], L1[3];
+  int64_t* nbt[3];
+  int n;
+};
+__global__ void bn_finalize_multi_kernel(const BnFinJobs J, int nviews, int train) {
+  const int j = blockIdx.y;
+  bn_finalize_body(J.L0[j], J.L1[j], nviews, train, J.nbt[j]);
 }
 
 // MaxPool2d(2)(ReLU(BN(y))) materialised once per pooled layer boundary (layers 1, 3, 5): the three consumers

@@ -1615,16 +1615,29 @@ static int bn_finalize(ssp_handle* h, Slot* const* slots, int nviews, int l, dou
   HIPCHK(hipGetLastError());
   return 0;
 }
-// two layers of one count whose statistics come out of the same launch: one finalize launch (blockIdx.y = layer)
-static int bn_finalize2(ssp_handle* h, Slot* const* slots, int nviews, int la, int lb, double count, int train, hipStream_t st) {
-  BnLayer a[2], b[2];
-  bn_layer_args(h, slots, nviews, la, count, a);
-  bn_layer_args(h, slots, nviews, lb, count, b);
-  const int nb = cdiv(std::max(h->L[la].cout, h->L[lb].cout) * 32, 256);
-  hipLaunchKernelGGL(bn_finalize2_kernel, dim3(nb, 2), dim3(256), 0, st, a[0], a[1], bn_nbt(h, la), b[0], b[1], bn_nbt(h, lb), nviews, train);
+// several layers whose statistics are complete at the same point: one finalize launch (blockIdx.y = layer)
+static int bn_finalize_n(ssp_handle* h, Slot* const* slots, int nviews, const int* layers, int n, double count, int train, hipStream_t st) {
+  if (n == 0) return 0;
+  if (n == 1) return bn_finalize(h, slots, nviews, layers[0], count, train, st);
+  if (n > 3) return fail(-3, "bn_finalize_n: at most three layers per launch");
+  BnFinJobs J;
+  J.n = n;
+  int maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    BnLayer b[2];
+    bn_layer_args(h, slots, nviews, layers[i], count, b);
+    J.L0[i] = b[0]; J.L1[i] = b[1]; J.nbt[i] = bn_nbt(h, layers[i]);
+    maxc = std::max(maxc, h->L[layers[i]].cout);
+  }
+  hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(cdiv(maxc * 32, 256), n), dim3(256), 0, st, J, nviews, train);
   HIPCHK(hipGetLastError());
   return 0;
 }
+// conv_layer_fwd / conv_layer_fwd_bf16 with `deferred` != nullptr leave the finalize of their layer to the caller (bn_finalize_n)
+struct BnDeferred {
+  int layers[3];
+  int n = 0;
+};
 
 static int pack_all(ssp_handle* h, bool with_bwd, int nprob, int N, int H, int W, hipStream_t st) {
   // default algorithm: every Winograd image (3x3 layers forward + data gradient, concatenated heads) in one launch
@@ -1782,7 +1795,7 @@ struct SlotSet {
 // pooled copy Apool[l]; heads: a slice of the [cells][256 heads] tensor) in the slot's buffers; the pointwise heads read those
 // under BatchNorm + ReLU and write the fp32 logits / descriptors the loss kernels take.
 static int conv_layer_fwd_bf16(ssp_handle* h, const SlotSet& SS, int l, int src, int N, int H, int W, int in_mode, int train,
-                               hipStream_t st) {
+                               hipStream_t st, BnDeferred* deferred = nullptr) {
   const LayerDesc& d = h->L[l];
   const bool pooled = in_mode == 2;  // input = raw pooled y of layer src (written by its conv), BatchNorm + ReLU on load
   ConvBCall c;
@@ -1828,15 +1841,16 @@ static int conv_layer_fwd_bf16(ssp_handle* h, const SlotSet& SS, int l, int src,
     ProfScope ps(h, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : -1, st, flops, bytes, flops, SSP_PROF_K_CONV_BF16);
     CHK(launch_conv_bf16(c, h->n_cu, st));
   }
-  if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));
+  if (d.bn && deferred != nullptr && deferred->n < 3) deferred->layers[deferred->n++] = l;
+  else if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));
   return 0;
 }
 
 static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int N, int H, int W, int in_mode, int train,
-                          hipStream_t st) {
+                          hipStream_t st, BnDeferred* deferred = nullptr) {
   const LayerDesc& d = h->L[l];
   Slot& A = *SS.s[0];
-  if (bf16_path()) return conv_layer_fwd_bf16(h, SS, l, src, N, H, W, in_mode, train, st);
+  if (bf16_path()) return conv_layer_fwd_bf16(h, SS, l, src, N, H, W, in_mode, train, st, deferred);
   FwdAlgoScope fwd_algo;
   const bool pooled = in_mode == 2;  // input = pooled output of layer src: raw pooled y (BatchNorm + ReLU on load, mode 1)
                                      // when its conv wrote it (pool_raw), else materialised maxpool(relu(bn(Y_src))) (mode 0)
@@ -1876,7 +1890,8 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
     for (int k = 0; k < SS.n; ++k) SS.s[k]->pool_raw[l] = raw;
   }
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
-  if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));  // view 0 then 1 inside the kernel
+  if (d.bn && deferred != nullptr && deferred->n < 3) deferred->layers[deferred->n++] = l;
+  else if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));  // view 0 then 1 inside the kernel
   return 0;
 }
 
@@ -1928,9 +1943,10 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
   auto pointwise = [&](const int* layers, int n) -> int {
     bool grouped = true;
     for (int i = 0; i < n; ++i) grouped = grouped && h->pk_g1[layers[i]];
-    if (!grouped) {
-      for (int i = 0; i < n; ++i) CHK(conv_layer_fwd(h, SS, layers[i], layers[i] - 1, N, Hc, Wc, 1, train, st));
-      return 0;
+    if (!grouped) {   // (the bf16 path: one launch per head, their BatchNorm finalizes together behind the last one)
+      BnDeferred fin;
+      for (int i = 0; i < n; ++i) CHK(conv_layer_fwd(h, SS, layers[i], layers[i] - 1, N, Hc, Wc, 1, train, st, &fin));
+      return bn_finalize_n(h, SS.s, SS.n, fin.layers, fin.n, (double)N * Hc * Wc, train, st);
     }
     G1Layer Lg[3];
     for (int i = 0; i < n; ++i) {
@@ -1949,16 +1965,19 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     int bl[3], nbl = 0;
     for (int i = 0; i < n; ++i)
       if (h->L[layers[i]].bn) bl[nbl++] = layers[i];
-    if (nbl == 2) return bn_finalize2(h, SS.s, SS.n, bl[0], bl[1], (double)N * Hc * Wc, train, st);   // convDb + convPb: one launch
-    for (int i = 0; i < nbl; ++i) CHK(bn_finalize(h, SS.s, SS.n, bl[i], (double)N * Hc * Wc, train, st));
-    return 0;
+    return bn_finalize_n(h, SS.s, SS.n, bl, nbl, (double)N * Hc * Wc, train, st);   // convDb + convPb: one launch
   };
   const int pw[3] = {L_DB, L_SOUT, L_PB};
-  CHK(conv_layer_fwd(h, SS, L_PA, 7, N, Hc, Wc, 1, train, st));
-  if (detector_only) return pointwise(pw + 2, 1);
-  CHK(conv_layer_fwd(h, SS, L_DA, 7, N, Hc, Wc, 1, train, st));
+  BnDeferred fin3;   // the 3x3 heads all read layer 7: their launches back to back, ONE finalize launch for their statistics
+  CHK(conv_layer_fwd(h, SS, L_PA, 7, N, Hc, Wc, 1, train, st, &fin3));
+  if (detector_only) {
+    CHK(bn_finalize_n(h, SS.s, SS.n, fin3.layers, fin3.n, (double)N * Hc * Wc, train, st));
+    return pointwise(pw + 2, 1);
+  }
+  CHK(conv_layer_fwd(h, SS, L_DA, 7, N, Hc, Wc, 1, train, st, &fin3));
+  if (h->nheads == 3) CHK(conv_layer_fwd(h, SS, L_DS, 7, N, Hc, Wc, 1, train, st, &fin3));
+  CHK(bn_finalize_n(h, SS.s, SS.n, fin3.layers, fin3.n, (double)N * Hc * Wc, train, st));
   if (h->nheads == 3) {
-    CHK(conv_layer_fwd(h, SS, L_DS, 7, N, Hc, Wc, 1, train, st));
     CHK(pointwise(pw, 3));
   } else {
     const int pw2[2] = {L_DB, L_PB};
