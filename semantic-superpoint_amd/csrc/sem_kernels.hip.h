@@ -368,7 +368,7 @@ __device__ __forceinline__ float xlane_allreduce16(float v, Op op) {
 
 // Launch geometry: one workgroup = four waves on four CONSECUTIVE TILE ROWS of one image, walking the same range of tile columns in
 // lockstep (one barrier per step).  A cell's gradient has four contributing tiles; instead of four atomics per (cell, class)
-//   * the two right corners of a tile stay in registers and join the left corners of the next tile of the walk (a quad shift), and
+//   * the two right corners of a tile wait in LDS for the next tile of the walk and join its left corners, and
 //   * the bottom-left total of a wave goes to the wave below through LDS and joins its top-left total,
 // so that a step of four tiles issues five cell vectors of atomics instead of sixteen (the L2 retires roughly one fp32 atomic per
 // channel and clock: 576 per tile were 105 of the kernel's 238 us).  Everything that leaves the workgroup is still an atomic add -
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, SEMX_WGS) void sem_ce_xc_kernel(const float* _
       for (int blk = 0; blk < NB; ++blk)
         mx = fmaxf(mx, cc[blk]);
       const float Mk = xlane_allreduce16(mx, [](float a, float b) { return fmaxf(a, b); });
-      // ---- forward: exponentials of the tile in registers, partial sums over this lane's classes ----
+      // ---- forward: anchors and ratios of the tile's exponentials in registers, partial sums over this lane's classes ----
       f32x2 E[NB][2][2];  // rows (0, 7) and the ratios (r, 1 / r) of each column: the gradient sweep runs the progressions again
       f32x2 SE[2][4];
 #pragma unroll
