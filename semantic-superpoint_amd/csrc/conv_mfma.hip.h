@@ -22,6 +22,78 @@ constexpr int CS = CK + 4;   // LDS pixel stride in floats (pad 4 -> conflict-fr
 constexpr int NB = 64;       // output channels per block
 constexpr int NREP = 32;     // replicas of every fp64 statistics accumulator (spreads same-address atomics)
 
+// ---- BatchNorm statistics -> affine on the CONSUMER side -------------------------------------------------------------------------
+// A 7-microsecond bn_finalize_kernel between two convolutions costs ~13 us of the step (dispatch of a dependent launch + its own
+// latency chain; PERF_LOG round 6 section 4).  In training, the convolution that READS a layer under BatchNorm + ReLU therefore derives
+// scale / shift in its prologue from the producer's raw statistics (32 replicas of sum and sum of squares per channel: the launch
+// boundary has made them visible) - every workgroup for the view it works on, and workgroup 0 additionally for both views, storing
+// scale / shift / mean / invstd for the later readers (weight gradients, BatchNorm backward) and updating the running statistics in the
+// reference's order (view 0, then view 1).  All of them evaluate ONE function (bn_lazy_stats + bn_affine_of), so the values used
+// and the values stored are the same bits.  The replicas are added in index order (bn_finalize_kernel: pairwise) - the fp64 sums may
+// differ in their last bit from that kernel's; under ssp_set_deterministic every addend is a multiple of one quantum and any order is exact.
+struct BnLazy {
+  const double* stats[2] = {nullptr, nullptr};   // [NREP][2C] of the producer layer, per view
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float* scale[2] = {nullptr, nullptr};          // where workgroup 0 stores (mode 2)
+  float* shift[2] = {nullptr, nullptr};
+  float* mean[2] = {nullptr, nullptr};
+  float* invstd[2] = {nullptr, nullptr};
+  float* running_mean = nullptr;
+  float* running_var = nullptr;
+  int64_t* nbt = nullptr;
+  double count = 0.0;
+  int C = 0;
+  int nviews = 0;
+  int mode = 0;   // 0: the arrays in_scale / in_shift are valid; 2: derive them here, workgroup 0 stores
+};
+__device__ __forceinline__ void bn_lazy_stats(const double* __restrict__ stats, int C, int c, double count, double& mean, double& var) {
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {   // two rounds of 16 replicas: 32 loads in flight
+    double v1[NREP / 2], v2[NREP / 2];
+#pragma unroll
+    for (int k = 0; k < NREP / 2; ++k) {
+      v1[k] = stats[(size_t)(h * (NREP / 2) + k) * 2 * C + c];
+      v2[k] = stats[(size_t)(h * (NREP / 2) + k) * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int k = 0; k < NREP / 2; ++k) { s1 += v1[k]; s2 += v2[k]; }
+  }
+  mean = s1 / count;
+  var = s2 / count - mean * mean;
+  if (var < 0) var = 0;
+}
+__device__ __forceinline__ void bn_affine_of(double mean, double var, float gamma, float beta, float& invstd, float& sc, float& sh) {
+  invstd = (float)(1.0 / sqrt(var + 1e-5));
+  sc = gamma * invstd;
+  sh = beta - (float)mean * sc;
+}
+// scale / shift of channel c of view `view` (every workgroup)
+__device__ __forceinline__ void bn_lazy_affine(const BnLazy& z, int view, int c, float& sc, float& sh) {
+  double mean, var;
+  float invstd;
+  bn_lazy_stats(z.stats[view], z.C, c, z.count, mean, var);
+  bn_affine_of(mean, var, z.gamma[c], z.beta[c], invstd, sc, sh);
+}
+// workgroup 0: what bn_finalize_kernel stored, for every view
+__device__ __forceinline__ void bn_lazy_store(const BnLazy& z, int c) {
+  for (int v = 0; v < z.nviews; ++v) {   // view 0 then view 1: the running statistics are updated in the reference's order
+    double mean, var;
+    float invstd, sc, sh;
+    bn_lazy_stats(z.stats[v], z.C, c, z.count, mean, var);
+    bn_affine_of(mean, var, z.gamma[c], z.beta[c], invstd, sc, sh);
+    const double unbiased = z.count > 1 ? var * z.count / (z.count - 1) : var;
+    z.running_mean[c] = (float)(0.9 * (double)z.running_mean[c] + 0.1 * mean);
+    z.running_var[c] = (float)(0.9 * (double)z.running_var[c] + 0.1 * unbiased);
+    if (c == 0 && z.nbt != nullptr) *z.nbt += 1;
+    z.mean[v][c] = (float)mean;
+    z.invstd[v][c] = invstd;
+    z.scale[v][c] = sc;
+    z.shift[v][c] = sh;
+  }
+}
+
 struct ConvArgs {
   const float* in;        // NHWC [N, H*(pool?2:1), W*(pool?2:1), in_cs]
   const float* wpk;       // packed weights [cob][chunk][tap][g][h][64][4]
@@ -70,6 +142,7 @@ struct ConvArgs {
   // perf-debug only (a build with SSP_HIPCC_EXTRA=-DW4_TRACE=1 and SSP_W4_TRACE=N in the environment): per-phase cycle sums of the four
   // waves of workgroup 0 of conv_wino4_kernel, else nullptr
   unsigned long long* trace = nullptr;
+  BnLazy lazy;   // training forward: BatchNorm affine of the INPUT layer derived here instead of by a bn_finalize_kernel launch
 };
 
 // lane/row index m (0..31) of an MFMA M-tile -> pixel (r,c) inside the SH x SW sub-rectangle.

@@ -392,9 +392,19 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvArgs a
     if (IN_MODE != 0) sG[tid] = (p_pool != nullptr && co_ < a.Cout && a.pool_gamma[co_] < 0.f) ? -1.f : 1.f;
   }
   if (IN_MODE != 0) {
-    for (int c = tid; c < a.Cin; c += W4_THREADS) {
-      sS[c] = p_scale[c];
-      sS[W4_MAX_CIN + c] = p_shift[c];
+    if (a.lazy.mode == 0) {
+      for (int c = tid; c < a.Cin; c += W4_THREADS) {
+        sS[c] = p_scale[c];
+        sS[W4_MAX_CIN + c] = p_shift[c];
+      }
+    } else {   // (BnLazy: the producer's statistics -> affine here; workgroup 0 stores for the later readers)
+      for (int c = tid; c < a.Cin; c += W4_THREADS) {
+        float sc_, sh_;
+        bn_lazy_affine(a.lazy, prob, c, sc_, sh_);
+        sS[c] = sc_;
+        sS[W4_MAX_CIN + c] = sh_;
+        if (blockIdx.x == 0) bn_lazy_store(a.lazy, c);
+      }
     }
   } else if (a.bnr_mode != 0) {
     // fused BatchNorm-backward sums (ConvArgs::bnr_*): the four per-channel parameters of this block's 64 output channels.

@@ -216,9 +216,19 @@ __global__ __launch_bounds__(P2_THREADS, 2) void conv_wino_p2_kernel(const ConvA
     sBias[tid] = (a.bias != nullptr && co_ < a.Cout) ? a.bias[co_] : 0.f;
   }
   if (IN_MODE != 0) {
-    for (int c = tid; c < a.Cin; c += P2_THREADS) {
-      sS[c] = p_scale[c];
-      sS[1024 + c] = p_shift[c];
+    if (a.lazy.mode == 0) {
+      for (int c = tid; c < a.Cin; c += P2_THREADS) {
+        sS[c] = p_scale[c];
+        sS[1024 + c] = p_shift[c];
+      }
+    } else {   // (BnLazy: the producer's statistics -> affine here; workgroup 0 stores for the later readers)
+      for (int c = tid; c < a.Cin; c += P2_THREADS) {
+        float sc_, sh_;
+        bn_lazy_affine(a.lazy, prob, c, sc_, sh_);
+        sS[c] = sc_;
+        sS[1024 + c] = sh_;
+        if (blockIdx.x == 0) bn_lazy_store(a.lazy, c);
+      }
     }
   } else if (a.bnr_mode != 0) {
     // fused BatchNorm-backward sums (ConvArgs::bnr_*): the four per-channel parameters of this block's 64 output channels.

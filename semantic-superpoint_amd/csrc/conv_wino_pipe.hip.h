@@ -253,9 +253,19 @@ __global__ __launch_bounds__(WINO_THREADS) void conv_wino_pipe_kernel(const Conv
   }
 
   if (IN_MODE != 0) {
-    for (int c = tid; c < a.Cin; c += WINO_THREADS) {
-      sS[c] = p_scale[c];
-      sS[1024 + c] = p_shift[c];
+    if (a.lazy.mode == 0) {
+      for (int c = tid; c < a.Cin; c += WINO_THREADS) {
+        sS[c] = p_scale[c];
+        sS[1024 + c] = p_shift[c];
+      }
+    } else {   // (BnLazy: the producer's statistics -> affine here; workgroup 0 stores for the later readers)
+      for (int c = tid; c < a.Cin; c += WINO_THREADS) {
+        float sc_, sh_;
+        bn_lazy_affine(a.lazy, prob, c, sc_, sh_);
+        sS[c] = sc_;
+        sS[1024 + c] = sh_;
+        if (blockIdx.x == 0) bn_lazy_store(a.lazy, c);
+      }
     }
     __syncthreads();
   } else if (a.bnr_mode != 0) {

@@ -179,6 +179,8 @@ struct ssp_handle {
   struct WredBQueue* rq_bf16 = nullptr;  // the same for the bf16 path's weight gradients (bf16_host.hip.h)
   WredJobs rjobs{};
   bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
+  bool fin_pending[16] = {};  // forward, training: layer l's statistics are complete but not finalized - the convolution that reads the
+  double fin_count[16] = {};  // layer does it in its prologue (BnLazy), or bn_finalize_pending() launches the kernel (count: pixels per view)
   bool apply_fused[16] = {};  // pass 2 (APPLY) of layer l was left to the layer's weight gradient (wgrad_wino_fused_kernel)
   bool bf16_fuse_apply = true;  // bf16 path: the same for wgrad_bf16_kernel<.., FUSE>; SSP_BF16_FUSE_APPLY, read ONCE per backward pass
                                 // (bf16_fuse_apply_env: tests switch it between two steps of one process) and part of the graph key
@@ -511,6 +513,7 @@ struct ConvCall {
   bool allow_w4 = true;  // false: wpk is an F(2x2,3x3) image whatever the shape (the concatenated data-gradient weights of the heads)
   int force_w4 = -1;     // engine launches: 1 / 0 = wpk is / is not an F(4x4,3x3) image (ssp_handle::pk_w4_*); -1 = decide from the
                          // shape (operator-level calls, which pack with the same predicate right before the launch)
+  BnLazy lazy;           // training forward: the input layer's BatchNorm affine derived by this launch (conv_has_bn_lazy() tells the caller)
 };
 static bool can_fuse_bnr(const ConvCall& c) {
   return c.wino && (pipe_algo() || g_conv_algo == 5 || g_conv_algo == 6 || bf16_algo()) && c.in_mode == 0 && c.cout % 4 == 0 && c.out_co % 4 == 0 &&
@@ -651,6 +654,17 @@ static bool conv_writes_pool(const ssp_handle* h, const ConvCall& c) {
          c.cout % 4 == 0 && c.out_co == 0 && c.out_cs == c.cout && (!conv_uses_w4(h, c) || c.cout % NB == 0);
 }
 
+// will this launch run a kernel whose prologue can derive its input layer's BatchNorm affine from the raw statistics (BnLazy:
+// conv_wino4 / conv_wino_p2 / conv_wino_pipe reading under BatchNorm + ReLU)?  SSP_BN_LAZY=0 (perf-debug): bn_finalize_kernel everywhere.
+static bool bn_lazy_env() {
+  static const int v = getenv("SSP_BN_LAZY") ? atoi(getenv("SSP_BN_LAZY")) : 1;
+  return v != 0;
+}
+static bool conv_has_bn_lazy(const ssp_handle* h, const ConvCall& c) {
+  if (!bn_lazy_env() || !c.wino || c.in_mode != 1 || bf16_algo() || g_conv_algo == 5) return false;
+  return conv_uses_w4(h, c) || conv_uses_p2(h, c) || pipe_algo();
+}
+
 static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int prof_family = 0) {
   ConvArgs a;
   a.in = c.in; a.wpk = c.wpk; a.bias = c.bias; a.out = c.out; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
@@ -658,6 +672,10 @@ static int launch_conv(ssp_handle* h, const ConvCall& c, hipStream_t st, int pro
   a.Cout = c.cout; a.out_cs = c.out_cs; a.out_co = c.out_co; a.nchunks = c.nchunks; a.ncob = c.ncob;
   a.nprob = c.nprob; a.in2 = c.in2; a.out2 = c.out2; a.in_scale2 = c.in_scale2; a.in_shift2 = c.in_shift2;
   a.stats2 = c.stats2;
+  if (c.lazy.mode != 0) {
+    if (!conv_has_bn_lazy(h, c)) return fail(-3, "consumer-side BatchNorm finalize needs one of the Winograd kernels of the default algorithm");
+    a.lazy = c.lazy;
+  }
   if (c.bnr_mode != 0) {
     if (!can_fuse_bnr(c)) return fail(-3, "fused BatchNorm-backward sums need the pipelined Winograd kernel");
     a.bnr_mode = c.bnr_mode; a.bnr_t = c.bnr_t[0]; a.bnr_t2 = c.bnr_t[1]; a.bnr_cs = c.bnr_cs; a.bnr_co = c.bnr_co;
@@ -1791,6 +1809,13 @@ struct SlotSet {
   Slot* s[2];
 };
 
+// a layer whose finalize was left to its reader (ssp_handle::fin_pending) and whose reader cannot do it: the launch after all
+static int bn_finalize_pending(ssp_handle* h, const SlotSet& SS, int l, int train, hipStream_t st) {
+  if (l < 0 || !h->fin_pending[l]) return 0;
+  h->fin_pending[l] = false;
+  return bn_finalize(h, SS.s, SS.n, l, h->fin_count[l], train, st);
+}
+
 // bf16 path (conv algorithm 12): layer l on conv_bf16_kernel.  Every 3x3 layer writes a bf16 tensor (encoder: Y[l] and the raw
 // pooled copy Apool[l]; heads: a slice of the [cells][256 heads] tensor) in the slot's buffers; the pointwise heads read those
 // under BatchNorm + ReLU and write the fp32 logits / descriptors the loss kernels take.
@@ -1857,6 +1882,7 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
   if (pooled && A.pool_raw[src]) {
     in_mode = 1;
   } else if (pooled) {
+    CHK(bn_finalize_pending(h, SS, src, train, st));   // (bn_relu_pool_kernel reads the affine)
     {
       Slot &S0 = *SS.s[0], &S1 = *SS.s[SS.n - 1];
       const long total = (long)N * H * W * (d.cin / 4);
@@ -1889,8 +1915,32 @@ static int conv_layer_fwd(ssp_handle* h, const SlotSet& SS, int l, int src, int 
     }
     for (int k = 0; k < SS.n; ++k) SS.s[k]->pool_raw[l] = raw;
   }
+  // the input layer's statistics are still raw (fin_pending): this launch derives the affine itself where its kernel can
+  if (src >= 0 && h->fin_pending[src]) {
+    if (conv_has_bn_lazy(h, c)) {
+      const LayerDesc& ds = h->L[src];
+      BnLazy& z = c.lazy;
+      for (int k = 0; k < SS.n; ++k) {
+        Slot& S = *SS.s[k];
+        z.stats[k] = S.bn[src].stats; z.scale[k] = S.bn[src].scale; z.shift[k] = S.bn[src].shift; z.mean[k] = S.bn[src].mean;
+        z.invstd[k] = S.bn[src].invstd;
+      }
+      if (SS.n == 1) { z.stats[1] = z.stats[0]; z.scale[1] = z.scale[0]; z.shift[1] = z.shift[0]; z.mean[1] = z.mean[0]; z.invstd[1] = z.invstd[0]; }
+      z.gamma = P(h, ds.g_off); z.beta = P(h, ds.be_off);
+      z.running_mean = h->buf.bn_running_dev + ds.bn_ch_off;
+      z.running_var = h->buf.bn_running_dev + h->n_bn_ch + ds.bn_ch_off;
+      z.nbt = bn_nbt(h, src); z.count = h->fin_count[src]; z.C = ds.cout; z.nviews = SS.n; z.mode = 2;
+      h->fin_pending[src] = false;
+    } else {
+      CHK(bn_finalize_pending(h, SS, src, train, st));
+    }
+  }
   CHK(launch_conv(h, c, st, d.ks == 3 ? SSP_PROF_CONV3X3_FWD : 0));
   if (d.bn && deferred != nullptr && deferred->n < 3) deferred->layers[deferred->n++] = l;
+  else if (d.bn && train && l < 8 && bn_lazy_env() && !bf16_algo()) {   // encoder layers: the next convolution finalizes (or bn_finalize_pending)
+    h->fin_pending[l] = true;
+    h->fin_count[l] = (double)N * H * W;
+  }
   else if (d.bn) CHK(bn_finalize(h, SS.s, SS.n, l, (double)N * H * W, train, st));  // view 0 then 1 inside the kernel
   return 0;
 }
@@ -1930,7 +1980,8 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
                        P(h, d.b_off), S0.Y[0], S1.Y[0], train ? S0.bn[0].stats : nullptr, train ? S1.bn[0].stats : nullptr,
                        N, H, W);
     HIPCHK(hipGetLastError());
-    CHK(bn_finalize(h, SS.s, SS.n, 0, (double)N * H * W, train, st));
+    if (train && bn_lazy_env() && !bf16_path()) { h->fin_pending[0] = true; h->fin_count[0] = (double)N * H * W; }   // layer 1 finalizes
+    else CHK(bn_finalize(h, SS.s, SS.n, 0, (double)N * H * W, train, st));
   }
   CHK(pack_fork.join());
   for (int l = 1; l < 8; ++l) {
@@ -1983,6 +2034,7 @@ static int run_forward(ssp_handle* h, const SlotSet& SS, const float* const* xs,
     const int pw2[2] = {L_DB, L_PB};
     CHK(pointwise(pw2, 2));
   }
+  for (int l = 0; l < 8; ++l) CHK(bn_finalize_pending(h, SS, l, train, st));   // (none is left on the shipped layer table)
   const int ncells = N * Hc * Wc;
   {
     Slot &S = *SS.s[0], &T = *SS.s[SS.n - 1];   // both views in one launch (blockIdx.y)
