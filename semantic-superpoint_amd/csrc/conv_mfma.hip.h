@@ -539,6 +539,15 @@ struct WgradArgs {
   const float* f_k12[2] = {nullptr, nullptr};
   const float* f_gamma = nullptr;
   int f_ycs = 0;
+  // f_lazy (layers without pooling): there was no bn_bwd_sums_kernel launch - every workgroup reduces the 32 replicas of the backward
+  // sums S1, S2 itself (f_bsums[k]: [NREP][2 Cout], complete since the data-gradient launch above), and the workgroups of the first
+  // input-channel block and split add dgamma / dbeta / the bias gradient, view 0 then view 1 like that kernel
+  int f_lazy = 0;
+  const double* f_bsums[2] = {nullptr, nullptr};
+  double f_count = 0.0;
+  float* f_dgamma = nullptr;
+  float* f_dbeta = nullptr;
+  float* f_dbias = nullptr;
   unsigned long long* trace = nullptr;  // WGF_TRACE builds only (wgrad_wino_fused.hip.h): phase cycle sums of workgroup 0
 };
 

@@ -179,6 +179,7 @@ struct ssp_handle {
   struct WredBQueue* rq_bf16 = nullptr;  // the same for the bf16 path's weight gradients (bf16_host.hip.h)
   WredJobs rjobs{};
   bool bsums_fused[16] = {};  // pass 1 of layer l's BatchNorm backward was accumulated by the data-gradient conv above it
+  bool sums_lazy[16] = {};    // backward: layer l's bn_bwd_sums_kernel launch was skipped - its fused weight gradient reduces the replicas itself
   bool fin_pending[16] = {};  // forward, training: layer l's statistics are complete but not finalized - the convolution that reads the
   double fin_count[16] = {};  // layer does it in its prologue (BnLazy), or bn_finalize_pending() launches the kernel (count: pixels per view)
   bool apply_fused[16] = {};  // pass 2 (APPLY) of layer l was left to the layer's weight gradient (wgrad_wino_fused_kernel)
@@ -1066,6 +1067,10 @@ struct WgradCall {
   const float* f_k12[2] = {nullptr, nullptr};
   const float* f_gamma = nullptr;
   int f_ycs = 0;
+  int f_lazy = 0;   // WgradArgs::f_lazy and its arguments
+  const double* f_bsums[2] = {nullptr, nullptr};
+  double f_count = 0.0;
+  float* f_dgamma = nullptr; float* f_dbeta = nullptr; float* f_dbias = nullptr;
 };
 
 // Can the weight gradient of a layer whose output feeds BatchNorm + ReLU + MaxPool2d(2) take that layer's APPLY pass along
@@ -1105,6 +1110,8 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
       a.f_mean[k] = c.f_mean[k]; a.f_invstd[k] = c.f_invstd[k]; a.f_k12[k] = c.f_k12[k];
     }
     a.f_gamma = c.f_gamma; a.f_ycs = c.f_ycs;
+    a.f_lazy = c.f_lazy; a.f_bsums[0] = c.f_bsums[0]; a.f_bsums[1] = c.f_bsums[1]; a.f_count = c.f_count;
+    a.f_dgamma = c.f_dgamma; a.f_dbeta = c.f_dbeta; a.f_dbias = c.f_dbias;
   }
   const bool wide = (c.W % 32) == 0;
   // Winograd F(3x3,2x2): 3x3 filters on even-sized maps with a prefetchable (non-pooled) input
@@ -2112,7 +2119,10 @@ static int bn_layer_backward(ssp_handle* h, const SlotSet& SS, int l, const floa
     const bool defer = l >= 1 && d_cs == SS.s[0]->y_cs[l] && d_co == SS.s[0]->y_co[l] && dy_cs == d_cs && dy_co == d_co &&
                        wgrad_can_fuse_apply(d.ks, 1, H, W, d.cout);
     h->apply_fused[l] = defer;
-    CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused, defer, queue)));
+    // pass 1 came from the data gradient above, pass 2 goes into the weight gradient: what is left is the replica reduction, and
+    // the fused weight gradient can do that in its prologue (WgradArgs::f_lazy) - no launch at all
+    if (fused && defer && bn_lazy_env() && !bf16_algo()) h->sums_lazy[l] = true;
+    else CHK((launch_bn_bwd<true, false>(a, SS.n, dg, db, st, fused, defer, queue)));
   }
   else if (collect != nullptr) {   // BatchNorm without ReLU (the pointwise heads): the caller launches two layers together
     collect->a[0] = a0; collect->a[1] = a1; collect->dg = dg; collect->db = db; collect->filled = true;
@@ -2216,6 +2226,11 @@ static int conv_layer_backward(ssp_handle* h, const SlotSet& SS, int l, int src,
       (k ? w.dout2 : w.dout) = din[k];
       w.f_y[k] = S.Y[l]; w.f_dy[k] = dy[k]; w.f_scale[k] = S.bn[l].scale; w.f_shift[k] = S.bn[l].shift;
       w.f_mean[k] = S.bn[l].mean; w.f_invstd[k] = S.bn[l].invstd; w.f_k12[k] = S.bn[l].k12;
+    }
+    if (h->sums_lazy[l]) {
+      h->sums_lazy[l] = false;
+      w.f_lazy = 1; w.f_count = (double)N * H * W; w.f_dgamma = Gd(h, d.g_off); w.f_dbeta = Gd(h, d.be_off); w.f_dbias = Gd(h, d.b_off);
+      for (int k = 0; k < SS.n; ++k) w.f_bsums[k] = SS.s[k]->bn[l].bsums;
     }
   }
   if (!skip_wgrad) CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));
@@ -2655,6 +2670,11 @@ static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* cons
           w.f_y[k] = S.Y[heads[hk]] + S.y_co[heads[hk]]; w.f_dy[k] = gQ[k] + 256 * hk;
           w.f_scale[k] = S.bn[heads[hk]].scale; w.f_shift[k] = S.bn[heads[hk]].shift; w.f_mean[k] = S.bn[heads[hk]].mean;
           w.f_invstd[k] = S.bn[heads[hk]].invstd; w.f_k12[k] = S.bn[heads[hk]].k12;
+        }
+        if (h->sums_lazy[heads[hk]]) {
+          h->sums_lazy[heads[hk]] = false;
+          w.f_lazy = 1; w.f_count = (double)N * Hc * Wc; w.f_dgamma = Gd(h, d.g_off); w.f_dbeta = Gd(h, d.be_off); w.f_dbias = Gd(h, d.b_off);
+          for (int k = 0; k < SS.n; ++k) w.f_bsums[k] = SS.s[k]->bn[heads[hk]].bsums;
         }
       }
       CHK(launch_wgrad(h, w, h->partial, h->partial_floats, h->n_cu, st));

@@ -40,7 +40,7 @@ template <bool WIDE>
 struct WgradFusedGeom {
   using G = WgradWinoGeom<WIDE>;
   static constexpr int NX = (G::HT * G::WT + 31) / 32;  // halo pixels per thread (pp = (tid >> 4) + 32 i)
-  static constexpr int F_FLOATS = 2 * 7 * 64;           // per problem: scale, shift, -mean invstd, invstd, gamma invstd, A, B
+  static constexpr int F_FLOATS = 2 * 10 * 64;          // per problem: scale, shift, -mean invstd, invstd, gamma invstd, A, B | f_lazy: S1, S2, bias term
   static constexpr int O_WORDS = (2 * NX + 9) * 512;    // parked per thread: halo offsets, halo coordinates, dY-side offsets / coordinates, mask
   static constexpr int LDS_BYTES = (G::X_FLOATS + G::D_FLOATS + 256 + F_FLOATS + O_WORDS) * 4;
 };
@@ -100,13 +100,37 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
   if (tid >= 64 && tid < 64 + 128) {
     const int pr = (tid - 64) >> 6, ch = (tid - 64) & 63, co = cob * 64 + ch;
     float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float lz[3] = {0.f, 0.f, 0.f};   // f_lazy: (float)S1, (float)S2, the bias-gradient term of this view
     if (co < a.Cout && pr < a.nprob) {
       const float is = a.f_invstd[pr][co], gs = a.f_gamma[co] * is;
       v[0] = a.f_scale[pr][co]; v[1] = a.f_shift[pr][co]; v[2] = -a.f_mean[pr][co] * is; v[3] = is; v[4] = gs;
-      v[5] = -gs * a.f_k12[pr][a.Cout + co]; v[6] = -gs * a.f_k12[pr][co];
+      float k1, k2;
+      if (!POOL && a.f_lazy) {   // the replica reduction of bn_bwd_sums_kernel, here
+        const double* __restrict__ q = a.f_bsums[pr];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {   // two rounds of 16 replicas: 32 loads in flight
+          double u1[NREP / 2], u2[NREP / 2];
+#pragma unroll
+          for (int k = 0; k < NREP / 2; ++k) {
+            u1[k] = q[(size_t)(hh * (NREP / 2) + k) * 2 * a.Cout + co];
+            u2[k] = q[(size_t)(hh * (NREP / 2) + k) * 2 * a.Cout + a.Cout + co];
+          }
+#pragma unroll
+          for (int k = 0; k < NREP / 2; ++k) { s1 += u1[k]; s2 += u2[k]; }
+        }
+        k1 = (float)(s1 / a.f_count); k2 = (float)(s2 / a.f_count);
+        lz[0] = (float)s1; lz[1] = (float)s2;
+        lz[2] = a.f_gamma[co] * is * (float)(s1 - a.f_count * (double)k1);   // (bn_bwd_sums_kernel: the conv bias gradient, rounding noise)
+      } else {
+        k1 = a.f_k12[pr][co]; k2 = a.f_k12[pr][a.Cout + co];
+      }
+      v[5] = -gs * k2; v[6] = -gs * k1;
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k) sF[(pr * 7 + k) * 64 + ch] = v[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sF[2 * 7 * 64 + (pr * 3 + k) * 64 + ch] = lz[k];
   }
   const int co0 = cob * 64 + q16 * 4;
   const bool covalid = co0 < a.Cout;
@@ -283,6 +307,15 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
   const float c1 = irow == 0 ? 0.f : irow == 1 ? 1.f : -1.f;
 
   __syncthreads();  // sF / sS
+  if (!POOL && a.f_lazy && cib == 0 && split == 0 && tid < 64) {   // one workgroup per output-channel block: dgamma, dbeta, bias gradient
+    const int co = cob * 64 + tid;
+    if (co < a.Cout)
+      for (int pr = 0; pr < a.nprob; ++pr) {   // view 0 then view 1, like bn_bwd_sums_kernel
+        a.f_dbeta[co] += sF[2 * 7 * 64 + (pr * 3 + 0) * 64 + tid];
+        a.f_dgamma[co] += sF[2 * 7 * 64 + (pr * 3 + 1) * 64 + tid];
+        if (a.f_dbias != nullptr) a.f_dbias[co] += sF[2 * 7 * 64 + (pr * 3 + 2) * 64 + tid];
+      }
+  }
   if (t_begin < t_end) {  // the first tile: slice 0 prepares it (w_more = false: the walker stays)
     if (BF16) WGF_PREP()
     WGF_LOAD_ALL()
