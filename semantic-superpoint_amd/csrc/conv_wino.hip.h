@@ -660,9 +660,11 @@ struct WredJob {
   const float* partial;
   float* dw;
   int cin, cout, ncob, nsplit;
+  int nblocks;  // blocks of the job: ncob * cin (f4 == 2: three times as many)
   int block0;
   int f4;  // 0: 16-component slabs of wgrad_wino_kernel (ncob = 64-channel blocks); 1: 9-tap slabs [9][64][32] of
-           // wgrad_wino4_kernel, already through G^T . G (ncob = 32-channel blocks)
+           // wgrad_wino4_kernel, already through G^T . G (ncob = 32-channel blocks); 2: 12-component slabs [4][3][64][64] of
+           // wgrad_wino_fused_kernel (right-hand product applied)
 };
 
 // wgrad_wino4_kernel's partial slabs [pair * nsplit + k][9 taps][64 ci][32 co] summed over the splits and ACCUMULATED into
@@ -698,17 +700,60 @@ __global__ __launch_bounds__(256) void wgrad_wino4_reduce_kernel(const float* __
   wgrad_wino4_reduce_block(partial, dw, Cin, Cout, ncob, nsplit, blockIdx.x, red);
 }
 
+// wgrad_wino_fused_kernel's slabs [(cib * ncob + cob) * nsplit + k][row i 4][x 3][64 ci][64 co] (the right-hand product of
+// dW = G^T M G applied by the workgroup) summed over the splits, the left-hand product, ACCUMULATED into the OIHW gradient.
+// block = one input channel, 64 consecutive co, ONE column x of the taps (the left-hand product mixes the rows i of a column only:
+// three blocks per (ci, cob) pair without an exchange); 256 threads = 16 co quads (16-byte loads) x 16 split groups - a 64 x 64
+// layer has 256 splits and only 64 pairs, so the splits, not the pairs, have to carry the parallelism.
+__device__ __forceinline__ void wgrad_fused12_reduce_block(const float* __restrict__ partial, float* __restrict__ dw, int Cin,
+                                                           int Cout, int ncob, int nsplit, int rel, float* red) {
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int x = rel % 3, bid = rel / 3;
+  const int cob = bid % ncob, ci = bid / ncob, cib = ci >> 6;
+  float4 m[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) m[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* src = partial + (size_t)((cib * ncob + cob) * nsplit) * (12 * 4096) + x * 4096 + (ci & 63) * 64 + q * 4;
+  for (int k = grp; k < nsplit; k += 16)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)k * 12 + i * 3) * 4096);
+      m[i].x += v.x; m[i].y += v.y; m[i].z += v.z; m[i].w += v.w;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(red + ((grp * 4 + i) * 16 + q) * 4) = m[i];   // [grp 16][i 4][co 64]
+  __syncthreads();
+  const int o = threadIdx.x & 63, u = threadIdx.x >> 6, co = cob * 64 + o;
+  if (u == 3 || co >= Cout) return;
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) { a0 += red[((g * 4 + i) * 64) + o]; a1 += red[(((g + 1) * 4 + i) * 64) + o]; }
+    r[i] = a0 + a1;
+  }
+  const float v = u == 0 ? r[0] + 0.5f * (r[1] + r[2]) : u == 1 ? 0.5f * (r[1] - r[2]) : 0.5f * (r[1] + r[2]) + r[3];
+  dw[((size_t)co * Cin + ci) * 9 + u * 3 + x] += v;
+}
+__global__ __launch_bounds__(256) void wgrad_fused12_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                   int Cin, int Cout, int ncob, int nsplit) {
+  __shared__ __attribute__((aligned(16))) float red[4 * WC * 64];
+  wgrad_fused12_reduce_block(partial, dw, Cin, Cout, ncob, nsplit, blockIdx.x, red);
+}
+
 constexpr int WRED_MAX_JOBS = 16;
 struct WredJobs {
   int n;
   WredJob j[WRED_MAX_JOBS];
 };
 __global__ __launch_bounds__(256) void wgrad_wino_reduce_multi_kernel(const WredJobs J) {
-  __shared__ float red[4][WC][64];
+  __shared__ __attribute__((aligned(16))) float red[4][WC][64];
   int k = 0;
   while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;
   const WredJob& q = J.j[k];
-  if (q.f4) wgrad_wino4_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, &red[0][0][0]);
+  if (q.f4 == 2) wgrad_fused12_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, &red[0][0][0]);
+  else if (q.f4) wgrad_wino4_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, &red[0][0][0]);
   else wgrad_wino_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, red);
 }
 

@@ -1088,7 +1088,7 @@ static int flush_wgrad_reduce(ssp_handle* h, hipStream_t st) {
   if (h != nullptr) CHK(flush_wgrad_reduce_bf16(h, st));
   if (h == nullptr || h->rjobs.n == 0) { if (h) h->partial_used = 0; return 0; }
   const WredJob& last = h->rjobs.j[h->rjobs.n - 1];
-  const int nblocks = last.block0 + last.ncob * last.cin;
+  const int nblocks = last.block0 + last.nblocks;
   hipLaunchKernelGGL(wgrad_wino_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, h->rjobs);
   HIPCHK(hipGetLastError());
   h->rjobs.n = 0;
@@ -1130,7 +1130,8 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
   a.ncib = cdiv(c.cin, 64); a.ncob = cdiv(c.cout, wino4 ? 32 : 64);
   const int pairs = a.ncib * a.ncob;
   const int taps = wino ? WC : c.ks * c.ks;  // 64 x 64 slabs per partial block
-  const size_t slab = wino4 ? (size_t)WG4_SLAB : (size_t)taps * 4096;  // floats per partial block
+  const bool fused12 = c.fuse_apply && wino && !wino4;  // wgrad_wino_fused_kernel applies the right-hand product of G^T M G itself: 12-component slabs
+  const size_t slab = wino4 ? (size_t)WG4_SLAB : fused12 ? (size_t)12 * 4096 : (size_t)taps * 4096;  // floats per partial block
   int nsplit = ((wino ? 1 : 2) * n_cu) / pairs / 8 * 8;  // blocks per CU; multiple of 8: blocks sharing tiles share an XCD
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.ntiles * a.nprob) nsplit = a.ntiles * a.nprob;
@@ -1145,8 +1146,9 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
     if (h->partial_used + need > partial_floats || h->rjobs.n == WRED_MAX_JOBS) CHK(flush_wgrad_reduce(h, st));
     a.partial = partial + h->partial_used;
     WredJob& q = h->rjobs.j[h->rjobs.n];
-    q.partial = a.partial; q.dw = c.dw; q.cin = c.cin; q.cout = c.cout; q.ncob = a.ncob; q.nsplit = nsplit; q.f4 = wino4 ? 1 : 0;
-    q.block0 = h->rjobs.n ? h->rjobs.j[h->rjobs.n - 1].block0 + h->rjobs.j[h->rjobs.n - 1].ncob * h->rjobs.j[h->rjobs.n - 1].cin : 0;
+    q.partial = a.partial; q.dw = c.dw; q.cin = c.cin; q.cout = c.cout; q.ncob = a.ncob; q.nsplit = nsplit; q.f4 = wino4 ? 1 : fused12 ? 2 : 0;
+    q.nblocks = a.ncob * c.cin * (fused12 ? 3 : 1);
+    q.block0 = h->rjobs.n ? h->rjobs.j[h->rjobs.n - 1].block0 + h->rjobs.j[h->rjobs.n - 1].nblocks : 0;
     ++h->rjobs.n;
     h->partial_used += need;
   } else if (h != nullptr && partial == h->partial && h->rjobs.n > 0) {
@@ -1192,6 +1194,9 @@ static int launch_wgrad(ssp_handle* h, const WgradCall& c, float* partial, size_
     if (wino) {
       if (!deferred && wino4)
         hipLaunchKernelGGL(wgrad_wino4_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
+                           a.ncob, nsplit);
+      else if (!deferred && fused12)
+        hipLaunchKernelGGL(wgrad_fused12_reduce_kernel, dim3(3 * a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,
                            a.ncob, nsplit);
       else if (!deferred)
         hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.ncob * c.cin), dim3(256), 0, st, partial, c.dw, c.cin, c.cout,

@@ -510,17 +510,21 @@ __global__ __launch_bounds__(512) void wgrad_wino_fused_kernel(const WgradArgs a
 #undef WGF_T
 #undef WGF_PREP
 #undef WGF_LOAD_ALL
-  // partial slab: [blk][component][ci 64][co 64]; M-tile e, row m <-> input channel 2 m + e
-  float* dst = a.partial + (size_t)blockIdx.x * WC * 4096;
+  // The right-hand product of dW = G^T M G runs over the four components of this wave's row: applied here, in registers, so that
+  // 12 instead of 16 components per (ci, co) travel to HBM and back (the left-hand product runs over the rows = waves and stays
+  // with wgrad_fused12_reduce_block; done here through LDS it cost the launch more than the smaller slab saved: PERF_LOG 3c).
+  // partial slab: [blk][row i][x 3][ci 64][co 64]; M-tile e, row m <-> input channel 2 m + e
+  float* dst = a.partial + (size_t)blockIdx.x * (12 * 4096) + (irow * 3) * 4096 + coh * 32 + li;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        dst[(irow * 4 + j) * 4096 + (2 * m + e) * 64 + coh * 32 + li] = acc[j][e][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float t = 0.5f * (acc[1][e][r] + acc[2][e][r]), d = 0.5f * (acc[1][e][r] - acc[2][e][r]);
+      dst[0 * 4096 + (2 * m + e) * 64] = acc[0][e][r] + t;
+      dst[1 * 4096 + (2 * m + e) * 64] = d;
+      dst[2 * 4096 + (2 * m + e) * 64] = t + acc[3][e][r];
+    }
 }
 
 }  // namespace sspk
