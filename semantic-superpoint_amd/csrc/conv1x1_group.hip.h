@@ -455,9 +455,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_group_kernel(const G1WArgs a)
 }
 
 // dw[n][k] += sum over the part's workgroups of slab[k][n]; block = 256 threads = 8 input channels x 32 output channels
-__global__ __launch_bounds__(256) void wgrad1x1_reduce_kernel(const G1WArgs a) {
+__device__ __forceinline__ void wgrad1x1_reduce_block(const G1WArgs& a, int b) {
   int pi = 0;
-  int b = blockIdx.x;
   // blocks per part: 32 channel groups x nt
   while (pi + 1 < a.nparts && b >= 32 * a.p[pi].nt) { b -= 32 * a.p[pi].nt; ++pi; }
   const G1WPart& p = a.p[pi];
@@ -475,5 +474,6 @@ __global__ __launch_bounds__(256) void wgrad1x1_reduce_kernel(const G1WArgs a) {
   if (w < p.nwg) s0 += src[(size_t)w * G1W_SLAB];
   p.dw[(size_t)n * 256 + k] += s0 + s1;
 }
+__global__ __launch_bounds__(256) void wgrad1x1_reduce_kernel(const G1WArgs a) { wgrad1x1_reduce_block(a, blockIdx.x); }
 
 }  // namespace sspk

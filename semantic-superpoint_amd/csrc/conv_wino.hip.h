@@ -747,15 +747,7 @@ struct WredJobs {
   int n;
   WredJob j[WRED_MAX_JOBS];
 };
-__global__ __launch_bounds__(256) void wgrad_wino_reduce_multi_kernel(const WredJobs J) {
-  __shared__ __attribute__((aligned(16))) float red[4][WC][64];
-  int k = 0;
-  while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].block0) ++k;
-  const WredJob& q = J.j[k];
-  if (q.f4 == 2) wgrad_fused12_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, &red[0][0][0]);
-  else if (q.f4) wgrad_wino4_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, &red[0][0][0]);
-  else wgrad_wino_reduce_block(q.partial, q.dw, q.cin, q.cout, q.ncob, q.nsplit, (int)blockIdx.x - q.block0, red);
-}
+// (wgrad_wino_reduce_multi_kernel, the launch that runs these jobs, lives in backward_tail.hip.h beside the other tail reductions)
 
 // OIHW 3x3 weights -> U = G g G^T in the LDS image of conv_wino_kernel: [cob][chunk][component][g][h][64][4].
 // transpose_flip: the data-gradient convolution (input channels = Cout_w, output = Cin_w, taps mirrored).

@@ -745,12 +745,10 @@ __global__ void sem_upsample_bwd_nchw_kernel(const float* __restrict__ dsem, flo
 // block = 256 threads = 64 float4 column quads x 4 row lanes (rows are read as contiguous float4 runs); a block owns
 // COLSUM_ROWS rows; the row lanes meet in LDS, one atomic per column and block.  cs % 4 == 0, cs <= 256.
 constexpr int COLSUM_ROWS = 512;
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m0, float* __restrict__ out, int rows, int C,
-                                                     int cs, const float* __restrict__ m1 = nullptr) {   // (blockIdx.y: matrix 0 / 1)
-  const float* __restrict__ m = blockIdx.y ? m1 : m0;
-  __shared__ float4 red[4][64];
+__device__ __forceinline__ void colsum_block(const float* __restrict__ m, float* __restrict__ out, int rows, int C, int cs, int bx,
+                                             float4 (*red)[64]) {   // red: [4][64] float4 of LDS
   const int rl = threadIdx.x >> 6;
-  const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(r0 + COLSUM_ROWS, rows);
+  const int r0 = bx * COLSUM_ROWS, r1 = min(r0 + COLSUM_ROWS, rows);
   for (int q = threadIdx.x & 63; q * 4 < cs; q += 64) {  // one pass per 256 columns (one for every shipped model)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     int r = r0 + rl;
@@ -778,6 +776,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m
       for (int e = 0; e < 4; ++e)
         if (q * 4 + e < C) facc_add(out + q * 4 + e, t[e]);
     }
+}
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m0, float* __restrict__ out, int rows, int C,
+                                                     int cs, const float* __restrict__ m1 = nullptr) {   // (blockIdx.y: matrix 0 / 1)
+  __shared__ float4 red[4][64];
+  colsum_block(blockIdx.y ? m1 : m0, out, rows, C, cs, blockIdx.x, red);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@
 #include "pair_kernels.hip.h"
 #include "export_kernels.hip.h"
 #include "sem_kernels.hip.h"
+#include "backward_tail.hip.h"
 
 using namespace sspk;
 
@@ -200,6 +201,7 @@ struct ssp_handle {
   float *wpk_g1_fwd[16] = {}, *wpk_g1_bwd[16] = {};
   bool pk_g1[16] = {};
   float* g1_partial = nullptr;  // wgrad1x1_group_kernel: one [256][128] slab per workgroup (2 per CU)
+  TailJobs tail = {};           // short reductions queued for the launch at the end of the backward pass (flush_wgrad_reduce)
   int g1_partial_slabs = 0;
   int packed_algo = -1;      // conv algorithm the images were packed for
   bool packed_bwd = false;   // the data-gradient images were packed too
@@ -900,7 +902,8 @@ struct G1WLayer {
 static bool g1w_fits(int cin, int cout, long npx, int x_cs, int dy_cs) {
   return cin == 256 && cout >= 1 && npx >= 2 && (double)npx * x_cs * 4.0 < 2147483648.0 && (double)npx * dy_cs * 4.0 < 2147483648.0;
 }
-static int launch_g1_wgrad(const G1WLayer* L, int nl, int nviews, long npx, float* partial, int partial_slabs, int n_cu, hipStream_t st) {
+static int launch_g1_wgrad(const G1WLayer* L, int nl, int nviews, long npx, float* partial, int partial_slabs, int n_cu, hipStream_t st,
+                           TailJobs* defer = nullptr) {   // defer: the slab reduction joins the tail launch of the backward pass
   G1WArgs a;
   a.nparts = 0;
   a.partial = partial;
@@ -941,7 +944,8 @@ static int launch_g1_wgrad(const G1WLayer* L, int nl, int nviews, long npx, floa
   hipLaunchKernelGGL(wgrad1x1_group_kernel, dim3(wg), dim3(256), 0, st, a);
   int rblocks = 0;
   for (int i = 0; i < a.nparts; ++i) rblocks += 32 * a.p[i].nt;
-  hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3(rblocks), dim3(256), 0, st, a);
+  if (defer != nullptr) { defer->g1 = a; defer->g1_blocks = rblocks; }
+  else hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3(rblocks), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1084,14 +1088,25 @@ static bool wgrad_can_fuse_apply(int ks, int in_mode, int H, int W, int cout) {
 
 // sums the pending partial slabs of the deferred Winograd weight-gradient launches into the OIHW gradients
 static int flush_wgrad_reduce_bf16(ssp_handle* h, hipStream_t st);
+// SSP_TAIL_MERGE=0 (perf-debug A/B): the pointwise slab reduction and the column sums as launches of their own
+static bool tail_merge_env() {
+  static const int v = getenv("SSP_TAIL_MERGE") ? atoi(getenv("SSP_TAIL_MERGE")) : 1;
+  return v != 0;
+}
 static int flush_wgrad_reduce(ssp_handle* h, hipStream_t st) {
   if (h != nullptr) CHK(flush_wgrad_reduce_bf16(h, st));
-  if (h == nullptr || h->rjobs.n == 0) { if (h) h->partial_used = 0; return 0; }
-  const WredJob& last = h->rjobs.j[h->rjobs.n - 1];
-  const int nblocks = last.block0 + last.nblocks;
-  hipLaunchKernelGGL(wgrad_wino_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, h->rjobs);
+  if (h == nullptr) return 0;
+  const int tail_blocks = h->tail.g1_blocks + h->tail.cs_blocks * h->tail.cs_views;
+  if (h->rjobs.n == 0 && tail_blocks == 0) { h->partial_used = 0; return 0; }
+  int nblocks = tail_blocks;
+  if (h->rjobs.n != 0) {
+    const WredJob& last = h->rjobs.j[h->rjobs.n - 1];
+    nblocks += last.block0 + last.nblocks;
+  }
+  hipLaunchKernelGGL(wgrad_wino_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, h->rjobs, h->tail);
   HIPCHK(hipGetLastError());
   h->rjobs.n = 0;
+  h->tail.g1_blocks = 0; h->tail.cs_views = 0;
   h->partial_used = 0;
   return 0;
 }
@@ -2523,6 +2538,7 @@ static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* cons
                              float* const* dsout, hipStream_t st, int part) {
   Slot& S0 = *SS.s[0];
   if (h->rq_bf16 != nullptr) { h->rq_bf16->J.n = 0; h->rq_bf16->used = 0; }   // (a failed pass must not leave slab reductions queued)
+  if (part != 2) { h->tail.g1_blocks = 0; h->tail.cs_views = 0; }
   if (!h->packed_bwd || h->packed_algo != g_conv_algo)
     return fail(-3, "backward: the packed weight images do not belong to this pass (%s) - run the forward of the step again",
                 !h->packed_bwd ? "the last forward packed no data-gradient weights" : "the conv algorithm changed since the forward");
@@ -2638,14 +2654,21 @@ static int run_backward_impl(ssp_handle* h, const SlotSet& SS, const float* cons
     const LayerDesc& d = h->L[L_SOUT];
     const int ncells = N * Hc * Wc;
     if (h->sout_cs > 256) return fail(-3, "segmentation head: more than 256 classes are not supported by colsum_kernel");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, COLSUM_ROWS), SS.n), dim3(256), 0, st, dsout[0], Gd(h, d.b_off), ncells, d.cout,
-                       h->sout_cs, dsout[SS.n - 1]);
-    HIPCHK(hipGetLastError());
+    if (tail_merge_env()) {   // dsout outlives the pass: the column sums join the tail launch
+      TailJobs& T = h->tail;
+      T.cs_m[0] = dsout[0]; T.cs_m[1] = dsout[SS.n - 1]; T.cs_out = Gd(h, d.b_off);
+      T.cs_rows = ncells; T.cs_C = d.cout; T.cs_cs = h->sout_cs; T.cs_blocks = cdiv(ncells, COLSUM_ROWS); T.cs_views = SS.n;
+    } else {
+      hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ncells, COLSUM_ROWS), SS.n), dim3(256), 0, st, dsout[0], Gd(h, d.b_off), ncells, d.cout,
+                         h->sout_cs, dsout[SS.n - 1]);
+      HIPCHK(hipGetLastError());
+    }
     CHK(conv_layer_backward(h, SS, L_SOUT, L_DS, dsout, h->sout_cs, 0, dact, hcs, 512, N, Hc, Wc, 1, st, grouped, gw));
     if (grouped) add_dgrad(L_SOUT, dsout, h->sout_cs, 512);
     if (gw) add_wgrad(L_SOUT, dsout, h->sout_cs);
   }
-  if (gw && nw > 0) CHK(launch_g1_wgrad(Lw, nw, SS.n, (long)ncells_all, h->g1_partial, h->g1_partial_slabs, h->n_cu, st));
+  if (gw && nw > 0) CHK(launch_g1_wgrad(Lw, nw, SS.n, (long)ncells_all, h->g1_partial, h->g1_partial_slabs, h->n_cu, st,
+                                        tail_merge_env() ? &h->tail : nullptr));
   if (grouped && ng > 0) CHK(launch_g1(Lg, ng, SS.n, (long)ncells_all, 0, h->n_cu, st));
   // ---- 3x3 heads: BN+ReLU backward gP -> gQ [cells][hcs]; weight gradients; ONE data-gradient conv over the
   // concatenated dY channels (sums the heads' contributions) gQ -> gP [cells][128] ----
