@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_multi_kernel(const Wred
     return;
   }
   b -= T.cs_blocks * T.cs_views;
+  // last job first: the encoder's first layers come last in a backward pass and have the most splits per block
+  b = J.j[J.n - 1].block0 + J.j[J.n - 1].nblocks - 1 - b;
   int k = 0;
   while (k + 1 < J.n && b >= J.j[k + 1].block0) ++k;
   const WredJob& q = J.j[k];
